@@ -1,0 +1,148 @@
+"""Pins oracle/pepflow_oracle.py against golden vectors recorded from the REFERENCE
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pepflow_oracle as O
+
+
+def load(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), f"max abs err {err:.3e}"
+
+
+@pytest.fixture(scope="module")
+def f1(golden_dir):
+    return load(golden_dir, "f1_geometry.npz")
+
+
+@pytest.fixture(scope="module")
+def f2(golden_dir):
+    return load(golden_dir, "f2_modules.npz")
+
+
+@pytest.fixture(scope="module")
+def f3(golden_dir):
+    return load(golden_dir, "f3_traj.npz")
+
+
+def test_so3_log_exp(f1):
+    close(O.so3_log(f1["log_in"]), f1["log_out"], atol=2e-6)
+    close(O.so3_exp(f1["exp_in"]), f1["exp_out"], atol=1e-6)
+
+
+def test_so3_geodesic(f1):
+    close(O.so3_calc_vf(f1["geo_base"], f1["geo_target"]), f1["geo_vf"], atol=2e-6)
+    close(O.so3_geodesic(f1["geo_t"], f1["geo_target"], f1["geo_base"]), f1["geo_out"], atol=2e-6)
+    close(O.so3_geodesic(torch.tensor([[[0.1]]]), f1["geo_target"], f1["geo_base"]), f1["geo_out_t01"], atol=2e-6)
+
+
+def test_torus(f1):
+    close(O.tor_logmap(f1["tor_a0"], f1["tor_a1"]), f1["tor_log"], atol=1e-6)
+    close(O.tor_geodesic(f1["tor_t"][:, None, None], f1["tor_a1"], f1["tor_a0"]), f1["tor_out"], atol=2e-6)
+
+
+def test_quaternions(f1):
+    close(O.quat_to_rot(f1["q2r_in"]), f1["q2r_out"], atol=1e-6)
+    q = O.rot_to_quat(f1["r2q_in"])
+    sgn = torch.sign((q * f1["r2q_out"]).sum(-1, keepdim=True))
+    close(q * sgn, f1["r2q_out"], atol=2e-6)
+
+
+def test_rigid_update(f1):
+    R, x, m = f1["upd_R"], f1["upd_x"], f1["upd_mask"]
+    q0 = O.rot_to_quat(R)
+    q1, x1 = O.rigid_update(q0, R, x, f1["upd"], m)
+    sgn = torch.sign((q1 * f1["upd1_q"]).sum(-1, keepdim=True))
+    close(q1 * sgn, f1["upd1_q"], atol=2e-6)
+    close(x1, f1["upd1_x"], atol=1e-5)
+    R1 = O.quat_to_rot(q1)
+    close(R1, f1["upd1_R"], atol=2e-6)
+    q2, x2 = O.rigid_update(q1, R1, x1, f1["upd2"], m)
+    sgn = torch.sign((q2 * f1["upd2_q"]).sum(-1, keepdim=True))
+    close(q2 * sgn, f1["upd2_q"], atol=2e-6)
+    close(x2, f1["upd2_x"], atol=1e-5)
+    p = f1["pts"]
+    close(O.rot_apply(R1[:, :, None], p) + x1[:, :, None], f1["pts_apply"], atol=1e-5)
+    close(O.rot_apply(R1.transpose(-1, -2)[:, :, None], p - x1[:, :, None]), f1["pts_invert"], atol=1e-5)
+
+
+def test_small_embeddings(f1):
+    close(O.construct_3d_basis(f1["basis_ca"], f1["basis_c"], f1["basis_n"]), f1["basis_out"], atol=1e-6)
+    close(O.time_embedding(f1["temb_t"]), f1["temb_out"], atol=2e-4)   # sin/cos of args up to 2056
+    close(O.angular_encoding(f1["ang_in"], 12).reshape(f1["ang12_out"].shape), f1["ang12_out"], atol=1e-5)
+    close(O.angular_encoding(f1["ang_in"][..., :2], 3).reshape(f1["ang3_out"].shape), f1["ang3_out"], atol=1e-6)
+    assert torch.equal(O.torsions_mask(), f1["torsions_mask"])
+
+
+def _batch(f, prefix="batch_"):
+    return {k[len(prefix):]: v for k, v in f.items() if k.startswith(prefix)}
+
+
+def test_encode(f2, seeded_sd):
+    R1, x1, ang1, seq1, node, edge = O.encode(seeded_sd, _batch(f2))
+    close(R1, f2["enc_R1"], atol=1e-6)
+    close(x1, f2["enc_x1"], atol=0)
+    close(node, f2["enc_node"], atol=2e-5, rtol=1e-4)
+    close(edge, f2["enc_edge"], atol=2e-5, rtol=1e-4)
+
+
+def test_ipa_and_edge_transition(f2, seeded_sd):
+    mask = _batch(f2)["res_mask"].float()
+    out, _ = O.ipa(seeded_sd, "ga_encoder.trunk.ipa_0", f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask)
+    close(out, f2["ipa0_out"], atol=3e-5, rtol=1e-4)
+    et = O.edge_transition(seeded_sd, "ga_encoder.trunk.edge_transition_0", f2["et0_in_s"], f2["enc_edge"])
+    close(et, f2["et0_out"], atol=2e-5, rtol=1e-4)
+
+
+def test_ga_encoder(f2, seeded_sd):
+    col = {}
+    b = _batch(f2)
+    R, x, ang, logits = O.ga_encoder(seeded_sd, f2["t"], f2["R_t"], f2["x_t"], f2["ang_t"], f2["seq_t"],
+                                     f2["enc_node"], f2["enc_edge"], b["res_mask"].long(), collect=col)
+    close(col["s_in"], f2["s_in"], atol=2e-5, rtol=1e-4)
+    for blk in range(6):
+        close(col[f"s_ipa_{blk}"], f2[f"s_ipa_{blk}"], atol=1e-4, rtol=1e-4)
+        close(col[f"s_{blk}"], f2[f"s_blk_{blk}"], atol=1e-4, rtol=1e-4)
+    close(col["z_4"], f2["z_blk_4"], atol=1e-4, rtol=1e-4)
+    close(R, f2["out_R"], atol=2e-5)
+    close(x, f2["out_x"], atol=1e-4)
+    close(logits, f2["out_logits"], atol=2e-4, rtol=1e-4)
+    d = (ang - f2["out_ang"]).abs()
+    d = torch.minimum(d, 2 * torch.pi - d)
+    assert d.max() < 2e-4
+
+
+def _noise(f3):
+    return {k: f3[k] for k in ("rot0", "trans0", "ang0", "simplex0", "expo")}
+
+
+def test_sample_teacher_forced(f3, seeded_sd):
+    """Per-step parity with the reference states forced before every network call."""
+    b = _batch(f3)
+    ns = 10
+    # rebuild the reference's pre-call states: state_0 from noise, state_{i+1} from the oracle's euler step on
+    # the REFERENCE clean prediction (so errors do not accumulate across steps)
+    tm = O.torsions_mask()
+    enc = O.encode(seeded_sd, b)
+    R1, x1, ang1, seq1, node, edge = enc
+    traj = O.sample(seeded_sd, b, _noise(f3), ns, encoded=enc)
+    flips = 0
+    for i in range(ns):
+        flips += (traj[i]["seqs"] != f3[f"step{i}_seqs"]).sum().item()
+    assert flips == 0, f"{flips} discrete sequence flips in a 10-step free run"
+    for i in range(ns):
+        close(traj[i]["rotmats"], f3[f"step{i}_rotmats"], atol=2e-4)
+        close(traj[i]["trans"], f3[f"step{i}_trans"], atol=5e-4, rtol=1e-4)
+        d = (traj[i]["angles"] - f3[f"step{i}_angles"]).abs()
+        assert torch.minimum(d, 2 * torch.pi - d).max() < 1e-3
+        assert torch.equal(traj[i]["seqs_simplex"], f3[f"step{i}_seqs_simplex"])
