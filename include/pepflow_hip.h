@@ -1,0 +1,205 @@
+/*
+ * pepflow_hip.h -- C ABI of libpepflow_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * PepFlow multi-modal flow-matching denoise path.
+ *
+ * The reference (Ced3-han/PepFlowww) has NO native/FFI interface for this path: it sits behind
+ * a plain torch nn.Module API.  This header therefore DEFINES the boundary a
+ * replacement must export; each entry point names the reference code it replaces
+ * (paths relative to /root/reference).  The reference-side binding (ctypes) is shown in
+ * INTEGRATION.md and implemented in pepflowww_amd/_capi.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator); kernels never
+ *     allocate, free or keep state; weights are read-only;
+ *   - all float tensors are fp32, contiguous row-major unless a leading dimension (ld*) is given;
+ *     sequences are int64; masks are fp32 0/1 ([B*L]);
+ *   - launches go to the hipStream_t passed as `stream` (opaque void*), no device sync;
+ *   - return value: hipError_t as int (0 = hipSuccess), PF_E_* (negative) for argument errors;
+ *     nothing throws.
+ */
+#ifndef PEPFLOW_HIP_H
+#define PEPFLOW_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+#define PF_E_BADARG (-1)
+#define PF_E_TOOLARGE (-2)
+
+typedef void* pf_stream_t;
+
+/* model constants (configs/learn_angle.yaml:3-14) baked into the kernels */
+#define PF_C_S 128
+#define PF_C_Z 64
+#define PF_HEADS 8
+#define PF_C_HID 128
+#define PF_QK_PTS 8
+#define PF_V_PTS 12
+#define PF_IPA_PROJ 3744  /* q 1024 | kv 2048 | q_pts 192 | kv_pts 480 */
+#define PF_IPA_FEATS 1536 /* o 1024 | o_pt x,y,z 3*96 | |o_pt| 96 | o_pair 128 */
+#define PF_ET_PRE 512     /* a 192 | c 192 | d 64 | e 64 */
+
+int pf_abi_version(void);
+
+/* MFMA fragment-layout self test: C[16,16] = A[16,K] * B[16,K]^T through the same tile
+ * primitive every GEMM below uses.  K multiple of 16. */
+int pf_selftest_mfma(const float* a, const float* b, float* c, int K, pf_stream_t stream);
+
+/* ---- fused row-linear -------------------------------------------------------------------
+ * y = epilogue(x W^T + bias), replaces torch.nn.Linear / ipa_pytorch.Linear (ipa_pytorch.py:116-181)
+ * plus the element-wise ops the reference applies right after it:
+ *   v = x W^T + bias ; relu ; v *= row_mask (mask_pre) ; v += residual ; LayerNorm(gamma,beta) ;
+ *   v *= row_mask (mask_post)
+ * covering ga.py:94-95,103-111, ipa_pytorch.py:196-206,478-482, TransformerEncoderLayer's
+ * projections.  K must be a multiple of 16 (host pads); LayerNorm needs N <= 128. */
+typedef struct {
+    const float* x;  int ldx;
+    const float* w;  int ldw;       /* [N, ldw], first K columns used */
+    const float* bias;              /* [N] or NULL */
+    float* y;        int ldy;
+    int M, N, K;
+    int relu;
+    const float* row_mask;          /* [M] or NULL */
+    int mask_pre, mask_post;
+    const float* residual; int ldr; /* [M, ldr] or NULL */
+    const float* ln_gamma; const float* ln_beta; float ln_eps; /* NULL = no LayerNorm */
+} pf_linear_args;
+int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
+
+/* ---- input mixing features: ga.py:94 (cat) + ga.py:79-85 / utils.py:60-71 (time embedding) +
+ * layers.py:92-113 (AngularEncoding, 12 funcs) + nn.Embedding lookup.
+ * out[B*L, 640] = [node_embed 128 | seq_emb[seqs] 128 | time 128 | angle code 245 | 0 x 11] */
+typedef struct {
+    const float* node_embed;   /* [B*L,128] */
+    const float* seq_table;    /* [22,128] */
+    const int64_t* seqs;       /* [B*L] */
+    const float* t;            /* [B] */
+    const float* time_freq;    /* [64] host-computed exp(-k ln(2056)/63) */
+    const float* ang_freq;     /* [24] AngularEncoding.freq_bands */
+    const float* angles;       /* [B*L,5] */
+    float* out;                /* [B*L,640] */
+    int B, L;
+} pf_embed_args;
+int pf_embed_inputs_fwd(const pf_embed_args* a, pf_stream_t stream);
+
+/* ---- rigid-body point projection: r.apply() on the IPA points, ipa_pytorch.py:360-387,
+ * rigid_utils.py:1124 / 82-106.  proj row = [q|kv|q_pts|kv_pts]; outputs global-frame points. */
+typedef struct {
+    const float* proj; int ldp;    /* [B*L, ldp>=3744] */
+    const float* rot;              /* [B*L,9] */
+    const float* trans;            /* [B*L,3] */
+    float* qp;                     /* [B*L, 8*8*3]  (h,p,xyz) */
+    float* kp;                     /* [B*L, 8*8*3] */
+    float* vp;                     /* [B*L, 8*12*3] */
+    int rows;
+} pf_ipa_points_args;
+int pf_ipa_points_fwd(const pf_ipa_points_args* a, pf_stream_t stream);
+
+/* ---- invariant point attention core: ipa_pytorch.py:389-475 (scores from scalar qk + pair bias +
+ * point distances, masked softmax, o / o_pt / o_pair, inverse-frame projection, norms).
+ * Reads z twice per query tile (bias pass, pair-value pass); never materialises the
+ * [B,L,L,H,Pq,3] / [B,H,3,L,L,Pv] intermediates of the reference. */
+typedef struct {
+    const float* proj; int ldp;    /* [B*L, ldp] q at 0, kv at 1024 (per head: k 128 | v 128) */
+    const float* qp; const float* kp; const float* vp; /* from pf_ipa_points_fwd */
+    const float* z;                /* [B,L,L,64] */
+    const float* rot; const float* trans; /* frames [B*L,9],[B*L,3] */
+    const float* mask;             /* [B*L] */
+    const float* w_b; const float* b_b;   /* linear_b  [8,64],[8]  */
+    const float* w_dz; const float* b_dz; /* down_z    [16,64],[16] */
+    const float* head_w;           /* [8] raw (softplus applied inside) */
+    float* feats;                  /* [B*L,1536] */
+    int B, L;
+} pf_ipa_attn_args;
+int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
+
+/* ---- sequence-transformer attention core (torch.nn.MultiheadAttention inside
+ * nn.TransformerEncoderLayer, ga.py:53-62): 4 heads x 32, key padding mask. */
+typedef struct {
+    const float* qkv;              /* [B*L,384] q|k|v */
+    const float* mask;             /* [B*L] */
+    float* out;                    /* [B*L,128] */
+    int B, L;
+} pf_seq_attn_args;
+int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream);
+
+/* ---- rot -> quat: rigid_utils.py:208-227 (top eigenvector of the 4x4 K matrix; the reference
+ * calls torch.linalg.eigh, here a shifted power iteration converged to fp32). */
+int pf_rot_to_quat(const float* rot, float* quat, int n, pf_stream_t stream);
+
+/* ---- backbone update: Rigid.compose_q_update_vec, rigid_utils.py:1039-1063,587-616,266-275,
+ * 331-332 and quat_to_rot 185-205.  In-place allowed. */
+typedef struct {
+    const float* quat_in;          /* [n,4] */
+    const float* rot_in;           /* [n,9] rotation applied to the translation update */
+    const float* trans_in;         /* [n,3] */
+    const float* upd; int ldu;     /* [n,ldu>=6] */
+    const float* mask;             /* [n] */
+    float* quat_out; float* rot_out; float* trans_out;
+    int n;
+} pf_rigid_update_args;
+int pf_rigid_update_fwd(const pf_rigid_update_args* a, pf_stream_t stream);
+
+/* ---- EdgeTransition: ipa_pytorch.py:233-248 + edge mask ga.py:118.  The 192-wide concat
+ * [z, n_i, n_j] is never built: pre[B*L,512] holds the per-residue terms
+ *   a = W1[:,64:128] n, c = W1[:,128:192] n + b1, d = Wf[:,64:128] n, e = Wf[:,128:192] n + bf
+ * (computed with pf_linear_fwd) and only the z part goes through the per-pair GEMMs. */
+typedef struct {
+    const float* z_in;             /* [B*L*L,64] */
+    float* z_out;                  /* may alias z_in */
+    const float* pre;              /* [B*L,512] */
+    const float* w1;               /* trunk.0.weight [192,192] (columns 0..63 used) */
+    const float* w2; const float* b2; /* trunk.2 */
+    const float* wf;               /* final_layer.weight [64,192] */
+    const float* ln_g; const float* ln_b;
+    const float* mask;             /* [B*L] */
+    int B, L;
+} pf_edge_transition_args;
+int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
+
+/* ---- sampler state, flow_model.py:229-374 ------------------------------------------------
+ * Device-resident sampler: the loop never syncs with the host.  `step` is a device counter so
+ * that one captured hipGraph can be replayed for every step. */
+typedef struct {
+    /* ground truth / context (from encode) */
+    const float* rot1; const float* trans1; const float* ang1; const int64_t* seq1;
+    const float* gen_mask;         /* [B*L] 1 = generated residue */
+    const float* res_mask;         /* [B*L] */
+    /* current state (updated in place) */
+    float* rot_t; float* trans_t; float* ang_t; int64_t* seq_t; float* simplex_t;
+    /* initial noise kept for the Euler step (flow_model.py:318,328) */
+    float* trans0; float* simplex0;
+    /* network outputs of this step */
+    const float* pred_rot; const float* pred_trans; const float* pred_ang_raw; const float* pred_logits;
+    /* trajectory buffers [num_steps, ...]; slot `*step` is written */
+    float* traj_rot; float* traj_trans; float* traj_ang; int64_t* traj_seq; float* traj_simplex;
+    /* time grid ts[num_steps] (torch.linspace(1e-2,1,N), flow_model.py:280) */
+    const float* ts; int num_steps;
+    int* step;                     /* device step counter */
+    float* t_out;                  /* [B] time fed to the next network call */
+    /* categorical noise: expo != NULL -> caller-supplied Exp(1) draws [2*num_steps,B*L,20];
+     * NULL -> in-kernel Philox4x32-10 keyed by (seed, first_sample+b, draw, residue, class) */
+    const float* expo; uint64_t seed; int64_t first_sample;
+    int B, L;
+    int sample_bb, sample_ang, sample_seq;
+} pf_sampler_args;
+/* initial state from raw noise (flow_model.py:252-277): rot0/trans0_raw/ang0/simplex0_raw as drawn */
+int pf_sampler_init(const pf_sampler_args* a, const float* rot0, const float* trans0_raw,
+                    const float* ang0, const float* simplex0_raw, pf_stream_t stream);
+/* post-process the prediction (291-312), record it, then Euler step (316-343) unless last step;
+ * increments *step */
+int pf_sampler_step(const pf_sampler_args* a, pf_stream_t stream);
+
+/* stand-alone manifold steps (KAT surface): so3_utils.geodesic_t (500-520) and torus.tor_geodesic_t */
+int pf_so3_geodesic(const float* base, const float* target, const float* t, float* out, int n, pf_stream_t stream);
+int pf_so3_log(const float* rot, float* rotvec, int n, pf_stream_t stream);
+int pf_so3_exp(const float* rotvec, float* rot, int n, pf_stream_t stream);
+int pf_torus_geodesic(const float* base, const float* target, const float* t, float* out, int n, pf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

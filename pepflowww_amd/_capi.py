@@ -1,0 +1,138 @@
+"""ctypes binding of include/pepflow_hip.h (libpepflow_hip.so, hand-written gfx950 kernels).
+
+This is the ONLY compute backend of the package: there is no CPU / PyTorch fallback.  If the
+shared library is missing, or a tensor is not a contiguous fp32/int64 tensor on a ROCm device,
+the call raises -- it never silently degrades.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
+ABI_VERSION = 1
+
+_fp = C.c_void_p
+_i = C.c_int
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("x", _fp), ("ldx", _i), ("w", _fp), ("ldw", _i), ("bias", _fp), ("y", _fp), ("ldy", _i),
+                ("M", _i), ("N", _i), ("K", _i), ("relu", _i), ("row_mask", _fp), ("mask_pre", _i),
+                ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
+                ("ln_eps", C.c_float)]
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("node_embed", _fp), ("seq_table", _fp), ("seqs", _fp), ("t", _fp), ("time_freq", _fp),
+                ("ang_freq", _fp), ("angles", _fp), ("out", _fp), ("B", _i), ("L", _i)]
+
+
+class IpaPointsArgs(C.Structure):
+    _fields_ = [("proj", _fp), ("ldp", _i), ("rot", _fp), ("trans", _fp), ("qp", _fp), ("kp", _fp), ("vp", _fp),
+                ("rows", _i)]
+
+
+class IpaAttnArgs(C.Structure):
+    _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
+                ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
+                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i)]
+
+
+class SeqAttnArgs(C.Structure):
+    _fields_ = [("qkv", _fp), ("mask", _fp), ("out", _fp), ("B", _i), ("L", _i)]
+
+
+class RigidUpdateArgs(C.Structure):
+    _fields_ = [("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp), ("upd", _fp), ("ldu", _i), ("mask", _fp),
+                ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("n", _i)]
+
+
+class EdgeTransitionArgs(C.Structure):
+    _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1", _fp), ("w2", _fp), ("b2", _fp), ("wf", _fp),
+                ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i)]
+
+
+class SamplerArgs(C.Structure):
+    _fields_ = [("rot1", _fp), ("trans1", _fp), ("ang1", _fp), ("seq1", _fp), ("gen_mask", _fp), ("res_mask", _fp),
+                ("rot_t", _fp), ("trans_t", _fp), ("ang_t", _fp), ("seq_t", _fp), ("simplex_t", _fp),
+                ("trans0", _fp), ("simplex0", _fp),
+                ("pred_rot", _fp), ("pred_trans", _fp), ("pred_ang_raw", _fp), ("pred_logits", _fp),
+                ("traj_rot", _fp), ("traj_trans", _fp), ("traj_ang", _fp), ("traj_seq", _fp), ("traj_simplex", _fp),
+                ("ts", _fp), ("num_steps", _i), ("step", _fp), ("t_out", _fp),
+                ("expo", _fp), ("seed", C.c_uint64), ("first_sample", C.c_int64),
+                ("B", _i), ("L", _i), ("sample_bb", _i), ("sample_ang", _i), ("sample_seq", _i)]
+
+
+_SIGNATURES = {
+    "pf_abi_version": ([], _i),
+    "pf_selftest_mfma": ([_fp, _fp, _fp, _i, _fp], _i),
+    "pf_linear_fwd": ([C.POINTER(LinearArgs), _fp], _i),
+    "pf_embed_inputs_fwd": ([C.POINTER(EmbedArgs), _fp], _i),
+    "pf_ipa_points_fwd": ([C.POINTER(IpaPointsArgs), _fp], _i),
+    "pf_ipa_attn_fwd": ([C.POINTER(IpaAttnArgs), _fp], _i),
+    "pf_seq_attn_fwd": ([C.POINTER(SeqAttnArgs), _fp], _i),
+    "pf_rot_to_quat": ([_fp, _fp, _i, _fp], _i),
+    "pf_rigid_update_fwd": ([C.POINTER(RigidUpdateArgs), _fp], _i),
+    "pf_edge_transition_fwd": ([C.POINTER(EdgeTransitionArgs), _fp], _i),
+    "pf_sampler_init": ([C.POINTER(SamplerArgs), _fp, _fp, _fp, _fp, _fp], _i),
+    "pf_sampler_step": ([C.POINTER(SamplerArgs), _fp], _i),
+    "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
+    "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
+    "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),
+    "pf_torus_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class PepflowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libpepflow_hip.so (built in-tree by pepflowww_amd/build.py).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PepflowHipError(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path of pepflowww_amd "
+            f"(no CPU fallback). Build it with `python -m pepflowww_amd.build` (hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.pf_abi_version() != ABI_VERSION:
+        raise PepflowHipError(f"ABI mismatch: library {lib.pf_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise PepflowHipError(f"{what} failed with code {code} "
+                              f"({'bad argument' if code == -1 else 'problem too large' if code == -2 else 'hipError_t'})")
+
+
+def dptr(t, dtype=torch.float32, name="tensor"):
+    """Device pointer of a contiguous tensor on a ROCm device; raises otherwise (no fallback)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise PepflowHipError(f"{name}: tensor is on {t.device}; pepflowww_amd only runs on a ROCm GPU "
+                              f"(the CPU restatement lives in oracle/ and is test infrastructure)")
+    if t.dtype != dtype:
+        raise PepflowHipError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise PepflowHipError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,418 @@
+// Device-resident flow-matching sampler updates (models_con/flow_model.py:229-374) and the
+// manifold maps they use: SO(3) log/exp/geodesic (data/so3_utils.py:88-311,486-520), torus
+// geodesic (models_con/torus.py:5-26), simplex Euler step + categorical draws
+// (pepflow/modules/common/layers.py:10-22), torsion masking (models_con/torsion.py:230-232).
+// One thread per residue; everything per-residue is fused into one launch per step.
+#include "common.h"
+#include "../../include/pepflow_hip.h"
+
+namespace {
+
+constexpr float TWO_PI_F = 6.2831855f;     // float32(2*pi), as torch promotes the python scalar
+constexpr float PI_F = 3.1415927f;
+constexpr int KCLS = 20;
+constexpr float SIMPLEX_K = 5.0f;
+
+// chi-angle existence: psi + constants.chi_angles_mask (constants.py:402-424), AA order 53-58
+__constant__ int c_nchi[22] = {0, 1, 2, 3, 2, 0, 2, 2, 4, 2, 3, 2, 2, 3, 4, 1, 1, 1, 2, 2, 0, -1};
+
+__device__ __forceinline__ bool torsion_exists(long long aa, int d) {
+    if (aa < 0 || aa > 21) return false;
+    const int n = c_nchi[aa];
+    return n >= 0 && d <= n;               // d = 0 is psi (row 21 = PAD has none)
+}
+
+__device__ __forceinline__ float py_mod_2pi(float x) {   // torch `%` (remainder, sign of divisor)
+    float m = fmodf(x, TWO_PI_F);
+    if (m != 0.f && m < 0.f) m += TWO_PI_F;
+    return m;
+}
+
+// ---- SO(3) ----------------------------------------------------------------------------------
+__device__ __forceinline__ void so3_log_dev(const float* M, float* w) {
+    const float vvx = M[7] - M[5], vvy = M[2] - M[6], vvz = M[3] - M[1];   // vee(R - R^T)
+    const float s = sqrtf(vvx * vvx + vvy * vvy + vvz * vvz) * 0.5f;
+    const float c = ((M[0] + M[4] + M[8]) - 1.f) * 0.5f;
+    const float th = atan2f(s, c);
+    const float m0 = (fabsf(th) <= 1e-8f) ? 1.f : 0.f;                          // isclose(th, 0)
+    const float mpi = (fabsf(th - PI_F) <= 1e-2f + 1e-5f * PI_F) ? 1.f : 0.f;   // isclose(th, pi, atol=1e-2)
+    const float mel = (1.f - m0) * (1.f - mpi);
+    const float num = m0 * 0.5f + th * mel;
+    const float den = (1.f - th * th / 6.f) * m0 + 2.f * s * mel + mpi;
+    const float pre = num / den;
+    w[0] = vvx * pre; w[1] = vvy * pre; w[2] = vvz * pre;
+    if (mpi != 0.f) {
+        float S[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S[k] = (((k % 4) == 0 ? 1.f : 0.f) + M[k]) * 0.5f;
+        S[0] = fmaxf(S[0], 0.f); S[4] = fmaxf(S[4], 0.f); S[8] = fmaxf(S[8], 0.f);
+        const float n0 = sqrtf(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+        const float n1 = sqrtf(S[3] * S[3] + S[4] * S[4] + S[5] * S[5]);
+        const float n2 = sqrtf(S[6] * S[6] + S[7] * S[7] + S[8] * S[8]);
+        int idx = 0;
+        float bn = n0;
+        if (n1 > bn) { bn = n1; idx = 1; }
+        if (n2 > bn) { bn = n2; idx = 2; }
+        const float r0 = idx == 0 ? S[0] : idx == 1 ? S[3] : S[6];
+        const float r1 = idx == 0 ? S[1] : idx == 1 ? S[4] : S[7];
+        const float r2 = idx == 0 ? S[2] : idx == 1 ? S[5] : S[8];
+        auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
+        w[0] += sqrtf(S[0]) * th * sgn(r0);
+        w[1] += sqrtf(S[4]) * th * sgn(r1);
+        w[2] += sqrtf(S[8]) * th * sgn(r2);
+    }
+}
+
+__device__ __forceinline__ void so3_exp_dev(const float* w, float* R) {
+    const float x = w[0], y = w[1], z = w[2];
+    const float th = sqrtf(x * x + y * y + z * z);
+    const float th2 = th * th;
+    float a, b;
+    if (fabsf(th) < 1e-7f) { a = 1.f - th2 / 6.f; b = 0.5f - th2 / 24.f; }
+    else { a = sinf(th) / th; b = (1.f - cosf(th)) / th2; }
+    // K = hat(w); K^2 = w w^T - |w|^2 I, evaluated as the explicit matrix product like the reference
+    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float k2 = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+            R[i * 3 + j] = ((i == j) ? 1.f : 0.f) + a * K[i * 3 + j] + b * k2;
+        }
+}
+
+// out = base * Exp(t * Log(base^T target))   (geodesic_t, so3_utils.py:500-520)
+__device__ __forceinline__ void so3_geodesic_dev(const float* base, const float* target, float t, float* out) {
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            M[i * 3 + k] = base[0 * 3 + i] * target[0 * 3 + k] + base[1 * 3 + i] * target[1 * 3 + k] + base[2 * 3 + i] * target[2 * 3 + k];
+    float w[3], E[9];
+    so3_log_dev(M, w);
+    w[0] *= t; w[1] *= t; w[2] *= t;
+    so3_exp_dev(w, E);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            out[i * 3 + k] = base[i * 3 + 0] * E[0 * 3 + k] + base[i * 3 + 1] * E[1 * 3 + k] + base[i * 3 + 2] * E[2 * 3 + k];
+}
+
+__device__ __forceinline__ float tor_geodesic_dev(float base, float target, float t) {
+    const float d = target - base;
+    const float u = t * atan2f(sinf(d), cosf(d));
+    return py_mod_2pi(base + u);
+}
+
+// ---- Philox4x32-10 ----------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// categorical draw = torch.multinomial(p + 1e-8, 1) = argmax((p + 1e-8) / E), E ~ Exp(1)
+// (layers.py:17-22).  logits -> softmax inside.  expo: 20 caller-supplied draws or NULL (Philox).
+__device__ __forceinline__ long long categorical_dev(const float* logit, const float* expo, uint64_t seed,
+                                                     long long gsample, int draw, int res) {
+    float mx = logit[0];
+#pragma unroll
+    for (int k = 1; k < KCLS; ++k) mx = fmaxf(mx, logit[k]);
+    float e[KCLS], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KCLS; ++k) { e[k] = expf(logit[k] - mx); sum += e[k]; }
+    float E[KCLS];
+    if (expo) {
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) E[k] = expo[k];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            uint32_t c[4] = {(uint32_t)(res * 5 + q), (uint32_t)draw, (uint32_t)gsample, (uint32_t)((uint64_t)gsample >> 32)};
+            philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) E[q * 4 + k] = -logf(((float)(c[k] >> 8) + 0.5f) * 5.9604644775390625e-08f);   // u in (0,1)
+        }
+    }
+    int best = 0;
+    float bv = (e[0] / sum + 1e-8f) / E[0];
+#pragma unroll
+    for (int k = 1; k < KCLS; ++k) {
+        const float v = (e[k] / sum + 1e-8f) / E[k];
+        if (v > bv) { bv = v; best = k; }
+    }
+    return best;
+}
+
+__device__ __forceinline__ float simplex_of(long long seq, int k) {   // seq_to_simplex, flow_model.py:108-109
+    return (seq >= 0 && seq < KCLS && seq == k) ? SIMPLEX_K : -SIMPLEX_K;
+}
+
+// ---- sampler init: flow_model.py:252-284, one workgroup per sample ----
+__global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, const float* rot0, const float* tr0,
+                                                           const float* ang0, const float* sx0) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.x, L = a.L;
+    const size_t rowb = (size_t)b * L;
+    // centre of the generated residues (zero_center_part, flow_model.py:95-106)
+    float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
+    for (int l = threadIdx.x; l < L; l += 256) {
+        const float gm = a.gen_mask[rowb + l];
+        sx += tr0[(rowb + l) * 3 + 0] * gm; sy += tr0[(rowb + l) * 3 + 1] * gm; sz += tr0[(rowb + l) * 3 + 2] * gm;
+        cnt += gm;
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); cnt = wave_sum(cnt);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; red[wave][3] = cnt; }
+    __syncthreads();
+    sx = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    sy = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    sz = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    cnt = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+    const float den = cnt + 1e-8f;
+    const float cx = sx / den, cy = sy / den, cz = sz / den;
+    for (int l = threadIdx.x; l < L; l += 256) {
+        const size_t row = rowb + l;
+        const bool gen = a.gen_mask[row] > 0.5f;
+        const float rm = a.res_mask[row];
+        const bool bb = gen && a.sample_bb, an = gen && a.sample_ang, sq = gen && a.sample_seq;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.rot_t[row * 9 + k] = bb ? rot0[row * 9 + k] : a.rot1[row * 9 + k];
+        const float c3[3] = {cx, cy, cz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = bb ? (tr0[row * 3 + k] - c3[k]) * rm : a.trans1[row * 3 + k];
+            a.trans0[row * 3 + k] = v;
+            a.trans_t[row * 3 + k] = v;
+        }
+        const long long s1 = a.seq1[row];
+        float lg[KCLS];
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) lg[k] = SIMPLEX_K * sx0[row * KCLS + k];
+        long long s0 = s1;
+        if (sq) s0 = categorical_dev(lg, a.expo ? a.expo + row * KCLS : nullptr, a.seed, a.first_sample + b, 0, l);
+        a.seq_t[row] = s0;
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) {
+            const float v = sq ? lg[k] : simplex_of(s1, k);
+            a.simplex0[row * KCLS + k] = v;
+            a.simplex_t[row * KCLS + k] = v;
+        }
+#pragma unroll
+        for (int d = 0; d < 5; ++d) a.ang_t[row * 5 + d] = an ? ang0[row * 5 + d] : a.ang1[row * 5 + d];
+    }
+    if (threadIdx.x == 0) {
+        a.t_out[b] = a.ts[0];
+        if (b == 0) *a.step = 0;
+    }
+}
+
+// ---- one sampler step: post-process (291-312 / 349-370), record, Euler (316-343) ----
+__global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int n = a.B * a.L;
+    if (row >= n) return;
+    const int s = *a.step;
+    if (s >= a.num_steps) return;
+    const int b = row / a.L, l = row - b * a.L;
+    const bool gen = a.gen_mask[row] > 0.5f;
+    const size_t nrow = (size_t)n;
+    const long long gs = a.first_sample + b;
+
+    // -------- clean prediction --------
+    float Rp[9], xp[3], angp[5], sxp[KCLS];
+    const bool bb = gen && a.sample_bb;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = bb ? a.pred_rot[(size_t)row * 9 + k] : a.rot1[(size_t)row * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xp[k] = bb ? a.pred_trans[(size_t)row * 3 + k] : a.trans1[(size_t)row * 3 + k];
+    const long long s1 = a.seq1[row];
+    long long seqp = s1;
+    if (gen && a.sample_seq) {
+        float lg[KCLS];
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) lg[k] = a.pred_logits[(size_t)row * KCLS + k];
+        const float* ex = a.expo ? a.expo + ((size_t)(1 + 2 * s) * nrow + row) * KCLS : nullptr;
+        seqp = categorical_dev(lg, ex, a.seed, gs, 1 + 2 * s, l);
+    }
+#pragma unroll
+    for (int k = 0; k < KCLS; ++k) sxp[k] = simplex_of(seqp, k);
+    // angles: where(gen, pred % 2pi, gt) ; then torsion mask of the drawn residue type (302-303).
+    // NB the reference draws the sequence and applies its torsion mask even when sample_seq=False.
+    long long seq_for_mask = seqp;
+    if (gen && !a.sample_seq) {
+        float lg[KCLS];
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) lg[k] = a.pred_logits[(size_t)row * KCLS + k];
+        const float* ex = a.expo ? a.expo + ((size_t)(1 + 2 * s) * nrow + row) * KCLS : nullptr;
+        seq_for_mask = categorical_dev(lg, ex, a.seed, gs, 1 + 2 * s, l);
+    }
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        float v = gen ? py_mod_2pi(a.pred_ang_raw[(size_t)row * 5 + d]) : a.ang1[(size_t)row * 5 + d];
+        if (!torsion_exists(seq_for_mask, d)) v = 0.f;
+        if (!a.sample_ang) v = a.ang1[(size_t)row * 5 + d];
+        angp[d] = v;
+    }
+    // record
+    {
+        const size_t o = (size_t)s * nrow + row;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.traj_rot[o * 9 + k] = Rp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.traj_trans[o * 3 + k] = xp[k];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) a.traj_ang[o * 5 + d] = angp[d];
+        a.traj_seq[o] = seqp;
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) a.traj_simplex[o * KCLS + k] = sxp[k];
+    }
+    if (s == a.num_steps - 1) return;
+
+    // -------- Euler step --------
+    const float dt = a.ts[s + 1] - a.ts[s];
+    // translations (318-320)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const size_t o = (size_t)row * 3 + k;
+        const float v = a.trans_t[o] + (xp[k] - a.trans0[o]) * dt;
+        a.trans_t[o] = bb ? v : a.trans1[o];
+    }
+    // rotations (322-323): geodesic with rate 10
+    {
+        float Rt[9], Rn[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rt[k] = a.rot_t[(size_t)row * 9 + k];
+        if (bb) so3_geodesic_dev(Rt, Rp, dt * 10.f, Rn);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.rot_t[(size_t)row * 9 + k] = bb ? Rn[k] : a.rot1[(size_t)row * 9 + k];
+    }
+    // simplex + state sequence (328-330)
+    float lg[KCLS];
+#pragma unroll
+    for (int k = 0; k < KCLS; ++k) {
+        const size_t o = (size_t)row * KCLS + k;
+        lg[k] = a.simplex_t[o] + (sxp[k] - a.simplex0[o]) * dt;
+        a.simplex_t[o] = lg[k];
+    }
+    long long seqn = s1;
+    long long seqn_mask = s1;
+    if (gen) {
+        const float* ex = a.expo ? a.expo + ((size_t)(2 + 2 * s) * nrow + row) * KCLS : nullptr;
+        seqn_mask = categorical_dev(lg, ex, a.seed, gs, 2 + 2 * s, l);
+        seqn = a.sample_seq ? seqn_mask : s1;
+    }
+    a.seq_t[row] = seqn;
+    // angles (325-326, 332-333)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const size_t o = (size_t)row * 5 + d;
+        float v = gen ? tor_geodesic_dev(a.ang_t[o], angp[d], dt) : a.ang1[o];
+        if (!torsion_exists(seqn_mask, d)) v = 0.f;
+        if (!a.sample_ang) v = a.ang1[o];
+        a.ang_t[o] = v;
+    }
+}
+
+__global__ void sampler_bump_kernel(pf_sampler_args a) {
+    const int s = *a.step + 1;
+    if (threadIdx.x == 0) *a.step = s;
+    const int sc = s < a.num_steps ? s : a.num_steps - 1;
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) a.t_out[b] = a.ts[sc];
+}
+
+__global__ __launch_bounds__(256) void so3_geodesic_kernel(const float* base, const float* target, const float* t, float* out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float B[9], T[9], O[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { B[k] = base[(size_t)i * 9 + k]; T[k] = target[(size_t)i * 9 + k]; }
+    so3_geodesic_dev(B, T, t[i], O);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[(size_t)i * 9 + k] = O[k];
+}
+__global__ __launch_bounds__(256) void so3_log_kernel(const float* rot, float* w, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float M[9], v[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M[k] = rot[(size_t)i * 9 + k];
+    so3_log_dev(M, v);
+    w[(size_t)i * 3] = v[0]; w[(size_t)i * 3 + 1] = v[1]; w[(size_t)i * 3 + 2] = v[2];
+}
+__global__ __launch_bounds__(256) void so3_exp_kernel(const float* w, float* rot, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v[3] = {w[(size_t)i * 3], w[(size_t)i * 3 + 1], w[(size_t)i * 3 + 2]}, R[9];
+    so3_exp_dev(v, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rot[(size_t)i * 9 + k] = R[k];
+}
+__global__ __launch_bounds__(256) void torus_geodesic_kernel(const float* base, const float* target, const float* t, float* out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = tor_geodesic_dev(base[i], target[i], t[i]);
+}
+
+bool sampler_args_ok(const pf_sampler_args* a) {
+    return a && a->rot1 && a->trans1 && a->ang1 && a->seq1 && a->gen_mask && a->res_mask && a->rot_t && a->trans_t &&
+           a->ang_t && a->seq_t && a->simplex_t && a->trans0 && a->simplex0 && a->ts && a->step && a->t_out &&
+           a->num_steps > 0 && a->B > 0 && a->L > 0;
+}
+
+}  // namespace
+
+extern "C" int pf_sampler_init(const pf_sampler_args* a, const float* rot0, const float* trans0_raw, const float* ang0,
+                               const float* simplex0_raw, pf_stream_t stream) {
+    if (!sampler_args_ok(a) || !rot0 || !trans0_raw || !ang0 || !simplex0_raw) return PF_E_BADARG;
+    hipLaunchKernelGGL(sampler_init_kernel, dim3((unsigned)a->B), dim3(256), 0, (hipStream_t)stream, *a, rot0, trans0_raw, ang0, simplex0_raw);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_sampler_step(const pf_sampler_args* a, pf_stream_t stream) {
+    if (!sampler_args_ok(a) || !a->pred_rot || !a->pred_trans || !a->pred_ang_raw || !a->pred_logits || !a->traj_rot ||
+        !a->traj_trans || !a->traj_ang || !a->traj_seq || !a->traj_simplex)
+        return PF_E_BADARG;
+    const int n = a->B * a->L;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sampler_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+#define PF_SIMPLE_LAUNCH(kern, n, ...)                                                                              \
+    do {                                                                                                            \
+        if ((n) <= 0) return PF_E_BADARG;                                                                           \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        PF_CHECK_LAUNCH();                                                                                          \
+        return 0;                                                                                                   \
+    } while (0)
+
+extern "C" int pf_so3_geodesic(const float* base, const float* target, const float* t, float* out, int n, pf_stream_t stream) {
+    if (!base || !target || !t || !out) return PF_E_BADARG;
+    PF_SIMPLE_LAUNCH(so3_geodesic_kernel, n, base, target, t, out, n);
+}
+extern "C" int pf_so3_log(const float* rot, float* rotvec, int n, pf_stream_t stream) {
+    if (!rot || !rotvec) return PF_E_BADARG;
+    PF_SIMPLE_LAUNCH(so3_log_kernel, n, rot, rotvec, n);
+}
+extern "C" int pf_so3_exp(const float* rotvec, float* rot, int n, pf_stream_t stream) {
+    if (!rotvec || !rot) return PF_E_BADARG;
+    PF_SIMPLE_LAUNCH(so3_exp_kernel, n, rotvec, rot, n);
+}
+extern "C" int pf_torus_geodesic(const float* base, const float* target, const float* t, float* out, int n, pf_stream_t stream) {
+    if (!base || !target || !t || !out) return PF_E_BADARG;
+    PF_SIMPLE_LAUNCH(torus_geodesic_kernel, n, base, target, t, out, n);
+}

@@ -1,0 +1,138 @@
+// pf_linear_fwd: y = epilogue(x W^T + b) on fp32 MFMA tiles (v_mfma_f32_16x16x4_f32).
+//
+// Workgroup = 4 waves, output tile [16*MT rows x 128 cols]; wave w owns columns [32w, 32w+32).
+// The x tile is staged through LDS in K-chunks of 128 (coalesced float4 loads, row stride
+// 132 floats); weights stream straight from global/L2 into MFMA B fragments (each wave reads
+// only its own 32 rows of W, so there is no redundant weight traffic inside a workgroup).
+// Replaces ipa_pytorch.Linear / nn.Linear + the elementwise tail the reference runs after it
+// (see include/pepflow_hip.h).
+#include "common.h"
+#include "../../include/pepflow_hip.h"
+
+namespace {
+
+constexpr int KC = 128;        // K chunk staged in LDS
+constexpr int LDA = KC + 4;    // padded row stride (floats)
+constexpr int BN = 128;
+constexpr int LDY = BN + 4;
+
+template <int MT>
+__global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
+    constexpr int BM = 16 * MT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [BM][LDA]
+    float* Ys = smem + BM * LDA;      // [BM][LDY] (LayerNorm path only)
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int nblk = blockIdx.y * BN;
+    const int n0 = nblk + wave * 32;
+
+    f32x4 acc[MT][2];
+    acc_zero<MT, 2>(acc);
+
+    for (int kc = 0; kc < p.K; kc += KC) {
+        const int kw = min(KC, p.K - kc);           // multiple of 16
+        const int kq = kw >> 2;                      // float4 per row
+        if (kc) __syncthreads();
+        for (int idx = tid; idx < BM * kq; idx += 256) {
+            int row = idx / kq, c4 = idx - row * kq;
+            int m = m0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M) v = *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + kc + 4 * c4);
+            *reinterpret_cast<float4*>(As + row * LDA + 4 * c4) = v;
+        }
+        __syncthreads();
+        gemm_ldsA_glbB<MT, 2>(As, LDA, p.w + kc, p.ldw, n0, p.N, kw, acc);
+    }
+
+    const bool do_ln = p.ln_gamma != nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + nt * 16 + r;
+            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mt * 16 + g * 4 + e;
+                const int m = m0 + row;
+                float v = acc[mt][nt][e] + bias;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (m < p.M && n < p.N) {
+                    if (p.mask_pre) v *= p.row_mask[m];
+                    if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+                    if (!do_ln) {
+                        if (p.mask_post) v *= p.row_mask[m];
+                        p.y[(size_t)m * p.ldy + n] = v;
+                    }
+                } else {
+                    v = 0.f;
+                }
+                if (do_ln) Ys[row * LDY + (n - nblk)] = v;
+            }
+        }
+    if (!do_ln) return;
+    __syncthreads();
+    // LayerNorm over the N (<=128) columns: 256/BM threads per row
+    constexpr int TPR = 256 / BM;                  // threads per row: 16 / 8 / 4
+    constexpr int CPT = BN / TPR;                  // columns per thread
+    const int row = tid / TPR, sub = tid % TPR;
+    const int m = m0 + row;
+    float vals[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        int n = sub + c * TPR;                     // interleaved -> conflict-free LDS reads
+        vals[c] = (n < p.N) ? Ys[row * LDY + n] : 0.f;
+        s += vals[c];
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)p.N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        int n = sub + c * TPR;
+        float d = (n < p.N) ? vals[c] - mean : 0.f;
+        q += d * d;
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)p.N + p.ln_eps);
+    if (m < p.M) {
+        const float mk = p.mask_post ? p.row_mask[m] : 1.f;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            int n = sub + c * TPR;
+            if (n < p.N) p.y[(size_t)m * p.ldy + n] = ((vals[c] - mean) * rstd * p.ln_gamma[n] + p.ln_beta[n]) * mk;
+        }
+    }
+}
+
+template <int MT>
+int launch(const pf_linear_args& a, hipStream_t s) {
+    constexpr int BM = 16 * MT;
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+    size_t lds = (size_t)BM * LDA * sizeof(float) + (a.ln_gamma ? (size_t)BM * LDY * sizeof(float) : 0);
+    hipLaunchKernelGGL(linear_kernel<MT>, grid, dim3(256), lds, s, a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
+    if (!a || !a->x || !a->w || !a->y || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    if (a->K % 16 || a->ldx % 4 || a->ldw % 4 || a->ldx < a->K || a->ldw < a->K) return PF_E_BADARG;
+    if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return PF_E_BADARG;
+    if ((a->mask_pre || a->mask_post) && !a->row_mask) return PF_E_BADARG;
+    if (a->ln_gamma && (a->N > BN || !a->ln_beta)) return PF_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    // enough workgroups to cover 256 CUs where the problem allows it
+    const long nb = (a->N + BN - 1) / BN;
+    if ((long)((a->M + 63) / 64) * nb >= 512) return launch<4>(*a, s);
+    if ((long)((a->M + 31) / 32) * nb >= 256) return launch<2>(*a, s);
+    return launch<1>(*a, s);
+}

@@ -1,0 +1,219 @@
+// Per-residue kernels of the denoise step: input feature assembly, sequence-transformer
+// attention core, rot->quat and the quaternion backbone update.
+#include "common.h"
+#include "../../include/pepflow_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// pf_embed_inputs_fwd: ga.py:94 concat; time embedding utils.py:60-71; AngularEncoding layers.py:92-113
+// out row (640) = node_embed[128] | seq_table[seq][128] | [sin,cos](t*2056*f_k)[128] | code[245] | 0[11]
+// code for angle d (49 values): x, sin(x*F[0..23]), cos(x*F[0..23])
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(pf_embed_args a) {
+    const int row = blockIdx.x;
+    const int b = row / a.L;
+    float* out = a.out + (size_t)row * 640;
+    const float tt = a.t[b] * 2056.f;
+    long long sq = a.seqs[row];
+    if (sq < 0) sq = 0;
+    if (sq > 21) sq = 21;
+    for (int c = threadIdx.x; c < 640; c += 256) {
+        float v;
+        if (c < 128) v = a.node_embed[(size_t)row * 128 + c];
+        else if (c < 256) v = a.seq_table[sq * 128 + (c - 128)];
+        else if (c < 320) v = sinf(tt * a.time_freq[c - 256]);
+        else if (c < 384) v = cosf(tt * a.time_freq[c - 320]);
+        else if (c < 629) {
+            const int q = c - 384, d = q / 49, k = q - d * 49;
+            const float x = a.angles[(size_t)row * 5 + d];
+            if (k == 0) v = x;
+            else if (k < 25) v = sinf(x * a.ang_freq[k - 1]);
+            else v = cosf(x * a.ang_freq[k - 25]);
+        } else v = 0.f;
+        out[c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pf_seq_attn_fwd: softmax(q k^T / sqrt(32) + key_padding) v for one (sample, head) per workgroup.
+// K/V head slices in LDS, one query row per thread, online softmax (no L x L matrix).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seq_attn_kernel(pf_seq_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = a.L;
+    float* Ks = smem;               // [L][32]
+    float* Vs = smem + (size_t)L * 32;
+    float* Ms = Vs + (size_t)L * 32; // [L]
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const size_t rowb = (size_t)b * L;
+    for (int idx = threadIdx.x; idx < L * 8; idx += 256) {
+        const int j = idx >> 3, c4 = idx & 7;
+        const float* src = a.qkv + (rowb + j) * 384 + h * 32 + 4 * c4;
+        *reinterpret_cast<float4*>(Ks + j * 32 + 4 * c4) = *reinterpret_cast<const float4*>(src + 128);
+        *reinterpret_cast<float4*>(Vs + j * 32 + 4 * c4) = *reinterpret_cast<const float4*>(src + 256);
+    }
+    for (int j = threadIdx.x; j < L; j += 256) Ms[j] = a.mask[rowb + j];
+    __syncthreads();
+    const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float q[32], acc[32];
+        const float* qsrc = a.qkv + (rowb + i) * 384 + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float4 t = *reinterpret_cast<const float4*>(qsrc + 4 * c);
+            q[4 * c] = t.x * scale; q[4 * c + 1] = t.y * scale; q[4 * c + 2] = t.z * scale; q[4 * c + 3] = t.w * scale;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+        float m = -3.0e38f, l = 0.f;
+        for (int j = 0; j < L; ++j) {
+            if (Ms[j] < 0.5f) continue;          // key padding (uniform across the workgroup)
+            const float* kj = Ks + j * 32;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) s += q[c] * kj[c];
+            const float mn = fmaxf(m, s);
+            const float corr = expf(m - mn);
+            const float pj = expf(s - mn);
+            l = l * corr + pj;
+            const float* vj = Vs + j * 32;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc[c] = acc[c] * corr + pj * vj[c];
+            m = mn;
+        }
+        const float inv = 1.f / l;
+        float* dst = a.out + (rowb + i) * 128 + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            *reinterpret_cast<float4*>(dst + 4 * c) =
+                make_float4(acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rot -> quat (rigid_utils.py:208-227): top eigenvector of K/3.  For a rotation the spectrum of
+// K/3 is {1, -1/3, -1/3, -1/3}; power iteration on (K/3 + I/3) (spectrum {4/3, 0, 0, 0})
+// started from the closed-form (Shepperd) quaternion converges to fp32 in one or two steps and,
+// unlike the closed form alone, returns the eigenvector of K itself when R is only orthonormal to
+// ~1e-5 (frames from construct_3d_basis).  Sign is arbitrary, as with eigh.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rot_to_quat_dev(const float* R, float* q) {
+    const float xx = R[0], xy = R[1], xz = R[2], yx = R[3], yy = R[4], yz = R[5], zx = R[6], zy = R[7], zz = R[8];
+    float K[4][4] = {
+        {xx + yy + zz, zy - yz, xz - zx, yx - xy},
+        {zy - yz, xx - yy - zz, xy + yx, xz + zx},
+        {xz - zx, xy + yx, yy - xx - zz, yz + zy},
+        {yx - xy, xz + zx, yz + zy, zz - xx - yy}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) K[i][j] = K[i][j] * (1.f / 3.f) + (i == j ? (1.f / 3.f) : 0.f);
+    // start vector: column of (K + I/3) with the largest diagonal (never orthogonal to the top eigvec)
+    int best = 0;
+    float bd = K[0][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (K[i][i] > bd) { bd = K[i][i]; best = i; }
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = (best == 0) ? K[i][0] : (best == 1) ? K[i][1] : (best == 2) ? K[i][2] : K[i][3];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        float n = rsqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = v[i] * n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = K[i][0] * u[0] + K[i][1] * u[1] + K[i][2] * u[2] + K[i][3] * u[3];
+    }
+    float n = rsqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = v[i] * n;
+}
+
+__global__ __launch_bounds__(256) void rot_to_quat_kernel(const float* rot, float* quat, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float R[9], q[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rot[(size_t)i * 9 + k];
+    rot_to_quat_dev(R, q);
+    *reinterpret_cast<float4*>(quat + (size_t)i * 4) = make_float4(q[0], q[1], q[2], q[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rigid.compose_q_update_vec (rigid_utils.py:1039-1063): q' = normalise(q + m q(x)(0,u)),
+// x' = x + m R_old v, R' = quat_to_rot(q') (185-205).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rigid_update_kernel(pf_rigid_update_args p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const float4 q = *reinterpret_cast<const float4*>(p.quat_in + (size_t)i * 4);
+    const float* u = p.upd + (size_t)i * p.ldu;
+    const float m = p.mask[i];
+    const float a = q.x, b = q.y, c = q.z, d = q.w;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float na = a + m * (-b * ux - c * uy - d * uz);
+    float nb = b + m * (a * ux + c * uz - d * uy);
+    float nc = c + m * (a * uy - b * uz + d * ux);
+    float nd = d + m * (a * uz + b * uy - c * ux);
+    const float inv = 1.f / sqrtf(na * na + nb * nb + nc * nc + nd * nd);
+    na *= inv; nb *= inv; nc *= inv; nd *= inv;
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = p.rot_in[(size_t)i * 9 + k];
+    const float vx = u[3], vy = u[4], vz = u[5];
+    const float tx = p.trans_in[(size_t)i * 3 + 0] + m * (R[0] * vx + R[1] * vy + R[2] * vz);
+    const float ty = p.trans_in[(size_t)i * 3 + 1] + m * (R[3] * vx + R[4] * vy + R[5] * vz);
+    const float tz = p.trans_in[(size_t)i * 3 + 2] + m * (R[6] * vx + R[7] * vy + R[8] * vz);
+    *reinterpret_cast<float4*>(p.quat_out + (size_t)i * 4) = make_float4(na, nb, nc, nd);
+    p.trans_out[(size_t)i * 3 + 0] = tx;
+    p.trans_out[(size_t)i * 3 + 1] = ty;
+    p.trans_out[(size_t)i * 3 + 2] = tz;
+    float* Ro = p.rot_out + (size_t)i * 9;
+    Ro[0] = na * na + nb * nb - nc * nc - nd * nd; Ro[1] = 2.f * (nb * nc - na * nd); Ro[2] = 2.f * (nb * nd + na * nc);
+    Ro[3] = 2.f * (nb * nc + na * nd); Ro[4] = na * na - nb * nb + nc * nc - nd * nd; Ro[5] = 2.f * (nc * nd - na * nb);
+    Ro[6] = 2.f * (nb * nd - na * nc); Ro[7] = 2.f * (nc * nd + na * nb); Ro[8] = na * na - nb * nb - nc * nc + nd * nd;
+}
+
+}  // namespace
+
+extern "C" int pf_embed_inputs_fwd(const pf_embed_args* a, pf_stream_t stream) {
+    if (!a || !a->node_embed || !a->seq_table || !a->seqs || !a->t || !a->time_freq || !a->ang_freq || !a->angles ||
+        !a->out || a->B <= 0 || a->L <= 0)
+        return PF_E_BADARG;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(a->B * a->L)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream) {
+    if (!a || !a->qkv || !a->mask || !a->out || a->B <= 0 || a->L <= 0) return PF_E_BADARG;
+    const size_t lds = ((size_t)a->L * 65) * sizeof(float);
+    if (lds > 160 * 1024) return PF_E_TOOLARGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)seq_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(seq_attn_kernel, dim3((unsigned)(a->B * 4)), dim3(256), lds, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_rot_to_quat(const float* rot, float* quat, int n, pf_stream_t stream) {
+    if (!rot || !quat || n <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(rot_to_quat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rot, quat, n);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_rigid_update_fwd(const pf_rigid_update_args* a, pf_stream_t stream) {
+    if (!a || !a->quat_in || !a->rot_in || !a->trans_in || !a->upd || !a->mask || !a->quat_out || !a->rot_out ||
+        !a->trans_out || a->n <= 0 || a->ldu < 6)
+        return PF_E_BADARG;
+    hipLaunchKernelGGL(rigid_update_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,253 @@
+"""DenoiseEngine: one denoise step (GAEncoder.forward, models_con/ga.py:87-127) as a fixed
+sequence of hand-written HIP kernel launches over preallocated HBM workspaces.
+
+The engine is built once per (B, L, device): every kernel-argument struct is created up front
+with stable device pointers, so a step is just `for fn, args in plan: fn(args, stream)` and the
+whole step can be captured into one hipGraph and replayed (pepflowww_amd/sampler.py).
+
+PyTorch is used here for device memory only (torch.empty / slicing / one-time weight packing);
+all arithmetic of the step runs in libpepflow_hip.so.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _capi
+
+N_BLOCKS = 6
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class PackedWeights:
+    """Kernel-friendly views/copies of the GAEncoder parameters (reference state_dict layout).
+
+    Most tensors are used in place (zero-copy).  Packed copies: the IPA projection weights of a
+    block concatenated to one [3744,128] matrix (one GEMM instead of four), mixer.0 padded from
+    K=629 to 640 (MFMA K granularity), and the per-residue part of EdgeTransition split out of
+    trunk.0 / final_layer (see pf_edge_transition_fwd)."""
+
+    def __init__(self, sd, device):
+        g = lambda k: _f32(sd["ga_encoder." + k]).to(device)
+        self.t = {}
+        t = self.t
+        w0 = g("res_feat_mixer.0.weight")
+        t["mix0.w"] = torch.nn.functional.pad(w0, (0, 640 - w0.shape[1])).contiguous()
+        t["mix0.b"] = g("res_feat_mixer.0.bias")
+        t["mix2.w"], t["mix2.b"] = g("res_feat_mixer.2.weight"), g("res_feat_mixer.2.bias")
+        t["seq_table"] = g("current_seq_embedder.weight")
+        t["ang_freq"] = g("angles_embedder.freq_bands")
+        half = 64
+        freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(2056) / (half - 1)))
+        t["time_freq"] = freq.to(device)
+        for net in ("seq_net", "angle_net"):
+            for i in (0, 2, 4):
+                t[f"{net}.{i}.w"], t[f"{net}.{i}.b"] = g(f"{net}.{i}.weight"), g(f"{net}.{i}.bias")
+        for b in range(N_BLOCKS):
+            p = f"trunk.ipa_{b}."
+            t[f"{b}.proj.w"] = torch.cat([g(p + "linear_q.weight"), g(p + "linear_kv.weight"),
+                                          g(p + "linear_q_points.weight"), g(p + "linear_kv_points.weight")], 0).contiguous()
+            t[f"{b}.proj.b"] = torch.cat([g(p + "linear_q.bias"), g(p + "linear_kv.bias"),
+                                          g(p + "linear_q_points.bias"), g(p + "linear_kv_points.bias")], 0).contiguous()
+            for nm in ("linear_b", "down_z", "linear_out"):
+                t[f"{b}.{nm}.w"], t[f"{b}.{nm}.b"] = g(p + nm + ".weight"), g(p + nm + ".bias")
+            t[f"{b}.head_w"] = g(p + "head_weights")
+            t[f"{b}.ipa_ln.w"], t[f"{b}.ipa_ln.b"] = g(f"trunk.ipa_ln_{b}.weight"), g(f"trunk.ipa_ln_{b}.bias")
+            for l in range(2):
+                q = f"trunk.seq_tfmr_{b}.layers.{l}."
+                t[f"{b}.{l}.in.w"], t[f"{b}.{l}.in.b"] = g(q + "self_attn.in_proj_weight"), g(q + "self_attn.in_proj_bias")
+                t[f"{b}.{l}.out.w"], t[f"{b}.{l}.out.b"] = g(q + "self_attn.out_proj.weight"), g(q + "self_attn.out_proj.bias")
+                for nm in ("linear1", "linear2", "norm1", "norm2"):
+                    t[f"{b}.{l}.{nm}.w"], t[f"{b}.{l}.{nm}.b"] = g(q + nm + ".weight"), g(q + nm + ".bias")
+            t[f"{b}.post.w"], t[f"{b}.post.b"] = g(f"trunk.post_tfmr_{b}.weight"), g(f"trunk.post_tfmr_{b}.bias")
+            q = f"trunk.node_transition_{b}."
+            for nm in ("linear_1", "linear_2", "linear_3", "ln"):
+                t[f"{b}.nt.{nm}.w"], t[f"{b}.nt.{nm}.b"] = g(q + nm + ".weight"), g(q + nm + ".bias")
+            t[f"{b}.bb.w"], t[f"{b}.bb.b"] = g(f"trunk.bb_update_{b}.linear.weight"), g(f"trunk.bb_update_{b}.linear.bias")
+            if b < N_BLOCKS - 1:
+                q = f"trunk.edge_transition_{b}."
+                t[f"{b}.et.init.w"], t[f"{b}.et.init.b"] = g(q + "initial_embed.weight"), g(q + "initial_embed.bias")
+                w1, b1 = g(q + "trunk.0.weight"), g(q + "trunk.0.bias")
+                wf, bf = g(q + "final_layer.weight"), g(q + "final_layer.bias")
+                t[f"{b}.et.w1"], t[f"{b}.et.wf"] = w1, wf
+                t[f"{b}.et.w2"], t[f"{b}.et.b2"] = g(q + "trunk.2.weight"), g(q + "trunk.2.bias")
+                t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
+                t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
+                t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+
+class DenoiseEngine:
+    def __init__(self, weights, B, L, device):
+        self.lib = _capi.load()
+        self.w = weights
+        self.B, self.L, self.device = B, L, device
+        rows = B * L
+        self.rows = rows
+        e = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
+        # inputs (stable storage: callers copy into these, or the sampler updates them in place)
+        self.t = e(B)
+        self.rot_t, self.trans_t, self.ang_t = e(rows, 9), e(rows, 3), e(rows, 5)
+        self.seq_t = e(rows, dt=torch.int64)
+        self.node_embed = e(rows, 128)
+        self.edge_embed = None                 # bound by bind_context (zero-copy, [B,L,L,64])
+        self.mask = e(rows)
+        # workspaces
+        self.feat = e(rows, 640)
+        self.s, self.u, self.v, self.ta, self.tb = (e(rows, 128) for _ in range(5))
+        self.proj = e(rows, 3744)
+        self.qp, self.kp, self.vp = e(rows, 192), e(rows, 192), e(rows, 288)
+        self.feats = e(rows, 1536)
+        self.qkv, self.att = e(rows, 384), e(rows, 128)
+        self.upd = e(rows, 8)
+        self.quat, self.rot, self.trans = e(rows, 4), e(rows, 9), e(rows, 3)
+        self.n64, self.pre = e(rows, 64), e(rows, 512)
+        self.zbuf = e(B, L, L, 64)
+        self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
+        self._keep = []
+        self.plan = None
+
+    # ---- plan construction -------------------------------------------------------------------
+    def _linear(self, x, w, b, y, N, K, relu=False, mask_pre=False, mask_post=False, residual=None, ln=None):
+        a = _capi.LinearArgs()
+        a.x, a.ldx = x.data_ptr(), x.shape[1]
+        a.w, a.ldw = w.data_ptr(), w.shape[1]
+        a.bias = b.data_ptr() if b is not None else None
+        a.y, a.ldy = y.data_ptr(), y.shape[1]
+        a.M, a.N, a.K = self.rows, N, K
+        a.relu = int(relu)
+        a.row_mask = self.mask.data_ptr() if (mask_pre or mask_post) else None
+        a.mask_pre, a.mask_post = int(mask_pre), int(mask_post)
+        if residual is not None:
+            a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
+        if ln is not None:
+            a.ln_gamma, a.ln_beta, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), 1e-5
+        self._keep.append(a)
+        return (self.lib.pf_linear_fwd, C.byref(a), "pf_linear_fwd")
+
+    def bind_context(self, node_embed, edge_embed, res_mask):
+        """Per-call context: node_embed / mask are copied (small); edge_embed is used zero-copy."""
+        B, L = self.B, self.L
+        self.node_embed.copy_(node_embed.reshape(B * L, 128))
+        self.mask.copy_(res_mask.reshape(B * L).to(torch.float32))
+        ee = edge_embed
+        if ee.dtype != torch.float32 or not ee.is_contiguous():
+            ee = ee.to(torch.float32).contiguous()
+        _capi.dptr(ee, name="edge_embed")
+        rebuild = self.plan is None or self.edge_embed is None or self.edge_embed.data_ptr() != ee.data_ptr()
+        self.edge_embed = ee
+        if rebuild:
+            self._build_plan()
+
+    def _build_plan(self):
+        w, lib = self.w, self.lib
+        self._keep = []
+        plan = []
+        B, L, rows = self.B, self.L, self.rows
+        lin = self._linear
+
+        ea = _capi.EmbedArgs()
+        ea.node_embed, ea.seq_table, ea.seqs = self.node_embed.data_ptr(), w["seq_table"].data_ptr(), self.seq_t.data_ptr()
+        ea.t, ea.time_freq, ea.ang_freq = self.t.data_ptr(), w["time_freq"].data_ptr(), w["ang_freq"].data_ptr()
+        ea.angles, ea.out, ea.B, ea.L = self.ang_t.data_ptr(), self.feat.data_ptr(), B, L
+        self._keep.append(ea)
+        plan.append((lib.pf_embed_inputs_fwd, C.byref(ea), "pf_embed_inputs_fwd"))
+        plan.append(lin(self.feat, w["mix0.w"], w["mix0.b"], self.ta, 128, 640, relu=True))
+        plan.append(lin(self.ta, w["mix2.w"], w["mix2.b"], self.s, 128, 128, mask_pre=True))
+        plan.append((lib.pf_rot_to_quat, (self.rot_t.data_ptr(), self.quat.data_ptr(), rows), "pf_rot_to_quat"))
+
+        for b in range(N_BLOCKS):
+            rot = self.rot_t if b == 0 else self.rot
+            trans = self.trans_t if b == 0 else self.trans
+            z_in = self.edge_embed if b == 0 else self.zbuf
+            plan.append(lin(self.s, w[f"{b}.proj.w"], w[f"{b}.proj.b"], self.proj, 3744, 128))
+            pa = _capi.IpaPointsArgs()
+            pa.proj, pa.ldp, pa.rot, pa.trans = self.proj.data_ptr(), 3744, rot.data_ptr(), trans.data_ptr()
+            pa.qp, pa.kp, pa.vp, pa.rows = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr(), rows
+            self._keep.append(pa)
+            plan.append((lib.pf_ipa_points_fwd, C.byref(pa), "pf_ipa_points_fwd"))
+            ia = _capi.IpaAttnArgs()
+            ia.proj, ia.ldp = self.proj.data_ptr(), 3744
+            ia.qp, ia.kp, ia.vp = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr()
+            ia.z, ia.rot, ia.trans, ia.mask = z_in.data_ptr(), rot.data_ptr(), trans.data_ptr(), self.mask.data_ptr()
+            ia.w_b, ia.b_b = w[f"{b}.linear_b.w"].data_ptr(), w[f"{b}.linear_b.b"].data_ptr()
+            ia.w_dz, ia.b_dz = w[f"{b}.down_z.w"].data_ptr(), w[f"{b}.down_z.b"].data_ptr()
+            ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
+            self._keep.append(ia)
+            plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
+            # s = LN(s + mask * linear_out(feats))                                   ga.py:103-104
+            plan.append(lin(self.feats, w[f"{b}.linear_out.w"], w[f"{b}.linear_out.b"], self.s, 128, 1536,
+                            mask_pre=True, residual=self.s, ln=(w[f"{b}.ipa_ln.w"], w[f"{b}.ipa_ln.b"])))
+            # 2-layer post-LN transformer encoder over the residue axis             ga.py:105-106
+            src = self.s
+            for l in range(2):
+                plan.append(lin(src, w[f"{b}.{l}.in.w"], w[f"{b}.{l}.in.b"], self.qkv, 384, 128))
+                sa = _capi.SeqAttnArgs()
+                sa.qkv, sa.mask, sa.out, sa.B, sa.L = self.qkv.data_ptr(), self.mask.data_ptr(), self.att.data_ptr(), B, L
+                self._keep.append(sa)
+                plan.append((lib.pf_seq_attn_fwd, C.byref(sa), "pf_seq_attn_fwd"))
+                plan.append(lin(self.att, w[f"{b}.{l}.out.w"], w[f"{b}.{l}.out.b"], self.u, 128, 128,
+                                residual=src, ln=(w[f"{b}.{l}.norm1.w"], w[f"{b}.{l}.norm1.b"])))
+                plan.append(lin(self.u, w[f"{b}.{l}.linear1.w"], w[f"{b}.{l}.linear1.b"], self.ta, 128, 128, relu=True))
+                plan.append(lin(self.ta, w[f"{b}.{l}.linear2.w"], w[f"{b}.{l}.linear2.b"], self.v, 128, 128,
+                                residual=self.u, ln=(w[f"{b}.{l}.norm2.w"], w[f"{b}.{l}.norm2.b"])))
+                src = self.v
+            plan.append(lin(self.v, w[f"{b}.post.w"], w[f"{b}.post.b"], self.s, 128, 128, residual=self.s))   # ga.py:107
+            # node transition + mask                                                 ga.py:108-109
+            plan.append(lin(self.s, w[f"{b}.nt.linear_1.w"], w[f"{b}.nt.linear_1.b"], self.ta, 128, 128, relu=True))
+            plan.append(lin(self.ta, w[f"{b}.nt.linear_2.w"], w[f"{b}.nt.linear_2.b"], self.tb, 128, 128, relu=True))
+            plan.append(lin(self.tb, w[f"{b}.nt.linear_3.w"], w[f"{b}.nt.linear_3.b"], self.s, 128, 128,
+                            residual=self.s, ln=(w[f"{b}.nt.ln.w"], w[f"{b}.nt.ln.b"]), mask_post=True))
+            # backbone update                                                         ga.py:110-113
+            plan.append(lin(self.s, w[f"{b}.bb.w"], w[f"{b}.bb.b"], self.upd, 6, 128))
+            ra = _capi.RigidUpdateArgs()
+            ra.quat_in, ra.rot_in, ra.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
+            ra.upd, ra.ldu, ra.mask = self.upd.data_ptr(), 8, self.mask.data_ptr()
+            ra.quat_out, ra.rot_out, ra.trans_out, ra.n = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr(), rows
+            self._keep.append(ra)
+            plan.append((lib.pf_rigid_update_fwd, C.byref(ra), "pf_rigid_update_fwd"))
+            if b < N_BLOCKS - 1:                                                     # ga.py:115-118
+                plan.append(lin(self.s, w[f"{b}.et.init.w"], w[f"{b}.et.init.b"], self.n64, 64, 128))
+                plan.append(lin(self.n64, w[f"{b}.et.pre.w"], w[f"{b}.et.pre.b"], self.pre, 512, 64))
+                et = _capi.EdgeTransitionArgs()
+                et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
+                et.w1, et.w2, et.b2 = w[f"{b}.et.w1"].data_ptr(), w[f"{b}.et.w2"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
+                et.wf, et.ln_g, et.ln_b = w[f"{b}.et.wf"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
+                et.mask, et.B, et.L = self.mask.data_ptr(), B, L
+                self._keep.append(et)
+                plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
+        # heads                                                                        ga.py:123-124
+        for net, out, n in (("seq_net", self.logits, 20), ("angle_net", self.ang_raw, 5)):
+            plan.append(lin(self.s, w[f"{net}.0.w"], w[f"{net}.0.b"], self.ta, 128, 128, relu=True))
+            plan.append(lin(self.ta, w[f"{net}.2.w"], w[f"{net}.2.b"], self.tb, 128, 128, relu=True))
+            plan.append(lin(self.tb, w[f"{net}.4.w"], w[f"{net}.4.b"], out, n, 128))
+        self.plan = plan
+
+    # ---- execution ---------------------------------------------------------------------------
+    def set_state(self, t, rotmats_t, trans_t, angles_t, seqs_t):
+        rows = self.rows
+        self.t.copy_(t.reshape(self.B).to(torch.float32))
+        self.rot_t.copy_(rotmats_t.reshape(rows, 9).to(torch.float32))
+        self.trans_t.copy_(trans_t.reshape(rows, 3))
+        self.ang_t.copy_(angles_t.reshape(rows, 5))
+        self.seq_t.copy_(seqs_t.reshape(rows))
+
+    def run(self, stream=None):
+        """Launch the whole step on `stream` (default: torch's current stream)."""
+        st = stream if stream is not None else _capi.stream_ptr()
+        for fn, args, name in self.plan:
+            if isinstance(args, tuple):
+                rc = fn(*args, st)
+            else:
+                rc = fn(args, st)
+            if rc != 0:
+                _capi.check(rc, name)
+
+    @property
+    def n_launches(self):
+        return len(self.plan)

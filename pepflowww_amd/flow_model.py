@@ -1,0 +1,66 @@
+"""FlowModel: drop-in for models_con/flow_model.py:59 (same constructor, sub-module names,
+state_dict layout, `sample()` signature and return format) running on hand-written gfx950
+kernels.  See INTEGRATION.md for how train.py / inference.py pick it up.
+"""
+import torch
+from torch import nn
+
+from . import _capi, featurize
+from .modules import EdgeEmbedder, GAEncoder, NodeEmbedder
+from .sampler import DeviceSampler, default_noise
+
+MAX_NUM_HEAVYATOMS = 15     # pepflow/modules/protein/constants.py:91
+
+
+class FlowModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self._model_cfg = cfg.encoder
+        self._interpolant_cfg = cfg.interpolant
+        self.node_embedder = NodeEmbedder(cfg.encoder.node_embed_size, MAX_NUM_HEAVYATOMS)
+        self.edge_embedder = EdgeEmbedder(cfg.encoder.edge_embed_size, MAX_NUM_HEAVYATOMS)
+        self.ga_encoder = GAEncoder(cfg.encoder.ipa)
+        self.sample_structure = self._interpolant_cfg.sample_structure
+        self.sample_sequence = self._interpolant_cfg.sample_sequence
+        self.K = self._interpolant_cfg.seqs.num_classes
+        self.k = self._interpolant_cfg.seqs.simplex_value
+        assert self.K == 20 and float(self.k) == 5.0, "sampler kernels are specialised to learn_angle.yaml:30-31"
+
+    # ---- flow_model.py:75-93 ----
+    def encode(self, batch):
+        _capi.dptr(batch["pos_heavyatom"].contiguous(), name="batch['pos_heavyatom']")
+        return featurize.encode(self, batch)
+
+    def forward(self, batch):
+        raise _capi.PepflowHipError(
+            "FlowModel.forward (training losses + backward, flow_model.py:111-227) is the next row of the "
+            "scope table (SURVEY.md 8(f) rank 1) and is not built in this round; sample() is.")
+
+    # ---- flow_model.py:229-374 ----
+    @torch.no_grad()
+    def sample(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
+               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False):
+        """Reference signature + keyword-only extensions:
+        noise        dict(rot0, trans0, ang0, simplex0[, expo]) of pre-drawn noise (parity tests);
+        seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator);
+        first_sample global index of this shard's first sample (world-size independent RNG streams);
+        use_graph    replay one captured hipGraph per step (default) or launch eagerly."""
+        _capi.load()
+        dev = batch["aa"].device
+        B, L = batch["aa"].shape
+        R1, x1, ang1, seq1, node, edge = self.encode(batch)
+        eng = self.ga_encoder.engine(B, L, dev)
+        eng.bind_context(node, edge, batch["res_mask"])
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        smp = DeviceSampler(eng, num_steps, (sample_bb, sample_ang, sample_seq), first_sample, seed)
+        smp.set_context(R1, x1, ang1, seq1, batch["generate_mask"])
+        if noise is None:
+            noise = default_noise(B, L)
+        # eager warm-up of the network plan (kernel attribute setup happens outside graph capture)
+        eng.run()
+        smp.init_state(noise)
+        smp.run(num_steps, use_graph=use_graph)
+        if return_sampler:
+            return smp
+        return smp.trajectory()

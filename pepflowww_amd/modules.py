@@ -1,0 +1,221 @@
+"""nn.Module tree with the reference's parameter names and shapes (checkpoint compatible:
+`state_dict()` keys == the reference's, see tests/golden/state_dict_layout.json and
+SURVEY.md 8(b)).  The modules are parameter containers + thin launch wrappers: arithmetic
+happens in libpepflow_hip.so through pepflowww_amd.engine / pepflowww_amd.sampler.
+
+Reference classes mirrored (paths relative to /root/reference):
+  Linear, StructureModuleTransition, EdgeTransition, InvariantPointAttention, BackboneUpdate
+      models_con/ipa_pytorch.py:116-248, 251-314, 544-572
+  GAEncoder            models_con/ga.py:15-127
+  NodeEmbedder         models_con/node.py:9-33
+  EdgeEmbedder         models_con/edge.py:11-37
+  AngularEncoding      pepflow/modules/common/layers.py:92-113
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _capi
+from .engine import DenoiseEngine, PackedWeights
+
+
+def _trunc_normal_(w, scale, fan):
+    # ipa_pytorch.py:64-75: std = sqrt(scale/fan_in) / std(truncnorm(-2,2))
+    std = math.sqrt(scale / max(1, fan)) / 0.87962566103423978
+    nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std)
+
+
+class Linear(nn.Linear):
+    """ipa_pytorch.Linear (116-181): nn.Linear with the AF2 initialisers."""
+
+    def __init__(self, in_dim, out_dim, bias=True, init="default"):
+        super().__init__(in_dim, out_dim, bias=bias)
+        with torch.no_grad():
+            if bias:
+                self.bias.zero_()
+            if init == "default":
+                _trunc_normal_(self.weight, 1.0, in_dim)
+            elif init == "relu":
+                _trunc_normal_(self.weight, 2.0, in_dim)
+            elif init == "final":
+                self.weight.zero_()
+            else:
+                raise ValueError("Invalid init string.")
+
+    def forward(self, x):
+        raise _capi.PepflowHipError("Linear is executed inside the fused HIP denoise step; call GAEncoder / FlowModel")
+
+
+class AngularEncoding(nn.Module):
+    def __init__(self, num_funcs=3):
+        super().__init__()
+        self.num_funcs = num_funcs
+        self.register_buffer("freq_bands", torch.FloatTensor(
+            [i + 1 for i in range(num_funcs)] + [1.0 / (i + 1) for i in range(num_funcs)]))
+
+    def get_out_dim(self, in_dim):
+        return in_dim * (1 + 4 * self.num_funcs)
+
+
+def _mlp(dims, final_act=False):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2 or final_act:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class StructureModuleTransition(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.linear_1 = Linear(c, c, init="relu")
+        self.linear_2 = Linear(c, c, init="relu")
+        self.linear_3 = Linear(c, c, init="final")
+        self.ln = nn.LayerNorm(c)
+
+
+class EdgeTransition(nn.Module):
+    def __init__(self, *, node_embed_size, edge_embed_in, edge_embed_out, num_layers=2, node_dilation=2):
+        super().__init__()
+        bias_embed = node_embed_size // node_dilation
+        self.initial_embed = Linear(node_embed_size, bias_embed, init="relu")
+        hidden = bias_embed * 2 + edge_embed_in
+        layers = []
+        for _ in range(num_layers):
+            layers += [Linear(hidden, hidden, init="relu"), nn.ReLU()]
+        self.trunk = nn.Sequential(*layers)
+        self.final_layer = Linear(hidden, edge_embed_out, init="final")
+        self.layer_norm = nn.LayerNorm(edge_embed_out)
+
+
+class InvariantPointAttention(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        hc = conf.c_hidden * conf.no_heads
+        self.linear_q = Linear(conf.c_s, hc)
+        self.linear_kv = Linear(conf.c_s, 2 * hc)
+        self.linear_q_points = Linear(conf.c_s, conf.no_heads * conf.no_qk_points * 3)
+        self.linear_kv_points = Linear(conf.c_s, conf.no_heads * (conf.no_qk_points + conf.no_v_points) * 3)
+        self.linear_b = Linear(conf.c_z, conf.no_heads)
+        self.down_z = Linear(conf.c_z, conf.c_z // 4)
+        self.head_weights = nn.Parameter(torch.full((conf.no_heads,), 0.541324854612918))
+        self.linear_out = Linear(conf.no_heads * (conf.c_z // 4 + conf.c_hidden + conf.no_v_points * 4), conf.c_s, init="final")
+
+
+class BackboneUpdate(nn.Module):
+    def __init__(self, c_s):
+        super().__init__()
+        self.linear = Linear(c_s, 6, init="final")
+
+
+class _SelfAttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayerParams(nn.Module):
+    """Parameter layout of torch.nn.TransformerEncoderLayer(d, nhead, dim_feedforward=d) (ga.py:53-60)."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _SelfAttnParams(d)
+        self.linear1 = nn.Linear(d, d)
+        self.linear2 = nn.Linear(d, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class _EncoderParams(nn.Module):
+    def __init__(self, d, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayerParams(d) for _ in range(n_layers)])
+
+
+class GAEncoder(nn.Module):
+    """models_con/ga.py:15.  forward() = one denoise step on the HIP engine."""
+
+    def __init__(self, ipa_conf):
+        super().__init__()
+        self._ipa_conf = ipa_conf
+        c = ipa_conf.c_s
+        assert (c, ipa_conf.c_z, ipa_conf.c_hidden, ipa_conf.no_heads, ipa_conf.no_qk_points, ipa_conf.no_v_points,
+                ipa_conf.seq_tfmr_num_heads, ipa_conf.seq_tfmr_num_layers, ipa_conf.num_blocks) == \
+               (128, 64, 128, 8, 8, 12, 4, 2, 6), "kernels are specialised to configs/learn_angle.yaml:3-14"
+        self.angles_embedder = AngularEncoding(num_funcs=12)
+        self.angle_net = _mlp([c, c, c, 5])
+        self.current_seq_embedder = nn.Embedding(22, c)
+        self.seq_net = _mlp([c, c, c, 20])
+        self.res_feat_mixer = _mlp([3 * c + self.angles_embedder.get_out_dim(5), c, c])
+        self.feat_dim = c
+        self.trunk = nn.ModuleDict()
+        for b in range(ipa_conf.num_blocks):
+            self.trunk[f"ipa_{b}"] = InvariantPointAttention(ipa_conf)
+            self.trunk[f"ipa_ln_{b}"] = nn.LayerNorm(c)
+            self.trunk[f"seq_tfmr_{b}"] = _EncoderParams(c, ipa_conf.seq_tfmr_num_layers)
+            self.trunk[f"post_tfmr_{b}"] = Linear(c, c, init="final")
+            self.trunk[f"node_transition_{b}"] = StructureModuleTransition(c)
+            self.trunk[f"bb_update_{b}"] = BackboneUpdate(c)
+            if b < ipa_conf.num_blocks - 1:
+                self.trunk[f"edge_transition_{b}"] = EdgeTransition(
+                    node_embed_size=c, edge_embed_in=ipa_conf.c_z, edge_embed_out=ipa_conf.c_z)
+        self._engine = None
+        self._engine_key = None
+
+    # -- engine cache: rebuilt when shape/device change or any parameter was modified in place --
+    def _param_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self, B, L, device):
+        key = (B, L, str(device), self._param_version())
+        if self._engine is None or self._engine_key != key:
+            sd = {"ga_encoder." + k: v for k, v in self.state_dict().items()}
+            self._engine = DenoiseEngine(PackedWeights(sd, device), B, L, device)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, t, rotmats_t, trans_t, angles_t, seqs_t, node_embed, edge_embed, generate_mask, res_mask):
+        """Same positional signature as the reference (ga.py:87); generate_mask is unused there too."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise _capi.PepflowHipError("backward kernels are not built yet (SURVEY.md 8(f) rank 1): "
+                                        "run the denoise step under torch.no_grad()")
+        B, L = seqs_t.shape
+        _capi.dptr(node_embed.contiguous(), name="node_embed")
+        eng = self.engine(B, L, node_embed.device)
+        eng.bind_context(node_embed, edge_embed, res_mask)
+        eng.set_state(t, rotmats_t, trans_t, angles_t, seqs_t)
+        eng.run()
+        rot = eng.rot.view(B, L, 3, 3).clone()
+        trans = eng.trans.view(B, L, 3).clone()
+        ang = torch.remainder(eng.ang_raw.view(B, L, 5), 2 * math.pi)     # ga.py:125
+        return rot, trans, ang, eng.logits.view(B, L, 20).clone()
+
+
+class NodeEmbedder(nn.Module):
+    def __init__(self, feat_dim, max_num_atoms, max_aa_types=22):
+        super().__init__()
+        self.max_num_atoms, self.max_aa_types, self.feat_dim = max_num_atoms, max_aa_types, feat_dim
+        self.aatype_embed = nn.Embedding(max_aa_types, feat_dim)
+        self.dihed_embed = AngularEncoding()
+        infeat = feat_dim + max_aa_types * max_num_atoms * 3 + self.dihed_embed.get_out_dim(3)
+        self.mlp = _mlp([infeat, feat_dim * 2, feat_dim, feat_dim, feat_dim])
+
+
+class EdgeEmbedder(nn.Module):
+    def __init__(self, feat_dim, max_num_atoms, max_aa_types=22, max_relpos=32):
+        super().__init__()
+        self.max_num_atoms, self.max_aa_types, self.max_relpos = max_num_atoms, max_aa_types, max_relpos
+        self.aa_pair_embed = nn.Embedding(max_aa_types * max_aa_types, feat_dim)
+        self.relpos_embed = nn.Embedding(2 * max_relpos + 1, feat_dim)
+        self.aapair_to_distcoef = nn.Embedding(max_aa_types * max_aa_types, max_num_atoms * max_num_atoms)
+        nn.init.zeros_(self.aapair_to_distcoef.weight)
+        self.distance_embed = _mlp([max_num_atoms * max_num_atoms, feat_dim, feat_dim], final_act=True)
+        self.dihedral_embed = AngularEncoding()
+        infeat = 3 * feat_dim + self.dihedral_embed.get_out_dim(2)
+        self.out_mlp = _mlp([infeat, feat_dim, feat_dim, feat_dim])

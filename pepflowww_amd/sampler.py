@@ -1,0 +1,130 @@
+"""Device-resident Euler sampler (FlowModel.sample loop, flow_model.py:279-374).
+
+The reference syncs with the host nine times per step (`.cpu()` into clean_traj, 313-314) and
+rebuilds `t` on the host every step (288).  Here the whole loop lives on the GPU:
+  * state (R_t, x_t, angles_t, seq_t, simplex_t), the time grid and a step counter are device
+    buffers; one step = DenoiseEngine plan + pf_sampler_step;
+  * that step is captured ONCE into a hipGraph and replayed num_steps times (launch-bound inner
+    loop -> one graph launch per step);
+  * every step's clean prediction is written into [num_steps, ...] trajectory buffers; a single
+    D2H copy at the end produces the reference's list of dicts of CPU tensors.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _capi
+
+
+def default_noise(B, L, generator=None):
+    """Initial noise drawn on the host like the reference's uniform_so3 (pepflow/modules/so3/dist.py:40-45,
+    Haar via normalised Gaussian quaternions) + randn / rand (flow_model.py:255,264,269)."""
+    g = generator
+    q = torch.randn(B, L, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    a, b, c, d = q.unbind(-1)
+    rot = torch.stack([a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c),
+                       2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b),
+                       2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d], -1).reshape(B, L, 3, 3)
+    return {"rot0": rot, "trans0": torch.randn(B, L, 3, generator=g),
+            "ang0": torch.rand(B, L, 5, generator=g) * (2 * math.pi),
+            "simplex0": torch.randn(B, L, 20, generator=g)}
+
+
+class DeviceSampler:
+    def __init__(self, engine, num_steps, flags=(True, True, True), first_sample=0, seed=0):
+        self.eng = engine
+        self.lib = engine.lib
+        self.N = num_steps
+        B, L, dev = engine.B, engine.L, engine.device
+        rows = B * L
+        e = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        self.rot1, self.trans1, self.ang1 = e(rows, 9), e(rows, 3), e(rows, 5)
+        self.seq1 = e(rows, dt=torch.int64)
+        self.gen = e(rows)
+        self.simplex_t, self.trans0, self.simplex0 = e(rows, 20), e(rows, 3), e(rows, 20)
+        self.traj_rot, self.traj_trans = e(num_steps, rows, 9), e(num_steps, rows, 3)
+        self.traj_ang, self.traj_simplex = e(num_steps, rows, 5), e(num_steps, rows, 20)
+        self.traj_seq = e(num_steps, rows, dt=torch.int64)
+        self.ts = torch.linspace(1e-2, 1.0, num_steps).to(dev)          # flow_model.py:280 (built on CPU, then H2D)
+        self.step = e(1, dt=torch.int32)
+        self.expo = None
+        a = _capi.SamplerArgs()
+        a.rot1, a.trans1, a.ang1, a.seq1 = self.rot1.data_ptr(), self.trans1.data_ptr(), self.ang1.data_ptr(), self.seq1.data_ptr()
+        a.gen_mask, a.res_mask = self.gen.data_ptr(), engine.mask.data_ptr()
+        a.rot_t, a.trans_t, a.ang_t, a.seq_t = engine.rot_t.data_ptr(), engine.trans_t.data_ptr(), engine.ang_t.data_ptr(), engine.seq_t.data_ptr()
+        a.simplex_t, a.trans0, a.simplex0 = self.simplex_t.data_ptr(), self.trans0.data_ptr(), self.simplex0.data_ptr()
+        a.pred_rot, a.pred_trans = engine.rot.data_ptr(), engine.trans.data_ptr()
+        a.pred_ang_raw, a.pred_logits = engine.ang_raw.data_ptr(), engine.logits.data_ptr()
+        a.traj_rot, a.traj_trans, a.traj_ang = self.traj_rot.data_ptr(), self.traj_trans.data_ptr(), self.traj_ang.data_ptr()
+        a.traj_seq, a.traj_simplex = self.traj_seq.data_ptr(), self.traj_simplex.data_ptr()
+        a.ts, a.num_steps, a.step, a.t_out = self.ts.data_ptr(), num_steps, self.step.data_ptr(), engine.t.data_ptr()
+        a.expo, a.seed, a.first_sample = None, seed, first_sample
+        a.B, a.L = B, L
+        a.sample_bb, a.sample_ang, a.sample_seq = (int(f) for f in flags)
+        self.args = a
+        self.graph = None
+
+    def set_context(self, R1, x1, ang1, seq1, gen_mask):
+        rows = self.eng.rows
+        self.rot1.copy_(R1.reshape(rows, 9))
+        self.trans1.copy_(x1.reshape(rows, 3))
+        self.ang1.copy_(ang1.reshape(rows, 5))
+        self.seq1.copy_(seq1.reshape(rows))
+        self.gen.copy_(gen_mask.reshape(rows).to(torch.float32))
+
+    def init_state(self, noise):
+        dev, rows = self.eng.device, self.eng.rows
+        up = lambda k, n: noise[k].to(dev, torch.float32).reshape(rows, n).contiguous()
+        rot0, tr0, ang0, sx0 = up("rot0", 9), up("trans0", 3), up("ang0", 5), up("simplex0", 20)
+        if noise.get("expo") is not None:
+            self.expo = noise["expo"].to(dev, torch.float32).contiguous()
+            assert self.expo.shape == (2 * self.N, self.eng.B, self.eng.L, 20), self.expo.shape
+            self.args.expo = self.expo.data_ptr()
+        else:
+            self.expo, self.args.expo = None, None
+        rc = self.lib.pf_sampler_init(C.byref(self.args), rot0.data_ptr(), tr0.data_ptr(), ang0.data_ptr(),
+                                      sx0.data_ptr(), _capi.stream_ptr())
+        _capi.check(rc, "pf_sampler_init")
+        self._init_keep = (rot0, tr0, ang0, sx0)
+
+    def _one_step(self):
+        self.eng.run()
+        rc = self.lib.pf_sampler_step(C.byref(self.args), _capi.stream_ptr())
+        _capi.check(rc, "pf_sampler_step")
+
+    def capture(self):
+        """Capture one step (network + flow update) into a hipGraph.  The engine must have run once
+        eagerly before (first-launch attribute setup must not happen under capture)."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                self._one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = g
+
+    def run(self, n_steps=None, use_graph=True):
+        n = self.N if n_steps is None else n_steps
+        if use_graph and self.graph is None:
+            self.capture()
+        for _ in range(n):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self._one_step()
+
+    def trajectory(self):
+        """One D2H copy -> list of num_steps dicts of CPU tensors (flow_model.py:313-314,371-374)."""
+        B, L, N = self.eng.B, self.eng.L, self.N
+        rot = self.traj_rot.cpu().view(N, B, L, 3, 3)
+        trans = self.traj_trans.cpu().view(N, B, L, 3)
+        ang = self.traj_ang.cpu().view(N, B, L, 5)
+        seq = self.traj_seq.cpu().view(N, B, L)
+        sx = self.traj_simplex.cpu().view(N, B, L, 20)
+        R1, x1 = self.rot1.cpu().view(B, L, 3, 3), self.trans1.cpu().view(B, L, 3)
+        a1, s1 = self.ang1.cpu().view(B, L, 5), self.seq1.cpu().view(B, L)
+        return [{"rotmats": rot[i], "trans": trans[i], "angles": ang[i], "seqs": seq[i], "seqs_simplex": sx[i],
+                 "rotmats_1": R1, "trans_1": x1, "angles_1": a1, "seqs_1": s1} for i in range(N)]

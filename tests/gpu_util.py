@@ -1,0 +1,146 @@
+"""Thin test-side wrappers that call the C-ABI entry points on torch device tensors."""
+import ctypes as C
+
+import torch
+
+from pepflowww_amd import _capi
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def linear(x, w, b=None, relu=False, row_mask=None, mask_pre=False, mask_post=False, residual=None, ln=None, N=None, K=None):
+    lib = _capi.load()
+    M = x.shape[0]
+    N = N or w.shape[0]
+    K = K or w.shape[1]
+    y = torch.full((M, N), float("nan"), device=x.device)
+    a = _capi.LinearArgs()
+    a.x, a.ldx, a.w, a.ldw, a.bias = _p(x), x.shape[1], _p(w), w.shape[1], _p(b)
+    a.y, a.ldy, a.M, a.N, a.K, a.relu = _p(y), N, M, N, K, int(relu)
+    a.row_mask, a.mask_pre, a.mask_post = _p(row_mask), int(mask_pre), int(mask_post)
+    if residual is not None:
+        a.residual, a.ldr = _p(residual), residual.shape[1]
+    if ln is not None:
+        a.ln_gamma, a.ln_beta, a.ln_eps = _p(ln[0]), _p(ln[1]), 1e-5
+    _capi.check(lib.pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
+    sync()
+    return y
+
+
+def so3_geodesic(base, target, t):
+    lib = _capi.load()
+    n = base.numel() // 9
+    out = torch.empty_like(base)
+    _capi.check(lib.pf_so3_geodesic(_p(base), _p(target), _p(t), _p(out), n, _capi.stream_ptr()), "pf_so3_geodesic")
+    sync()
+    return out
+
+
+def so3_log(R):
+    lib = _capi.load()
+    n = R.numel() // 9
+    out = torch.empty(n, 3, device=R.device)
+    _capi.check(lib.pf_so3_log(_p(R), _p(out), n, _capi.stream_ptr()), "pf_so3_log")
+    sync()
+    return out
+
+
+def so3_exp(w):
+    lib = _capi.load()
+    n = w.numel() // 3
+    out = torch.empty(n, 3, 3, device=w.device)
+    _capi.check(lib.pf_so3_exp(_p(w), _p(out), n, _capi.stream_ptr()), "pf_so3_exp")
+    sync()
+    return out
+
+
+def torus_geodesic(base, target, t):
+    lib = _capi.load()
+    out = torch.empty_like(base)
+    _capi.check(lib.pf_torus_geodesic(_p(base), _p(target), _p(t), _p(out), base.numel(), _capi.stream_ptr()), "torus")
+    sync()
+    return out
+
+
+def rot_to_quat(R):
+    lib = _capi.load()
+    n = R.numel() // 9
+    q = torch.empty(n, 4, device=R.device)
+    _capi.check(lib.pf_rot_to_quat(_p(R), _p(q), n, _capi.stream_ptr()), "pf_rot_to_quat")
+    sync()
+    return q
+
+
+def rigid_update(quat, rot, trans, upd, mask):
+    lib = _capi.load()
+    n = quat.shape[0]
+    qo, ro, to = torch.empty_like(quat), torch.empty(n, 9, device=quat.device), torch.empty_like(trans)
+    a = _capi.RigidUpdateArgs()
+    a.quat_in, a.rot_in, a.trans_in, a.upd, a.ldu, a.mask = _p(quat), _p(rot), _p(trans), _p(upd), upd.shape[1], _p(mask)
+    a.quat_out, a.rot_out, a.trans_out, a.n = _p(qo), _p(ro), _p(to), n
+    _capi.check(lib.pf_rigid_update_fwd(C.byref(a), _capi.stream_ptr()), "pf_rigid_update_fwd")
+    sync()
+    return qo, ro, to
+
+
+def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L):
+    lib = _capi.load()
+    rows = B * L
+    d = proj.device
+    qp, kp, vp = torch.empty(rows, 192, device=d), torch.empty(rows, 192, device=d), torch.empty(rows, 288, device=d)
+    pa = _capi.IpaPointsArgs()
+    pa.proj, pa.ldp, pa.rot, pa.trans, pa.qp, pa.kp, pa.vp, pa.rows = _p(proj), proj.shape[1], _p(rot), _p(trans), _p(qp), _p(kp), _p(vp), rows
+    _capi.check(lib.pf_ipa_points_fwd(C.byref(pa), _capi.stream_ptr()), "pf_ipa_points_fwd")
+    feats = torch.full((rows, 1536), float("nan"), device=d)
+    ia = _capi.IpaAttnArgs()
+    ia.proj, ia.ldp, ia.qp, ia.kp, ia.vp, ia.z = _p(proj), proj.shape[1], _p(qp), _p(kp), _p(vp), _p(z)
+    ia.rot, ia.trans, ia.mask = _p(rot), _p(trans), _p(mask)
+    ia.w_b, ia.b_b, ia.w_dz, ia.b_dz, ia.head_w = _p(w_b), _p(b_b), _p(w_dz), _p(b_dz), _p(head_w)
+    ia.feats, ia.B, ia.L = _p(feats), B, L
+    _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
+    sync()
+    return feats, (qp, kp, vp)
+
+
+def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False):
+    lib = _capi.load()
+    out = z if inplace else torch.full_like(z, float("nan"))
+    a = _capi.EdgeTransitionArgs()
+    a.z_in, a.z_out, a.pre, a.w1, a.w2, a.b2, a.wf = _p(z), _p(out), _p(pre), _p(w1), _p(w2), _p(b2), _p(wf)
+    a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
+    _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
+    sync()
+    return out
+
+
+def seq_attn(qkv, mask, B, L):
+    lib = _capi.load()
+    out = torch.full((B * L, 128), float("nan"), device=qkv.device)
+    a = _capi.SeqAttnArgs()
+    a.qkv, a.mask, a.out, a.B, a.L = _p(qkv), _p(mask), _p(out), B, L
+    _capi.check(lib.pf_seq_attn_fwd(C.byref(a), _capi.stream_ptr()), "pf_seq_attn_fwd")
+    sync()
+    return out
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def assert_close(a, b, rel=1e-4, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    e = rel_err(a, b)
+    assert e <= rel, f"{what}: max|a-b|/max|b| = {e:.3e} > {rel:.1e}"

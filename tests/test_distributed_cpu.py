@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests of the multi-GPU host logic (sharding, packing, ragged all-gather)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pepflowww_amd import distributed as D
+from pepflowww_amd import synth
+
+
+def test_shard_bounds_cover_everything():
+    for total in (1, 7, 16, 512):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_pack_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    st = {"rotmats": torch.randn(3, 5, 3, 3, generator=g), "trans": torch.randn(3, 5, 3, generator=g),
+          "angles": torch.rand(3, 5, 5, generator=g), "seqs_simplex": torch.randn(3, 5, 20, generator=g),
+          "seqs": torch.randint(0, 20, (3, 5), generator=g)}
+    back = D.unpack_state(D.pack_state(st))
+    for k in st:
+        assert torch.equal(back[k], st[k]), k
+
+
+def test_noise_shards_match_global_draw():
+    full = synth.make_noise(5, 8, 3, seed=11)
+    lo, hi = D.shard_bounds(5, 2, 1)
+    part = synth.make_noise(hi - lo, 8, 3, seed=11, first_sample=lo)
+    sl = D.shard_noise(full, lo, hi)
+    for k in full:
+        assert torch.equal(sl[k], part[k]), k
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch = synth.make_pocket_batch(total, 12, 4, seed=3)
+        local, lo, hi = D.shard_batch(batch, world, rank)
+        assert local["aa"].shape[0] == hi - lo
+        # each rank fabricates a "final state" that is a pure function of the GLOBAL sample index
+        idx = torch.arange(lo, hi, dtype=torch.float32)
+        st = {"rotmats": idx[:, None, None, None].expand(-1, 12, 3, 3) + 0.25, "trans": idx[:, None, None].expand(-1, 12, 3),
+              "angles": idx[:, None, None].expand(-1, 12, 5) * 0.5, "seqs_simplex": idx[:, None, None].expand(-1, 12, 20),
+              "seqs": local["aa"].clamp(max=19)}
+        sizes = [D.shard_bounds(total, world, r)[1] - D.shard_bounds(total, world, r)[0] for r in range(world)]
+        full = D.unpack_state(D.all_gather_packed(D.pack_state(st), sizes))
+        ok = (full["trans"][:, 0, 0] == torch.arange(total, dtype=torch.float32)).all().item()
+        ok = ok and torch.equal(full["seqs"], batch["aa"].clamp(max=19))
+        ok = ok and full["rotmats"].shape == (total, 12, 3, 3)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4, 5])
+def test_ragged_all_gather_gloo_world2(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
