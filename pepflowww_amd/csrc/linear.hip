@@ -75,38 +75,41 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
         }
     if (!do_ln) return;
     __syncthreads();
-    // LayerNorm over the N (<=128) columns: 256/BM threads per row
-    constexpr int TPR = 256 / BM;                  // threads per row: 16 / 8 / 4
-    constexpr int CPT = BN / TPR;                  // columns per thread
-    const int row = tid / TPR, sub = tid % TPR;
-    const int m = m0 + row;
-    float vals[CPT];
-    float s = 0.f;
+    // LayerNorm over the N (<=128) columns.  ALWAYS 16 threads per row and 8 interleaved columns per thread,
+    // whatever the tile height: the reduction order (hence the bits) must not depend on the batch size.
+    {
+        const int sub = tid & 15;
+        for (int row = tid >> 4; row < BM; row += 16) {
+            const int m = m0 + row;
+            float vals[8];
+            float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        int n = sub + c * TPR;                     // interleaved -> conflict-free LDS reads
-        vals[c] = (n < p.N) ? Ys[row * LDY + n] : 0.f;
-        s += vals[c];
-    }
+            for (int c = 0; c < 8; ++c) {
+                const int n = sub + c * 16;
+                vals[c] = (n < p.N) ? Ys[row * LDY + n] : 0.f;
+                s += vals[c];
+            }
 #pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)p.N;
-    float q = 0.f;
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s / (float)p.N;
+            float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        int n = sub + c * TPR;
-        float d = (n < p.N) ? vals[c] - mean : 0.f;
-        q += d * d;
-    }
+            for (int c = 0; c < 8; ++c) {
+                const int n = sub + c * 16;
+                const float d = (n < p.N) ? vals[c] - mean : 0.f;
+                q += d * d;
+            }
 #pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = rsqrtf(q / (float)p.N + p.ln_eps);
-    if (m < p.M) {
-        const float mk = p.mask_post ? p.row_mask[m] : 1.f;
+            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q / (float)p.N + p.ln_eps);
+            if (m < p.M) {
+                const float mk = p.mask_post ? p.row_mask[m] : 1.f;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            int n = sub + c * TPR;
-            if (n < p.N) p.y[(size_t)m * p.ldy + n] = ((vals[c] - mean) * rstd * p.ln_gamma[n] + p.ln_beta[n]) * mk;
+                for (int c = 0; c < 8; ++c) {
+                    const int n = sub + c * 16;
+                    if (n < p.N) p.y[(size_t)m * p.ldy + n] = ((vals[c] - mean) * rstd * p.ln_gamma[n] + p.ln_beta[n]) * mk;
+                }
+            }
         }
     }
 }

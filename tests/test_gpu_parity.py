@@ -66,7 +66,8 @@ def test_mfma_fragment_layout():
     for K in (16, 64, 192):
         a, b = torch.randn(16, K, generator=g), torch.randn(16, K, generator=g)
         c = torch.full((16, 16), float("nan"), device=G.dev())
-        _capi.check(lib.pf_selftest_mfma(cu(a).data_ptr(), cu(b).data_ptr(), c.data_ptr(), K, _capi.stream_ptr()), "selftest")
+        da, db = cu(a), cu(b)        # keep the device tensors alive across the launch
+        _capi.check(lib.pf_selftest_mfma(da.data_ptr(), db.data_ptr(), c.data_ptr(), K, _capi.stream_ptr()), "selftest")
         G.sync()
         G.assert_close(c, a @ b.T, 2e-6, f"mfma K={K}")
 
