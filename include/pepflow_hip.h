@@ -160,6 +160,45 @@ typedef struct {
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 
+/* ---- encode(): once-per-call context featurisation (FlowModel.encode, flow_model.py:75-93) -------
+ * node features: NodeEmbedder.forward up to the MLP input (node.py:35-99): aa embedding, per-aa-type
+ * local heavy-atom coordinates, backbone dihedral code; plus the ground-truth frames
+ * construct_3d_basis(CA, C, N) (geometry.py:89-111).  feat row = 1157 values padded to 1168;
+ * the 4-layer MLP (node.py:20-25,101-102) then runs through pf_linear_fwd. */
+typedef struct {
+    const int64_t* aa; const int64_t* res_nb; const int64_t* chain_nb;  /* [B*L] */
+    const float* pos;          /* [B*L,15,3] */
+    const float* mask_atoms;   /* [B*L,15] 0/1 */
+    const float* gen_mask;     /* [B*L] */
+    const float* aa_table;     /* node_embedder.aatype_embed.weight [22,128] */
+    const float* freq3;        /* dihed_embed.freq_bands [6] */
+    float* feat;               /* [B*L,1168] */
+    float* rot1; float* trans1;/* [B*L,9], [B*L,3] ground-truth frames */
+    float* mres; float* ctx;   /* [B*L] residue mask (CA present), context mask (CA present & !generate) */
+    int B, L;
+    int sample_structure, sample_sequence;   /* cfg.interpolant flags (flow_model.py:86-87) */
+} pf_node_feat_args;
+int pf_node_features_fwd(const pf_node_feat_args* a, pf_stream_t stream);
+
+/* edge features + all five Linears of EdgeEmbedder.forward (edge.py:39-111) fused; 64 pairs per
+ * workgroup, the [B,L,L,225] distance tensor never leaves LDS.  w_d0 is distance_embed.0.weight
+ * padded to [64,240], w_o0 is out_mlp.0.weight padded to [64,224] (MFMA K granularity). */
+typedef struct {
+    const int64_t* aa; const int64_t* res_nb; const int64_t* chain_nb;
+    const float* pos; const float* mask_atoms;
+    const float* ctx; const float* mres;           /* from pf_node_features_fwd */
+    const float* aapair_table;  /* [484,64] */
+    const float* relpos_table;  /* [65,64] */
+    const float* distcoef;      /* aapair_to_distcoef.weight [484,225] (softplus applied inside) */
+    const float* freq3;         /* dihedral_embed.freq_bands [6] */
+    const float* w_d0; const float* b_d0; const float* w_d2; const float* b_d2;
+    const float* w_o0; const float* b_o0; const float* w_o2; const float* b_o2; const float* w_o4; const float* b_o4;
+    float* out;                 /* [B,L,L,64] */
+    int B, L;
+    int sample_structure, sample_sequence;
+} pf_edge_feat_args;
+int pf_edge_features_fwd(const pf_edge_feat_args* a, pf_stream_t stream);
+
 /* ---- sampler state, flow_model.py:229-374 ------------------------------------------------
  * Device-resident sampler: the loop never syncs with the host.  `step` is a device counter so
  * that one captured hipGraph can be replayed for every step. */

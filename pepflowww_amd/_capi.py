@@ -65,6 +65,20 @@ class SamplerArgs(C.Structure):
                 ("B", _i), ("L", _i), ("sample_bb", _i), ("sample_ang", _i), ("sample_seq", _i)]
 
 
+class NodeFeatArgs(C.Structure):
+    _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("gen_mask", _fp),
+                ("aa_table", _fp), ("freq3", _fp), ("feat", _fp), ("rot1", _fp), ("trans1", _fp), ("mres", _fp),
+                ("ctx", _fp), ("B", _i), ("L", _i), ("sample_structure", _i), ("sample_sequence", _i)]
+
+
+class EdgeFeatArgs(C.Structure):
+    _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("ctx", _fp),
+                ("mres", _fp), ("aapair_table", _fp), ("relpos_table", _fp), ("distcoef", _fp), ("freq3", _fp),
+                ("w_d0", _fp), ("b_d0", _fp), ("w_d2", _fp), ("b_d2", _fp), ("w_o0", _fp), ("b_o0", _fp),
+                ("w_o2", _fp), ("b_o2", _fp), ("w_o4", _fp), ("b_o4", _fp), ("out", _fp), ("B", _i), ("L", _i),
+                ("sample_structure", _i), ("sample_sequence", _i)]
+
+
 _SIGNATURES = {
     "pf_abi_version": ([], _i),
     "pf_selftest_mfma": ([_fp, _fp, _fp, _i, _fp], _i),
@@ -76,6 +90,8 @@ _SIGNATURES = {
     "pf_rot_to_quat": ([_fp, _fp, _i, _fp], _i),
     "pf_rigid_update_fwd": ([C.POINTER(RigidUpdateArgs), _fp], _i),
     "pf_edge_transition_fwd": ([C.POINTER(EdgeTransitionArgs), _fp], _i),
+    "pf_node_features_fwd": ([C.POINTER(NodeFeatArgs), _fp], _i),
+    "pf_edge_features_fwd": ([C.POINTER(EdgeFeatArgs), _fp], _i),
     "pf_sampler_init": ([C.POINTER(SamplerArgs), _fp, _fp, _fp, _fp, _fp], _i),
     "pf_sampler_step": ([C.POINTER(SamplerArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
