@@ -44,43 +44,78 @@ __device__ __forceinline__ void mfma_slice(const float4 (&a)[MT], const float4 (
         }
 }
 
-// acc[MT][NT] += A_lds[16*MT rows][K] * W[n0 .. n0+16*NT)[K]^T   for one wave.
-//   A_lds : LDS, row stride lda floats (multiple of 4), rows 0..16*MT-1, K multiple of 16
-//   W     : global, row-major [N][ldw]; rows >= n_valid read as zero
-// B fragments are prefetched one slice ahead (global/L2 latency hides behind the MFMAs).
+// B-operand stream of one wave: NT column tiles of W ([N][ldw] row-major, rows >= n_valid read as zero),
+// kept PF_DEPTH K-slices (of 16) ahead in registers.  Weights come from L2/MALL with ~1-2 us latency when
+// cold, and the small GEMMs of the node track are pure latency chains unless several slices are in flight,
+// so: prefetch() is called BEFORE the activation tile is staged / the barrier, and the ring is refilled as
+// soon as a slice has been consumed.  All ring indices are compile-time constants (no scratch).
+constexpr int PF_DEPTH = 4;
+
+template <int NT>
+struct BStream {
+    const float* wrow[NT];
+    bool wok[NT];
+    float4 ring[PF_DEPTH][NT];
+    int nslices;
+
+    __device__ __forceinline__ void init(const float* __restrict__ W, int ldw, int n0, int n_valid, int K) {
+        const int lane = threadIdx.x & 63;
+        const int r = lane & 15, g = lane >> 4;
+        nslices = K >> 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + 16 * nt + r;
+            wok[nt] = n < n_valid;
+            wrow[nt] = W + (size_t)(wok[nt] ? n : 0) * ldw + 4 * g;
+        }
+    }
+    __device__ __forceinline__ void load(int slot_static, int slice, float4 (&dst)[NT]) {
+        (void)slot_static;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            dst[nt] = wok[nt] ? *reinterpret_cast<const float4*>(wrow[nt] + 16 * slice) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void prefetch() {
+#pragma unroll
+        for (int d = 0; d < PF_DEPTH; ++d)
+            if (d < nslices) load(d, d, ring[d]);
+    }
+};
+
+// acc[MT][NT] += A_lds[16*MT rows][16*count] * W[:, 16*slice0 ...]^T for one wave; `bs` must have been
+// init()+prefetch()ed and slices [0, slice0) already consumed (slice0 % PF_DEPTH == 0).
+//   A_lds : LDS tile holding K-slices slice0.. as columns 0.., row stride lda floats (multiple of 4)
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_ldsA_stream(const float* __restrict__ A_lds, int lda, BStream<NT>& bs,
+                                                 f32x4 (&acc)[MT][NT], int slice0, int count) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = A_lds + (lane & 15) * lda + 4 * (lane >> 4);
+    const int ns = bs.nslices;
+    for (int base = 0; base < count; base += PF_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < PF_DEPTH; ++u) {
+            if (base + u < count) {
+                const int sl = slice0 + base + u;
+                float4 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    a[mt] = *reinterpret_cast<const float4*>(arow + mt * 16 * lda + 16 * (base + u));
+                mfma_slice<MT, NT>(a, bs.ring[u], acc);
+                if (sl + PF_DEPTH < ns) bs.load(u, sl + PF_DEPTH, bs.ring[u]);
+            }
+        }
+    }
+}
+
+// Convenience form: stream set-up + GEMM in one call (used where nothing can overlap the prefetch).
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_ldsA_glbB(const float* __restrict__ A_lds, int lda,
                                                const float* __restrict__ W, int ldw, int n0, int n_valid,
                                                int K, f32x4 (&acc)[MT][NT]) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
-    const float* wrow[NT];
-    bool wok[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        int n = n0 + 16 * nt + r;
-        wok[nt] = n < n_valid;
-        wrow[nt] = W + (size_t)(wok[nt] ? n : 0) * ldw + 4 * g;
-    }
-    const float* arow = A_lds + r * lda + 4 * g;
-    float4 bcur[NT], bnxt[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-        bcur[nt] = wok[nt] ? *reinterpret_cast<const float4*>(wrow[nt]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        if (k0 + 16 < K) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                bnxt[nt] = wok[nt] ? *reinterpret_cast<const float4*>(wrow[nt] + k0 + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 a[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            a[mt] = *reinterpret_cast<const float4*>(arow + mt * 16 * lda + k0);
-        mfma_slice<MT, NT>(a, bcur, acc);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
-    }
+    BStream<NT> bs;
+    bs.init(W, ldw, n0, n_valid, K);
+    bs.prefetch();
+    gemm_ldsA_stream<MT, NT>(A_lds, lda, bs, acc, 0, bs.nslices);
 }
 
 template <int MT, int NT>

@@ -49,35 +49,80 @@ __global__ __launch_bounds__(256) void ipa_points_kernel(pf_ipa_points_args a) {
 
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// 16-lane transpose-reduce of HG per-lane partial sums (one value per head): while more than one value is
+// left, lanes exchange halves (8 -> 4 -> 2 -> 1 values), then plain xor-sums.  On return every lane holds the
+// full 16-lane sum of head `head_of_lane<HG>(lane)`.
+template <int HG> __device__ __forceinline__ int head_of_lane(int lane) {
+    return HG == 8 ? ((lane & 15) >> 1) : HG == 4 ? ((lane & 15) >> 2) : ((lane & 15) >> 3);
+}
+template <int HG> __device__ __forceinline__ float reduce16(float (&v)[HG], int lane) {
+    float cur[8];
+#pragma unroll
+    for (int q = 0; q < HG; ++q) cur[q] = v[q];
+    int n = HG;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        if (n > 1) {
+            const bool hi = lane & off;
+            const int half = n >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < half) {
+                    const float send = hi ? cur[q] : cur[half + q];
+                    const float keep = hi ? cur[half + q] : cur[q];
+                    cur[q] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            n = half;
+        } else {
+            cur[0] += __shfl_xor(cur[0], off, 64);
+        }
+    }
+    return cur[0];
+}
+
+// One workgroup = (sample b, 16 query residues, group of HG heads), 4 waves.
+//   HG = 8 : all heads in one workgroup (z is streamed once per query tile)       -- large batches
+//   HG = 4/2: 2 / 4 workgroups per query tile (z re-read from L2 by each)          -- fills the 256 CUs when
+//             B*L/16 is small (cfg2 has only 64 query tiles)
+template <int HG>
 __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int LP, int LDS_S) {
+    constexpr int NG = H / HG;                    // head groups per query tile
+    constexpr int HPW = HG >= 4 ? HG / 4 : 1;     // heads per wave
+    constexpr int WPH = HG >= 4 ? 1 : 4 / HG;     // waves per head
+    constexpr int NTC = HG >= 4 ? 11 : 6;         // [V | Vp] column tiles per wave in phase C
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* S = smem;                              // [TI][H][LDS_S]
-    float* QP = S + TI * H * LDS_S;               // [TI][H*PQ*3] query points (global frame)
-    float* OPT = QP + TI * 192;                   // [TI][H][36]  o_pt (global frame)
-    float* ZB = OPT + TI * H * 36;                // [4 waves][H][64] zbar scratch
+    float* S = smem;                              // [TI][HG][LDS_S]
+    float* QP = S + TI * HG * LDS_S;              // [TI][HG*24] query points (global frame)
+    float* OPT = QP + TI * HG * 24;               // [TI][HG][36]  o_pt (global frame)
+    float* ZB = OPT + TI * HG * 36;               // [4 waves][HG][64] zbar scratch
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
     const int tiles = (L + TI - 1) / TI;
-    const int b = blockIdx.x / tiles;
-    const int i0 = (blockIdx.x - b * tiles) * TI;
+    const int hg = blockIdx.x % NG;
+    const int bt = blockIdx.x / NG;
+    const int b = bt / tiles;
+    const int i0 = (bt - b * tiles) * TI;
+    const int h0 = hg * HG;                       // first head of this workgroup
     const size_t rowb = (size_t)b * L;
 
-    // ---- phase 0: query points -> LDS; zero the padded tail of S ----
-    for (int idx = tid; idx < TI * 192; idx += 256) {
-        int ti = idx / 192, c = idx - ti * 192;
-        QP[idx] = (i0 + ti < L) ? a.qp[(rowb + i0 + ti) * 192 + c] : 0.f;
+    // ---- phase 0: query points of this head group -> LDS ----
+    for (int idx = tid; idx < TI * HG * 24; idx += 256) {
+        const int ti = idx / (HG * 24), c = idx - ti * (HG * 24);
+        QP[idx] = (i0 + ti < L) ? a.qp[(rowb + i0 + ti) * 192 + h0 * 24 + c] : 0.f;
     }
 
-    // ---- phase A: pair bias for all 8 heads.  wave w -> query rows 4w..4w+3 ----
+    // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) for the HG heads.  wave w -> query rows 4w..4w+3 ----
     {
         const int c4 = lane & 15, js = lane >> 4;
-        float4 wb[H];
+        float4 wb[HG];
 #pragma unroll
-        for (int h = 0; h < H; ++h) wb[h] = *reinterpret_cast<const float4*>(a.w_b + h * 64 + 4 * c4);
-        const int hsel = (lane & 15) >> 1;
-        const float bb = a.b_b[hsel];
+        for (int h = 0; h < HG; ++h) wb[h] = *reinterpret_cast<const float4*>(a.w_b + (h0 + h) * 64 + 4 * c4);
+        const int hsel = head_of_lane<HG>(lane);
+        const bool writer = (lane & (16 / HG - 1)) == 0;
+        const float bb = a.b_b[h0 + hsel];
         const float s13 = 0.57735026918962576f;   // sqrt(1/3)
         for (int t4 = 0; t4 < 4; ++t4) {
             const int ti = wave * 4 + t4;
@@ -87,110 +132,87 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
                 const int j = j0 + js;
                 float4 zq = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (j < L) zq = *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4);
-                float v[H];
+                float v[HG];
 #pragma unroll
-                for (int h = 0; h < H; ++h) v[h] = wb[h].x * zq.x + wb[h].y * zq.y + wb[h].z * zq.z + wb[h].w * zq.w;
-                // butterfly over the 16 lanes that share this pair: 8 -> 4 -> 2 -> 1 values
-                float k4[4];
-                {
-                    const bool hi = lane & 8;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float send = hi ? v[q] : v[4 + q];
-                        float keep = hi ? v[4 + q] : v[q];
-                        k4[q] = keep + __shfl_xor(send, 8, 64);
-                    }
-                }
-                float k2[2];
-                {
-                    const bool hi = lane & 4;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        float send = hi ? k4[q] : k4[2 + q];
-                        float keep = hi ? k4[2 + q] : k4[q];
-                        k2[q] = keep + __shfl_xor(send, 4, 64);
-                    }
-                }
-                float k1;
-                {
-                    const bool hi = lane & 2;
-                    float send = hi ? k2[0] : k2[1];
-                    float keep = hi ? k2[1] : k2[0];
-                    k1 = keep + __shfl_xor(send, 2, 64);
-                }
-                k1 += __shfl_xor(k1, 1, 64);
-                if ((lane & 1) == 0 && j < LP) S[(ti * H + hsel) * LDS_S + j] = (j < L) ? s13 * (k1 + bb) : 0.f;
+                for (int h = 0; h < HG; ++h) v[h] = wb[h].x * zq.x + wb[h].y * zq.y + wb[h].z * zq.z + wb[h].w * zq.w;
+                const float tot = reduce16<HG>(v, lane);
+                if (writer) S[(ti * HG + hsel) * LDS_S + j] = (j < L) ? s13 * (tot + bb) : 0.f;
             }
         }
     }
     __syncthreads();
 
-    // ---- phase B: scalar qk (MFMA) + point term + mask + softmax ; wave -> heads 2w, 2w+1 ----
+    // ---- phase B: scalar qk (MFMA) + point term + mask ----
     const float scale_qk = 0.051031036307982884f;            // sqrt(1/(3*128))
     const float scale_pt = 0.09622504486493763f;              // sqrt(1/(3*(8*9/2)))
-    for (int hh = 0; hh < 2; ++hh) {
-        const int h = wave * 2 + hh;
-        const float gamma = softplusf(a.head_w[h]) * scale_pt;
-        float4 qf[8];
-        {
-            const int i = i0 + r;
-            const float* qrow = a.proj + (rowb + (i < L ? i : 0)) * a.ldp + h * C + 4 * g;
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                qf[s] = (i < L) ? *reinterpret_cast<const float4*>(qrow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int j0 = 0; j0 < LP; j0 += 16) {
-            const int j = j0 + r;
-            const bool jok = j < L;
-            const float* krow = a.proj + (rowb + (jok ? j : 0)) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                float4 kf = jok ? *reinterpret_cast<const float4*>(krow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc = mfma16(qf[s].x, kf.x, acc);
-                acc = mfma16(qf[s].y, kf.y, acc);
-                acc = mfma16(qf[s].z, kf.z, acc);
-                acc = mfma16(qf[s].w, kf.w, acc);
-            }
-            // point term for (ti = 4g+e, j): sum_p |qp - kp|^2
-            float kpt[24];
+    {
+        const int hh0 = (wave / WPH) * HPW;
+        const int tile_off = wave % WPH;
+        for (int hq = 0; hq < HPW; ++hq) {
+            const int hh = hh0 + hq, h = h0 + hh;
+            const float gamma = softplusf(a.head_w[h]) * scale_pt;
+            float4 qf[8];
             {
-                const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
+                const int i = i0 + r;
+                const float* qrow = a.proj + (rowb + (i < L ? i : 0)) * a.ldp + h * C + 4 * g;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    float4 t = *reinterpret_cast<const float4*>(kp + 4 * q);
-                    kpt[4 * q] = t.x; kpt[4 * q + 1] = t.y; kpt[4 * q + 2] = t.z; kpt[4 * q + 3] = t.w;
-                }
+                for (int s = 0; s < 8; ++s)
+                    qf[s] = (i < L) ? *reinterpret_cast<const float4*>(qrow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            const float mj = jok ? a.mask[rowb + j] : 0.f;
+            for (int j0 = 16 * tile_off; j0 < LP; j0 += 16 * WPH) {
+                const int j = j0 + r;
+                const bool jok = j < L;
+                const float* krow = a.proj + (rowb + (jok ? j : 0)) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
+                float4 kf[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ti = 4 * g + e;
-                const float* qp = QP + ti * 192 + h * 24;
-                float d2 = 0.f;
+                for (int s = 0; s < 8; ++s)
+                    kf[s] = jok ? *reinterpret_cast<const float4*>(krow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float kpt[24];
+                {
+                    const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    float4 t = *reinterpret_cast<const float4*>(qp + 4 * q);
-                    float d0 = t.x - kpt[4 * q], d1 = t.y - kpt[4 * q + 1], dd2 = t.z - kpt[4 * q + 2], d3 = t.w - kpt[4 * q + 3];
-                    d2 += d0 * d0; d2 += d1 * d1; d2 += dd2 * dd2; d2 += d3 * d3;
+                    for (int q = 0; q < 6; ++q) {
+                        float4 t = *reinterpret_cast<const float4*>(kp + 4 * q);
+                        kpt[4 * q] = t.x; kpt[4 * q + 1] = t.y; kpt[4 * q + 2] = t.z; kpt[4 * q + 3] = t.w;
+                    }
                 }
-                const int i = i0 + ti;
-                const float mi = (i < L) ? a.mask[rowb + i] : 0.f;
-                if (jok) {
-                    float* sp = S + (ti * H + h) * LDS_S + j;
-                    float v = acc[e] * scale_qk + *sp;
-                    v = v + (-0.5f) * (gamma * d2);
-                    v = v + 1e5f * (mi * mj - 1.f);
-                    *sp = v;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    acc = mfma16(qf[s].x, kf[s].x, acc);
+                    acc = mfma16(qf[s].y, kf[s].y, acc);
+                    acc = mfma16(qf[s].z, kf[s].z, acc);
+                    acc = mfma16(qf[s].w, kf[s].w, acc);
+                }
+                const float mj = jok ? a.mask[rowb + j] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ti = 4 * g + e;
+                    const float* qp = QP + ti * (HG * 24) + hh * 24;
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        float4 t = *reinterpret_cast<const float4*>(qp + 4 * q);
+                        float d0 = t.x - kpt[4 * q], d1 = t.y - kpt[4 * q + 1], dd2 = t.z - kpt[4 * q + 2], d3 = t.w - kpt[4 * q + 3];
+                        d2 += d0 * d0; d2 += d1 * d1; d2 += dd2 * dd2; d2 += d3 * d3;
+                    }
+                    const int i = i0 + ti;
+                    const float mi = (i < L) ? a.mask[rowb + i] : 0.f;
+                    if (jok) {
+                        float* sp = S + (ti * HG + hh) * LDS_S + j;
+                        float v = acc[e] * scale_qk + *sp;
+                        v = v + (-0.5f) * (gamma * d2);
+                        v = v + 1e5f * (mi * mj - 1.f);
+                        *sp = v;
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    // softmax over j for the 32 (ti,h) rows of this wave
-    for (int rr = 0; rr < 32; ++rr) {
-        const int ti = rr >> 1, h = wave * 2 + (rr & 1);
-        float* sp = S + (ti * H + h) * LDS_S;
+    // softmax over j for the 16*HG (ti,h) rows, 4 waves interleaved
+    for (int rr = wave; rr < TI * HG; rr += 4) {
+        float* sp = S + rr * LDS_S;
         float m = -3.0e38f;
         for (int j = lane; j < L; j += 64) m = fmaxf(m, sp[j]);
         m = wave_max(m);
@@ -203,71 +225,73 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     __syncthreads();
 
     // ---- phase C: [o | o_pt] = P [V | Vp] on MFMA ----
-    for (int hh = 0; hh < 2; ++hh) {
-        const int h = wave * 2 + hh;
-        f32x4 acc[11];
+    {
+        const int hh0 = (wave / WPH) * HPW;
+        const int tb = (WPH > 1) ? (wave % WPH) * NTC : 0;     // first column tile of this wave
+        for (int hq = 0; hq < HPW; ++hq) {
+            const int hh = hh0 + hq, h = h0 + hh;
+            f32x4 acc[NTC];
 #pragma unroll
-        for (int n = 0; n < 11; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* prow = S + (r * H + h) * LDS_S + 4 * g;
-        for (int k0 = 0; k0 < LP; k0 += 16) {
-            const float4 pa = *reinterpret_cast<const float4*>(prow + k0);
-            int jr[4];
+            for (int n = 0; n < NTC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* prow = S + (r * HG + hh) * LDS_S + 4 * g;
+            for (int k0 = 0; k0 < LP; k0 += 16) {
+                const float4 pa = *reinterpret_cast<const float4*>(prow + k0);
+                int jr[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { int j = k0 + 4 * g + t; jr[t] = j < L ? j : L - 1; }
+                for (int t = 0; t < 4; ++t) { int j = k0 + 4 * g + t; jr[t] = j < L ? j : L - 1; }
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                float vb[4];
+                for (int n = 0; n < NTC; ++n) {
+                    const int nt = tb + n;                       // wave-uniform
+                    float vb[4];
+                    if (nt < 8) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    vb[t] = a.proj[(rowb + jr[t]) * a.ldp + OFF_KV + h * 2 * C + C + nt * 16 + r];
-                acc[nt] = mfma16(pa.x, vb[0], acc[nt]);
-                acc[nt] = mfma16(pa.y, vb[1], acc[nt]);
-                acc[nt] = mfma16(pa.z, vb[2], acc[nt]);
-                acc[nt] = mfma16(pa.w, vb[3], acc[nt]);
+                        for (int t = 0; t < 4; ++t)
+                            vb[t] = a.proj[(rowb + jr[t]) * a.ldp + OFF_KV + h * 2 * C + C + nt * 16 + r];
+                    } else if (nt < 11) {
+                        const int c = (nt - 8) * 16 + r;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            vb[t] = (c < 36) ? a.vp[(rowb + jr[t]) * 288 + h * 36 + c] : 0.f;
+                    } else {
+                        continue;
+                    }
+                    acc[n] = mfma16(pa.x, vb[0], acc[n]);
+                    acc[n] = mfma16(pa.y, vb[1], acc[n]);
+                    acc[n] = mfma16(pa.z, vb[2], acc[n]);
+                    acc[n] = mfma16(pa.w, vb[3], acc[n]);
+                }
             }
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-                const int n = nt * 16 + r;
-                float vb[4];
+            for (int e = 0; e < 4; ++e) {
+                const int ti = 4 * g + e, i = i0 + ti;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    vb[t] = (n < 36) ? a.vp[(rowb + jr[t]) * 288 + h * 36 + n] : 0.f;
-                acc[8 + nt] = mfma16(pa.x, vb[0], acc[8 + nt]);
-                acc[8 + nt] = mfma16(pa.y, vb[1], acc[8 + nt]);
-                acc[8 + nt] = mfma16(pa.z, vb[2], acc[8 + nt]);
-                acc[8 + nt] = mfma16(pa.w, vb[3], acc[8 + nt]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ti = 4 * g + e, i = i0 + ti;
-            if (i < L) {
-                float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * C;
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) f[nt * 16 + r] = acc[nt][e];
-            }
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-                const int n = nt * 16 + r;
-                if (n < 36) OPT[(ti * H + h) * 36 + n] = acc[8 + nt][e];
+                for (int n = 0; n < NTC; ++n) {
+                    const int nt = tb + n;
+                    if (nt < 8) {
+                        if (i < L) a.feats[(rowb + i) * PF_IPA_FEATS + h * C + nt * 16 + r] = acc[n][e];
+                    } else if (nt < 11) {
+                        const int c = (nt - 8) * 16 + r;
+                        if (c < 36) OPT[(ti * HG + hh) * 36 + c] = acc[n][e];
+                    }
+                }
             }
         }
     }
     __syncthreads();
 
     // ---- phase D1: o_pt -> local frame (invert_apply) + norms ----
-    for (int idx = tid; idx < TI * H * PV; idx += 256) {
-        const int ti = idx / (H * PV), hp = idx - ti * (H * PV);
+    for (int idx = tid; idx < TI * HG * PV; idx += 256) {
+        const int ti = idx / (HG * PV), hp = idx - ti * (HG * PV);     // hp = hh*12 + p
         const int i = i0 + ti;
         if (i >= L) continue;
         const float* R = a.rot + (rowb + i) * 9;
         const float* T = a.trans + (rowb + i) * 3;
-        const float* o = OPT + ti * H * 36 + hp * 3;
+        const float* o = OPT + ti * HG * 36 + hp * 3;
         const float x = o[0] - T[0], y = o[1] - T[1], z = o[2] - T[2];
         const float lx = R[0] * x + R[3] * y + R[6] * z;     // R^T (o - t)
         const float ly = R[1] * x + R[4] * y + R[7] * z;
         const float lz = R[2] * x + R[5] * y + R[8] * z;
-        float* f = a.feats + (rowb + i) * PF_IPA_FEATS;
+        float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h0 * PV;
         f[1024 + hp] = lx;
         f[1120 + hp] = ly;
         f[1216 + hp] = lz;
@@ -277,27 +301,27 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     // ---- phase D2: zbar[h][c] = sum_j P[h][j] z[i][j][c] ; o_pair = W_dz zbar + b_dz ----
     {
         const int c4 = lane & 15, js = lane >> 4;
-        float* zb = ZB + wave * H * 64;
+        float* zb = ZB + wave * HG * 64;
         for (int t4 = 0; t4 < 4; ++t4) {
             const int ti = wave * 4 + t4, i = i0 + ti;
             if (i >= L) continue;                          // wave-uniform
             const float* zrow = a.z + ((rowb + i) * L) * 64;
-            float4 zacc[H];
+            float4 zacc[HG];
 #pragma unroll
-            for (int h = 0; h < H; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int h = 0; h < HG; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int j0 = 0; j0 < L; j0 += 4) {
                 const int j = j0 + js;
                 if (j < L) {
                     const float4 zq = *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const float pw = S[(ti * H + h) * LDS_S + j];
+                    for (int h = 0; h < HG; ++h) {
+                        const float pw = S[(ti * HG + h) * LDS_S + j];
                         zacc[h].x += pw * zq.x; zacc[h].y += pw * zq.y; zacc[h].z += pw * zq.z; zacc[h].w += pw * zq.w;
                     }
                 }
             }
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
+            for (int h = 0; h < HG; ++h) {
                 float4 v = zacc[h];
                 v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64);
                 v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
@@ -307,23 +331,36 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            // 128 outputs (h, d): lane -> (h = lane>>3, d = (lane&7) and +8)
-            {
-                const int h = lane >> 3, d0 = lane & 7;
-                float o0 = a.b_dz[d0], o1 = a.b_dz[d0 + 8];
-                const float* w0 = a.w_dz + d0 * 64;
-                const float* w1 = a.w_dz + (d0 + 8) * 64;
-                const float* zz = zb + h * 64;
+            for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d)
+                const int hh = o >> 4, d = o & 15;
+                float acc = a.b_dz[d];
+                const float* w = a.w_dz + d * 64;
+                const float* zz = zb + hh * 64;
 #pragma unroll 8
-                for (int c = 0; c < 64; ++c) { const float zv = zz[c]; o0 += w0[c] * zv; o1 += w1[c] * zv; }
-                float* f = a.feats + (rowb + i) * PF_IPA_FEATS + 1408 + h * 16;
-                f[d0] = o0;
-                f[d0 + 8] = o1;
+                for (int c = 0; c < 64; ++c) acc += w[c] * zz[c];
+                a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+template <int HG>
+int launch_attn(const pf_ipa_attn_args& a, hipStream_t s) {
+    const int LP = (a.L + 15) / 16 * 16;
+    const int LDS_S = LP + 4;
+    const size_t lds = ((size_t)TI * HG * LDS_S + TI * HG * 24 + TI * HG * 36 + 4 * HG * 64) * sizeof(float);
+    if (lds > 160 * 1024) return PF_E_TOOLARGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ipa_attn_kernel<HG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int tiles = (a.L + TI - 1) / TI;
+    hipLaunchKernelGGL(ipa_attn_kernel<HG>, dim3((unsigned)(a.B * tiles * (H / HG))), dim3(256), lds, s, a, LP, LDS_S);
+    PF_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // namespace
@@ -342,17 +379,10 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
         !a->b_b || !a->w_dz || !a->b_dz || !a->head_w || !a->feats || a->B <= 0 || a->L <= 0 || a->ldp < PF_IPA_PROJ ||
         a->ldp % 4)
         return PF_E_BADARG;
-    const int LP = (a->L + 15) / 16 * 16;
-    const int LDS_S = LP + 4;
-    const size_t lds = ((size_t)TI * H * LDS_S + TI * 192 + TI * H * 36 + 4 * H * 64) * sizeof(float);
-    if (lds > 160 * 1024) return PF_E_TOOLARGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ipa_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    const int tiles = (a->L + TI - 1) / TI;
-    hipLaunchKernelGGL(ipa_attn_kernel, dim3((unsigned)(a->B * tiles)), dim3(256), lds, (hipStream_t)stream, *a, LP, LDS_S);
-    PF_CHECK_LAUNCH();
-    return 0;
+    // head-group split chosen from the number of query tiles so that >= ~256 workgroups exist
+    const long qt = (long)a->B * ((a->L + TI - 1) / TI);
+    hipStream_t s = (hipStream_t)stream;
+    if (qt >= 256) return launch_attn<8>(*a, s);
+    if (qt >= 128) return launch_attn<4>(*a, s);
+    return launch_attn<2>(*a, s);
 }

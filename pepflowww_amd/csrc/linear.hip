@@ -20,8 +20,7 @@ template <int MT>
 __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
     constexpr int BM = 16 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [BM][LDA]
-    float* Ys = smem + BM * LDA;      // [BM][LDY] (LayerNorm path only)
+    float* As = smem;                 // [2][BM][LDA] double-buffered activation chunks; then Ys [BM][LDY] (LayerNorm only)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -32,20 +31,44 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
     f32x4 acc[MT][2];
     acc_zero<MT, 2>(acc);
 
-    for (int kc = 0; kc < p.K; kc += KC) {
-        const int kw = min(KC, p.K - kc);           // multiple of 16
-        const int kq = kw >> 2;                      // float4 per row
-        if (kc) __syncthreads();
-        for (int idx = tid; idx < BM * kq; idx += 256) {
-            int row = idx / kq, c4 = idx - row * kq;
-            int m = m0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < p.M) v = *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + kc + 4 * c4);
-            *reinterpret_cast<float4*>(As + row * LDA + 4 * c4) = v;
+    // weights first: the B stream is PF_DEPTH slices deep before the activation tile is even requested
+    BStream<2> bs;
+    bs.init(p.w, p.ldw, n0, p.N, p.K);
+    bs.prefetch();
+
+    // activation tile: K-chunks of 128, double-buffered in LDS (global -> registers -> LDS one chunk ahead)
+    constexpr int NLD = BM * (KC / 4) / 256;          // float4 per thread per chunk: 2 * MT
+    const int nchunks = (p.K + KC - 1) / KC;
+    float4 stage[NLD];
+    auto fetch = [&](int c) {
+        const int kc = c * KC, kq = min(KC, p.K - kc) >> 2;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = tid + q * 256;
+            const int row = idx / (KC / 4), c4 = idx % (KC / 4);
+            const int m = m0 + row;
+            stage[q] = (m < p.M && c4 < kq) ? *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + kc + 4 * c4)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto commit = [&](float* dst) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = tid + q * 256;
+            *reinterpret_cast<float4*>(dst + (idx / (KC / 4)) * LDA + 4 * (idx % (KC / 4))) = stage[q];
+        }
+    };
+    fetch(0);
+    commit(As);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        float* cur = As + (c & 1) * BM * LDA;
+        if (c + 1 < nchunks) fetch(c + 1);
+        gemm_ldsA_stream<MT, 2>(cur, LDA, bs, acc, c * (KC / 16), min(KC, p.K - c * KC) >> 4);
+        if (c + 1 < nchunks) commit(As + ((c + 1) & 1) * BM * LDA);
         __syncthreads();
-        gemm_ldsA_glbB<MT, 2>(As, LDA, p.w + kc, p.ldw, n0, p.N, kw, acc);
     }
+    float* Ys = As + 2 * BM * LDA;
 
     const bool do_ln = p.ln_gamma != nullptr;
 #pragma unroll
@@ -118,7 +141,7 @@ template <int MT>
 int launch(const pf_linear_args& a, hipStream_t s) {
     constexpr int BM = 16 * MT;
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-    size_t lds = (size_t)BM * LDA * sizeof(float) + (a.ln_gamma ? (size_t)BM * LDY * sizeof(float) : 0);
+    size_t lds = (size_t)2 * BM * LDA * sizeof(float) + (a.ln_gamma ? (size_t)BM * LDY * sizeof(float) : 0);
     hipLaunchKernelGGL(linear_kernel<MT>, grid, dim3(256), lds, s, a);
     PF_CHECK_LAUNCH();
     return 0;

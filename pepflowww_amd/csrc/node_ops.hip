@@ -37,28 +37,35 @@ __global__ __launch_bounds__(256) void embed_kernel(pf_embed_args a) {
 
 // ---------------------------------------------------------------------------------------------
 // pf_seq_attn_fwd: softmax(q k^T / sqrt(32) + key_padding) v for one (sample, head) per workgroup.
-// K/V head slices in LDS, one query row per thread, online softmax (no L x L matrix).
+// K/V head slices in LDS (row stride 36 floats: the 4 rows a quad reads sit on disjoint banks).
+// FOUR lanes per query row, each owning the keys j = sub (mod 4) with its own online-softmax state
+// (m, l, acc[32]); the four states are merged with two xor-shuffles at the end.  4x the waves of a
+// one-thread-per-query layout (L = 64 would otherwise be a single wave per workgroup).
 // ---------------------------------------------------------------------------------------------
+constexpr int SA_LD = 36;
 __global__ __launch_bounds__(256) void seq_attn_kernel(pf_seq_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;
-    float* Ks = smem;               // [L][32]
-    float* Vs = smem + (size_t)L * 32;
-    float* Ms = Vs + (size_t)L * 32; // [L]
+    float* Ks = smem;                         // [L][36]
+    float* Vs = smem + (size_t)L * SA_LD;
+    float* Ms = Vs + (size_t)L * SA_LD;        // [L]
     const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
     const size_t rowb = (size_t)b * L;
     for (int idx = threadIdx.x; idx < L * 8; idx += 256) {
         const int j = idx >> 3, c4 = idx & 7;
         const float* src = a.qkv + (rowb + j) * 384 + h * 32 + 4 * c4;
-        *reinterpret_cast<float4*>(Ks + j * 32 + 4 * c4) = *reinterpret_cast<const float4*>(src + 128);
-        *reinterpret_cast<float4*>(Vs + j * 32 + 4 * c4) = *reinterpret_cast<const float4*>(src + 256);
+        *reinterpret_cast<float4*>(Ks + j * SA_LD + 4 * c4) = *reinterpret_cast<const float4*>(src + 128);
+        *reinterpret_cast<float4*>(Vs + j * SA_LD + 4 * c4) = *reinterpret_cast<const float4*>(src + 256);
     }
     for (int j = threadIdx.x; j < L; j += 256) Ms[j] = a.mask[rowb + j];
     __syncthreads();
     const float scale = 0.17677669529663687f;   // 1/sqrt(32)
-    for (int i = threadIdx.x; i < L; i += 256) {
+    const int sub = threadIdx.x & 3;
+    const int nq = (L + 63) / 64 * 64;          // whole waves stay convergent for the shuffles
+    for (int i = threadIdx.x >> 2; i < nq; i += 64) {
+        const bool iok = i < L;
         float q[32], acc[32];
-        const float* qsrc = a.qkv + (rowb + i) * 384 + h * 32;
+        const float* qsrc = a.qkv + (rowb + (iok ? i : 0)) * 384 + h * 32;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float4 t = *reinterpret_cast<const float4*>(qsrc + 4 * c);
@@ -67,27 +74,49 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(pf_seq_attn_args a) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) acc[c] = 0.f;
         float m = -3.0e38f, l = 0.f;
-        for (int j = 0; j < L; ++j) {
-            if (Ms[j] < 0.5f) continue;          // key padding (uniform across the workgroup)
-            const float* kj = Ks + j * 32;
+        for (int j = sub; j < L; j += 4) {
+            if (Ms[j] < 0.5f) continue;          // key padding
+            const float* kj = Ks + j * SA_LD;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) s += q[c] * kj[c];
+            for (int c = 0; c < 8; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(kj + 4 * c);
+                s += q[4 * c] * t.x; s += q[4 * c + 1] * t.y; s += q[4 * c + 2] * t.z; s += q[4 * c + 3] * t.w;
+            }
             const float mn = fmaxf(m, s);
             const float corr = expf(m - mn);
             const float pj = expf(s - mn);
             l = l * corr + pj;
-            const float* vj = Vs + j * 32;
+            const float* vj = Vs + j * SA_LD;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) acc[c] = acc[c] * corr + pj * vj[c];
+            for (int c = 0; c < 8; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(vj + 4 * c);
+                acc[4 * c] = acc[4 * c] * corr + pj * t.x; acc[4 * c + 1] = acc[4 * c + 1] * corr + pj * t.y;
+                acc[4 * c + 2] = acc[4 * c + 2] * corr + pj * t.z; acc[4 * c + 3] = acc[4 * c + 3] * corr + pj * t.w;
+            }
             m = mn;
         }
+        // merge the four key-subset states of this query
+        float mt = fmaxf(m, __shfl_xor(m, 1, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 2, 64));
+        const float f = expf(m - mt);            // lanes that saw no key: m = -3e38 -> f = 0
+        l *= f;
+        l += __shfl_xor(l, 1, 64);
+        l += __shfl_xor(l, 2, 64);
         const float inv = 1.f / l;
-        float* dst = a.out + (rowb + i) * 128 + h * 32;
+        float o[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            *reinterpret_cast<float4*>(dst + 4 * c) =
-                make_float4(acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv);
+        for (int c = 0; c < 32; ++c) {
+            float v = acc[c] * f;
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if ((c >> 3) == sub) o[c & 7] = v * inv;
+        }
+        if (iok) {
+            float* dst = a.out + (rowb + i) * 128 + h * 32 + 8 * sub;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
     }
 }
 
@@ -190,7 +219,7 @@ extern "C" int pf_embed_inputs_fwd(const pf_embed_args* a, pf_stream_t stream) {
 
 extern "C" int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream) {
     if (!a || !a->qkv || !a->mask || !a->out || a->B <= 0 || a->L <= 0) return PF_E_BADARG;
-    const size_t lds = ((size_t)a->L * 65) * sizeof(float);
+    const size_t lds = ((size_t)a->L * (2 * SA_LD + 1)) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
     static bool attr_set = false;
     if (!attr_set) {
