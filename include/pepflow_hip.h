@@ -126,6 +126,51 @@ typedef struct {
 } pf_seq_attn_args;
 int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream);
 
+/* ---- fused node track of one GAEncoder block (csrc/node_track.hip) ----------------------------------
+ * pf_node_head_fwd: s_ipa = LayerNorm(s + mask * linear_out(feats)) (ga.py:103-104, ipa_pytorch.py:478-482)
+ *                   and qkv = in_proj(s_ipa) of seq_tfmr layer 0.  s_ipa may alias s_in. */
+typedef struct {
+    const float* feats;            /* [rows,1536] */
+    const float* s_in;             /* [rows,128] */
+    const float* mask;             /* [rows] */
+    const float* w_out; const float* b_out;   /* ipa linear_out [128,1536] */
+    const float* ln_g; const float* ln_b;     /* ipa_ln */
+    const float* w_in; const float* b_in;     /* seq_tfmr layers.0.self_attn.in_proj [384,128] */
+    float* s_ipa;                  /* [rows,128] */
+    float* qkv;                    /* [rows,384] */
+    int rows;
+} pf_node_head_args;
+int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream);
+
+/* pf_node_tfmr_fwd: one post-LN nn.TransformerEncoderLayer (ga.py:53-62,105-106; d=128, 4 heads, ffn 128,
+ * key padding mask) for 16 query rows per workgroup, followed by
+ *   last == 0: the next layer's in_proj (qkv_out must not alias qkv: other workgroups still read K/V);
+ *   last == 1: the block tail -- post_tfmr + residual (ga.py:107), StructureModuleTransition + mask
+ *              (ga.py:108-109), BackboneUpdate + Rigid.compose_q_update_vec (ga.py:110-113) and, if has_et,
+ *              EdgeTransition.initial_embed + its per-residue terms pre[rows,512] (ipa_pytorch.py:234-243).
+ * s_out may alias s_ipa; quat/rot/trans may be updated in place. */
+typedef struct {
+    const float* qkv;              /* [B*L,384] this layer's q|k|v */
+    const float* resid;            /* [B*L,128] layer input */
+    const float* mask;             /* [B*L] */
+    const float* w_o; const float* b_o; const float* n1_g; const float* n1_b;
+    const float* w_1; const float* b_1; const float* w_2; const float* b_2; const float* n2_g; const float* n2_b;
+    const float* w_in_next; const float* b_in_next; float* qkv_out; float* v_out;      /* last == 0 */
+    int last;
+    const float* s_ipa;                                                                /* last == 1 ... */
+    const float* w_post; const float* b_post;
+    const float* w_t1; const float* b_t1; const float* w_t2; const float* b_t2; const float* w_t3; const float* b_t3;
+    const float* nt_g; const float* nt_b;
+    const float* w_bb; const float* b_bb;
+    float* s_out;
+    const float* quat_in; const float* rot_in; const float* trans_in;
+    float* quat_out; float* rot_out; float* trans_out;
+    int has_et;
+    const float* w_init; const float* b_init; const float* w_pre; const float* b_pre; float* pre;
+    int B, L;
+} pf_node_tfmr_args;
+int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
+
 /* ---- rot -> quat: rigid_utils.py:208-227 (top eigenvector of the 4x4 K matrix; the reference
  * calls torch.linalg.eigh, here a shifted power iteration converged to fp32). */
 int pf_rot_to_quat(const float* rot, float* quat, int n, pf_stream_t stream);

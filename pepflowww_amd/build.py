@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpepflow_hip.so")
-SOURCES = ["selftest.hip", "linear.hip", "edge_transition.hip", "ipa_attn.hip", "node_ops.hip", "flow_step.hip", "encode.hip"]
+SOURCES = ["selftest.hip", "linear.hip", "edge_transition.hip", "ipa_attn.hip", "node_ops.hip", "flow_step.hip", "encode.hip", "node_track.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
@@ -21,7 +21,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pepflow_hip.h"), __file__]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(HERE, "..", "include", "pepflow_hip.h"), __file__]
     objs = []
     procs = []
     for src in SOURCES:

@@ -1,6 +1,7 @@
 // Per-residue kernels of the denoise step: input feature assembly, sequence-transformer
 // attention core, rot->quat and the quaternion backbone update.
 #include "common.h"
+#include "rigid_dev.h"
 #include "../../include/pepflow_hip.h"
 
 namespace {
@@ -179,31 +180,18 @@ __global__ __launch_bounds__(256) void rigid_update_kernel(pf_rigid_update_args 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const float4 q = *reinterpret_cast<const float4*>(p.quat_in + (size_t)i * 4);
-    const float* u = p.upd + (size_t)i * p.ldu;
-    const float m = p.mask[i];
-    const float a = q.x, b = q.y, c = q.z, d = q.w;
-    const float ux = u[0], uy = u[1], uz = u[2];
-    float na = a + m * (-b * ux - c * uy - d * uz);
-    float nb = b + m * (a * ux + c * uz - d * uy);
-    float nc = c + m * (a * uy - b * uz + d * ux);
-    float nd = d + m * (a * uz + b * uy - c * ux);
-    const float inv = 1.f / sqrtf(na * na + nb * nb + nc * nc + nd * nd);
-    na *= inv; nb *= inv; nc *= inv; nd *= inv;
-    float R[9];
+    float R[9], x[3], Ro[9], xo[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = p.rot_in[(size_t)i * 9 + k];
-    const float vx = u[3], vy = u[4], vz = u[5];
-    const float tx = p.trans_in[(size_t)i * 3 + 0] + m * (R[0] * vx + R[1] * vy + R[2] * vz);
-    const float ty = p.trans_in[(size_t)i * 3 + 1] + m * (R[3] * vx + R[4] * vy + R[5] * vz);
-    const float tz = p.trans_in[(size_t)i * 3 + 2] + m * (R[6] * vx + R[7] * vy + R[8] * vz);
-    *reinterpret_cast<float4*>(p.quat_out + (size_t)i * 4) = make_float4(na, nb, nc, nd);
-    p.trans_out[(size_t)i * 3 + 0] = tx;
-    p.trans_out[(size_t)i * 3 + 1] = ty;
-    p.trans_out[(size_t)i * 3 + 2] = tz;
-    float* Ro = p.rot_out + (size_t)i * 9;
-    Ro[0] = na * na + nb * nb - nc * nc - nd * nd; Ro[1] = 2.f * (nb * nc - na * nd); Ro[2] = 2.f * (nb * nd + na * nc);
-    Ro[3] = 2.f * (nb * nc + na * nd); Ro[4] = na * na - nb * nb + nc * nc - nd * nd; Ro[5] = 2.f * (nc * nd - na * nb);
-    Ro[6] = 2.f * (nb * nd - na * nc); Ro[7] = 2.f * (nc * nd + na * nb); Ro[8] = na * na - nb * nb - nc * nc + nd * nd;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = p.trans_in[(size_t)i * 3 + k];
+    float4 qo;
+    rigid_update_dev(q, R, x, p.upd + (size_t)i * p.ldu, p.mask[i], qo, Ro, xo);
+    *reinterpret_cast<float4*>(p.quat_out + (size_t)i * 4) = qo;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.trans_out[(size_t)i * 3 + k] = xo[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.rot_out[(size_t)i * 9 + k] = Ro[k];
 }
 
 }  // namespace

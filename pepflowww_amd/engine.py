@@ -103,7 +103,7 @@ class DenoiseEngine:
         self.proj = e(rows, 3744)
         self.qp, self.kp, self.vp = e(rows, 192), e(rows, 192), e(rows, 288)
         self.feats = e(rows, 1536)
-        self.qkv, self.att = e(rows, 384), e(rows, 128)
+        self.qkv, self.qkv2 = e(rows, 384), e(rows, 384)
         self.upd = e(rows, 8)
         self.quat, self.rot, self.trans = e(rows, 4), e(rows, 9), e(rows, 3)
         self.n64, self.pre = e(rows, 64), e(rows, 512)
@@ -180,40 +180,49 @@ class DenoiseEngine:
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
-            # s = LN(s + mask * linear_out(feats))                                   ga.py:103-104
-            plan.append(lin(self.feats, w[f"{b}.linear_out.w"], w[f"{b}.linear_out.b"], self.s, 128, 1536,
-                            mask_pre=True, residual=self.s, ln=(w[f"{b}.ipa_ln.w"], w[f"{b}.ipa_ln.b"])))
-            # 2-layer post-LN transformer encoder over the residue axis             ga.py:105-106
-            src = self.s
+            # ---- fused node track: 3 launches (csrc/node_track.hip) ----
+            ha = _capi.NodeHeadArgs()
+            ha.feats, ha.s_in, ha.mask = self.feats.data_ptr(), self.s.data_ptr(), self.mask.data_ptr()
+            ha.w_out, ha.b_out = w[f"{b}.linear_out.w"].data_ptr(), w[f"{b}.linear_out.b"].data_ptr()
+            ha.ln_g, ha.ln_b = w[f"{b}.ipa_ln.w"].data_ptr(), w[f"{b}.ipa_ln.b"].data_ptr()
+            ha.w_in, ha.b_in = w[f"{b}.0.in.w"].data_ptr(), w[f"{b}.0.in.b"].data_ptr()
+            ha.s_ipa, ha.qkv, ha.rows = self.s.data_ptr(), self.qkv.data_ptr(), rows
+            self._keep.append(ha)
+            plan.append((lib.pf_node_head_fwd, C.byref(ha), "pf_node_head_fwd"))
             for l in range(2):
-                plan.append(lin(src, w[f"{b}.{l}.in.w"], w[f"{b}.{l}.in.b"], self.qkv, 384, 128))
-                sa = _capi.SeqAttnArgs()
-                sa.qkv, sa.mask, sa.out, sa.B, sa.L = self.qkv.data_ptr(), self.mask.data_ptr(), self.att.data_ptr(), B, L
-                self._keep.append(sa)
-                plan.append((lib.pf_seq_attn_fwd, C.byref(sa), "pf_seq_attn_fwd"))
-                plan.append(lin(self.att, w[f"{b}.{l}.out.w"], w[f"{b}.{l}.out.b"], self.u, 128, 128,
-                                residual=src, ln=(w[f"{b}.{l}.norm1.w"], w[f"{b}.{l}.norm1.b"])))
-                plan.append(lin(self.u, w[f"{b}.{l}.linear1.w"], w[f"{b}.{l}.linear1.b"], self.ta, 128, 128, relu=True))
-                plan.append(lin(self.ta, w[f"{b}.{l}.linear2.w"], w[f"{b}.{l}.linear2.b"], self.v, 128, 128,
-                                residual=self.u, ln=(w[f"{b}.{l}.norm2.w"], w[f"{b}.{l}.norm2.b"])))
-                src = self.v
-            plan.append(lin(self.v, w[f"{b}.post.w"], w[f"{b}.post.b"], self.s, 128, 128, residual=self.s))   # ga.py:107
-            # node transition + mask                                                 ga.py:108-109
-            plan.append(lin(self.s, w[f"{b}.nt.linear_1.w"], w[f"{b}.nt.linear_1.b"], self.ta, 128, 128, relu=True))
-            plan.append(lin(self.ta, w[f"{b}.nt.linear_2.w"], w[f"{b}.nt.linear_2.b"], self.tb, 128, 128, relu=True))
-            plan.append(lin(self.tb, w[f"{b}.nt.linear_3.w"], w[f"{b}.nt.linear_3.b"], self.s, 128, 128,
-                            residual=self.s, ln=(w[f"{b}.nt.ln.w"], w[f"{b}.nt.ln.b"]), mask_post=True))
-            # backbone update                                                         ga.py:110-113
-            plan.append(lin(self.s, w[f"{b}.bb.w"], w[f"{b}.bb.b"], self.upd, 6, 128))
-            ra = _capi.RigidUpdateArgs()
-            ra.quat_in, ra.rot_in, ra.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
-            ra.upd, ra.ldu, ra.mask = self.upd.data_ptr(), 8, self.mask.data_ptr()
-            ra.quat_out, ra.rot_out, ra.trans_out, ra.n = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr(), rows
-            self._keep.append(ra)
-            plan.append((lib.pf_rigid_update_fwd, C.byref(ra), "pf_rigid_update_fwd"))
+                ta = _capi.NodeTfmrArgs()
+                ta.qkv = (self.qkv if l == 0 else self.qkv2).data_ptr()
+                ta.resid = (self.s if l == 0 else self.v).data_ptr()
+                ta.mask = self.mask.data_ptr()
+                ta.w_o, ta.b_o = w[f"{b}.{l}.out.w"].data_ptr(), w[f"{b}.{l}.out.b"].data_ptr()
+                ta.n1_g, ta.n1_b = w[f"{b}.{l}.norm1.w"].data_ptr(), w[f"{b}.{l}.norm1.b"].data_ptr()
+                ta.w_1, ta.b_1 = w[f"{b}.{l}.linear1.w"].data_ptr(), w[f"{b}.{l}.linear1.b"].data_ptr()
+                ta.w_2, ta.b_2 = w[f"{b}.{l}.linear2.w"].data_ptr(), w[f"{b}.{l}.linear2.b"].data_ptr()
+                ta.n2_g, ta.n2_b = w[f"{b}.{l}.norm2.w"].data_ptr(), w[f"{b}.{l}.norm2.b"].data_ptr()
+                ta.B, ta.L = B, L
+                if l == 0:
+                    ta.last = 0
+                    ta.w_in_next, ta.b_in_next = w[f"{b}.1.in.w"].data_ptr(), w[f"{b}.1.in.b"].data_ptr()
+                    ta.qkv_out, ta.v_out = self.qkv2.data_ptr(), self.v.data_ptr()
+                else:
+                    ta.last = 1
+                    ta.s_ipa, ta.s_out = self.s.data_ptr(), self.s.data_ptr()
+                    ta.w_post, ta.b_post = w[f"{b}.post.w"].data_ptr(), w[f"{b}.post.b"].data_ptr()
+                    ta.w_t1, ta.b_t1 = w[f"{b}.nt.linear_1.w"].data_ptr(), w[f"{b}.nt.linear_1.b"].data_ptr()
+                    ta.w_t2, ta.b_t2 = w[f"{b}.nt.linear_2.w"].data_ptr(), w[f"{b}.nt.linear_2.b"].data_ptr()
+                    ta.w_t3, ta.b_t3 = w[f"{b}.nt.linear_3.w"].data_ptr(), w[f"{b}.nt.linear_3.b"].data_ptr()
+                    ta.nt_g, ta.nt_b = w[f"{b}.nt.ln.w"].data_ptr(), w[f"{b}.nt.ln.b"].data_ptr()
+                    ta.w_bb, ta.b_bb = w[f"{b}.bb.w"].data_ptr(), w[f"{b}.bb.b"].data_ptr()
+                    ta.quat_in, ta.rot_in, ta.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
+                    ta.quat_out, ta.rot_out, ta.trans_out = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr()
+                    ta.has_et = int(b < N_BLOCKS - 1)
+                    if ta.has_et:
+                        ta.w_init, ta.b_init = w[f"{b}.et.init.w"].data_ptr(), w[f"{b}.et.init.b"].data_ptr()
+                        ta.w_pre, ta.b_pre = w[f"{b}.et.pre.w"].data_ptr(), w[f"{b}.et.pre.b"].data_ptr()
+                        ta.pre = self.pre.data_ptr()
+                self._keep.append(ta)
+                plan.append((lib.pf_node_tfmr_fwd, C.byref(ta), "pf_node_tfmr_fwd"))
             if b < N_BLOCKS - 1:                                                     # ga.py:115-118
-                plan.append(lin(self.s, w[f"{b}.et.init.w"], w[f"{b}.et.init.b"], self.n64, 64, 128))
-                plan.append(lin(self.n64, w[f"{b}.et.pre.w"], w[f"{b}.et.pre.b"], self.pre, 512, 64))
                 et = _capi.EdgeTransitionArgs()
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
                 et.w1, et.w2, et.b2 = w[f"{b}.et.w1"].data_ptr(), w[f"{b}.et.w2"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
