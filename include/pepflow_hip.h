@@ -47,6 +47,9 @@ int pf_abi_version(void);
 /* MFMA fragment-layout self test: C[16,16] = A[16,K] * B[16,K]^T through the same tile
  * primitive every GEMM below uses.  K multiple of 16. */
 int pf_selftest_mfma(const float* a, const float* b, float* c, int K, pf_stream_t stream);
+/* Cross-lane primitive self test (DPP / permlane swaps used by every reduction): in[64] -> out[10][64] =
+ * lane^1, lane^2, lane^4, lane^8 values; v+v[lane^16]; v+v[lane^32]; 16-lane row sum; wave sum; wave max; row max. */
+int pf_selftest_lanes(const float* in, float* out, pf_stream_t stream);
 
 /* ---- fused row-linear -------------------------------------------------------------------
  * y = epilogue(x W^T + bias), replaces torch.nn.Linear / ipa_pytorch.Linear (ipa_pytorch.py:116-181)
@@ -191,14 +194,17 @@ int pf_rigid_update_fwd(const pf_rigid_update_args* a, pf_stream_t stream);
 /* ---- EdgeTransition: ipa_pytorch.py:233-248 + edge mask ga.py:118.  The 192-wide concat
  * [z, n_i, n_j] is never built: pre[B*L,512] holds the per-residue terms
  *   a = W1[:,64:128] n, c = W1[:,128:192] n + b1, d = Wf[:,64:128] n, e = Wf[:,128:192] n + bf
- * (computed with pf_linear_fwd) and only the z part goes through the per-pair GEMMs. */
+ * (pf_node_tfmr_fwd tail, or pf_linear_fwd) and only the z part goes through the per-pair GEMMs.
+ * Weights are passed PRE-SPLIT for the split-precision MFMA path: each *_f16 buffer holds two f16
+ * planes [2][N][K]: plane 0 = f16(w), plane 1 = f16((w - plane0) * 2048)  (see csrc/edge_transition.hip). */
 typedef struct {
     const float* z_in;             /* [B*L*L,64] */
     float* z_out;                  /* may alias z_in */
     const float* pre;              /* [B*L,512] */
-    const float* w1;               /* trunk.0.weight [192,192] (columns 0..63 used) */
-    const float* w2; const float* b2; /* trunk.2 */
-    const float* wf;               /* final_layer.weight [64,192] */
+    const void* w1z_f16;           /* trunk.0.weight[:, :64]   -> [2][192][64]  f16 */
+    const void* w2_f16;            /* trunk.2.weight           -> [2][192][192] f16 */
+    const float* b2;               /* trunk.2.bias [192] */
+    const void* wf_f16;            /* final_layer.weight       -> [2][64][192]  f16 */
     const float* ln_g; const float* ln_b;
     const float* mask;             /* [B*L] */
     int B, L;

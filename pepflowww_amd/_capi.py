@@ -50,7 +50,7 @@ class RigidUpdateArgs(C.Structure):
 
 
 class EdgeTransitionArgs(C.Structure):
-    _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1", _fp), ("w2", _fp), ("b2", _fp), ("wf", _fp),
+    _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1z_f16", _fp), ("w2_f16", _fp), ("b2", _fp), ("wf_f16", _fp),
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i)]
 
 
@@ -99,6 +99,7 @@ class NodeTfmrArgs(C.Structure):
 _SIGNATURES = {
     "pf_abi_version": ([], _i),
     "pf_selftest_mfma": ([_fp, _fp, _fp, _i, _fp], _i),
+    "pf_selftest_lanes": ([_fp, _fp, _fp], _i),
     "pf_linear_fwd": ([C.POINTER(LinearArgs), _fp], _i),
     "pf_embed_inputs_fwd": ([C.POINTER(EmbedArgs), _fp], _i),
     "pf_ipa_points_fwd": ([C.POINTER(IpaPointsArgs), _fp], _i),

@@ -15,16 +15,55 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane primitives on DPP / permlane (VALU speed) --------------------------------------------
+// hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, ~100 cycles of dependent latency per step);
+// the reductions in these kernels are latency chains, so they use DPP row operations for lanes within a
+// 16-lane row and gfx950's v_permlane16_swap / v_permlane32_swap across rows instead.
+template <int CTRL, int BANK = 0xF>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v, v); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v, v); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor4(float v) {                                   // row_shl:4 | row_shr:4 by bank
+    float t = dpp_mov<0x104, 0x5>(v, v);
+    return dpp_mov<0x114, 0xA>(t, v);
+}
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_mov<0x128>(v, v); }    // row_ror:8
+template <int OFF> __device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (OFF == 1) return lane_xor1(v);
+    else if constexpr (OFF == 2) return lane_xor2(v);
+    else if constexpr (OFF == 4) return lane_xor4(v);
+    else return lane_xor8(v);
+}
+// value of lane^16 / lane^32 SUMMED (resp. MAXed) with the own value, for all 64 lanes
+__device__ __forceinline__ float sum_xor16(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_xor16(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum / max over the 16 lanes of a row (every lane gets the result); same tree as xor 8,4,2,1
+__device__ __forceinline__ float row16_sum(float v) {
+    v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, lane_xor8(v)); v = fmaxf(v, lane_xor4(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, lane_xor1(v));
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return sum_xor32(sum_xor16(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return max_xor32(max_xor16(row16_max(v))); }
 
 // One K=16 slice of a [16*MT x 16*NT] tile product on one wave.
 //   a[mt] : float4 of A[row = 16*mt + (lane&15)][k0 + 4*(lane>>4) + 0..3]
@@ -49,9 +88,9 @@ __device__ __forceinline__ void mfma_slice(const float4 (&a)[MT], const float4 (
 // cold, and the small GEMMs of the node track are pure latency chains unless several slices are in flight,
 // so: prefetch() is called BEFORE the activation tile is staged / the barrier, and the ring is refilled as
 // soon as a slice has been consumed.  All ring indices are compile-time constants (no scratch).
-constexpr int PF_DEPTH = 4;
-
-template <int NT>
+// Depth rule of thumb: one slice feeds 4*MT*NT MFMAs (32 cycles each); the ring must cover ~1 us of L2/MALL
+// latency, so wide tiles (EdgeTransition: 48 MFMAs/slice) need 4 slices, 16-row single-tile stages need 8-16.
+template <int NT, int PF_DEPTH = 4>
 struct BStream {
     const float* wrow[NT];
     bool wok[NT];
@@ -85,8 +124,8 @@ struct BStream {
 // acc[MT][NT] += A_lds[16*MT rows][16*count] * W[:, 16*slice0 ...]^T for one wave; `bs` must have been
 // init()+prefetch()ed and slices [0, slice0) already consumed (slice0 % PF_DEPTH == 0).
 //   A_lds : LDS tile holding K-slices slice0.. as columns 0.., row stride lda floats (multiple of 4)
-template <int MT, int NT>
-__device__ __forceinline__ void gemm_ldsA_stream(const float* __restrict__ A_lds, int lda, BStream<NT>& bs,
+template <int MT, int NT, int PF_DEPTH>
+__device__ __forceinline__ void gemm_ldsA_stream(const float* __restrict__ A_lds, int lda, BStream<NT, PF_DEPTH>& bs,
                                                  f32x4 (&acc)[MT][NT], int slice0, int count) {
     const int lane = threadIdx.x & 63;
     const float* arow = A_lds + (lane & 15) * lda + 4 * (lane >> 4);
@@ -115,7 +154,7 @@ __device__ __forceinline__ void gemm_ldsA_glbB(const float* __restrict__ A_lds, 
     BStream<NT> bs;
     bs.init(W, ldw, n0, n_valid, K);
     bs.prefetch();
-    gemm_ldsA_stream<MT, NT>(A_lds, lda, bs, acc, 0, bs.nslices);
+    gemm_ldsA_stream<MT, NT, 4>(A_lds, lda, bs, acc, 0, bs.nslices);
 }
 
 template <int MT, int NT>

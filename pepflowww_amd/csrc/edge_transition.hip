@@ -6,120 +6,218 @@
 //   y = Wf (h2 + x) + bf;  z' = LayerNorm(y) * m_i m_j
 //
 // MI355X mapping
-//   * the n_i / n_j parts of W1 x and Wf x are per-RESIDUE terms (pre[B*L,512], computed by
-//     pf_linear_fwd), so only the 64-wide z part goes through per-pair GEMMs:
-//     131 kFLOP/pair instead of the reference's 172 kFLOP, and the [B*L*L,192] concat never
-//     exists in HBM;
-//   * a workgroup (4 waves) owns 64 consecutive pairs of the flattened [B*L*L] axis: its z tile
-//     is one contiguous 16 KiB block, read once with coalesced float4 loads into LDS and written
-//     once at the end -> algorithmic HBM traffic 512 B/pair;
-//   * all three GEMMs run on fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32): activations
-//     (z, h1, h2) live in LDS as A operands, each wave owns a column slab of the weights and
-//     streams ONLY that slab from global/L2 as B operands (no redundant weight traffic in a WG);
+//   * the n_i / n_j parts of W1 x and Wf x are per-RESIDUE terms (pre[B*L,512], produced by the fused
+//     node-track tail), so only the 64-wide z part goes through per-pair GEMMs: 131 kFLOP/pair instead
+//     of the reference's 172 kFLOP, and the [B*L*L,192] concat never exists in HBM;
+//   * a workgroup (4 waves) owns 64 consecutive pairs of the flattened [B*L*L] axis: its z tile is one
+//     contiguous 16 KiB block, read once (coalesced float4) and written once -> 512 B/pair of HBM traffic;
+//   * SPLIT-PRECISION MFMA: gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the f16 rate, so every
+//     fp32 operand x is carried as two f16 planes  x = hi + lo/2048  (hi = f16(x), lo = f16((x-hi)*2048),
+//     22-23 significant bits) and every product as three v_mfma_f32_16x16x32_f16:
+//         hi*hi -> acc_main ;  hi*lo + lo*hi -> acc_corr ;  result = acc_main + acc_corr/2048
+//     (fp32 accumulation inside the MFMA; the dropped lo*lo term is 2^-22 relative).  3 MFMAs of K=32 replace
+//     8 fp32 MFMAs of K=4: ~4.5x the fp32 matrix rate at fp32-class accuracy (tests: 1e-4 relative
+//     end-to-end against the fp32 reference; measured ~1e-6 on this kernel);
+//   * operands: activations (z, h1, h2) live in LDS as hi/lo f16 planes; each wave owns a slab of output
+//     features and streams ONLY that slab of the host-pre-split weights from global/L2.  The product is
+//     computed transposed (features x pairs), so a lane's 4 accumulator registers are 4 CONSECUTIVE features
+//     of one pair: they are re-split and stored to LDS with one 8-byte write per plane, directly in the
+//     layout the next GEMM reads;
 //   * LayerNorm + mask + coalesced store fused in the epilogue.
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
 namespace {
 
-constexpr int P = 64;          // pairs per workgroup
-constexpr int HID = 192;
-constexpr int LDH = HID + 4;   // 196
-constexpr int LDZ = 64 + 4;    // 68
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-struct RowInfo { int bi, bj; };
+constexpr int P = 64;            // pairs per workgroup
+constexpr int HID = 192;
+constexpr int LDHh = HID + 8;    // f16 row stride of the hidden planes (400 B: conflict-free b128 reads)
+constexpr int LDZh = 64 + 8;     // f16 row stride of the z planes
+constexpr int LDY = 68;          // fp32 row stride of the pre-LayerNorm tile
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        lo[e] = (_Float16)((v[e] - (float)h) * LO_SCALE);
+    }
+}
+
+// acc_main/acc_corr[WT][PT] += W[n0 + 16*wt + r][:K] (x) X[16*pt + r][:K]   (features x pairs)
+//   Wh/Wl : global f16 planes [N][ldw]      Xh/Xl : LDS f16 planes [64][ldx]
+template <int WT, int PT>
+__device__ __forceinline__ void gemm_split(const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int ldw, int n0,
+                                           const _Float16* Xh, const _Float16* Xl, int ldx, int K,
+                                           f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const _Float16* wh = Wh + (size_t)(n0 + r) * ldw + 8 * g;
+    const _Float16* wl = Wl + (size_t)(n0 + r) * ldw + 8 * g;
+    const _Float16* xh = Xh + r * ldx + 8 * g;
+    const _Float16* xl = Xl + r * ldx + 8 * g;
+    half8 bh[WT], bl[WT], nh[WT], nl[WT];
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt) {
+        bh[wt] = *reinterpret_cast<const half8*>(wh + (size_t)wt * 16 * ldw);
+        bl[wt] = *reinterpret_cast<const half8*>(wl + (size_t)wt * 16 * ldw);
+    }
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (k0 + 32 < K) {
+#pragma unroll
+            for (int wt = 0; wt < WT; ++wt) {
+                nh[wt] = *reinterpret_cast<const half8*>(wh + (size_t)wt * 16 * ldw + k0 + 32);
+                nl[wt] = *reinterpret_cast<const half8*>(wl + (size_t)wt * 16 * ldw + k0 + 32);
+            }
+        }
+        half8 ah[PT], al[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            ah[pt] = *reinterpret_cast<const half8*>(xh + pt * 16 * ldx + k0);
+            al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + k0);
+        }
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                am[wt][pt] = mfma_h(bh[wt], ah[pt], am[wt][pt]);
+                ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
+                ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
+            }
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; bl[wt] = nl[wt]; }
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transition_args a, long long npairs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Hs = smem;                    // [P][LDH]  h1, then h2, then y
-    float* Zs = smem + P * LDH;          // [P][LDZ]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* Hh = reinterpret_cast<_Float16*>(smem_raw);          // [P][LDHh] hidden hi plane
+    _Float16* Hl = Hh + P * LDHh;                                  // lo plane
+    _Float16* Zh = Hl + P * LDHh;                                  // [P][LDZh]
+    _Float16* Zl = Zh + P * LDZh;
+    float* Ys = reinterpret_cast<float*>(smem_raw);                // [P][LDY] fp32, aliases Hh/Hl after GEMM3
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const long long p0 = (long long)blockIdx.x * P;
     const int L = a.L;
     const long long LL = (long long)L * L;
+    const _Float16* w1h = reinterpret_cast<const _Float16*>(a.w1z_f16);
+    const _Float16* w1l = w1h + HID * 64;
+    const _Float16* w2h = reinterpret_cast<const _Float16*>(a.w2_f16);
+    const _Float16* w2l = w2h + HID * HID;
+    const _Float16* wfh = reinterpret_cast<const _Float16*>(a.wf_f16);
+    const _Float16* wfl = wfh + 64 * HID;
 
-    // ---- stage z tile (contiguous 64 x 64 floats) ----
+    // ---- stage z tile (contiguous 64 x 64 floats) as hi/lo f16 planes ----
     for (int idx = tid; idx < P * 16; idx += 256) {
-        int row = idx >> 4, c4 = idx & 15;
-        long long pr = p0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pr < npairs) v = *reinterpret_cast<const float4*>(a.z_in + pr * 64 + 4 * c4);
-        *reinterpret_cast<float4*>(Zs + row * LDZ + 4 * c4) = v;
+        const int row = idx >> 4, c4 = idx & 15;
+        const long long pr = p0 + row;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pr < npairs) {
+            const float4 t = *reinterpret_cast<const float4*>(a.z_in + pr * 64 + 4 * c4);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+        half4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<half4*>(Zh + row * LDZh + 4 * c4) = hi;
+        *reinterpret_cast<half4*>(Zl + row * LDZh + 4 * c4) = lo;
     }
-    // per-thread row decode for the MFMA accumulator rows: row = 16*mt + 4*g + e
-    int rbi[16], rbj[16];
+    // residue rows (b*L+i, b*L+j) of the 4 pairs this lane owns in the accumulator layout: pair = 16*pt + r
+    int rbi[4], rbj[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            long long pr = p0 + mt * 16 + g * 4 + e;
-            if (pr >= npairs) pr = npairs - 1;
-            int b = (int)(pr / LL);
-            int rem = (int)(pr - (long long)b * LL);
-            int i = rem / L, j = rem - i * L;
-            rbi[mt * 4 + e] = b * L + i;
-            rbj[mt * 4 + e] = b * L + j;
-        }
-    __syncthreads();
-
-    // ---- GEMM1: t1 = z W1z^T (K=64), wave slab = 48 columns ----
-    {
-        f32x4 acc[4][3];
-        acc_zero<4, 3>(acc);
-        gemm_ldsA_glbB<4, 3>(Zs, LDZ, a.w1, HID, wave * 48, HID, 64, acc);
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            const int n = wave * 48 + nt * 16 + r;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = mt * 16 + g * 4 + e;
-                    float v = acc[mt][nt][e] + a.pre[(size_t)rbi[mt * 4 + e] * PF_ET_PRE + n]
-                                             + a.pre[(size_t)rbj[mt * 4 + e] * PF_ET_PRE + 192 + n];
-                    Hs[row * LDH + n] = fmaxf(v, 0.f);
-                }
-        }
+    for (int pt = 0; pt < 4; ++pt) {
+        long long pr = p0 + pt * 16 + r;
+        if (pr >= npairs) pr = npairs - 1;
+        const int b = (int)(pr / LL);
+        const int rem = (int)(pr - (long long)b * LL);
+        const int i = rem / L, j = rem - i * L;
+        rbi[pt] = b * L + i;
+        rbj[pt] = b * L + j;
     }
     __syncthreads();
 
-    // ---- GEMM2: h2 = relu(h1 W2^T + b2) (K=192) ----
+    // ---- GEMM1: t1 = W1z z (K=64); wave slab = 48 features; + a_i + c_j, ReLU -> H planes ----
     {
-        f32x4 acc[4][3];
-        acc_zero<4, 3>(acc);
-        gemm_ldsA_glbB<4, 3>(Hs, LDH, a.w2, HID, wave * 48, HID, HID, acc);
+        f32x4 am[3][4], ac[3][4];
+        acc_zero<3, 4>(am);
+        acc_zero<3, 4>(ac);
+        gemm_split<3, 4>(w1h, w1l, 64, wave * 48, Zh, Zl, LDZh, 64, am, ac);
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt) {
+            const int n = wave * 48 + wt * 16 + 4 * g;           // 4 consecutive features n..n+3
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const float4 pa = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + n);
+                const float4 pc = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 192 + n);
+                float v[4];
+                v[0] = fmaxf(am[wt][pt][0] + ac[wt][pt][0] * LO_INV + pa.x + pc.x, 0.f);
+                v[1] = fmaxf(am[wt][pt][1] + ac[wt][pt][1] * LO_INV + pa.y + pc.y, 0.f);
+                v[2] = fmaxf(am[wt][pt][2] + ac[wt][pt][2] * LO_INV + pa.z + pc.z, 0.f);
+                v[3] = fmaxf(am[wt][pt][3] + ac[wt][pt][3] * LO_INV + pa.w + pc.w, 0.f);
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<half4*>(Hh + (pt * 16 + r) * LDHh + n) = hi;
+                *reinterpret_cast<half4*>(Hl + (pt * 16 + r) * LDHh + n) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- GEMM2: h2 = relu(W2 h1 + b2) (K=192) ----
+    {
+        f32x4 am[3][4], ac[3][4];
+        acc_zero<3, 4>(am);
+        acc_zero<3, 4>(ac);
+        gemm_split<3, 4>(w2h, w2l, HID, wave * 48, Hh, Hl, LDHh, HID, am, ac);
         __syncthreads();                       // every wave finished reading h1
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            const int n = wave * 48 + nt * 16 + r;
-            const float b2 = a.b2[n];
+        for (int wt = 0; wt < 3; ++wt) {
+            const int n = wave * 48 + wt * 16 + 4 * g;
+            const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + n);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    Hs[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][nt][e] + b2, 0.f);
+            for (int pt = 0; pt < 4; ++pt) {
+                float v[4];
+                v[0] = fmaxf(am[wt][pt][0] + ac[wt][pt][0] * LO_INV + b2.x, 0.f);
+                v[1] = fmaxf(am[wt][pt][1] + ac[wt][pt][1] * LO_INV + b2.y, 0.f);
+                v[2] = fmaxf(am[wt][pt][2] + ac[wt][pt][2] * LO_INV + b2.z, 0.f);
+                v[3] = fmaxf(am[wt][pt][3] + ac[wt][pt][3] * LO_INV + b2.w, 0.f);
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<half4*>(Hh + (pt * 16 + r) * LDHh + n) = hi;
+                *reinterpret_cast<half4*>(Hl + (pt * 16 + r) * LDHh + n) = lo;
+            }
         }
     }
     __syncthreads();
 
-    // ---- GEMM3: y = h2 Wf^T + z Wf[:, :64]^T + d_i + e_j ; wave slab = 16 columns ----
+    // ---- GEMM3: y = Wf h2 + Wf[:, :64] z + d_i + e_j ; wave slab = 16 features -> fp32 tile ----
     {
-        f32x4 acc[4][1];
-        acc_zero<4, 1>(acc);
-        gemm_ldsA_glbB<4, 1>(Hs, LDH, a.wf, HID, wave * 16, 64, HID, acc);
-        gemm_ldsA_glbB<4, 1>(Zs, LDZ, a.wf, HID, wave * 16, 64, 64, acc);
-        __syncthreads();                       // h2 fully consumed -> reuse Hs for y
-        const int n = wave * 16 + r;
+        f32x4 am[1][4], ac[1][4];
+        acc_zero<1, 4>(am);
+        acc_zero<1, 4>(ac);
+        gemm_split<1, 4>(wfh, wfl, HID, wave * 16, Hh, Hl, LDHh, HID, am, ac);
+        gemm_split<1, 4>(wfh, wfl, HID, wave * 16, Zh, Zl, LDZh, 64, am, ac);
+        __syncthreads();                       // h2 fully consumed -> reuse the H region for y (fp32)
+        const int n = wave * 16 + 4 * g;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[mt][0][e] + a.pre[(size_t)rbi[mt * 4 + e] * PF_ET_PRE + 384 + n]
-                                        + a.pre[(size_t)rbj[mt * 4 + e] * PF_ET_PRE + 448 + n];
-                Hs[(mt * 16 + g * 4 + e) * LDH + n] = v;
-            }
+        for (int pt = 0; pt < 4; ++pt) {
+            const float4 pd = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + 384 + n);
+            const float4 pe = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 448 + n);
+            float4 y;
+            y.x = am[0][pt][0] + ac[0][pt][0] * LO_INV + pd.x + pe.x;
+            y.y = am[0][pt][1] + ac[0][pt][1] * LO_INV + pd.y + pe.y;
+            y.z = am[0][pt][2] + ac[0][pt][2] * LO_INV + pd.z + pe.z;
+            y.w = am[0][pt][3] + ac[0][pt][3] * LO_INV + pd.w + pe.w;
+            *reinterpret_cast<float4*>(Ys + (pt * 16 + r) * LDY + n) = y;
+        }
     }
     __syncthreads();
 
@@ -131,18 +229,18 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float4 t = *reinterpret_cast<const float4*>(Hs + row * LDH + 16 * qd + 4 * c);
+            float4 t = *reinterpret_cast<const float4*>(Ys + row * LDY + 16 * qd + 4 * c);
             v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
             s += (t.x + t.y) + (t.z + t.w);
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
+        s += lane_xor1(s);
+        s += lane_xor2(s);
         const float mean = s * (1.f / 64.f);
         float q = 0.f;
 #pragma unroll
         for (int c = 0; c < 16; ++c) { float d = v[c] - mean; q += d * d; }
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
+        q += lane_xor1(q);
+        q += lane_xor2(q);
         const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
         if (pr < npairs) {
             int b = (int)(pr / LL);
@@ -168,13 +266,13 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
 }  // namespace
 
 extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream) {
-    if (!a || !a->z_in || !a->z_out || !a->pre || !a->w1 || !a->w2 || !a->b2 || !a->wf || !a->ln_g || !a->ln_b ||
-        !a->mask || a->B <= 0 || a->L <= 0)
+    if (!a || !a->z_in || !a->z_out || !a->pre || !a->w1z_f16 || !a->w2_f16 || !a->b2 || !a->wf_f16 || !a->ln_g ||
+        !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
         return PF_E_BADARG;
     const long long npairs = (long long)a->B * a->L * a->L;
     const long long nblk = (npairs + P - 1) / P;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
-    size_t lds = (size_t)(P * LDH + P * LDZ) * sizeof(float);
+    const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16);
     hipLaunchKernelGGL(edge_transition_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *a, npairs);
     PF_CHECK_LAUNCH();
     return 0;

@@ -55,29 +55,28 @@ __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1
 template <int HG> __device__ __forceinline__ int head_of_lane(int lane) {
     return HG == 8 ? ((lane & 15) >> 1) : HG == 4 ? ((lane & 15) >> 2) : ((lane & 15) >> 3);
 }
+template <int OFF, int N> __device__ __forceinline__ void reduce16_step(float (&cur)[8], int lane) {
+    if constexpr (N > 1) {
+        const bool hi = lane & OFF;
+        constexpr int half = N / 2;
+#pragma unroll
+        for (int q = 0; q < half; ++q) {
+            const float send = hi ? cur[q] : cur[half + q];
+            const float keep = hi ? cur[half + q] : cur[q];
+            cur[q] = keep + lane_xor<OFF>(send);
+        }
+    } else {
+        cur[0] += lane_xor<OFF>(cur[0]);
+    }
+}
 template <int HG> __device__ __forceinline__ float reduce16(float (&v)[HG], int lane) {
     float cur[8];
 #pragma unroll
     for (int q = 0; q < HG; ++q) cur[q] = v[q];
-    int n = HG;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        if (n > 1) {
-            const bool hi = lane & off;
-            const int half = n >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < half) {
-                    const float send = hi ? cur[q] : cur[half + q];
-                    const float keep = hi ? cur[half + q] : cur[q];
-                    cur[q] = keep + __shfl_xor(send, off, 64);
-                }
-            }
-            n = half;
-        } else {
-            cur[0] += __shfl_xor(cur[0], off, 64);
-        }
-    }
+    reduce16_step<8, HG>(cur, lane);
+    reduce16_step<4, (HG > 1 ? HG / 2 : 1)>(cur, lane);
+    reduce16_step<2, (HG > 2 ? HG / 4 : 1)>(cur, lane);
+    reduce16_step<1, (HG > 4 ? HG / 8 : 1)>(cur, lane);
     return cur[0];
 }
 
@@ -323,10 +322,8 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
 #pragma unroll
             for (int h = 0; h < HG; ++h) {
                 float4 v = zacc[h];
-                v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64);
-                v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
-                v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64);
-                v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+                v.x = sum_xor32(sum_xor16(v.x)); v.y = sum_xor32(sum_xor16(v.y));
+                v.z = sum_xor32(sum_xor16(v.z)); v.w = sum_xor32(sum_xor16(v.w));
                 if (js == 0) *reinterpret_cast<float4*>(zb + h * 64 + 4 * c4) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

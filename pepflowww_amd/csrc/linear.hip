@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
     for (int c = 0; c < nchunks; ++c) {
         float* cur = As + (c & 1) * BM * LDA;
         if (c + 1 < nchunks) fetch(c + 1);
-        gemm_ldsA_stream<MT, 2>(cur, LDA, bs, acc, c * (KC / 16), min(KC, p.K - c * KC) >> 4);
+        gemm_ldsA_stream<MT, 2, 4>(cur, LDA, bs, acc, c * (KC / 16), min(KC, p.K - c * KC) >> 4);
         if (c + 1 < nchunks) commit(As + ((c + 1) & 1) * BM * LDA);
         __syncthreads();
     }
@@ -112,8 +112,7 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
                 vals[c] = (n < p.N) ? Ys[row * LDY + n] : 0.f;
                 s += vals[c];
             }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = row16_sum(s);
             const float mean = s / (float)p.N;
             float q = 0.f;
 #pragma unroll
@@ -122,8 +121,7 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
                 const float d = (n < p.N) ? vals[c] - mean : 0.f;
                 q += d * d;
             }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            q = row16_sum(q);
             const float rstd = rsqrtf(q / (float)p.N + p.ln_eps);
             if (m < p.M) {
                 const float mk = p.mask_post ? p.row_mask[m] : 1.f;

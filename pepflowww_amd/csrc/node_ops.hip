@@ -98,19 +98,19 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(pf_seq_attn_args a) {
             m = mn;
         }
         // merge the four key-subset states of this query
-        float mt = fmaxf(m, __shfl_xor(m, 1, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 2, 64));
+        float mt = fmaxf(m, lane_xor1(m));
+        mt = fmaxf(mt, lane_xor2(mt));
         const float f = expf(m - mt);            // lanes that saw no key: m = -3e38 -> f = 0
         l *= f;
-        l += __shfl_xor(l, 1, 64);
-        l += __shfl_xor(l, 2, 64);
+        l += lane_xor1(l);
+        l += lane_xor2(l);
         const float inv = 1.f / l;
         float o[8];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
             float v = acc[c] * f;
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
+            v += lane_xor1(v);
+            v += lane_xor2(v);
             if ((c >> 3) == sub) o[c & 7] = v * inv;
         }
         if (iok) {

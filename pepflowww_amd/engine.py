@@ -22,6 +22,18 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+LO_SCALE = 2048.0
+
+
+def split_f16(w):
+    """fp32 matrix -> [2, N, K] f16 planes (hi, lo*2048) for the split-precision MFMA kernels:
+    w ~= hi + lo/2048 to 22-23 bits (layout/packing only; see csrc/edge_transition.hip)."""
+    w = _f32(w)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.to(torch.float32)) * LO_SCALE).to(torch.float16)
+    return torch.stack([hi, lo], 0).contiguous()
+
+
 class PackedWeights:
     """Kernel-friendly views/copies of the GAEncoder parameters (reference state_dict layout).
 
@@ -72,8 +84,8 @@ class PackedWeights:
                 t[f"{b}.et.init.w"], t[f"{b}.et.init.b"] = g(q + "initial_embed.weight"), g(q + "initial_embed.bias")
                 w1, b1 = g(q + "trunk.0.weight"), g(q + "trunk.0.bias")
                 wf, bf = g(q + "final_layer.weight"), g(q + "final_layer.bias")
-                t[f"{b}.et.w1"], t[f"{b}.et.wf"] = w1, wf
-                t[f"{b}.et.w2"], t[f"{b}.et.b2"] = g(q + "trunk.2.weight"), g(q + "trunk.2.bias")
+                t[f"{b}.et.w1z16"], t[f"{b}.et.wf16"] = split_f16(w1[:, :64]), split_f16(wf)
+                t[f"{b}.et.w216"], t[f"{b}.et.b2"] = split_f16(g(q + "trunk.2.weight")), g(q + "trunk.2.bias")
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
                 t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
@@ -225,8 +237,8 @@ class DenoiseEngine:
             if b < N_BLOCKS - 1:                                                     # ga.py:115-118
                 et = _capi.EdgeTransitionArgs()
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
-                et.w1, et.w2, et.b2 = w[f"{b}.et.w1"].data_ptr(), w[f"{b}.et.w2"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
-                et.wf, et.ln_g, et.ln_b = w[f"{b}.et.wf"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
+                et.w1z_f16, et.w2_f16, et.b2 = w[f"{b}.et.w1z16"].data_ptr(), w[f"{b}.et.w216"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
+                et.wf_f16, et.ln_g, et.ln_b = w[f"{b}.et.wf16"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))

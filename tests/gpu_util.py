@@ -113,10 +113,13 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L):
 
 
 def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False):
+    """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes."""
+    from pepflowww_amd.engine import split_f16
     lib = _capi.load()
     out = z if inplace else torch.full_like(z, float("nan"))
+    w1s, w2s, wfs = split_f16(w1[:, :64]), split_f16(w2), split_f16(wf)
     a = _capi.EdgeTransitionArgs()
-    a.z_in, a.z_out, a.pre, a.w1, a.w2, a.b2, a.wf = _p(z), _p(out), _p(pre), _p(w1), _p(w2), _p(b2), _p(wf)
+    a.z_in, a.z_out, a.pre, a.w1z_f16, a.w2_f16, a.b2, a.wf_f16 = _p(z), _p(out), _p(pre), _p(w1s), _p(w2s), _p(b2), _p(wfs)
     a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()

@@ -72,6 +72,26 @@ def test_mfma_fragment_layout():
         G.assert_close(c, a @ b.T, 2e-6, f"mfma K={K}")
 
 
+def test_cross_lane_primitives():
+    """DPP / permlane-swap helpers against the lane permutations they claim to implement."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn(64, generator=g)
+    dv, out = cu(v), torch.full((10, 64), float("nan"), device=G.dev())
+    _capi.check(lib.pf_selftest_lanes(dv.data_ptr(), out.data_ptr(), _capi.stream_ptr()), "selftest lanes")
+    G.sync()
+    out = out.cpu()
+    idx = torch.arange(64)
+    for row, x in enumerate((1, 2, 4, 8)):
+        assert torch.equal(out[row], v[idx ^ x]), f"lane^{x}"
+    assert torch.allclose(out[4], v + v[idx ^ 16]) and torch.allclose(out[5], v + v[idx ^ 32])
+    rows = v.view(4, 16)
+    assert torch.allclose(out[6], rows.sum(1, keepdim=True).expand(4, 16).reshape(64), atol=1e-5)
+    assert torch.allclose(out[7], v.sum().expand(64), atol=1e-5)
+    assert torch.equal(out[8], v.max().expand(64))
+    assert torch.equal(out[9], rows.max(1, keepdim=True).values.expand(4, 16).reshape(64))
+
+
 @pytest.mark.parametrize("M,N,K", [(100, 128, 640), (48, 3744, 128), (1024, 128, 1536), (77, 6, 128), (130, 384, 128),
                                     (33, 512, 64), (64, 20, 128)])
 def test_linear_plain(M, N, K):

@@ -1,0 +1,36 @@
+#!/bin/bash
+# dev-only: build a PF_PROFILE variant of the library in /tmp and print phase cycle stamps of node_tfmr block 0
+set -e
+R=$GRAFT_REPO_ROOT
+mkdir -p /tmp/pfprof/lib
+for f in selftest linear edge_transition ipa_attn node_ops flow_step encode node_track; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPF_PROFILE -c $R/pepflowww_amd/csrc/$f.hip -o /tmp/pfprof/lib/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/pfprof/libpepflow_hip.so /tmp/pfprof/lib/*.o
+cp $R/pepflowww_amd/lib/libpepflow_hip.so /tmp/pfprof/orig.so
+cp /tmp/pfprof/libpepflow_hip.so $R/pepflowww_amd/lib/libpepflow_hip.so
+python - <<'PY'
+import ctypes as C, torch, sys
+sys.path.insert(0, ".")
+import pepflowww_amd
+from pepflowww_amd import synth, _capi
+lib = _capi.load()
+dev = torch.device("cuda:0")
+m = pepflowww_amd.FlowModel(pepflowww_amd.default_config()); m.load_state_dict(synth.seeded_state_dict()); m = m.to(dev).eval()
+B, L = 16, 64
+batch = {k: v.to(dev) for k, v in synth.make_pocket_batch(B, L, 12).items()}
+with torch.no_grad():
+    R1, x1, a1, s1, node, edge = m.encode(batch)
+    eng = m.ga_encoder.engine(B, L, dev)
+    eng.bind_context(node, edge, batch["res_mask"])
+    eng.set_state(torch.full((B, 1), 0.3, device=dev), R1, x1, a1, s1)
+    for _ in range(3): eng.run()
+    torch.cuda.synchronize()
+    raw = C.CDLL(_capi.LIB_PATH)
+    out = (C.c_longlong * 16)()
+    raw.pf_debug_prof(out, 16)
+    v = list(out)
+    print("stamps (cycles rel.):", [x - v[0] for x in v[:13]])
+PY
+cp /tmp/pfprof/orig.so $R/pepflowww_amd/lib/libpepflow_hip.so
