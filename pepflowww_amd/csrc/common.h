@@ -165,4 +165,13 @@ __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][NT]) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// XCD-aware workgroup remap (MI355X: 8 XCDs, private 4 MiB L2 each; the dispatcher places block b on XCD b % 8).
+// Returns a bijective logical index such that CONSECUTIVE logical ids run on the SAME XCD, so workgroups that
+// share operands (the query tiles of one sample share its K/V/points) hit one L2 instead of eight.
+// Placement is a speed hint only -- nothing depends on it for correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, rem = nblk & 7, x = bid & 7, k = bid >> 3;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+}
+
 #define PF_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

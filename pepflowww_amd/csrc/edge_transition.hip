@@ -27,6 +27,16 @@
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
+#ifdef PF_PROFILE
+__device__ long long g_prof_et[64];
+#define PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof_et[i] = clock64(); } while (0)
+extern "C" int pf_debug_prof_et(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_et), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define PROF(i)
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -116,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     const _Float16* wfh = reinterpret_cast<const _Float16*>(a.wf_f16);
     const _Float16* wfl = wfh + 64 * HID;
 
+    PROF(0);
     // ---- stage z tile (contiguous 64 x 64 floats) as hi/lo f16 planes ----
     for (int idx = tid; idx < P * 16; idx += 256) {
         const int row = idx >> 4, c4 = idx & 15;
@@ -144,12 +155,14 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     }
     __syncthreads();
 
+    PROF(1);
     // ---- GEMM1: t1 = W1z z (K=64); wave slab = 48 features; + a_i + c_j, ReLU -> H planes ----
     {
         f32x4 am[3][4], ac[3][4];
         acc_zero<3, 4>(am);
         acc_zero<3, 4>(ac);
         gemm_split<3, 4>(w1h, w1l, 64, wave * 48, Zh, Zl, LDZh, 64, am, ac);
+        PROF(2);
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
             const int n = wave * 48 + wt * 16 + 4 * g;           // 4 consecutive features n..n+3
@@ -171,13 +184,16 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     }
     __syncthreads();
 
+    PROF(3);
     // ---- GEMM2: h2 = relu(W2 h1 + b2) (K=192) ----
     {
         f32x4 am[3][4], ac[3][4];
         acc_zero<3, 4>(am);
         acc_zero<3, 4>(ac);
         gemm_split<3, 4>(w2h, w2l, HID, wave * 48, Hh, Hl, LDHh, HID, am, ac);
+        PROF(4);
         __syncthreads();                       // every wave finished reading h1
+        PROF(5);
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
             const int n = wave * 48 + wt * 16 + 4 * g;
@@ -198,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     }
     __syncthreads();
 
+    PROF(6);
     // ---- GEMM3: y = Wf h2 + Wf[:, :64] z + d_i + e_j ; wave slab = 16 features -> fp32 tile ----
     {
         f32x4 am[1][4], ac[1][4];
@@ -205,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         acc_zero<1, 4>(ac);
         gemm_split<1, 4>(wfh, wfl, HID, wave * 16, Hh, Hl, LDHh, HID, am, ac);
         gemm_split<1, 4>(wfh, wfl, HID, wave * 16, Zh, Zl, LDZh, 64, am, ac);
+        PROF(7);
         __syncthreads();                       // h2 fully consumed -> reuse the H region for y (fp32)
         const int n = wave * 16 + 4 * g;
 #pragma unroll
@@ -221,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     }
     __syncthreads();
 
+    PROF(8);
     // ---- LayerNorm(64) + edge mask + coalesced store: 4 threads per pair row ----
     {
         const int row = tid >> 2, qd = tid & 3;
@@ -261,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
             }
         }
     }
+    PROF(9);
 }
 
 }  // namespace

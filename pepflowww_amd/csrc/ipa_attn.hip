@@ -17,6 +17,16 @@
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
+#ifdef PF_PROFILE
+__device__ long long g_prof_ipa[64];
+#define PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof_ipa[i] = clock64(); } while (0)
+extern "C" int pf_debug_prof_ipa(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_ipa), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define PROF(i)
+#endif
+
 namespace {
 
 constexpr int H = PF_HEADS, C = PF_C_HID, PQ = PF_QK_PTS, PV = PF_V_PTS;
@@ -100,19 +110,22 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
     const int tiles = (L + TI - 1) / TI;
-    const int hg = blockIdx.x % NG;
-    const int bt = blockIdx.x / NG;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);   // all query tiles / head groups of a sample on one XCD
+    const int hg = lid % NG;
+    const int bt = lid / NG;
     const int b = bt / tiles;
     const int i0 = (bt - b * tiles) * TI;
     const int h0 = hg * HG;                       // first head of this workgroup
     const size_t rowb = (size_t)b * L;
 
+    PROF(0);
     // ---- phase 0: query points of this head group -> LDS ----
     for (int idx = tid; idx < TI * HG * 24; idx += 256) {
         const int ti = idx / (HG * 24), c = idx - ti * (HG * 24);
         QP[idx] = (i0 + ti < L) ? a.qp[(rowb + i0 + ti) * 192 + h0 * 24 + c] : 0.f;
     }
 
+    PROF(1);
     // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) for the HG heads.  wave w -> query rows 4w..4w+3 ----
     {
         const int c4 = lane & 15, js = lane >> 4;
@@ -123,30 +136,46 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
         const bool writer = (lane & (16 / HG - 1)) == 0;
         const float bb = a.b_b[h0 + hsel];
         const float s13 = 0.57735026918962576f;   // sqrt(1/3)
+        // z rows are streamed in batches of ZB loads per lane: one memory latency per batch, not per pair
+        constexpr int ZBATCH = 8;
         for (int t4 = 0; t4 < 4; ++t4) {
             const int ti = wave * 4 + t4;
             const int i = i0 + ti;
-            const float* zrow = a.z + ((rowb + (i < L ? i : L - 1)) * L) * 64;
-            for (int j0 = 0; j0 < LP; j0 += 4) {
-                const int j = j0 + js;
-                float4 zq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j < L) zq = *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4);
-                float v[HG];
+            const float* zrow = a.z + ((rowb + (i < L ? i : L - 1)) * L) * 64 + 4 * c4;
+            for (int jb = 0; jb < LP; jb += 4 * ZBATCH) {
+                float4 zq[ZBATCH];
 #pragma unroll
-                for (int h = 0; h < HG; ++h) v[h] = wb[h].x * zq.x + wb[h].y * zq.y + wb[h].z * zq.z + wb[h].w * zq.w;
-                const float tot = reduce16<HG>(v, lane);
-                if (writer) S[(ti * HG + hsel) * LDS_S + j] = (j < L) ? s13 * (tot + bb) : 0.f;
+                for (int u = 0; u < ZBATCH; ++u) {
+                    const int j = jb + 4 * u + js;
+                    zq[u] = (j < L) ? *reinterpret_cast<const float4*>(zrow + (size_t)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < ZBATCH; ++u) {
+                    const int j = jb + 4 * u + js;
+                    float v[HG];
+#pragma unroll
+                    for (int h = 0; h < HG; ++h)
+                        v[h] = wb[h].x * zq[u].x + wb[h].y * zq[u].y + wb[h].z * zq[u].z + wb[h].w * zq[u].w;
+                    const float tot = reduce16<HG>(v, lane);
+                    if (writer && j < LP) S[(ti * HG + hsel) * LDS_S + j] = (j < L) ? s13 * (tot + bb) : 0.f;
+                }
             }
         }
     }
     __syncthreads();
 
+    PROF(2);
     // ---- phase B: scalar qk (MFMA) + point term + mask ----
     const float scale_qk = 0.051031036307982884f;            // sqrt(1/(3*128))
     const float scale_pt = 0.09622504486493763f;              // sqrt(1/(3*(8*9/2)))
     {
         const int hh0 = (wave / WPH) * HPW;
         const int tile_off = wave % WPH;
+        // query-row masks are tile-invariant: loaded ONCE.  (A global load issued inside the tile loop would make
+        // its s_waitcnt drain the whole in-order vmcnt queue, i.e. the next tile's prefetch, every iteration.)
+        float mi4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = i0 + 4 * g + e; mi4[e] = (i < L) ? a.mask[rowb + i] : 0.f; }
         for (int hq = 0; hq < HPW; ++hq) {
             const int hh = hh0 + hq, h = h0 + hh;
             const float gamma = softplusf(a.head_w[h]) * scale_pt;
@@ -158,32 +187,42 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
                 for (int s = 0; s < 8; ++s)
                     qf[s] = (i < L) ? *reinterpret_cast<const float4*>(qrow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            for (int j0 = 16 * tile_off; j0 < LP; j0 += 16 * WPH) {
+            // operands of key tile j0: 8 K fragments, 8 key points (24 floats), key mask; next tile prefetched
+            auto loadk = [&](int j0, float4 (&kf)[8], float4 (&kp4)[6], float& mj) {
                 const int j = j0 + r;
                 const bool jok = j < L;
                 const float* krow = a.proj + (rowb + (jok ? j : 0)) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
-                float4 kf[8];
+                const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    kf[s] = jok ? *reinterpret_cast<const float4*>(krow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float kpt[24];
-                {
-                    const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
+                for (int s8 = 0; s8 < 8; ++s8)
+                    kf[s8] = jok ? *reinterpret_cast<const float4*>(krow + 16 * s8) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        float4 t = *reinterpret_cast<const float4*>(kp + 4 * q);
-                        kpt[4 * q] = t.x; kpt[4 * q + 1] = t.y; kpt[4 * q + 2] = t.z; kpt[4 * q + 3] = t.w;
-                    }
+                for (int q = 0; q < 6; ++q) kp4[q] = *reinterpret_cast<const float4*>(kp + 4 * q);
+                mj = jok ? a.mask[rowb + j] : 0.f;
+            };
+            float4 kf[8], kp4[6];
+            float mj;
+            loadk(16 * tile_off, kf, kp4, mj);
+            for (int j0 = 16 * tile_off; j0 < LP; j0 += 16 * WPH) {
+                const int j = j0 + r;
+                const bool jok = j < L;
+                float4 kfn[8], kpn[6];
+                float mjn = 0.f;
+                const bool more = j0 + 16 * WPH < LP;
+                if (more) loadk(j0 + 16 * WPH, kfn, kpn, mjn);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: MFMA dependent latency 40 > issue 32
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8 += 2) {
+                    acc = mfma16(qf[s8].x, kf[s8].x, acc);
+                    acc2 = mfma16(qf[s8 + 1].x, kf[s8 + 1].x, acc2);
+                    acc = mfma16(qf[s8].y, kf[s8].y, acc);
+                    acc2 = mfma16(qf[s8 + 1].y, kf[s8 + 1].y, acc2);
+                    acc = mfma16(qf[s8].z, kf[s8].z, acc);
+                    acc2 = mfma16(qf[s8 + 1].z, kf[s8 + 1].z, acc2);
+                    acc = mfma16(qf[s8].w, kf[s8].w, acc);
+                    acc2 = mfma16(qf[s8 + 1].w, kf[s8 + 1].w, acc2);
                 }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    acc = mfma16(qf[s].x, kf[s].x, acc);
-                    acc = mfma16(qf[s].y, kf[s].y, acc);
-                    acc = mfma16(qf[s].z, kf[s].z, acc);
-                    acc = mfma16(qf[s].w, kf[s].w, acc);
-                }
-                const float mj = jok ? a.mask[rowb + j] : 0.f;
+                acc += acc2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ti = 4 * g + e;
@@ -191,38 +230,48 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
                     float d2 = 0.f;
 #pragma unroll
                     for (int q = 0; q < 6; ++q) {
-                        float4 t = *reinterpret_cast<const float4*>(qp + 4 * q);
-                        float d0 = t.x - kpt[4 * q], d1 = t.y - kpt[4 * q + 1], dd2 = t.z - kpt[4 * q + 2], d3 = t.w - kpt[4 * q + 3];
+                        const float4 t = *reinterpret_cast<const float4*>(qp + 4 * q);
+                        const float d0 = t.x - kp4[q].x, d1 = t.y - kp4[q].y, dd2 = t.z - kp4[q].z, d3 = t.w - kp4[q].w;
                         d2 += d0 * d0; d2 += d1 * d1; d2 += dd2 * dd2; d2 += d3 * d3;
                     }
-                    const int i = i0 + ti;
-                    const float mi = (i < L) ? a.mask[rowb + i] : 0.f;
                     if (jok) {
                         float* sp = S + (ti * HG + hh) * LDS_S + j;
                         float v = acc[e] * scale_qk + *sp;
                         v = v + (-0.5f) * (gamma * d2);
-                        v = v + 1e5f * (mi * mj - 1.f);
+                        v = v + 1e5f * (mi4[e] * mj - 1.f);
                         *sp = v;
                     }
+                }
+                if (more) {
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) kf[s8] = kfn[s8];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) kp4[q] = kpn[q];
+                    mj = mjn;
                 }
             }
         }
     }
     __syncthreads();
-    // softmax over j for the 16*HG (ti,h) rows, 4 waves interleaved
-    for (int rr = wave; rr < TI * HG; rr += 4) {
-        float* sp = S + rr * LDS_S;
-        float m = -3.0e38f;
-        for (int j = lane; j < L; j += 64) m = fmaxf(m, sp[j]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int j = lane; j < L; j += 64) { float e = expf(sp[j] - m); sp[j] = e; sum += e; }
-        sum = wave_sum(sum);
-        const float inv = 1.f / sum;
-        for (int j = lane; j < L; j += 64) sp[j] *= inv;
+    PROF(3);
+    // softmax over j: 8 (ti,h) rows per wave at a time, 8 lanes per row (DPP xor-1/2/4 reductions)
+    {
+        const int sub = lane & 7;
+        for (int rr = wave * 8 + (lane >> 3); rr < TI * HG; rr += 32) {
+            float* sp = S + rr * LDS_S;
+            float m = -3.0e38f;
+            for (int j = sub; j < L; j += 8) m = fmaxf(m, sp[j]);
+            m = fmaxf(m, lane_xor1(m)); m = fmaxf(m, lane_xor2(m)); m = fmaxf(m, lane_xor4(m));
+            float sum = 0.f;
+            for (int j = sub; j < L; j += 8) { const float e = expf(sp[j] - m); sp[j] = e; sum += e; }
+            sum += lane_xor1(sum); sum += lane_xor2(sum); sum += lane_xor4(sum);
+            const float inv = 1.f / sum;
+            for (int j = sub; j < L; j += 8) sp[j] *= inv;
+        }
     }
     __syncthreads();
 
+    PROF(4);
     // ---- phase C: [o | o_pt] = P [V | Vp] on MFMA ----
     {
         const int hh0 = (wave / WPH) * HPW;
@@ -233,31 +282,44 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
 #pragma unroll
             for (int n = 0; n < NTC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* prow = S + (r * HG + hh) * LDS_S + 4 * g;
-            for (int k0 = 0; k0 < LP; k0 += 16) {
-                const float4 pa = *reinterpret_cast<const float4*>(prow + k0);
+            // B operands of one K=16 step: for every column tile 4 key rows x 1 column (V) or 1 point coordinate (Vp)
+            auto loadv = [&](int k0, float (&vb)[NTC][4]) {
                 int jr[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { int j = k0 + 4 * g + t; jr[t] = j < L ? j : L - 1; }
+                for (int t = 0; t < 4; ++t) { const int j = k0 + 4 * g + t; jr[t] = j < L ? j : L - 1; }
 #pragma unroll
                 for (int n = 0; n < NTC; ++n) {
                     const int nt = tb + n;                       // wave-uniform
-                    float vb[4];
-                    if (nt < 8) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            vb[t] = a.proj[(rowb + jr[t]) * a.ldp + OFF_KV + h * 2 * C + C + nt * 16 + r];
-                    } else if (nt < 11) {
-                        const int c = (nt - 8) * 16 + r;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            vb[t] = (c < 36) ? a.vp[(rowb + jr[t]) * 288 + h * 36 + c] : 0.f;
-                    } else {
-                        continue;
+                    for (int t = 0; t < 4; ++t) {
+                        float v = 0.f;
+                        if (nt < 8) v = a.proj[(rowb + jr[t]) * a.ldp + OFF_KV + h * 2 * C + C + nt * 16 + r];
+                        else if (nt < 11) { const int c = (nt - 8) * 16 + r; if (c < 36) v = a.vp[(rowb + jr[t]) * 288 + h * 36 + c]; }
+                        vb[n][t] = v;
                     }
-                    acc[n] = mfma16(pa.x, vb[0], acc[n]);
-                    acc[n] = mfma16(pa.y, vb[1], acc[n]);
-                    acc[n] = mfma16(pa.z, vb[2], acc[n]);
-                    acc[n] = mfma16(pa.w, vb[3], acc[n]);
+                }
+            };
+            float vb[NTC][4];
+            loadv(0, vb);
+            for (int k0 = 0; k0 < LP; k0 += 16) {
+                float vn[NTC][4];
+                const bool more = k0 + 16 < LP;
+                if (more) loadv(k0 + 16, vn);
+                const float4 pa = *reinterpret_cast<const float4*>(prow + k0);
+#pragma unroll
+                for (int n = 0; n < NTC; ++n) {
+                    if (tb + n < 11) {
+                        acc[n] = mfma16(pa.x, vb[n][0], acc[n]);
+                        acc[n] = mfma16(pa.y, vb[n][1], acc[n]);
+                        acc[n] = mfma16(pa.z, vb[n][2], acc[n]);
+                        acc[n] = mfma16(pa.w, vb[n][3], acc[n]);
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int n = 0; n < NTC; ++n)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) vb[n][t] = vn[n][t];
                 }
             }
 #pragma unroll
@@ -278,6 +340,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     }
     __syncthreads();
 
+    PROF(5);
     // ---- phase D1: o_pt -> local frame (invert_apply) + norms ----
     for (int idx = tid; idx < TI * HG * PV; idx += 256) {
         const int ti = idx / (HG * PV), hp = idx - ti * (HG * PV);     // hp = hh*12 + p
@@ -297,10 +360,16 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
         f[1312 + hp] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
     }
 
+    PROF(6);
     // ---- phase D2: zbar[h][c] = sum_j P[h][j] z[i][j][c] ; o_pair = W_dz zbar + b_dz ----
     {
         const int c4 = lane & 15, js = lane >> 4;
         float* zb = ZB + wave * HG * 64;
+        // down_z row d = lane & 15 of this lane's o_pair outputs, kept in registers for all four query rows
+        float4 wdz[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wdz[c] = *reinterpret_cast<const float4*>(a.w_dz + (lane & 15) * 64 + 4 * c);
+        const float bdz = a.b_dz[lane & 15];
         for (int t4 = 0; t4 < 4; ++t4) {
             const int ti = wave * 4 + t4, i = i0 + ti;
             if (i >= L) continue;                          // wave-uniform
@@ -308,14 +377,23 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
             float4 zacc[HG];
 #pragma unroll
             for (int h = 0; h < HG; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j0 = 0; j0 < L; j0 += 4) {
-                const int j = j0 + js;
-                if (j < L) {
-                    const float4 zq = *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4);
+            constexpr int ZBATCH = 8;
+            for (int jb = 0; jb < L; jb += 4 * ZBATCH) {
+                float4 zq[ZBATCH];
 #pragma unroll
-                    for (int h = 0; h < HG; ++h) {
-                        const float pw = S[(ti * HG + h) * LDS_S + j];
-                        zacc[h].x += pw * zq.x; zacc[h].y += pw * zq.y; zacc[h].z += pw * zq.z; zacc[h].w += pw * zq.w;
+                for (int u = 0; u < ZBATCH; ++u) {
+                    const int j = jb + 4 * u + js;
+                    zq[u] = (j < L) ? *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < ZBATCH; ++u) {
+                    const int j = jb + 4 * u + js;
+                    if (j < L) {
+#pragma unroll
+                        for (int h = 0; h < HG; ++h) {
+                            const float pw = S[(ti * HG + h) * LDS_S + j];
+                            zacc[h].x += pw * zq[u].x; zacc[h].y += pw * zq[u].y; zacc[h].z += pw * zq[u].z; zacc[h].w += pw * zq[u].w;
+                        }
                     }
                 }
             }
@@ -328,19 +406,22 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d)
+            for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
                 const int hh = o >> 4, d = o & 15;
-                float acc = a.b_dz[d];
-                const float* w = a.w_dz + d * 64;
+                float acc = bdz;
                 const float* zz = zb + hh * 64;
-#pragma unroll 8
-                for (int c = 0; c < 64; ++c) acc += w[c] * zz[c];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float4 zv = *reinterpret_cast<const float4*>(zz + 4 * c);
+                    acc += wdz[c].x * zv.x; acc += wdz[c].y * zv.y; acc += wdz[c].z * zv.z; acc += wdz[c].w * zv.w;
+                }
                 a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
     }
+    PROF(7);
 }
 
 template <int HG>

@@ -158,8 +158,9 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
     const int tiles = (L + TR - 1) / TR;
-    const int b = blockIdx.x / tiles;
-    const int i0 = (blockIdx.x - b * tiles) * TR;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);   // the query tiles of one sample share its K/V: same XCD/L2
+    const int b = lid / tiles;
+    const int i0 = (lid - b * tiles) * TR;
     const size_t rowb = (size_t)b * L;
     const int m0 = (int)rowb + i0;           // global row of tile row 0
     const int M = (int)rowb + L;             // rows of this sample end here (tile rows beyond are padding)

@@ -11,14 +11,14 @@ wait
 cp $R/pepflowww_amd/lib/libpepflow_hip.so /tmp/pfprof/orig.so
 cp /tmp/pfprof/libpepflow_hip.so $R/pepflowww_amd/lib/libpepflow_hip.so
 python - <<'PY'
-import ctypes as C, torch, sys
+import ctypes as C, torch, sys, os
 sys.path.insert(0, ".")
 import pepflowww_amd
 from pepflowww_amd import synth, _capi
 lib = _capi.load()
 dev = torch.device("cuda:0")
 m = pepflowww_amd.FlowModel(pepflowww_amd.default_config()); m.load_state_dict(synth.seeded_state_dict()); m = m.to(dev).eval()
-B, L = 16, 64
+B, L = int(os.environ.get('PB', 16)), int(os.environ.get('PL', 64))
 batch = {k: v.to(dev) for k, v in synth.make_pocket_batch(B, L, 12).items()}
 with torch.no_grad():
     R1, x1, a1, s1, node, edge = m.encode(batch)
@@ -29,8 +29,9 @@ with torch.no_grad():
     torch.cuda.synchronize()
     raw = C.CDLL(_capi.LIB_PATH)
     out = (C.c_longlong * 16)()
-    raw.pf_debug_prof(out, 16)
-    v = list(out)
-    print("stamps (cycles rel.):", [x - v[0] for x in v[:13]])
+    for sym, n in (("pf_debug_prof", 13), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8)):
+        getattr(raw, sym)(out, 16)
+        v = list(out)
+        print(sym, "stamps (cycles rel.):", [x - v[0] for x in v[:n]])
 PY
 cp /tmp/pfprof/orig.so $R/pepflowww_amd/lib/libpepflow_hip.so
