@@ -136,9 +136,9 @@ typedef struct {
     const float* feats;            /* [rows,1536] */
     const float* s_in;             /* [rows,128] */
     const float* mask;             /* [rows] */
-    const float* w_out; const float* b_out;   /* ipa linear_out [128,1536] */
+    const void* w_out_f16; const float* b_out; /* ipa linear_out [128,1536] as f16 hi/lo planes [2][128][1536] */
     const float* ln_g; const float* ln_b;     /* ipa_ln */
-    const float* w_in; const float* b_in;     /* seq_tfmr layers.0.self_attn.in_proj [384,128] */
+    const void* w_in_f16; const float* b_in;   /* seq_tfmr layers.0.self_attn.in_proj -> [2][384][128] f16 */
     float* s_ipa;                  /* [rows,128] */
     float* qkv;                    /* [rows,384] */
     int rows;
@@ -156,20 +156,21 @@ typedef struct {
     const float* qkv;              /* [B*L,384] this layer's q|k|v */
     const float* resid;            /* [B*L,128] layer input */
     const float* mask;             /* [B*L] */
-    const float* w_o; const float* b_o; const float* n1_g; const float* n1_b;
-    const float* w_1; const float* b_1; const float* w_2; const float* b_2; const float* n2_g; const float* n2_b;
-    const float* w_in_next; const float* b_in_next; float* qkv_out; float* v_out;      /* last == 0 */
+    /* every *_f16 weight is the reference matrix [N,K] pre-split into f16 planes [2][N][K] (hi, lo*2048) */
+    const void* w_o_f16; const float* b_o; const float* n1_g; const float* n1_b;
+    const void* w_1_f16; const float* b_1; const void* w_2_f16; const float* b_2; const float* n2_g; const float* n2_b;
+    const void* w_in_next_f16; const float* b_in_next; float* qkv_out; float* v_out;   /* last == 0 */
     int last;
     const float* s_ipa;                                                                /* last == 1 ... */
-    const float* w_post; const float* b_post;
-    const float* w_t1; const float* b_t1; const float* w_t2; const float* b_t2; const float* w_t3; const float* b_t3;
+    const void* w_post_f16; const float* b_post;
+    const void* w_t1_f16; const float* b_t1; const void* w_t2_f16; const float* b_t2; const void* w_t3_f16; const float* b_t3;
     const float* nt_g; const float* nt_b;
-    const float* w_bb; const float* b_bb;
+    const void* w_bb_f16; const float* b_bb;
     float* s_out;
     const float* quat_in; const float* rot_in; const float* trans_in;
     float* quat_out; float* rot_out; float* trans_out;
     int has_et;
-    const float* w_init; const float* b_init; const float* w_pre; const float* b_pre; float* pre;
+    const void* w_init_f16; const float* b_init; const void* w_pre_f16; const float* b_pre; float* pre;
     int B, L;
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);

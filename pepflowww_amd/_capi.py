@@ -80,20 +80,20 @@ class EdgeFeatArgs(C.Structure):
 
 
 class NodeHeadArgs(C.Structure):
-    _fields_ = [("feats", _fp), ("s_in", _fp), ("mask", _fp), ("w_out", _fp), ("b_out", _fp), ("ln_g", _fp),
-                ("ln_b", _fp), ("w_in", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i)]
+    _fields_ = [("feats", _fp), ("s_in", _fp), ("mask", _fp), ("w_out_f16", _fp), ("b_out", _fp), ("ln_g", _fp),
+                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i)]
 
 
 class NodeTfmrArgs(C.Structure):
     _fields_ = [("qkv", _fp), ("resid", _fp), ("mask", _fp),
-                ("w_o", _fp), ("b_o", _fp), ("n1_g", _fp), ("n1_b", _fp), ("w_1", _fp), ("b_1", _fp),
-                ("w_2", _fp), ("b_2", _fp), ("n2_g", _fp), ("n2_b", _fp),
-                ("w_in_next", _fp), ("b_in_next", _fp), ("qkv_out", _fp), ("v_out", _fp), ("last", _i),
-                ("s_ipa", _fp), ("w_post", _fp), ("b_post", _fp), ("w_t1", _fp), ("b_t1", _fp), ("w_t2", _fp),
-                ("b_t2", _fp), ("w_t3", _fp), ("b_t3", _fp), ("nt_g", _fp), ("nt_b", _fp), ("w_bb", _fp),
+                ("w_o_f16", _fp), ("b_o", _fp), ("n1_g", _fp), ("n1_b", _fp), ("w_1_f16", _fp), ("b_1", _fp),
+                ("w_2_f16", _fp), ("b_2", _fp), ("n2_g", _fp), ("n2_b", _fp),
+                ("w_in_next_f16", _fp), ("b_in_next", _fp), ("qkv_out", _fp), ("v_out", _fp), ("last", _i),
+                ("s_ipa", _fp), ("w_post_f16", _fp), ("b_post", _fp), ("w_t1_f16", _fp), ("b_t1", _fp), ("w_t2_f16", _fp),
+                ("b_t2", _fp), ("w_t3_f16", _fp), ("b_t3", _fp), ("nt_g", _fp), ("nt_b", _fp), ("w_bb_f16", _fp),
                 ("b_bb", _fp), ("s_out", _fp), ("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp),
                 ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("has_et", _i),
-                ("w_init", _fp), ("b_init", _fp), ("w_pre", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i)]
+                ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i)]
 
 
 _SIGNATURES = {

@@ -157,6 +157,98 @@ __device__ __forceinline__ void gemm_ldsA_glbB(const float* __restrict__ A_lds, 
     gemm_ldsA_stream<MT, NT, 4>(A_lds, lda, bs, acc, 0, bs.nslices);
 }
 
+// ---- split-precision MFMA ("3 x f16 = fp32") ----------------------------------------------------------
+// gfx950 has no TF32 and its fp32-input MFMA runs at 1/16 of the f16 rate.  An fp32 operand x is carried as two
+// f16 planes, x = hi + lo/2048 with hi = f16(x), lo = f16((x - hi) * 2048) (22-23 significant bits), and a
+// product as three v_mfma_f32_16x16x32_f16: hi*hi -> acc_main, hi*lo + lo*hi -> acc_corr, result =
+// acc_main + acc_corr/2048 (fp32 accumulation in the MFMA; the dropped lo*lo term is 2^-22 relative).
+// Weights are pre-split on the host ([2][N][K] f16 planes); activations are split when written to LDS.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+constexpr float PF_LO_SCALE = 2048.f, PF_LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        lo[e] = (_Float16)((v[e] - (float)h) * PF_LO_SCALE);
+    }
+}
+__device__ __forceinline__ float join(f32x4 m, f32x4 c, int e) { return m[e] + c[e] * PF_LO_INV; }
+
+// Weight stream of one wave for a 16-row activation tile: WT tiles of 16 output features, D K-steps (of 32)
+// in flight.  Computed TRANSPOSED (features x rows): the weights are the MFMA A operand, so a lane's four
+// accumulator registers are four CONSECUTIVE output features (n0 + 16*wt + 4*(lane>>4) + e) of ONE activation
+// row (lane & 15): biases/residuals load as float4 and the re-split result is stored with 8-byte writes.
+template <int WT, int D>
+struct WSplit {
+    const _Float16* wh[WT];
+    const _Float16* wl[WT];
+    bool ok[WT];
+    half8 rh[D][WT], rl[D][WT];
+    int nsteps;
+    __device__ __forceinline__ void init(const void* planes, int N, int ldw, int n0, int K) {
+        const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+        const _Float16* hi = reinterpret_cast<const _Float16*>(planes);
+        const _Float16* lo = hi + (size_t)N * ldw;
+        nsteps = K >> 5;
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+            const int n = n0 + 16 * wt + r;
+            ok[wt] = n < N;
+            wh[wt] = hi + (size_t)(ok[wt] ? n : 0) * ldw + 8 * g;
+            wl[wt] = lo + (size_t)(ok[wt] ? n : 0) * ldw + 8 * g;
+        }
+    }
+    __device__ __forceinline__ void load(int step, half8 (&dh)[WT], half8 (&dl)[WT]) {
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+            dh[wt] = ok[wt] ? *reinterpret_cast<const half8*>(wh[wt] + 32 * step) : z;
+            dl[wt] = ok[wt] ? *reinterpret_cast<const half8*>(wl[wt] + 32 * step) : z;
+        }
+    }
+    __device__ __forceinline__ void prefetch() {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nsteps) load(d, rh[d], rl[d]);
+    }
+};
+
+// am/ac[WT] += W-slab x X[16 rows][32*count K-columns starting at K-step step0];  Xh/Xl: LDS planes whose
+// column 0 is K-step step0 (step0 % D == 0).
+template <int WT, int D>
+__device__ __forceinline__ void gemm_split16(WSplit<WT, D>& ws, const _Float16* Xh, const _Float16* Xl, int ldx,
+                                             f32x4 (&am)[WT], f32x4 (&ac)[WT], int step0, int count) {
+    const int lane = threadIdx.x & 63;
+    const int off = (lane & 15) * ldx + 8 * (lane >> 4);
+    for (int base = 0; base < count; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (base + u < count) {
+                const int st = step0 + base + u;
+                const half8 xh = *reinterpret_cast<const half8*>(Xh + off + 32 * (base + u));
+                const half8 xl = *reinterpret_cast<const half8*>(Xl + off + 32 * (base + u));
+#pragma unroll
+                for (int wt = 0; wt < WT; ++wt) {
+                    am[wt] = mfma_h(ws.rh[u][wt], xh, am[wt]);
+                    ac[wt] = mfma_h(ws.rh[u][wt], xl, ac[wt]);
+                    ac[wt] = mfma_h(ws.rl[u][wt], xh, ac[wt]);
+                }
+                if (st + D < ws.nsteps) ws.load(st + D, ws.rh[u], ws.rl[u]);
+            }
+        }
+    }
+}
+template <int WT> __device__ __forceinline__ void acc_zero1(f32x4 (&a)[WT], f32x4 (&b)[WT]) {
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt) { a[wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; b[wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][NT]) {
 #pragma unroll

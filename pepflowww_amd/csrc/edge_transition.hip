@@ -39,28 +39,12 @@ extern "C" int pf_debug_prof_et(long long* out, int n) {
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
 constexpr int P = 64;            // pairs per workgroup
 constexpr int HID = 192;
 constexpr int LDHh = HID + 8;    // f16 row stride of the hidden planes (400 B: conflict-free b128 reads)
 constexpr int LDZh = 64 + 8;     // f16 row stride of the z planes
 constexpr int LDY = 68;          // fp32 row stride of the pre-LayerNorm tile
-constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
-
-__device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (_Float16)v[e];
-        hi[e] = h;
-        lo[e] = (_Float16)((v[e] - (float)h) * LO_SCALE);
-    }
-}
+constexpr float LO_INV = PF_LO_INV;
 
 // acc_main/acc_corr[WT][PT] += W[n0 + 16*wt + r][:K] (x) X[16*pt + r][:K]   (features x pairs)
 //   Wh/Wl : global f16 planes [N][ldw]      Xh/Xl : LDS f16 planes [64][ldx]

@@ -66,6 +66,7 @@ class PackedWeights:
                                           g(p + "linear_q_points.bias"), g(p + "linear_kv_points.bias")], 0).contiguous()
             for nm in ("linear_b", "down_z", "linear_out"):
                 t[f"{b}.{nm}.w"], t[f"{b}.{nm}.b"] = g(p + nm + ".weight"), g(p + nm + ".bias")
+            t[f"{b}.linear_out.w16"] = split_f16(t[f"{b}.linear_out.w"])
             t[f"{b}.head_w"] = g(p + "head_weights")
             t[f"{b}.ipa_ln.w"], t[f"{b}.ipa_ln.b"] = g(f"trunk.ipa_ln_{b}.weight"), g(f"trunk.ipa_ln_{b}.bias")
             for l in range(2):
@@ -74,11 +75,17 @@ class PackedWeights:
                 t[f"{b}.{l}.out.w"], t[f"{b}.{l}.out.b"] = g(q + "self_attn.out_proj.weight"), g(q + "self_attn.out_proj.bias")
                 for nm in ("linear1", "linear2", "norm1", "norm2"):
                     t[f"{b}.{l}.{nm}.w"], t[f"{b}.{l}.{nm}.b"] = g(q + nm + ".weight"), g(q + nm + ".bias")
+                for nm in ("in", "out", "linear1", "linear2"):
+                    t[f"{b}.{l}.{nm}.w16"] = split_f16(t[f"{b}.{l}.{nm}.w"])
             t[f"{b}.post.w"], t[f"{b}.post.b"] = g(f"trunk.post_tfmr_{b}.weight"), g(f"trunk.post_tfmr_{b}.bias")
+            t[f"{b}.post.w16"] = split_f16(t[f"{b}.post.w"])
             q = f"trunk.node_transition_{b}."
             for nm in ("linear_1", "linear_2", "linear_3", "ln"):
                 t[f"{b}.nt.{nm}.w"], t[f"{b}.nt.{nm}.b"] = g(q + nm + ".weight"), g(q + nm + ".bias")
+            for nm in ("linear_1", "linear_2", "linear_3"):
+                t[f"{b}.nt.{nm}.w16"] = split_f16(t[f"{b}.nt.{nm}.w"])
             t[f"{b}.bb.w"], t[f"{b}.bb.b"] = g(f"trunk.bb_update_{b}.linear.weight"), g(f"trunk.bb_update_{b}.linear.bias")
+            t[f"{b}.bb.w16"] = split_f16(t[f"{b}.bb.w"])
             if b < N_BLOCKS - 1:
                 q = f"trunk.edge_transition_{b}."
                 t[f"{b}.et.init.w"], t[f"{b}.et.init.b"] = g(q + "initial_embed.weight"), g(q + "initial_embed.bias")
@@ -89,6 +96,7 @@ class PackedWeights:
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
                 t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
+                t[f"{b}.et.init.w16"], t[f"{b}.et.pre.w16"] = split_f16(t[f"{b}.et.init.w"]), split_f16(t[f"{b}.et.pre.w"])
 
     def __getitem__(self, k):
         return self.t[k]
@@ -195,9 +203,9 @@ class DenoiseEngine:
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----
             ha = _capi.NodeHeadArgs()
             ha.feats, ha.s_in, ha.mask = self.feats.data_ptr(), self.s.data_ptr(), self.mask.data_ptr()
-            ha.w_out, ha.b_out = w[f"{b}.linear_out.w"].data_ptr(), w[f"{b}.linear_out.b"].data_ptr()
+            ha.w_out_f16, ha.b_out = w[f"{b}.linear_out.w16"].data_ptr(), w[f"{b}.linear_out.b"].data_ptr()
             ha.ln_g, ha.ln_b = w[f"{b}.ipa_ln.w"].data_ptr(), w[f"{b}.ipa_ln.b"].data_ptr()
-            ha.w_in, ha.b_in = w[f"{b}.0.in.w"].data_ptr(), w[f"{b}.0.in.b"].data_ptr()
+            ha.w_in_f16, ha.b_in = w[f"{b}.0.in.w16"].data_ptr(), w[f"{b}.0.in.b"].data_ptr()
             ha.s_ipa, ha.qkv, ha.rows = self.s.data_ptr(), self.qkv.data_ptr(), rows
             self._keep.append(ha)
             plan.append((lib.pf_node_head_fwd, C.byref(ha), "pf_node_head_fwd"))
@@ -206,31 +214,31 @@ class DenoiseEngine:
                 ta.qkv = (self.qkv if l == 0 else self.qkv2).data_ptr()
                 ta.resid = (self.s if l == 0 else self.v).data_ptr()
                 ta.mask = self.mask.data_ptr()
-                ta.w_o, ta.b_o = w[f"{b}.{l}.out.w"].data_ptr(), w[f"{b}.{l}.out.b"].data_ptr()
+                ta.w_o_f16, ta.b_o = w[f"{b}.{l}.out.w16"].data_ptr(), w[f"{b}.{l}.out.b"].data_ptr()
                 ta.n1_g, ta.n1_b = w[f"{b}.{l}.norm1.w"].data_ptr(), w[f"{b}.{l}.norm1.b"].data_ptr()
-                ta.w_1, ta.b_1 = w[f"{b}.{l}.linear1.w"].data_ptr(), w[f"{b}.{l}.linear1.b"].data_ptr()
-                ta.w_2, ta.b_2 = w[f"{b}.{l}.linear2.w"].data_ptr(), w[f"{b}.{l}.linear2.b"].data_ptr()
+                ta.w_1_f16, ta.b_1 = w[f"{b}.{l}.linear1.w16"].data_ptr(), w[f"{b}.{l}.linear1.b"].data_ptr()
+                ta.w_2_f16, ta.b_2 = w[f"{b}.{l}.linear2.w16"].data_ptr(), w[f"{b}.{l}.linear2.b"].data_ptr()
                 ta.n2_g, ta.n2_b = w[f"{b}.{l}.norm2.w"].data_ptr(), w[f"{b}.{l}.norm2.b"].data_ptr()
                 ta.B, ta.L = B, L
                 if l == 0:
                     ta.last = 0
-                    ta.w_in_next, ta.b_in_next = w[f"{b}.1.in.w"].data_ptr(), w[f"{b}.1.in.b"].data_ptr()
+                    ta.w_in_next_f16, ta.b_in_next = w[f"{b}.1.in.w16"].data_ptr(), w[f"{b}.1.in.b"].data_ptr()
                     ta.qkv_out, ta.v_out = self.qkv2.data_ptr(), self.v.data_ptr()
                 else:
                     ta.last = 1
                     ta.s_ipa, ta.s_out = self.s.data_ptr(), self.s.data_ptr()
-                    ta.w_post, ta.b_post = w[f"{b}.post.w"].data_ptr(), w[f"{b}.post.b"].data_ptr()
-                    ta.w_t1, ta.b_t1 = w[f"{b}.nt.linear_1.w"].data_ptr(), w[f"{b}.nt.linear_1.b"].data_ptr()
-                    ta.w_t2, ta.b_t2 = w[f"{b}.nt.linear_2.w"].data_ptr(), w[f"{b}.nt.linear_2.b"].data_ptr()
-                    ta.w_t3, ta.b_t3 = w[f"{b}.nt.linear_3.w"].data_ptr(), w[f"{b}.nt.linear_3.b"].data_ptr()
+                    ta.w_post_f16, ta.b_post = w[f"{b}.post.w16"].data_ptr(), w[f"{b}.post.b"].data_ptr()
+                    ta.w_t1_f16, ta.b_t1 = w[f"{b}.nt.linear_1.w16"].data_ptr(), w[f"{b}.nt.linear_1.b"].data_ptr()
+                    ta.w_t2_f16, ta.b_t2 = w[f"{b}.nt.linear_2.w16"].data_ptr(), w[f"{b}.nt.linear_2.b"].data_ptr()
+                    ta.w_t3_f16, ta.b_t3 = w[f"{b}.nt.linear_3.w16"].data_ptr(), w[f"{b}.nt.linear_3.b"].data_ptr()
                     ta.nt_g, ta.nt_b = w[f"{b}.nt.ln.w"].data_ptr(), w[f"{b}.nt.ln.b"].data_ptr()
-                    ta.w_bb, ta.b_bb = w[f"{b}.bb.w"].data_ptr(), w[f"{b}.bb.b"].data_ptr()
+                    ta.w_bb_f16, ta.b_bb = w[f"{b}.bb.w16"].data_ptr(), w[f"{b}.bb.b"].data_ptr()
                     ta.quat_in, ta.rot_in, ta.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
                     ta.quat_out, ta.rot_out, ta.trans_out = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr()
                     ta.has_et = int(b < N_BLOCKS - 1)
                     if ta.has_et:
-                        ta.w_init, ta.b_init = w[f"{b}.et.init.w"].data_ptr(), w[f"{b}.et.init.b"].data_ptr()
-                        ta.w_pre, ta.b_pre = w[f"{b}.et.pre.w"].data_ptr(), w[f"{b}.et.pre.b"].data_ptr()
+                        ta.w_init_f16, ta.b_init = w[f"{b}.et.init.w16"].data_ptr(), w[f"{b}.et.init.b"].data_ptr()
+                        ta.w_pre_f16, ta.b_pre = w[f"{b}.et.pre.w16"].data_ptr(), w[f"{b}.et.pre.b"].data_ptr()
                         ta.pre = self.pre.data_ptr()
                 self._keep.append(ta)
                 plan.append((lib.pf_node_tfmr_fwd, C.byref(ta), "pf_node_tfmr_fwd"))
