@@ -184,32 +184,32 @@ __device__ __forceinline__ float join(f32x4 m, f32x4 c, int e) { return m[e] + c
 // in flight.  Computed TRANSPOSED (features x rows): the weights are the MFMA A operand, so a lane's four
 // accumulator registers are four CONSECUTIVE output features (n0 + 16*wt + 4*(lane>>4) + e) of ONE activation
 // row (lane & 15): biases/residuals load as float4 and the re-split result is stored with 8-byte writes.
+// Weight planes are stored in FRAGMENT ORDER by the host (engine.split_f16): [2 planes][N/16][K/32][64 lanes][8 f16],
+// so each operand load of a wave is one contiguous 1 KiB block; rows beyond N are zero-padded by the packer.
 template <int WT, int D>
 struct WSplit {
     const _Float16* wh[WT];
     const _Float16* wl[WT];
-    bool ok[WT];
     half8 rh[D][WT], rl[D][WT];
     int nsteps;
-    __device__ __forceinline__ void init(const void* planes, int N, int ldw, int n0, int K) {
-        const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    // planes: packed weights; Npad: N rounded up to 16; n0: first output feature of this wave (multiple of 16)
+    __device__ __forceinline__ void init(const void* planes, int Npad, int K, int n0) {
+        const int lane = threadIdx.x & 63;
         const _Float16* hi = reinterpret_cast<const _Float16*>(planes);
-        const _Float16* lo = hi + (size_t)N * ldw;
+        const _Float16* lo = hi + (size_t)Npad * K;
         nsteps = K >> 5;
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) {
-            const int n = n0 + 16 * wt + r;
-            ok[wt] = n < N;
-            wh[wt] = hi + (size_t)(ok[wt] ? n : 0) * ldw + 8 * g;
-            wl[wt] = lo + (size_t)(ok[wt] ? n : 0) * ldw + 8 * g;
+            const size_t off = ((size_t)((n0 >> 4) + wt) * nsteps * 64 + lane) * 8;
+            wh[wt] = hi + off;
+            wl[wt] = lo + off;
         }
     }
     __device__ __forceinline__ void load(int step, half8 (&dh)[WT], half8 (&dl)[WT]) {
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) {
-            dh[wt] = ok[wt] ? *reinterpret_cast<const half8*>(wh[wt] + 32 * step) : z;
-            dl[wt] = ok[wt] ? *reinterpret_cast<const half8*>(wl[wt] + 32 * step) : z;
+            dh[wt] = *reinterpret_cast<const half8*>(wh[wt] + (size_t)step * 512);
+            dl[wt] = *reinterpret_cast<const half8*>(wl[wt] + (size_t)step * 512);
         }
     }
     __device__ __forceinline__ void prefetch() {

@@ -46,36 +46,40 @@ constexpr int LDZh = 64 + 8;     // f16 row stride of the z planes
 constexpr int LDY = 68;          // fp32 row stride of the pre-LayerNorm tile
 constexpr float LO_INV = PF_LO_INV;
 
-// acc_main/acc_corr[WT][PT] += W[n0 + 16*wt + r][:K] (x) X[16*pt + r][:K]   (features x pairs)
-//   Wh/Wl : global f16 planes [N][ldw]      Xh/Xl : LDS f16 planes [64][ldx]
+// acc_main/acc_corr[WT][PT] += W[n0 + 16*wt + r][k_off : k_off + K] (x) X[16*pt + r][:K]   (features x pairs)
+//   W  : fragment-order f16 planes of an [N][Kw] matrix (engine.split_f16), hi plane then lo plane
+//   Xh/Xl : LDS f16 planes [64][ldx]
 template <int WT, int PT>
-__device__ __forceinline__ void gemm_split(const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int ldw, int n0,
-                                           const _Float16* Xh, const _Float16* Xl, int ldx, int K,
+__device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, int n0, int K,
+                                           const _Float16* Xh, const _Float16* Xl, int ldx,
                                            f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const _Float16* wh = Wh + (size_t)(n0 + r) * ldw + 8 * g;
-    const _Float16* wl = Wl + (size_t)(n0 + r) * ldw + 8 * g;
+    const int wsteps = Kw >> 5;
+    const _Float16* wh = reinterpret_cast<const _Float16*>(planes) + ((size_t)(n0 >> 4) * wsteps * 64 + lane) * 8;
+    const _Float16* wl = wh + (size_t)N * Kw;
+    const size_t tstride = (size_t)wsteps * 512;          // f16 elements between consecutive feature tiles
     const _Float16* xh = Xh + r * ldx + 8 * g;
     const _Float16* xl = Xl + r * ldx + 8 * g;
     half8 bh[WT], bl[WT], nh[WT], nl[WT];
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) {
-        bh[wt] = *reinterpret_cast<const half8*>(wh + (size_t)wt * 16 * ldw);
-        bl[wt] = *reinterpret_cast<const half8*>(wl + (size_t)wt * 16 * ldw);
+        bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride);
+        bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
     }
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        if (k0 + 32 < K) {
+    const int nst = K >> 5;
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) {
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt) {
-                nh[wt] = *reinterpret_cast<const half8*>(wh + (size_t)wt * 16 * ldw + k0 + 32);
-                nl[wt] = *reinterpret_cast<const half8*>(wl + (size_t)wt * 16 * ldw + k0 + 32);
+                nh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)(st + 1) * 512);
+                nl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)(st + 1) * 512);
             }
         }
         half8 ah[PT], al[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            ah[pt] = *reinterpret_cast<const half8*>(xh + pt * 16 * ldx + k0);
-            al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + k0);
+            ah[pt] = *reinterpret_cast<const half8*>(xh + pt * 16 * ldx + 32 * st);
+            al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + 32 * st);
         }
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt)
@@ -103,13 +107,6 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     const long long p0 = (long long)blockIdx.x * P;
     const int L = a.L;
     const long long LL = (long long)L * L;
-    const _Float16* w1h = reinterpret_cast<const _Float16*>(a.w1z_f16);
-    const _Float16* w1l = w1h + HID * 64;
-    const _Float16* w2h = reinterpret_cast<const _Float16*>(a.w2_f16);
-    const _Float16* w2l = w2h + HID * HID;
-    const _Float16* wfh = reinterpret_cast<const _Float16*>(a.wf_f16);
-    const _Float16* wfl = wfh + 64 * HID;
-
     PROF(0);
     // ---- stage z tile (contiguous 64 x 64 floats) as hi/lo f16 planes ----
     for (int idx = tid; idx < P * 16; idx += 256) {
@@ -145,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         f32x4 am[3][4], ac[3][4];
         acc_zero<3, 4>(am);
         acc_zero<3, 4>(ac);
-        gemm_split<3, 4>(w1h, w1l, 64, wave * 48, Zh, Zl, LDZh, 64, am, ac);
+        gemm_split<3, 4>(a.w1z_f16, HID, 64, wave * 48, 64, Zh, Zl, LDZh, am, ac);
         PROF(2);
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         f32x4 am[3][4], ac[3][4];
         acc_zero<3, 4>(am);
         acc_zero<3, 4>(ac);
-        gemm_split<3, 4>(w2h, w2l, HID, wave * 48, Hh, Hl, LDHh, HID, am, ac);
+        gemm_split<3, 4>(a.w2_f16, HID, HID, wave * 48, HID, Hh, Hl, LDHh, am, ac);
         PROF(4);
         __syncthreads();                       // every wave finished reading h1
         PROF(5);
@@ -204,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         f32x4 am[1][4], ac[1][4];
         acc_zero<1, 4>(am);
         acc_zero<1, 4>(ac);
-        gemm_split<1, 4>(wfh, wfl, HID, wave * 16, Hh, Hl, LDHh, HID, am, ac);
-        gemm_split<1, 4>(wfh, wfl, HID, wave * 16, Zh, Zl, LDZh, 64, am, ac);
+        gemm_split<1, 4>(a.wf_f16, 64, HID, wave * 16, HID, Hh, Hl, LDHh, am, ac);
+        gemm_split<1, 4>(a.wf_f16, 64, HID, wave * 16, 64, Zh, Zl, LDZh, am, ac);
         PROF(7);
         __syncthreads();                       // h2 fully consumed -> reuse the H region for y (fp32)
         const int n = wave * 16 + 4 * g;

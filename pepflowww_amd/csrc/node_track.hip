@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
     const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
 
     WSplit<1, 8> ws;
-    ws.init(a.w_out_f16, 128, PF_IPA_FEATS, wave * 16, PF_IPA_FEATS);
+    ws.init(a.w_out_f16, 128, PF_IPA_FEATS, wave * 16);
     ws.prefetch();
     // small per-lane operands
     LnParams lnp;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
         __syncthreads();
     }
     WSplit<3, 4> wq;                                      // next stage's weights: in_proj of tfmr layer 0
-    wq.init(a.w_in_f16, 384, 128, wave * 48, 128);
+    wq.init(a.w_in_f16, 384, 128, wave * 48);
     wq.prefetch();
     {
         float4 y;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         q1 = *reinterpret_cast<const float4*>(qrow + 16);
     }
     WSplit<1, 4> ws;
-    ws.init(a.w_o_f16, 128, 128, wave * 16, 128);
+    ws.init(a.w_o_f16, 128, 128, wave * 16);
     ws.prefetch();
     LnParams ln1, ln2, ln3;
     if (tid < 256) {
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
     // ---- out_proj + residual -> T1 (fp32) ; LN1 -> u: T1 + planes Xb ----
     acc_zero1<1>(am, ac);
     gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
-    ws.init(a.w_1_f16, 128, 128, wave * 16, 128);
+    ws.init(a.w_1_f16, 128, 128, wave * 16);
     ws.prefetch();
     *reinterpret_cast<float4*>(T1 + r * LDX + n) =
         make_float4(join(am[0], ac[0], 0) + bias_o.x + rres.x, join(am[0], ac[0], 1) + bias_o.y + rres.y,
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
     // ---- linear1 + ReLU -> planes Xa ----
     acc_zero1<1>(am, ac);
     gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
-    ws.init(a.w_2_f16, 128, 128, wave * 16, 128);
+    ws.init(a.w_2_f16, 128, 128, wave * 16);
     ws.prefetch();
     {
         const float v[4] = {fmaxf(join(am[0], ac[0], 0) + bias_1.x, 0.f), fmaxf(join(am[0], ac[0], 1) + bias_1.y, 0.f),
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
     gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
     if constexpr (!LAST) {
         WSplit<3, 4> wq;
-        wq.init(a.w_in_next_f16, 384, 128, wave * 48, 128);
+        wq.init(a.w_in_next_f16, 384, 128, wave * 48);
         wq.prefetch();
         {
             const float4 u = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         }
         PROF(8);
     } else {
-        ws.init(a.w_post_f16, 128, 128, wave * 16, 128);
+        ws.init(a.w_post_f16, 128, 128, wave * 16);
         ws.prefetch();
         {
             const float4 u = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         // ---- s = s_ipa + post_tfmr(v) -> T1 (fp32) + planes Xa                 (ga.py:107) ----
         acc_zero1<1>(am, ac);
         gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
-        ws.init(a.w_t1_f16, 128, 128, wave * 16, 128);
+        ws.init(a.w_t1_f16, 128, 128, wave * 16);
         ws.prefetch();
         {
             const float v[4] = {join(am[0], ac[0], 0) + bias_post.x + rsipa.x, join(am[0], ac[0], 1) + bias_post.y + rsipa.y,
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         // ---- StructureModuleTransition: relu(l1) -> Xb, relu(l2) -> Xa, l3 + s -> T0, LN, * mask ----
         acc_zero1<1>(am, ac);
         gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
-        ws.init(a.w_t2_f16, 128, 128, wave * 16, 128);
+        ws.init(a.w_t2_f16, 128, 128, wave * 16);
         ws.prefetch();
         {
             const float v[4] = {fmaxf(join(am[0], ac[0], 0) + bias_t1.x, 0.f), fmaxf(join(am[0], ac[0], 1) + bias_t1.y, 0.f),
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         __syncthreads();
         acc_zero1<1>(am, ac);
         gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
-        ws.init(a.w_t3_f16, 128, 128, wave * 16, 128);
+        ws.init(a.w_t3_f16, 128, 128, wave * 16);
         ws.prefetch();
         {
             const float v[4] = {fmaxf(join(am[0], ac[0], 0) + bias_t2.x, 0.f), fmaxf(join(am[0], ac[0], 1) + bias_t2.y, 0.f),
@@ -465,10 +465,10 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
         // next stage streams: wave 0 -> backbone update (6 outputs), waves 4..7 -> EdgeTransition initial_embed (64)
         const bool do_bb = wave == 0, do_init = a.has_et && wave >= 4;
-        if (do_bb) { ws.init(a.w_bb_f16, 6, 128, 0, 128); ws.prefetch(); }
-        else if (do_init) { ws.init(a.w_init_f16, 64, 128, (wave - 4) * 16, 128); ws.prefetch(); }
+        if (do_bb) { ws.init(a.w_bb_f16, 16, 128, 0); ws.prefetch(); }
+        else if (do_init) { ws.init(a.w_init_f16, 64, 128, (wave - 4) * 16); ws.prefetch(); }
         WSplit<4, 2> wp;
-        if (a.has_et) { wp.init(a.w_pre_f16, PF_ET_PRE, 64, wave * 64, 64); wp.prefetch(); }
+        if (a.has_et) { wp.init(a.w_pre_f16, PF_ET_PRE, 64, wave * 64); wp.prefetch(); }
         {
             const float4 s0 = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
             *reinterpret_cast<float4*>(T0 + r * LDX + n) =

@@ -26,12 +26,24 @@ LO_SCALE = 2048.0
 
 
 def split_f16(w):
-    """fp32 matrix -> [2, N, K] f16 planes (hi, lo*2048) for the split-precision MFMA kernels:
-    w ~= hi + lo/2048 to 22-23 bits (layout/packing only; see csrc/edge_transition.hip)."""
+    """fp32 matrix [N, K] -> f16 hi/lo planes in MFMA FRAGMENT ORDER for the split-precision kernels.
+
+    w ~= hi + lo/2048 to 22-23 bits.  Layout [2 planes][N/16 tiles][K/32 steps][64 lanes][8]: the 8 f16 that lane
+    (g = lane>>4, r = lane&15) feeds to one v_mfma_f32_16x16x32_f16 for feature tile t and K-step s are
+    W[16t + r][32s + 8g .. +7], stored contiguously, so a wave's operand load is ONE fully coalesced 1 KiB block
+    (row-major planes make every load touch sixteen half-used 128-B lines and thrash the 32 KiB L1).
+    N is zero-padded to a multiple of 16; K must be a multiple of 32.  Layout/packing only -- no model arithmetic."""
     w = _f32(w)
+    N, K = w.shape
+    assert K % 32 == 0, K
+    Np = (N + 15) // 16 * 16
+    if Np != N:
+        w = torch.nn.functional.pad(w, (0, 0, 0, Np - N))
     hi = w.to(torch.float16)
     lo = ((w - hi.to(torch.float32)) * LO_SCALE).to(torch.float16)
-    return torch.stack([hi, lo], 0).contiguous()
+    planes = torch.stack([hi, lo], 0)                                   # [2, Np, K]
+    frag = planes.view(2, Np // 16, 16, K // 32, 4, 8).permute(0, 1, 3, 4, 2, 5)   # [2, t, s, g, r, 8]
+    return frag.contiguous()
 
 
 class PackedWeights:
