@@ -81,14 +81,20 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
             ah[pt] = *reinterpret_cast<const half8*>(xh + pt * 16 * ldx + 32 * st);
             al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + 32 * st);
         }
+        // three passes: the two MFMAs that accumulate into acc_corr are WT*PT instructions apart (no back-to-back
+        // dependency on one accumulator)
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                am[wt][pt] = mfma_h(bh[wt], ah[pt], am[wt][pt]);
-                ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
-                ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
-            }
+            for (int pt = 0; pt < PT; ++pt) am[wt][pt] = mfma_h(bh[wt], ah[pt], am[wt][pt]);
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; bl[wt] = nl[wt]; }
     }
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     _Float16* Hl = Hh + P * LDHh;                                  // lo plane
     _Float16* Zh = Hl + P * LDHh;                                  // [P][LDZh]
     _Float16* Zl = Zh + P * LDZh;
+    float* Gs = reinterpret_cast<float*>(Zl + P * LDZh);           // [128] LayerNorm gamma | beta
     float* Ys = reinterpret_cast<float*>(smem_raw);                // [P][LDY] fp32, aliases Hh/Hl after GEMM3
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -107,20 +114,19 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     const long long p0 = (long long)blockIdx.x * P;
     const int L = a.L;
     const long long LL = (long long)L * L;
+    if (tid < 64) Gs[tid] = a.ln_g[tid];
+    else if (tid < 128) Gs[tid] = a.ln_b[tid - 64];
     PROF(0);
-    // ---- stage z tile (contiguous 64 x 64 floats) as hi/lo f16 planes ----
-    for (int idx = tid; idx < P * 16; idx += 256) {
-        const int row = idx >> 4, c4 = idx & 15;
-        const long long pr = p0 + row;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pr < npairs) {
-            const float4 t = *reinterpret_cast<const float4*>(a.z_in + pr * 64 + 4 * c4);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        }
-        half4 hi, lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<half4*>(Zh + row * LDZh + 4 * c4) = hi;
-        *reinterpret_cast<half4*>(Zl + row * LDZh + 4 * c4) = lo;
+    // ---- everything this tile needs from HBM/L2 is requested up front: z rows, the per-residue gathers of the
+    //      GEMM1 epilogue (24 float4 per lane) and the LayerNorm constants; one exposed latency instead of four.
+    //      (A persistent-workgroup variant that prefetches the next tile's z was tried: it needs 16 more live
+    //      registers, spills 153 VGPRs at this tile shape and runs 1.9x slower.) ----
+    float4 zt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q;
+        const long long pr = p0 + (idx >> 4);
+        zt[q] = (pr < npairs) ? *reinterpret_cast<const float4*>(a.z_in + pr * 64 + 4 * (idx & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // residue rows (b*L+i, b*L+j) of the 4 pairs this lane owns in the accumulator layout: pair = 16*pt + r
     int rbi[4], rbj[4];
@@ -134,35 +140,62 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         rbi[pt] = b * L + i;
         rbj[pt] = b * L + j;
     }
+    float4 pa[3][4], pc[3][4];
+#pragma unroll
+    for (int wt = 0; wt < 3; ++wt) {
+        const int n = wave * 48 + wt * 16 + 4 * g;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            pa[wt][pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + n);
+            pc[wt][pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 192 + n);
+        }
+    }
+    float lnmk = 0.f;                                   // edge mask of the pair row this thread normalises at the end
+    {
+        const long long pr = p0 + (tid >> 2);
+        if (pr < npairs) {
+            const int b = (int)(pr / LL);
+            const int rem = (int)(pr - (long long)b * LL);
+            lnmk = a.mask[b * L + rem / L] * a.mask[b * L + rem % L];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q;
+        const int row = idx >> 4, c4 = idx & 15;
+        const float v[4] = {zt[q].x, zt[q].y, zt[q].z, zt[q].w};
+        half4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<half4*>(Zh + row * LDZh + 4 * c4) = hi;
+        *reinterpret_cast<half4*>(Zl + row * LDZh + 4 * c4) = lo;
+    }
     __syncthreads();
 
     PROF(1);
-    // ---- GEMM1: t1 = W1z z (K=64); wave slab = 48 features; + a_i + c_j, ReLU -> H planes ----
-    {
-        f32x4 am[3][4], ac[3][4];
-        acc_zero<3, 4>(am);
-        acc_zero<3, 4>(ac);
-        gemm_split<3, 4>(a.w1z_f16, HID, 64, wave * 48, 64, Zh, Zl, LDZh, am, ac);
-        PROF(2);
+    // ---- GEMM1: t1 = W1z z (K=64); wave slab = 48 features as three 16-feature sub-GEMMs (32 accumulator
+    //      registers live instead of 96, which is what lets the gathers above stay in registers);
+    //      + a_i + c_j, ReLU -> H planes ----
 #pragma unroll
-        for (int wt = 0; wt < 3; ++wt) {
-            const int n = wave * 48 + wt * 16 + 4 * g;           // 4 consecutive features n..n+3
+    for (int wt = 0; wt < 3; ++wt) {
+        f32x4 am[1][4], ac[1][4];
+        acc_zero<1, 4>(am);
+        acc_zero<1, 4>(ac);
+        gemm_split<1, 4>(a.w1z_f16, HID, 64, wave * 48 + wt * 16, 64, Zh, Zl, LDZh, am, ac);
+        const int n = wave * 48 + wt * 16 + 4 * g;           // 4 consecutive features n..n+3
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const float4 pa = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + n);
-                const float4 pc = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 192 + n);
-                float v[4];
-                v[0] = fmaxf(am[wt][pt][0] + ac[wt][pt][0] * LO_INV + pa.x + pc.x, 0.f);
-                v[1] = fmaxf(am[wt][pt][1] + ac[wt][pt][1] * LO_INV + pa.y + pc.y, 0.f);
-                v[2] = fmaxf(am[wt][pt][2] + ac[wt][pt][2] * LO_INV + pa.z + pc.z, 0.f);
-                v[3] = fmaxf(am[wt][pt][3] + ac[wt][pt][3] * LO_INV + pa.w + pc.w, 0.f);
-                half4 hi, lo;
-                split4(v, hi, lo);
-                *reinterpret_cast<half4*>(Hh + (pt * 16 + r) * LDHh + n) = hi;
-                *reinterpret_cast<half4*>(Hl + (pt * 16 + r) * LDHh + n) = lo;
-            }
+        for (int pt = 0; pt < 4; ++pt) {
+            float v[4];
+            v[0] = fmaxf(am[0][pt][0] + ac[0][pt][0] * LO_INV + pa[wt][pt].x + pc[wt][pt].x, 0.f);
+            v[1] = fmaxf(am[0][pt][1] + ac[0][pt][1] * LO_INV + pa[wt][pt].y + pc[wt][pt].y, 0.f);
+            v[2] = fmaxf(am[0][pt][2] + ac[0][pt][2] * LO_INV + pa[wt][pt].z + pc[wt][pt].z, 0.f);
+            v[3] = fmaxf(am[0][pt][3] + ac[0][pt][3] * LO_INV + pa[wt][pt].w + pc[wt][pt].w, 0.f);
+            half4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<half4*>(Hh + (pt * 16 + r) * LDHh + n) = hi;
+            *reinterpret_cast<half4*>(Hl + (pt * 16 + r) * LDHh + n) = lo;
         }
     }
+    PROF(2);
     __syncthreads();
 
     PROF(3);
@@ -201,6 +234,12 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         f32x4 am[1][4], ac[1][4];
         acc_zero<1, 4>(am);
         acc_zero<1, 4>(ac);
+        float4 pd[4], pe[4];                   // d_i / e_j gathers of the epilogue, requested before the GEMM
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            pd[pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + 384 + wave * 16 + 4 * g);
+            pe[pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 448 + wave * 16 + 4 * g);
+        }
         gemm_split<1, 4>(a.wf_f16, 64, HID, wave * 16, HID, Hh, Hl, LDHh, am, ac);
         gemm_split<1, 4>(a.wf_f16, 64, HID, wave * 16, 64, Zh, Zl, LDZh, am, ac);
         PROF(7);
@@ -208,13 +247,11 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         const int n = wave * 16 + 4 * g;
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const float4 pd = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + 384 + n);
-            const float4 pe = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 448 + n);
             float4 y;
-            y.x = am[0][pt][0] + ac[0][pt][0] * LO_INV + pd.x + pe.x;
-            y.y = am[0][pt][1] + ac[0][pt][1] * LO_INV + pd.y + pe.y;
-            y.z = am[0][pt][2] + ac[0][pt][2] * LO_INV + pd.z + pe.z;
-            y.w = am[0][pt][3] + ac[0][pt][3] * LO_INV + pd.w + pe.w;
+            y.x = am[0][pt][0] + ac[0][pt][0] * LO_INV + pd[pt].x + pe[pt].x;
+            y.y = am[0][pt][1] + ac[0][pt][1] * LO_INV + pd[pt].y + pe[pt].y;
+            y.z = am[0][pt][2] + ac[0][pt][2] * LO_INV + pd[pt].z + pe[pt].z;
+            y.w = am[0][pt][3] + ac[0][pt][3] * LO_INV + pd[pt].w + pe[pt].w;
             *reinterpret_cast<float4*>(Ys + (pt * 16 + r) * LDY + n) = y;
         }
     }
@@ -243,15 +280,12 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
         q += lane_xor2(q);
         const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
         if (pr < npairs) {
-            int b = (int)(pr / LL);
-            int rem = (int)(pr - (long long)b * LL);
-            int i = rem / L, j = rem - i * L;
-            const float mk = a.mask[b * L + i] * a.mask[b * L + j];
+            const float mk = lnmk;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int n = 16 * qd + 4 * c;
-                float4 gm = *reinterpret_cast<const float4*>(a.ln_g + n);
-                float4 bt = *reinterpret_cast<const float4*>(a.ln_b + n);
+                const float4 gm = *reinterpret_cast<const float4*>(Gs + n);
+                const float4 bt = *reinterpret_cast<const float4*>(Gs + 64 + n);
                 float4 o;
                 o.x = ((v[4 * c] - mean) * rstd * gm.x + bt.x) * mk;
                 o.y = ((v[4 * c + 1] - mean) * rstd * gm.y + bt.y) * mk;
@@ -273,7 +307,7 @@ extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_strea
     const long long npairs = (long long)a->B * a->L * a->L;
     const long long nblk = (npairs + P - 1) / P;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
-    const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16);
+    const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16) + 128 * sizeof(float);
     hipLaunchKernelGGL(edge_transition_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *a, npairs);
     PF_CHECK_LAUNCH();
     return 0;
