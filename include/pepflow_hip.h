@@ -69,6 +69,8 @@ typedef struct {
     int mask_pre, mask_post;
     const float* residual; int ldr; /* [M, ldr] or NULL */
     const float* ln_gamma; const float* ln_beta; float ln_eps; /* NULL = no LayerNorm */
+    const void* w_f16;              /* optional: W pre-split into fragment-order f16 hi/lo planes (engine.split_f16);
+                                       selects the split-precision MFMA path (bias / ReLU / row mask only, K % 32 == 0) */
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 

@@ -21,7 +21,7 @@ class LinearArgs(C.Structure):
     _fields_ = [("x", _fp), ("ldx", _i), ("w", _fp), ("ldw", _i), ("bias", _fp), ("y", _fp), ("ldy", _i),
                 ("M", _i), ("N", _i), ("K", _i), ("relu", _i), ("row_mask", _fp), ("mask_pre", _i),
                 ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
-                ("ln_eps", C.c_float)]
+                ("ln_eps", C.c_float), ("w_f16", _fp)]
 
 
 class EmbedArgs(C.Structure):

@@ -46,60 +46,6 @@ constexpr int LDZh = 64 + 8;     // f16 row stride of the z planes
 constexpr int LDY = 68;          // fp32 row stride of the pre-LayerNorm tile
 constexpr float LO_INV = PF_LO_INV;
 
-// acc_main/acc_corr[WT][PT] += W[n0 + 16*wt + r][k_off : k_off + K] (x) X[16*pt + r][:K]   (features x pairs)
-//   W  : fragment-order f16 planes of an [N][Kw] matrix (engine.split_f16), hi plane then lo plane
-//   Xh/Xl : LDS f16 planes [64][ldx]
-template <int WT, int PT>
-__device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, int n0, int K,
-                                           const _Float16* Xh, const _Float16* Xl, int ldx,
-                                           f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT]) {
-    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const int wsteps = Kw >> 5;
-    const _Float16* wh = reinterpret_cast<const _Float16*>(planes) + ((size_t)(n0 >> 4) * wsteps * 64 + lane) * 8;
-    const _Float16* wl = wh + (size_t)N * Kw;
-    const size_t tstride = (size_t)wsteps * 512;          // f16 elements between consecutive feature tiles
-    const _Float16* xh = Xh + r * ldx + 8 * g;
-    const _Float16* xl = Xl + r * ldx + 8 * g;
-    half8 bh[WT], bl[WT], nh[WT], nl[WT];
-#pragma unroll
-    for (int wt = 0; wt < WT; ++wt) {
-        bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride);
-        bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
-    }
-    const int nst = K >> 5;
-    for (int st = 0; st < nst; ++st) {
-        if (st + 1 < nst) {
-#pragma unroll
-            for (int wt = 0; wt < WT; ++wt) {
-                nh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)(st + 1) * 512);
-                nl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)(st + 1) * 512);
-            }
-        }
-        half8 ah[PT], al[PT];
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            ah[pt] = *reinterpret_cast<const half8*>(xh + pt * 16 * ldx + 32 * st);
-            al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + 32 * st);
-        }
-        // three passes: the two MFMAs that accumulate into acc_corr are WT*PT instructions apart (no back-to-back
-        // dependency on one accumulator)
-#pragma unroll
-        for (int wt = 0; wt < WT; ++wt)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) am[wt][pt] = mfma_h(bh[wt], ah[pt], am[wt][pt]);
-#pragma unroll
-        for (int wt = 0; wt < WT; ++wt)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
-#pragma unroll
-        for (int wt = 0; wt < WT; ++wt)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
-#pragma unroll
-        for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; bl[wt] = nl[wt]; }
-    }
-}
-
 __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transition_args a, long long npairs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* Hh = reinterpret_cast<_Float16*>(smem_raw);          // [P][LDHh] hidden hi plane

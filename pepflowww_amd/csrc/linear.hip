@@ -145,15 +145,96 @@ int launch(const pf_linear_args& a, hipStream_t s) {
     return 0;
 }
 
+
+// ---- split-precision variant (weights pre-split in fragment order, see common.h / engine.split_f16) ----------
+// Tile = 64 rows x 128 features per workgroup (4 waves, 32 features each); the x tile is converted to hi/lo f16
+// planes on its way into LDS.  Epilogue: bias (+ReLU, + row mask).  Used for the IPA projection (N = 3744) and
+// the other plain Linears of the step; 3 f16 MFMAs of K=32 replace 8 fp32 MFMAs of K=4.
+constexpr int SP_BM = 64, SP_BN = 128;
+__global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int Npad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = p.K, LDK = K + 8;
+    _Float16* Xh = reinterpret_cast<_Float16*>(smem_raw);       // [64][K+8]
+    _Float16* Xl = Xh + SP_BM * LDK;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * SP_BM;
+    const int n0 = blockIdx.y * SP_BN + wave * 32;
+    const bool wave_on = n0 < Npad;
+    const int kq = K >> 2;
+    for (int idx = tid; idx < SP_BM * kq; idx += 256) {
+        const int row = idx / kq, c4 = idx - row * kq;
+        const int m = m0 + row;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) {
+            const float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + 4 * c4);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+        half4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<half4*>(Xh + row * LDK + 4 * c4) = hi;
+        *reinterpret_cast<half4*>(Xl + row * LDK + 4 * c4) = lo;
+    }
+    __syncthreads();
+    if (!wave_on) return;
+    f32x4 am[2][4], ac[2][4];
+    acc_zero<2, 4>(am);
+    acc_zero<2, 4>(ac);
+    if (n0 + 16 < Npad) {
+        gemm_split<2, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
+    } else {                                           // last feature tile of a ragged N: one tile only
+        f32x4 bm[1][4], bc[1][4];
+        acc_zero<1, 4>(bm);
+        acc_zero<1, 4>(bc);
+        gemm_split<1, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, bm, bc);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) { am[0][pt] = bm[0][pt]; ac[0][pt] = bc[0][pt]; }
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int m = m0 + pt * 16 + r;
+        if (m < p.M) {
+            const float mk = (p.mask_pre || p.mask_post) ? p.row_mask[m] : 1.f;
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) {
+                const int n = n0 + wt * 16 + 4 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < p.N) {
+                        float v = am[wt][pt][e] + ac[wt][pt][e] * PF_LO_INV + (p.bias ? p.bias[n + e] : 0.f);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        p.y[(size_t)m * p.ldy + n + e] = v * mk;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
-    if (!a || !a->x || !a->w || !a->y || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
-    if (a->K % 16 || a->ldx % 4 || a->ldw % 4 || a->ldx < a->K || a->ldw < a->K) return PF_E_BADARG;
-    if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return PF_E_BADARG;
+    if (!a || !a->x || (!a->w && !a->w_f16) || !a->y || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    if (a->K % 16 || a->ldx % 4 || a->ldx < a->K) return PF_E_BADARG;
+    if (!a->w_f16 && (a->ldw % 4 || a->ldw < a->K || ((uintptr_t)a->w & 15))) return PF_E_BADARG;
+    if ((uintptr_t)a->x & 15) return PF_E_BADARG;
     if ((a->mask_pre || a->mask_post) && !a->row_mask) return PF_E_BADARG;
     if (a->ln_gamma && (a->N > BN || !a->ln_beta)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (a->w_f16) {                                   // split-precision path: plain Linear (+bias, ReLU, row mask)
+        if (a->K % 32 || a->residual || a->ln_gamma || a->K > 512) return PF_E_BADARG;   // x tile [64][K] must fit LDS
+        const int Npad = (a->N + 15) / 16 * 16;
+        dim3 grid((a->M + SP_BM - 1) / SP_BM, (Npad + SP_BN - 1) / SP_BN);
+        const size_t lds = (size_t)2 * SP_BM * (a->K + 8) * sizeof(_Float16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(linear_split_kernel, grid, dim3(256), lds, s, *a, Npad);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     // enough workgroups to cover 256 CUs where the problem allows it
     const long nb = (a->N + BN - 1) / BN;
     if ((long)((a->M + 63) / 64) * nb >= 512) return launch<4>(*a, s);

@@ -76,6 +76,7 @@ class PackedWeights:
                                           g(p + "linear_q_points.weight"), g(p + "linear_kv_points.weight")], 0).contiguous()
             t[f"{b}.proj.b"] = torch.cat([g(p + "linear_q.bias"), g(p + "linear_kv.bias"),
                                           g(p + "linear_q_points.bias"), g(p + "linear_kv_points.bias")], 0).contiguous()
+            t[f"{b}.proj.w16"] = split_f16(t[f"{b}.proj.w"])
             for nm in ("linear_b", "down_z", "linear_out"):
                 t[f"{b}.{nm}.w"], t[f"{b}.{nm}.b"] = g(p + nm + ".weight"), g(p + nm + ".bias")
             t[f"{b}.linear_out.w16"] = split_f16(t[f"{b}.linear_out.w"])
@@ -145,10 +146,12 @@ class DenoiseEngine:
         self.plan = None
 
     # ---- plan construction -------------------------------------------------------------------
-    def _linear(self, x, w, b, y, N, K, relu=False, mask_pre=False, mask_post=False, residual=None, ln=None):
+    def _linear(self, x, w, b, y, N, K, relu=False, mask_pre=False, mask_post=False, residual=None, ln=None, w16=None):
         a = _capi.LinearArgs()
         a.x, a.ldx = x.data_ptr(), x.shape[1]
         a.w, a.ldw = w.data_ptr(), w.shape[1]
+        if w16 is not None:
+            a.w_f16 = w16.data_ptr()
         a.bias = b.data_ptr() if b is not None else None
         a.y, a.ldy = y.data_ptr(), y.shape[1]
         a.M, a.N, a.K = self.rows, N, K
@@ -189,7 +192,7 @@ class DenoiseEngine:
         ea.angles, ea.out, ea.B, ea.L = self.ang_t.data_ptr(), self.feat.data_ptr(), B, L
         self._keep.append(ea)
         plan.append((lib.pf_embed_inputs_fwd, C.byref(ea), "pf_embed_inputs_fwd"))
-        plan.append(lin(self.feat, w["mix0.w"], w["mix0.b"], self.ta, 128, 640, relu=True))
+        plan.append(lin(self.feat, w["mix0.w"], w["mix0.b"], self.ta, 128, 640, relu=True))   # K=640: fp32 MFMA path
         plan.append(lin(self.ta, w["mix2.w"], w["mix2.b"], self.s, 128, 128, mask_pre=True))
         plan.append((lib.pf_rot_to_quat, (self.rot_t.data_ptr(), self.quat.data_ptr(), rows), "pf_rot_to_quat"))
 
@@ -197,7 +200,7 @@ class DenoiseEngine:
             rot = self.rot_t if b == 0 else self.rot
             trans = self.trans_t if b == 0 else self.trans
             z_in = self.edge_embed if b == 0 else self.zbuf
-            plan.append(lin(self.s, w[f"{b}.proj.w"], w[f"{b}.proj.b"], self.proj, 3744, 128))
+            plan.append(lin(self.s, w[f"{b}.proj.w"], w[f"{b}.proj.b"], self.proj, 3744, 128, w16=w[f"{b}.proj.w16"]))
             pa = _capi.IpaPointsArgs()
             pa.proj, pa.ldp, pa.rot, pa.trans = self.proj.data_ptr(), 3744, rot.data_ptr(), trans.data_ptr()
             pa.qp, pa.kp, pa.vp, pa.rows = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr(), rows

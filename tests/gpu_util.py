@@ -18,7 +18,7 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def linear(x, w, b=None, relu=False, row_mask=None, mask_pre=False, mask_post=False, residual=None, ln=None, N=None, K=None):
+def linear(x, w, b=None, relu=False, row_mask=None, mask_pre=False, mask_post=False, residual=None, ln=None, N=None, K=None, split=False):
     lib = _capi.load()
     M = x.shape[0]
     N = N or w.shape[0]
@@ -32,6 +32,10 @@ def linear(x, w, b=None, relu=False, row_mask=None, mask_pre=False, mask_post=Fa
         a.residual, a.ldr = _p(residual), residual.shape[1]
     if ln is not None:
         a.ln_gamma, a.ln_beta, a.ln_eps = _p(ln[0]), _p(ln[1]), 1e-5
+    if split:
+        from pepflowww_amd.engine import split_f16
+        w16 = split_f16(w)
+        a.w_f16 = _p(w16)
     _capi.check(lib.pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
     sync()
     return y

@@ -101,6 +101,17 @@ def test_linear_plain(M, N, K):
     G.assert_close(y, F.linear(x, w, b), 2e-5, "linear")
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 128, 256), (48, 3744, 128), (77, 6, 128), (1030, 20, 128), (64, 128, 512)])
+def test_linear_split_precision(M, N, K):
+    """3 x f16 MFMA path against fp64: must be fp32-class (the fp32 MFMA path is ~1e-6 on the same data)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, w, b = torch.randn(M, K, generator=g) * 3, torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    mask = (torch.rand(M, generator=g) > 0.2).float()
+    ref = (F.linear(x.double(), w.double(), b.double()).relu() * mask[:, None].double()).float()
+    y = G.linear(cu(x), cu(w), cu(b), relu=True, row_mask=cu(mask), mask_post=True, split=True)
+    G.assert_close(y, ref, 3e-6, "split-precision linear")
+
+
 def test_linear_epilogues():
     g = torch.Generator().manual_seed(3)
     M, N, K = 150, 128, 128
