@@ -177,6 +177,15 @@ __global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int
     }
     __syncthreads();
     if (!wave_on) return;
+    float bias4[2][4];
+#pragma unroll
+    for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wt * 16 + 4 * g + e;
+            bias4[wt][e] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+    const bool vec_ok = (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
     f32x4 am[2][4], ac[2][4];
     acc_zero<2, 4>(am);
     acc_zero<2, 4>(ac);
@@ -198,13 +207,19 @@ __global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int
 #pragma unroll
             for (int wt = 0; wt < 2; ++wt) {
                 const int n = n0 + wt * 16 + 4 * g;
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (n + e < p.N) {
-                        float v = am[wt][pt][e] + ac[wt][pt][e] * PF_LO_INV + (p.bias ? p.bias[n + e] : 0.f);
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        p.y[(size_t)m * p.ldy + n + e] = v * mk;
-                    }
+                    v[e] = am[wt][pt][e] + ac[wt][pt][e] * PF_LO_INV + bias4[wt][e];
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                    v[e] *= mk;
+                }
+                float* dst = p.y + (size_t)m * p.ldy + n;
+                if (vec_ok && n + 3 < p.N) {             // one 16-byte store per lane (the store tail is issue-bound)
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) dst[e] = v[e];
                 }
             }
         }
