@@ -131,6 +131,15 @@ def main():
     et_avg_s = sum(et_ms) / len(et_ms) * 1e-3
     pairs = B * L * L
 
+    # HBM traffic of the dominant kernel from the PMC passes recorded under profiles/ (rocprofv3 cannot run inside
+    # this process); per launch, corrected as MI355X_MICROARCH.md prescribes.  None if no record for this workload.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+            traffic = json.load(f)[args.workload]["edge_transition_kernel"]["hbm_bytes_corrected"]
+    except Exception:
+        pass
+
     ms_per_step = elapsed / K * 1e3
     value = world * B * L * K / elapsed
     per_gpu = value / world
@@ -144,7 +153,8 @@ def main():
         "roofline": {
             "kernel": "edge_transition_kernel", "bound": "mfma",
             "achieved": pairs * ET_FLOPS_EXEC / et_avg_s / 1e12, "peak": MFMA_F16_PEAK / ET_SPLIT / 1e12, "unit": "TFLOP/s",
-            "frac": pairs * ET_FLOPS_EXEC * ET_SPLIT / et_avg_s / MFMA_F16_PEAK, "traffic": None,
+            "frac": pairs * ET_FLOPS_EXEC * ET_SPLIT / et_avg_s / MFMA_F16_PEAK, "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from profiles/r01/pmc_traffic.json (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair",
             "note": "fp32-equivalent FLOPs; 3 f16 MFMA products per fp32 product (split precision), peak = 2.5 PF/3",
             "vs_fp32_mfma_peak": pairs * ET_FLOPS_EXEC / et_avg_s / MFMA_F32_PEAK,
             "avg_launch_us": et_avg_s * 1e6, "flops_per_pair_executed": ET_FLOPS_EXEC,
