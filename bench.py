@@ -116,7 +116,10 @@ def main():
         evs = []
         st = _capi.stream_ptr()
         for _ in range(min(K, 10)):
-            for fn, a, name in eng.plan:
+            for entry in eng.plan:
+                fn, a, name = entry[0], entry[1], entry[2]
+                if fn is None:
+                    continue
                 if name == "pf_edge_transition_fwd":
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
