@@ -56,13 +56,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if os.environ.get("PF_BENCH_SHARE_GPU"):              # test hook: several ranks on one GPU (single-GPU dev boxes)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)            # RCCL over xGMI
+        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")       # "nccl" = RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import pepflowww_amd
     from pepflowww_amd import synth, _capi

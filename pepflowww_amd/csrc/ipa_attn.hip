@@ -126,49 +126,91 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     }
 
     PROF(1);
-    // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) as a [pairs x 64] x [64 x heads] GEMM on fp32 MFMA:
-    //      A = z rows (16 pairs per tile, fragments straight from global), B = W_b (heads padded to 16, preloaded).
-    //      wave w -> query rows 4w..4w+3.  (A VALU version with 16-lane butterfly reductions took 2.5x longer.) ----
-    {
-        float4 wbf[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-            wbf[s4] = (r < HG) ? *reinterpret_cast<const float4*>(a.w_b + (h0 + r) * 64 + 16 * s4 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float bb = (r < HG) ? a.b_b[h0 + r] : 0.f;
-        const float s13 = 0.57735026918962576f;   // sqrt(1/3)
-        const int ntile = LP >> 4;
-        auto zfetch = [&](int it, float4 (&zf)[4]) {
-            const int t4 = it / ntile, j = (it - t4 * ntile) * 16 + r;
-            const int i = i0 + wave * 4 + t4;
-            const float* zp = a.z + ((rowb + (i < L ? i : L - 1)) * L + (j < L ? j : L - 1)) * 64 + 4 * g;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) zf[s4] = *reinterpret_cast<const float4*>(zp + 16 * s4);
-        };
-        float4 zc[4], zn[4];
-        zfetch(0, zc);
-        for (int it = 0; it < 4 * ntile; ++it) {
-            if (it + 1 < 4 * ntile) zfetch(it + 1, zn);
-            const int t4 = it / ntile, j0 = (it - t4 * ntile) * 16;
-            const int ti = wave * 4 + t4;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4 += 2) {
-                acc = mfma16(zc[s4].x, wbf[s4].x, acc);   acc2 = mfma16(zc[s4 + 1].x, wbf[s4 + 1].x, acc2);
-                acc = mfma16(zc[s4].y, wbf[s4].y, acc);   acc2 = mfma16(zc[s4 + 1].y, wbf[s4 + 1].y, acc2);
-                acc = mfma16(zc[s4].z, wbf[s4].z, acc);   acc2 = mfma16(zc[s4 + 1].z, wbf[s4 + 1].z, acc2);
-                acc = mfma16(zc[s4].w, wbf[s4].w, acc);   acc2 = mfma16(zc[s4 + 1].w, wbf[s4 + 1].w, acc2);
+    // The two z-streaming phases exist in two forms: on MFMA (heads padded to a 16-wide tile; wins when the
+    // workgroup owns >= 4 heads) and on VALU with 16-lane butterfly reductions (wins for the 2-head workgroups
+    // used at small batch, where 14 of the 16 MFMA columns would be padding: 39 vs 45 us at B=16, L=64).
+    if constexpr (HG >= 4) {
+        // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) as a [pairs x 64] x [64 x heads] GEMM on fp32 MFMA:
+        //      A = z rows (16 pairs per tile, fragments straight from global), B = W_b (heads padded to 16, preloaded).
+        //      wave w -> query rows 4w..4w+3.  (A VALU version with 16-lane butterfly reductions took 2.5x longer.) ----
+        {
+            float4 wbf[4];
+    #pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                wbf[s4] = (r < HG) ? *reinterpret_cast<const float4*>(a.w_b + (h0 + r) * 64 + 16 * s4 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bb = (r < HG) ? a.b_b[h0 + r] : 0.f;
+            const float s13 = 0.57735026918962576f;   // sqrt(1/3)
+            const int ntile = LP >> 4;
+            auto zfetch = [&](int it, float4 (&zf)[4]) {
+                const int t4 = it / ntile, j = (it - t4 * ntile) * 16 + r;
+                const int i = i0 + wave * 4 + t4;
+                const float* zp = a.z + ((rowb + (i < L ? i : L - 1)) * L + (j < L ? j : L - 1)) * 64 + 4 * g;
+    #pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) zf[s4] = *reinterpret_cast<const float4*>(zp + 16 * s4);
+            };
+            float4 zc[4], zn[4];
+            zfetch(0, zc);
+            for (int it = 0; it < 4 * ntile; ++it) {
+                if (it + 1 < 4 * ntile) zfetch(it + 1, zn);
+                const int t4 = it / ntile, j0 = (it - t4 * ntile) * 16;
+                const int ti = wave * 4 + t4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int s4 = 0; s4 < 4; s4 += 2) {
+                    acc = mfma16(zc[s4].x, wbf[s4].x, acc);   acc2 = mfma16(zc[s4 + 1].x, wbf[s4 + 1].x, acc2);
+                    acc = mfma16(zc[s4].y, wbf[s4].y, acc);   acc2 = mfma16(zc[s4 + 1].y, wbf[s4 + 1].y, acc2);
+                    acc = mfma16(zc[s4].z, wbf[s4].z, acc);   acc2 = mfma16(zc[s4 + 1].z, wbf[s4 + 1].z, acc2);
+                    acc = mfma16(zc[s4].w, wbf[s4].w, acc);   acc2 = mfma16(zc[s4 + 1].w, wbf[s4 + 1].w, acc2);
+                }
+                if (r < HG) {                                   // lane (r = head, g): rows e -> pairs j0 + 4g + e
+                    float4 o;
+                    const int jj = j0 + 4 * g;
+                    o.x = (jj + 0 < L) ? s13 * (acc[0] + acc2[0] + bb) : 0.f;
+                    o.y = (jj + 1 < L) ? s13 * (acc[1] + acc2[1] + bb) : 0.f;
+                    o.z = (jj + 2 < L) ? s13 * (acc[2] + acc2[2] + bb) : 0.f;
+                    o.w = (jj + 3 < L) ? s13 * (acc[3] + acc2[3] + bb) : 0.f;
+                    *reinterpret_cast<float4*>(S + (ti * HG + r) * LDS_S + jj) = o;
+                }
+    #pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) zc[s4] = zn[s4];
             }
-            if (r < HG) {                                   // lane (r = head, g): rows e -> pairs j0 + 4g + e
-                float4 o;
-                const int jj = j0 + 4 * g;
-                o.x = (jj + 0 < L) ? s13 * (acc[0] + acc2[0] + bb) : 0.f;
-                o.y = (jj + 1 < L) ? s13 * (acc[1] + acc2[1] + bb) : 0.f;
-                o.z = (jj + 2 < L) ? s13 * (acc[2] + acc2[2] + bb) : 0.f;
-                o.w = (jj + 3 < L) ? s13 * (acc[3] + acc2[3] + bb) : 0.f;
-                *reinterpret_cast<float4*>(S + (ti * HG + r) * LDS_S + jj) = o;
+        }
+    } else {
+        // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) for the HG heads.  wave w -> query rows 4w..4w+3 ----
+        {
+            const int c4 = lane & 15, js = lane >> 4;
+            float4 wb[HG];
+    #pragma unroll
+            for (int h = 0; h < HG; ++h) wb[h] = *reinterpret_cast<const float4*>(a.w_b + (h0 + h) * 64 + 4 * c4);
+            const int hsel = head_of_lane<HG>(lane);
+            const bool writer = (lane & (16 / HG - 1)) == 0;
+            const float bb = a.b_b[h0 + hsel];
+            const float s13 = 0.57735026918962576f;   // sqrt(1/3)
+            // z rows are streamed in batches of ZB loads per lane: one memory latency per batch, not per pair
+            constexpr int ZBATCH = 8;
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int ti = wave * 4 + t4;
+                const int i = i0 + ti;
+                const float* zrow = a.z + ((rowb + (i < L ? i : L - 1)) * L) * 64 + 4 * c4;
+                for (int jb = 0; jb < LP; jb += 4 * ZBATCH) {
+                    float4 zq[ZBATCH];
+    #pragma unroll
+                    for (int u = 0; u < ZBATCH; ++u) {
+                        const int j = jb + 4 * u + js;
+                        zq[u] = (j < L) ? *reinterpret_cast<const float4*>(zrow + (size_t)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < ZBATCH; ++u) {
+                        const int j = jb + 4 * u + js;
+                        float v[HG];
+    #pragma unroll
+                        for (int h = 0; h < HG; ++h)
+                            v[h] = wb[h].x * zq[u].x + wb[h].y * zq[u].y + wb[h].z * zq[u].z + wb[h].w * zq[u].w;
+                        const float tot = reduce16<HG>(v, lane);
+                        if (writer && j < LP) S[(ti * HG + hsel) * LDS_S + j] = (j < L) ? s13 * (tot + bb) : 0.f;
+                    }
+                }
             }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) zc[s4] = zn[s4];
         }
     }
     __syncthreads();
@@ -370,74 +412,137 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     }
 
     PROF(6);
-    // ---- phase D2: zbar[h][c] = sum_j P[h][j] z[i][j][c] as a [heads x L] x [L x 64] GEMM on fp32 MFMA per query
-    //      row (A = P from LDS, B = z rows from L2: second pass over z), then o_pair = W_dz zbar + b_dz ----
-    {
-        float* zb = ZB + wave * HG * 64;
-        // down_z row d = lane & 15 of this lane's o_pair outputs, kept in registers for all four query rows
-        float4 wdz[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) wdz[c] = *reinterpret_cast<const float4*>(a.w_dz + (lane & 15) * 64 + 4 * c);
-        const float bdz = a.b_dz[lane & 15];
-        const int nrow = min(4, max(0, L - (i0 + wave * 4)));          // valid query rows of this wave
-        const int ntile = LP >> 4;
-        auto zfetch = [&](int it, float (&vb)[4][4]) {                 // B operands of one K=16 step: 4 column tiles
-            const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
-            const float* zrow = a.z + ((rowb + i0 + wave * 4 + t4) * L) * 64 + r;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int j = k0 + 4 * g + t;
-                j = j < L ? j : L - 1;
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) vb[ct][t] = zrow[(size_t)j * 64 + 16 * ct];
-            }
-        };
-        float vc[4][4], vn[4][4];
-        if (nrow > 0) zfetch(0, vc);
-        f32x4 zacc[4];
-        for (int it = 0; it < nrow * ntile; ++it) {
-            if (it + 1 < nrow * ntile) zfetch(it + 1, vn);
-            const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
-            const int ti = wave * 4 + t4, i = i0 + ti;
-            if (k0 == 0) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) zacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            const float4 pa = (r < HG) ? *reinterpret_cast<const float4*>(S + (ti * HG + r) * LDS_S + k0 + 4 * g)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                zacc[ct] = mfma16(pa.x, vc[ct][0], zacc[ct]);
-                zacc[ct] = mfma16(pa.y, vc[ct][1], zacc[ct]);
-                zacc[ct] = mfma16(pa.z, vc[ct][2], zacc[ct]);
-                zacc[ct] = mfma16(pa.w, vc[ct][3], zacc[ct]);
-            }
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) vc[ct][t] = vn[ct][t];
-            if (k0 + 16 < LP) continue;                       // more K steps of this row to come (wave-uniform)
-            // D: lane (r = column within tile, g), register e -> head 4g+e
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * g + e < HG) zb[(4 * g + e) * 64 + 16 * ct + r] = zacc[ct][e];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
-                const int hh = o >> 4, d = o & 15;
-                float acc = bdz;
-                const float* zz = zb + hh * 64;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const float4 zv = *reinterpret_cast<const float4*>(zz + 4 * c);
-                    acc += wdz[c].x * zv.x; acc += wdz[c].y * zv.y; acc += wdz[c].z * zv.z; acc += wdz[c].w * zv.w;
+    if constexpr (HG >= 4) {
+        // ---- phase D2: zbar[h][c] = sum_j P[h][j] z[i][j][c] as a [heads x L] x [L x 64] GEMM on fp32 MFMA per query
+        //      row (A = P from LDS, B = z rows from L2: second pass over z), then o_pair = W_dz zbar + b_dz ----
+        {
+            float* zb = ZB + wave * HG * 64;
+            // down_z row d = lane & 15 of this lane's o_pair outputs, kept in registers for all four query rows
+            float4 wdz[16];
+    #pragma unroll
+            for (int c = 0; c < 16; ++c) wdz[c] = *reinterpret_cast<const float4*>(a.w_dz + (lane & 15) * 64 + 4 * c);
+            const float bdz = a.b_dz[lane & 15];
+            const int nrow = min(4, max(0, L - (i0 + wave * 4)));          // valid query rows of this wave
+            const int ntile = LP >> 4;
+            auto zfetch = [&](int it, float (&vb)[4][4]) {                 // B operands of one K=16 step: 4 column tiles
+                const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
+                const float* zrow = a.z + ((rowb + i0 + wave * 4 + t4) * L) * 64 + r;
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int j = k0 + 4 * g + t;
+                    j = j < L ? j : L - 1;
+    #pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) vb[ct][t] = zrow[(size_t)j * 64 + 16 * ct];
                 }
-                a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
+            };
+            float vc[4][4], vn[4][4];
+            if (nrow > 0) zfetch(0, vc);
+            f32x4 zacc[4];
+            for (int it = 0; it < nrow * ntile; ++it) {
+                if (it + 1 < nrow * ntile) zfetch(it + 1, vn);
+                const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
+                const int ti = wave * 4 + t4, i = i0 + ti;
+                if (k0 == 0) {
+    #pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) zacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                const float4 pa = (r < HG) ? *reinterpret_cast<const float4*>(S + (ti * HG + r) * LDS_S + k0 + 4 * g)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    #pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    zacc[ct] = mfma16(pa.x, vc[ct][0], zacc[ct]);
+                    zacc[ct] = mfma16(pa.y, vc[ct][1], zacc[ct]);
+                    zacc[ct] = mfma16(pa.z, vc[ct][2], zacc[ct]);
+                    zacc[ct] = mfma16(pa.w, vc[ct][3], zacc[ct]);
+                }
+    #pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t) vc[ct][t] = vn[ct][t];
+                if (k0 + 16 < LP) continue;                       // more K steps of this row to come (wave-uniform)
+                // D: lane (r = column within tile, g), register e -> head 4g+e
+    #pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * g + e < HG) zb[(4 * g + e) * 64 + 16 * ct + r] = zacc[ct][e];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
+                    const int hh = o >> 4, d = o & 15;
+                    float acc = bdz;
+                    const float* zz = zb + hh * 64;
+    #pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const float4 zv = *reinterpret_cast<const float4*>(zz + 4 * c);
+                        acc += wdz[c].x * zv.x; acc += wdz[c].y * zv.y; acc += wdz[c].z * zv.z; acc += wdz[c].w * zv.w;
+                    }
+                    a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // ---- phase D2: zbar[h][c] = sum_j P[h][j] z[i][j][c] ; o_pair = W_dz zbar + b_dz ----
+        {
+            const int c4 = lane & 15, js = lane >> 4;
+            float* zb = ZB + wave * HG * 64;
+            // down_z row d = lane & 15 of this lane's o_pair outputs, kept in registers for all four query rows
+            float4 wdz[16];
+    #pragma unroll
+            for (int c = 0; c < 16; ++c) wdz[c] = *reinterpret_cast<const float4*>(a.w_dz + (lane & 15) * 64 + 4 * c);
+            const float bdz = a.b_dz[lane & 15];
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int ti = wave * 4 + t4, i = i0 + ti;
+                if (i >= L) continue;                          // wave-uniform
+                const float* zrow = a.z + ((rowb + i) * L) * 64;
+                float4 zacc[HG];
+    #pragma unroll
+                for (int h = 0; h < HG; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                constexpr int ZBATCH = 8;
+                for (int jb = 0; jb < L; jb += 4 * ZBATCH) {
+                    float4 zq[ZBATCH];
+    #pragma unroll
+                    for (int u = 0; u < ZBATCH; ++u) {
+                        const int j = jb + 4 * u + js;
+                        zq[u] = (j < L) ? *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < ZBATCH; ++u) {
+                        const int j = jb + 4 * u + js;
+                        if (j < L) {
+    #pragma unroll
+                            for (int h = 0; h < HG; ++h) {
+                                const float pw = S[(ti * HG + h) * LDS_S + j];
+                                zacc[h].x += pw * zq[u].x; zacc[h].y += pw * zq[u].y; zacc[h].z += pw * zq[u].z; zacc[h].w += pw * zq[u].w;
+                            }
+                        }
+                    }
+                }
+    #pragma unroll
+                for (int h = 0; h < HG; ++h) {
+                    float4 v = zacc[h];
+                    v.x = sum_xor32(sum_xor16(v.x)); v.y = sum_xor32(sum_xor16(v.y));
+                    v.z = sum_xor32(sum_xor16(v.z)); v.w = sum_xor32(sum_xor16(v.w));
+                    if (js == 0) *reinterpret_cast<float4*>(zb + h * 64 + 4 * c4) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
+                    const int hh = o >> 4, d = o & 15;
+                    float acc = bdz;
+                    const float* zz = zb + hh * 64;
+    #pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const float4 zv = *reinterpret_cast<const float4*>(zz + 4 * c);
+                        acc += wdz[c].x * zv.x; acc += wdz[c].y * zv.y; acc += wdz[c].z * zv.z; acc += wdz[c].w * zv.w;
+                    }
+                    a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     PROF(7);
@@ -476,12 +581,13 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
         !a->b_b || !a->w_dz || !a->b_dz || !a->head_w || !a->feats || a->B <= 0 || a->L <= 0 || a->ldp < PF_IPA_PROJ ||
         a->ldp % 4)
         return PF_E_BADARG;
-    // head-group split chosen from the number of query tiles so that >= ~256 workgroups exist
+    // head-group split chosen from the number of query tiles so that >= ~256 workgroups exist; a variant whose
+    // S[16][HG][L] tile does not fit the 160 KiB LDS falls through to the next smaller HG (L <= ~290 / 600 / 1200)
     const long qt = (long)a->B * ((a->L + TI - 1) / TI);
     hipStream_t s = (hipStream_t)stream;
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
-    if (qt >= 256) return launch_attn<8>(*a, s);
-    if (qt >= 128) return launch_attn<4>(*a, s);
+    if (qt >= 256) { const int rc = launch_attn<8>(*a, s); if (rc != PF_E_TOOLARGE) return rc; }
+    if (qt >= 128) { const int rc = launch_attn<4>(*a, s); if (rc != PF_E_TOOLARGE) return rc; }
     return launch_attn<2>(*a, s);
 }

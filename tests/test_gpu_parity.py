@@ -382,3 +382,77 @@ def test_philox_sampling_is_world_size_invariant(model):
     gen = batch["generate_mask"]
     counts = torch.bincount(full[0]["seqs"][gen], minlength=20)
     assert counts.sum() == gen.sum()
+
+
+# ------------------------------------------------------------------ ragged shapes / edge cases
+@pytest.mark.parametrize("B,L,lengths", [(1, 37, [30]), (3, 17, [17, 9, 16]), (2, 80, [80, 61]), (1, 130, [121]), (5, 16, None)])
+def test_ga_encoder_ragged_shapes_vs_oracle(model, seeded_sd, B, L, lengths):
+    """Lengths that are not multiples of the 16-row / 64-pair tiles, padding inside a sample, L > 128."""
+    batch = synth.make_pocket_batch(B, L, 6, seed=1000 + L, lengths=lengths)
+    g = torch.Generator().manual_seed(L)
+    enc = O.encode(seeded_sd, batch)
+    R1, x1, ang1, seq1, node, edge = enc
+    t = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    q = torch.randn(B, L, 4, generator=g)
+    Rn = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    R_t = O.so3_geodesic(t[..., None], R1, Rn)
+    x_t = x1 + torch.randn(B, L, 3, generator=g)
+    ang_t = torch.rand(B, L, 5, generator=g) * 2 * math.pi
+    seq_t = torch.randint(0, 20, (B, L), generator=g)
+    resm = batch["res_mask"]
+    ref = O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, node, edge, resm.long())
+    out = model.ga_encoder(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t), cu(node), cu(edge), cu(batch["generate_mask"].long()), cu(resm.long()))
+    G.sync()
+    valid = resm
+    G.assert_close(out[0].cpu()[valid], ref[0][valid], REL, "rotmats")
+    G.assert_close(out[1].cpu()[valid], ref[1][valid], REL, "trans")
+    G.assert_close(out[3].cpu()[valid], ref[3][valid], 2 * REL, "logits")
+    d = (out[2].cpu()[valid] - ref[2][valid]).abs()
+    assert torch.minimum(d, 2 * math.pi - d).max() < 3e-4
+
+
+def test_encode_ragged_vs_oracle(model, seeded_sd):
+    batch = synth.make_pocket_batch(3, 21, 5, seed=77, lengths=[21, 13, 20])
+    ref = O.encode(seeded_sd, batch)
+    got = model.encode({k: cu(v) for k, v in batch.items()})
+    G.assert_close(got[4], ref[4], REL, "node_embed")
+    G.assert_close(got[5], ref[5], REL, "edge_embed")
+    G.assert_close(got[0], ref[0], 1e-5, "frames")
+
+
+def test_sample_flags_pin_channels(model):
+    """sample_bb / sample_ang / sample_seq = False pin the corresponding channels to the ground truth
+    (flow_model.py:304-312, 335-341)."""
+    B, L, NS = 2, 24, 3
+    batch = synth.make_pocket_batch(B, L, 6, seed=5)
+    noise = synth.make_noise(B, L, NS, seed=6)
+    dev_batch = {k: cu(v) for k, v in batch.items()}
+    enc = model.encode(dev_batch)
+    t = model.sample(dev_batch, num_steps=NS, noise=noise, sample_bb=False)
+    assert torch.equal(t[-1]["rotmats"], enc[0].cpu()) and torch.equal(t[-1]["trans"], enc[1].cpu())
+    t = model.sample(dev_batch, num_steps=NS, noise=noise, sample_ang=False)
+    assert torch.equal(t[-1]["angles"], batch["torsion_angle"])
+    t = model.sample(dev_batch, num_steps=NS, noise=noise, sample_seq=False)
+    assert torch.equal(t[-1]["seqs"], batch["aa"])
+
+
+def test_all_residues_generated(model, seeded_sd):
+    """No context at all (generate_mask all True): zero_center_part divides by the full count."""
+    B, L, NS = 2, 16, 2
+    batch = synth.make_pocket_batch(B, L, 15, seed=9)
+    batch["generate_mask"] = torch.ones_like(batch["generate_mask"])
+    noise = synth.make_noise(B, L, NS, seed=10)
+    t = model.sample({k: cu(v) for k, v in batch.items()}, num_steps=NS, noise=noise)
+    ref = O.sample(seeded_sd, batch, noise, NS)
+    assert torch.equal(t[0]["seqs"], ref[0]["seqs"])
+    G.assert_close(t[0]["trans"], ref[0]["trans"], REL, "trans")
+    G.assert_close(t[0]["rotmats"], ref[0]["rotmats"], REL, "rotmats")
+
+
+def test_too_long_sequence_is_rejected_loudly(model):
+    B, L = 1, 1300           # beyond the LDS score tiles of the attention kernels (L <= ~1200 at HG = 2)
+    with pytest.raises(_capi.PepflowHipError):
+        model.ga_encoder(torch.zeros(B, 1, device=G.dev()), torch.eye(3, device=G.dev()).expand(B, L, 3, 3).contiguous(),
+                         torch.zeros(B, L, 3, device=G.dev()), torch.zeros(B, L, 5, device=G.dev()),
+                         torch.zeros(B, L, dtype=torch.long, device=G.dev()), torch.zeros(B, L, 128, device=G.dev()),
+                         torch.zeros(B, L, L, 64, device=G.dev()), torch.ones(B, L, device=G.dev()), torch.ones(B, L, device=G.dev()))
