@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+#define PF_ABI_VERSION 2
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -138,9 +138,9 @@ typedef struct {
     const float* feats;            /* [rows,1536] */
     const float* s_in;             /* [rows,128] */
     const float* mask;             /* [rows] */
-    const void* w_out_f16; const float* b_out; /* ipa linear_out [128,1536] as f16 hi/lo planes [2][128][1536] */
+    const void* w_out_f16; const float* b_out; /* ipa linear_out [128,1536], split planes */
     const float* ln_g; const float* ln_b;     /* ipa_ln */
-    const void* w_in_f16; const float* b_in;   /* seq_tfmr layers.0.self_attn.in_proj -> [2][384][128] f16 */
+    const void* w_in_f16; const float* b_in;   /* seq_tfmr layers.0.self_attn.in_proj [384,128], split planes */
     float* s_ipa;                  /* [rows,128] */
     float* qkv;                    /* [rows,384] */
     int rows;
@@ -158,7 +158,7 @@ typedef struct {
     const float* qkv;              /* [B*L,384] this layer's q|k|v */
     const float* resid;            /* [B*L,128] layer input */
     const float* mask;             /* [B*L] */
-    /* every *_f16 weight is the reference matrix [N,K] pre-split into f16 planes [2][N][K] (hi, lo*2048) */
+    /* every *_f16 weight is the reference matrix [N,K] pre-split into fragment-order f16 planes (engine.split_f16) */
     const void* w_o_f16; const float* b_o; const float* n1_g; const float* n1_b;
     const void* w_1_f16; const float* b_1; const void* w_2_f16; const float* b_2; const float* n2_g; const float* n2_b;
     const void* w_in_next_f16; const float* b_in_next; float* qkv_out; float* v_out;   /* last == 0 */
@@ -198,16 +198,17 @@ int pf_rigid_update_fwd(const pf_rigid_update_args* a, pf_stream_t stream);
  * [z, n_i, n_j] is never built: pre[B*L,512] holds the per-residue terms
  *   a = W1[:,64:128] n, c = W1[:,128:192] n + b1, d = Wf[:,64:128] n, e = Wf[:,128:192] n + bf
  * (pf_node_tfmr_fwd tail, or pf_linear_fwd) and only the z part goes through the per-pair GEMMs.
- * Weights are passed PRE-SPLIT for the split-precision MFMA path: each *_f16 buffer holds two f16
- * planes [2][N][K]: plane 0 = f16(w), plane 1 = f16((w - plane0) * 2048)  (see csrc/edge_transition.hip). */
+ * Weights are passed PRE-SPLIT for the split-precision MFMA path: each *_f16 buffer holds the matrix as two
+ * f16 planes (hi = f16(w), lo = f16((w - hi) * 2048)) in MFMA fragment order
+ * [plane][N/16][K/32][64 lanes][8] -- produced by pepflowww_amd.engine.split_f16 (see csrc/common.h). */
 typedef struct {
     const float* z_in;             /* [B*L*L,64] */
     float* z_out;                  /* may alias z_in */
     const float* pre;              /* [B*L,512] */
-    const void* w1z_f16;           /* trunk.0.weight[:, :64]   -> [2][192][64]  f16 */
-    const void* w2_f16;            /* trunk.2.weight           -> [2][192][192] f16 */
+    const void* w1z_f16;           /* trunk.0.weight[:, :64]  (N=192, K=64)  */
+    const void* w2_f16;            /* trunk.2.weight          (N=192, K=192) */
     const float* b2;               /* trunk.2.bias [192] */
-    const void* wf_f16;            /* final_layer.weight       -> [2][64][192]  f16 */
+    const void* wf_f16;            /* final_layer.weight      (N=64,  K=192) */
     const float* ln_g; const float* ln_b;
     const float* mask;             /* [B*L] */
     int B, L;

@@ -4,16 +4,16 @@
 //   pf_ipa_attn_fwd   : logits (399-430) -> masked softmax (431) -> o, o_pt, o_pair (437-473)
 //                       -> inverse-frame projection + norms (455-463) -> feats[B*L,1536] (475)
 //
-// One workgroup = (sample b, 16 query residues), 4 waves.  Phases (LDS-resident S[16][8][L]):
-//   A  all waves : pair bias  sqrt(1/3) (W_b z_ij + b_b)     -- z streamed once, coalesced float4,
-//                  16-lane butterfly reduction per (pair, head)
-//   B  wave w -> heads 2w,2w+1 : S += scale * Q K^T on fp32 MFMA (operands straight from L2),
-//                  point-distance term on VALU (direct differences: no |q|^2+|k|^2-2qk cancellation),
-//                  mask, softmax (wave shuffles)
-//   C  same waves: [o | o_pt] = P [V | V_pts] on MFMA, o -> feats, o_pt -> LDS
-//   D  all waves : o_pt -> local frame + norms ; zbar = sum_j P z_ij (z streamed a second time,
-//                  L2/MALL hit), o_pair = W_dz zbar + b_dz  (linear in z, so the [B,L,L,16]
-//                  pair_z tensor of the reference is never formed)
+// One workgroup = (sample b, 16 query residues, group of HG heads), 4 waves.  Phases (LDS-resident S[16][HG][L]):
+//   A  all waves : pair bias  sqrt(1/3) (W_b z_ij + b_b)  -- z streamed once: fp32 MFMA GEMM [pairs x 64] x [64 x heads]
+//                  for HG >= 4, VALU + 16-lane DPP butterfly for the 2-head workgroups used at small batch
+//   B  head-split: S += scale * Q K^T on fp32 MFMA (operands straight from L2, next key tile prefetched),
+//                  point-distance term on VALU (direct differences: no |q|^2+|k|^2-2qk cancellation), mask
+//      softmax   : 8 (query, head) rows per wave in parallel, DPP reductions
+//   C  head-split: [o | o_pt] = P [V | V_pts] on MFMA, o -> feats, o_pt -> LDS
+//   D  all waves : o_pt -> local frame + norms ; zbar = sum_j P z_ij (second pass over z, MFMA for HG >= 4),
+//                  o_pair = W_dz zbar + b_dz  (linear in z, so the [B,L,L,16] pair_z tensor of the reference is
+//                  never formed)
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
