@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2
+#define PF_ABI_VERSION 3
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -292,6 +292,34 @@ int pf_so3_geodesic(const float* base, const float* target, const float* t, floa
 int pf_so3_log(const float* rot, float* rotvec, int n, pf_stream_t stream);
 int pf_so3_exp(const float* rotvec, float* rot, int n, pf_stream_t stream);
 int pf_torus_geodesic(const float* base, const float* target, const float* t, float* out, int n, pf_stream_t stream);
+
+/* ---- training forward, flow_model.py:111-227 (no autograd; the backward row is next) -------
+ * corrupt: t = t_raw*(1-2*min_t)+min_t; generated residues are moved to time t on each manifold
+ * (translations 131-134, SO(3) geodesic 136-138, torus geodesic 140-142, simplex + categorical
+ * draw 149-155); context residues keep the clean values.
+ * losses: trans / rot-vf / idealised-backbone / cross-entropy / angle-vf / torsion (161-227),
+ * losses[6] in that order = mean over samples of per_sample[B,6]. */
+typedef struct {
+    /* clean data (from encode) */
+    const float* rot1; const float* trans1; const float* ang1; const int64_t* seq1;
+    const float* gen_mask; const float* res_mask;     /* [B*L] */
+    /* raw noise as drawn: t_raw [B] U[0,1), rot0 [B*L,9], trans0_raw [B*L,3], ang0 [B*L,5], simplex0_raw [B*L,20] */
+    const float* t_raw; const float* rot0; const float* trans0_raw; const float* ang0; const float* simplex0_raw;
+    /* categorical noise: expo != NULL -> Exp(1) draws [2,B*L,20] (0: seq_t, 1: predicted seq); NULL -> Philox */
+    const float* expo; uint64_t seed; int64_t first_sample;
+    /* corrupted state (written by corrupt, read by losses) */
+    float* t; float* rot_t; float* trans_t; float* ang_t; int64_t* seq_t;
+    /* network prediction (losses only); pred_ang_raw = angle_net output before the % 2pi of ga.py:125 */
+    const float* pred_rot; const float* pred_trans; const float* pred_ang_raw; const float* pred_logits;
+    /* outputs of losses */
+    int64_t* pred_seq;            /* [B*L] drawn sequence (optional, may be NULL) */
+    float* per_sample;            /* [B,6] */
+    float* losses;                /* [6] */
+    int B, L;
+    int sample_structure, sample_sequence;
+} pf_train_args;
+int pf_train_corrupt_fwd(const pf_train_args* a, pf_stream_t stream);
+int pf_train_losses_fwd(const pf_train_args* a, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -547,3 +547,62 @@ def sample(sd, batch, noise, num_steps, encoded=None, teacher=None):
         dt = ((ts[i + 1] - ts[i]) * torch.ones(B, 1))[..., None]
         state = euler_step(state, clean, (x0, sx0), gt, gen, dt, next(expo), tmask)
     return traj
+
+
+# ----------------------------------------------------------------------------
+# training forward (models_con/flow_model.py:111-227) with injectable noise
+# ----------------------------------------------------------------------------
+# idealised ALA backbone in the residue frame, openfold/np/residue_constants.py (rigid_group_atom_positions['ALA'])
+BB_IDEAL = torch.tensor([[-0.525, 1.363, 0.0], [0.0, 0.0, 0.0], [1.526, -0.0, -0.0]])
+MIN_T, T_NORM_CLIP, TRANS_SIGMA = 1e-2, 0.9, 1.0      # configs/learn_angle.yaml:17-18,26
+
+
+def backbone_atoms(trans, rots):
+    """all_atom.to_atom37(trans, rots)[:, :, :3] (all_atom.py:39-45,178-197): N, CA, C = R * ideal + x
+    (backbone group frame = identity, aatype = ALA, zero torsions only move O/side chains)."""
+    return torch.einsum("blij,aj->blai", rots, BB_IDEAL) + trans[:, :, None, :]
+
+
+def corrupt(batch, enc, noise):
+    """flow_model.py:125-158.  noise: 't' [B,1] in [0,1) (raw torch.rand), 'trans0' [B,L,3], 'rot0' [B,L,3,3],
+    'ang0' [B,L,5], 'simplex0' [B,L,20] (raw randn), 'expo' [2,B,L,20]."""
+    R1, x1, ang1, seq1, node, edge = enc
+    gen, resm = batch["generate_mask"], batch["res_mask"]
+    t = noise["t"] * (1 - 2 * MIN_T) + MIN_T
+    x0 = zero_center_part(noise["trans0"] * TRANS_SIGMA, gen, resm)
+    x_t = torch.where(gen[..., None], (1 - t[..., None]) * x0 + t[..., None] * x1, x1)
+    R_t = torch.where(gen[..., None, None], so3_geodesic(t[..., None], R1, noise["rot0"]), R1)
+    ang_t = torch.where(gen[..., None], tor_geodesic(t[..., None], ang1, noise["ang0"]), ang1)
+    sx1 = seq_to_simplex(seq1)
+    sx_t = torch.where(gen[..., None], (1 - t[..., None]) * (SIMPLEX_K * noise["simplex0"]) + t[..., None] * sx1, sx1)
+    seq_t = torch.where(gen, categorical(torch.softmax(sx_t, -1), noise["expo"][0]), seq1)
+    return t, R_t, x_t, ang_t, seq_t
+
+
+def forward_losses(sd, batch, noise, encoded=None):
+    """FlowModel.forward, flow_model.py:111-227 -> dict of six scalar losses (no autograd)."""
+    enc = encode(sd, batch) if encoded is None else encoded
+    R1, x1, ang1, seq1, node, edge = enc
+    gen = batch["generate_mask"]
+    g = gen.float()
+    t, R_t, x_t, ang_t, seq_t = corrupt(batch, enc, noise)
+    pR, px, pang, plog = ga_encoder(sd, t, R_t, x_t, ang_t, seq_t, node, edge, batch["res_mask"].long())
+    pseq = torch.where(gen, categorical(torch.softmax(plog, -1), noise["expo"][1]), seq1.clamp(0, 19))
+    scale = 1.0 / (1.0 - torch.minimum(t[..., None], torch.tensor(T_NORM_CLIP)))
+    ng = g.sum(-1) + 1e-8
+    out = {}
+    out["trans_loss"] = (((px - x1) ** 2 * g[..., None]).sum((-1, -2)) / ng).mean()
+    vf_gt, vf_pr = so3_calc_vf(R_t, R1), so3_calc_vf(R_t, pR)
+    out["rot_loss"] = ((((vf_gt - vf_pr) * scale) ** 2 * g[..., None]).sum((-1, -2)) / ng).mean()
+    bb_gt, bb_pr = backbone_atoms(x1, R1), backbone_atoms(px, pR)
+    out["bb_atom_loss"] = (((bb_gt - bb_pr) ** 2 * g[..., None, None]).sum((-1, -2, -3)) / ng).mean()
+    ce = F.cross_entropy(plog.reshape(-1, N_CLASSES), seq1.clamp(0, 19).reshape(-1), reduction="none").view(plog.shape[:-1])
+    out["seqs_loss"] = ((ce * g).sum(-1) / ng).mean()
+    am = torsions_mask()[pseq]
+    am = (torch.cat([am, am], -1).bool() & gen[..., None]).float()
+    na = am.sum((-1, -2)) + 1e-8
+    vec = lambda a: torch.cat([torch.sin(a), torch.cos(a)], -1)
+    avf_gt, avf_pr = vec(tor_logmap(ang_t, ang1)), vec(tor_logmap(ang_t, pang))
+    out["angle_loss"] = ((((avf_gt - avf_pr) * scale) ** 2 * am).sum((-1, -2)) / na).mean()
+    out["torsion_loss"] = (((vec(pang) - vec(ang1)) ** 2 * am).sum((-1, -2)) / na).mean()
+    return out

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -65,6 +65,16 @@ class SamplerArgs(C.Structure):
                 ("B", _i), ("L", _i), ("sample_bb", _i), ("sample_ang", _i), ("sample_seq", _i)]
 
 
+class TrainArgs(C.Structure):
+    _fields_ = [("rot1", _fp), ("trans1", _fp), ("ang1", _fp), ("seq1", _fp), ("gen_mask", _fp), ("res_mask", _fp),
+                ("t_raw", _fp), ("rot0", _fp), ("trans0_raw", _fp), ("ang0", _fp), ("simplex0_raw", _fp),
+                ("expo", _fp), ("seed", C.c_uint64), ("first_sample", C.c_int64),
+                ("t", _fp), ("rot_t", _fp), ("trans_t", _fp), ("ang_t", _fp), ("seq_t", _fp),
+                ("pred_rot", _fp), ("pred_trans", _fp), ("pred_ang_raw", _fp), ("pred_logits", _fp),
+                ("pred_seq", _fp), ("per_sample", _fp), ("losses", _fp),
+                ("B", _i), ("L", _i), ("sample_structure", _i), ("sample_sequence", _i)]
+
+
 class NodeFeatArgs(C.Structure):
     _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("gen_mask", _fp),
                 ("aa_table", _fp), ("freq3", _fp), ("feat", _fp), ("rot1", _fp), ("trans1", _fp), ("mres", _fp),
@@ -114,6 +124,8 @@ _SIGNATURES = {
     "pf_edge_features_fwd": ([C.POINTER(EdgeFeatArgs), _fp], _i),
     "pf_sampler_init": ([C.POINTER(SamplerArgs), _fp, _fp, _fp, _fp, _fp], _i),
     "pf_sampler_step": ([C.POINTER(SamplerArgs), _fp], _i),
+    "pf_train_corrupt_fwd": ([C.POINTER(TrainArgs), _fp], _i),
+    "pf_train_losses_fwd": ([C.POINTER(TrainArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
     "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),

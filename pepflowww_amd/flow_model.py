@@ -8,6 +8,7 @@ from torch import nn
 from . import _capi, featurize
 from .modules import EdgeEmbedder, GAEncoder, NodeEmbedder
 from .sampler import DeviceSampler, default_noise
+from .train_forward import TrainForward, default_train_noise
 
 MAX_NUM_HEAVYATOMS = 15     # pepflow/modules/protein/constants.py:91
 
@@ -31,10 +32,26 @@ class FlowModel(nn.Module):
         _capi.dptr(batch["pos_heavyatom"].contiguous(), name="batch['pos_heavyatom']")
         return featurize.encode(self, batch)
 
-    def forward(self, batch):
-        raise _capi.PepflowHipError(
-            "FlowModel.forward (training losses + backward, flow_model.py:111-227) is the next row of the "
-            "scope table (SURVEY.md 8(f) rank 1) and is not built in this round; sample() is.")
+    # ---- flow_model.py:111-227 (forward only) ----
+    @torch.no_grad()
+    def forward(self, batch, *, noise=None, seed=None, first_sample=0, return_state=False):
+        """Six training losses of one noisy denoise pass, as 0-dim device tensors WITHOUT autograd
+        (the backward kernels are the next scope row; `loss.backward()` raises on these tensors).
+        noise: dict(t [B,1], rot0, trans0, ang0, simplex0[, expo [2,B,L,20]]) to replay draws."""
+        _capi.load()
+        dev = batch["aa"].device
+        B, L = batch["aa"].shape
+        R1, x1, ang1, seq1, node, edge = self.encode(batch)
+        eng = self.ga_encoder.engine(B, L, dev)
+        eng.bind_context(node, edge, batch["res_mask"])
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        tf = TrainForward(eng, (self.sample_structure, self.sample_sequence), first_sample, seed)
+        tf.set_context(R1, x1, ang1, seq1, batch["generate_mask"])
+        tf.corrupt(default_train_noise(B, L) if noise is None else noise)
+        eng.run()
+        losses = tf.compute_losses()
+        return (losses, tf) if return_state else losses
 
     # ---- flow_model.py:229-374 ----
     @torch.no_grad()

@@ -1,0 +1,70 @@
+"""F4: FlowModel.forward (training losses) of the REFERENCE with recorded corruption noise.
+Build container only (needs /root/reference).  Re-run: python tests/golden/make_golden_f4.py"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "tools"))
+import ref_shim  # noqa: E402
+from pepflowww_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+model, cfg = ref_shim.build_reference_model()
+model.load_state_dict(synth.seeded_state_dict(), strict=True)
+import models_con.flow_model as fm  # noqa: E402
+import models_con.torus as torus  # noqa: E402
+from data import all_atom  # noqa: E402
+
+B, L = 3, 24
+batch = synth.make_pocket_batch(B, L, 7, seed=31337, lengths=[24, 20, 23])
+g = torch.Generator().manual_seed(8)
+nz = synth.make_noise(B, L, 1, seed=123)
+noise = {"t": torch.rand(B, 1, generator=g), "trans0": nz["trans0"], "rot0": nz["rot0"], "ang0": nz["ang0"],
+         "simplex0": nz["simplex0"]}
+rec = []
+orig = dict(multinomial=torch.multinomial, rand=torch.rand, randn=torch.randn, randn_like=torch.randn_like,
+            so3=fm.uniform_so3, tor=torus.tor_random_uniform)
+
+
+def multinomial_rec(c, n, *a, **k):
+    st = torch.get_rng_state()
+    out = orig["multinomial"](c, n, *a, **k)
+    torch.set_rng_state(st)
+    Ex = torch.empty_like(c).exponential_(1)
+    assert torch.equal(out[:, 0], torch.argmax(c / Ex, -1))
+    rec.append(Ex.reshape(B, L, 20).clone())
+    return out
+
+
+torch.multinomial = multinomial_rec
+torch.rand = lambda *s, **k: noise["t"].clone()
+torch.randn = lambda *s, **k: noise["trans0"].clone()
+torch.randn_like = lambda x, **k: noise["simplex0"].clone()
+fm.uniform_so3 = lambda nb, nr, device=None: noise["rot0"].clone()
+torus.tor_random_uniform = lambda *s, dtype=None, device=None: noise["ang0"].clone()
+torch.manual_seed(7)
+try:
+    with torch.no_grad():
+        losses = model(batch)
+finally:
+    torch.multinomial, torch.rand, torch.randn, torch.randn_like = orig["multinomial"], orig["rand"], orig["randn"], orig["randn_like"]
+    fm.uniform_so3, torus.tor_random_uniform = orig["so3"], orig["tor"]
+assert len(rec) == 2
+# idealised backbone KAT
+q = torch.randn(2, 5, 4, generator=g)
+from openfold.utils import rigid_utils as ru  # noqa: E402
+Rb = ru.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+xb = torch.randn(2, 5, 3, generator=g) * 4
+bb = all_atom.to_atom37(xb, Rb)[:, :, :3]
+out = {"expo": torch.stack(rec, 0), "bb_R": Rb, "bb_x": xb, "bb_out": bb}
+out.update({k: v for k, v in noise.items()})
+out.update({"loss_" + k: v for k, v in losses.items()})
+out.update({"batch_" + k: v for k, v in batch.items()})
+np.savez_compressed(os.path.join(HERE, "f4_train_forward.npz"), **{k: v.detach().cpu().numpy() for k, v in out.items()})
+print({k: float(v) for k, v in losses.items()})

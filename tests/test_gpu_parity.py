@@ -456,3 +456,86 @@ def test_too_long_sequence_is_rejected_loudly(model):
                          torch.zeros(B, L, 3, device=G.dev()), torch.zeros(B, L, 5, device=G.dev()),
                          torch.zeros(B, L, dtype=torch.long, device=G.dev()), torch.zeros(B, L, 128, device=G.dev()),
                          torch.zeros(B, L, L, 64, device=G.dev()), torch.ones(B, L, device=G.dev()), torch.ones(B, L, device=G.dev()))
+
+
+# ------------------------------------------------------------------ training forward (flow_model.py:111-227)
+@pytest.fixture(scope="module")
+def f4(golden_dir):
+    return load(golden_dir, "f4_train_forward.npz")
+
+
+def _to_dev(d):
+    return {k: cu(v) for k, v in d.items()}
+
+
+def test_train_forward_losses_vs_reference(f4, model):
+    """The six losses of the REFERENCE's model(batch) with its RNG draws replayed."""
+    batch = _batch(f4)
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    out = model(_to_dev(batch), noise=noise)
+    G.sync()
+    assert list(out) == ["trans_loss", "rot_loss", "bb_atom_loss", "seqs_loss", "angle_loss", "torsion_loss"]
+    for k, v in out.items():
+        ref = f4["loss_" + k].item()
+        assert v.device.type == "cuda" and v.dim() == 0 and not v.requires_grad
+        assert abs(v.item() - ref) <= REL * abs(ref), (k, v.item(), ref)
+
+
+def test_train_corrupt_state_vs_oracle(f4, model, seeded_sd):
+    """Corrupted state (t, R_t, x_t, angles_t, seqs_t) and the drawn sequence, element-wise."""
+    batch = _batch(f4)
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    _, tf = model(_to_dev(batch), noise=noise, return_state=True)
+    G.sync()
+    B, L = batch["aa"].shape
+    enc = O.encode(seeded_sd, batch)
+    t, R_t, x_t, ang_t, seq_t = O.corrupt(batch, enc, noise)
+    eng = tf.eng
+    G.assert_close(eng.t.view(B, 1), t, 1e-6, "t")
+    G.assert_close(eng.rot_t.view(B, L, 3, 3), R_t, REL, "R_t")
+    G.assert_close(eng.trans_t.view(B, L, 3), x_t, REL, "x_t")
+    G.assert_close(eng.ang_t.view(B, L, 5), ang_t, REL, "angles_t")
+    assert torch.equal(eng.seq_t.view(B, L).cpu(), seq_t)
+    pR, px, pang, plog = O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, enc[4], enc[5], batch["res_mask"].long())
+    pseq = torch.where(batch["generate_mask"], O.categorical(torch.softmax(plog, -1), noise["expo"][1]), enc[3].clamp(0, 19))
+    assert torch.equal(tf.pred_seq.view(B, L).cpu(), pseq)
+
+
+def test_train_forward_full_size_vs_oracle(model, seeded_sd):
+    """BASELINE cfg2 shape (B=16, L=64), recorded exponential draws, against the CPU oracle."""
+    B, L = 16, 64
+    batch = synth.make_pocket_batch(B, L, 10, seed=77)
+    nz = synth.make_noise(B, L, 1, seed=5)
+    noise = {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(3)), "trans0": nz["trans0"], "rot0": nz["rot0"],
+             "ang0": nz["ang0"], "simplex0": nz["simplex0"], "expo": nz["expo"][:2]}
+    out, tf = model(_to_dev(batch), noise=noise, return_state=True)
+    G.sync()
+    ref = O.forward_losses(seeded_sd, batch, noise)
+    for k, v in out.items():
+        assert abs(v.item() - ref[k].item()) <= REL * abs(ref[k].item()), (k, v.item(), ref[k].item())
+    # mean over samples of the per-sample table is what is reported
+    G.assert_close(tf.per_sample.mean(0), tf.losses, 1e-6, "batch mean")
+
+
+def test_train_forward_properties(model):
+    """No generated residue -> every loss is exactly 0 (masked sums over an empty set);
+    Philox draws are keyed by the global sample index (shard == slice of the full batch);
+    the result carries no autograd graph."""
+    B, L = 4, 32
+    batch = synth.make_pocket_batch(B, L, 6, seed=9)
+    none = dict(batch)
+    none["generate_mask"] = torch.zeros_like(batch["generate_mask"])
+    out = model(_to_dev(none), seed=1)
+    assert all(v.item() == 0.0 for v in out.values()), {k: v.item() for k, v in out.items()}
+    nz = synth.make_noise(B, L, 1, seed=2)
+    noise = {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(4)), **{k: nz[k] for k in ("trans0", "rot0", "ang0", "simplex0")}}
+    _, full = model(_to_dev(batch), noise=noise, seed=99, return_state=True)
+    per_full, seq_full = full.per_sample.cpu().clone(), full.pred_seq.view(B, L).cpu().clone()
+    lo, hi = 1, 3
+    sh = {k: v[lo:hi] for k, v in batch.items()}
+    nsh = {k: v[lo:hi] for k, v in noise.items()}
+    _, part = model(_to_dev(sh), noise=nsh, seed=99, first_sample=lo, return_state=True)
+    assert torch.equal(part.pred_seq.view(hi - lo, L).cpu(), seq_full[lo:hi])
+    assert torch.equal(part.per_sample.cpu(), per_full[lo:hi])
+    with pytest.raises(RuntimeError):
+        full.losses[0].backward()

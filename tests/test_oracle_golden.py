@@ -146,3 +146,24 @@ def test_sample_teacher_forced(f3, seeded_sd):
         d = (traj[i]["angles"] - f3[f"step{i}_angles"]).abs()
         assert torch.minimum(d, 2 * torch.pi - d).max() < 1e-3
         assert torch.equal(traj[i]["seqs_simplex"], f3[f"step{i}_seqs_simplex"])
+
+
+@pytest.fixture(scope="module")
+def f4(golden_dir):
+    return load(golden_dir, "f4_train_forward.npz")
+
+
+def test_backbone_atoms_kat(f4):
+    """all_atom.to_atom37(...)[:, :, :3] of the reference on random frames."""
+    close(O.backbone_atoms(f4["bb_x"], f4["bb_R"]), f4["bb_out"], 1e-6, 1e-6)
+
+
+def test_training_forward_losses(f4, seeded_sd):
+    """FlowModel.forward of the reference (flow_model.py:111-227) with its RNG draws recorded."""
+    batch = {k[6:]: v for k, v in f4.items() if k.startswith("batch_")}
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    out = O.forward_losses(seeded_sd, batch, noise)
+    assert set(out) == {k[5:] for k in f4 if k.startswith("loss_")}
+    for k, v in out.items():
+        ref = f4["loss_" + k].item()
+        assert abs(v.item() - ref) <= 2e-6 * abs(ref), (k, v.item(), ref)
