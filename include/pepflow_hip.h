@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -212,6 +212,10 @@ typedef struct {
     const float* ln_g; const float* ln_b;
     const float* mask;             /* [B*L] */
     int B, L;
+    /* optional: the three matrices as ONE 256 KiB stream of 128 fragment pairs in consumption order
+     * (pepflowww_amd.engine.pack_et_stream).  When set, the persistent LDS-ring kernel is used
+     * (csrc/edge_transition_v3.hip) and w1z_f16 / w2_f16 / wf_f16 may be NULL. */
+    const void* w_stream;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 

@@ -252,30 +252,60 @@ template <int WT> __device__ __forceinline__ void acc_zero1(f32x4 (&a)[WT], f32x
 // acc_main/acc_corr[WT][PT] += W[n0 + 16*wt + r][k_off : k_off + K] (x) X[16*pt + r][:K]   (features x pairs)
 //   W  : fragment-order f16 planes of an [N][Kw] matrix (engine.split_f16), hi plane then lo plane
 //   Xh/Xl : LDS f16 planes [64][ldx]
-template <int WT, int PT>
+// SWZ: the LDS planes are XOR-swizzled at 16-byte granularity, chunk ^= (row >> 2) & 1, with a row stride of
+// 32 (mod 64) bytes: ds_read_b128 fragment reads are then bank-conflict free in the b128 lane grouping of gfx950
+// (MI355X_MICROARCH.md, LDS) while the 8-byte epilogue writes stay at their 2-way minimum (see swz_col()).
+// First K-step of a wave's weight slab, requested EARLY (before the previous stage's epilogue / barrier) so the
+// L2 latency of a stage's first fragments is not exposed at its start.
+template <int WT>
+struct WPre {
+    half8 h[WT], l[WT];
+    __device__ __forceinline__ void load(const void* planes, int N, int Kw, int n0) {
+        const int lane = threadIdx.x & 63;
+        const int wsteps = Kw >> 5;
+        const _Float16* wh = reinterpret_cast<const _Float16*>(planes) + ((size_t)(n0 >> 4) * wsteps * 64 + lane) * 8;
+        const _Float16* wl = wh + (size_t)N * Kw;
+        const size_t tstride = (size_t)wsteps * 512;
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+            h[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride);
+            l[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
+        }
+    }
+};
+
+template <int WT, int PT, bool SWZ = false>
 __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, int n0, int K,
                                            const _Float16* Xh, const _Float16* Xl, int ldx,
-                                           f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT]) {
+                                           f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT], const WPre<WT>* pre = nullptr) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wsteps = Kw >> 5;
     const _Float16* wh = reinterpret_cast<const _Float16*>(planes) + ((size_t)(n0 >> 4) * wsteps * 64 + lane) * 8;
     const _Float16* wl = wh + (size_t)N * Kw;
     const size_t tstride = (size_t)wsteps * 512;          // f16 elements between consecutive feature tiles
-    const _Float16* xh = Xh + r * ldx + 8 * g;
-    const _Float16* xl = Xl + r * ldx + 8 * g;
+    const int gs = SWZ ? (g ^ ((r >> 2) & 1)) : g;
+    const _Float16* xh = Xh + r * ldx + 8 * gs;
+    const _Float16* xl = Xl + r * ldx + 8 * gs;
     half8 bh[WT], bl[WT], nh[WT], nl[WT];
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) {
-        bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride);
-        bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
+        if (pre) { bh[wt] = pre->h[wt]; bl[wt] = pre->l[wt]; }
+        else {
+            bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride);
+            bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
+        }
     }
     const int nst = K >> 5;
     for (int st = 0; st < nst; ++st) {
         if (st + 1 < nst) {
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt) {
+#ifdef PF_EXP_NOWSTREAM   // dev experiment: no weight streaming (wrong results)
+                nh[wt] = bh[wt]; nl[wt] = bl[wt];
+#else
                 nh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)(st + 1) * 512);
                 nl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)(st + 1) * 512);
+#endif
             }
         }
         half8 ah[PT], al[PT];
@@ -301,6 +331,12 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; bl[wt] = nl[wt]; }
     }
+}
+
+// f16 column (within a swizzled plane row) where accumulator lane (r, g) stores its 4 consecutive features n0 + 4g
+// (n0 a multiple of 16): 16-byte chunk (n0/8 + g/2) ^ ((r>>2)&1), 8-byte half g&1.
+__device__ __forceinline__ int swz_col(int n0, int r, int g) {
+    return n0 + 8 * ((g >> 1) ^ ((r >> 2) & 1)) + 4 * (g & 1);
 }
 
 template <int MT, int NT>

@@ -24,12 +24,13 @@
 //     of one pair: they are re-split and stored to LDS with one 8-byte write per plane, directly in the
 //     layout the next GEMM reads;
 //   * LayerNorm + mask + coalesced store fused in the epilogue.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
 #ifdef PF_PROFILE
 __device__ long long g_prof_et[64];
-#define PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof_et[i] = clock64(); } while (0)
+#define PROF(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_prof_et[i] = clock64(); } while (0)   // a steady-state tile
 extern "C" int pf_debug_prof_et(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_et), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
 }
@@ -39,14 +40,22 @@ extern "C" int pf_debug_prof_et(long long* out, int n) {
 
 namespace {
 
-constexpr int P = 64;            // pairs per workgroup
 constexpr int HID = 192;
-constexpr int LDHh = HID + 8;    // f16 row stride of the hidden planes (400 B: conflict-free b128 reads)
-constexpr int LDZh = 64 + 8;     // f16 row stride of the z planes
+constexpr int LDHh = HID + 16;   // f16 row stride of the hidden planes: 416 B = 32 (mod 64) + chunk swizzle -> conflict-free b128 reads
+constexpr int LDZh = 64 + 16;    // f16 row stride of the z planes (160 B, same rule)
 constexpr int LDY = 68;          // fp32 row stride of the pre-LayerNorm tile
 constexpr float LO_INV = PF_LO_INV;
 
-__global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transition_args a, long long npairs) {
+// NPH = number of pair halves: 1 -> 4 waves, each wave owns 48 features x all 64 pairs (2 waves/SIMD, 254 VGPRs);
+//       2 -> 8 waves, wave = (pair half, feature slab): 48 features x 32 pairs (4 waves/SIMD, <=128 VGPRs); the two
+//            waves of a slab read the same weight fragments close in time (second read hits the 32 KiB L1).
+// P = pairs per workgroup (64 or 32).  P = 32 / NPH = 1: 4 waves x (48 features x 32 pairs), 37 KB LDS -> four
+//     INDEPENDENT workgroups per CU whose phases (HBM prologue, GEMMs, epilogues) overlap each other.
+template <int P, int NPH>
+__global__ __launch_bounds__(256 * NPH, (P == 32 ? 4 : 2)) void edge_transition_kernel(pf_edge_transition_args a, long long npairs) {
+    constexpr int NT = 256 * NPH;    // threads
+    constexpr int PT = P / 16 / NPH; // 16-pair tiles per wave
+    constexpr int ZQ = P * 16 / NT;  // z float4 per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* Hh = reinterpret_cast<_Float16*>(smem_raw);          // [P][LDHh] hidden hi plane
     _Float16* Hl = Hh + P * LDHh;                                  // lo plane
@@ -55,7 +64,10 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     float* Gs = reinterpret_cast<float*>(Zl + P * LDZh);           // [128] LayerNorm gamma | beta
     float* Ys = reinterpret_cast<float*>(smem_raw);                // [P][LDY] fp32, aliases Hh/Hl after GEMM3
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) & 3;          // feature slab
+    const int ph = tid >> 8;                  // pair half (0 when NPH == 1)
+    const int prow0 = ph * (P / NPH);         // first pair row of this wave
     const int r = lane & 15, g = lane >> 4;
     const long long p0 = (long long)blockIdx.x * P;
     const int L = a.L;
@@ -67,53 +79,73 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     //      GEMM1 epilogue (24 float4 per lane) and the LayerNorm constants; one exposed latency instead of four.
     //      (A persistent-workgroup variant that prefetches the next tile's z was tried: it needs 16 more live
     //      registers, spills 153 VGPRs at this tile shape and runs 1.9x slower.) ----
-    float4 zt[4];
+    float4 zt[ZQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
+    for (int q = 0; q < ZQ; ++q) {
+        const int idx = tid + NT * q;
         const long long pr = p0 + (idx >> 4);
         zt[q] = (pr < npairs) ? *reinterpret_cast<const float4*>(a.z_in + pr * 64 + 4 * (idx & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // residue rows (b*L+i, b*L+j) of the 4 pairs this lane owns in the accumulator layout: pair = 16*pt + r
-    int rbi[4], rbj[4];
+    // residue rows (b*L+i, b*L+j) of the 4 pairs this lane owns in the accumulator layout: pair = 16*pt + r.
+    // (b, i, j) of the tile's first pair is workgroup-uniform (scalar unit); lanes add a <64 offset in 32-bit
+    // arithmetic -- per-lane 64-bit divisions were ~900 of this kernel's ~2900 instructions.
+    const int b0 = (int)(p0 / LL);
+    const int rem0 = (int)(p0 - (long long)b0 * LL);
+    const int i0 = rem0 / L, j0 = rem0 - i0 * L;
+    const long long last = npairs - 1 - p0;              // >= 0: offset of the last valid pair from p0
+    auto rows_of = [&](int off, int& rb_i, int& rb_j) {
+        if (off > last) off = (int)last;             // (off < 64 always)
+        int b = b0, i = i0, j = j0 + off;
+        if (L >= 64) {                                   // uniform branch: at most one wrap of j and of i
+            if (j >= L) { j -= L; ++i; }
+            if (i >= L) { i -= L; ++b; }
+        } else {
+            const unsigned rem = (unsigned)rem0 + (unsigned)off;
+            const unsigned LLu = (unsigned)LL;
+            const unsigned db = rem / LLu, r2 = rem - db * LLu;
+            b = b0 + (int)db;
+            i = (int)(r2 / (unsigned)L);
+            j = (int)r2 - i * L;
+        }
+        rb_i = b * L + i;
+        rb_j = b * L + j;
+    };
+    int rbi[PT], rbj[PT];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        long long pr = p0 + pt * 16 + r;
-        if (pr >= npairs) pr = npairs - 1;
-        const int b = (int)(pr / LL);
-        const int rem = (int)(pr - (long long)b * LL);
-        const int i = rem / L, j = rem - i * L;
-        rbi[pt] = b * L + i;
-        rbj[pt] = b * L + j;
-    }
-    float4 pa[3][4], pc[3][4];
+    for (int pt = 0; pt < PT; ++pt) rows_of(prow0 + pt * 16 + r, rbi[pt], rbj[pt]);
+    WPre<1> w1pre;                           // first weight fragments of GEMM1, in flight while z arrives
+    w1pre.load(a.w1z_f16, HID, 64, wave * 48);
+    float4 pa[3][PT], pc[3][PT];
 #pragma unroll
     for (int wt = 0; wt < 3; ++wt) {
         const int n = wave * 48 + wt * 16 + 4 * g;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
+#ifdef PF_EXP_NOGATHER     // dev experiment: no per-residue gathers (wrong results)
+            pa[wt][pt] = make_float4(0.f, 0.f, 0.f, (float)n); pc[wt][pt] = make_float4((float)rbi[pt], 0.f, 0.f, 0.f);
+#else
             pa[wt][pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + n);
             pc[wt][pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 192 + n);
+#endif
         }
     }
     float lnmk = 0.f;                                   // edge mask of the pair row this thread normalises at the end
-    {
-        const long long pr = p0 + (tid >> 2);
-        if (pr < npairs) {
-            const int b = (int)(pr / LL);
-            const int rem = (int)(pr - (long long)b * LL);
-            lnmk = a.mask[b * L + rem / L] * a.mask[b * L + rem % L];
-        }
+    constexpr int TPR = NT / P;                         // LayerNorm threads per pair row (4 or 8)
+    if ((tid / TPR) <= last) {
+        int mi, mj;
+        rows_of(tid / TPR, mi, mj);
+        lnmk = a.mask[mi] * a.mask[mj];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
+    for (int q = 0; q < ZQ; ++q) {
+        const int idx = tid + NT * q;
         const int row = idx >> 4, c4 = idx & 15;
         const float v[4] = {zt[q].x, zt[q].y, zt[q].z, zt[q].w};
         half4 hi, lo;
         split4(v, hi, lo);
-        *reinterpret_cast<half4*>(Zh + row * LDZh + 4 * c4) = hi;
-        *reinterpret_cast<half4*>(Zl + row * LDZh + 4 * c4) = lo;
+        const int col = 8 * ((c4 >> 1) ^ ((row >> 2) & 1)) + 4 * (c4 & 1);      // swizzled 16-byte chunk
+        *reinterpret_cast<half4*>(Zh + row * LDZh + col) = hi;
+        *reinterpret_cast<half4*>(Zl + row * LDZh + col) = lo;
     }
     __syncthreads();
 
@@ -121,15 +153,18 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     // ---- GEMM1: t1 = W1z z (K=64); wave slab = 48 features as three 16-feature sub-GEMMs (32 accumulator
     //      registers live instead of 96, which is what lets the gathers above stay in registers);
     //      + a_i + c_j, ReLU -> H planes ----
+    WPre<3> w2pre;                           // first K-step of W2, requested before the last GEMM1 epilogue
 #pragma unroll
     for (int wt = 0; wt < 3; ++wt) {
-        f32x4 am[1][4], ac[1][4];
-        acc_zero<1, 4>(am);
-        acc_zero<1, 4>(ac);
-        gemm_split<1, 4>(a.w1z_f16, HID, 64, wave * 48 + wt * 16, 64, Zh, Zl, LDZh, am, ac);
-        const int n = wave * 48 + wt * 16 + 4 * g;           // 4 consecutive features n..n+3
+        f32x4 am[1][PT], ac[1][PT];
+        acc_zero<1, PT>(am);
+        acc_zero<1, PT>(ac);
+        gemm_split<1, PT, true>(a.w1z_f16, HID, 64, wave * 48 + wt * 16, 64, Zh + prow0 * LDZh, Zl + prow0 * LDZh, LDZh, am, ac,
+                                wt == 0 ? &w1pre : nullptr);
+        if (wt == 2) w2pre.load(a.w2_f16, HID, HID, wave * 48);
+        const int ncol = swz_col(wave * 48 + wt * 16, r, g); // LDS column of the 4 consecutive features n..n+3
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
             float v[4];
             v[0] = fmaxf(am[0][pt][0] + ac[0][pt][0] * LO_INV + pa[wt][pt].x + pc[wt][pt].x, 0.f);
             v[1] = fmaxf(am[0][pt][1] + ac[0][pt][1] * LO_INV + pa[wt][pt].y + pc[wt][pt].y, 0.f);
@@ -137,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
             v[3] = fmaxf(am[0][pt][3] + ac[0][pt][3] * LO_INV + pa[wt][pt].w + pc[wt][pt].w, 0.f);
             half4 hi, lo;
             split4(v, hi, lo);
-            *reinterpret_cast<half4*>(Hh + (pt * 16 + r) * LDHh + n) = hi;
-            *reinterpret_cast<half4*>(Hl + (pt * 16 + r) * LDHh + n) = lo;
+            *reinterpret_cast<half4*>(Hh + (prow0 + pt * 16 + r) * LDHh + ncol) = hi;
+            *reinterpret_cast<half4*>(Hl + (prow0 + pt * 16 + r) * LDHh + ncol) = lo;
         }
     }
     PROF(2);
@@ -146,20 +181,23 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
 
     PROF(3);
     // ---- GEMM2: h2 = relu(W2 h1 + b2) (K=192) ----
+    WPre<1> wfpre;                           // first K-step of Wf, requested before the GEMM2 epilogue
     {
-        f32x4 am[3][4], ac[3][4];
-        acc_zero<3, 4>(am);
-        acc_zero<3, 4>(ac);
-        gemm_split<3, 4>(a.w2_f16, HID, HID, wave * 48, HID, Hh, Hl, LDHh, am, ac);
+        f32x4 am[3][PT], ac[3][PT];
+        acc_zero<3, PT>(am);
+        acc_zero<3, PT>(ac);
+        gemm_split<3, PT, true>(a.w2_f16, HID, HID, wave * 48, HID, Hh + prow0 * LDHh, Hl + prow0 * LDHh, LDHh, am, ac, &w2pre);
         PROF(4);
+        wfpre.load(a.wf_f16, 64, HID, wave * 16);
         __syncthreads();                       // every wave finished reading h1
         PROF(5);
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
             const int n = wave * 48 + wt * 16 + 4 * g;
+            const int ncol = swz_col(wave * 48 + wt * 16, r, g);
             const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + n);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
+            for (int pt = 0; pt < PT; ++pt) {
                 float v[4];
                 v[0] = fmaxf(am[wt][pt][0] + ac[wt][pt][0] * LO_INV + b2.x, 0.f);
                 v[1] = fmaxf(am[wt][pt][1] + ac[wt][pt][1] * LO_INV + b2.y, 0.f);
@@ -167,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
                 v[3] = fmaxf(am[wt][pt][3] + ac[wt][pt][3] * LO_INV + b2.w, 0.f);
                 half4 hi, lo;
                 split4(v, hi, lo);
-                *reinterpret_cast<half4*>(Hh + (pt * 16 + r) * LDHh + n) = hi;
-                *reinterpret_cast<half4*>(Hl + (pt * 16 + r) * LDHh + n) = lo;
+                *reinterpret_cast<half4*>(Hh + (prow0 + pt * 16 + r) * LDHh + ncol) = hi;
+                *reinterpret_cast<half4*>(Hl + (prow0 + pt * 16 + r) * LDHh + ncol) = lo;
             }
         }
     }
@@ -177,59 +215,62 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
     PROF(6);
     // ---- GEMM3: y = Wf h2 + Wf[:, :64] z + d_i + e_j ; wave slab = 16 features -> fp32 tile ----
     {
-        f32x4 am[1][4], ac[1][4];
-        acc_zero<1, 4>(am);
-        acc_zero<1, 4>(ac);
-        float4 pd[4], pe[4];                   // d_i / e_j gathers of the epilogue, requested before the GEMM
+        f32x4 am[1][PT], ac[1][PT];
+        acc_zero<1, PT>(am);
+        acc_zero<1, PT>(ac);
+        float4 pd[PT], pe[PT];                 // d_i / e_j gathers of the epilogue, requested before the GEMM
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
             pd[pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + 384 + wave * 16 + 4 * g);
             pe[pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 448 + wave * 16 + 4 * g);
         }
-        gemm_split<1, 4>(a.wf_f16, 64, HID, wave * 16, HID, Hh, Hl, LDHh, am, ac);
-        gemm_split<1, 4>(a.wf_f16, 64, HID, wave * 16, 64, Zh, Zl, LDZh, am, ac);
+        gemm_split<1, PT, true>(a.wf_f16, 64, HID, wave * 16, HID, Hh + prow0 * LDHh, Hl + prow0 * LDHh, LDHh, am, ac, &wfpre);
+        gemm_split<1, PT, true>(a.wf_f16, 64, HID, wave * 16, 64, Zh + prow0 * LDZh, Zl + prow0 * LDZh, LDZh, am, ac);
         PROF(7);
         __syncthreads();                       // h2 fully consumed -> reuse the H region for y (fp32)
         const int n = wave * 16 + 4 * g;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
             float4 y;
             y.x = am[0][pt][0] + ac[0][pt][0] * LO_INV + pd[pt].x + pe[pt].x;
             y.y = am[0][pt][1] + ac[0][pt][1] * LO_INV + pd[pt].y + pe[pt].y;
             y.z = am[0][pt][2] + ac[0][pt][2] * LO_INV + pd[pt].z + pe[pt].z;
             y.w = am[0][pt][3] + ac[0][pt][3] * LO_INV + pd[pt].w + pe[pt].w;
-            *reinterpret_cast<float4*>(Ys + (pt * 16 + r) * LDY + n) = y;
+            *reinterpret_cast<float4*>(Ys + (prow0 + pt * 16 + r) * LDY + n) = y;
         }
     }
     __syncthreads();
 
     PROF(8);
-    // ---- LayerNorm(64) + edge mask + coalesced store: 4 threads per pair row ----
+    // ---- LayerNorm(64) + edge mask + coalesced store: TPR threads per pair row ----
     {
-        const int row = tid >> 2, qd = tid & 3;
+        constexpr int EPT = 64 / TPR;          // elements per thread (16 or 8)
+        const int row = tid / TPR, qd = tid % TPR;
         const long long pr = p0 + row;
-        float v[16];
+        float v[EPT];
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float4 t = *reinterpret_cast<const float4*>(Ys + row * LDY + 16 * qd + 4 * c);
+        for (int c = 0; c < EPT / 4; ++c) {
+            float4 t = *reinterpret_cast<const float4*>(Ys + row * LDY + EPT * qd + 4 * c);
             v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
             s += (t.x + t.y) + (t.z + t.w);
         }
         s += lane_xor1(s);
         s += lane_xor2(s);
+        if (TPR == 8) s += lane_xor4(s);
         const float mean = s * (1.f / 64.f);
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { float d = v[c] - mean; q += d * d; }
+        for (int c = 0; c < EPT; ++c) { float d = v[c] - mean; q += d * d; }
         q += lane_xor1(q);
         q += lane_xor2(q);
+        if (TPR == 8) q += lane_xor4(q);
         const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
         if (pr < npairs) {
             const float mk = lnmk;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int n = 16 * qd + 4 * c;
+            for (int c = 0; c < EPT / 4; ++c) {
+                const int n = EPT * qd + 4 * c;
                 const float4 gm = *reinterpret_cast<const float4*>(Gs + n);
                 const float4 bt = *reinterpret_cast<const float4*>(Gs + 64 + n);
                 float4 o;
@@ -246,15 +287,24 @@ __global__ __launch_bounds__(256, 2) void edge_transition_kernel(pf_edge_transit
 
 }  // namespace
 
+int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream);   // edge_transition_v3.hip
+
 extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream) {
-    if (!a || !a->z_in || !a->z_out || !a->pre || !a->w1z_f16 || !a->w2_f16 || !a->b2 || !a->wf_f16 || !a->ln_g ||
-        !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
+    if (!a || !a->z_in || !a->z_out || !a->pre || !a->b2 || !a->ln_g || !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
         return PF_E_BADARG;
+    static const int force_tiled = [] { const char* e = getenv("PF_ET_TILE"); return e ? atoi(e) : 0; }();
+    if (a->w_stream && !force_tiled) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);
+    if (!a->w1z_f16 || !a->w2_f16 || !a->wf_f16) return PF_E_BADARG;
     const long long npairs = (long long)a->B * a->L * a->L;
+    // tile shape: PF_ET_TILE=64x1 (64 pairs, 4 waves), 64x2 (64 pairs, 8 waves), 32 (32 pairs, 4 waves; default)
+    const int mode = force_tiled ? force_tiled : 642;
+    const int P = mode == 32 ? 32 : 64;
     const long long nblk = (npairs + P - 1) / P;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
     const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16) + 128 * sizeof(float);
-    hipLaunchKernelGGL(edge_transition_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *a, npairs);
+    if (mode == 32) hipLaunchKernelGGL((edge_transition_kernel<32, 1>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *a, npairs);
+    else if (mode == 642) hipLaunchKernelGGL((edge_transition_kernel<64, 2>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, *a, npairs);
+    else hipLaunchKernelGGL((edge_transition_kernel<64, 1>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *a, npairs);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,376 @@
+// pf_edge_transition_fwd, persistent form ("v3") -- EdgeTransition (ipa_pytorch.py:233-248) + edge mask (ga.py:118).
+//
+//   x = [z_ij, n_i, n_j];  h1 = relu(W1 x + b1);  h2 = relu(W2 h1 + b2);
+//   y = Wf (h2 + x) + bf;  z' = LayerNorm(y) * m_i m_j
+//
+// Same arithmetic as edge_transition.hip (split-precision MFMA, per-residue terms from pre[B*L,512]); different
+// machine mapping, built around what the PMC counters showed for the tiled kernel (waves parked 67 % of their time
+// at barriers / load latencies between three short GEMM phases, 260 KB of weights re-streamed from L2 per 64 pairs,
+// 2 KB of per-residue gathers per pair):
+//   * one PERSISTENT workgroup per CU: 8 consumer waves + 1 loader wave, tiles of 8 rows i x 16 columns j
+//     (consumer wave w <-> row i0 + w, lane & 15 <-> column j0 + r);
+//   * a consumer keeps every activation of its 16 pairs in REGISTERS for the whole tile: the MFMA result layout
+//     (4 consecutive features of one pair per lane) is directly the B-operand layout of the next GEMM under a
+//     fixed permutation of its K index, so the host packs W2 / Wf with that permutation and the activations never
+//     touch LDS -- no inter-GEMM barriers, no LDS round trip;
+//   * the 256 KB weight set is a linear stream of 128 fragment pairs (hi|lo, 2 KB each) in exactly the order the
+//     consumers use them; the loader wave pushes it through a 3-slot x 32 KB LDS ring with LDS-DMA
+//     (global_load_lds: no VGPRs, no ds_write), one s_barrier per 32 KB stage, two stages of run-ahead; each weight
+//     byte leaves L2 once per 128 pairs and is read by the 8 consumers as conflict-free 1 KiB ds_read_b128 fragments;
+//   * the loader also DMAs the NEXT tile's z rows (32 KB, source-swizzled so the fragment reads are conflict-free),
+//     its 8 a|d and 16 c|e rows of `pre` (2-D tile: 24 KB instead of 128 KB of gathers) and its masks while the
+//     consumers compute: a consumer issues NO global load at all, only its 4 output stores per tile;
+//   * GEMM2 -> GEMM3 are fused per 32-feature chunk (h2 never exists as a whole): < 168 VGPRs, 9 waves per CU;
+//   * loader and consumers use disjoint memory paths (LDS-DMA vs ds_read / stores), so neither side's s_waitcnt
+//     drains the other's queue (vmcnt is per wave).
+#include <cstdlib>
+#include "common.h"
+#include "../../include/pepflow_hip.h"
+
+#ifdef PF_PROFILE
+__device__ long long g_prof_et3[64];
+#define PROF3(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && it == 1) g_prof_et3[i] = clock64(); } while (0)
+extern "C" int pf_debug_prof_et3(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_et3), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define PROF3(i)
+#endif
+
+namespace {
+
+constexpr int NCW = 8;                        // consumer waves = rows i of a tile
+constexpr int TJ = 16;                        // columns j of a tile
+constexpr int KF = 2048;                      // bytes of one fragment pair: hi 1 KiB | lo 1 KiB
+constexpr int STAGE_B = 16 * KF;              // 32 KiB ring stage = 16 fragment pairs
+constexpr int NSTAGE = 8;                     // stages per tile (256 KiB of weights)
+constexpr int NSLOT = 3;
+constexpr int CE_STRIDE = 1056;               // bytes between c|e rows in LDS (1 KiB + 32: conflict-free b128 reads)
+constexpr int CE_PIECES = 17;                 // ceil(16 * 1056 / 1024)
+// LDS map (bytes)
+constexpr int OFF_Z = NSLOT * STAGE_B;        // z rows of the tile, [8 waves][16 pairs][256 B], chunk-swizzled
+constexpr int OFF_AD = OFF_Z + NCW * 4096;    // [8][a 768 B | d 256 B]
+constexpr int OFF_CE = OFF_AD + NCW * 1024;   // [16][c 768 B | e 256 B | pad 32]
+constexpr int OFF_MK = OFF_CE + CE_PIECES * 1024;   // mask_i[8] | mask_j[16]
+constexpr int OFF_CS = OFF_MK + 256;          // LayerNorm gamma[64] | beta[64] | b2[192]
+constexpr int CONST_F = 64 + 64 + 192;
+constexpr int LDS_BYTES = OFF_CS + CONST_F * 4;
+constexpr float LOI = PF_LO_INV;
+
+__device__ __forceinline__ void stage_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define GLDS4(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 4, 0, 0)
+
+struct Frag { half8 h, l; };
+__device__ __forceinline__ Frag ldfrag(const unsigned char* slot, int kf, int lane) {
+    Frag f;
+    f.h = *reinterpret_cast<const half8*>(slot + kf * KF + lane * 16);
+    f.l = *reinterpret_cast<const half8*>(slot + kf * KF + 1024 + lane * 16);
+    return f;
+}
+// two independent (main, corr) accumulator pairs per call; the two MFMAs into one corr accumulator are 4 issue slots apart
+__device__ __forceinline__ void mac2(const Frag& w0, const Frag& w1, half8 xh, half8 xl, f32x4& m0, f32x4& c0, f32x4& m1, f32x4& c1) {
+    c0 = mfma_h(w0.h, xl, c0);
+    c1 = mfma_h(w1.h, xl, c1);
+    m0 = mfma_h(w0.h, xh, m0);
+    m1 = mfma_h(w1.h, xh, m1);
+    c0 = mfma_h(w0.l, xh, c0);
+    c1 = mfma_h(w1.l, xh, c1);
+}
+__device__ __forceinline__ half8 cat4(half4 a, half4 b) {
+    half8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    return o;
+}
+__device__ __forceinline__ void split8(const float4& a, const float4& b, half8& hi, half8& lo) {
+    const float v0[4] = {a.x, a.y, a.z, a.w}, v1[4] = {b.x, b.y, b.z, b.w};
+    half4 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    hi = cat4(h0, h1);
+    lo = cat4(l0, l1);
+}
+__device__ __forceinline__ f32x4 add4(const float4& a, const float4& b) { return (f32x4){a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+
+struct Tile { int b, i0, j0; };
+
+__global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    float* Cs = reinterpret_cast<float*>(smem + OFF_CS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int L = a.L;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // blockIdx.x, + gridDim.x, ...
+    const int total_stages = my_tiles * NSTAGE;
+    auto tile_of = [&](int t) {
+        Tile tl;
+        const int per = nib * njb;
+        tl.b = t / per;
+        const int rem = t - tl.b * per;
+        const int ib = rem / njb;
+        tl.i0 = ib * NCW;
+        tl.j0 = (rem - ib * njb) * TJ;
+        return tl;
+    };
+
+    for (int i = tid; i < CONST_F; i += blockDim.x) Cs[i] = i < 64 ? a.ln_g[i] : (i < 128 ? a.ln_b[i - 64] : a.b2[i - 128]);
+    __syncthreads();
+
+    if (wave == NCW) {
+        // ------------------- loader wave: weight stream -> LDS ring; next tile's z / pre / masks -> LDS -------------------
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w_stream) + lane * 16;
+        auto issue_w = [&](int stage, int slot, int k0, int k1) {
+#pragma unroll
+            for (int k = k0; k < k1; ++k) GLDS16(wsrc + stage * STAGE_B + k * 1024, ring + slot * STAGE_B + k * 1024);
+        };
+        // z piece k: consumer region k >> 2, pairs (k & 3) * 4 + (lane >> 4); 16-byte chunk q = lane & 15 of the LDS row
+        // holds the global chunk q ^ pair (so that the consumers' fragment reads are bank-conflict free)
+        auto issue_z = [&](const Tile& tl, int k0, int k1) {
+            const int q = lane & 15;
+            for (int k = k0; k < k1; ++k) {
+                const int rr = (k & 3) * 4 + (lane >> 4);
+                int i = tl.i0 + (k >> 2), j = tl.j0 + rr;
+                i = i < L ? i : L - 1;
+                j = j < L ? j : L - 1;
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.z_in + ((size_t)(tl.b * L + i) * L + j) * 64) + 16 * (q ^ rr);
+                GLDS16(src, smem + OFF_Z + k * 1024);
+            }
+        };
+        auto issue_ad = [&](const Tile& tl) {                    // 8 pieces: row i0 + k, [a | d]
+            const int off = lane * 16;
+            const int soff = off < 768 ? off : 1536 + (off - 768);
+            for (int k = 0; k < NCW; ++k) {
+                int i = tl.i0 + k;
+                i = i < L ? i : L - 1;
+                GLDS16(reinterpret_cast<const unsigned char*>(a.pre + (size_t)(tl.b * L + i) * PF_ET_PRE) + soff, smem + OFF_AD + k * 1024);
+            }
+        };
+        auto issue_ce = [&](const Tile& tl, int k0, int k1) {    // 17 pieces over 16 padded rows [c | e | pad]
+            for (int k = k0; k < k1; ++k) {
+                const int pos = k * 1024 + lane * 16;
+                int row = pos / CE_STRIDE;
+                int off = pos - row * CE_STRIDE;
+                row = row < TJ ? row : TJ - 1;
+                off = off < 1024 ? off : 0;
+                int j = tl.j0 + row;
+                j = j < L ? j : L - 1;
+                const int soff = off < 768 ? 768 + off : 1792 + (off - 768);
+                GLDS16(reinterpret_cast<const unsigned char*>(a.pre + (size_t)(tl.b * L + j) * PF_ET_PRE) + soff, smem + OFF_CE + k * 1024);
+            }
+        };
+        auto issue_mask = [&](const Tile& tl) {                  // lanes 0-7: mask_i, 8-23: mask_j
+            int row = lane < 8 ? tl.i0 + lane : tl.j0 + ((lane - 8) & 15);
+            row = row < L ? row : L - 1;
+            GLDS4(a.mask + tl.b * L + row, smem + OFF_MK);
+        };
+
+        int tile = blockIdx.x;
+        Tile tl = tile_of(tile);
+        issue_z(tl, 0, 32);
+        issue_ad(tl);
+        issue_ce(tl, 0, CE_PIECES);
+        issue_mask(tl);                                            // 58 in flight (the counter holds 63)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_w(0, 0, 0, 32);
+        issue_w(1, 1, 0, 16);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // stage 0 complete
+        issue_w(1, 1, 16, 32);
+        int st_next = 2 % NSTAGE, slot_next = 2 % NSLOT;           // stream stage / ring slot of global stage gs + 2
+        int st_cur = 0;                                            // stage of the current tile the consumers are entering
+        bool have_next = my_tiles > 1;
+        if (have_next) tl = tile_of(tile + gridDim.x);
+        for (int gs = 0; gs < total_stages; ++gs) {
+            // here: stage gs and everything issued before its last 16 pieces have landed
+            stage_barrier();                                       // consumers: start stage gs; they are done with gs - 1
+            if (gs + 2 < total_stages) {
+                issue_w(st_next, slot_next, 0, 16);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage gs + 1 complete
+                issue_w(st_next, slot_next, 16, 32);
+                st_next = (st_next + 1 == NSTAGE) ? 0 : st_next + 1;
+                slot_next = (slot_next + 1 == NSLOT) ? 0 : slot_next + 1;
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // next tile's inputs, spread over stages 2..6 (<= 13 pieces each, all complete before the next tile's first
+            // barrier): z rows were consumed right after barrier 0, pre rows / masks during stages 0-1
+            if (have_next) {
+                if (st_cur == 2) issue_z(tl, 0, 11);
+                else if (st_cur == 3) issue_z(tl, 11, 22);
+                else if (st_cur == 4) issue_z(tl, 22, 32);
+                else if (st_cur == 5) { issue_ad(tl); issue_ce(tl, 0, 5); }
+                else if (st_cur == 6) { issue_ce(tl, 5, CE_PIECES); issue_mask(tl); }
+            }
+            if (++st_cur == NSTAGE) {
+                st_cur = 0;
+                tile += gridDim.x;
+                have_next = tile + (int)gridDim.x < ntiles;
+                if (have_next) tl = tile_of(tile + gridDim.x);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------- consumer waves ----------------------------------
+    const unsigned char* zs = smem + OFF_Z + wave * 4096 + r * 256;           // this lane's pair row (chunk-swizzled)
+    const float* ad = reinterpret_cast<const float*>(smem + OFF_AD + wave * 1024) + 4 * g;          // a_i | d_i, features 4g..
+    const float* ce = reinterpret_cast<const float*>(smem + OFF_CE + r * CE_STRIDE) + 4 * g;        // c_j | e_j
+    const float* mkb = reinterpret_cast<const float*>(smem + OFF_MK);
+    int slot = 0;
+    int tile = blockIdx.x;
+    for (int it = 0; it < my_tiles; ++it, tile += gridDim.x) {
+        PROF3(0);
+        const Tile tl = tile_of(tile);
+        const int i = tl.i0 + wave, j = tl.j0 + r;
+        const bool valid = i < L && j < L;
+        half8 h1h[6], h1l[6];
+        f32x4 m3[4], c3[4];
+        half8 zh[2], zl[2];
+        float mk = 0.f;
+        // ---- stages 0-1: GEMM1 (12 feature tiles, two at a time) then the z part of GEMM3 ----
+#pragma unroll
+        for (int tp = 0; tp < 6; ++tp) {
+            if (tp == 0 || tp == 4) {
+                PROF3(tp == 0 ? 1 : 3);
+                stage_barrier();
+                PROF3(tp == 0 ? 2 : 4);
+                if (tp == 4) slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+            }
+            if (tp == 0) {            // this tile's z rows / mask are in LDS now
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(zs + 16 * ((8 * s + 2 * g) ^ r));
+                    const float4 q1 = *reinterpret_cast<const float4*>(zs + 16 * ((8 * s + 2 * g + 1) ^ r));
+                    split8(q0, q1, zh[s], zl[s]);
+                }
+                mk = mkb[wave] * mkb[8 + r];
+            }
+            const unsigned char* sl = ring + slot * STAGE_B;
+            const int kf0 = (tp < 4 ? tp * 4 : (tp - 4) * 4);         // tile 2tp: kf0, kf0+1 ; tile 2tp+1: kf0+2, kf0+3
+            // accumulators start at a_i + c_j (b1 is folded into c)
+            f32x4 m0 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp), *reinterpret_cast<const float4*>(ce + 32 * tp));
+            f32x4 m1 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp + 16), *reinterpret_cast<const float4*>(ce + 32 * tp + 16));
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag w0 = ldfrag(sl, kf0 + s, lane), w1 = ldfrag(sl, kf0 + 2 + s, lane);
+                mac2(w0, w1, zh[s], zl[s], m0, c0, m1, c1);
+            }
+            float4 v0, v1;
+            v0.x = fmaxf(m0[0] + c0[0] * LOI, 0.f); v0.y = fmaxf(m0[1] + c0[1] * LOI, 0.f);
+            v0.z = fmaxf(m0[2] + c0[2] * LOI, 0.f); v0.w = fmaxf(m0[3] + c0[3] * LOI, 0.f);
+            v1.x = fmaxf(m1[0] + c1[0] * LOI, 0.f); v1.y = fmaxf(m1[1] + c1[1] * LOI, 0.f);
+            v1.z = fmaxf(m1[2] + c1[2] * LOI, 0.f); v1.w = fmaxf(m1[3] + c1[3] * LOI, 0.f);
+            split8(v0, v1, h1h[tp], h1l[tp]);
+        }
+        PROF3(5);
+        {   // z part of the final layer (stage 1, fragment pairs 8..15): acc3[t] = d_i + e_j + Wf[:, :64] z  (bf folded into e)
+            const unsigned char* sl = ring + slot * STAGE_B;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                m3[t] = add4(*reinterpret_cast<const float4*>(ad + 192 + 16 * t), *reinterpret_cast<const float4*>(ce + 192 + 16 * t));
+                c3[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag w0 = ldfrag(sl, 8 + s, lane), w1 = ldfrag(sl, 10 + s, lane);
+                const Frag w2 = ldfrag(sl, 12 + s, lane), w3 = ldfrag(sl, 14 + s, lane);
+                mac2(w0, w1, zh[s], zl[s], m3[0], c3[0], m3[1], c3[1]);
+                mac2(w2, w3, zh[s], zl[s], m3[2], c3[2], m3[3], c3[3]);
+            }
+        }
+        PROF3(6);
+        // ---- stages 2-7: GEMM2 feature tiles (2c, 2c+1) -> ReLU, split -> K-chunk c of GEMM3 ----
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            PROF3(7 + c);
+            stage_barrier();
+            slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+            const unsigned char* sl = ring + slot * STAGE_B;
+            const float4 b0 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 4 * g);
+            const float4 b1 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 16 + 4 * g);
+            f32x4 m0 = {b0.x, b0.y, b0.z, b0.w}, m1 = {b1.x, b1.y, b1.z, b1.w};      // accumulators start at b2
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const Frag w0 = ldfrag(sl, k, lane), w1 = ldfrag(sl, 6 + k, lane);
+                mac2(w0, w1, h1h[k], h1l[k], m0, c0, m1, c1);
+            }
+            float4 v0, v1;
+            v0.x = fmaxf(m0[0] + c0[0] * LOI, 0.f); v0.y = fmaxf(m0[1] + c0[1] * LOI, 0.f);
+            v0.z = fmaxf(m0[2] + c0[2] * LOI, 0.f); v0.w = fmaxf(m0[3] + c0[3] * LOI, 0.f);
+            v1.x = fmaxf(m1[0] + c1[0] * LOI, 0.f); v1.y = fmaxf(m1[1] + c1[1] * LOI, 0.f);
+            v1.z = fmaxf(m1[2] + c1[2] * LOI, 0.f); v1.w = fmaxf(m1[3] + c1[3] * LOI, 0.f);
+            half8 xh, xl;
+            split8(v0, v1, xh, xl);
+            const Frag w0 = ldfrag(sl, 12, lane), w1 = ldfrag(sl, 13, lane), w2 = ldfrag(sl, 14, lane), w3 = ldfrag(sl, 15, lane);
+            mac2(w0, w1, xh, xl, m3[0], c3[0], m3[1], c3[1]);
+            mac2(w2, w3, xh, xl, m3[2], c3[2], m3[3], c3[3]);
+        }
+        PROF3(13);
+        slot = (slot + 1 == NSLOT) ? 0 : slot + 1;           // slot of the next tile's stage 0
+
+        // ---- LayerNorm over the 64 features (16 in this lane, the rest in lanes r + 16k), mask, store ----
+        float y[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            y[4 * t + 0] = m3[t][0] + c3[t][0] * LOI;
+            y[4 * t + 1] = m3[t][1] + c3[t][1] * LOI;
+            y[4 * t + 2] = m3[t][2] + c3[t][2] * LOI;
+            y[4 * t + 3] = m3[t][3] + c3[t][3] * LOI;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) s += (y[e] + y[e + 1]) + (y[e + 2] + y[e + 3]);
+        s = sum_xor32(sum_xor16(s));
+        const float mean = s * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float d = y[e] - mean; q += d * d; }
+        q = sum_xor32(sum_xor16(q));
+        const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
+        if (valid) {
+            float* zo = a.z_out + ((size_t)(tl.b * L + i) * L + j) * 64 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 gm = *reinterpret_cast<const float4*>(Cs + 16 * t + 4 * g);
+                const float4 bt = *reinterpret_cast<const float4*>(Cs + 64 + 16 * t + 4 * g);
+                float4 o;
+                o.x = ((y[4 * t + 0] - mean) * rstd * gm.x + bt.x) * mk;
+                o.y = ((y[4 * t + 1] - mean) * rstd * gm.y + bt.y) * mk;
+                o.z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk;
+                o.w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk;
+                *reinterpret_cast<float4*>(zo + 16 * t) = o;
+            }
+        }
+        PROF3(14);
+    }
+}
+
+}  // namespace
+
+// launcher used by pf_edge_transition_fwd (edge_transition.hip) when args.w_stream is set
+int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
+    const int nib = (a->L + NCW - 1) / NCW, njb = (a->L + TJ - 1) / TJ;
+    const long long nt = (long long)a->B * nib * njb;
+    if (nt > 0x7fffffffLL || (long long)a->B * a->L > 0x7fffffffLL) return PF_E_TOOLARGE;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n > 0 ? n : 256;
+    }();
+    const int grid = (int)(nt < ncu ? nt : ncu);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return PF_E_BADARG;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(edge_transition_v3_kernel, dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    PF_CHECK_LAUNCH();
+    return 0;
+}

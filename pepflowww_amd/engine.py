@@ -46,6 +46,46 @@ def split_f16(w):
     return frag.contiguous()
 
 
+def _frag_pair(W, ft, kidx):
+    """One fragment pair (hi 512 f16 | lo 512 f16) of feature tile ft: lane (row = lane & 15, kg = lane >> 4) holds
+    W[16 ft + row][kidx[kg, 0..7]]."""
+    lane = torch.arange(64, device=W.device)
+    rows = 16 * ft + (lane & 15)
+    v = W[rows[:, None], kidx[(lane >> 4)]]                     # [64, 8]
+    hi = v.to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * LO_SCALE).to(torch.float16)
+    return torch.cat([hi.reshape(-1), lo.reshape(-1)])
+
+
+def pack_et_stream(w1z, w2, wf):
+    """EdgeTransition weights as the linear 256 KiB fragment stream of csrc/edge_transition_v3.hip:
+    128 fragment pairs in the exact order a consumer wave uses them.
+      stage 0-1 : W1z feature tiles 0..11 (2 K-steps each, natural K order), then Wf[:, :64] tiles 0..3 (2 K-steps)
+      stage 2-7 : for c in 0..5: W2 tile 2c (6 K-steps), W2 tile 2c+1 (6 K-steps), Wf tiles 0..3 K-step c
+    W2 / Wf use the PERMUTED K order  slot(8 kg + 4 h + e) <-> feature 32 s + 16 h + 4 kg + e  -- the order in which
+    the previous GEMM's accumulator registers of a lane become its next B operand (activations stay in registers).
+    Layout/packing only -- no model arithmetic."""
+    w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
+    assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
+    dev = w2.device
+    kg = torch.arange(4, device=dev)[:, None]
+    i8 = torch.arange(8, device=dev)[None, :]
+    ident = lambda s: 32 * s + 8 * kg + i8
+    perm = lambda s: 32 * s + 16 * (i8 >> 2) + 4 * kg + (i8 & 3)
+    out = []
+    for ft in range(12):
+        out += [_frag_pair(w1z, ft, ident(s)) for s in range(2)]
+    for t in range(4):
+        out += [_frag_pair(wf[:, :64].contiguous(), t, ident(s)) for s in range(2)]
+    for c in range(6):
+        for ft in (2 * c, 2 * c + 1):
+            out += [_frag_pair(w2, ft, perm(k)) for k in range(6)]
+        out += [_frag_pair(wf, t, perm(c)) for t in range(4)]
+    stream = torch.cat(out).contiguous()
+    assert stream.numel() * 2 == 256 * 1024
+    return stream
+
+
 class PackedWeights:
     """Kernel-friendly views/copies of the GAEncoder parameters (reference state_dict layout).
 
@@ -106,6 +146,7 @@ class PackedWeights:
                 wf, bf = g(q + "final_layer.weight"), g(q + "final_layer.bias")
                 t[f"{b}.et.w1z16"], t[f"{b}.et.wf16"] = split_f16(w1[:, :64]), split_f16(wf)
                 t[f"{b}.et.w216"], t[f"{b}.et.b2"] = split_f16(g(q + "trunk.2.weight")), g(q + "trunk.2.bias")
+                t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
                 t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
@@ -274,6 +315,7 @@ class DenoiseEngine:
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
                 et.w1z_f16, et.w2_f16, et.b2 = w[f"{b}.et.w1z16"].data_ptr(), w[f"{b}.et.w216"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
                 et.wf_f16, et.ln_g, et.ln_b = w[f"{b}.et.wf16"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
+                et.w_stream = w[f"{b}.et.stream"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))

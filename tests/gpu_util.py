@@ -116,15 +116,18 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L):
     return feats, (qp, kp, vp)
 
 
-def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False):
-    """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes."""
-    from pepflowww_amd.engine import split_f16
+def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True):
+    """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
+    persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes)."""
+    from pepflowww_amd.engine import split_f16, pack_et_stream
     lib = _capi.load()
     out = z if inplace else torch.full_like(z, float("nan"))
     w1s, w2s, wfs = split_f16(w1[:, :64]), split_f16(w2), split_f16(wf)
     a = _capi.EdgeTransitionArgs()
     a.z_in, a.z_out, a.pre, a.w1z_f16, a.w2_f16, a.b2, a.wf_f16 = _p(z), _p(out), _p(pre), _p(w1s), _p(w2s), _p(b2), _p(wfs)
     a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
+    ws = pack_et_stream(w1[:, :64], w2, wf) if persistent else None
+    a.w_stream = _p(ws)
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()
     return out

@@ -227,7 +227,7 @@ def test_ipa_block(f2, seeded_sd):
         G.assert_close(fg[:, sl], fr[:, sl], REL, f"IPA feats[{name}] vs oracle")
 
 
-def _et_run(sd, pfx, s, z, mask, B, L):
+def _et_run(sd, pfx, s, z, mask, B, L, persistent=True):
     g = lambda k: sd[pfx + k]
     n64 = G.linear(cu(s.reshape(B * L, 128)), cu(g("initial_embed.weight")), cu(g("initial_embed.bias")))
     w1, b1, wf, bf = g("trunk.0.weight"), g("trunk.0.bias"), g("final_layer.weight"), g("final_layer.bias")
@@ -235,27 +235,30 @@ def _et_run(sd, pfx, s, z, mask, B, L):
     bpre = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0)
     pre = G.linear(n64, cu(wpre), cu(bpre))
     return G.edge_transition(cu(z.reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")), cu(wf),
-                             cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L)
+                             cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L, persistent=persistent)
 
 
-def test_edge_transition(f2, seeded_sd):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_edge_transition(f2, seeded_sd, persistent):
+    """persistent: LDS-ring kernel (edge_transition_v3.hip); else the tiled kernel (edge_transition.hip)."""
     b = _batch(f2)
     B, L = b["aa"].shape
-    out = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_0.", f2["et0_in_s"], f2["enc_edge"], torch.ones(B, L), B, L)
+    out = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_0.", f2["et0_in_s"], f2["enc_edge"], torch.ones(B, L), B, L, persistent)
     G.assert_close(out.view(B, L, L, 64), f2["et0_out"], REL, "EdgeTransition vs reference")
     # masked + ragged tile tail (B*L*L = 1152 pairs = 18 tiles) + in-place
     mask = b["res_mask"].float()
-    out2 = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_0.", f2["et0_in_s"], f2["enc_edge"], mask, B, L)
+    out2 = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_0.", f2["et0_in_s"], f2["enc_edge"], mask, B, L, persistent)
     em = (mask[:, None, :] * mask[:, :, None])[..., None]
     G.assert_close(out2.view(B, L, L, 64), f2["et0_out"] * em, REL, "EdgeTransition masked")
 
 
-def test_edge_transition_ragged_tail(seeded_sd):
-    """B*L*L not a multiple of the 64-pair tile; compare with the oracle."""
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("B,L", [(3, 7), (2, 45), (1, 3)])
+def test_edge_transition_ragged_tail(seeded_sd, persistent, B, L):
+    """B*L*L not a multiple of the pair tile (64 / 128), tiles spanning several rows and samples; vs the oracle."""
     g = torch.Generator().manual_seed(9)
-    B, L = 3, 7
     s, z = torch.randn(B, L, 128, generator=g), torch.randn(B, L, L, 64, generator=g)
-    out = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_2.", s, z, torch.ones(B, L), B, L)
+    out = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_2.", s, z, torch.ones(B, L), B, L, persistent)
     ref = O.edge_transition(seeded_sd, "ga_encoder.trunk.edge_transition_2", s, z)
     G.assert_close(out.view(B, L, L, 64), ref, REL, "EdgeTransition ragged")
 

@@ -3,7 +3,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/pfprof/lib
-for f in selftest linear edge_transition ipa_attn node_ops flow_step encode node_track; do
+for f in selftest linear edge_transition edge_transition_v3 ipa_attn node_ops flow_step encode node_track train_fwd; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPF_PROFILE -c $R/pepflowww_amd/csrc/$f.hip -o /tmp/pfprof/lib/$f.o &
 done
 wait
@@ -28,9 +28,9 @@ with torch.no_grad():
     for _ in range(3): eng.run()
     torch.cuda.synchronize()
     raw = C.CDLL(_capi.LIB_PATH)
-    out = (C.c_longlong * 16)()
-    for sym, n in (("pf_debug_prof", 13), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8)):
-        getattr(raw, sym)(out, 16)
+    out = (C.c_longlong * 64)()
+    for sym, n in (("pf_debug_prof", 13), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_et3", 40)):
+        getattr(raw, sym)(out, 64)
         v = list(out)
         print(sym, "stamps (cycles rel.):", [x - v[0] for x in v[:n]])
 PY
