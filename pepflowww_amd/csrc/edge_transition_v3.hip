@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         half8 zh[2], zl[2];
         float mk = 0.f;
         // ---- stages 0-1: GEMM1 (12 feature tiles, two at a time) then the z part of GEMM3 ----
+        Frag ga0, gb0;
 #pragma unroll
         for (int tp = 0; tp < 6; ++tp) {
             if (tp == 0 || tp == 4) {
@@ -255,11 +256,12 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             f32x4 m0 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp), *reinterpret_cast<const float4*>(ce + 32 * tp));
             f32x4 m1 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp + 16), *reinterpret_cast<const float4*>(ce + 32 * tp + 16));
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const Frag w0 = ldfrag(sl, kf0 + s, lane), w1 = ldfrag(sl, kf0 + 2 + s, lane);
-                mac2(w0, w1, zh[s], zl[s], m0, c0, m1, c1);
-            }
+            // fragment reads run one K-step ahead of the MFMAs (within a ring stage)
+            if (tp == 0 || tp == 4) { ga0 = ldfrag(sl, kf0, lane); gb0 = ldfrag(sl, kf0 + 2, lane); }
+            const Frag ga1 = ldfrag(sl, kf0 + 1, lane), gb1 = ldfrag(sl, kf0 + 3, lane);
+            mac2(ga0, gb0, zh[0], zl[0], m0, c0, m1, c1);
+            if (tp != 3 && tp != 5) { ga0 = ldfrag(sl, kf0 + 4, lane); gb0 = ldfrag(sl, kf0 + 6, lane); }
+            mac2(ga1, gb1, zh[1], zl[1], m0, c0, m1, c1);
             float4 v0, v1;
             v0.x = fmaxf(m0[0] + c0[0] * LOI, 0.f); v0.y = fmaxf(m0[1] + c0[1] * LOI, 0.f);
             v0.z = fmaxf(m0[2] + c0[2] * LOI, 0.f); v0.w = fmaxf(m0[3] + c0[3] * LOI, 0.f);
@@ -289,16 +291,23 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         for (int c = 0; c < 6; ++c) {
             PROF3(7 + c);
             stage_barrier();
+            PROF3(16 + c);
             slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
             const unsigned char* sl = ring + slot * STAGE_B;
             const float4 b0 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 4 * g);
             const float4 b1 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 16 + 4 * g);
             f32x4 m0 = {b0.x, b0.y, b0.z, b0.w}, m1 = {b1.x, b1.y, b1.z, b1.w};      // accumulators start at b2
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+            Frag wa[2], wb[2];                 // fragment reads run one K-step ahead of the MFMAs that use them
+            wa[0] = ldfrag(sl, 0, lane);
+            wb[0] = ldfrag(sl, 6, lane);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const Frag w0 = ldfrag(sl, k, lane), w1 = ldfrag(sl, 6 + k, lane);
-                mac2(w0, w1, h1h[k], h1l[k], m0, c0, m1, c1);
+                if (k < 5) {
+                    wa[(k + 1) & 1] = ldfrag(sl, k + 1, lane);
+                    wb[(k + 1) & 1] = ldfrag(sl, 7 + k, lane);
+                }
+                mac2(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, c0, m1, c1);
             }
             float4 v0, v1;
             v0.x = fmaxf(m0[0] + c0[0] * LOI, 0.f); v0.y = fmaxf(m0[1] + c0[1] * LOI, 0.f);

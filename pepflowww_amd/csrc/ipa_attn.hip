@@ -14,6 +14,7 @@
 //   D  all waves : o_pt -> local frame + norms ; zbar = sum_j P z_ij (second pass over z, MFMA for HG >= 4),
 //                  o_pair = W_dz zbar + b_dz  (linear in z, so the [B,L,L,16] pair_z tensor of the reference is
 //                  never formed)
+#include <cstdlib>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
@@ -94,17 +95,22 @@ template <int HG> __device__ __forceinline__ float reduce16(float (&v)[HG], int 
 //   HG = 8 : all heads in one workgroup (z is streamed once per query tile)       -- large batches
 //   HG = 4/2: 2 / 4 workgroups per query tile (z re-read from L2 by each)          -- fills the 256 CUs when
 //             B*L/16 is small (cfg2 has only 64 query tiles)
-template <int HG>
-__global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int LP, int LDS_S) {
+//   NW = waves per workgroup (4, or 8 for the all-heads variant whose 106 KB LDS tile allows only ONE workgroup
+//        per CU: 8 waves then give each SIMD two waves to overlap the z / K / V load latencies)
+template <int HG, int NW>
+__global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, int LP, int LDS_S) {
     constexpr int NG = H / HG;                    // head groups per query tile
-    constexpr int HPW = HG >= 4 ? HG / 4 : 1;     // heads per wave
-    constexpr int WPH = HG >= 4 ? 1 : 4 / HG;     // waves per head
+    constexpr int HPW = HG >= NW ? HG / NW : 1;   // heads per wave
+    constexpr int WPH = HG >= NW ? 1 : NW / HG;   // waves per head
+    constexpr int RPW = TI / NW;                  // query rows per wave in the z-streaming phases
+    constexpr int NTH = 64 * NW;
+    static_assert(NW == 4 || (NW == 8 && HG == 8), "8 waves only for the all-heads variant");
     constexpr int NTC = HG >= 4 ? 11 : 6;         // [V | Vp] column tiles per wave in phase C
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* S = smem;                              // [TI][HG][LDS_S]
     float* QP = S + TI * HG * LDS_S;              // [TI][HG*24] query points (global frame)
     float* OPT = QP + TI * HG * 24;               // [TI][HG][36]  o_pt (global frame)
-    float* ZB = OPT + TI * HG * 36;               // [4 waves][HG][64] zbar scratch
+    float* ZB = OPT + TI * HG * 36;               // [NW waves][HG][64] zbar scratch
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
 
     PROF(0);
     // ---- phase 0: query points of this head group -> LDS ----
-    for (int idx = tid; idx < TI * HG * 24; idx += 256) {
+    for (int idx = tid; idx < TI * HG * 24; idx += NTH) {
         const int ti = idx / (HG * 24), c = idx - ti * (HG * 24);
         QP[idx] = (i0 + ti < L) ? a.qp[(rowb + i0 + ti) * 192 + h0 * 24 + c] : 0.f;
     }
@@ -143,17 +149,17 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
             const int ntile = LP >> 4;
             auto zfetch = [&](int it, float4 (&zf)[4]) {
                 const int t4 = it / ntile, j = (it - t4 * ntile) * 16 + r;
-                const int i = i0 + wave * 4 + t4;
+                const int i = i0 + wave * RPW + t4;
                 const float* zp = a.z + ((rowb + (i < L ? i : L - 1)) * L + (j < L ? j : L - 1)) * 64 + 4 * g;
     #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) zf[s4] = *reinterpret_cast<const float4*>(zp + 16 * s4);
             };
             float4 zc[4], zn[4];
             zfetch(0, zc);
-            for (int it = 0; it < 4 * ntile; ++it) {
-                if (it + 1 < 4 * ntile) zfetch(it + 1, zn);
+            for (int it = 0; it < RPW * ntile; ++it) {
+                if (it + 1 < RPW * ntile) zfetch(it + 1, zn);
                 const int t4 = it / ntile, j0 = (it - t4 * ntile) * 16;
-                const int ti = wave * 4 + t4;
+                const int ti = wave * RPW + t4;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     #pragma unroll
                 for (int s4 = 0; s4 < 4; s4 += 2) {
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     // softmax over j: 8 (ti,h) rows per wave at a time, 8 lanes per row (DPP xor-1/2/4 reductions)
     {
         const int sub = lane & 7;
-        for (int rr = wave * 8 + (lane >> 3); rr < TI * HG; rr += 32) {
+        for (int rr = wave * 8 + (lane >> 3); rr < TI * HG; rr += 8 * NW) {
             float* sp = S + rr * LDS_S;
             float m = -3.0e38f;
             for (int j = sub; j < L; j += 8) m = fmaxf(m, sp[j]);
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
 
     PROF(5);
     // ---- phase D1: o_pt -> local frame (invert_apply) + norms ----
-    for (int idx = tid; idx < TI * HG * PV; idx += 256) {
+    for (int idx = tid; idx < TI * HG * PV; idx += NTH) {
         const int ti = idx / (HG * PV), hp = idx - ti * (HG * PV);     // hp = hh*12 + p
         const int i = i0 + ti;
         if (i >= L) continue;
@@ -422,11 +428,11 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     #pragma unroll
             for (int c = 0; c < 16; ++c) wdz[c] = *reinterpret_cast<const float4*>(a.w_dz + (lane & 15) * 64 + 4 * c);
             const float bdz = a.b_dz[lane & 15];
-            const int nrow = min(4, max(0, L - (i0 + wave * 4)));          // valid query rows of this wave
+            const int nrow = min(RPW, max(0, L - (i0 + wave * RPW)));      // valid query rows of this wave
             const int ntile = LP >> 4;
             auto zfetch = [&](int it, float (&vb)[4][4]) {                 // B operands of one K=16 step: 4 column tiles
                 const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
-                const float* zrow = a.z + ((rowb + i0 + wave * 4 + t4) * L) * 64 + r;
+                const float* zrow = a.z + ((rowb + i0 + wave * RPW + t4) * L) * 64 + r;
     #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     int j = k0 + 4 * g + t;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
             for (int it = 0; it < nrow * ntile; ++it) {
                 if (it + 1 < nrow * ntile) zfetch(it + 1, vn);
                 const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
-                const int ti = wave * 4 + t4, i = i0 + ti;
+                const int ti = wave * RPW + t4, i = i0 + ti;
                 if (k0 == 0) {
     #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) zacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -548,19 +554,19 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(pf_ipa_attn_args a, int L
     PROF(7);
 }
 
-template <int HG>
+template <int HG, int NW>
 int launch_attn(const pf_ipa_attn_args& a, hipStream_t s) {
     const int LP = (a.L + 15) / 16 * 16;
     const int LDS_S = LP + 4;
-    const size_t lds = ((size_t)TI * HG * LDS_S + TI * HG * 24 + TI * HG * 36 + 4 * HG * 64) * sizeof(float);
+    const size_t lds = ((size_t)TI * HG * LDS_S + TI * HG * 24 + TI * HG * 36 + NW * HG * 64) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ipa_attn_kernel<HG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ipa_attn_kernel<HG, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int tiles = (a.L + TI - 1) / TI;
-    hipLaunchKernelGGL(ipa_attn_kernel<HG>, dim3((unsigned)(a.B * tiles * (H / HG))), dim3(256), lds, s, a, LP, LDS_S);
+    hipLaunchKernelGGL((ipa_attn_kernel<HG, NW>), dim3((unsigned)(a.B * tiles * (H / HG))), dim3(64 * NW), lds, s, a, LP, LDS_S);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -587,7 +593,11 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
-    if (qt >= 256) { const int rc = launch_attn<8>(*a, s); if (rc != PF_E_TOOLARGE) return rc; }
-    if (qt >= 128) { const int rc = launch_attn<4>(*a, s); if (rc != PF_E_TOOLARGE) return rc; }
-    return launch_attn<2>(*a, s);
+    static const int nw8 = [] { const char* e = getenv("PF_IPA_NW"); return e ? atoi(e) : 8; }();
+    if (qt >= 256) {
+        const int rc = nw8 == 8 ? launch_attn<8, 8>(*a, s) : launch_attn<8, 4>(*a, s);
+        if (rc != PF_E_TOOLARGE) return rc;
+    }
+    if (qt >= 128) { const int rc = launch_attn<4, 4>(*a, s); if (rc != PF_E_TOOLARGE) return rc; }
+    return launch_attn<2, 4>(*a, s);
 }
