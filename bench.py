@@ -145,7 +145,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-            traffic = json.load(f)[args.workload]["edge_transition_kernel"]["hbm_bytes_corrected"]
+            traffic = json.load(f)[args.workload]["edge_transition_v3_kernel"]["hbm_bytes_corrected"]
     except Exception:
         pass
 
@@ -160,7 +160,7 @@ def main():
         "config": {"workload": wl["name"], "per_gpu_batch": B, "residues": L, "global_batch": world * B,
                    "parallelism": f"batch-shard x{world}", "hipgraph": use_graph, "launches_per_step": eng.n_launches + 2},
         "roofline": {
-            "kernel": "edge_transition_kernel", "bound": "mfma",
+            "kernel": "edge_transition_v3_kernel", "bound": "mfma",
             "achieved": pairs * ET_FLOPS_EXEC / et_avg_s / 1e12, "peak": MFMA_F16_PEAK / ET_SPLIT / 1e12, "unit": "TFLOP/s",
             "frac": pairs * ET_FLOPS_EXEC * ET_SPLIT / et_avg_s / MFMA_F16_PEAK, "traffic": traffic,
             "traffic_note": "HBM bytes per launch from profiles/r01/pmc_traffic.json (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair",
