@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 4
+#define PF_ABI_VERSION 5
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -324,6 +324,17 @@ typedef struct {
 } pf_train_args;
 int pf_train_corrupt_fwd(const pf_train_args* a, pf_stream_t stream);
 int pf_train_losses_fwd(const pf_train_args* a, pf_stream_t stream);
+/* backward of sum_k w[k] * loss_k (train.py:121; weights learn_angle.yaml:37-43, order as losses[6]) with respect
+ * to the four network outputs; `a` as passed to pf_train_losses_fwd (pred_seq must have been written by it).
+ * First stage of the backward row: the gradients this call produces seed the trunk backward (not built yet). */
+typedef struct {
+    float w[6];
+    float* d_rot;      /* [B*L,9]  d/d pred_rot   */
+    float* d_trans;    /* [B*L,3]  d/d pred_trans */
+    float* d_ang;      /* [B*L,5]  d/d pred_ang_raw (the % 2pi of ga.py:125 has unit slope) */
+    float* d_logits;   /* [B*L,20] d/d pred_logits */
+} pf_train_bwd_args;
+int pf_train_losses_bwd(const pf_train_args* a, const pf_train_bwd_args* g, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -579,15 +579,15 @@ def corrupt(batch, enc, noise):
     return t, R_t, x_t, ang_t, seq_t
 
 
-def forward_losses(sd, batch, noise, encoded=None):
-    """FlowModel.forward, flow_model.py:111-227 -> dict of six scalar losses (no autograd)."""
-    enc = encode(sd, batch) if encoded is None else encoded
+def losses_from_predictions(batch, enc, state, preds, expo1):
+    """The six losses (flow_model.py:161-227) from the corrupted state and the network outputs.
+    state = (t, R_t, x_t, ang_t, seq_t); preds = (pR, px, pang, plog); expo1 = Exp(1) draws of the sequence sample."""
     R1, x1, ang1, seq1, node, edge = enc
+    t, R_t, x_t, ang_t, seq_t = state
+    pR, px, pang, plog = preds
     gen = batch["generate_mask"]
     g = gen.float()
-    t, R_t, x_t, ang_t, seq_t = corrupt(batch, enc, noise)
-    pR, px, pang, plog = ga_encoder(sd, t, R_t, x_t, ang_t, seq_t, node, edge, batch["res_mask"].long())
-    pseq = torch.where(gen, categorical(torch.softmax(plog, -1), noise["expo"][1]), seq1.clamp(0, 19))
+    pseq = torch.where(gen, categorical(torch.softmax(plog.detach(), -1), expo1), seq1.clamp(0, 19))
     scale = 1.0 / (1.0 - torch.minimum(t[..., None], torch.tensor(T_NORM_CLIP)))
     ng = g.sum(-1) + 1e-8
     out = {}
@@ -606,3 +606,26 @@ def forward_losses(sd, batch, noise, encoded=None):
     out["angle_loss"] = ((((avf_gt - avf_pr) * scale) ** 2 * am).sum((-1, -2)) / na).mean()
     out["torsion_loss"] = (((vec(pang) - vec(ang1)) ** 2 * am).sum((-1, -2)) / na).mean()
     return out
+
+
+def forward_losses(sd, batch, noise, encoded=None, return_all=False):
+    """FlowModel.forward, flow_model.py:111-227 -> dict of six scalar losses."""
+    enc = encode(sd, batch) if encoded is None else encoded
+    state = corrupt(batch, enc, noise)
+    t, R_t, x_t, ang_t, seq_t = state
+    preds = ga_encoder(sd, t, R_t, x_t, ang_t, seq_t, enc[4], enc[5], batch["res_mask"].long())
+    out = losses_from_predictions(batch, enc, state, preds, noise["expo"][1])
+    return (out, enc, state, preds) if return_all else out
+
+
+LOSS_WEIGHTS = {"trans_loss": 0.5, "rot_loss": 0.5, "bb_atom_loss": 0.25, "seqs_loss": 1.0, "angle_loss": 1.0,
+                "torsion_loss": 0.5}                                  # configs/learn_angle.yaml:37-43
+
+
+def loss_grads_wrt_predictions(batch, enc, state, preds, expo1, weights=LOSS_WEIGHTS):
+    """d(sum_k w_k loss_k)/d(pR, px, pang, plog) by torch autograd on the restatement (train.py:121,133).
+    The `% 2pi` of ga.py:125 has unit slope, so d/d pang is also d/d(raw angle_net output)."""
+    leaves = [p.detach().clone().requires_grad_(True) for p in preds]
+    losses = losses_from_predictions(batch, enc, state, tuple(leaves), expo1)
+    total = sum(weights[k] * v for k, v in losses.items())
+    return torch.autograd.grad(total, leaves)

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -75,6 +75,10 @@ class TrainArgs(C.Structure):
                 ("B", _i), ("L", _i), ("sample_structure", _i), ("sample_sequence", _i)]
 
 
+class TrainBwdArgs(C.Structure):
+    _fields_ = [("w", C.c_float * 6), ("d_rot", _fp), ("d_trans", _fp), ("d_ang", _fp), ("d_logits", _fp)]
+
+
 class NodeFeatArgs(C.Structure):
     _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("gen_mask", _fp),
                 ("aa_table", _fp), ("freq3", _fp), ("feat", _fp), ("rot1", _fp), ("trans1", _fp), ("mres", _fp),
@@ -126,6 +130,7 @@ _SIGNATURES = {
     "pf_sampler_step": ([C.POINTER(SamplerArgs), _fp], _i),
     "pf_train_corrupt_fwd": ([C.POINTER(TrainArgs), _fp], _i),
     "pf_train_losses_fwd": ([C.POINTER(TrainArgs), _fp], _i),
+    "pf_train_losses_bwd": ([C.POINTER(TrainArgs), C.POINTER(TrainBwdArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
     "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),

@@ -67,6 +67,19 @@ class TrainForward:
         self._keep = keep
         _capi.check(self.lib.pf_train_corrupt_fwd(C.byref(a), _capi.stream_ptr()), "pf_train_corrupt_fwd")
 
+    def loss_grads(self, weights):
+        """d(sum_k weights[k] * loss_k) / d(pred_rot, pred_trans, pred_ang_raw, pred_logits) -- the seed of the trunk
+        backward (train.py:121,133).  weights: dict keyed like the loss dict (learn_angle.yaml:37-43)."""
+        dev, rows = self.eng.device, self.eng.rows
+        g = _capi.TrainBwdArgs()
+        for i, k in enumerate(LOSS_KEYS):
+            g.w[i] = float(weights[k])
+        out = {"d_rot": torch.empty(rows, 9, device=dev), "d_trans": torch.empty(rows, 3, device=dev),
+               "d_ang": torch.empty(rows, 5, device=dev), "d_logits": torch.empty(rows, 20, device=dev)}
+        g.d_rot, g.d_trans, g.d_ang, g.d_logits = (out[k].data_ptr() for k in ("d_rot", "d_trans", "d_ang", "d_logits"))
+        _capi.check(self.lib.pf_train_losses_bwd(C.byref(self.args), C.byref(g), _capi.stream_ptr()), "pf_train_losses_bwd")
+        return out
+
     def compute_losses(self):
         _capi.check(self.lib.pf_train_losses_fwd(C.byref(self.args), _capi.stream_ptr()), "pf_train_losses_fwd")
         return {k: self.losses[i] for i, k in enumerate(LOSS_KEYS)}

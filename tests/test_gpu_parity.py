@@ -542,3 +542,64 @@ def test_train_forward_properties(model):
     assert torch.equal(part.per_sample.cpu(), per_full[lo:hi])
     with pytest.raises(RuntimeError):
         full.losses[0].backward()
+
+
+@pytest.fixture(scope="module")
+def f5(golden_dir):
+    return load(golden_dir, "f5_train_grads.npz")
+
+
+def test_train_loss_gradients_vs_reference(f4, f5, model):
+    """pf_train_losses_bwd against the reference's autograd gradients with respect to the network outputs
+    (first stage of the backward row; weights learn_angle.yaml:37-43)."""
+    batch = _batch(f4)
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    _, tf = model(_to_dev(batch), noise=noise, return_state=True)
+    B, L = batch["aa"].shape
+    # the forward's own predictions agree with the reference's (padding rows hold degenerate frames: not compared) ...
+    ok = batch["res_mask"]
+    G.assert_close(tf.eng.rot.view(B, L, 3, 3).cpu()[ok], f5["pred_rot"][ok], REL, "pred_rot")
+    G.assert_close(tf.eng.trans.view(B, L, 3).cpu()[ok], f5["pred_trans"][ok], REL, "pred_trans")
+    grads = tf.loss_grads(O.LOSS_WEIGHTS)
+    G.sync()
+    # ... so do the gradients (tolerance relative to the largest entry of each tensor)
+    G.assert_close(grads["d_rot"].view(B, L, 3, 3), f5["d_pred_rot"], 5 * REL, "d pred_rot")
+    G.assert_close(grads["d_trans"].view(B, L, 3), f5["d_pred_trans"], REL, "d pred_trans")
+    G.assert_close(grads["d_ang"].view(B, L, 5), f5["d_pred_ang"], REL, "d pred_ang")
+    G.assert_close(grads["d_logits"].view(B, L, 20), f5["d_pred_logits"], REL, "d pred_logits")
+    ctx = ~batch["generate_mask"]
+    assert grads["d_rot"].view(B, L, 9).cpu()[ctx].abs().max() == 0          # context residues carry no loss
+
+
+def test_train_loss_gradients_finite_difference(model):
+    """Size-independent check at the BASELINE cfg2 shape: directional derivative of the weighted loss along a random
+    perturbation of the predictions equals <grad, direction> (central differences on the HIP loss kernel itself)."""
+    B, L = 16, 64
+    batch = synth.make_pocket_batch(B, L, 12, seed=3)
+    nz = synth.make_noise(B, L, 1, seed=11)
+    noise = {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(5)), "trans0": nz["trans0"], "rot0": nz["rot0"],
+             "ang0": nz["ang0"], "simplex0": nz["simplex0"], "expo": nz["expo"][:2]}
+    _, tf = model(_to_dev(batch), noise=noise, return_state=True)
+    eng = tf.eng
+    gen = torch.Generator().manual_seed(1)
+    # (a) translations + torsions with the full weights; (b) logits with the torsion terms switched off (their
+    # mask is a function of the sequence DRAWN from the logits, i.e. piecewise constant in them)
+    w_all = dict(O.LOSS_WEIGHTS)
+    w_seq = dict(O.LOSS_WEIGHTS, angle_loss=0.0, torsion_loss=0.0)
+    for w, names in ((w_all, (("trans", "d_trans", 3), ("ang_raw", "d_ang", 5))), (w_seq, (("logits", "d_logits", 20),))):
+        grads = tf.loss_grads(w)
+        base = {n: getattr(eng, n).clone() for n, _, _ in names}
+        dirs = {n: torch.randn(B * L, k, generator=gen).to(G.dev()) for n, _, k in names}
+        pred = sum((grads[gk] * dirs[n]).sum().item() for n, gk, _ in names)
+
+        def total(eps):
+            for n, _, _ in names:
+                getattr(eng, n).copy_(base[n] + eps * dirs[n])
+            ls = tf.compute_losses()
+            return sum(w[k] * v.double().item() for k, v in ls.items())
+        eps = 1e-2
+        fd = (total(eps) - total(-eps)) / (2 * eps)
+        for n, _, _ in names:
+            getattr(eng, n).copy_(base[n])
+        tf.compute_losses()
+        assert abs(fd - pred) <= 3e-3 * abs(pred), (fd, pred, [n for n, _, _ in names])

@@ -167,3 +167,24 @@ def test_training_forward_losses(f4, seeded_sd):
     for k, v in out.items():
         ref = f4["loss_" + k].item()
         assert abs(v.item() - ref) <= 2e-6 * abs(ref), (k, v.item(), ref)
+
+
+@pytest.fixture(scope="module")
+def f5(golden_dir):
+    return load(golden_dir, "f5_train_grads.npz")
+
+
+def test_loss_gradients_wrt_predictions(f4, f5, seeded_sd):
+    """d(weighted loss)/d(network outputs) of the reference's autograd (train.py:121,133)."""
+    batch = {k[6:]: v for k, v in f4.items() if k.startswith("batch_")}
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    assert [O.LOSS_WEIGHTS[k] for k in ("trans_loss", "rot_loss", "bb_atom_loss", "seqs_loss", "angle_loss", "torsion_loss")] == \
+        [round(float(w), 6) for w in f5["weights"]]
+    enc = O.encode(seeded_sd, batch)
+    state = O.corrupt(batch, enc, noise)
+    preds = (f5["pred_rot"], f5["pred_trans"], f5["pred_ang"], f5["pred_logits"])       # the reference's own predictions
+    gR, gx, ga, gl = O.loss_grads_wrt_predictions(batch, enc, state, preds, noise["expo"][1])
+    close(gR, f5["d_pred_rot"], 2e-5, 2e-4)
+    close(gx, f5["d_pred_trans"], 1e-6, 1e-4)
+    close(ga, f5["d_pred_ang"], 2e-6, 1e-4)
+    close(gl, f5["d_pred_logits"], 1e-7, 1e-4)
