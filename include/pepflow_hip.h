@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 5
+#define PF_ABI_VERSION 6
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -118,6 +118,9 @@ typedef struct {
     const float* head_w;           /* [8] raw (softplus applied inside) */
     float* feats;                  /* [B*L,1536] */
     int B, L;
+    /* optional: sqrt(1/3) (W_b z + b_b) precomputed per pair [B*L*L, 8] by the producer of z
+     * (pf_edge_transition_fwd, bias_out): the bias pass over z is skipped, z is read once. */
+    const float* bias;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 
@@ -216,6 +219,10 @@ typedef struct {
      * (pepflowww_amd.engine.pack_et_stream).  When set, the persistent LDS-ring kernel is used
      * (csrc/edge_transition_v3.hip) and w1z_f16 / w2_f16 / wf_f16 may be NULL. */
     const void* w_stream;
+    /* optional (persistent kernel only): also emit the NEXT block's IPA pair bias sqrt(1/3)(W_b z' + b_b)
+     * from the normalised, masked z' while it is still in registers: bias_out [B*L*L, 8], wb_frags = linear_b
+     * of the next block as 2 split-precision fragment pairs (pepflowww_amd.engine.pack_bias_frags), bb = its bias [8]. */
+    float* bias_out; const void* wb_frags; const float* bb;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -37,7 +37,7 @@ class IpaPointsArgs(C.Structure):
 class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
-                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i)]
+                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp)]
 
 
 class SeqAttnArgs(C.Structure):
@@ -51,7 +51,8 @@ class RigidUpdateArgs(C.Structure):
 
 class EdgeTransitionArgs(C.Structure):
     _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1z_f16", _fp), ("w2_f16", _fp), ("b2", _fp), ("wf_f16", _fp),
-                ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp)]
+                ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
+                ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp)]
 
 
 class SamplerArgs(C.Structure):

@@ -52,9 +52,10 @@ constexpr int OFF_Z = NSLOT * STAGE_B;        // z rows of the tile, [8 waves][1
 constexpr int OFF_AD = OFF_Z + NCW * 4096;    // [8][a 768 B | d 256 B]
 constexpr int OFF_CE = OFF_AD + NCW * 1024;   // [16][c 768 B | e 256 B | pad 32]
 constexpr int OFF_MK = OFF_CE + CE_PIECES * 1024;   // mask_i[8] | mask_j[16]
-constexpr int OFF_CS = OFF_MK + 256;          // LayerNorm gamma[64] | beta[64] | b2[192]
-constexpr int CONST_F = 64 + 64 + 192;
-constexpr int LDS_BYTES = OFF_CS + CONST_F * 4;
+constexpr int OFF_CS = OFF_MK + 256;          // LayerNorm gamma[64] | beta[64] | b2[192] | b_b[8] (+pad)
+constexpr int CONST_F = 64 + 64 + 192 + 16;
+constexpr int OFF_WB = OFF_CS + CONST_F * 4;  // 2 fragment pairs of the next block's linear_b (heads padded to 16)
+constexpr int LDS_BYTES = OFF_WB + 2 * KF;
 constexpr float LOI = PF_LO_INV;
 
 __device__ __forceinline__ void stage_barrier() {
@@ -118,7 +119,11 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         return tl;
     };
 
-    for (int i = tid; i < CONST_F; i += blockDim.x) Cs[i] = i < 64 ? a.ln_g[i] : (i < 128 ? a.ln_b[i - 64] : a.b2[i - 128]);
+    for (int i = tid; i < CONST_F; i += blockDim.x)
+        Cs[i] = i < 64 ? a.ln_g[i] : (i < 128 ? a.ln_b[i - 64] : (i < 320 ? a.b2[i - 128] : (a.bias_out && i < 328 ? a.bb[i - 320] : 0.f)));
+    if (a.bias_out)
+        for (int i = tid; i < 2 * KF / 16; i += blockDim.x)
+            reinterpret_cast<float4*>(smem + OFF_WB)[i] = reinterpret_cast<const float4*>(a.wb_frags)[i];
     __syncthreads();
 
     if (wave == NCW) {
@@ -342,20 +347,54 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         for (int e = 0; e < 16; ++e) { const float d = y[e] - mean; q += d * d; }
         q = sum_xor32(sum_xor16(q));
         const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
-        if (valid) {
-            float* zo = a.z_out + ((size_t)(tl.b * L + i) * L + j) * 64 + 4 * g;
+        float4 o4[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 gm = *reinterpret_cast<const float4*>(Cs + 16 * t + 4 * g);
-                const float4 bt = *reinterpret_cast<const float4*>(Cs + 64 + 16 * t + 4 * g);
-                float4 o;
-                o.x = ((y[4 * t + 0] - mean) * rstd * gm.x + bt.x) * mk;
-                o.y = ((y[4 * t + 1] - mean) * rstd * gm.y + bt.y) * mk;
-                o.z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk;
-                o.w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk;
-                *reinterpret_cast<float4*>(zo + 16 * t) = o;
+        for (int t = 0; t < 4; ++t) {
+            const float4 gm = *reinterpret_cast<const float4*>(Cs + 16 * t + 4 * g);
+            const float4 bt = *reinterpret_cast<const float4*>(Cs + 64 + 16 * t + 4 * g);
+            o4[t].x = ((y[4 * t + 0] - mean) * rstd * gm.x + bt.x) * mk;
+            o4[t].y = ((y[4 * t + 1] - mean) * rstd * gm.y + bt.y) * mk;
+            o4[t].z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk;
+            o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk;
+        }
+        const size_t pidx = (size_t)(tl.b * L + i) * L + j;
+        if (valid) {
+            float* zo = a.z_out + pidx * 64 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(zo + 16 * t) = o4[t];
+        }
+#ifndef PF_EXP_NOBIAS
+        if (a.bias_out) {
+            // pair bias of the NEXT IPA block from z' while it is in registers: one more 64 -> 8(16) split-precision GEMM with
+            // z' as the B operand (same K permutation as the other register-resident activations); heads 4*(lane>>4)+e
+            const unsigned char* wb = smem + OFF_WB;
+            f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bc = bm, bm2 = bm, bc2 = bm;
+            half8 oh0, ol0, oh1, ol1;
+            split8(o4[0], o4[1], oh0, ol0);
+            split8(o4[2], o4[3], oh1, ol1);
+            const Frag f0 = ldfrag(wb, 0, lane), f1 = ldfrag(wb, 1, lane);
+            bc = mfma_h(f0.h, ol0, bc);
+            bc2 = mfma_h(f1.h, ol1, bc2);
+            bm = mfma_h(f0.h, oh0, bm);
+            bm2 = mfma_h(f1.h, oh1, bm2);
+            bc = mfma_h(f0.l, oh0, bc);
+            bc2 = mfma_h(f1.l, oh1, bc2);
+            if (valid && g < 2) {
+                const float4 bb = *reinterpret_cast<const float4*>(Cs + 320 + 4 * g);
+                const float s13 = 0.57735026918962576f;   // sqrt(1/3), ipa_pytorch.py:404
+                float4 ob;
+                ob.x = s13 * ((bm[0] + bm2[0]) + (bc[0] + bc2[0]) * LOI + bb.x);
+                ob.y = s13 * ((bm[1] + bm2[1]) + (bc[1] + bc2[1]) * LOI + bb.y);
+                ob.z = s13 * ((bm[2] + bm2[2]) + (bc[2] + bc2[2]) * LOI + bb.z);
+                ob.w = s13 * ((bm[3] + bm2[3]) + (bc[3] + bc2[3]) * LOI + bb.w);
+#ifndef PF_EXP_NOBIASSTORE
+                *reinterpret_cast<float4*>(a.bias_out + pidx * 8 + 4 * g) = ob;
+#else
+                if (ob.x == 12345.678f) a.bias_out[0] = ob.y + ob.z + ob.w;
+#endif
             }
         }
+#endif
         PROF3(14);
     }
 }

@@ -135,7 +135,30 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
     // The two z-streaming phases exist in two forms: on MFMA (heads padded to a 16-wide tile; wins when the
     // workgroup owns >= 4 heads) and on VALU with 16-lane butterfly reductions (wins for the 2-head workgroups
     // used at small batch, where 14 of the 16 MFMA columns would be padding: 39 vs 45 us at B=16, L=64).
-    if constexpr (HG >= 4) {
+    if (a.bias) {
+        // ---- phase A': the producer of z already emitted sqrt(1/3)(W_b z + b_b) per pair ([B*L*L, 8]): copy this
+        //      workgroup's heads into the score tile; z is then read only once (pair-value pass) ----
+        constexpr int Q4 = HG >= 4 ? HG / 4 : 1;      // float4 (or float2 for HG = 2) groups per pair
+        for (int idx = tid; idx < TI * LP * Q4; idx += NTH) {
+            const int q = idx % Q4, pj = idx / Q4;
+            const int j = pj % LP, ti = pj / LP;
+            const int i = i0 + ti;
+            if (j < L && i < L) {
+                const float* bp = a.bias + ((rowb + i) * L + j) * 8 + h0 + 4 * q;
+                if constexpr (HG >= 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp);
+                    S[(ti * HG + 4 * q + 0) * LDS_S + j] = v.x; S[(ti * HG + 4 * q + 1) * LDS_S + j] = v.y;
+                    S[(ti * HG + 4 * q + 2) * LDS_S + j] = v.z; S[(ti * HG + 4 * q + 3) * LDS_S + j] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(bp);
+                    S[(ti * HG + 0) * LDS_S + j] = v.x; S[(ti * HG + 1) * LDS_S + j] = v.y;
+                }
+            } else if (j < LP) {
+#pragma unroll
+                for (int h = 0; h < (HG >= 4 ? 4 : 2); ++h) S[(ti * HG + (HG >= 4 ? 4 * q : 0) + h) * LDS_S + j] = 0.f;
+            }
+        }
+    } else if constexpr (HG >= 4) {
         // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) as a [pairs x 64] x [64 x heads] GEMM on fp32 MFMA:
         //      A = z rows (16 pairs per tile, fragments straight from global), B = W_b (heads padded to 16, preloaded).
         //      wave w -> query rows 4w..4w+3.  (A VALU version with 16-lane butterfly reductions took 2.5x longer.) ----

@@ -86,6 +86,18 @@ def pack_et_stream(w1z, w2, wf):
     return stream
 
 
+def pack_bias_frags(w_b):
+    """IPA linear_b [8,64] (heads zero-padded to 16 rows) as the 2 fragment pairs (K-steps, permuted K order) the
+    persistent EdgeTransition kernel uses to emit the next block's pair bias.  Layout/packing only."""
+    w = _f32(w_b)
+    assert w.shape == (8, 64)
+    w = torch.nn.functional.pad(w, (0, 0, 0, 8))
+    kg = torch.arange(4, device=w.device)[:, None]
+    i8 = torch.arange(8, device=w.device)[None, :]
+    perm = lambda s: 32 * s + 16 * (i8 >> 2) + 4 * kg + (i8 & 3)
+    return torch.cat([_frag_pair(w, 0, perm(s)) for s in range(2)]).contiguous()
+
+
 class PackedWeights:
     """Kernel-friendly views/copies of the GAEncoder parameters (reference state_dict layout).
 
@@ -147,6 +159,7 @@ class PackedWeights:
                 t[f"{b}.et.w1z16"], t[f"{b}.et.wf16"] = split_f16(w1[:, :64]), split_f16(wf)
                 t[f"{b}.et.w216"], t[f"{b}.et.b2"] = split_f16(g(q + "trunk.2.weight")), g(q + "trunk.2.bias")
                 t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
+                t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"))
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
                 t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
@@ -182,6 +195,7 @@ class DenoiseEngine:
         self.quat, self.rot, self.trans = e(rows, 4), e(rows, 9), e(rows, 3)
         self.n64, self.pre = e(rows, 64), e(rows, 512)
         self.zbuf = e(B, L, L, 64)
+        self.pair_bias = e(B, L, L, 8)          # sqrt(1/3)(W_b z + b_b) of the next IPA block, written by EdgeTransition
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -262,6 +276,7 @@ class DenoiseEngine:
             ia.w_b, ia.b_b = w[f"{b}.linear_b.w"].data_ptr(), w[f"{b}.linear_b.b"].data_ptr()
             ia.w_dz, ia.b_dz = w[f"{b}.down_z.w"].data_ptr(), w[f"{b}.down_z.b"].data_ptr()
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
+            ia.bias = self.pair_bias.data_ptr() if b > 0 else None     # emitted by EdgeTransition(b - 1)
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----
@@ -316,6 +331,8 @@ class DenoiseEngine:
                 et.w1z_f16, et.w2_f16, et.b2 = w[f"{b}.et.w1z16"].data_ptr(), w[f"{b}.et.w216"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
                 et.wf_f16, et.ln_g, et.ln_b = w[f"{b}.et.wf16"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
                 et.w_stream = w[f"{b}.et.stream"].data_ptr()
+                et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
+                et.bb = w[f"{b + 1}.linear_b.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))

@@ -97,7 +97,7 @@ def rigid_update(quat, rot, trans, upd, mask):
     return qo, ro, to
 
 
-def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L):
+def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None):
     lib = _capi.load()
     rows = B * L
     d = proj.device
@@ -111,12 +111,13 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L):
     ia.rot, ia.trans, ia.mask = _p(rot), _p(trans), _p(mask)
     ia.w_b, ia.b_b, ia.w_dz, ia.b_dz, ia.head_w = _p(w_b), _p(b_b), _p(w_dz), _p(b_dz), _p(head_w)
     ia.feats, ia.B, ia.L = _p(feats), B, L
+    ia.bias = _p(bias)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
 
 
-def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True):
+def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
     persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes)."""
     from pepflowww_amd.engine import split_f16, pack_et_stream
@@ -128,9 +129,14 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
     a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
     ws = pack_et_stream(w1[:, :64], w2, wf) if persistent else None
     a.w_stream = _p(ws)
+    if next_bias is not None:                 # (linear_b.weight [8,64], linear_b.bias [8]) of the next IPA block
+        from pepflowww_amd.engine import pack_bias_frags
+        wbf = pack_bias_frags(next_bias[0])
+        bias = torch.full((z.shape[0], 8), float("nan"), device=z.device)
+        a.bias_out, a.wb_frags, a.bb = _p(bias), _p(wbf), _p(next_bias[1])
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()
-    return out
+    return (out, bias) if next_bias is not None else out
 
 
 def seq_attn(qkv, mask, B, L):

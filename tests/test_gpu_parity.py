@@ -201,24 +201,28 @@ def test_seq_attention_core():
 
 
 # ------------------------------------------------------------------ module level (golden F2)
-def _ipa_run(sd, pfx, s, z, R, x, mask, B, L):
+def _ipa_run(sd, pfx, s, z, R, x, mask, B, L, with_bias=False):
     g = lambda k: cu(sd[pfx + k])
     wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
     bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
     proj = G.linear(cu(s.reshape(B * L, 128)), cu(wproj), cu(bproj))
     feats, pts = G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)),
                              g("linear_b.weight"), g("linear_b.bias"), g("down_z.weight"), g("down_z.bias"),
-                             g("head_weights"), B, L)
+                             g("head_weights"), B, L,
+                             bias=cu(math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"]).reshape(-1, 8))
+                             if with_bias else None)
     out = G.linear(feats, g("linear_out.weight"), g("linear_out.bias"))
     return feats, out
 
 
-def test_ipa_block(f2, seeded_sd):
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_ipa_block(f2, seeded_sd, with_bias):
+    """with_bias: the pair bias arrives precomputed (as EdgeTransition emits it for blocks >= 1), z read once."""
     b = _batch(f2)
     B, L = b["aa"].shape
     mask = b["res_mask"].float()
     pfx = "ga_encoder.trunk.ipa_0."
-    feats, out = _ipa_run(seeded_sd, pfx, f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask, B, L)
+    feats, out = _ipa_run(seeded_sd, pfx, f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask, B, L, with_bias)
     valid = mask.reshape(-1).bool()
     G.assert_close(out.cpu()[valid], f2["ipa0_out"].reshape(B * L, 128)[valid], REL, "IPA block vs reference")
     ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask)
@@ -250,6 +254,28 @@ def test_edge_transition(f2, seeded_sd, persistent):
     out2 = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_0.", f2["et0_in_s"], f2["enc_edge"], mask, B, L, persistent)
     em = (mask[:, None, :] * mask[:, :, None])[..., None]
     G.assert_close(out2.view(B, L, L, 64), f2["et0_out"] * em, REL, "EdgeTransition masked")
+
+
+def test_edge_transition_emits_next_pair_bias(f2, seeded_sd):
+    """The persistent kernel also writes sqrt(1/3)(W_b z' + b_b) of the NEXT IPA block from z' in registers."""
+    b = _batch(f2)
+    B, L = b["aa"].shape
+    sd, pfx = seeded_sd, "ga_encoder.trunk.edge_transition_0."
+    g = lambda k: sd[pfx + k]
+    mask = b["res_mask"].float()
+    n64 = G.linear(cu(f2["et0_in_s"].reshape(B * L, 128)), cu(g("initial_embed.weight")), cu(g("initial_embed.bias")))
+    w1, b1, wf, bf = g("trunk.0.weight"), g("trunk.0.bias"), g("final_layer.weight"), g("final_layer.bias")
+    wpre = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
+    bpre = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0)
+    pre = G.linear(n64, cu(wpre), cu(bpre))
+    wb, bb = sd["ga_encoder.trunk.ipa_1.linear_b.weight"], sd["ga_encoder.trunk.ipa_1.linear_b.bias"]
+    out, bias = G.edge_transition(cu(f2["enc_edge"].reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")),
+                                  cu(wf), cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
+                                  next_bias=(cu(wb), cu(bb)))
+    em = (mask[:, None, :] * mask[:, :, None])[..., None]
+    zref = f2["et0_out"] * em
+    G.assert_close(out.view(B, L, L, 64), zref, REL, "z'")
+    G.assert_close(bias.view(B, L, L, 8), math.sqrt(1.0 / 3.0) * F.linear(zref, wb, bb), REL, "next block's pair bias")
 
 
 @pytest.mark.parametrize("persistent", [True, False])
