@@ -170,7 +170,7 @@ typedef struct {
     const void* w_post_f16; const float* b_post;
     const void* w_t1_f16; const float* b_t1; const void* w_t2_f16; const float* b_t2; const void* w_t3_f16; const float* b_t3;
     const float* nt_g; const float* nt_b;
-    const void* w_bb_f16; const float* b_bb;
+    const void* w_bb_f16; const float* b_bb;   /* b_bb: bb_update bias [6] zero-padded to 8 floats */
     float* s_out;
     const float* quat_in; const float* rot_in; const float* trans_in;
     float* quat_out; float* rot_out; float* trans_out;

@@ -617,7 +617,10 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
     static const int nw8 = [] { const char* e = getenv("PF_IPA_NW"); return e ? atoi(e) : 8; }();
-    if (qt >= 256) {
+    static const int force_hg = [] { const char* e = getenv("PF_IPA_HG"); return e ? atoi(e) : 0; }();   // dev: force a variant
+    if (force_hg == 4) return launch_attn<4, 4>(*a, s);
+    if (force_hg == 2) return launch_attn<2, 4>(*a, s);
+    if (qt >= 256 || force_hg == 8) {
         const int rc = nw8 == 8 ? launch_attn<8, 8>(*a, s) : launch_attn<8, 4>(*a, s);
         if (rc != PF_E_TOOLARGE) return rc;
     }

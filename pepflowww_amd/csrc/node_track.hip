@@ -89,6 +89,16 @@ __device__ __forceinline__ void ln_tile(float* T, const LnParams& p, float mk, P
     }
 }
 
+// Loads that may be out of range read a CLAMPED (always valid) address unconditionally and are zeroed by a select
+// at their use: `cond ? *p : 0` compiles to a load inside a branch followed by an immediate s_waitcnt vmcnt(0),
+// which drains every prefetch issued before it.
+// (a multiply by 0/1, not a select: the compiler sinks a selected load back into a branch.)  The clamped rows
+// hold finite data, so 0 * v is 0.
+__device__ __forceinline__ float4 sel4(bool ok, const float4& v) {
+    const float f = ok ? 1.f : 0.f;
+    return make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+}
+
 // store 4 consecutive features of row r as hi/lo planes
 __device__ __forceinline__ void put_planes(Planes p, int r, int n, const float (&v)[4]) {
     half4 hi, lo;
@@ -114,14 +124,15 @@ __global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
     ws.prefetch();
     // small per-lane operands
     LnParams lnp;
-    if (tid < 256) ln_load(lnp, a.ln_g, a.ln_b);
+    ln_load(lnp, a.ln_g, a.ln_b);          // every wave loads (no branch: a guarded load is followed by vmcnt(0))
     const float4 bias_out = *reinterpret_cast<const float4*>(a.b_out + n);
     float4 bias_in[3];
 #pragma unroll
     for (int wt = 0; wt < 3; ++wt) bias_in[wt] = *reinterpret_cast<const float4*>(a.b_in + wave * 48 + wt * 16 + 4 * g);
     const int mr = m0 + r;
-    const float rmask = mr < M ? a.mask[mr] : 0.f;
-    const float4 rres = mr < M ? *reinterpret_cast<const float4*>(a.s_in + (size_t)mr * 128 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int mrc = mr < M ? mr : M - 1;
+    const float rmask_ld = a.mask[mrc];
+    const float4 rres_ld = *reinterpret_cast<const float4*>(a.s_in + (size_t)mrc * 128 + n);
     // the whole 16 x 1536 feats tile is requested up front (12 float4 per thread): one latency, not six
     const int srow = tid >> 5, sc4 = tid & 31;
     const bool sok = m0 + srow < M;
@@ -132,13 +143,14 @@ __global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf)
-            st[c][hlf] = sok ? *reinterpret_cast<const float4*>(src + c * CK + hlf * 128) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st[c][hlf] = *reinterpret_cast<const float4*>(src + c * CK + hlf * 128);
     auto commit = [&](int c) {
         _Float16* bh = Ch + (c & 1) * 2 * TR * LDC;
         _Float16* bl = bh + TR * LDC;
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
-            const float v[4] = {st[c][hlf].x, st[c][hlf].y, st[c][hlf].z, st[c][hlf].w};
+            const float4 sv = sel4(sok, st[c][hlf]);
+            const float v[4] = {sv.x, sv.y, sv.z, sv.w};
             half4 hi, lo;
             split4(v, hi, lo);
             *reinterpret_cast<half4*>(bh + srow * LDC + hlf * 128 + 4 * sc4) = hi;
@@ -160,6 +172,8 @@ __global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
     wq.init(a.w_in_f16, 384, 128, wave * 48);
     wq.prefetch();
     {
+        const float rmask = rmask_ld * (mr < M ? 1.f : 0.f);
+        const float4 rres = sel4(mr < M, rres_ld);
         float4 y;
         y.x = (join(am[0], ac[0], 0) + bias_out.x) * rmask + rres.x;
         y.y = (join(am[0], ac[0], 1) + bias_out.y) * rmask + rres.y;
@@ -217,74 +231,24 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
         q0 = *reinterpret_cast<const float4*>(qrow);
         q1 = *reinterpret_cast<const float4*>(qrow + 16);
     }
-    WSplit<1, 4> ws;
-    ws.init(a.w_o_f16, 128, 128, wave * 16);
-    ws.prefetch();
-    LnParams ln1, ln2, ln3;
-    if (tid < 256) {
-        ln_load(ln1, a.n1_g, a.n1_b);
-        ln_load(ln2, a.n2_g, a.n2_b);
-        if (LAST) ln_load(ln3, a.nt_g, a.nt_b);
-    }
+    // K rows of the first key block and the V operands of the first PV block: requested before everything else --
+    // they gate the first MFMAs, and vmcnt completes in order (for L <= 64 these are ALL the K/V loads)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 bias_o = *reinterpret_cast<const float4*>(a.b_o + n), bias_1 = *reinterpret_cast<const float4*>(a.b_1 + n),
-                 bias_2 = *reinterpret_cast<const float4*>(a.b_2 + n);
-    float4 bias_post = z4, bias_t1 = z4, bias_t2 = z4, bias_t3 = z4, bias_bb = z4, bias_init = z4;
-    float4 bias_in[3] = {z4, z4, z4}, bias_pre[4] = {z4, z4, z4, z4};
-    const float4 rres = mr < M ? *reinterpret_cast<const float4*>(a.resid + (size_t)mr * 128 + n) : z4;
-    float4 rsipa = z4;
-    float lnmask = 1.f;                       // row mask of the LayerNorm lane's row (tail LayerNorm only)
-    if (LAST) {
-        rsipa = mr < M ? *reinterpret_cast<const float4*>(a.s_ipa + (size_t)mr * 128 + n) : z4;
-        bias_post = *reinterpret_cast<const float4*>(a.b_post + n);
-        bias_t1 = *reinterpret_cast<const float4*>(a.b_t1 + n);
-        bias_t2 = *reinterpret_cast<const float4*>(a.b_t2 + n);
-        bias_t3 = *reinterpret_cast<const float4*>(a.b_t3 + n);
-        if (wave == 0 && g == 0) bias_bb = *reinterpret_cast<const float4*>(a.b_bb);
-        if (wave == 0 && g == 1) bias_bb = make_float4(a.b_bb[4], a.b_bb[5], 0.f, 0.f);
-        if (a.has_et) {
-            bias_init = *reinterpret_cast<const float4*>(a.b_init + (wave & 3) * 16 + 4 * g);
+    const int par = wave >> 2;
+    float4 kf0[2], kf1[2];
+    float kfm[2];
+    auto kload = [&](int j0, float4 (&k0)[2], float4 (&k1)[2], float (&km)[2]) {
 #pragma unroll
-            for (int wt = 0; wt < 4; ++wt) bias_pre[wt] = *reinterpret_cast<const float4*>(a.b_pre + wave * 64 + wt * 16 + 4 * g);
+        for (int t = 0; t < 2; ++t) {
+            const int j = j0 + 32 * t + r;
+            const bool jok = j < L;
+            const float* krow = a.qkv + (rowb + (jok ? j : 0)) * 384 + 128 + h * 32 + 4 * g;
+            k0[t] = *reinterpret_cast<const float4*>(krow);              // (clamped row; masked out through km)
+            k1[t] = *reinterpret_cast<const float4*>(krow + 16);
+            km[t] = a.mask[rowb + (jok ? j : 0)] * (jok ? 1.f : 0.f);
         }
-        if (tid < 256) { const int m = m0 + (tid >> 4); lnmask = m < M ? a.mask[m] : 0.f; }
-    } else {
-#pragma unroll
-        for (int wt = 0; wt < 3; ++wt) bias_in[wt] = *reinterpret_cast<const float4*>(a.b_in_next + wave * 48 + wt * 16 + 4 * g);
-    }
-
-    PROF(1);
-    // ---- attention scores (exact fp32 MFMA): wave -> head h = w&3, key tiles of parity w>>2 ----
-    {
-        const int par = wave >> 2;
-        const float scale = 0.17677669529663687f;   // 1/sqrt(32)
-        for (int j0 = 16 * par; j0 < LP; j0 += 64) {
-            float4 k0[2], k1[2];
-            float km[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int j = j0 + 32 * t + r;
-                const bool jok = j < L;
-                const float* krow = a.qkv + (rowb + (jok ? j : 0)) * 384 + 128 + h * 32 + 4 * g;
-                k0[t] = jok ? *reinterpret_cast<const float4*>(krow) : z4;
-                k1[t] = jok ? *reinterpret_cast<const float4*>(krow + 16) : z4;
-                km[t] = jok ? a.mask[rowb + j] : 0.f;
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int j = j0 + 32 * t + r;
-                if (j0 + 32 * t < LP) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma16(q0.x, k0[t].x, acc); acc = mfma16(q0.y, k0[t].y, acc); acc = mfma16(q0.z, k0[t].z, acc); acc = mfma16(q0.w, k0[t].w, acc);
-                    acc = mfma16(q1.x, k1[t].x, acc); acc = mfma16(q1.y, k1[t].y, acc); acc = mfma16(q1.z, k1[t].z, acc); acc = mfma16(q1.w, k1[t].w, acc);
-                    const bool keep = km[t] > 0.5f;               // key padding mask
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) S[((4 * g + e) * 4 + h) * LDS_S + j] = keep ? acc[e] * scale : -3.0e38f;
-                }
-            }
-        }
-    }
-    // V operands of the first key block are requested before the barrier
+    };
+    kload(16 * par, kf0, kf1, kfm);
     const int ct = wave >> 2;
     const float* vcol = a.qkv + rowb * 384 + 256 + h * 32 + ct * 16 + r;
     auto vload = [&](int k0, float (&vb)[4][4]) {
@@ -299,6 +263,68 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
     };
     float vb[4][4];
     vload(0, vb);
+    WSplit<1, 4> ws;
+    ws.init(a.w_o_f16, 128, 128, wave * 16);
+    ws.prefetch();
+    LnParams ln1, ln2, ln3;
+    ln_load(ln1, a.n1_g, a.n1_b);             // every wave loads (no branch: a guarded load is followed by vmcnt(0))
+    ln_load(ln2, a.n2_g, a.n2_b);
+    if (LAST) ln_load(ln3, a.nt_g, a.nt_b);
+    const float4 bias_o = *reinterpret_cast<const float4*>(a.b_o + n), bias_1 = *reinterpret_cast<const float4*>(a.b_1 + n),
+                 bias_2 = *reinterpret_cast<const float4*>(a.b_2 + n);
+    float4 bias_post = z4, bias_t1 = z4, bias_t2 = z4, bias_t3 = z4, bias_bb = z4, bias_init = z4;
+    float4 bias_in[3] = {z4, z4, z4}, bias_pre[4] = {z4, z4, z4, z4};
+    const int mrc = mr < M ? mr : M - 1;
+    const float4 rres = sel4(mr < M, *reinterpret_cast<const float4*>(a.resid + (size_t)mrc * 128 + n));
+    float4 rsipa = z4;
+    float lnmask = 1.f;                       // row mask of the LayerNorm lane's row (tail LayerNorm only)
+    if (LAST) {
+        rsipa = sel4(mr < M, *reinterpret_cast<const float4*>(a.s_ipa + (size_t)mrc * 128 + n));
+        bias_post = *reinterpret_cast<const float4*>(a.b_post + n);
+        bias_t1 = *reinterpret_cast<const float4*>(a.b_t1 + n);
+        bias_t2 = *reinterpret_cast<const float4*>(a.b_t2 + n);
+        bias_t3 = *reinterpret_cast<const float4*>(a.b_t3 + n);
+        // b_bb is padded to 8 floats by the caller: ONE load (two masked loads into the same registers made the
+        // compiler drain vmcnt(0) -- i.e. every prefetch issued above -- in wave 0 before it could go on)
+        bias_bb = sel4(wave == 0 && g < 2, *reinterpret_cast<const float4*>(a.b_bb + 4 * (g & 1)));
+        if (a.has_et) {
+            bias_init = *reinterpret_cast<const float4*>(a.b_init + (wave & 3) * 16 + 4 * g);
+#pragma unroll
+            for (int wt = 0; wt < 4; ++wt) bias_pre[wt] = *reinterpret_cast<const float4*>(a.b_pre + wave * 64 + wt * 16 + 4 * g);
+        }
+        { const int m = m0 + ((tid & 255) >> 4); const float mv = a.mask[m < M ? m : M - 1]; lnmask = mv * (m < M ? 1.f : 0.f); }
+    } else {
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt) bias_in[wt] = *reinterpret_cast<const float4*>(a.b_in_next + wave * 48 + wt * 16 + 4 * g);
+    }
+
+    PROF(1);
+    // ---- attention scores (exact fp32 MFMA): wave -> head h = w&3, key tiles of parity w>>2 ----
+    {
+        const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+        for (int j0 = 16 * par; j0 < LP; j0 += 64) {
+            float4 kn0[2], kn1[2];
+            float knm[2];
+            const bool more = j0 + 64 < LP;
+            if (more) kload(j0 + 64, kn0, kn1, knm);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = j0 + 32 * t + r;
+                if (j0 + 32 * t < LP) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = mfma16(q0.x, kf0[t].x, acc); acc = mfma16(q0.y, kf0[t].y, acc); acc = mfma16(q0.z, kf0[t].z, acc); acc = mfma16(q0.w, kf0[t].w, acc);
+                    acc = mfma16(q1.x, kf1[t].x, acc); acc = mfma16(q1.y, kf1[t].y, acc); acc = mfma16(q1.z, kf1[t].z, acc); acc = mfma16(q1.w, kf1[t].w, acc);
+                    const bool keep = kfm[t] > 0.5f;              // key padding mask
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[((4 * g + e) * 4 + h) * LDS_S + j] = keep ? acc[e] * scale : -3.0e38f;
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { kf0[t] = kn0[t]; kf1[t] = kn1[t]; kfm[t] = knm[t]; }
+            }
+        }
+    }
     __syncthreads();
     PROF(2);
     // softmax: the 64 (ti,h) rows, 8 rows per wave at once, 8 lanes per row

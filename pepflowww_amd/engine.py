@@ -151,6 +151,7 @@ class PackedWeights:
                 t[f"{b}.nt.{nm}.w16"] = split_f16(t[f"{b}.nt.{nm}.w"])
             t[f"{b}.bb.w"], t[f"{b}.bb.b"] = g(f"trunk.bb_update_{b}.linear.weight"), g(f"trunk.bb_update_{b}.linear.bias")
             t[f"{b}.bb.w16"] = split_f16(t[f"{b}.bb.w"])
+            t[f"{b}.bb.b8"] = torch.nn.functional.pad(t[f"{b}.bb.b"], (0, 2)).contiguous()
             if b < N_BLOCKS - 1:
                 q = f"trunk.edge_transition_{b}."
                 t[f"{b}.et.init.w"], t[f"{b}.et.init.b"] = g(q + "initial_embed.weight"), g(q + "initial_embed.bias")
@@ -311,7 +312,7 @@ class DenoiseEngine:
                     ta.w_t2_f16, ta.b_t2 = w[f"{b}.nt.linear_2.w16"].data_ptr(), w[f"{b}.nt.linear_2.b"].data_ptr()
                     ta.w_t3_f16, ta.b_t3 = w[f"{b}.nt.linear_3.w16"].data_ptr(), w[f"{b}.nt.linear_3.b"].data_ptr()
                     ta.nt_g, ta.nt_b = w[f"{b}.nt.ln.w"].data_ptr(), w[f"{b}.nt.ln.b"].data_ptr()
-                    ta.w_bb_f16, ta.b_bb = w[f"{b}.bb.w16"].data_ptr(), w[f"{b}.bb.b"].data_ptr()
+                    ta.w_bb_f16, ta.b_bb = w[f"{b}.bb.w16"].data_ptr(), w[f"{b}.bb.b8"].data_ptr()
                     ta.quat_in, ta.rot_in, ta.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
                     ta.quat_out, ta.rot_out, ta.trans_out = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr()
                     ta.has_et = int(b < N_BLOCKS - 1)
