@@ -65,6 +65,16 @@ __device__ __forceinline__ float row16_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return sum_xor32(sum_xor16(row16_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) { return max_xor32(max_xor16(row16_max(v))); }
 
+// Zero a loaded value unless `ok`.  A bitwise AND on purpose: `ok ? *p : 0` (and a select of a loaded value) is
+// compiled to a load inside a branch followed by an immediate s_waitcnt vmcnt(0), which drains every prefetch
+// issued before it; callers load from a CLAMPED (always valid) address unconditionally and mask afterwards.
+__device__ __forceinline__ float keep_if(bool ok, float v) { return __uint_as_float(__float_as_uint(v) & (ok ? 0xffffffffu : 0u)); }
+__device__ __forceinline__ float4 keep_if(bool ok, const float4& v) {
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                       __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+}
+
 // One K=16 slice of a [16*MT x 16*NT] tile product on one wave.
 //   a[mt] : float4 of A[row = 16*mt + (lane&15)][k0 + 4*(lane>>4) + 0..3]
 //   b[nt] : float4 of W[col = 16*nt + (lane&15)][k0 + 4*(lane>>4) + 0..3]   (W is [N][K])
@@ -112,7 +122,9 @@ struct BStream {
         (void)slot_static;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            dst[nt] = wok[nt] ? *reinterpret_cast<const float4*>(wrow[nt] + 16 * slice) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // rows >= n_valid read a clamped valid row UNMASKED: the output columns they feed are never stored, and
+            // masking here (select or AND) would put an s_waitcnt vmcnt(0) right behind every prefetch load
+            dst[nt] = *reinterpret_cast<const float4*>(wrow[nt] + 16 * slice);
     }
     __device__ __forceinline__ void prefetch() {
 #pragma unroll

@@ -36,6 +36,31 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
     bs.init(p.w, p.ldw, n0, p.N, p.K);
     bs.prefetch();
 
+    // epilogue operands (bias, row mask, residual) are requested NOW, unconditionally, and stay in flight during the
+    // GEMM: optional operands read a valid dummy address and are neutralised bitwise (no select, no branch -- either
+    // puts an s_waitcnt vmcnt(0) right behind the load; they used to be fetched one by one in the element loop)
+    const bool do_ln = p.ln_gamma != nullptr;
+    float eb[2], erm[MT][4], eres[MT][2][4];
+    {
+        const unsigned ub = p.bias ? 0xffffffffu : 0u, um = p.row_mask ? 0xffffffffu : 0u, ur = p.residual ? 0xffffffffu : 0u;
+        const float* bp = p.bias ? p.bias : p.w;
+        const float* mp = p.row_mask ? p.row_mask : p.x;
+        const float* rp = p.residual ? p.residual : p.y;
+        const int ldr = p.residual ? p.ldr : p.ldy;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) eb[nt] = __uint_as_float(__float_as_uint(bp[min(n0 + nt * 16 + r, p.N - 1)]) & ub);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + mt * 16 + g * 4 + e, p.M - 1);
+                erm[mt][e] = __uint_as_float((__float_as_uint(mp[mc]) & um) | (0x3f800000u & ~um));      // 1.0f when there is no mask
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    eres[mt][nt][e] = __uint_as_float(__float_as_uint(rp[(size_t)mc * ldr + min(n0 + nt * 16 + r, p.N - 1)]) & ur);
+            }
+    }
+
     // activation tile: K-chunks of 128, double-buffered in LDS (global -> registers -> LDS one chunk ahead)
     constexpr int NLD = BM * (KC / 4) / 256;          // float4 per thread per chunk: 2 * MT
     const int nchunks = (p.K + KC - 1) / KC;
@@ -47,6 +72,7 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
             const int idx = tid + q * 256;
             const int row = idx / (KC / 4), c4 = idx % (KC / 4);
             const int m = m0 + row;
+            // (kept as a guarded load: the unconditional clamped form made hipcc keep `stage` in scratch memory)
             stage[q] = (m < p.M && c4 < kq) ? *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + kc + 4 * c4)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -70,13 +96,12 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
     }
     float* Ys = As + 2 * BM * LDA;
 
-    const bool do_ln = p.ln_gamma != nullptr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = n0 + nt * 16 + r;
-            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            const float bias = eb[nt];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = mt * 16 + g * 4 + e;
@@ -84,10 +109,10 @@ __global__ __launch_bounds__(256) void linear_kernel(pf_linear_args p) {
                 float v = acc[mt][nt][e] + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (m < p.M && n < p.N) {
-                    if (p.mask_pre) v *= p.row_mask[m];
-                    if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+                    if (p.mask_pre) v *= erm[mt][e];
+                    v += eres[mt][nt][e];
                     if (!do_ln) {
-                        if (p.mask_post) v *= p.row_mask[m];
+                        if (p.mask_post) v *= erm[mt][e];
                         p.y[(size_t)m * p.ldy + n] = v;
                     }
                 } else {
