@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 6
+#define PF_ABI_VERSION 7
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -177,6 +177,12 @@ typedef struct {
     int has_et;
     const void* w_init_f16; const float* b_init; const void* w_pre_f16; const float* b_pre; float* pre;
     int B, L;
+    /* optional (last == 1, has_et == 0, i.e. the final block): the two output heads ga.py:123-124 on the new node
+     * state while it is in LDS -- seq_net / angle_net = Linear(128,128)+ReLU, Linear(128,128)+ReLU, Linear(128,20|5);
+     * h_w[net][layer] are fragment-order f16 planes (last layers padded to 32 / 16 rows), h_b[net][layer] the biases. */
+    const void* h_w[2][3]; const float* h_b[2][3];
+    float* logits_out;             /* [B*L,20] */
+    float* ang_out;                /* [B*L,5] (before the % 2pi of ga.py:125) */
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
 

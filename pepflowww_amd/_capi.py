@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -108,7 +108,8 @@ class NodeTfmrArgs(C.Structure):
                 ("b_t2", _fp), ("w_t3_f16", _fp), ("b_t3", _fp), ("nt_g", _fp), ("nt_b", _fp), ("w_bb_f16", _fp),
                 ("b_bb", _fp), ("s_out", _fp), ("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp),
                 ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("has_et", _i),
-                ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i)]
+                ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i),
+                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp)]
 
 
 _SIGNATURES = {

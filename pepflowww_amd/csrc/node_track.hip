@@ -544,6 +544,50 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
                     *reinterpret_cast<float4*>(a.pre + (size_t)mr * PF_ET_PRE + wave * 64 + wt * 16 + 4 * g) = y;
                 }
             }
+        } else if (a.logits_out) {
+            // ---- final block: the two output heads on s_new (planes Xb)      (ga.py:123-124, seq_net / angle_net) ----
+            __syncthreads();                                   // T0 / T1 / U are free from here on
+            Planes Xc = {reinterpret_cast<_Float16*>(T0), reinterpret_cast<_Float16*>(T0) + TR * LDP};
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                const int nout = net ? 5 : 20, ntile = net ? 1 : 2;
+                ws.init(a.h_w[net][0], 128, 128, wave * 16);
+                ws.prefetch();
+                const float4 hb0 = *reinterpret_cast<const float4*>(a.h_b[net][0] + n), hb1 = *reinterpret_cast<const float4*>(a.h_b[net][1] + n);
+                acc_zero1<1>(am, ac);
+                gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
+                ws.init(a.h_w[net][1], 128, 128, wave * 16);
+                ws.prefetch();
+                {
+                    const float v[4] = {fmaxf(join(am[0], ac[0], 0) + hb0.x, 0.f), fmaxf(join(am[0], ac[0], 1) + hb0.y, 0.f),
+                                        fmaxf(join(am[0], ac[0], 2) + hb0.z, 0.f), fmaxf(join(am[0], ac[0], 3) + hb0.w, 0.f)};
+                    put_planes(Xa, r, n, v);
+                }
+                __syncthreads();
+                acc_zero1<1>(am, ac);
+                gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+                if (wave < ntile) { ws.init(a.h_w[net][2], 16 * ntile, 128, wave * 16); ws.prefetch(); }
+                {
+                    const float v[4] = {fmaxf(join(am[0], ac[0], 0) + hb1.x, 0.f), fmaxf(join(am[0], ac[0], 1) + hb1.y, 0.f),
+                                        fmaxf(join(am[0], ac[0], 2) + hb1.z, 0.f), fmaxf(join(am[0], ac[0], 3) + hb1.w, 0.f)};
+                    put_planes(Xc, r, n, v);
+                }
+                __syncthreads();
+                if (wave < ntile) {
+                    const float4 hb2 = *reinterpret_cast<const float4*>(a.h_b[net][2] + n);   // bias padded to 32 by the caller
+                    acc_zero1<1>(am, ac);
+                    gemm_split16(ws, Xc.h, Xc.l, LDP, am, ac, 0, 4);
+                    if (mr < M) {
+                        float* op = (net ? a.ang_out : a.logits_out) + (size_t)mr * nout;
+                        const float v[4] = {join(am[0], ac[0], 0) + hb2.x, join(am[0], ac[0], 1) + hb2.y,
+                                            join(am[0], ac[0], 2) + hb2.z, join(am[0], ac[0], 3) + hb2.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < nout) op[n + e] = v[e];
+                    }
+                }
+                __syncthreads();                               // planes Xa / Xc are rewritten by the second head
+            }
         }
     }
 }
@@ -571,6 +615,12 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
                     !a->rot_in || !a->trans_in || !a->quat_out || !a->rot_out || !a->trans_out))
         return PF_E_BADARG;
     if (a->last && a->has_et && (!a->w_init_f16 || !a->b_init || !a->w_pre_f16 || !a->b_pre || !a->pre)) return PF_E_BADARG;
+    if (a->last && !a->has_et && a->logits_out) {
+        if (!a->ang_out) return PF_E_BADARG;
+        for (int net = 0; net < 2; ++net)
+            for (int l = 0; l < 3; ++l)
+                if (!a->h_w[net][l] || !a->h_b[net][l]) return PF_E_BADARG;
+    }
     const int LP = (a->L + 15) / 16 * 16;
     const int LDS_S = LP + 4;
     const size_t lds = ((size_t)2 * TR * LDX + TR * 8 + (size_t)TR * 4 * LDS_S) * sizeof(float) +

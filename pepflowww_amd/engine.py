@@ -122,6 +122,9 @@ class PackedWeights:
         for net in ("seq_net", "angle_net"):
             for i in (0, 2, 4):
                 t[f"{net}.{i}.w"], t[f"{net}.{i}.b"] = g(f"{net}.{i}.weight"), g(f"{net}.{i}.bias")
+                t[f"{net}.{i}.w16"] = split_f16(t[f"{net}.{i}.w"])
+                if i == 4:                  # padded so that the kernel's float4 bias load stays inside the buffer
+                    t[f"{net}.{i}.b"] = torch.nn.functional.pad(t[f"{net}.{i}.b"], (0, 32 - t[f"{net}.{i}.b"].numel())).contiguous()
         for b in range(N_BLOCKS):
             p = f"trunk.ipa_{b}."
             t[f"{b}.proj.w"] = torch.cat([g(p + "linear_q.weight"), g(p + "linear_kv.weight"),
@@ -316,6 +319,12 @@ class DenoiseEngine:
                     ta.quat_in, ta.rot_in, ta.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
                     ta.quat_out, ta.rot_out, ta.trans_out = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr()
                     ta.has_et = int(b < N_BLOCKS - 1)
+                    if not ta.has_et:
+                        for ni, net in enumerate(("seq_net", "angle_net")):
+                            for li, layer in enumerate((0, 2, 4)):
+                                ta.h_w[ni][li] = w[f"{net}.{layer}.w16"].data_ptr()
+                                ta.h_b[ni][li] = w[f"{net}.{layer}.b"].data_ptr()
+                        ta.logits_out, ta.ang_out = self.logits.data_ptr(), self.ang_raw.data_ptr()
                     if ta.has_et:
                         ta.w_init_f16, ta.b_init = w[f"{b}.et.init.w16"].data_ptr(), w[f"{b}.et.init.b"].data_ptr()
                         ta.w_pre_f16, ta.b_pre = w[f"{b}.et.pre.w16"].data_ptr(), w[f"{b}.et.pre.b"].data_ptr()
@@ -338,11 +347,7 @@ class DenoiseEngine:
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
                 plan.append((None, None, "join", 0))
-        # heads                                                                        ga.py:123-124
-        for net, out, n in (("seq_net", self.logits, 20), ("angle_net", self.ang_raw, 5)):
-            plan.append(lin(self.s, w[f"{net}.0.w"], w[f"{net}.0.b"], self.ta, 128, 128, relu=True))
-            plan.append(lin(self.ta, w[f"{net}.2.w"], w[f"{net}.2.b"], self.tb, 128, 128, relu=True))
-            plan.append(lin(self.tb, w[f"{net}.4.w"], w[f"{net}.4.b"], out, n, 128))
+        # heads (ga.py:123-124): fused into the last block's node_tfmr tail (h_w / h_b above)
         self.plan = plan
 
     # ---- execution ---------------------------------------------------------------------------
