@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 7
+#define PF_ABI_VERSION 8
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -348,6 +348,39 @@ typedef struct {
     float* d_logits;   /* [B*L,20] d/d pred_logits */
 } pf_train_bwd_args;
 int pf_train_losses_bwd(const pf_train_args* a, const pf_train_bwd_args* g, pf_stream_t stream);
+
+/* ---- building blocks of the training backward (train.py:133; csrc/backward.hip) -----------------------------
+ * Correctness-first fp32 kernels from which the trunk backward is assembled (first users: output heads, final
+ * backbone update).  A Linear y = x W^T + b (ipa_pytorch.Linear / nn.Linear) needs three GEMMs:
+ *   forward y = x W^T : A = x (sam = ldx, sak = 1), B(k,n) = W[n,k] (sbk = 1, sbn = ldw)
+ *   dx = dy W         : A = dy,                     B(k,n) = W[k,n] (sbk = ldw, sbn = 1)      [K = N_out]
+ *   dW (+)= dy^T x    : A(m,k) = dy[k,m] (sam = 1, sak = ldy), B = x (sbk = ldx, sbn = 1)     [K = rows] */
+typedef struct {
+    const float* A; long long sam, sak;
+    const float* B; long long sbk, sbn;
+    float* C; int ldc;
+    int M, N, K;
+    int accumulate;                /* C += instead of C = */
+} pf_gemm_args;
+int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
+int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
+int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);                                /* dy *= (y > 0) */
+/* nn.LayerNorm backward over the last dimension (N <= 256, eps 1e-5): dx; dgamma_rows[m,n] = dy xhat (optional;
+ * dgamma = column sum of it, dbeta = column sum of dy -- pf_colsum_f32). */
+typedef struct { const float* x; const float* dy; const float* gamma; float* dx; float* dgamma_rows; int M, N; } pf_layernorm_bwd_args;
+int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream);
+/* reverse of pf_rigid_update_fwd (Rigid.compose_q_update_vec + quat_to_rot, rigid_utils.py:1039-1063,185-205):
+ * upstream gradients w.r.t. the NEW rotation matrix / quaternion (optional) / translation -> gradients w.r.t. the
+ * update vector [n,6], the old quaternion, the old translation and (optional) the rotation used for the translation
+ * update; rot_is_from_quat != 0 folds that last term into g_quat_in (blocks >= 1, where R_old = quat_to_rot(q)). */
+typedef struct {
+    const float* quat_in; const float* rot_in; const float* upd; int ldu; const float* mask;
+    const float* g_rot_out; const float* g_quat_out; const float* g_trans_out;
+    float* g_upd; float* g_quat_in; float* g_trans_in; float* g_rot_in;
+    int rot_is_from_quat;
+    int n;
+} pf_rigid_update_bwd_args;
+int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -323,6 +323,8 @@ def ga_encoder(sd, t, rotmats_t, trans_t, angles_t, seqs_t, node_embed, edge_emb
         upd = lin(sd, f"{tp}bb_update_{b}.linear", s * mask[..., None])
         if quat is None:                       # block 0: rot-mat backed frame -> eigh (rigid_utils.py:208)
             quat = rot_to_quat(R)
+        if collect is not None:
+            collect[f"quat_in_{b}"], collect[f"R_in_{b}"], collect[f"upd_{b}"] = quat.clone(), R.clone(), upd.clone()
         quat, x = rigid_update(quat, R, x, upd, mask[..., None])
         R = quat_to_rot(quat)
         if collect is not None:

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -80,6 +80,21 @@ class TrainBwdArgs(C.Structure):
     _fields_ = [("w", C.c_float * 6), ("d_rot", _fp), ("d_trans", _fp), ("d_ang", _fp), ("d_logits", _fp)]
 
 
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _fp), ("sam", C.c_longlong), ("sak", C.c_longlong), ("B", _fp), ("sbk", C.c_longlong), ("sbn", C.c_longlong),
+                ("C", _fp), ("ldc", _i), ("M", _i), ("N", _i), ("K", _i), ("accumulate", _i)]
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [("x", _fp), ("dy", _fp), ("gamma", _fp), ("dx", _fp), ("dgamma_rows", _fp), ("M", _i), ("N", _i)]
+
+
+class RigidUpdateBwdArgs(C.Structure):
+    _fields_ = [("quat_in", _fp), ("rot_in", _fp), ("upd", _fp), ("ldu", _i), ("mask", _fp),
+                ("g_rot_out", _fp), ("g_quat_out", _fp), ("g_trans_out", _fp),
+                ("g_upd", _fp), ("g_quat_in", _fp), ("g_trans_in", _fp), ("g_rot_in", _fp), ("rot_is_from_quat", _i), ("n", _i)]
+
+
 class NodeFeatArgs(C.Structure):
     _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("gen_mask", _fp),
                 ("aa_table", _fp), ("freq3", _fp), ("feat", _fp), ("rot1", _fp), ("trans1", _fp), ("mres", _fp),
@@ -133,6 +148,11 @@ _SIGNATURES = {
     "pf_train_corrupt_fwd": ([C.POINTER(TrainArgs), _fp], _i),
     "pf_train_losses_fwd": ([C.POINTER(TrainArgs), _fp], _i),
     "pf_train_losses_bwd": ([C.POINTER(TrainArgs), C.POINTER(TrainBwdArgs), _fp], _i),
+    "pf_gemm_f32": ([C.POINTER(GemmArgs), _fp], _i),
+    "pf_colsum_f32": ([_fp, _i, _i, _i, _fp, _i, _fp], _i),
+    "pf_relu_bwd": ([_fp, _fp, C.c_longlong, _fp], _i),
+    "pf_layernorm_bwd": ([C.POINTER(LayerNormBwdArgs), _fp], _i),
+    "pf_rigid_update_bwd": ([C.POINTER(RigidUpdateBwdArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
     "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),

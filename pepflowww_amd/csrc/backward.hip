@@ -1,0 +1,197 @@
+// Building blocks of the training backward (the trunk backward of flow_model.py:111-227 / train.py:133 is assembled
+// from these; first users: the output heads and the final backbone update).  Correctness-first fp32 kernels:
+//   pf_gemm_f32        C = op(A) op(B) (+ C)  on fp32 MFMA, arbitrary row/column strides -> covers the three GEMMs of a
+//                      Linear:  y = x W^T (NT),  dx = dy W (NN),  dW += dy^T x (TN)
+//   pf_colsum_f32      db += sum_m dy[m, :]
+//   pf_relu_bwd        dy *= (y > 0)
+//   pf_layernorm_bwd   dx, dgamma, dbeta of nn.LayerNorm (eps 1e-5) over the last dimension
+#include "common.h"
+#include "rigid_dev.h"
+#include "../../include/pepflow_hip.h"
+
+namespace {
+
+constexpr int GT = 64;        // C tile 64 x 64, 4 waves of 32 x 32
+constexpr int GK = 32;        // K chunk
+constexpr int LDT = GK + 1;   // LDS row stride (floats) of a [64][GK] operand tile
+
+// C[M,N] (ldc) = sum_k A(m,k) B(k,n) (+ C if accumulate);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+__global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
+    __shared__ float As[GT * LDT];      // [m][k]
+    __shared__ float Bs[GT * LDT];      // [n][k]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x4 acc[2][2];
+    acc_zero<2, 2>(acc);
+    for (int k0 = 0; k0 < p.K; k0 += GK) {
+        // stage: 64 x 32 elements of each operand, 8 per thread; the fastest-varying thread index follows the
+        // unit-stride dimension of the operand so that the global reads coalesce in either layout
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            int mm, kk;
+            if (p.sak == 1) { kk = idx & (GK - 1); mm = idx >> 5; } else { mm = idx & (GT - 1); kk = idx >> 6; }
+            const int m = m0 + mm, k = k0 + kk;
+            float v = 0.f;
+            if (m < p.M && k < p.K) v = p.A[(size_t)m * p.sam + (size_t)k * p.sak];
+            As[mm * LDT + kk] = v;
+            int nn, kb;
+            if (p.sbk == 1) { kb = idx & (GK - 1); nn = idx >> 5; } else { nn = idx & (GT - 1); kb = idx >> 6; }
+            const int n = n0 + nn, k2 = k0 + kb;
+            float w = 0.f;
+            if (n < p.N && k2 < p.K) w = p.B[(size_t)k2 * p.sbk + (size_t)n * p.sbn];
+            Bs[nn * LDT + kb] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK; ks += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(wm + 16 * t + r) * LDT + ks + g];
+                b[t] = Bs[(wn + 16 * t + r) * LDT + ks + g];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt], b[nt], acc[mt][nt]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm + 16 * mt + 4 * g + e, n = n0 + wn + 16 * nt + r;
+                if (m < p.M && n < p.N) {
+                    float* c = p.C + (size_t)m * p.ldc + n;
+                    *c = acc[mt][nt][e] + (p.accumulate ? *c : 0.f);
+                }
+            }
+}
+
+// out[n] (+)= sum_m x[m*ld + n]; one workgroup per 64 columns, deterministic tree
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int M, int N, float* out, int accumulate) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (n < N)
+        for (int m = part; m < M; m += 4) s += x[(size_t)m * ld + n];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && n < N) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[n] = t + (accumulate ? out[n] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* y, float* dy, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+// one wave per row (N <= 256): xhat = (x - mean) rstd; dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_args p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.M) return;
+    const float* x = p.x + (size_t)row * p.N;
+    const float* dy = p.dy + (size_t)row * p.N;
+    float xv[4], gv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; xv[c] = n < p.N ? x[n] : 0.f; s += xv[c]; }
+    const float mean = wave_sum(s) / (float)p.N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; const float d = n < p.N ? xv[c] - mean : 0.f; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)p.N + 1e-5f);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = lane + 64 * c;
+        const float xh = n < p.N ? (xv[c] - mean) * rstd : 0.f;
+        gv[c] = n < p.N ? dy[n] * p.gamma[n] : 0.f;
+        xv[c] = xh;
+        sg += gv[c];
+        sgx += gv[c] * xh;
+    }
+    sg = wave_sum(sg) / (float)p.N;
+    sgx = wave_sum(sgx) / (float)p.N;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = lane + 64 * c;
+        if (n < p.N) {
+            p.dx[(size_t)row * p.N + n] = rstd * (gv[c] - sg - xv[c] * sgx);
+            if (p.dgamma_rows) {                       // per-row contributions; reduced over rows by pf_colsum_f32
+                p.dgamma_rows[(size_t)row * p.N + n] = dy[n] * xv[c];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rigid_update_bwd_kernel(pf_rigid_update_bwd_args p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const float4 q = *reinterpret_cast<const float4*>(p.quat_in + (size_t)i * 4);
+    float R[9], u[6], gRn[9], gxn[3], gqn[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R[k] = p.rot_in[(size_t)i * 9 + k]; gRn[k] = p.g_rot_out[(size_t)i * 9 + k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = p.upd[(size_t)i * p.ldu + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gxn[k] = p.g_trans_out[(size_t)i * 3 + k];
+    if (p.g_quat_out)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gqn[k] = p.g_quat_out[(size_t)i * 4 + k];
+    float gu[6], gq[4], gRo[9], gx[3];
+    rigid_update_bwd_dev(q, R, u, p.mask[i], gRn, p.g_quat_out ? gqn : nullptr, gxn, p.rot_is_from_quat != 0, gu, gq, gRo, gx);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p.g_upd[(size_t)i * 6 + k] = gu[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.g_quat_in[(size_t)i * 4 + k] = gq[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.g_trans_in[(size_t)i * 3 + k] = gx[k];
+    if (p.g_rot_in)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p.g_rot_in[(size_t)i * 9 + k] = gRo[k];
+}
+
+}  // namespace
+
+extern "C" int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream) {
+    if (!a || !a->quat_in || !a->rot_in || !a->upd || !a->mask || !a->g_rot_out || !a->g_trans_out || !a->g_upd || !a->g_quat_in ||
+        !a->g_trans_in || a->n <= 0 || a->ldu < 6)
+        return PF_E_BADARG;
+    hipLaunchKernelGGL(rigid_update_bwd_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT)), dim3(256), 0,
+                       (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream) {
+    if (!x || !out || M <= 0 || N <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream) {
+    if (!y || !dy || n <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, n);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream) {
+    if (!a || !a->x || !a->dy || !a->gamma || !a->dx || a->M <= 0 || a->N <= 0 || a->N > 256) return PF_E_BADARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((a->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}

@@ -23,3 +23,60 @@ __device__ __forceinline__ void rigid_update_dev(const float4 q, const float* R,
     Ro[3] = 2.f * (nb * nc + na * nd); Ro[4] = na * na - nb * nb + nc * nc - nd * nd; Ro[5] = 2.f * (nc * nd - na * nb);
     Ro[6] = 2.f * (nb * nd - na * nc); Ro[7] = 2.f * (nc * nd + na * nb); Ro[8] = na * na - nb * nb - nc * nc + nd * nd;
 }
+
+// Reverse of rigid_update_dev.  Inputs: the forward operands (q, R_old, u, m), upstream gradients gR' [9] (w.r.t. the
+// NEW rotation matrix quat_to_rot(q')), gq' (w.r.t. the new quaternion, e.g. from the next block) and gx' [3].
+// Outputs: gu [6], gq (w.r.t. the old quaternion), gRold [9] (w.r.t. the rotation used for the translation update),
+// gx [3].  r_from_q: R_old was quat_to_rot(q) (blocks >= 1), so gRold is folded into gq.
+__device__ __forceinline__ void rot_from_quat_bwd(float a, float b, float c, float d, const float* gR, float* gq) {
+    // R = [[aa+bb-cc-dd, 2(bc-ad), 2(bd+ac)], [2(bc+ad), aa-bb+cc-dd, 2(cd-ab)], [2(bd-ac), 2(cd+ab), aa-bb-cc+dd]]
+    gq[0] = 2.f * (a * (gR[0] + gR[4] + gR[8]) + d * (gR[3] - gR[1]) + c * (gR[2] - gR[6]) + b * (gR[7] - gR[5]));
+    gq[1] = 2.f * (b * (gR[0] - gR[4] - gR[8]) + c * (gR[1] + gR[3]) + d * (gR[2] + gR[6]) + a * (gR[7] - gR[5]));
+    gq[2] = 2.f * (c * (gR[4] - gR[0] - gR[8]) + b * (gR[1] + gR[3]) + a * (gR[2] - gR[6]) + d * (gR[5] + gR[7]));
+    gq[3] = 2.f * (d * (gR[8] - gR[0] - gR[4]) + a * (gR[3] - gR[1]) + b * (gR[2] + gR[6]) + c * (gR[5] + gR[7]));
+}
+__device__ __forceinline__ void rigid_update_bwd_dev(const float4 q, const float* R, const float* u, float m, const float* gRn,
+                                                     const float* gqn_in, const float* gxn, bool r_from_q, float* gu, float* gq,
+                                                     float* gRold, float* gx) {
+    const float a = q.x, b = q.y, c = q.z, d = q.w;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float n[4] = {a + m * (-b * ux - c * uy - d * uz), b + m * (a * ux + c * uz - d * uy), c + m * (a * uy - b * uz + d * ux),
+                  d + m * (a * uz + b * uy - c * ux)};
+    const float inv = 1.f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3]);
+    const float qn[4] = {n[0] * inv, n[1] * inv, n[2] * inv, n[3] * inv};
+    float gqn[4];
+    rot_from_quat_bwd(qn[0], qn[1], qn[2], qn[3], gRn, gqn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gqn[k] += gqn_in ? gqn_in[k] : 0.f;
+    // normalisation: g_n = (g_q' - q' (q' . g_q')) / |n|
+    const float dot = qn[0] * gqn[0] + qn[1] * gqn[1] + qn[2] * gqn[2] + qn[3] * gqn[3];
+    float gn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gn[k] = (gqn[k] - qn[k] * dot) * inv;
+    // n = q + m * q (x) (0, u)
+    gu[0] = m * (-b * gn[0] + a * gn[1] + d * gn[2] - c * gn[3]);
+    gu[1] = m * (-c * gn[0] - d * gn[1] + a * gn[2] + b * gn[3]);
+    gu[2] = m * (-d * gn[0] + c * gn[1] - b * gn[2] + a * gn[3]);
+    gq[0] = gn[0] + m * (ux * gn[1] + uy * gn[2] + uz * gn[3]);
+    gq[1] = gn[1] + m * (-ux * gn[0] - uz * gn[2] + uy * gn[3]);
+    gq[2] = gn[2] + m * (-uy * gn[0] + uz * gn[1] - ux * gn[3]);
+    gq[3] = gn[3] + m * (-uz * gn[0] - uy * gn[1] + ux * gn[2]);
+    // x' = x + m R_old v
+    const float vx = u[3], vy = u[4], vz = u[5];
+    gu[3] = m * (R[0] * gxn[0] + R[3] * gxn[1] + R[6] * gxn[2]);
+    gu[4] = m * (R[1] * gxn[0] + R[4] * gxn[1] + R[7] * gxn[2]);
+    gu[5] = m * (R[2] * gxn[0] + R[5] * gxn[1] + R[8] * gxn[2]);
+    const float v[3] = {vx, vy, vz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gRold[i * 3 + j] = m * gxn[i] * v[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gx[k] = gxn[k];
+    if (r_from_q) {
+        float g2[4];
+        rot_from_quat_bwd(a, b, c, d, gRold, g2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gq[k] += g2[k];
+    }
+}

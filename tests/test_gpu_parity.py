@@ -629,3 +629,109 @@ def test_train_loss_gradients_finite_difference(model):
             getattr(eng, n).copy_(base[n])
         tf.compute_losses()
         assert abs(fd - pred) <= 3e-3 * abs(pred), (fd, pred, [n for n, _, _ in names])
+
+
+# ------------------------------------------------------------------ backward building blocks (csrc/backward.hip)
+def test_gemm_three_forms():
+    """The three GEMMs of a Linear (forward NT, dx NN, dW TN) incl. ragged sizes and accumulation."""
+    from pepflowww_amd import backward as Bk
+    g = torch.Generator().manual_seed(2)
+    for M, N, K in ((100, 20, 128), (72, 128, 128), (1030, 6, 128), (64, 192, 64)):
+        x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(M, N, generator=g)
+        y = Bk.linear_fwd(cu(x), cu(w), cu(torch.zeros(N)))
+        G.assert_close(y, x @ w.T, 2e-5, "y = x W^T")
+        dW0 = torch.randn(N, K, generator=g)
+        dWd = cu(dW0.clone())
+        dx, dW, db = Bk.linear_bwd(cu(x), cu(w), cu(dy), dW=dWd)
+        G.sync()
+        G.assert_close(dx, dy @ w, 2e-5, "dx = dy W")
+        G.assert_close(dW, dW0 + dy.T @ x, 2e-5, "dW += dy^T x")
+        G.assert_close(db, dy.sum(0), 2e-5, "db")
+
+
+def test_layernorm_and_relu_backward():
+    from pepflowww_amd import backward as Bk
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(77, 128, generator=g) * 2 + 0.3).requires_grad_(True)
+    gamma, beta = (torch.randn(128, generator=g) * 0.2 + 1).requires_grad_(True), torch.randn(128, generator=g).requires_grad_(True)
+    dy = torch.randn(77, 128, generator=g)
+    F.layer_norm(x, (128,), gamma, beta, 1e-5).backward(dy)
+    dx, dg, dbeta = Bk.layernorm_bwd(cu(x.detach()), cu(gamma.detach()), cu(dy))
+    G.sync()
+    G.assert_close(dx, x.grad, 2e-5, "LN dx")
+    G.assert_close(dg, gamma.grad, 2e-5, "LN dgamma")
+    G.assert_close(dbeta, beta.grad, 2e-5, "LN dbeta")
+    y = torch.randn(50, 64, generator=g)
+    d = torch.randn(50, 64, generator=g)
+    assert torch.equal(Bk.relu_bwd_(cu(y), cu(d)).cpu(), d * (y > 0))
+
+
+def _last_block_inputs(f4, seeded_sd):
+    batch = _batch(f4)
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    enc = O.encode(seeded_sd, batch)
+    t, R_t, x_t, ang_t, seq_t = O.corrupt(batch, enc, noise)
+    col = {}
+    O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, enc[4], enc[5], batch["res_mask"].long(), collect=col)
+    rows = R_t.shape[0] * R_t.shape[1]
+    return col, rows, batch["res_mask"].float().reshape(-1)
+
+
+def test_heads_backward_vs_reference(f4, f5, seeded_sd):
+    """d(weighted loss)/d(parameters of seq_net / angle_net) and d/d(final node state) against the reference's autograd,
+    seeded by the reference's own d/d(logits), d/d(angles), d/d(frames) (golden F5).  The final node state feeds the two
+    heads AND the last backbone update, so its gradient is the sum of the three paths."""
+    from pepflowww_amd import backward as Bk
+    sd = seeded_sd
+    x = cu(f5["node_final"].reshape(-1, 128))
+    dx_tot = None
+    for net, dkey in (("seq_net", "d_pred_logits"), ("angle_net", "d_pred_ang")):
+        ws = [cu(sd[f"ga_encoder.{net}.{i}.weight"]) for i in (0, 2, 4)]
+        bs = [cu(sd[f"ga_encoder.{net}.{i}.bias"]) for i in (0, 2, 4)]
+        dout = cu(f5[dkey].reshape(x.shape[0], -1))
+        dx, grads = Bk.mlp3_backward(x, ws, bs, dout)
+        dx_tot = dx if dx_tot is None else dx_tot + dx
+        for li, layer in enumerate((0, 2, 4)):
+            for kind, gval in (("weight", grads[li][0]), ("bias", grads[li][1])):
+                key = f"grad_ga_encoder.{net}.{layer}.{kind}"
+                if key in f5:
+                    G.assert_close(gval, f5[key], REL, key)
+                nk = f"gradnorm_ga_encoder.{net}.{layer}.{kind}"
+                if nk in f5:
+                    assert abs(gval.norm().item() - f5[nk].item()) <= REL * f5[nk].item(), nk
+    col, rows, mask = _last_block_inputs(f4, seeded_sd)
+    gu5, _, _, _ = Bk.rigid_update_bwd(cu(col["quat_in_5"].reshape(rows, 4)), cu(col["R_in_5"].reshape(rows, 9)), cu(col["upd_5"].reshape(rows, 6)),
+                                       cu(mask), cu(f5["d_pred_rot"].reshape(rows, 9)), cu(f5["d_pred_trans"].reshape(rows, 3)))
+    dx_bb, _, _ = Bk.linear_bwd(x, cu(sd["ga_encoder.trunk.bb_update_5.linear.weight"]), gu5)
+    dx_tot = dx_tot + dx_bb * cu(mask)[:, None]
+    G.assert_close(dx_tot.view(f5["d_node_final"].shape), f5["d_node_final"], REL, "d node_final")
+
+
+def test_rigid_update_backward(f4, f5, seeded_sd):
+    """(i) random frames against torch autograd on the oracle's compose_q_update_vec + quat_to_rot; (ii) the final backbone
+    update of the golden training step: ||d loss / d bb_update_5.linear.weight|| of the reference's autograd."""
+    from pepflowww_amd import backward as Bk
+    g = torch.Generator().manual_seed(6)
+    n = 200
+    q = torch.randn(n, 4, generator=g)
+    q = (q / q.norm(dim=-1, keepdim=True)).requires_grad_(True)
+    x = torch.randn(n, 3, generator=g).requires_grad_(True)
+    u = (torch.randn(n, 6, generator=g) * 0.3).requires_grad_(True)
+    m = (torch.rand(n, 1, generator=g) > 0.2).float()
+    gR, gx, gq2 = torch.randn(n, 3, 3, generator=g), torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g)
+    nq, nx = O.rigid_update(q, O.quat_to_rot(q), x, u, m)
+    ((O.quat_to_rot(nq) * gR).sum() + (nx * gx).sum() + (nq * gq2).sum()).backward()
+    gu, gq, gxo, _ = Bk.rigid_update_bwd(cu(q.detach()), cu(O.quat_to_rot(q.detach()).reshape(n, 9)), cu(u.detach()), cu(m.reshape(-1)),
+                                         cu(gR.reshape(n, 9)), cu(gx), g_quat_out=cu(gq2), rot_is_from_quat=True)
+    G.sync()
+    G.assert_close(gu, u.grad, 2e-5, "g upd")
+    G.assert_close(gq, q.grad, 2e-5, "g quat")
+    G.assert_close(gxo, x.grad, 1e-6, "g trans")
+    # (ii) golden: last block of the reference's training step
+    col, rows, mask = _last_block_inputs(f4, seeded_sd)
+    gu5, _, _, _ = Bk.rigid_update_bwd(cu(col["quat_in_5"].reshape(rows, 4)), cu(col["R_in_5"].reshape(rows, 9)), cu(col["upd_5"].reshape(rows, 6)),
+                                       cu(mask), cu(f5["d_pred_rot"].reshape(rows, 9)), cu(f5["d_pred_trans"].reshape(rows, 3)))
+    s5 = col["s_5"].reshape(rows, 128) * mask[:, None]
+    _, dW, _ = Bk.linear_bwd(cu(s5), cu(seeded_sd["ga_encoder.trunk.bb_update_5.linear.weight"]), gu5, need_dx=False)
+    ref = f5["gradnorm_ga_encoder.trunk.bb_update_5.linear.weight"].item()
+    assert abs(dW.norm().item() - ref) <= 2 * REL * ref, (dW.norm().item(), ref)
