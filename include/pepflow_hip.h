@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 8
+#define PF_ABI_VERSION 9
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -361,6 +361,8 @@ typedef struct {
     float* C; int ldc;
     int M, N, K;
     int accumulate;                /* C += instead of C = */
+    /* optional forward epilogue: C = relu?(A B + bias[n]) + residual[m,n] (residual with C's leading dimension) */
+    const float* bias; int relu; const float* residual;
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
@@ -369,6 +371,13 @@ int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);    
  * dgamma = column sum of it, dbeta = column sum of dy -- pf_colsum_f32). */
 typedef struct { const float* x; const float* dy; const float* gamma; float* dx; float* dgamma_rows; int M, N; } pf_layernorm_bwd_args;
 int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream);
+int pf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int N, pf_stream_t stream);
+int pf_row_mask(float* x, const float* mask, int M, int N, pf_stream_t stream);        /* x[m,:] *= mask[m] */
+int pf_add_inplace(float* dst, const float* src, long long n, pf_stream_t stream);     /* dst += src */
+/* backward of the attention core of the sequence transformer (pf_seq_attn_fwd; ga.py:53-62): qkv [B*L,384],
+ * g_out [B*L,128] -> g_qkv [B*L,384]; stats = scratch [B*4*L*3] floats.  Probabilities are recomputed. */
+int pf_seq_attn_bwd(const float* qkv, const float* mask, const float* g_out, float* g_qkv, float* stats, int B, int L,
+                    pf_stream_t stream);
 /* reverse of pf_rigid_update_fwd (Rigid.compose_q_update_vec + quat_to_rot, rigid_utils.py:1039-1063,185-205):
  * upstream gradients w.r.t. the NEW rotation matrix / quaternion (optional) / translation -> gradients w.r.t. the
  * update vector [n,6], the old quaternion, the old translation and (optional) the rotation used for the translation

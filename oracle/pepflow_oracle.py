@@ -314,6 +314,8 @@ def ga_encoder(sd, t, rotmats_t, trans_t, angles_t, seqs_t, node_embed, edge_emb
     for b in range(N_BLOCKS):
         tp = f"ga_encoder.trunk."
         upd_ipa, feats = ipa(sd, f"{tp}ipa_{b}", s, z, R, x, mask)
+        if collect is not None:
+            collect[f"ln_in_{b}"] = (s + upd_ipa * mask[..., None]).clone()
         s = lnorm(sd, f"{tp}ipa_ln_{b}", s + upd_ipa * mask[..., None])
         if collect is not None:
             collect[f"ipa_feats_{b}"] = feats

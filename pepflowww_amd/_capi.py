@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -82,7 +82,8 @@ class TrainBwdArgs(C.Structure):
 
 class GemmArgs(C.Structure):
     _fields_ = [("A", _fp), ("sam", C.c_longlong), ("sak", C.c_longlong), ("B", _fp), ("sbk", C.c_longlong), ("sbn", C.c_longlong),
-                ("C", _fp), ("ldc", _i), ("M", _i), ("N", _i), ("K", _i), ("accumulate", _i)]
+                ("C", _fp), ("ldc", _i), ("M", _i), ("N", _i), ("K", _i), ("accumulate", _i),
+                ("bias", _fp), ("relu", _i), ("residual", _fp)]
 
 
 class LayerNormBwdArgs(C.Structure):
@@ -152,6 +153,10 @@ _SIGNATURES = {
     "pf_colsum_f32": ([_fp, _i, _i, _i, _fp, _i, _fp], _i),
     "pf_relu_bwd": ([_fp, _fp, C.c_longlong, _fp], _i),
     "pf_layernorm_bwd": ([C.POINTER(LayerNormBwdArgs), _fp], _i),
+    "pf_layernorm_fwd": ([_fp, _fp, _fp, _fp, _i, _i, _fp], _i),
+    "pf_row_mask": ([_fp, _fp, _i, _i, _fp], _i),
+    "pf_add_inplace": ([_fp, _fp, C.c_longlong, _fp], _i),
+    "pf_seq_attn_bwd": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_rigid_update_bwd": ([C.POINTER(RigidUpdateBwdArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),

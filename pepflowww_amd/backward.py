@@ -15,13 +15,19 @@ def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False):
     _capi.check(_capi.load().pf_gemm_f32(C.byref(a), _capi.stream_ptr()), "pf_gemm_f32")
 
 
-def linear_fwd(x, w, b=None):
-    """y = x W^T (+ b) with the fp32 GEMM (the saved-activation forward of the training path)."""
+def linear_fwd(x, w, b=None, relu=False, residual=None):
+    """y = relu?(x W^T + b) + residual in ONE launch of the fp32 GEMM (the saved-activation forward of the training path)."""
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device)
-    _gemm(x, K, 1, w, 1, K, y, M, N, K)
-    return y if b is None else y.add_(b)          # (bias add: elementwise plumbing on the result buffer)
+    a = _capi.GemmArgs()
+    a.A, a.sam, a.sak, a.B, a.sbk, a.sbn = x.data_ptr(), K, 1, w.data_ptr(), 1, K
+    a.C, a.ldc, a.M, a.N, a.K, a.accumulate = y.data_ptr(), N, M, N, K, 0
+    a.bias = b.data_ptr() if b is not None else None
+    a.relu = int(relu)
+    a.residual = residual.data_ptr() if residual is not None else None
+    _capi.check(_capi.load().pf_gemm_f32(C.byref(a), _capi.stream_ptr()), "pf_gemm_f32")
+    return y
 
 
 def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None):
@@ -80,11 +86,117 @@ def rigid_update_bwd(quat_in, rot_in, upd, mask, g_rot_out, g_trans_out, g_quat_
 def mlp3_backward(x, ws, bs, dout):
     """Backward of Linear-ReLU-Linear-ReLU-Linear (seq_net / angle_net, ga.py:65-77): the forward is re-run with saved
     activations (fp32 GEMM), then three linear_bwd.  Returns (dx, [(dW, db)] * 3)."""
-    h1 = torch.relu_(linear_fwd(x, ws[0], bs[0]))
-    h2 = torch.relu_(linear_fwd(h1, ws[1], bs[1]))
+    h1 = linear_fwd(x, ws[0], bs[0], relu=True)
+    h2 = linear_fwd(h1, ws[1], bs[1], relu=True)
     d2, dW2, db2 = linear_bwd(h2, ws[2], dout)
     relu_bwd_(h2, d2)
     d1, dW1, db1 = linear_bwd(h1, ws[1], d2)
     relu_bwd_(h1, d1)
     dx, dW0, db0 = linear_bwd(x, ws[0], d1)
     return dx, [(dW0, db0), (dW1, db1), (dW2, db2)]
+
+
+def layernorm_fwd(x, gamma, beta):
+    y = torch.empty_like(x)
+    _capi.check(_capi.load().pf_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1],
+                                              _capi.stream_ptr()), "pf_layernorm_fwd")
+    return y
+
+
+def row_mask_(x, mask):
+    _capi.check(_capi.load().pf_row_mask(x.data_ptr(), mask.data_ptr(), x.shape[0], x.shape[1], _capi.stream_ptr()), "pf_row_mask")
+    return x
+
+
+def add_(dst, src):
+    _capi.check(_capi.load().pf_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), _capi.stream_ptr()), "pf_add_inplace")
+    return dst
+
+
+def seq_attn_fwd(qkv, mask, B, L):
+    out = torch.empty(B * L, 128, device=qkv.device)
+    a = _capi.SeqAttnArgs()
+    a.qkv, a.mask, a.out, a.B, a.L = qkv.data_ptr(), mask.data_ptr(), out.data_ptr(), B, L
+    _capi.check(_capi.load().pf_seq_attn_fwd(C.byref(a), _capi.stream_ptr()), "pf_seq_attn_fwd")
+    return out
+
+
+def seq_attn_bwd(qkv, mask, g_out, B, L):
+    g_qkv = torch.empty_like(qkv)
+    stats = torch.empty(B * 4 * L * 3, device=qkv.device)
+    _capi.check(_capi.load().pf_seq_attn_bwd(qkv.data_ptr(), mask.data_ptr(), g_out.data_ptr(), g_qkv.data_ptr(), stats.data_ptr(), B, L,
+                                             _capi.stream_ptr()), "pf_seq_attn_bwd")
+    return g_qkv
+
+
+class NodeTrackBlock:
+    """Node track of one trunk block (ga.py:103-113 after the IPA): LayerNorm(s + ipa) -> 2 post-LN transformer layers ->
+    + post_tfmr -> StructureModuleTransition -> * mask, as a saved-activation forward and its backward, both made of the
+    HIP building blocks above.  `W` maps reference parameter names (relative to ga_encoder.trunk.) to fp32 device tensors."""
+
+    def __init__(self, W, b, B, L, mask):
+        self.W, self.b, self.B, self.L, self.mask = W, b, B, L, mask
+
+    def p(self, name):
+        return self.W[name]
+
+    def forward(self, a0):
+        b, B, L, m = self.b, self.B, self.L, self.mask
+        sv = {"a0": a0}
+        x = layernorm_fwd(a0, self.p(f"ipa_ln_{b}.weight"), self.p(f"ipa_ln_{b}.bias"))
+        sv["s1"] = x
+        for l in range(2):
+            q = f"seq_tfmr_{b}.layers.{l}."
+            qkv = linear_fwd(x, self.p(q + "self_attn.in_proj_weight"), self.p(q + "self_attn.in_proj_bias"))
+            att = seq_attn_fwd(qkv, m, B, L)
+            h = linear_fwd(att, self.p(q + "self_attn.out_proj.weight"), self.p(q + "self_attn.out_proj.bias"), residual=x)
+            x1 = layernorm_fwd(h, self.p(q + "norm1.weight"), self.p(q + "norm1.bias"))
+            f = linear_fwd(x1, self.p(q + "linear1.weight"), self.p(q + "linear1.bias"), relu=True)
+            h2 = linear_fwd(f, self.p(q + "linear2.weight"), self.p(q + "linear2.bias"), residual=x1)
+            y = layernorm_fwd(h2, self.p(q + "norm2.weight"), self.p(q + "norm2.bias"))
+            sv[l] = dict(x=x, qkv=qkv, att=att, h=h, x1=x1, f=f, h2=h2)
+            x = y
+        sv["tf"] = x
+        s2 = linear_fwd(x, self.p(f"post_tfmr_{b}.weight"), self.p(f"post_tfmr_{b}.bias"), residual=sv["s1"])
+        t = f"node_transition_{b}."
+        t1 = linear_fwd(s2, self.p(t + "linear_1.weight"), self.p(t + "linear_1.bias"), relu=True)
+        t2 = linear_fwd(t1, self.p(t + "linear_2.weight"), self.p(t + "linear_2.bias"), relu=True)
+        h3 = linear_fwd(t2, self.p(t + "linear_3.weight"), self.p(t + "linear_3.bias"), residual=s2)
+        s3 = row_mask_(layernorm_fwd(h3, self.p(t + "ln.weight"), self.p(t + "ln.bias")), m)
+        sv.update(s2=s2, t1=t1, t2=t2, h3=h3)
+        self.saved = sv
+        return s3
+
+    def backward(self, g_s3m):
+        """g_s3m: gradient w.r.t. the masked block output.  Returns (g_a0, grads) -- g_a0 is the gradient w.r.t.
+        s_in + ipa_embed * mask (i.e. d/d s_in contribution and, times mask, d/d ipa_embed)."""
+        b, B, L, m, sv = self.b, self.B, self.L, self.mask, self.saved
+        G = {}
+        g = row_mask_(g_s3m.clone(), m)
+        t = f"node_transition_{b}."
+        g_h3, G[t + "ln.weight"], G[t + "ln.bias"] = layernorm_bwd(sv["h3"], self.p(t + "ln.weight"), g)
+        g_t2, G[t + "linear_3.weight"], G[t + "linear_3.bias"] = linear_bwd(sv["t2"], self.p(t + "linear_3.weight"), g_h3)
+        relu_bwd_(sv["t2"], g_t2)
+        g_t1, G[t + "linear_2.weight"], G[t + "linear_2.bias"] = linear_bwd(sv["t1"], self.p(t + "linear_2.weight"), g_t2)
+        relu_bwd_(sv["t1"], g_t1)
+        g_s2, G[t + "linear_1.weight"], G[t + "linear_1.bias"] = linear_bwd(sv["s2"], self.p(t + "linear_1.weight"), g_t1)
+        add_(g_s2, g_h3)                                        # residual s2 + t3
+        g_y, G[f"post_tfmr_{b}.weight"], G[f"post_tfmr_{b}.bias"] = linear_bwd(sv["tf"], self.p(f"post_tfmr_{b}.weight"), g_s2)
+        g_s1 = g_s2                                             # residual s1 + post_tfmr(tf)
+        for l in (1, 0):
+            q = f"seq_tfmr_{b}.layers.{l}."
+            a = sv[l]
+            g_h2, G[q + "norm2.weight"], G[q + "norm2.bias"] = layernorm_bwd(a["h2"], self.p(q + "norm2.weight"), g_y)
+            g_f, G[q + "linear2.weight"], G[q + "linear2.bias"] = linear_bwd(a["f"], self.p(q + "linear2.weight"), g_h2)
+            relu_bwd_(a["f"], g_f)
+            g_x1, G[q + "linear1.weight"], G[q + "linear1.bias"] = linear_bwd(a["x1"], self.p(q + "linear1.weight"), g_f)
+            add_(g_x1, g_h2)                                    # residual x1 + ffn
+            g_h, G[q + "norm1.weight"], G[q + "norm1.bias"] = layernorm_bwd(a["h"], self.p(q + "norm1.weight"), g_x1)
+            g_att, G[q + "self_attn.out_proj.weight"], G[q + "self_attn.out_proj.bias"] = linear_bwd(a["att"], self.p(q + "self_attn.out_proj.weight"), g_h)
+            g_qkv = seq_attn_bwd(a["qkv"], m, g_att, B, L)
+            g_x, G[q + "self_attn.in_proj_weight"], G[q + "self_attn.in_proj_bias"] = linear_bwd(a["x"], self.p(q + "self_attn.in_proj_weight"), g_qkv)
+            add_(g_x, g_h)                                      # residual x + mha
+            g_y = g_x
+        add_(g_s1, g_y)
+        g_a0, G[f"ipa_ln_{b}.weight"], G[f"ipa_ln_{b}.bias"] = layernorm_bwd(sv["a0"], self.p(f"ipa_ln_{b}.weight"), g_s1)
+        return g_a0, G

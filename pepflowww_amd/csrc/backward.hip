@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
                 const int m = m0 + wm + 16 * mt + 4 * g + e, n = n0 + wn + 16 * nt + r;
                 if (m < p.M && n < p.N) {
                     float* c = p.C + (size_t)m * p.ldc + n;
-                    *c = acc[mt][nt][e] + (p.accumulate ? *c : 0.f);
+                    float v = acc[mt][nt][e];
+                    if (p.bias) v += p.bias[n];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.residual) v += p.residual[(size_t)m * p.ldc + n];
+                    *c = v + (p.accumulate ? *c : 0.f);
                 }
             }
 }
@@ -132,6 +136,118 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_arg
     }
 }
 
+// nn.LayerNorm forward, one wave per row (the saved-activation training forward; N <= 256)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y, int M, int N) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float xv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; xv[c] = n < N ? x[(size_t)row * N + n] : 0.f; s += xv[c]; }
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; const float d = n < N ? xv[c] - mean : 0.f; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)N + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; if (n < N) y[(size_t)row * N + n] = (xv[c] - mean) * rstd * gamma[n] + beta[n]; }
+}
+
+// x[m, :] *= mask[m]
+__global__ __launch_bounds__(256) void row_mask_kernel(float* x, const float* mask, long long M, int N) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < M * N) x[i] *= mask[i / N];
+}
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* dst, const float* src, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// Backward of the sequence-transformer attention core (MHA of nn.TransformerEncoderLayer, ga.py:53-62: 4 heads x 32,
+// key padding mask): qkv [B*L,384], g_out [B*L,128] (gradient w.r.t. the concatenated head outputs, before out_proj)
+// -> g_qkv [B*L,384].  Probabilities are recomputed.  One workgroup per (sample, head); pass A: one thread per query
+// (row max / sum, delta_i = sum_j p_ij (g_o_i . v_j), g_q_i); pass B: one thread per key (g_k_j, g_v_j).  No atomics.
+constexpr int AD = 32;
+__global__ __launch_bounds__(256) void seq_attn_bwd_kernel(const float* qkv, const float* mask, const float* g_out, float* g_qkv,
+                                                           float* stats, int B, int L) {
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const size_t rowb = (size_t)b * L;
+    const float scale = 0.17677669529663687f;     // 1/sqrt(32)
+    float* st = stats + ((size_t)blockIdx.x * L) * 3;     // per query: max, 1/sum, delta
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float q[AD], go[AD];
+#pragma unroll
+        for (int c = 0; c < AD; ++c) { q[c] = qkv[(rowb + i) * 384 + h * AD + c]; go[c] = g_out[(rowb + i) * 128 + h * AD + c]; }
+        float mx = -3.0e38f;
+        for (int j = 0; j < L; ++j) {
+            if (mask[rowb + j] < 0.5f) continue;
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < AD; ++c) sc += q[c] * qkv[(rowb + j) * 384 + 128 + h * AD + c];
+            mx = fmaxf(mx, sc * scale);
+        }
+        float sum = 0.f, dl = 0.f;
+        for (int j = 0; j < L; ++j) {
+            if (mask[rowb + j] < 0.5f) continue;
+            float sc = 0.f, gp = 0.f;
+#pragma unroll
+            for (int c = 0; c < AD; ++c) {
+                sc += q[c] * qkv[(rowb + j) * 384 + 128 + h * AD + c];
+                gp += go[c] * qkv[(rowb + j) * 384 + 256 + h * AD + c];
+            }
+            const float e = expf(sc * scale - mx);
+            sum += e;
+            dl += e * gp;
+        }
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        dl *= inv;
+        st[i * 3 + 0] = mx; st[i * 3 + 1] = inv; st[i * 3 + 2] = dl;
+        float gq[AD];
+#pragma unroll
+        for (int c = 0; c < AD; ++c) gq[c] = 0.f;
+        for (int j = 0; j < L; ++j) {
+            if (mask[rowb + j] < 0.5f) continue;
+            float sc = 0.f, gp = 0.f;
+#pragma unroll
+            for (int c = 0; c < AD; ++c) {
+                sc += q[c] * qkv[(rowb + j) * 384 + 128 + h * AD + c];
+                gp += go[c] * qkv[(rowb + j) * 384 + 256 + h * AD + c];
+            }
+            const float gs = expf(sc * scale - mx) * inv * (gp - dl) * scale;
+#pragma unroll
+            for (int c = 0; c < AD; ++c) gq[c] += gs * qkv[(rowb + j) * 384 + 128 + h * AD + c];
+        }
+#pragma unroll
+        for (int c = 0; c < AD; ++c) g_qkv[(rowb + i) * 384 + h * AD + c] = gq[c];
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int j = threadIdx.x; j < L; j += 256) {
+        float k[AD], v[AD], gk[AD], gv[AD];
+#pragma unroll
+        for (int c = 0; c < AD; ++c) { k[c] = qkv[(rowb + j) * 384 + 128 + h * AD + c]; v[c] = qkv[(rowb + j) * 384 + 256 + h * AD + c]; gk[c] = 0.f; gv[c] = 0.f; }
+        if (mask[rowb + j] >= 0.5f) {
+            for (int i = 0; i < L; ++i) {
+                float sc = 0.f, gp = 0.f;
+#pragma unroll
+                for (int c = 0; c < AD; ++c) {
+                    sc += qkv[(rowb + i) * 384 + h * AD + c] * k[c];
+                    gp += g_out[(rowb + i) * 128 + h * AD + c] * v[c];
+                }
+                const float p = expf(sc * scale - st[i * 3 + 0]) * st[i * 3 + 1];
+                const float gs = p * (gp - st[i * 3 + 2]) * scale;
+#pragma unroll
+                for (int c = 0; c < AD; ++c) {
+                    gk[c] += gs * qkv[(rowb + i) * 384 + h * AD + c];
+                    gv[c] += p * g_out[(rowb + i) * 128 + h * AD + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < AD; ++c) { g_qkv[(rowb + j) * 384 + 128 + h * AD + c] = gk[c]; g_qkv[(rowb + j) * 384 + 256 + h * AD + c] = gv[c]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void rigid_update_bwd_kernel(pf_rigid_update_bwd_args p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
@@ -166,6 +282,33 @@ extern "C" int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_
         !a->g_trans_in || a->n <= 0 || a->ldu < 6)
         return PF_E_BADARG;
     hipLaunchKernelGGL(rigid_update_bwd_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int N, pf_stream_t stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || N <= 0 || N > 256) return PF_E_BADARG;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, M, N);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_row_mask(float* x, const float* mask, int M, int N, pf_stream_t stream) {
+    if (!x || !mask || M <= 0 || N <= 0) return PF_E_BADARG;
+    const long long n = (long long)M * N;
+    hipLaunchKernelGGL(row_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, (long long)M, N);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_add_inplace(float* dst, const float* src, long long n, pf_stream_t stream) {
+    if (!dst || !src || n <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float* g_out, float* g_qkv, float* stats, int B, int L,
+                               pf_stream_t stream) {
+    if (!qkv || !mask || !g_out || !g_qkv || !stats || B <= 0 || L <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(seq_attn_bwd_kernel, dim3((unsigned)(B * 4)), dim3(256), 0, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
     PF_CHECK_LAUNCH();
     return 0;
 }

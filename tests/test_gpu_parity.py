@@ -735,3 +735,53 @@ def test_rigid_update_backward(f4, f5, seeded_sd):
     _, dW, _ = Bk.linear_bwd(cu(s5), cu(seeded_sd["ga_encoder.trunk.bb_update_5.linear.weight"]), gu5, need_dx=False)
     ref = f5["gradnorm_ga_encoder.trunk.bb_update_5.linear.weight"].item()
     assert abs(dW.norm().item() - ref) <= 2 * REL * ref, (dW.norm().item(), ref)
+
+
+@pytest.fixture(scope="module")
+def f6(golden_dir):
+    d = load(golden_dir, "f6_trunk_grads.npz")
+    import json
+    names = json.load(open(os.path.join(golden_dir, "f6_param_names.json")))
+    d["_gradnorm"] = dict(zip(names, d["param_gradnorms"].tolist()))
+    return d
+
+
+def test_seq_attention_backward():
+    """pf_seq_attn_bwd against torch autograd on the unfused attention of the oracle (padding in one sample)."""
+    from pepflowww_amd import backward as Bk
+    g = torch.Generator().manual_seed(12)
+    B, L = 3, 37
+    qkv = torch.randn(B, L, 384, generator=g).requires_grad_(True)
+    mask = torch.ones(B, L)
+    mask[1, 30:] = 0
+    go = torch.randn(B, L, 128, generator=g)
+    q, k, v = [t.view(B, L, 4, 32).transpose(1, 2) for t in qkv.split(128, dim=-1)]
+    att = (q @ k.transpose(-1, -2)) / math.sqrt(32)
+    att = torch.softmax(att.masked_fill((mask < 0.5)[:, None, None, :], float("-inf")), -1)
+    ((att @ v).transpose(1, 2).reshape(B, L, 128) * go).sum().backward()
+    gq = Bk.seq_attn_bwd(cu(qkv.detach().reshape(B * L, 384)), cu(mask.reshape(-1)), cu(go.reshape(B * L, 128)), B, L)
+    G.sync()
+    ref = qkv.grad.reshape(B * L, 384).clone()
+    ref[(mask.reshape(-1) < 0.5)][:, 128:] = 0          # (masked keys receive no gradient in either implementation)
+    G.assert_close(gq, ref, 2e-5, "g qkv")
+
+
+def test_node_track_block_backward_vs_reference(f4, f5, f6, seeded_sd):
+    """Node track of the LAST trunk block: saved-activation forward == oracle, and its backward seeded with the reference's
+    d/d(final node state) reproduces the reference's d/d(IPA output) and the gradient norm of every parameter of the
+    block's LayerNorm / transformer layers / post_tfmr / transition (golden F5/F6)."""
+    from pepflowww_amd import backward as Bk
+    col, rows, mask = _last_block_inputs(f4, seeded_sd)
+    B, L = f5["node_final"].shape[:2]
+    pre = "ga_encoder.trunk."
+    W = {k[len(pre):]: cu(v) for k, v in seeded_sd.items() if k.startswith(pre) and ("_5." in k)}
+    blk = Bk.NodeTrackBlock(W, 5, B, L, cu(mask))
+    s3 = blk.forward(cu(col["ln_in_5"].reshape(rows, 128)))
+    G.assert_close(s3, col["s_5"].reshape(rows, 128) * mask[:, None], 2e-5, "saved-activation forward")
+    g_a0, grads = blk.backward(cu(f5["d_node_final"].reshape(rows, 128)))
+    G.sync()
+    ok = mask > 0.5
+    G.assert_close(g_a0.cpu()[ok], f6["d_ipa_out_5"].reshape(rows, 128)[ok], REL, "d ipa_embed (block 5)")
+    for k, gval in grads.items():
+        ref = f6["_gradnorm"][pre + k]
+        assert abs(gval.norm().item() - ref) <= 2 * REL * max(ref, 1e-6), (k, gval.norm().item(), ref)
