@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 9
+#define PF_ABI_VERSION 11
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -361,8 +361,12 @@ typedef struct {
     float* C; int ldc;
     int M, N, K;
     int accumulate;                /* C += instead of C = */
-    /* optional forward epilogue: C = relu?(A B + bias[n]) + residual[m,n] (residual with C's leading dimension) */
+    /* optional forward epilogue: C = relu?(alpha A B + bias[n]) + residual[m,n] (residual with C's leading dimension) */
     const float* bias; int relu; const float* residual;
+    float alpha;                   /* scale of the product (set 1) */
+    /* optional two-level batching (e.g. sample x head): slice (z1, z2) uses A + z1*bsA1 + z2*bsA2 etc.; 0 = no batching */
+    int batch1, batch2;
+    long long bsA1, bsA2, bsB1, bsB2, bsC1, bsC2;
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
@@ -390,6 +394,32 @@ typedef struct {
     int n;
 } pf_rigid_update_bwd_args;
 int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream);
+/* g_quat (+)= (d quat_to_rot(q)/dq)^T g_rot  (rigid_utils.py:185-205): rotation gradients of a block's IPA -> its quaternion */
+int pf_quat_to_rot_bwd(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate, pf_stream_t stream);
+
+/* ---- backward of the IPA core (ipa_pytorch.py:389-475; csrc/ipa_bwd.hip), correctness-first -------------------
+ * Forward operands as for pf_ipa_attn_fwd; g_feats [B*L,1536] is the gradient w.r.t. its output.  Call order:
+ *   pf_ipa_bwd_rows  -> P, gA [B,8,L,L], g_opt [rows,288] (global-frame gradient of o_pt), g_frame_rows [rows,12]
+ *                       (d/d trans 3 | d/d rot 9 of the inverse-frame projection), g_gamma_rows [rows,8]
+ *   pf_ipa_bwd_pairs -> g_bias [pairs,8], g_pz [pairs,16], g_z [pairs,64] (+= if accumulate_gz)
+ *   host GEMMs (pf_gemm_f32, batched over sample x head): g_q = s_qk gA K, g_k = s_qk gA^T Q, g_v = P^T g_o into
+ *                       g_proj[:, :3072]; g_qp = gA KP, g_kp = gA^T QP [rows,192], g_vp = P^T g_opt [rows,288]
+ *   pf_ipa_bwd_points -> g_proj[:, 3072:3744] (raw point projections) and += g_frame_rows (point transforms)
+ *   pf_ipa_headw_bwd  -> d/d head_weights [8] from the column sum of g_gamma_rows */
+typedef struct {
+    const float* proj; int ldp; const float* qp; const float* kp; const float* vp; const float* z;
+    const float* rot; const float* trans; const float* mask;
+    const float* w_b; const float* b_b; const float* w_dz; const float* b_dz; const float* head_w;
+    const float* g_feats;
+    float* P; float* gA; float* g_opt; float* g_frame_rows; float* g_gamma_rows;
+    float* g_bias; float* g_pz; float* g_z; int accumulate_gz;
+    const float* g_qp; const float* g_kp; const float* g_vp; float* g_proj;
+    int B, L;
+} pf_ipa_bwd_args;
+int pf_ipa_bwd_rows(const pf_ipa_bwd_args* a, pf_stream_t stream);
+int pf_ipa_bwd_pairs(const pf_ipa_bwd_args* a, pf_stream_t stream);
+int pf_ipa_bwd_points(const pf_ipa_bwd_args* a, pf_stream_t stream);
+int pf_ipa_headw_bwd(const float* g_gamma, const float* head_w, float* g_head_w, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

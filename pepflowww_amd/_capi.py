@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 11
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -83,7 +83,9 @@ class TrainBwdArgs(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("A", _fp), ("sam", C.c_longlong), ("sak", C.c_longlong), ("B", _fp), ("sbk", C.c_longlong), ("sbn", C.c_longlong),
                 ("C", _fp), ("ldc", _i), ("M", _i), ("N", _i), ("K", _i), ("accumulate", _i),
-                ("bias", _fp), ("relu", _i), ("residual", _fp)]
+                ("bias", _fp), ("relu", _i), ("residual", _fp), ("alpha", C.c_float), ("batch1", _i), ("batch2", _i),
+                ("bsA1", C.c_longlong), ("bsA2", C.c_longlong), ("bsB1", C.c_longlong), ("bsB2", C.c_longlong),
+                ("bsC1", C.c_longlong), ("bsC2", C.c_longlong)]
 
 
 class LayerNormBwdArgs(C.Structure):
@@ -94,6 +96,14 @@ class RigidUpdateBwdArgs(C.Structure):
     _fields_ = [("quat_in", _fp), ("rot_in", _fp), ("upd", _fp), ("ldu", _i), ("mask", _fp),
                 ("g_rot_out", _fp), ("g_quat_out", _fp), ("g_trans_out", _fp),
                 ("g_upd", _fp), ("g_quat_in", _fp), ("g_trans_in", _fp), ("g_rot_in", _fp), ("rot_is_from_quat", _i), ("n", _i)]
+
+
+class IpaBwdArgs(C.Structure):
+    _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp), ("trans", _fp), ("mask", _fp),
+                ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp), ("head_w", _fp), ("g_feats", _fp),
+                ("P", _fp), ("gA", _fp), ("g_opt", _fp), ("g_frame_rows", _fp), ("g_gamma_rows", _fp),
+                ("g_bias", _fp), ("g_pz", _fp), ("g_z", _fp), ("accumulate_gz", _i),
+                ("g_qp", _fp), ("g_kp", _fp), ("g_vp", _fp), ("g_proj", _fp), ("B", _i), ("L", _i)]
 
 
 class NodeFeatArgs(C.Structure):
@@ -158,6 +168,11 @@ _SIGNATURES = {
     "pf_add_inplace": ([_fp, _fp, C.c_longlong, _fp], _i),
     "pf_seq_attn_bwd": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_rigid_update_bwd": ([C.POINTER(RigidUpdateBwdArgs), _fp], _i),
+    "pf_quat_to_rot_bwd": ([_fp, _fp, _fp, _i, _i, _fp], _i),
+    "pf_ipa_bwd_rows": ([C.POINTER(IpaBwdArgs), _fp], _i),
+    "pf_ipa_bwd_pairs": ([C.POINTER(IpaBwdArgs), _fp], _i),
+    "pf_ipa_bwd_points": ([C.POINTER(IpaBwdArgs), _fp], _i),
+    "pf_ipa_headw_bwd": ([_fp, _fp, _fp, _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
     "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),

@@ -8,10 +8,16 @@ import torch
 from . import _capi
 
 
-def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False):
+def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None):
+    """C = alpha * A B (+ C).  Offsets in elements; batch = (n1, n2, (sA1, sA2), (sB1, sB2), (sC1, sC2)) for sample x head slices."""
     a = _capi.GemmArgs()
-    a.A, a.sam, a.sak, a.B, a.sbk, a.sbn = A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn
-    a.C, a.ldc, a.M, a.N, a.K, a.accumulate = Cm.data_ptr(), Cm.shape[1], M, N, K, int(accumulate)
+    a.A, a.sam, a.sak = A.data_ptr() + 4 * a_off, sam, sak
+    a.B, a.sbk, a.sbn = Bm.data_ptr() + 4 * b_off, sbk, sbn
+    a.C, a.ldc, a.M, a.N, a.K, a.accumulate = Cm.data_ptr() + 4 * c_off, (Cm.shape[-1] if ldc is None else ldc), M, N, K, int(accumulate)
+    a.alpha = alpha
+    if batch is not None:
+        a.batch1, a.batch2 = batch[0], batch[1]
+        (a.bsA1, a.bsA2), (a.bsB1, a.bsB2), (a.bsC1, a.bsC2) = batch[2], batch[3], batch[4]
     _capi.check(_capi.load().pf_gemm_f32(C.byref(a), _capi.stream_ptr()), "pf_gemm_f32")
 
 
@@ -23,6 +29,7 @@ def linear_fwd(x, w, b=None, relu=False, residual=None):
     a = _capi.GemmArgs()
     a.A, a.sam, a.sak, a.B, a.sbk, a.sbn = x.data_ptr(), K, 1, w.data_ptr(), 1, K
     a.C, a.ldc, a.M, a.N, a.K, a.accumulate = y.data_ptr(), N, M, N, K, 0
+    a.alpha = 1.0
     a.bias = b.data_ptr() if b is not None else None
     a.relu = int(relu)
     a.residual = residual.data_ptr() if residual is not None else None
@@ -200,3 +207,110 @@ class NodeTrackBlock:
         add_(g_s1, g_y)
         g_a0, G[f"ipa_ln_{b}.weight"], G[f"ipa_ln_{b}.bias"] = layernorm_bwd(sv["a0"], self.p(f"ipa_ln_{b}.weight"), g_s1)
         return g_a0, G
+
+
+# ------------------------------------------------------------------------------------------------- IPA
+S_QK = 0.051031036307982884     # sqrt(1/(3*128))
+
+
+class IpaBlock:
+    """InvariantPointAttention of one trunk block (ipa_pytorch.py:316-484) as saved-activation forward (stand-alone forward
+    kernels) + backward (csrc/ipa_bwd.hip + batched fp32 GEMMs).  `W` as in NodeTrackBlock."""
+
+    def __init__(self, W, b, B, L, mask):
+        self.W, self.b, self.B, self.L, self.mask = W, b, B, L, mask
+        p = f"ipa_{b}."
+        self.names = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")
+        self.w_proj = torch.cat([W[p + n + ".weight"] for n in self.names], 0).contiguous()      # [3744,128]
+        self.b_proj = torch.cat([W[p + n + ".bias"] for n in self.names], 0).contiguous()
+
+    def forward(self, s, z, rot, trans):
+        """s [rows,128], z [B*L*L,64], rot [rows,9], trans [rows,3] -> ipa_embed (masked) [rows,128]."""
+        lib, B, L, W, p = _capi.load(), self.B, self.L, self.W, f"ipa_{self.b}."
+        rows = B * L
+        dev = s.device
+        proj = linear_fwd(s, self.w_proj, self.b_proj)
+        qp, kp, vp = torch.empty(rows, 192, device=dev), torch.empty(rows, 192, device=dev), torch.empty(rows, 288, device=dev)
+        pa = _capi.IpaPointsArgs()
+        pa.proj, pa.ldp, pa.rot, pa.trans, pa.qp, pa.kp, pa.vp, pa.rows = proj.data_ptr(), 3744, rot.data_ptr(), trans.data_ptr(), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), rows
+        _capi.check(lib.pf_ipa_points_fwd(C.byref(pa), _capi.stream_ptr()), "pf_ipa_points_fwd")
+        feats = torch.zeros(rows, 1536, device=dev)
+        ia = _capi.IpaAttnArgs()
+        ia.proj, ia.ldp, ia.qp, ia.kp, ia.vp, ia.z = proj.data_ptr(), 3744, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), z.data_ptr()
+        ia.rot, ia.trans, ia.mask = rot.data_ptr(), trans.data_ptr(), self.mask.data_ptr()
+        ia.w_b, ia.b_b, ia.w_dz, ia.b_dz = W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(), W[p + "down_z.weight"].data_ptr(), W[p + "down_z.bias"].data_ptr()
+        ia.head_w, ia.feats, ia.B, ia.L = W[p + "head_weights"].data_ptr(), feats.data_ptr(), B, L
+        _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
+        out = row_mask_(linear_fwd(feats, W[p + "linear_out.weight"], W[p + "linear_out.bias"]), self.mask)
+        self.saved = dict(s=s, z=z, rot=rot, trans=trans, proj=proj, qp=qp, kp=kp, vp=vp, feats=feats)
+        return out
+
+    def backward(self, g_out, g_z=None):
+        """g_out: gradient w.r.t. the masked IPA output.  g_z: optional buffer to accumulate d/dz into.
+        Returns (g_s, g_z, g_trans, g_rot, grads)."""
+        lib, B, L, W, p, sv = _capi.load(), self.B, self.L, self.W, f"ipa_{self.b}.", self.saved
+        rows, dev = B * L, g_out.device
+        G = {}
+        g = row_mask_(g_out.clone(), self.mask)
+        g_feats, G[p + "linear_out.weight"], G[p + "linear_out.bias"] = linear_bwd(sv["feats"], W[p + "linear_out.weight"], g)
+        e = lambda *shape: torch.empty(*shape, device=dev)
+        P, gA = e(B, 8, L, L), e(B, 8, L, L)
+        g_opt, g_frame, g_gam = e(rows, 288), e(rows, 12), e(rows, 8)
+        g_bias, g_pz = e(rows * L, 8), e(rows * L, 16)
+        acc_z = g_z is not None
+        if g_z is None:
+            g_z = e(rows * L, 64)
+        g_qp, g_kp, g_vp = e(rows, 192), e(rows, 192), e(rows, 288)
+        g_proj = e(rows, 3744)
+        a = _capi.IpaBwdArgs()
+        a.proj, a.ldp, a.qp, a.kp, a.vp, a.z = sv["proj"].data_ptr(), 3744, sv["qp"].data_ptr(), sv["kp"].data_ptr(), sv["vp"].data_ptr(), sv["z"].data_ptr()
+        a.rot, a.trans, a.mask = sv["rot"].data_ptr(), sv["trans"].data_ptr(), self.mask.data_ptr()
+        a.w_b, a.b_b, a.w_dz, a.b_dz = W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(), W[p + "down_z.weight"].data_ptr(), W[p + "down_z.bias"].data_ptr()
+        a.head_w, a.g_feats = W[p + "head_weights"].data_ptr(), g_feats.data_ptr()
+        a.P, a.gA, a.g_opt, a.g_frame_rows, a.g_gamma_rows = P.data_ptr(), gA.data_ptr(), g_opt.data_ptr(), g_frame.data_ptr(), g_gam.data_ptr()
+        a.g_bias, a.g_pz, a.g_z, a.accumulate_gz = g_bias.data_ptr(), g_pz.data_ptr(), g_z.data_ptr(), int(acc_z)
+        a.g_qp, a.g_kp, a.g_vp, a.g_proj, a.B, a.L = g_qp.data_ptr(), g_kp.data_ptr(), g_vp.data_ptr(), g_proj.data_ptr(), B, L
+        st = _capi.stream_ptr()
+        _capi.check(lib.pf_ipa_bwd_rows(C.byref(a), st), "pf_ipa_bwd_rows")
+        _capi.check(lib.pf_ipa_bwd_pairs(C.byref(a), st), "pf_ipa_bwd_pairs")
+        LL, ldp = L * L, 3744
+        bAh = (8 * LL, LL)                                  # gA / P slices: sample, head
+        # g_q[b,i,h,:] = s_qk gA[b,h] K[b,:,h,:]            (A: [L x L] row-major; B(k=j, n=c) = proj[(b,j), 1024 + 256 h + c])
+        _gemm(gA, L, 1, sv["proj"], ldp, 1, g_proj, L, 128, L, alpha=S_QK, ldc=ldp, b_off=1024, batch=(B, 8, bAh, (L * ldp, 256), (L * ldp, 128)))
+        # g_k[b,j,h,:] = s_qk gA[b,h]^T Q[b,:,h,:]
+        _gemm(gA, 1, L, sv["proj"], ldp, 1, g_proj, L, 128, L, alpha=S_QK, ldc=ldp, c_off=1024, batch=(B, 8, bAh, (L * ldp, 128), (L * ldp, 256)))
+        # g_v[b,j,h,:] = P[b,h]^T g_o[b,:,h,:]
+        _gemm(P, 1, L, g_feats, 1536, 1, g_proj, L, 128, L, ldc=ldp, c_off=1024 + 128, batch=(B, 8, bAh, (L * 1536, 128), (L * ldp, 256)))
+        # point contractions (global frame): gA KP, gA^T QP, P^T g_opt
+        _gemm(gA, L, 1, sv["kp"], 192, 1, g_qp, L, 24, L, ldc=192, batch=(B, 8, bAh, (L * 192, 24), (L * 192, 24)))
+        _gemm(gA, 1, L, sv["qp"], 192, 1, g_kp, L, 24, L, ldc=192, batch=(B, 8, bAh, (L * 192, 24), (L * 192, 24)))
+        _gemm(P, 1, L, g_opt, 288, 1, g_vp, L, 36, L, ldc=288, batch=(B, 8, bAh, (L * 288, 36), (L * 288, 36)))
+        _capi.check(lib.pf_ipa_bwd_points(C.byref(a), st), "pf_ipa_bwd_points")
+        # parameters of the pair projections: dW_b = g_bias^T z, dW_dz = g_pz^T z (K = pairs)
+        for nm, gb, n in (("linear_b", g_bias, 8), ("down_z", g_pz, 16)):
+            dW = e(n, 64)
+            _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L)
+            db = e(n)
+            _capi.check(lib.pf_colsum_f32(gb.data_ptr(), n, rows * L, n, db.data_ptr(), 0, st), "pf_colsum_f32")
+            G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
+        gg = e(8)
+        _capi.check(lib.pf_colsum_f32(g_gam.data_ptr(), 8, rows, 8, gg.data_ptr(), 0, st), "pf_colsum_f32")
+        ghw = e(8)
+        _capi.check(lib.pf_ipa_headw_bwd(gg.data_ptr(), W[p + "head_weights"].data_ptr(), ghw.data_ptr(), st), "pf_ipa_headw_bwd")
+        G[p + "head_weights"] = ghw
+        g_s, dWp, dbp = linear_bwd(sv["s"], self.w_proj, g_proj)
+        o = 0
+        for n in self.names:
+            k = W[p + n + ".weight"].shape[0]
+            G[p + n + ".weight"], G[p + n + ".bias"] = dWp[o:o + k], dbp[o:o + k]
+            o += k
+        return g_s, g_z, g_frame[:, :3].contiguous(), g_frame[:, 3:].contiguous(), G
+
+
+def quat_to_rot_bwd(quat, g_rot, g_quat=None):
+    acc = g_quat is not None
+    if g_quat is None:
+        g_quat = torch.empty(quat.shape[0], 4, device=quat.device)
+    _capi.check(_capi.load().pf_quat_to_rot_bwd(quat.data_ptr(), g_rot.data_ptr(), g_quat.data_ptr(), quat.shape[0], int(acc), _capi.stream_ptr()),
+                "pf_quat_to_rot_bwd")
+    return g_quat

@@ -19,6 +19,13 @@ constexpr int LDT = GK + 1;   // LDS row stride (floats) of a [64][GK] operand t
 __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
     __shared__ float As[GT * LDT];      // [m][k]
     __shared__ float Bs[GT * LDT];      // [n][k]
+    // batched form: blockIdx.z = z1 * batch2 + z2 selects the operand slices
+    {
+        const int z1 = blockIdx.z / (p.batch2 > 0 ? p.batch2 : 1), z2 = blockIdx.z - z1 * (p.batch2 > 0 ? p.batch2 : 1);
+        p.A += z1 * p.bsA1 + z2 * p.bsA2;
+        p.B += z1 * p.bsB1 + z2 * p.bsB2;
+        p.C += z1 * p.bsC1 + z2 * p.bsC2;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
                 const int m = m0 + wm + 16 * mt + 4 * g + e, n = n0 + wn + 16 * nt + r;
                 if (m < p.M && n < p.N) {
                     float* c = p.C + (size_t)m * p.ldc + n;
-                    float v = acc[mt][nt][e];
+                    float v = acc[mt][nt][e] * p.alpha;
                     if (p.bias) v += p.bias[n];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.residual) v += p.residual[(size_t)m * p.ldc + n];
@@ -275,7 +282,26 @@ __global__ __launch_bounds__(256) void rigid_update_bwd_kernel(pf_rigid_update_b
         for (int k = 0; k < 9; ++k) p.g_rot_in[(size_t)i * 9 + k] = gRo[k];
 }
 
+// g_quat (+)= (d quat_to_rot(q) / d q)^T g_rot : frames enter IPA as R = quat_to_rot(q) in blocks >= 1
+__global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gR[9], gq[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gR[k] = g_rot[(size_t)i * 9 + k];
+    rot_from_quat_bwd(quat[(size_t)i * 4], quat[(size_t)i * 4 + 1], quat[(size_t)i * 4 + 2], quat[(size_t)i * 4 + 3], gR, gq);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g_quat[(size_t)i * 4 + k] = gq[k] + (accumulate ? g_quat[(size_t)i * 4 + k] : 0.f);
+}
+
 }  // namespace
+
+extern "C" int pf_quat_to_rot_bwd(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate, pf_stream_t stream) {
+    if (!quat || !g_rot || !g_quat || n <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(quat_to_rot_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, quat, g_rot, g_quat, n, accumulate);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream) {
     if (!a || !a->quat_in || !a->rot_in || !a->upd || !a->mask || !a->g_rot_out || !a->g_trans_out || !a->g_upd || !a->g_quat_in ||
@@ -315,7 +341,8 @@ extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float*
 
 extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT)), dim3(256), 0,
+    const int nb = (a->batch1 > 0 ? a->batch1 : 1) * (a->batch2 > 0 ? a->batch2 : 1);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT), (unsigned)nb), dim3(256), 0,
                        (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;

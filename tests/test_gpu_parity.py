@@ -785,3 +785,39 @@ def test_node_track_block_backward_vs_reference(f4, f5, f6, seeded_sd):
     for k, gval in grads.items():
         ref = f6["_gradnorm"][pre + k]
         assert abs(gval.norm().item() - ref) <= 2 * REL * max(ref, 1e-6), (k, gval.norm().item(), ref)
+
+
+def test_ipa_block_backward_vs_reference(f4, f5, f6, seeded_sd):
+    """IPA of the LAST trunk block: saved-activation forward == oracle; backward seeded with the reference's d/d(IPA output)
+    reproduces the reference's d/d(pair tensor), d/d(frames) (together with the final backbone update) and the gradient norm
+    of every IPA parameter (golden F6)."""
+    from pepflowww_amd import backward as Bk
+    col, rows, mask = _last_block_inputs(f4, seeded_sd)
+    B, L = f5["node_final"].shape[:2]
+    pre = "ga_encoder.trunk."
+    W = {k[len(pre):]: cu(v) for k, v in seeded_sd.items() if k.startswith(pre) and ("_5." in k)}
+    blk = Bk.IpaBlock(W, 5, B, L, cu(mask))
+    s_in, z_in = col["s_4"].reshape(rows, 128) * mask[:, None], col["z_4"].reshape(rows * L, 64)
+    R_in, x_in = col["R_4"].reshape(rows, 9), col["x_4"].reshape(rows, 3)
+    out = blk.forward(cu(s_in), cu(z_in), cu(R_in), cu(x_in))
+    ref = col["ln_in_5"].reshape(rows, 128) - s_in                      # = ipa_embed * mask
+    G.assert_close(out, ref, 2e-5, "saved-activation IPA forward")
+    g_s, g_z, g_x, g_R, grads = blk.backward(cu(f6["d_ipa_out_5"].reshape(rows, 128)))
+    G.sync()
+    ok = mask > 0.5
+    okp = (ok.view(B, L)[:, :, None] & ok.view(B, L)[:, None, :]).reshape(-1)
+    G.assert_close(g_z.cpu()[okp], f6["d_z_in_5"].reshape(rows * L, 64)[okp], REL, "d z (block 5)")
+    for k, gval in grads.items():
+        refn = f6["_gradnorm"][pre + k]            # (linear_b.bias: exactly 0 by softmax shift invariance -> rounding noise)
+        assert abs(gval.norm().item() - refn) <= 2 * REL * refn + 2e-6, (k, gval.norm().item(), refn)
+    # frames entering block 5 feed its IPA and its backbone update
+    gu5, gq5, gx5, _ = Bk.rigid_update_bwd(cu(col["quat_in_5"].reshape(rows, 4)), cu(col["R_in_5"].reshape(rows, 9)), cu(col["upd_5"].reshape(rows, 6)),
+                                           cu(mask), cu(f5["d_pred_rot"].reshape(rows, 9)), cu(f5["d_pred_trans"].reshape(rows, 3)))
+    Bk.quat_to_rot_bwd(cu(col["quat_in_5"].reshape(rows, 4)), g_R, gq5)
+    Bk.add_(gx5, g_x)
+    G.assert_close(gx5.cpu()[ok], f6["d_trans_in_5"].reshape(rows, 3)[ok], REL, "d trans entering block 5")
+    # the quaternion of a frame is defined up to sign (rot -> quat in block 0 is an eigenvector, rigid_utils.py:208-227);
+    # d/dq flips with it, so rows are compared after aligning the sign
+    mine, refq = gq5.cpu()[ok], f6["d_quat_in_5"].reshape(rows, 4)[ok]
+    sgn = torch.sign((mine * refq).sum(-1, keepdim=True))
+    G.assert_close(mine * sgn, refq, REL, "d quat entering block 5")
