@@ -394,6 +394,11 @@ typedef struct {
     int n;
 } pf_rigid_update_bwd_args;
 int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream);
+/* EdgeTransition in unfused (saved-activation) form for the training path: x [B*L*L,192] = [z_ij | n_i | n_j]
+ * (ipa_pytorch.py:236-243), emask [B*L*L] = m_i m_j (optional); and the reverse scatter g_z (+)= g_x[:, :64],
+ * g_n [B*L,64] = sum_j g_x[(i,j),64:128] + sum_j g_x[(j,i),128:192]. */
+int pf_et_concat(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L, pf_stream_t stream);
+int pf_et_concat_bwd(const float* gx, float* gz, int accumulate_gz, float* gn, int B, int L, pf_stream_t stream);
 /* g_quat (+)= (d quat_to_rot(q)/dq)^T g_rot  (rigid_utils.py:185-205): rotation gradients of a block's IPA -> its quaternion */
 int pf_quat_to_rot_bwd(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate, pf_stream_t stream);
 

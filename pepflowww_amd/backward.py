@@ -314,3 +314,49 @@ def quat_to_rot_bwd(quat, g_rot, g_quat=None):
     _capi.check(_capi.load().pf_quat_to_rot_bwd(quat.data_ptr(), g_rot.data_ptr(), g_quat.data_ptr(), quat.shape[0], int(acc), _capi.stream_ptr()),
                 "pf_quat_to_rot_bwd")
     return g_quat
+
+
+# ------------------------------------------------------------------------------------------------- EdgeTransition
+class EdgeTransitionBlock:
+    """EdgeTransition of one trunk block (ipa_pytorch.py:233-248 + ga.py:118) in unfused, saved-activation form and its
+    backward (the inference path uses the fused persistent kernel instead)."""
+
+    def __init__(self, W, b, B, L, mask):
+        self.W, self.b, self.B, self.L, self.mask = W, b, B, L, mask
+
+    def forward(self, s, z):
+        lib, B, L, W, p = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}."
+        dev = s.device
+        n = linear_fwd(s, W[p + "initial_embed.weight"], W[p + "initial_embed.bias"])
+        x = torch.empty(B * L * L, 192, device=dev)
+        em = torch.empty(B * L * L, device=dev)
+        _capi.check(lib.pf_et_concat(z.data_ptr(), n.data_ptr(), self.mask.data_ptr(), x.data_ptr(), em.data_ptr(), B, L, _capi.stream_ptr()), "pf_et_concat")
+        h1 = linear_fwd(x, W[p + "trunk.0.weight"], W[p + "trunk.0.bias"], relu=True)
+        h2 = linear_fwd(h1, W[p + "trunk.2.weight"], W[p + "trunk.2.bias"], relu=True)
+        u = add_(h2.clone(), x)                                  # final_layer(h2 + x)
+        y = linear_fwd(u, W[p + "final_layer.weight"], W[p + "final_layer.bias"])
+        out = row_mask_(layernorm_fwd(y, W[p + "layer_norm.weight"], W[p + "layer_norm.bias"]), em)
+        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, u=u, y=y)
+        return out
+
+    def backward(self, g_out, g_z=None):
+        """g_out: gradient w.r.t. the masked output pair tensor.  Returns (g_s, g_z_in, grads); g_z given -> accumulated into."""
+        lib, B, L, W, p, sv = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}.", self.saved
+        G = {}
+        g = row_mask_(g_out.clone(), sv["em"])
+        g_y, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"] = layernorm_bwd(sv["y"], W[p + "layer_norm.weight"], g)
+        g_u, G[p + "final_layer.weight"], G[p + "final_layer.bias"] = linear_bwd(sv["u"], W[p + "final_layer.weight"], g_y)
+        g_h2 = g_u.clone()
+        g_x = g_u                                                # skip connection h2 + x
+        relu_bwd_(sv["h2"], g_h2)
+        g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2)
+        relu_bwd_(sv["h1"], g_h1)
+        g_x1, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1)
+        add_(g_x, g_x1)
+        acc = g_z is not None
+        if g_z is None:
+            g_z = torch.empty(B * L * L, 64, device=g_out.device)
+        g_n = torch.empty(B * L, 64, device=g_out.device)
+        _capi.check(lib.pf_et_concat_bwd(g_x.data_ptr(), g_z.data_ptr(), int(acc), g_n.data_ptr(), B, L, _capi.stream_ptr()), "pf_et_concat_bwd")
+        g_s, G[p + "initial_embed.weight"], G[p + "initial_embed.bias"] = linear_bwd(sv["s"], W[p + "initial_embed.weight"], g_n)
+        return g_s, g_z, G

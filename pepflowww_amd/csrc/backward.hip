@@ -282,6 +282,42 @@ __global__ __launch_bounds__(256) void rigid_update_bwd_kernel(pf_rigid_update_b
         for (int k = 0; k < 9; ++k) p.g_rot_in[(size_t)i * 9 + k] = gRo[k];
 }
 
+// EdgeTransition input x_ij = [z_ij | n_i | n_j] (ipa_pytorch.py:236-243) and the pair mask m_i m_j
+__global__ __launch_bounds__(256) void et_concat_kernel(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tot = (long long)B * L * L * 192;
+    if (idx >= tot) return;
+    const long long pair = idx / 192;
+    const int c = (int)(idx - pair * 192);
+    const int b = (int)(pair / ((long long)L * L));
+    const int rem = (int)(pair - (long long)b * L * L);
+    const int i = rem / L, j = rem - i * L;
+    x[idx] = c < 64 ? z[pair * 64 + c] : (c < 128 ? n[((size_t)b * L + i) * 64 + (c - 64)] : n[((size_t)b * L + j) * 64 + (c - 128)]);
+    if (c == 0 && emask) emask[pair] = mask[b * L + i] * mask[b * L + j];
+}
+// reverse: g_z = g_x[:, :64] (+= optional), g_n[b,i] = sum_j g_x[(i,j), 64:128] + sum_j' g_x[(j',i), 128:192]; one thread per (b,i,c)
+__global__ __launch_bounds__(256) void et_concat_bwd_kernel(const float* gx, float* gz, int accumulate_gz, float* gn, int B, int L) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npz = (long long)B * L * L * 64;
+    if (idx < npz) {
+        const long long pair = idx >> 6;
+        const int c = (int)(idx & 63);
+        gz[idx] = gx[pair * 192 + c] + (accumulate_gz ? gz[idx] : 0.f);
+    }
+    const long long nn = (long long)B * L * 64;
+    if (idx < nn) {
+        const int c = (int)(idx & 63);
+        const long long r = idx >> 6;
+        const int b = (int)(r / L), i = (int)(r - (long long)b * L);
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) {
+            acc += gx[(((size_t)b * L + i) * L + j) * 192 + 64 + c];
+            acc += gx[(((size_t)b * L + j) * L + i) * 192 + 128 + c];
+        }
+        gn[idx] = acc;
+    }
+}
+
 // g_quat (+)= (d quat_to_rot(q) / d q)^T g_rot : frames enter IPA as R = quat_to_rot(q) in blocks >= 1
 __global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -295,6 +331,21 @@ __global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat,
 }
 
 }  // namespace
+
+extern "C" int pf_et_concat(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L, pf_stream_t stream) {
+    if (!z || !n || !mask || !x || B <= 0 || L <= 0) return PF_E_BADARG;
+    const long long tot = (long long)B * L * L * 192;
+    hipLaunchKernelGGL(et_concat_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, n, mask, x, emask, B, L);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_et_concat_bwd(const float* gx, float* gz, int accumulate_gz, float* gn, int B, int L, pf_stream_t stream) {
+    if (!gx || !gz || !gn || B <= 0 || L <= 0) return PF_E_BADARG;
+    const long long tot = (long long)B * L * L * 64;
+    hipLaunchKernelGGL(et_concat_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gx, gz, accumulate_gz, gn, B, L);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pf_quat_to_rot_bwd(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate, pf_stream_t stream) {
     if (!quat || !g_rot || !g_quat || n <= 0) return PF_E_BADARG;

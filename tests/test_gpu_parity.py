@@ -821,3 +821,24 @@ def test_ipa_block_backward_vs_reference(f4, f5, f6, seeded_sd):
     mine, refq = gq5.cpu()[ok], f6["d_quat_in_5"].reshape(rows, 4)[ok]
     sgn = torch.sign((mine * refq).sum(-1, keepdim=True))
     G.assert_close(mine * sgn, refq, REL, "d quat entering block 5")
+
+
+def test_edge_transition_block_backward_vs_reference(f4, f5, f6, seeded_sd):
+    """EdgeTransition of block 4 (unfused training form): forward == oracle; backward seeded with the reference's
+    d/d(pair tensor entering block 5) reproduces the gradient norm of every EdgeTransition parameter (golden F6)."""
+    from pepflowww_amd import backward as Bk
+    col, rows, mask = _last_block_inputs(f4, seeded_sd)
+    B, L = f5["node_final"].shape[:2]
+    pre = "ga_encoder.trunk."
+    W = {k[len(pre):]: cu(v) for k, v in seeded_sd.items() if k.startswith(pre) and ("_4." in k)}
+    blk = Bk.EdgeTransitionBlock(W, 4, B, L, cu(mask))
+    s4 = col["s_4"].reshape(rows, 128) * mask[:, None]
+    z3 = col["z_3"].reshape(rows * L, 64)
+    out = blk.forward(cu(s4), cu(z3))
+    G.assert_close(out, col["z_4"].reshape(rows * L, 64), 2e-5, "unfused EdgeTransition forward")
+    g_s, g_z, grads = blk.backward(cu(f6["d_z_in_5"].reshape(rows * L, 64)))
+    G.sync()
+    for k, gval in grads.items():
+        refn = f6["_gradnorm"][pre + k]
+        assert abs(gval.norm().item() - refn) <= 2 * REL * refn + 2e-6, (k, gval.norm().item(), refn)
+    assert abs(g_z.norm().item() - 0) > 0 and torch.isfinite(g_z).all() and torch.isfinite(g_s).all()
