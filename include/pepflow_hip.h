@@ -394,6 +394,8 @@ typedef struct {
     int n;
 } pf_rigid_update_bwd_args;
 int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream);
+/* nn.Embedding backward: table_grad[c, :dim] = sum of g[r, :dim] (row stride ldg) over rows with idx[r] == c */
+int pf_embedding_bwd(const float* g, int ldg, const int64_t* idx, int rows, int ncls, int dim, float* table_grad, pf_stream_t stream);
 /* EdgeTransition in unfused (saved-activation) form for the training path: x [B*L*L,192] = [z_ij | n_i | n_j]
  * (ipa_pytorch.py:236-243), emask [B*L*L] = m_i m_j (optional); and the reverse scatter g_z (+)= g_x[:, :64],
  * g_n [B*L,64] = sum_j g_x[(i,j),64:128] + sum_j g_x[(j,i),128:192]. */

@@ -169,6 +169,7 @@ _SIGNATURES = {
     "pf_seq_attn_bwd": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_rigid_update_bwd": ([C.POINTER(RigidUpdateBwdArgs), _fp], _i),
     "pf_quat_to_rot_bwd": ([_fp, _fp, _fp, _i, _i, _fp], _i),
+    "pf_embedding_bwd": ([_fp, _i, _fp, _i, _i, _i, _fp, _fp], _i),
     "pf_et_concat": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_et_concat_bwd": ([_fp, _fp, _i, _fp, _i, _i, _fp], _i),
     "pf_ipa_bwd_rows": ([C.POINTER(IpaBwdArgs), _fp], _i),

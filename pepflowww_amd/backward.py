@@ -360,3 +360,127 @@ class EdgeTransitionBlock:
         _capi.check(lib.pf_et_concat_bwd(g_x.data_ptr(), g_z.data_ptr(), int(acc), g_n.data_ptr(), B, L, _capi.stream_ptr()), "pf_et_concat_bwd")
         g_s, G[p + "initial_embed.weight"], G[p + "initial_embed.bias"] = linear_bwd(sv["s"], W[p + "initial_embed.weight"], g_n)
         return g_s, g_z, G
+
+
+# ------------------------------------------------------------------------------------------------- whole trunk
+class TrunkTrainer:
+    """GAEncoder (ga.py:87-127) as a saved-activation forward and its full backward, assembled from the blocks above.
+    `sd`: {name relative to "ga_encoder." -> fp32 device tensor}.  forward() returns the four network outputs; backward()
+    takes their gradients (pf_train_losses_bwd) and returns ({parameter name: gradient}, d/d node_embed, d/d edge_embed)."""
+
+    N_BLOCKS = 6
+
+    def __init__(self, sd, B, L, res_mask):
+        self.sd, self.B, self.L = sd, B, L
+        self.mask = res_mask.reshape(-1).to(torch.float32).contiguous()
+        W = {k[len("trunk."):]: v for k, v in sd.items() if k.startswith("trunk.")}
+        self.ipa = [IpaBlock(W, b, B, L, self.mask) for b in range(self.N_BLOCKS)]
+        self.node = [NodeTrackBlock(W, b, B, L, self.mask) for b in range(self.N_BLOCKS)]
+        self.et = [EdgeTransitionBlock(W, b, B, L, self.mask) for b in range(self.N_BLOCKS - 1)]
+        self.W = W
+        import math
+        half = 64
+        dev = self.mask.device
+        self.time_freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(2056) / (half - 1))).to(dev)
+
+    def forward(self, t, rot_t, trans_t, ang_t, seq_t, node_embed, edge_embed):
+        lib, B, L, sd, st = _capi.load(), self.B, self.L, self.sd, _capi.stream_ptr()
+        rows, dev = B * L, self.mask.device
+        f32 = lambda x, *shape: x.to(torch.float32).reshape(*shape).contiguous()
+        feat = torch.zeros(rows, 640, device=dev)
+        ea = _capi.EmbedArgs()
+        self.seq_t = seq_t.reshape(rows).contiguous()
+        ne, tt, ang = f32(node_embed, rows, 128), f32(t, B), f32(ang_t, rows, 5)
+        ea.node_embed, ea.seq_table, ea.seqs = ne.data_ptr(), sd["current_seq_embedder.weight"].data_ptr(), self.seq_t.data_ptr()
+        ea.t, ea.time_freq, ea.ang_freq = tt.data_ptr(), self.time_freq.data_ptr(), sd["angles_embedder.freq_bands"].data_ptr()
+        ea.angles, ea.out, ea.B, ea.L = ang.data_ptr(), feat.data_ptr(), B, L
+        _capi.check(lib.pf_embed_inputs_fwd(C.byref(ea), st), "pf_embed_inputs_fwd")
+        self._keep = (ne, tt, ang)
+        # res_feat_mixer (ga.py:94-95): Linear(629,128) ReLU Linear(128,128), * mask
+        m1 = torch.empty(rows, 128, device=dev)
+        a = _capi.GemmArgs()
+        w0 = sd["res_feat_mixer.0.weight"]
+        a.A, a.sam, a.sak, a.B, a.sbk, a.sbn = feat.data_ptr(), 640, 1, w0.data_ptr(), 1, w0.shape[1]
+        a.C, a.ldc, a.M, a.N, a.K, a.alpha, a.relu = m1.data_ptr(), 128, rows, 128, w0.shape[1], 1.0, 1
+        a.bias = sd["res_feat_mixer.0.bias"].data_ptr()
+        _capi.check(lib.pf_gemm_f32(C.byref(a), st), "pf_gemm_f32")
+        s = row_mask_(linear_fwd(m1, sd["res_feat_mixer.2.weight"], sd["res_feat_mixer.2.bias"]), self.mask)
+        self.saved = dict(feat=feat, m1=m1, blocks=[])
+        z = f32(edge_embed, rows * L, 64)
+        R, x = f32(rot_t, rows, 9), f32(trans_t, rows, 3)
+        quat = torch.empty(rows, 4, device=dev)
+        _capi.check(lib.pf_rot_to_quat(R.data_ptr(), quat.data_ptr(), rows, st), "pf_rot_to_quat")
+        for b in range(self.N_BLOCKS):
+            ipa_out = self.ipa[b].forward(s, z, R, x)
+            a0 = add_(ipa_out.clone(), s)
+            s3 = self.node[b].forward(a0)
+            upd = linear_fwd(s3, self.W[f"bb_update_{b}.linear.weight"], self.W[f"bb_update_{b}.linear.bias"])
+            nq, nR, nx = torch.empty(rows, 4, device=dev), torch.empty(rows, 9, device=dev), torch.empty(rows, 3, device=dev)
+            ra = _capi.RigidUpdateArgs()
+            ra.quat_in, ra.rot_in, ra.trans_in, ra.upd, ra.ldu, ra.mask = quat.data_ptr(), R.data_ptr(), x.data_ptr(), upd.data_ptr(), 6, self.mask.data_ptr()
+            ra.quat_out, ra.rot_out, ra.trans_out, ra.n = nq.data_ptr(), nR.data_ptr(), nx.data_ptr(), rows
+            _capi.check(lib.pf_rigid_update_fwd(C.byref(ra), st), "pf_rigid_update_fwd")
+            self.saved["blocks"].append(dict(s3=s3, quat_in=quat, R_in=R, upd=upd))
+            quat, R, x = nq, nR, nx
+            s = s3
+            if b < self.N_BLOCKS - 1:
+                z = self.et[b].forward(s3, z)
+        self.saved["s_final"] = s
+        outs = []
+        for net in ("seq_net", "angle_net"):
+            h1 = linear_fwd(s, sd[f"{net}.0.weight"], sd[f"{net}.0.bias"], relu=True)
+            h2 = linear_fwd(h1, sd[f"{net}.2.weight"], sd[f"{net}.2.bias"], relu=True)
+            outs.append(linear_fwd(h2, sd[f"{net}.4.weight"], sd[f"{net}.4.bias"]))
+        return R, x, outs[1], outs[0]                      # pred_rot [rows,9], pred_trans, pred_ang_raw, pred_logits
+
+    def backward(self, g_rot, g_trans, g_ang, g_logits):
+        lib, B, L, sd, st = _capi.load(), self.B, self.L, self.sd, _capi.stream_ptr()
+        rows, dev = B * L, self.mask.device
+        G = {}
+        s = self.saved["s_final"]
+        g_s3 = None
+        for net, gout in (("seq_net", g_logits), ("angle_net", g_ang)):
+            ws = [sd[f"{net}.{i}.weight"] for i in (0, 2, 4)]
+            bs = [sd[f"{net}.{i}.bias"] for i in (0, 2, 4)]
+            dx, gr = mlp3_backward(s, ws, bs, gout)
+            for li, layer in enumerate((0, 2, 4)):
+                G[f"{net}.{layer}.weight"], G[f"{net}.{layer}.bias"] = gr[li]
+            g_s3 = dx if g_s3 is None else add_(g_s3, dx)
+        g_z = None            # gradient w.r.t. the pair tensor entering the block being processed + 1
+        g_q_next, g_x_next, g_R_next = None, g_trans, g_rot
+        for b in reversed(range(self.N_BLOCKS)):
+            blk = self.saved["blocks"][b]
+            g_upd, g_q_in, g_x_in, _ = rigid_update_bwd(blk["quat_in"], blk["R_in"], blk["upd"], self.mask, g_R_next, g_x_next,
+                                                        g_quat_out=g_q_next, rot_is_from_quat=(b > 0))
+            wbb = self.W[f"bb_update_{b}.linear.weight"]
+            dx, G[f"trunk.bb_update_{b}.linear.weight"], G[f"trunk.bb_update_{b}.linear.bias"] = linear_bwd(blk["s3"], wbb, g_upd)
+            add_(g_s3, dx)                                   # (s3 is already masked; bb_update sees s3 * mask)
+            if b < self.N_BLOCKS - 1:
+                g_s_et, g_z, Ge = self.et[b].backward(g_z)   # g_z in: d/d z_{b+1};  out: ET's share of d/d z_b
+                add_(g_s3, g_s_et)
+                G.update({"trunk." + k: v for k, v in Ge.items()})
+            g_a0, Gn = self.node[b].backward(g_s3)
+            G.update({"trunk." + k: v for k, v in Gn.items()})
+            g_s, g_z, g_x_ipa, g_R_ipa, Gi = self.ipa[b].backward(g_a0, g_z=g_z)
+            G.update({"trunk." + k: v for k, v in Gi.items()})
+            g_s3 = add_(g_s, g_a0)                           # d/d (node state entering block b)
+            g_q_next, g_x_next, g_R_next = g_q_in, add_(g_x_in, g_x_ipa), g_R_ipa
+        # res_feat_mixer
+        g = row_mask_(g_s3, self.mask)
+        g_m1, G["res_feat_mixer.2.weight"], G["res_feat_mixer.2.bias"] = linear_bwd(self.saved["m1"], sd["res_feat_mixer.2.weight"], g)
+        relu_bwd_(self.saved["m1"], g_m1)
+        w0 = sd["res_feat_mixer.0.weight"]
+        K = w0.shape[1]
+        feat = self.saved["feat"]
+        g_feat = torch.zeros(rows, 640, device=dev)
+        _gemm(g_m1, 128, 1, w0, K, 1, g_feat, rows, K, 128, ldc=640)
+        dW0 = torch.empty(128, K, device=dev)
+        _gemm(g_m1, 1, 128, feat, 640, 1, dW0, 128, K, rows)
+        db0 = torch.empty(128, device=dev)
+        _capi.check(lib.pf_colsum_f32(g_m1.data_ptr(), 128, rows, 128, db0.data_ptr(), 0, st), "pf_colsum_f32")
+        G["res_feat_mixer.0.weight"], G["res_feat_mixer.0.bias"] = dW0, db0
+        tg = torch.empty(22, 128, device=dev)
+        _capi.check(lib.pf_embedding_bwd(g_feat.data_ptr() + 4 * 128, 640, self.seq_t.data_ptr(), rows, 22, 128, tg.data_ptr(), st), "pf_embedding_bwd")
+        G["current_seq_embedder.weight"] = tg
+        g_node_embed = g_feat[:, :128].contiguous()
+        return G, g_node_embed, g_z

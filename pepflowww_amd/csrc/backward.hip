@@ -318,6 +318,18 @@ __global__ __launch_bounds__(256) void et_concat_bwd_kernel(const float* gx, flo
     }
 }
 
+// nn.Embedding backward: table_grad[c, d] = sum over rows r with idx[r] == c of g[r*ldg + d]; one thread per (c, d),
+// deterministic (rows in order)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* g, int ldg, const long long* idx, int rows, int ncls, int dim, float* tg) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ncls * dim) return;
+    const int c = t / dim, d = t - c * dim;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r)
+        if (idx[r] == c) acc += g[(size_t)r * ldg + d];
+    tg[t] = acc;
+}
+
 // g_quat (+)= (d quat_to_rot(q) / d q)^T g_rot : frames enter IPA as R = quat_to_rot(q) in blocks >= 1
 __global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -331,6 +343,14 @@ __global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat,
 }
 
 }  // namespace
+
+extern "C" int pf_embedding_bwd(const float* g, int ldg, const int64_t* idx, int rows, int ncls, int dim, float* table_grad, pf_stream_t stream) {
+    if (!g || !idx || !table_grad || rows <= 0 || ncls <= 0 || dim <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((ncls * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+                       reinterpret_cast<const long long*>(idx), rows, ncls, dim, table_grad);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pf_et_concat(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L, pf_stream_t stream) {
     if (!z || !n || !mask || !x || B <= 0 || L <= 0) return PF_E_BADARG;

@@ -842,3 +842,35 @@ def test_edge_transition_block_backward_vs_reference(f4, f5, f6, seeded_sd):
         refn = f6["_gradnorm"][pre + k]
         assert abs(gval.norm().item() - refn) <= 2 * REL * refn + 2e-6, (k, gval.norm().item(), refn)
     assert abs(g_z.norm().item() - 0) > 0 and torch.isfinite(g_z).all() and torch.isfinite(g_s).all()
+
+
+def test_trunk_backward_vs_reference(f4, f5, f6, seeded_sd):
+    """The whole GAEncoder backward: saved-activation forward on the reference's corrupted state == reference predictions;
+    backward seeded by pf_train_losses_bwd reproduces the reference's gradient norm of EVERY ga_encoder parameter and its
+    d/d(node state entering block 0..5), d/d(pair tensor entering block 1) (golden F5/F6)."""
+    from pepflowww_amd import backward as Bk
+    batch = _batch(f4)
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    enc = O.encode(seeded_sd, batch)
+    t, R_t, x_t, ang_t, seq_t = O.corrupt(batch, enc, noise)
+    B, L = seq_t.shape
+    rows = B * L
+    pre = "ga_encoder."
+    sd = {k[len(pre):]: cu(v) for k, v in seeded_sd.items() if k.startswith(pre)}
+    tr = Bk.TrunkTrainer(sd, B, L, cu(batch["res_mask"]))
+    pR, px, pang, plog = tr.forward(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t), cu(enc[4]), cu(enc[5]))
+    ok = batch["res_mask"].reshape(-1)
+    G.assert_close(pR.cpu()[ok], f5["pred_rot"].reshape(rows, 9)[ok], REL, "pred_rot")
+    G.assert_close(px.cpu()[ok], f5["pred_trans"].reshape(rows, 3)[ok], REL, "pred_trans")
+    G.assert_close(plog.cpu()[ok], f5["pred_logits"].reshape(rows, 20)[ok], REL, "pred_logits")
+    grads, g_node, g_edge = tr.backward(cu(f5["d_pred_rot"].reshape(rows, 9)), cu(f5["d_pred_trans"].reshape(rows, 3)),
+                                        cu(f5["d_pred_ang"].reshape(rows, 5)), cu(f5["d_pred_logits"].reshape(rows, 20)))
+    G.sync()
+    bad = []
+    for k, gval in grads.items():
+        refn = f6["_gradnorm"][pre + k]
+        if abs(gval.norm().item() - refn) > 3 * REL * refn + 2e-6:
+            bad.append((k, gval.norm().item(), refn))
+    assert not bad, bad[:8]
+    missing = [n for n in f6["_gradnorm"] if n.startswith(pre) and n[len(pre):] not in grads]
+    assert not missing, missing[:8]
