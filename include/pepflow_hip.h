@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 11
+#define PF_ABI_VERSION 12
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -268,6 +268,9 @@ typedef struct {
     float* out;                 /* [B,L,L,64] */
     int B, L;
     int sample_structure, sample_sequence;
+    /* optional (training path): intermediates the backward needs, per pair: Gaussian features [225], squared
+     * distances/100 [225], distance_embed.0 output [64], the 224-wide concat tile, out_mlp.0 / .2 outputs [64] */
+    float* dump_g; float* dump_d2; float* dump_h1; float* dump_cat; float* dump_o1; float* dump_o2;
 } pf_edge_feat_args;
 int pf_edge_features_fwd(const pf_edge_feat_args* a, pf_stream_t stream);
 
@@ -396,6 +399,19 @@ typedef struct {
 int pf_rigid_update_bwd(const pf_rigid_update_bwd_args* a, pf_stream_t stream);
 /* nn.Embedding backward: table_grad[c, :dim] = sum of g[r, :dim] (row stride ldg) over rows with idx[r] == c */
 int pf_embedding_bwd(const float* g, int ldg, const int64_t* idx, int rows, int ncls, int dim, float* table_grad, pf_stream_t stream);
+/* encoder backward helpers (node.py / edge.py): per-pair indices and masks of EdgeEmbedder.forward (aa-pair class, clamped
+ * relative position + 32, same-chain flag, structure-pair mask, residue-pair mask; aa_node = masked residue type per row),
+ * embedding-table gradient with atomics and an optional per-row scale, a masked column-slice copy, and the gradient of
+ * aapair_to_distcoef through exp(-softplus(w) d^2) (edge.py:83-89). */
+int pf_edge_index(const int64_t* aa, const int64_t* res_nb, const int64_t* chain_nb, const float* ctx, const float* mres,
+                  int sample_structure, int sample_sequence, int* aap, int* rel, float* same, float* sp, float* mp,
+                  int64_t* aa_node, int B, int L, pf_stream_t stream);
+int pf_embedding_bwd_atomic(const float* g, int ldg, const int* idx, const float* scale, long long rows, int dim, float* table_grad,
+                            pf_stream_t stream);
+int pf_slice_relu_mask(const float* src, int lds, int off, const float* ref, int ldr, int off_r, const float* rowscale, float* dst,
+                       long long rows, int width, pf_stream_t stream);
+int pf_edge_distcoef_bwd(const float* g_g, const float* gfeat, const float* d2, const int* aap, const float* w, long long pairs,
+                         float* table_grad, pf_stream_t stream);
 /* EdgeTransition in unfused (saved-activation) form for the training path: x [B*L*L,192] = [z_ij | n_i | n_j]
  * (ipa_pytorch.py:236-243), emask [B*L*L] = m_i m_j (optional); and the reverse scatter g_z (+)= g_x[:, :64],
  * g_n [B*L,64] = sum_j g_x[(i,j),64:128] + sum_j g_x[(j,i),128:192]. */

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -117,7 +117,8 @@ class EdgeFeatArgs(C.Structure):
                 ("mres", _fp), ("aapair_table", _fp), ("relpos_table", _fp), ("distcoef", _fp), ("freq3", _fp),
                 ("w_d0", _fp), ("b_d0", _fp), ("w_d2", _fp), ("b_d2", _fp), ("w_o0", _fp), ("b_o0", _fp),
                 ("w_o2", _fp), ("b_o2", _fp), ("w_o4", _fp), ("b_o4", _fp), ("out", _fp), ("B", _i), ("L", _i),
-                ("sample_structure", _i), ("sample_sequence", _i)]
+                ("sample_structure", _i), ("sample_sequence", _i),
+                ("dump_g", _fp), ("dump_d2", _fp), ("dump_h1", _fp), ("dump_cat", _fp), ("dump_o1", _fp), ("dump_o2", _fp)]
 
 
 class NodeHeadArgs(C.Structure):
@@ -170,6 +171,10 @@ _SIGNATURES = {
     "pf_rigid_update_bwd": ([C.POINTER(RigidUpdateBwdArgs), _fp], _i),
     "pf_quat_to_rot_bwd": ([_fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_embedding_bwd": ([_fp, _i, _fp, _i, _i, _i, _fp, _fp], _i),
+    "pf_edge_index": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
+    "pf_embedding_bwd_atomic": ([_fp, _i, _fp, _fp, C.c_longlong, _i, _fp, _fp], _i),
+    "pf_slice_relu_mask": ([_fp, _i, _i, _fp, _i, _i, _fp, _fp, C.c_longlong, _i, _fp], _i),
+    "pf_edge_distcoef_bwd": ([_fp, _fp, _fp, _fp, _fp, C.c_longlong, _fp, _fp], _i),
     "pf_et_concat": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_et_concat_bwd": ([_fp, _fp, _i, _fp, _i, _i, _fp], _i),
     "pf_ipa_bwd_rows": ([C.POINTER(IpaBwdArgs), _fp], _i),

@@ -484,3 +484,71 @@ class TrunkTrainer:
         G["current_seq_embedder.weight"] = tg
         g_node_embed = g_feat[:, :128].contiguous()
         return G, g_node_embed, g_z
+
+
+# ------------------------------------------------------------------------------------------------- encoder (node.py / edge.py)
+def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
+    """Backward of NodeEmbedder / EdgeEmbedder (flow_model.py:75-93) from d/d node_embed [rows,128], d/d edge_embed [pairs,64]
+    and the intermediates featurize.encode(..., save=saved) recorded.  model_sd: {full parameter name -> fp32 device tensor}.
+    Inputs of the encoder are data, so only parameter gradients are produced."""
+    lib, st = _capi.load(), _capi.stream_ptr()
+    rows, P = B * L, B * L * L
+    dev = g_node.device
+    G = {}
+    e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=dev)
+    aap, rel = e(P, dt=torch.int32), e(P, dt=torch.int32)
+    same, sp, mp = e(P), e(P), e(P)
+    aa_node = e(rows, dt=torch.int64)
+    _capi.check(lib.pf_edge_index(saved["aa"].data_ptr(), saved["res_nb"].data_ptr(), saved["chain_nb"].data_ptr(), saved["ctx"].data_ptr(),
+                                  saved["mres"].data_ptr(), saved["sample_structure"], saved["sample_sequence"], aap.data_ptr(), rel.data_ptr(),
+                                  same.data_ptr(), sp.data_ptr(), mp.data_ptr(), aa_node.data_ptr(), B, L, st), "pf_edge_index")
+    # ---- node embedder: MLP 1157 -> 256 -> 128 -> 128 -> 128, * mres
+    w = lambda k: model_sd[k]
+    g = row_mask_(g_node.clone(), saved["mres"])
+    g2, G["node_embedder.mlp.6.weight"], G["node_embedder.mlp.6.bias"] = linear_bwd(saved["n_h2"], w("node_embedder.mlp.6.weight"), g)
+    relu_bwd_(saved["n_h2"], g2)
+    g1, G["node_embedder.mlp.4.weight"], G["node_embedder.mlp.4.bias"] = linear_bwd(saved["n_h1"], w("node_embedder.mlp.4.weight"), g2)
+    relu_bwd_(saved["n_h1"], g1)
+    g0, G["node_embedder.mlp.2.weight"], G["node_embedder.mlp.2.bias"] = linear_bwd(saved["n_h0"], w("node_embedder.mlp.2.weight"), g1)
+    relu_bwd_(saved["n_h0"], g0)
+    w0 = w("node_embedder.mlp.0.weight")                        # [256,1157]; feat rows are 1168 wide
+    K = w0.shape[1]
+    g_feat = e(rows, 128)
+    _gemm(g0, 256, 1, w0, K, 1, g_feat, rows, 128, 256, ldc=128)              # only the aa-embedding columns are needed
+    dW0 = e(256, K)
+    _gemm(g0, 1, 256, saved["feat"], 1168, 1, dW0, 256, K, rows)
+    db0 = e(256)
+    _capi.check(lib.pf_colsum_f32(g0.data_ptr(), 256, rows, 256, db0.data_ptr(), 0, st), "pf_colsum_f32")
+    G["node_embedder.mlp.0.weight"], G["node_embedder.mlp.0.bias"] = dW0, db0
+    tg = e(22, 128)
+    _capi.check(lib.pf_embedding_bwd(g_feat.data_ptr(), 128, aa_node.data_ptr(), rows, 22, 128, tg.data_ptr(), st), "pf_embedding_bwd")
+    G["node_embedder.aatype_embed.weight"] = tg
+    # ---- edge embedder
+    ge = row_mask_(g_edge.clone(), mp)
+    g_o2, G["edge_embedder.out_mlp.4.weight"], G["edge_embedder.out_mlp.4.bias"] = linear_bwd(saved["o2"], w("edge_embedder.out_mlp.4.weight"), ge)
+    relu_bwd_(saved["o2"], g_o2)
+    g_o1, G["edge_embedder.out_mlp.2.weight"], G["edge_embedder.out_mlp.2.bias"] = linear_bwd(saved["o1"], w("edge_embedder.out_mlp.2.weight"), g_o2)
+    relu_bwd_(saved["o1"], g_o1)
+    wo0 = w("edge_embedder.out_mlp.0.weight")                   # [64,218]; the concat tile is 224 wide
+    g_cat = e(P, 224)
+    _gemm(g_o1, 64, 1, wo0, 218, 1, g_cat, P, 218, 64, ldc=224)
+    dWo0 = e(64, 218)
+    _gemm(g_o1, 1, 64, saved["cat"], 224, 1, dWo0, 64, 218, P)
+    dbo0 = e(64)
+    _capi.check(lib.pf_colsum_f32(g_o1.data_ptr(), 64, P, 64, dbo0.data_ptr(), 0, st), "pf_colsum_f32")
+    G["edge_embedder.out_mlp.0.weight"], G["edge_embedder.out_mlp.0.bias"] = dWo0, dbo0
+    t_aap, t_rel = torch.zeros(484, 64, device=dev), torch.zeros(65, 64, device=dev)
+    _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr(), 224, aap.data_ptr(), None, P, 64, t_aap.data_ptr(), st), "pf_embedding_bwd_atomic")
+    _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr() + 4 * 64, 224, rel.data_ptr(), same.data_ptr(), P, 64, t_rel.data_ptr(), st), "pf_embedding_bwd_atomic")
+    G["edge_embedder.aa_pair_embed.weight"], G["edge_embedder.relpos_embed.weight"] = t_aap, t_rel
+    g_fd = e(P, 64)
+    _capi.check(lib.pf_slice_relu_mask(g_cat.data_ptr(), 224, 128, saved["cat"].data_ptr(), 224, 128, sp.data_ptr(), g_fd.data_ptr(), P, 64, st),
+                "pf_slice_relu_mask")
+    g_h1, G["edge_embedder.distance_embed.2.weight"], G["edge_embedder.distance_embed.2.bias"] = linear_bwd(saved["h1"], w("edge_embedder.distance_embed.2.weight"), g_fd)
+    relu_bwd_(saved["h1"], g_h1)
+    g_g, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], w("edge_embedder.distance_embed.0.weight"), g_h1)
+    t_c = torch.zeros(484, 225, device=dev)
+    _capi.check(lib.pf_edge_distcoef_bwd(g_g.data_ptr(), saved["g"].data_ptr(), saved["d2"].data_ptr(), aap.data_ptr(),
+                                         w("edge_embedder.aapair_to_distcoef.weight").data_ptr(), P, t_c.data_ptr(), st), "pf_edge_distcoef_bwd")
+    G["edge_embedder.aapair_to_distcoef.weight"] = t_c
+    return G

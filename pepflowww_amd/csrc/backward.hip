@@ -330,6 +330,62 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* g, int 
     tg[t] = acc;
 }
 
+// ---- encoder (node.py / edge.py) backward helpers --------------------------------------------------------------
+// per-pair indices / masks of EdgeEmbedder.forward (edge.py:44-60,101-110), same rules as pf_edge_features_fwd
+__global__ __launch_bounds__(256) void edge_index_kernel(const long long* aa, const long long* res_nb, const long long* chain_nb,
+                                                         const float* ctx, const float* mres, int sample_structure, int sample_sequence,
+                                                         int* aap, int* rel, float* same, float* sp, float* mp, long long* aa_node,
+                                                         int B, int L) {
+    const long long pair = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long np = (long long)B * L * L;
+    if (pair >= np) return;
+    const int b = (int)(pair / ((long long)L * L));
+    const int rem = (int)(pair - (long long)b * L * L);
+    const int pi = b * L + rem / L, pj = b * L + rem % L;
+    auto aa_of = [&](int r) {
+        long long v = aa[r];
+        if (sample_sequence && ctx[r] < 0.5f) v = 20;         // AA_UNK
+        return (int)(v < 0 ? 0 : (v > 21 ? 21 : v));
+    };
+    aap[pair] = aa_of(pi) * 22 + aa_of(pj);
+    const long long d = res_nb[pi] - res_nb[pj];
+    rel[pair] = (int)(d < -32 ? -32 : (d > 32 ? 32 : d)) + 32;
+    same[pair] = chain_nb[pi] == chain_nb[pj] ? 1.f : 0.f;
+    sp[pair] = sample_structure ? ctx[pi] * ctx[pj] : 1.f;
+    mp[pair] = mres[pi] * mres[pj];
+    if (rem % L == 0 && aa_node) aa_node[pi] = aa_of(pi);
+}
+// table_grad[idx[r], :dim] += scale[r] * g[r, :dim]  (atomics: large row counts; table_grad zeroed by the caller)
+__global__ __launch_bounds__(256) void embedding_bwd_atomic_kernel(const float* g, int ldg, const int* idx, const float* scale, long long rows,
+                                                                   int dim, float* tg) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * dim) return;
+    const long long r = t / dim;
+    const int d = (int)(t - r * dim);
+    const float v = g[r * ldg + d] * (scale ? scale[r] : 1.f);
+    if (v != 0.f) atomicAdd(tg + (size_t)idx[r] * dim + d, v);
+}
+// dst[p, c] = src[p*lds + off + c] * rowscale[p] * (ref[p*ldr + off_r + c] > 0)
+__global__ __launch_bounds__(256) void slice_relu_mask_kernel(const float* src, int lds_, int off, const float* ref, int ldr, int off_r,
+                                                              const float* rowscale, float* dst, long long rows, int width) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * width) return;
+    const long long p = t / width;
+    const int c = (int)(t - p * width);
+    dst[t] = ref[p * ldr + off_r + c] > 0.f ? src[p * lds_ + off + c] * rowscale[p] : 0.f;
+}
+// Gaussian distance features g = exp(-softplus(w[aap]) d2) * atom-mask (edge.py:83-89): d/dw[aap, e] += g_g * g * (-d2) * sigmoid(w)
+__global__ __launch_bounds__(256) void edge_distcoef_bwd_kernel(const float* g_g, const float* gfeat, const float* d2, const int* aap,
+                                                                const float* w, long long pairs, float* tg) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pairs * 225) return;
+    const long long p = t / 225;
+    const int e = (int)(t - p * 225);
+    const size_t wi = (size_t)aap[p] * 225 + e;
+    const float v = g_g[t] * gfeat[t] * (-d2[t]) / (1.f + expf(-w[wi]));
+    if (v != 0.f) atomicAdd(tg + wi, v);
+}
+
 // g_quat (+)= (d quat_to_rot(q) / d q)^T g_rot : frames enter IPA as R = quat_to_rot(q) in blocks >= 1
 __global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat, const float* g_rot, float* g_quat, int n, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -348,6 +404,42 @@ extern "C" int pf_embedding_bwd(const float* g, int ldg, const int64_t* idx, int
     if (!g || !idx || !table_grad || rows <= 0 || ncls <= 0 || dim <= 0) return PF_E_BADARG;
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((ncls * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg,
                        reinterpret_cast<const long long*>(idx), rows, ncls, dim, table_grad);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_edge_index(const int64_t* aa, const int64_t* res_nb, const int64_t* chain_nb, const float* ctx, const float* mres,
+                             int sample_structure, int sample_sequence, int* aap, int* rel, float* same, float* sp, float* mp,
+                             int64_t* aa_node, int B, int L, pf_stream_t stream) {
+    if (!aa || !res_nb || !chain_nb || !ctx || !mres || !aap || !rel || !same || !sp || !mp || B <= 0 || L <= 0) return PF_E_BADARG;
+    const long long np = (long long)B * L * L;
+    hipLaunchKernelGGL(edge_index_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(aa), reinterpret_cast<const long long*>(res_nb), reinterpret_cast<const long long*>(chain_nb),
+                       ctx, mres, sample_structure, sample_sequence, aap, rel, same, sp, mp, reinterpret_cast<long long*>(aa_node), B, L);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_embedding_bwd_atomic(const float* g, int ldg, const int* idx, const float* scale, long long rows, int dim, float* table_grad,
+                                       pf_stream_t stream) {
+    if (!g || !idx || !table_grad || rows <= 0 || dim <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(embedding_bwd_atomic_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, idx, scale,
+                       rows, dim, table_grad);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_slice_relu_mask(const float* src, int lds_, int off, const float* ref, int ldr, int off_r, const float* rowscale, float* dst,
+                                  long long rows, int width, pf_stream_t stream) {
+    if (!src || !ref || !rowscale || !dst || rows <= 0 || width <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(slice_relu_mask_kernel, dim3((unsigned)((rows * width + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds_, off, ref,
+                       ldr, off_r, rowscale, dst, rows, width);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_edge_distcoef_bwd(const float* g_g, const float* gfeat, const float* d2, const int* aap, const float* w, long long pairs,
+                                    float* table_grad, pf_stream_t stream) {
+    if (!g_g || !gfeat || !d2 || !aap || !w || !table_grad || pairs <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(edge_distcoef_bwd_kernel, dim3((unsigned)((pairs * 225 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_g, gfeat, d2, aap,
+                       w, pairs, table_grad);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -176,6 +176,14 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
     const int aap = aa_of(pi) * 22 + aa_of(pj);
     const float spair = a.sample_structure ? a.ctx[pi] * a.ctx[pj] : 1.f;
 
+    // training path: optional dumps of the intermediates the backward needs (whole LDS tiles, cooperative copy)
+    auto dump_tile = [&](float* dst, const float* tile, int ld, int width, int dst_ld) {
+        if (!dst) return;
+        for (int idx = tid; idx < EP * width; idx += 256) {
+            const int row = idx / width, c = idx - row * width;
+            if (p0 + row < npairs) dst[(p0 + row) * dst_ld + c] = tile[row * ld + c];
+        }
+    };
     // ---- phase 1: Gaussian atom-pair distances (edge.py:83-89) ----
     {
         const float* posi = a.pos + (size_t)pi * A * 3;
@@ -191,11 +199,13 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
                 const float d = sqrtf((dx * dx + dy * dy) + dz * dz) / 10.f;
                 const float c = softplus_t(coef[e]);
                 v = expf((-1.f * c) * (d * d)) * (mi[ai] * mj[bj]);
+                if (a.dump_d2 && pok) a.dump_d2[(p0 + prow) * 225 + e] = d * d;
             }
             Ft[prow * LDF + e] = v;
         }
     }
     __syncthreads();
+    dump_tile(a.dump_g, Ft, LDF, 225, 225);
 
     // ---- GEMM1: distance_embed.0 (225 -> 64) + ReLU ----
     {
@@ -210,6 +220,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();      // Ft fully consumed, H1 complete
+    dump_tile(a.dump_h1, H1, LDH, 64, 64);
 
     // ---- phase 2: concat tile [aa-pair 64 | relpos 64 | (dist, filled by GEMM2) 64 | dihedral code 26 | 0 x 6] ----
     {
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             }
     }
     __syncthreads();
+    dump_tile(a.dump_cat, Ft, LDF, 224, 224);
 
     // ---- GEMM3..5: out_mlp (218 -> 64 -> 64 -> 64) ----
     {
@@ -269,6 +281,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();
+    dump_tile(a.dump_o1, H1, LDH, 64, 64);
     {
         f32x4 acc[4][1];
         acc_zero<4, 1>(acc);
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             for (int e = 0; e < 4; ++e) H2[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();
+    dump_tile(a.dump_o2, H2, LDH, 64, 64);
     {
         f32x4 acc[4][1];
         acc_zero<4, 1>(acc);

@@ -874,3 +874,40 @@ def test_trunk_backward_vs_reference(f4, f5, f6, seeded_sd):
     assert not bad, bad[:8]
     missing = [n for n in f6["_gradnorm"] if n.startswith(pre) and n[len(pre):] not in grads]
     assert not missing, missing[:8]
+
+
+def test_full_training_backward_vs_reference(f4, f5, f6, model, seeded_sd):
+    """The complete training step forward + backward on the device: encode (with saved intermediates) -> corruption ->
+    saved-activation trunk forward -> six losses -> loss / trunk / encoder backward.  The gradient norm of EVERY one of the
+    407 parameters of the model matches the reference's autograd (train.py:121,133; golden F6)."""
+    from pepflowww_amd import backward as Bk, featurize
+    batch = _batch(f4)
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    dbatch = _to_dev(batch)
+    B, L = batch["aa"].shape
+    rows = B * L
+    saved = {}
+    R1, x1, ang1, seq1, node, edge = featurize.encode(model, dbatch, save=saved)
+    _, tf = model(dbatch, noise=noise, return_state=True)            # corruption state + loss buffers (inference kernels)
+    eng = tf.eng
+    sd_dev = {k: cu(v) for k, v in seeded_sd.items()}
+    tr = Bk.TrunkTrainer({k[len("ga_encoder."):]: v for k, v in sd_dev.items() if k.startswith("ga_encoder.")}, B, L, dbatch["res_mask"])
+    pR, px, pang, plog = tr.forward(eng.t, eng.rot_t, eng.trans_t, eng.ang_t, eng.seq_t, node, edge)
+    # hand the training forward's predictions to the loss kernels, then seed the backward
+    eng.rot.copy_(pR); eng.trans.copy_(px); eng.ang_raw.copy_(pang); eng.logits.copy_(plog)
+    losses = tf.compute_losses()
+    for k, v in losses.items():
+        assert abs(v.item() - f4["loss_" + k].item()) <= REL * abs(f4["loss_" + k].item()), k
+    g = tf.loss_grads(O.LOSS_WEIGHTS)
+    grads, g_node, g_edge = tr.backward(g["d_rot"], g["d_trans"], g["d_ang"], g["d_logits"])
+    grads = {"ga_encoder." + k: v for k, v in grads.items()}
+    grads.update(Bk.encoder_backward(sd_dev, saved, g_node, g_edge, B, L))
+    G.sync()
+    bad = []
+    for name, refn in f6["_gradnorm"].items():
+        if name not in grads:
+            bad.append((name, "missing"))
+        elif abs(grads[name].norm().item() - refn) > 3 * REL * refn + 2e-6:
+            bad.append((name, grads[name].norm().item(), refn))
+    assert not bad, (len(bad), bad[:8])
+    assert len(grads) == len(f6["_gradnorm"]) == 407
