@@ -32,12 +32,20 @@ class FlowModel(nn.Module):
         _capi.dptr(batch["pos_heavyatom"].contiguous(), name="batch['pos_heavyatom']")
         return featurize.encode(self, batch)
 
-    # ---- flow_model.py:111-227 (forward only) ----
-    @torch.no_grad()
+    # ---- flow_model.py:111-227 ----
     def forward(self, batch, *, noise=None, seed=None, first_sample=0, return_state=False):
-        """Six training losses of one noisy denoise pass, as 0-dim device tensors WITHOUT autograd
-        (the backward kernels are the next scope row; `loss.backward()` raises on these tensors).
+        """Six training losses of one noisy denoise pass as 0-dim device tensors.
+        In train() mode with autograd enabled (the training loop: `sum_weighted_losses(model(batch), w).backward()`, train.py:121,133) the
+        losses carry an autograd node whose backward is the hand-written HIP backward (pepflowww_amd/train_step.py); under
+        eval() / torch.no_grad() / return_state=True the forward-only inference kernels are used.
         noise: dict(t [B,1], rot0, trans0, ang0, simplex0[, expo [2,B,L,20]]) to replay draws."""
+        if self.training and torch.is_grad_enabled() and not return_state:
+            from .train_step import training_forward
+            return training_forward(self, batch, noise=noise, seed=seed, first_sample=first_sample)
+        with torch.no_grad():
+            return self._forward_nograd(batch, noise=noise, seed=seed, first_sample=first_sample, return_state=return_state)
+
+    def _forward_nograd(self, batch, *, noise=None, seed=None, first_sample=0, return_state=False):
         _capi.load()
         dev = batch["aa"].device
         B, L = batch["aa"].shape

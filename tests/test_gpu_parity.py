@@ -911,3 +911,60 @@ def test_full_training_backward_vs_reference(f4, f5, f6, model, seeded_sd):
             bad.append((name, grads[name].norm().item(), refn))
     assert not bad, (len(bad), bad[:8])
     assert len(grads) == len(f6["_gradnorm"]) == 407
+
+
+def test_training_step_through_autograd(f4, f6, seeded_sd):
+    """The reference's training-loop code runs unchanged: model.train(); loss = sum_weighted(model(batch)); loss.backward()
+    (train.py:117-145) -> .grad of all 407 parameters with the reference's norms; an SGD step on them lowers the loss."""
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.to(G.dev()).train()
+    batch = _to_dev(_batch(f4))
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    w = O.LOSS_WEIGHTS
+
+    def total():
+        ld = m(batch, noise=noise)
+        assert list(ld) == ["trans_loss", "rot_loss", "bb_atom_loss", "seqs_loss", "angle_loss", "torsion_loss"]
+        return sum(w[k] * v for k, v in ld.items()), ld
+    loss, ld = total()
+    for k, v in ld.items():
+        assert v.requires_grad and abs(v.item() - f4["loss_" + k].item()) <= REL * abs(f4["loss_" + k].item()), k
+    loss.backward()
+    bad = []
+    for name, p in m.named_parameters():
+        refn = f6["_gradnorm"][name]
+        if p.grad is None or p.grad.shape != p.shape or abs(p.grad.norm().item() - refn) > 3 * REL * refn + 2e-6:
+            bad.append((name, None if p.grad is None else p.grad.norm().item(), refn))
+    assert not bad, (len(bad), bad[:6])
+    gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9)
+    l0 = loss.item()
+    with torch.no_grad():
+        for p in m.parameters():
+            p -= (1e-3 / gn) * p.grad                       # a small step along -grad
+    l1 = total()[0].item()
+    assert l1 < l0, (l0, l1)
+
+
+def test_training_gradients_are_shard_additive(seeded_sd):
+    """Data-parallel training: per-sample losses are averaged over the batch, so the gradient of the full
+    batch equals the mean of the gradients of its equal shards -- what the gradient all-reduce relies on."""
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.to(G.dev()).train()
+    B, L = 4, 32
+    batch = synth.make_pocket_batch(B, L, 6, seed=21)
+    nz = synth.make_noise(B, L, 1, seed=8)
+    noise = {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(2)), **{k: nz[k] for k in ("trans0", "rot0", "ang0", "simplex0")},
+             "expo": nz["expo"][:2]}
+    w = O.LOSS_WEIGHTS
+
+    def grads(lo, hi):
+        m.zero_grad(set_to_none=True)
+        sh = {k: v[lo:hi] for k, v in batch.items()}
+        ns = {k: (v[:, lo:hi] if k == "expo" else v[lo:hi]) for k, v in noise.items()}
+        sum(w[k] * v for k, v in m(_to_dev(sh), noise=ns).items()).backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    full = grads(0, 4)
+    mean = 0.5 * (grads(0, 2) + grads(2, 4))
+    G.assert_close(mean, full, 5 * REL, "mean of shard gradients == full-batch gradient")
