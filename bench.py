@@ -29,7 +29,10 @@ WORKLOADS = {
     "cfg2": dict(B=16, L=64, n_gen=12, name="cfg2: B=16 x 64-residue synthetic pockets (52 ctx + 12 gen) per GPU, fp32"),
     # BASELINE.json configs[3] per-GPU share: 64 x 128-residue pockets (112 + 16)
     "cfg4": dict(B=64, L=128, n_gen=16, name="cfg4/GPU: B=64 x 128-residue synthetic pockets (112 ctx + 16 gen) per GPU, fp32"),
+    # BASELINE.json configs[4] per-GPU share: train_ddp-equivalent step (forward + 6 losses + backward [+ gradient all-reduce])
+    "cfg5": dict(B=16, L=128, n_gen=16, name="cfg5/GPU: training step on B=16 x 128-residue synthetic pockets per GPU, fp32", train=True),
 }
+TRAIN_FLOPS_PER_RES = 3 * 129.2e6   # forward 129.2 MFLOP per residue at L=128, backward ~2x forward
 HBM_PEAK = 8.0e12            # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 MFMA_F32_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
 MFMA_F16_PEAK = 2.5e15       # FLOP/s dense f16/bf16 MFMA (MI355X_MICROARCH.md; 2:1-sparse marketing figure excluded)
@@ -79,6 +82,8 @@ def main():
     B, L = wl["B"], wl["L"]
     K, W = args.steps, args.warmup
     NS = K + W
+    if wl.get("train"):
+        return bench_train(args, wl, dev, dist, rank, world)
     sd = synth.seeded_state_dict()
     model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
     model.load_state_dict(sd)
@@ -177,6 +182,60 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, batch, B, L)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_train(args, wl, dev, dist, rank, world):
+    """cfg5: one training step = model(batch) -> weighted loss -> backward (HIP backward kernels) -> for N > 1 one flat
+    gradient all-reduce (RCCL).  Correctness-first backward (fp32 GEMM building blocks): reported as measured."""
+    import pepflowww_amd
+    from pepflowww_amd import synth
+    from pepflowww_amd.distributed import allreduce_gradients
+    B, L, K, W = wl["B"], wl["L"], args.steps, args.warmup
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    model.load_state_dict(synth.seeded_state_dict())
+    model = model.to(dev).train()
+    first = rank * B
+    batch = {k: v.to(dev) for k, v in synth.make_pocket_batch(B, L, wl["n_gen"], seed=114514 + first).items()}
+    wts = {"trans_loss": 0.5, "rot_loss": 0.5, "bb_atom_loss": 0.25, "seqs_loss": 1.0, "angle_loss": 1.0, "torsion_loss": 0.5}
+    gen = torch.Generator().manual_seed(1234 + rank)
+
+    def step():
+        from pepflowww_amd.train_forward import default_train_noise
+        model.zero_grad(set_to_none=True)
+        losses = model(batch, noise=default_train_noise(B, L, gen), seed=20240227, first_sample=first)
+        sum(wts[k] * v for k, v in losses.items()).backward()
+        allreduce_gradients(model.parameters(), dist)
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = world * B * L * K / elapsed
+    out = {"metric": "residues x training-steps / s (forward + 6 losses + backward + gradient all-reduce)", "value": value,
+           "unit": "res*step/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random pockets, seeded random-init weights)",
+           "config": {"workload": wl["name"], "per_gpu_batch": B, "residues": L, "global_batch": world * B,
+                      "parallelism": f"data-parallel x{world}, one flat gradient all-reduce (27.5 MB)"},
+           "roofline": {"kernel": "whole training step", "bound": "mfma", "achieved": value / world * TRAIN_FLOPS_PER_RES / 1e12,
+                        "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": value / world * TRAIN_FLOPS_PER_RES / MFMA_F32_PEAK,
+                        "traffic": None, "note": "correctness-first fp32 backward; flops = 3 x forward (SURVEY.md 8(d))"}}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -94,3 +94,26 @@ def sample_sharded(model, batch, num_steps=100, *, noise=None, seed=0, group=Non
     nz = shard_noise(noise, lo, hi) if noise is not None else None
     smp = model.sample(local, num_steps, noise=nz, seed=seed, first_sample=lo, return_sampler=True, **kw)
     return all_gather_final_state(smp, group)
+
+
+def allreduce_gradients(parameters, dist=None):
+    """Data-parallel training step (train_ddp.py:94 wraps the model in DDP): average the gradients of the
+    replicas with ONE all-reduce over a flat fp32 bucket (6.88 M parameters = 27.5 MB; on the xGMI mesh one large
+    collective beats per-tensor ones).  Works on any backend (RCCL on the GPU box, gloo in the CPU tests).
+    Returns the number of elements reduced."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return 0
+    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+    o = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
+    return o

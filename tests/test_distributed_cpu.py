@@ -82,3 +82,35 @@ def test_ragged_all_gather_gloo_world2(total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pepflowww_amd.distributed import allreduce_gradients
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
+    for i, p in enumerate(ps[:2]):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    n = allreduce_gradients(ps, dist)                     # the third parameter has no gradient and is skipped
+    q.put((rank, n, [p.grad.clone() if p.grad is not None else None for p in ps]))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks():
+    """One flat-bucket all-reduce averages the replicas' gradients (train_ddp.py:94 equivalent), gloo, world size 2."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    for rank, n, grads in res:
+        assert n == 15 + 7
+        assert torch.allclose(grads[0], torch.full((3, 5), 1.5)) and torch.allclose(grads[1], torch.full((7,), 3.0))
+        assert grads[2] is None
