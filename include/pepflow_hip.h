@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 12
+#define PF_ABI_VERSION 13
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -370,6 +370,7 @@ typedef struct {
     /* optional two-level batching (e.g. sample x head): slice (z1, z2) uses A + z1*bsA1 + z2*bsA2 etc.; 0 = no batching */
     int batch1, batch2;
     long long bsA1, bsA2, bsB1, bsB2, bsC1, bsC2;
+    int ksplit;                    /* internal (set by the launcher): split-K factor for long-K, few-tile products */
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */

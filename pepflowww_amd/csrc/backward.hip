@@ -20,7 +20,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
     __shared__ float As[GT * LDT];      // [m][k]
     __shared__ float Bs[GT * LDT];      // [n][k]
     // batched form: blockIdx.z = z1 * batch2 + z2 selects the operand slices
-    {
+    int kbeg = 0, kend = p.K;
+    if (p.ksplit > 1) {                 // split-K (no batching in this mode): this workgroup owns K range [kbeg, kend), atomicAdd into C
+        const int per = ((p.K + p.ksplit - 1) / p.ksplit + GK - 1) / GK * GK;
+        kbeg = blockIdx.z * per;
+        kend = min(p.K, kbeg + per);
+        if (kbeg >= kend) return;
+    } else {
         const int z1 = blockIdx.z / (p.batch2 > 0 ? p.batch2 : 1), z2 = blockIdx.z - z1 * (p.batch2 > 0 ? p.batch2 : 1);
         p.A += z1 * p.bsA1 + z2 * p.bsA2;
         p.B += z1 * p.bsB1 + z2 * p.bsB2;
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     f32x4 acc[2][2];
     acc_zero<2, 2>(acc);
-    for (int k0 = 0; k0 < p.K; k0 += GK) {
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
         // stage: 64 x 32 elements of each operand, 8 per thread; the fastest-varying thread index follows the
         // unit-stride dimension of the operand so that the global reads coalesce in either layout
         for (int q = 0; q < 8; ++q) {
@@ -41,13 +47,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
             if (p.sak == 1) { kk = idx & (GK - 1); mm = idx >> 5; } else { mm = idx & (GT - 1); kk = idx >> 6; }
             const int m = m0 + mm, k = k0 + kk;
             float v = 0.f;
-            if (m < p.M && k < p.K) v = p.A[(size_t)m * p.sam + (size_t)k * p.sak];
+            if (m < p.M && k < kend) v = p.A[(size_t)m * p.sam + (size_t)k * p.sak];
             As[mm * LDT + kk] = v;
             int nn, kb;
             if (p.sbk == 1) { kb = idx & (GK - 1); nn = idx >> 5; } else { nn = idx & (GT - 1); kb = idx >> 6; }
             const int n = n0 + nn, k2 = k0 + kb;
             float w = 0.f;
-            if (n < p.N && k2 < p.K) w = p.B[(size_t)k2 * p.sbk + (size_t)n * p.sbn];
+            if (n < p.N && k2 < kend) w = p.B[(size_t)k2 * p.sbk + (size_t)n * p.sbn];
             Bs[nn * LDT + kb] = w;
         }
         __syncthreads();
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
                 if (m < p.M && n < p.N) {
                     float* c = p.C + (size_t)m * p.ldc + n;
                     float v = acc[mt][nt][e] * p.alpha;
+                    if (p.ksplit > 1) { atomicAdd(c, v); continue; }
                     if (p.bias) v += p.bias[n];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.residual) v += p.residual[(size_t)m * p.ldc + n];
@@ -85,17 +92,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
 }
 
 // out[n] (+)= sum_m x[m*ld + n]; one workgroup per 64 columns, deterministic tree
+// rows are chunked over blockIdx.y (4096 rows each); a single chunk writes directly (deterministic), several chunks
+// add their partial sums atomically into the (pre-zeroed / accumulated) output
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int M, int N, float* out, int accumulate) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 4096, m1 = min(M, m0 + 4096);
     float s = 0.f;
     if (n < N)
-        for (int m = part; m < M; m += 4) s += x[(size_t)m * ld + n];
+        for (int m = m0 + part; m < m1; m += 4) s += x[(size_t)m * ld + n];
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
     if (part == 0 && n < N) {
         const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        out[n] = t + (accumulate ? out[n] : 0.f);
+        if (gridDim.y == 1) out[n] = t + (accumulate ? out[n] : 0.f);
+        else atomicAdd(out + n, t);
     }
 }
 
@@ -505,14 +516,29 @@ extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float*
 extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
     const int nb = (a->batch1 > 0 ? a->batch1 : 1) * (a->batch2 > 0 ? a->batch2 : 1);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT), (unsigned)nb), dim3(256), 0,
-                       (hipStream_t)stream, *a);
+    pf_gemm_args g = *a;
+    g.ksplit = 1;
+    const long long tiles = (long long)((a->M + GT - 1) / GT) * ((a->N + GT - 1) / GT);
+    // long-K, few-tile products (dW = dy^T x over all pairs): split K over workgroups, partial sums by atomicAdd
+    if (nb == 1 && !a->bias && !a->relu && !a->residual && a->K >= 4096 && tiles < 256) {
+        long long want = (1024 + tiles - 1) / tiles, kmax = (a->K + 4 * GK - 1) / (4 * GK);
+        g.ksplit = (int)(want < kmax ? want : kmax);
+        if (g.ksplit > 1 && !a->accumulate) {
+            if (a->ldc == a->N) { if (hipMemsetAsync(a->C, 0, (size_t)a->M * a->N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PF_E_BADARG; }
+            else g.ksplit = 1;            // strided C: keep the simple path
+        }
+    }
+    const int gz = g.ksplit > 1 ? g.ksplit : nb;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz), dim3(256), 0,
+                       (hipStream_t)stream, g);
     PF_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream) {
     if (!x || !out || M <= 0 || N <= 0) return PF_E_BADARG;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
+    const int chunks = (M + 4095) / 4096;
+    if (chunks > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PF_E_BADARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
     PF_CHECK_LAUNCH();
     return 0;
 }
