@@ -13,13 +13,44 @@ namespace {
 
 constexpr int GT = 64;        // C tile 64 x 64, 4 waves of 32 x 32
 constexpr int GK = 32;        // K chunk
-constexpr int LDT = GK + 1;   // LDS row stride (floats) of a [64][GK] operand tile
+constexpr int LDT = GK + 4;   // LDS row stride (floats) of a [64][GK] operand tile (16-byte aligned rows)
 
-// C[M,N] (ldc) = sum_k A(m,k) B(k,n) (+ C if accumulate);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
-__global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
-    __shared__ float As[GT * LDT];      // [m][k]
-    __shared__ float Bs[GT * LDT];      // [n][k]
-    // batched form: blockIdx.z = z1 * batch2 + z2 selects the operand slices
+// stage a [64 rows][GK] tile of an operand X(row, k) = X[row*sr + k*sk] into LDS [row][k]; float4 global loads along the
+// unit-stride dimension when the layout allows it (vec), scalar otherwise
+__device__ __forceinline__ void stage_tile(const float* X, long long sr, long long sk, int row0, int nrows, int k0, int kend, float* T, bool vec) {
+    const int tid = threadIdx.x;
+    if (vec && sk == 1) {                       // k contiguous: 8 float4 per row
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 256 * q, rr = idx >> 3, kq = (idx & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + rr < nrows && k0 + kq < kend) v = *reinterpret_cast<const float4*>(X + (size_t)(row0 + rr) * sr + k0 + kq);
+            *reinterpret_cast<float4*>(T + rr * LDT + kq) = v;
+        }
+    } else if (vec && sr == 1) {                // rows contiguous: float4 over 4 rows at one k, transposed into LDS
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 256 * q, r4 = (idx & 15) * 4, kk = idx >> 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r4 < nrows && k0 + kk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)(k0 + kk) * sk + row0 + r4);
+            T[(r4 + 0) * LDT + kk] = v.x; T[(r4 + 1) * LDT + kk] = v.y; T[(r4 + 2) * LDT + kk] = v.z; T[(r4 + 3) * LDT + kk] = v.w;
+        }
+    } else {
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            int rr, kk;
+            if (sk == 1) { kk = idx & (GK - 1); rr = idx >> 5; } else { rr = idx & (GT - 1); kk = idx >> 6; }
+            float v = 0.f;
+            if (row0 + rr < nrows && k0 + kk < kend) v = X[(size_t)(row0 + rr) * sr + (size_t)(k0 + kk) * sk];
+            T[rr * LDT + kk] = v;
+        }
+    }
+}
+
+// C[M,N] (ldc) = alpha sum_k A(m,k) B(k,n) (+ epilogue / + C);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+__global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[GT * LDT];      // [m][k]
+    __shared__ __attribute__((aligned(16))) float Bs[GT * LDT];      // [n][k]
     int kbeg = 0, kend = p.K;
     if (p.ksplit > 1) {                 // split-K (no batching in this mode): this workgroup owns K range [kbeg, kend), atomicAdd into C
         const int per = ((p.K + p.ksplit - 1) / p.ksplit + GK - 1) / GK * GK;
@@ -39,36 +70,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
     f32x4 acc[2][2];
     acc_zero<2, 2>(acc);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // stage: 64 x 32 elements of each operand, 8 per thread; the fastest-varying thread index follows the
-        // unit-stride dimension of the operand so that the global reads coalesce in either layout
-        for (int q = 0; q < 8; ++q) {
-            const int idx = tid + 256 * q;
-            int mm, kk;
-            if (p.sak == 1) { kk = idx & (GK - 1); mm = idx >> 5; } else { mm = idx & (GT - 1); kk = idx >> 6; }
-            const int m = m0 + mm, k = k0 + kk;
-            float v = 0.f;
-            if (m < p.M && k < kend) v = p.A[(size_t)m * p.sam + (size_t)k * p.sak];
-            As[mm * LDT + kk] = v;
-            int nn, kb;
-            if (p.sbk == 1) { kb = idx & (GK - 1); nn = idx >> 5; } else { nn = idx & (GT - 1); kb = idx >> 6; }
-            const int n = n0 + nn, k2 = k0 + kb;
-            float w = 0.f;
-            if (n < p.N && k2 < kend) w = p.B[(size_t)k2 * p.sbk + (size_t)n * p.sbn];
-            Bs[nn * LDT + kb] = w;
-        }
+        stage_tile(p.A, p.sam, p.sak, m0, p.M, k0, kend, As, vecA != 0);
+        stage_tile(p.B, p.sbn, p.sbk, n0, p.N, k0, kend, Bs, vecB != 0);
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < GK; ks += 4) {
-            float a[2], b[2];
+        for (int ks = 0; ks < GK; ks += 16) {            // one float4 per lane feeds 4 consecutive MFMA k-steps (k permutation)
+            float4 a[2], b[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a[t] = As[(wm + 16 * t + r) * LDT + ks + g];
-                b[t] = Bs[(wn + 16 * t + r) * LDT + ks + g];
+                a[t] = *reinterpret_cast<const float4*>(As + (wm + 16 * t + r) * LDT + ks + 4 * g);
+                b[t] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * t + r) * LDT + ks + 4 * g);
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt], b[nt], acc[mt][nt]);
+            mfma_slice<2, 2>(a, b, acc);
         }
         __syncthreads();
     }
@@ -91,13 +104,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p) {
             }
 }
 
-// out[n] (+)= sum_m x[m*ld + n]; one workgroup per 64 columns, deterministic tree
 // rows are chunked over blockIdx.y (4096 rows each); a single chunk writes directly (deterministic), several chunks
 // add their partial sums atomically into the (pre-zeroed / accumulated) output
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int M, int N, float* out, int accumulate) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 4096, m1 = min(M, m0 + 4096);
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
     float s = 0.f;
     if (n < N)
         for (int m = m0 + part; m < m1; m += 4) s += x[(size_t)m * ld + n];
@@ -529,14 +542,22 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
         }
     }
     const int gz = g.ksplit > 1 ? g.ksplit : nb;
+    // float4 staging needs 16-byte aligned rows / slices of the operand along its unit-stride dimension
+    auto vec_ok = [&](const float* X, long long s_row, long long s_k, int n_rows, long long b1, long long b2) {
+        if (((uintptr_t)X & 15) || (b1 & 3) || (b2 & 3)) return 0;
+        if (s_k == 1) return (s_row % 4 == 0 && a->K % 4 == 0) ? 1 : 0;
+        if (s_row == 1) return (s_k % 4 == 0 && n_rows % 4 == 0) ? 1 : 0;
+        return 0;
+    };
+    const int vA = vec_ok(a->A, a->sam, a->sak, a->M, a->bsA1, a->bsA2), vB = vec_ok(a->B, a->sbn, a->sbk, a->N, a->bsB1, a->bsB2);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz), dim3(256), 0,
-                       (hipStream_t)stream, g);
+                       (hipStream_t)stream, g, vA, vB);
     PF_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream) {
     if (!x || !out || M <= 0 || N <= 0) return PF_E_BADARG;
-    const int chunks = (M + 4095) / 4096;
+    const int chunks = M > 65536 ? (M + 511) / 512 : (M + 4095) / 4096;
     if (chunks > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PF_E_BADARG;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
     PF_CHECK_LAUNCH();
