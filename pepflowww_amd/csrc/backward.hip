@@ -557,7 +557,7 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
 }
 extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream) {
     if (!x || !out || M <= 0 || N <= 0) return PF_E_BADARG;
-    const int chunks = M > 65536 ? (M + 511) / 512 : (M + 4095) / 4096;
+    const int chunks = M <= 512 ? 1 : (M + 255) / 256 > 1024 ? 1024 : (M + 255) / 256;
     if (chunks > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PF_E_BADARG;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
     PF_CHECK_LAUNCH();
