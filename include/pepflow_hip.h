@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 13
+#define PF_ABI_VERSION 14
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -444,6 +444,24 @@ int pf_ipa_bwd_rows(const pf_ipa_bwd_args* a, pf_stream_t stream);
 int pf_ipa_bwd_pairs(const pf_ipa_bwd_args* a, pf_stream_t stream);
 int pf_ipa_bwd_points(const pf_ipa_bwd_args* a, pf_stream_t stream);
 int pf_ipa_headw_bwd(const float* g_gamma, const float* head_w, float* g_head_w, pf_stream_t stream);
+
+/* ---- full-atom reconstruction of sampled residues: models_con/torsion.py:140-226 (+ get_heavyatom_mask 121-138 and
+ * the context merge of sample.py:104-108).  Tables: the reference's idealised rigid groups (constants.py), 21 residue
+ * types: tab_rot [21,8,9], tab_trans [21,8,3], tab_group [21,14] (int32), tab_pos [21,14,3], tab_mask [22,15] (uint8),
+ * frame_group[5] = rigid-group index of psi, chi1..4.  Optional outputs may be NULL. */
+typedef struct {
+    const float* rot; const float* trans;   /* backbone frames [rows,9], [rows,3] */
+    const float* angles;                    /* [rows,5] psi, chi1..4 */
+    const int64_t* aa;                      /* [rows] residue types */
+    const float* tab_rot; const float* tab_trans; const int* tab_group; const float* tab_pos; const unsigned char* tab_mask;
+    int frame_group[5];
+    float* pos14;                           /* [rows,14,3] */
+    float* frames_rot; float* frames_trans; /* [rows,6,9], [rows,6,3]: backbone, psi, chi1..4 */
+    const float* gen_mask; const float* ctx_pos15; float* pos15_merged;   /* where(generate, pad15(pos14), context) */
+    unsigned char* mask15;                  /* [rows,15] heavy-atom mask of the residue type */
+    int rows;
+} pf_full_atom_args;
+int pf_full_atom_fwd(const pf_full_atom_args* a, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

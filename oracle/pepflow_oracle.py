@@ -633,3 +633,30 @@ def loss_grads_wrt_predictions(batch, enc, state, preds, expo1, weights=LOSS_WEI
     losses = losses_from_predictions(batch, enc, state, tuple(leaves), expo1)
     total = sum(weights[k] * v for k, v in losses.items())
     return torch.autograd.grad(total, leaves)
+
+
+# ----------------------------------------------------------------------------
+# full-atom reconstruction (models_con/torsion.py:140-226), tables passed in (pepflowww_amd/data/rigid_groups.npz)
+# ----------------------------------------------------------------------------
+def full_atom(R_bb, t_bb, angles, aa, tab):
+    """tab: dict(rotation [21,8,3,3], translation [21,8,3], atom14_group [21,14], atom14_position [21,14,3], frames [5])."""
+    sn, cs = torch.sin(angles), torch.cos(angles)
+    z, o = torch.zeros_like(sn), torch.ones_like(sn)
+    Rx = torch.stack([o, z, z, z, cs, -sn, z, sn, cs], -1).reshape(*angles.shape, 3, 3)          # torsion.py:67-92
+    Rg, tg = tab["rotation"][aa], tab["translation"][aa]
+    comp = lambda R1, t1, R2, t2: (R1 @ R2, (R1 @ t2[..., None])[..., 0] + t1)
+    Rs, ts = [R_bb], [t_bb]
+    for f in range(5):
+        grp = int(tab["frames"][f])
+        Rm, tm = comp(Rg[:, :, grp], tg[:, :, grp], Rx[:, :, f], torch.zeros_like(t_bb))
+        parent = 0 if f < 2 else f
+        R, t = comp(Rs[parent], ts[parent], Rm, tm)
+        Rs.append(R)
+        ts.append(t)
+    R_all = torch.stack([Rs[0], Rs[0], Rs[0]] + Rs[1:], 2)
+    t_all = torch.stack([ts[0], ts[0], ts[0]] + ts[1:], 2)
+    grp = tab["atom14_group"][aa]
+    Ra = torch.gather(R_all, 2, grp[..., None, None].expand(*grp.shape, 3, 3))
+    ta = torch.gather(t_all, 2, grp[..., None].expand(*grp.shape, 3))
+    pos14 = (Ra @ tab["atom14_position"][aa][..., None])[..., 0] + ta
+    return pos14, torch.stack(Rs, 2), torch.stack(ts, 2)

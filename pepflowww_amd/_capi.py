@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -106,6 +106,12 @@ class IpaBwdArgs(C.Structure):
                 ("g_qp", _fp), ("g_kp", _fp), ("g_vp", _fp), ("g_proj", _fp), ("B", _i), ("L", _i)]
 
 
+class FullAtomArgs(C.Structure):
+    _fields_ = [("rot", _fp), ("trans", _fp), ("angles", _fp), ("aa", _fp), ("tab_rot", _fp), ("tab_trans", _fp), ("tab_group", _fp),
+                ("tab_pos", _fp), ("tab_mask", _fp), ("frame_group", _i * 5), ("pos14", _fp), ("frames_rot", _fp), ("frames_trans", _fp),
+                ("gen_mask", _fp), ("ctx_pos15", _fp), ("pos15_merged", _fp), ("mask15", _fp), ("rows", _i)]
+
+
 class NodeFeatArgs(C.Structure):
     _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("gen_mask", _fp),
                 ("aa_table", _fp), ("freq3", _fp), ("feat", _fp), ("rot1", _fp), ("trans1", _fp), ("mres", _fp),
@@ -181,6 +187,7 @@ _SIGNATURES = {
     "pf_ipa_bwd_pairs": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_bwd_points": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_headw_bwd": ([_fp, _fp, _fp, _fp], _i),
+    "pf_full_atom_fwd": ([C.POINTER(FullAtomArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
     "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),

@@ -968,3 +968,23 @@ def test_training_gradients_are_shard_additive(seeded_sd):
     full = grads(0, 4)
     mean = 0.5 * (grads(0, 2) + grads(2, 4))
     G.assert_close(mean, full, 5 * REL, "mean of shard gradients == full-batch gradient")
+
+
+def test_full_atom_reconstruction_vs_reference(golden_dir):
+    """pf_full_atom_fwd against the reference's full_atom_reconstruction / get_heavyatom_mask on all 21 residue types
+    (golden F7), and the sample.py merge with the context atoms."""
+    from pepflowww_amd import full_atom as FA
+    f7 = load(golden_dir, "f7_full_atom.npz")
+    pos14, Rf, tf = FA.full_atom_reconstruction(cu(f7["R"]), cu(f7["t"]), cu(f7["ang"]), cu(f7["aa"]))
+    G.assert_close(pos14, f7["pos14"], 1e-5, "pos14")
+    G.assert_close(Rf, f7["R_ret"], 1e-5, "frames R")
+    G.assert_close(tf, f7["t_ret"], 1e-5, "frames t")
+    assert torch.equal(FA.get_heavyatom_mask(cu(f7["aa"])).cpu(), f7["mask"])
+    B, N = f7["aa"].shape
+    gen = torch.zeros(B, N, dtype=torch.bool)
+    gen[:, -5:] = True
+    ctx = torch.randn(B, N, 15, 3, generator=torch.Generator().manual_seed(3))
+    pos, mask = FA.reconstruct_sample(cu(f7["R"]), cu(f7["t"]), cu(f7["ang"]), cu(f7["aa"]), cu(gen), cu(ctx))
+    ref = torch.where(gen[:, :, None, None], F.pad(f7["pos14"], (0, 0, 0, 1)), ctx)
+    G.assert_close(pos, ref, 1e-5, "merged heavy atoms")
+    assert torch.equal(mask.cpu(), f7["mask"])

@@ -188,3 +188,17 @@ def test_loss_gradients_wrt_predictions(f4, f5, seeded_sd):
     close(gx, f5["d_pred_trans"], 1e-6, 1e-4)
     close(ga, f5["d_pred_ang"], 2e-6, 1e-4)
     close(gl, f5["d_pred_logits"], 1e-7, 1e-4)
+
+
+def _rigid_tables():
+    d = np.load(os.path.join(os.path.dirname(__file__), "..", "pepflowww_amd", "data", "rigid_groups.npz"))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+def test_full_atom_reconstruction(golden_dir):
+    """models_con/torsion.py:full_atom_reconstruction on all 21 residue types (golden F7)."""
+    f7 = load(golden_dir, "f7_full_atom.npz")
+    pos14, Rr, tr = O.full_atom(f7["R"], f7["t"], f7["ang"], f7["aa"], _rigid_tables())
+    close(pos14, f7["pos14"], 2e-5, 1e-5)
+    close(Rr, f7["R_ret"], 1e-6, 1e-5)
+    close(tr, f7["t_ret"], 2e-5, 1e-5)
