@@ -15,13 +15,14 @@ constexpr int GT = 64;        // C tile 64 x 64, 4 waves of 32 x 32
 constexpr int GK = 32;        // K chunk
 constexpr int LDT = GK + 4;   // LDS row stride (floats) of a [64][GK] operand tile (16-byte aligned rows)
 
-// stage a [64 rows][GK] tile of an operand X(row, k) = X[row*sr + k*sk] into LDS [row][k]; float4 global loads along the
+// stage a [NR rows][GK] tile of an operand X(row, k) = X[row*sr + k*sk] into LDS [row][k]; float4 global loads along the
 // unit-stride dimension when the layout allows it (vec), scalar otherwise
+template <int NR>
 __device__ __forceinline__ void stage_tile(const float* X, long long sr, long long sk, int row0, int nrows, int k0, int kend, float* T, bool vec) {
     const int tid = threadIdx.x;
     if (vec && sk == 1) {                       // k contiguous: 8 float4 per row
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NR / 32; ++q) {
             const int idx = tid + 256 * q, rr = idx >> 3, kq = (idx & 7) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + rr < nrows && k0 + kq < kend) v = *reinterpret_cast<const float4*>(X + (size_t)(row0 + rr) * sr + k0 + kq);
@@ -29,17 +30,17 @@ __device__ __forceinline__ void stage_tile(const float* X, long long sr, long lo
         }
     } else if (vec && sr == 1) {                // rows contiguous: float4 over 4 rows at one k, transposed into LDS
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int idx = tid + 256 * q, r4 = (idx & 15) * 4, kk = idx >> 4;
+        for (int q = 0; q < NR / 32; ++q) {
+            const int idx = tid + 256 * q, r4 = (idx % (NR / 4)) * 4, kk = idx / (NR / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + r4 < nrows && k0 + kk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)(k0 + kk) * sk + row0 + r4);
             T[(r4 + 0) * LDT + kk] = v.x; T[(r4 + 1) * LDT + kk] = v.y; T[(r4 + 2) * LDT + kk] = v.z; T[(r4 + 3) * LDT + kk] = v.w;
         }
     } else {
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NR / 8; ++q) {
             const int idx = tid + 256 * q;
             int rr, kk;
-            if (sk == 1) { kk = idx & (GK - 1); rr = idx >> 5; } else { rr = idx & (GT - 1); kk = idx >> 6; }
+            if (sk == 1) { kk = idx & (GK - 1); rr = idx >> 5; } else { rr = idx % NR; kk = idx / NR; }
             float v = 0.f;
             if (row0 + rr < nrows && k0 + kk < kend) v = X[(size_t)(row0 + rr) * sr + (size_t)(k0 + kk) * sk];
             T[rr * LDT + kk] = v;
@@ -48,8 +49,11 @@ __device__ __forceinline__ void stage_tile(const float* X, long long sr, long lo
 }
 
 // C[M,N] (ldc) = alpha sum_k A(m,k) B(k,n) (+ epilogue / + C);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+// MT = 16-row tiles per wave along M: C tile (32 MT) x 64 per workgroup (MT = 4 for tall problems)
+template <int MT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[GT * LDT];      // [m][k]
+    constexpr int TM = 32 * MT;
+    __shared__ __attribute__((aligned(16))) float As[TM * LDT];      // [m][k]
     __shared__ __attribute__((aligned(16))) float Bs[GT * LDT];      // [n][k]
     int kbeg = 0, kend = p.K;
     if (p.ksplit > 1) {                 // split-K (no batching in this mode): this workgroup owns K range [kbeg, kend), atomicAdd into C
@@ -65,28 +69,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x4 acc[2][2];
-    acc_zero<2, 2>(acc);
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * GT;
+    const int wm = (wave >> 1) * 16 * MT, wn = (wave & 1) * 32;
+    f32x4 acc[MT][2];
+    acc_zero<MT, 2>(acc);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        stage_tile(p.A, p.sam, p.sak, m0, p.M, k0, kend, As, vecA != 0);
-        stage_tile(p.B, p.sbn, p.sbk, n0, p.N, k0, kend, Bs, vecB != 0);
+        stage_tile<TM>(p.A, p.sam, p.sak, m0, p.M, k0, kend, As, vecA != 0);
+        stage_tile<GT>(p.B, p.sbn, p.sbk, n0, p.N, k0, kend, Bs, vecB != 0);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < GK; ks += 16) {            // one float4 per lane feeds 4 consecutive MFMA k-steps (k permutation)
-            float4 a[2], b[2];
+            float4 a[MT], b[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = *reinterpret_cast<const float4*>(As + (wm + 16 * t + r) * LDT + ks + 4 * g);
-                b[t] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * t + r) * LDT + ks + 4 * g);
-            }
-            mfma_slice<2, 2>(a, b, acc);
+            for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(As + (wm + 16 * t + r) * LDT + ks + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * t + r) * LDT + ks + 4 * g);
+            mfma_slice<MT, 2>(a, b, acc);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -531,7 +534,9 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     const int nb = (a->batch1 > 0 ? a->batch1 : 1) * (a->batch2 > 0 ? a->batch2 : 1);
     pf_gemm_args g = *a;
     g.ksplit = 1;
-    const long long tiles = (long long)((a->M + GT - 1) / GT) * ((a->N + GT - 1) / GT);
+    const bool tall = a->M >= 8192;                       // 128-row C tiles for the pair-sized products
+    const int TM = tall ? 128 : 64;
+    const long long tiles = (long long)((a->M + TM - 1) / TM) * ((a->N + GT - 1) / GT);
     // long-K, few-tile products (dW = dy^T x over all pairs): split K over workgroups, partial sums by atomicAdd
     if (nb == 1 && !a->bias && !a->relu && !a->residual && a->K >= 4096 && tiles < 256) {
         long long want = (1024 + tiles - 1) / tiles, kmax = (a->K + 4 * GK - 1) / (4 * GK);
@@ -550,8 +555,9 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
         return 0;
     };
     const int vA = vec_ok(a->A, a->sam, a->sak, a->M, a->bsA1, a->bsA2), vB = vec_ok(a->B, a->sbn, a->sbk, a->N, a->bsB1, a->bsB2);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((a->M + GT - 1) / GT), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz), dim3(256), 0,
-                       (hipStream_t)stream, g, vA, vB);
+    const dim3 grid((unsigned)((a->M + TM - 1) / TM), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz);
+    if (tall) hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
+    else hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
     PF_CHECK_LAUNCH();
     return 0;
 }

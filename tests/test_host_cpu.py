@@ -82,3 +82,48 @@ def test_synthetic_batch_schema():
     n1 = synth.make_noise(4, 24, 3, seed=5)
     n2 = synth.make_noise(2, 24, 3, seed=5, first_sample=2)
     assert torch.equal(n1["expo"][:, 2:], n2["expo"]) and torch.equal(n1["rot0"][2:], n2["rot0"])
+
+
+def test_padding_collate_matches_reference(golden_dir):
+    """pepflow/utils/data.py:19-78 on three ragged samples, eight=True/False (golden F8 recorded from the reference)."""
+    import numpy as np
+    from pepflowww_amd.io import PaddingCollate
+    for eight in (1, 0):
+        g = np.load(os.path.join(golden_dir, f"f8_collate_eight{eight}.npz"))
+        samples = []
+        for i in range(3):
+            s = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"in{i}_")}
+            s["chain_id"] = ["A"] * s["aa"].shape[0]
+            s["id"] = f"s{i}"
+            samples.append(s)
+        out = PaddingCollate(eight=bool(eight))(samples)
+        for k in ("aa", "pos_heavyatom", "mask_heavyatom", "generate_mask", "res_mask"):
+            assert torch.equal(out[k], torch.from_numpy(g[k])), (k, eight)
+        assert out["id"] == ["s0", "s1", "s2"] and len(out["chain_id"]) == out["aa"].shape[1]
+
+
+def test_trajectory_file_and_pdb_writer(tmp_path):
+    """`.pt` trajectory round trip and PDB records (fixed columns of the PDB format; parity with Biopython's PDBIO is
+    unpinned: the reference's writer needs Biopython, absent here)."""
+    from pepflowww_amd.io import load_trajectory, save_trajectory, write_pdb
+    n = 6
+    g = torch.Generator().manual_seed(1)
+    data = dict(aa=torch.tensor([0, 4, 7, 21, 14, 20]), pos_heavyatom=torch.randn(n, 15, 3, generator=g) * 30,
+                mask_heavyatom=torch.rand(n, 15, generator=g) > 0.2, chain_nb=torch.tensor([1, 1, 1, 1, 0, 0]),
+                chain_id=["A", "A", "A", "A", "B", "B"], resseq=torch.tensor([5, 6, 7, 8, 1, 2]), icode=[" "] * n)
+    p = tmp_path / "x.pdb"
+    write_pdb(data, str(p))
+    lines = p.read_text().splitlines()
+    atoms = [l for l in lines if l.startswith("ATOM")]
+    assert lines[-1] == "END" and sum(l.startswith("TER") for l in lines) == 2
+    assert all(len(l) == 78 for l in atoms)
+    first_b = [l for l in atoms if l[21] == "B"][0]                     # chain_nb 0 is written first
+    from pepflowww_amd.io import _names
+    assert atoms[0] == first_b and first_b[17:20] == _names()[1][14] and int(first_b[22:26]) == 1
+    x = float(first_b[30:38])
+    assert abs(x - round(float(data["pos_heavyatom"][4, 0, 0]), 3)) < 1e-3
+    assert not any(l[17:20] == "UNK" and l[12:16].strip() == "CB" for l in atoms)      # UNK has backbone atoms only
+    traj = {"rotmats": torch.randn(2, n, 3, 3), "seqs": torch.zeros(2, n, dtype=torch.long)}
+    save_trajectory(traj, {"aa": data["aa"][None]}, str(tmp_path / "t.pt"))
+    back = load_trajectory(str(tmp_path / "t.pt"))
+    assert torch.equal(back["rotmats"], traj["rotmats"]) and torch.equal(back["batch"]["aa"], data["aa"][None])

@@ -20,8 +20,25 @@ tab = dict(rotation=K.restype_rigid_group_rotation.float(), translation=K.restyp
            atom14_group=K.restype_heavyatom_to_rigid_group.long(), atom14_position=K.restype_heavyatom_rigid_group_positions.float(),
            heavyatom_mask=T.restype_to_heavyatom_masks, torsions_mask=T.torsions_mask,
            frames=torch.tensor([K.PSI_FRAME, K.CHI1_FRAME, K.CHI2_FRAME, K.CHI3_FRAME, K.CHI4_FRAME]))
+names = [[K.restype_to_heavyatom_names[K.AA(i)][j] if i < 21 else "" for j in range(15)] for i in range(22)]
+resnames = [str(K.AA(i)) for i in range(21)] + ["UNK"]
 print({k: tuple(v.shape) for k, v in tab.items()})
-np.savez_compressed(os.path.join(ROOT, "pepflowww_amd", "data", "rigid_groups.npz"), **{k: v.numpy() for k, v in tab.items()})
+np.savez_compressed(os.path.join(ROOT, "pepflowww_amd", "data", "rigid_groups.npz"), **{k: v.numpy() for k, v in tab.items()},
+                    atom_names=np.array(names), resnames=np.array(resnames))
+# golden: PaddingCollate (pepflow/utils/data.py:19-78) on three ragged samples
+from pepflow.utils.data import PaddingCollate  # noqa: E402
+gg = torch.Generator().manual_seed(5)
+samples = []
+for n in (11, 17, 8):
+    samples.append({"aa": torch.randint(0, 20, (n,), generator=gg), "pos_heavyatom": torch.randn(n, 15, 3, generator=gg),
+                    "mask_heavyatom": torch.rand(n, 15, generator=gg) > 0.3, "generate_mask": torch.arange(n) >= n - 3,
+                    "chain_id": ["A"] * n, "id": f"s{n}"})
+for eight in (True, False):
+    out = PaddingCollate(eight=eight)(samples)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"f8_collate_eight{int(eight)}.npz"),
+                        **{k: v.numpy() for k, v in out.items() if isinstance(v, torch.Tensor)},
+                        **{"in%d_%s" % (i, k): v.numpy() for i, sm in enumerate(samples) for k, v in sm.items() if isinstance(v, torch.Tensor)})
+    print(eight, {k: (tuple(v.shape) if isinstance(v, torch.Tensor) else type(v).__name__) for k, v in out.items()})
 
 g = torch.Generator().manual_seed(77)
 B, L = 3, 21
