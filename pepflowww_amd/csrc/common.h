@@ -312,12 +312,8 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
         if (st + 1 < nst) {
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt) {
-#ifdef PF_EXP_NOWSTREAM   // dev experiment: no weight streaming (wrong results)
-                nh[wt] = bh[wt]; nl[wt] = bl[wt];
-#else
                 nh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)(st + 1) * 512);
                 nl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)(st + 1) * 512);
-#endif
             }
         }
         half8 ah[PT], al[PT];

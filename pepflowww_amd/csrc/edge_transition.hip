@@ -121,12 +121,8 @@ __global__ __launch_bounds__(256 * NPH, (P == 32 ? 4 : 2)) void edge_transition_
         const int n = wave * 48 + wt * 16 + 4 * g;
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-#ifdef PF_EXP_NOGATHER     // dev experiment: no per-residue gathers (wrong results)
-            pa[wt][pt] = make_float4(0.f, 0.f, 0.f, (float)n); pc[wt][pt] = make_float4((float)rbi[pt], 0.f, 0.f, 0.f);
-#else
             pa[wt][pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbi[pt] * PF_ET_PRE + n);
             pc[wt][pt] = *reinterpret_cast<const float4*>(a.pre + (size_t)rbj[pt] * PF_ET_PRE + 192 + n);
-#endif
         }
     }
     float lnmk = 0.f;                                   // edge mask of the pair row this thread normalises at the end

@@ -363,7 +363,6 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(zo + 16 * t) = o4[t];
         }
-#ifndef PF_EXP_NOBIAS
         if (a.bias_out) {
             // pair bias of the NEXT IPA block from z' while it is in registers: one more 64 -> 8(16) split-precision GEMM with
             // z' as the B operand (same K permutation as the other register-resident activations); heads 4*(lane>>4)+e
@@ -387,14 +386,9 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
                 ob.y = s13 * ((bm[1] + bm2[1]) + (bc[1] + bc2[1]) * LOI + bb.y);
                 ob.z = s13 * ((bm[2] + bm2[2]) + (bc[2] + bc2[2]) * LOI + bb.z);
                 ob.w = s13 * ((bm[3] + bm2[3]) + (bc[3] + bc2[3]) * LOI + bb.w);
-#ifndef PF_EXP_NOBIASSTORE
                 *reinterpret_cast<float4*>(a.bias_out + pidx * 8 + 4 * g) = ob;
-#else
-                if (ob.x == 12345.678f) a.bias_out[0] = ob.y + ob.z + ob.w;
-#endif
             }
         }
-#endif
         PROF3(14);
     }
 }
