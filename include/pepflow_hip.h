@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 14
+#define PF_ABI_VERSION 15
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -123,6 +123,9 @@ typedef struct {
     const float* bias;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
+/* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
+ * sampler steps -> computed once per sample() call): bias [B*L*L, 8] = sqrt(1/3)(linear_b(z)), ipa_pytorch.py:393-404 */
+int pf_pair_bias_fwd(const float* z, const float* w_b, const float* b_b, float* bias, int B, int L, pf_stream_t stream);
 
 /* ---- sequence-transformer attention core (torch.nn.MultiheadAttention inside
  * nn.TransformerEncoderLayer, ga.py:53-62): 4 heads x 32, key padding mask. */

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -153,6 +153,7 @@ _SIGNATURES = {
     "pf_embed_inputs_fwd": ([C.POINTER(EmbedArgs), _fp], _i),
     "pf_ipa_points_fwd": ([C.POINTER(IpaPointsArgs), _fp], _i),
     "pf_ipa_attn_fwd": ([C.POINTER(IpaAttnArgs), _fp], _i),
+    "pf_pair_bias_fwd": ([_fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_seq_attn_fwd": ([C.POINTER(SeqAttnArgs), _fp], _i),
     "pf_node_head_fwd": ([C.POINTER(NodeHeadArgs), _fp], _i),
     "pf_node_tfmr_fwd": ([C.POINTER(NodeTfmrArgs), _fp], _i),

@@ -596,6 +596,39 @@ int launch_attn(const pf_ipa_attn_args& a, hipStream_t s) {
 
 }  // namespace
 
+// sqrt(1/3)(W_b z + b_b) per pair for a pair tensor that does not come out of EdgeTransition (block 0: the encoder's
+// edge_embed is constant over the sampler steps, so this runs ONCE per sample() call, not per step); one thread per pair
+__global__ __launch_bounds__(256) void pair_bias_kernel(const float* z, const float* w_b, const float* b_b, float* bias, long long npairs) {
+    __shared__ float W[8 * 64 + 8];
+    for (int i = threadIdx.x; i < 8 * 64 + 8; i += 256) W[i] = i < 512 ? w_b[i] : b_b[i - 512];
+    __syncthreads();
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npairs) return;
+    float acc[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) acc[h] = W[512 + h];
+    const float4* zp = reinterpret_cast<const float4*>(z + p * 64);
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 v = zp[c4];
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            acc[h] += W[h * 64 + 4 * c4] * v.x + W[h * 64 + 4 * c4 + 1] * v.y + W[h * 64 + 4 * c4 + 2] * v.z + W[h * 64 + 4 * c4 + 3] * v.w;
+    }
+    const float s13 = 0.57735026918962576f;
+    float4* o = reinterpret_cast<float4*>(bias + p * 8);
+    o[0] = make_float4(s13 * acc[0], s13 * acc[1], s13 * acc[2], s13 * acc[3]);
+    o[1] = make_float4(s13 * acc[4], s13 * acc[5], s13 * acc[6], s13 * acc[7]);
+}
+
+extern "C" int pf_pair_bias_fwd(const float* z, const float* w_b, const float* b_b, float* bias, int B, int L, pf_stream_t stream) {
+    if (!z || !w_b || !b_b || !bias || B <= 0 || L <= 0) return PF_E_BADARG;
+    const long long np = (long long)B * L * L;
+    hipLaunchKernelGGL(pair_bias_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, w_b, b_b, bias, np);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pf_ipa_points_fwd(const pf_ipa_points_args* a, pf_stream_t stream) {
     if (!a || !a->proj || !a->rot || !a->trans || !a->qp || !a->kp || !a->vp || a->rows <= 0 || a->ldp < PF_IPA_PROJ)
         return PF_E_BADARG;

@@ -200,6 +200,7 @@ class DenoiseEngine:
         self.n64, self.pre = e(rows, 64), e(rows, 512)
         self.zbuf = e(B, L, L, 64)
         self.pair_bias = e(B, L, L, 8)          # sqrt(1/3)(W_b z + b_b) of the next IPA block, written by EdgeTransition
+        self.pair_bias0 = e(B, L, L, 8)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -236,6 +237,8 @@ class DenoiseEngine:
         _capi.dptr(ee, name="edge_embed")
         rebuild = self.plan is None or self.edge_embed is None or self.edge_embed.data_ptr() != ee.data_ptr()
         self.edge_embed = ee
+        _capi.check(self.lib.pf_pair_bias_fwd(ee.data_ptr(), self.w["0.linear_b.w"].data_ptr(), self.w["0.linear_b.b"].data_ptr(),
+                                              self.pair_bias0.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
         if rebuild:
             self._build_plan()
 
@@ -280,7 +283,7 @@ class DenoiseEngine:
             ia.w_b, ia.b_b = w[f"{b}.linear_b.w"].data_ptr(), w[f"{b}.linear_b.b"].data_ptr()
             ia.w_dz, ia.b_dz = w[f"{b}.down_z.w"].data_ptr(), w[f"{b}.down_z.b"].data_ptr()
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
-            ia.bias = self.pair_bias.data_ptr() if b > 0 else None     # emitted by EdgeTransition(b - 1)
+            ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----
