@@ -522,41 +522,55 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
     #pragma unroll
             for (int c = 0; c < 16; ++c) wdz[c] = *reinterpret_cast<const float4*>(a.w_dz + (lane & 15) * 64 + 4 * c);
             const float bdz = a.b_dz[lane & 15];
-            for (int t4 = 0; t4 < 4; ++t4) {
+            // z rows are streamed in batches of ZBATCH loads per lane, ONE BATCH AHEAD of the arithmetic and across the four
+            // query rows of the wave (the loads read a clamped, always valid pair; padding is removed through the weight)
+            constexpr int ZBATCH = 8;
+            const int nbr = (L + 4 * ZBATCH - 1) / (4 * ZBATCH);              // batches per query row
+            const int nrow = min(4, max(0, L - (i0 + wave * 4)));             // valid query rows of this wave
+            const int nbt = nrow * nbr;
+            auto zload = [&](int bi, float4 (&zq)[ZBATCH]) {
+                const int t4 = bi / nbr, jb = (bi - t4 * nbr) * 4 * ZBATCH;
+                const float* zrow = a.z + ((rowb + i0 + wave * 4 + t4) * L) * 64 + 4 * c4;
+#pragma unroll
+                for (int u = 0; u < ZBATCH; ++u) {
+                    const int jj = jb + 4 * u + js;
+                    zq[u] = *reinterpret_cast<const float4*>(zrow + (size_t)(jj < L ? jj : L - 1) * 64);
+                }
+            };
+            float4 zq[ZBATCH], zn[ZBATCH];
+            if (nbt > 0) zload(0, zq);
+            float4 zacc[HG];
+            for (int bi = 0; bi < nbt; ++bi) {
+                if (bi + 1 < nbt) zload(bi + 1, zn);
+                const int t4 = bi / nbr, jb = (bi - t4 * nbr) * 4 * ZBATCH;
                 const int ti = wave * 4 + t4, i = i0 + ti;
-                if (i >= L) continue;                          // wave-uniform
-                const float* zrow = a.z + ((rowb + i) * L) * 64;
-                float4 zacc[HG];
-    #pragma unroll
-                for (int h = 0; h < HG; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                constexpr int ZBATCH = 8;
-                for (int jb = 0; jb < L; jb += 4 * ZBATCH) {
-                    float4 zq[ZBATCH];
-    #pragma unroll
-                    for (int u = 0; u < ZBATCH; ++u) {
-                        const int j = jb + 4 * u + js;
-                        zq[u] = (j < L) ? *reinterpret_cast<const float4*>(zrow + (size_t)j * 64 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-    #pragma unroll
-                    for (int u = 0; u < ZBATCH; ++u) {
-                        const int j = jb + 4 * u + js;
-                        if (j < L) {
-    #pragma unroll
-                            for (int h = 0; h < HG; ++h) {
-                                const float pw = S[(ti * HG + h) * LDS_S + j];
-                                zacc[h].x += pw * zq[u].x; zacc[h].y += pw * zq[u].y; zacc[h].z += pw * zq[u].z; zacc[h].w += pw * zq[u].w;
-                            }
-                        }
+                if (jb == 0) {
+#pragma unroll
+                    for (int h = 0; h < HG; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < ZBATCH; ++u) {
+                    const int jj = jb + 4 * u + js;
+                    const float keep = jj < L ? 1.f : 0.f;
+#pragma unroll
+                    for (int h = 0; h < HG; ++h) {
+                        const float pw = S[(ti * HG + h) * LDS_S + (jj < L ? jj : 0)] * keep;
+                        zacc[h].x += pw * zq[u].x; zacc[h].y += pw * zq[u].y; zacc[h].z += pw * zq[u].z; zacc[h].w += pw * zq[u].w;
                     }
                 }
-    #pragma unroll
+#pragma unroll
+                for (int u = 0; u < ZBATCH; ++u) zq[u] = zn[u];
+                if (jb + 4 * ZBATCH < L) continue;                            // more batches of this row (wave-uniform)
+#pragma unroll
                 for (int h = 0; h < HG; ++h) {
                     float4 v = zacc[h];
                     v.x = sum_xor32(sum_xor16(v.x)); v.y = sum_xor32(sum_xor16(v.y));
                     v.z = sum_xor32(sum_xor16(v.z)); v.w = sum_xor32(sum_xor16(v.w));
                     if (js == 0) *reinterpret_cast<float4*>(zb + h * 64 + 4 * c4) = v;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // wave-private LDS hand-off: only the LDS counter has to drain (a workgroup fence would also wait for the
+                // z prefetch that is in flight)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
                     const int hh = o >> 4, d = o & 15;
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
                     }
                     a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
         }
