@@ -203,11 +203,20 @@ def bench_train(args, wl, dev, dist, rank, world):
     wts = {"trans_loss": 0.5, "rot_loss": 0.5, "bb_atom_loss": 0.25, "seqs_loss": 1.0, "angle_loss": 1.0, "torsion_loss": 0.5}
     gen = torch.Generator().manual_seed(1234 + rank)
 
+    from pepflowww_amd.train_forward import default_train_noise
+    graphed = None
+    if not args.no_graph:
+        # the whole step (corrupt, forward, losses, backward) replayed as one hipGraph; gradients land in static tensors
+        from pepflowww_amd.train_step import GraphedTrainStep
+        graphed = GraphedTrainStep(model, batch, wts, first_sample=first, generator=gen)
+
     def step():
-        from pepflowww_amd.train_forward import default_train_noise
-        model.zero_grad(set_to_none=True)
-        losses = model(batch, noise=default_train_noise(B, L, gen), seed=20240227, first_sample=first)
-        sum(wts[k] * v for k, v in losses.items()).backward()
+        if graphed is not None:
+            graphed(None, noise=default_train_noise(B, L, gen), seed=20240227)
+        else:
+            model.zero_grad(set_to_none=True)
+            losses = model(batch, noise=default_train_noise(B, L, gen), seed=20240227, first_sample=first)
+            sum(wts[k] * v for k, v in losses.items()).backward()
         allreduce_gradients(model.parameters(), dist)
     for _ in range(W):
         step()

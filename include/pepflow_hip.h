@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 15
+#define PF_ABI_VERSION 16
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -340,6 +340,9 @@ typedef struct {
     float* losses;                /* [6] */
     int B, L;
     int sample_structure, sample_sequence;
+    /* optional: the Philox seed read from DEVICE memory at run time (overrides `seed`), so that a training step
+     * captured once as a hipGraph draws fresh categorical noise on every replay */
+    const uint64_t* seed_dev;
 } pf_train_args;
 int pf_train_corrupt_fwd(const pf_train_args* a, pf_stream_t stream);
 int pf_train_losses_fwd(const pf_train_args* a, pf_stream_t stream);
@@ -352,6 +355,7 @@ typedef struct {
     float* d_trans;    /* [B*L,3]  d/d pred_trans */
     float* d_ang;      /* [B*L,5]  d/d pred_ang_raw (the % 2pi of ga.py:125 has unit slope) */
     float* d_logits;   /* [B*L,20] d/d pred_logits */
+    const float* w_dev; /* optional: the six weights read from device memory (overrides w; graph-captured steps) */
 } pf_train_bwd_args;
 int pf_train_losses_bwd(const pf_train_args* a, const pf_train_bwd_args* g, pf_stream_t stream);
 

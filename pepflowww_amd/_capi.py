@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -73,11 +73,11 @@ class TrainArgs(C.Structure):
                 ("t", _fp), ("rot_t", _fp), ("trans_t", _fp), ("ang_t", _fp), ("seq_t", _fp),
                 ("pred_rot", _fp), ("pred_trans", _fp), ("pred_ang_raw", _fp), ("pred_logits", _fp),
                 ("pred_seq", _fp), ("per_sample", _fp), ("losses", _fp),
-                ("B", _i), ("L", _i), ("sample_structure", _i), ("sample_sequence", _i)]
+                ("B", _i), ("L", _i), ("sample_structure", _i), ("sample_sequence", _i), ("seed_dev", _fp)]
 
 
 class TrainBwdArgs(C.Structure):
-    _fields_ = [("w", C.c_float * 6), ("d_rot", _fp), ("d_trans", _fp), ("d_ang", _fp), ("d_logits", _fp)]
+    _fields_ = [("w", C.c_float * 6), ("d_rot", _fp), ("d_trans", _fp), ("d_ang", _fp), ("d_logits", _fp), ("w_dev", _fp)]
 
 
 class GemmArgs(C.Structure):

@@ -5,6 +5,14 @@ import ctypes as C
 
 import torch
 
+_DEVICE_CONSTANTS = {}
+
+
+def _zeros(*shape, device, dtype=torch.float32):
+    """Zero-initialised tensor written by a fill KERNEL (torch.zeros / zero_() use hipMemsetAsync, whose graph memset
+    node was observed to race with following atomics when the training step is replayed as a hipGraph)."""
+    return torch.full(shape, 0, dtype=dtype, device=device)
+
 from . import _capi
 
 
@@ -21,10 +29,35 @@ def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, l
     _capi.check(_capi.load().pf_gemm_f32(C.byref(a), _capi.stream_ptr()), "pf_gemm_f32")
 
 
+SPLIT_MIN_ROWS = 8192          # pair-sized products go to the split-precision kernel of the inference path
+
+
+def _linear_split(x, w, b=None, relu=False):
+    """y = relu?(x W^T + b) on the split-precision f16 MFMA kernel (csrc/linear.hip, fp32-level accuracy): ~2.3x the rate
+    of the fp32-MFMA GEMM on the [B*L*L, 192] products of EdgeTransition.  w: [N, K] fp32, K % 32 == 0, K <= 512."""
+    from .engine import split_f16
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device)
+    w16 = split_f16(w)
+    a = _capi.LinearArgs()
+    a.x, a.ldx, a.w, a.ldw, a.w_f16 = x.data_ptr(), K, w.data_ptr(), K, w16.data_ptr()
+    a.bias = b.data_ptr() if b is not None else None
+    a.y, a.ldy, a.M, a.N, a.K, a.relu = y.data_ptr(), N, M, N, K, int(relu)
+    _capi.check(_capi.load().pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
+    return y
+
+
+def _split_ok(M, K):
+    return M >= SPLIT_MIN_ROWS and K % 32 == 0 and K <= 512
+
+
 def linear_fwd(x, w, b=None, relu=False, residual=None):
     """y = relu?(x W^T + b) + residual in ONE launch of the fp32 GEMM (the saved-activation forward of the training path)."""
     M, K = x.shape
     N = w.shape[0]
+    if residual is None and _split_ok(M, K) and w.is_contiguous():
+        return _linear_split(x, w, b, relu)
     y = torch.empty(M, N, device=x.device)
     a = _capi.GemmArgs()
     a.A, a.sam, a.sak, a.B, a.sbk, a.sbn = x.data_ptr(), K, 1, w.data_ptr(), 1, K
@@ -44,8 +77,11 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None):
     N = w.shape[0]
     dx = None
     if need_dx:
-        dx = torch.empty(M, K, device=x.device)
-        _gemm(dy, N, 1, w, K, 1, dx, M, K, N)
+        if _split_ok(M, N) and dy.is_contiguous():
+            dx = _linear_split(dy, w.t().contiguous())          # dx = dy W = dy (W^T)^T
+        else:
+            dx = torch.empty(M, K, device=x.device)
+            _gemm(dy, N, 1, w, K, 1, dx, M, K, N)
     acc = dW is not None
     if dW is None:
         dW = torch.empty(N, K, device=x.device)
@@ -234,7 +270,7 @@ class IpaBlock:
         pa = _capi.IpaPointsArgs()
         pa.proj, pa.ldp, pa.rot, pa.trans, pa.qp, pa.kp, pa.vp, pa.rows = proj.data_ptr(), 3744, rot.data_ptr(), trans.data_ptr(), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), rows
         _capi.check(lib.pf_ipa_points_fwd(C.byref(pa), _capi.stream_ptr()), "pf_ipa_points_fwd")
-        feats = torch.zeros(rows, 1536, device=dev)
+        feats = _zeros(rows, 1536, device=dev)
         ia = _capi.IpaAttnArgs()
         ia.proj, ia.ldp, ia.qp, ia.kp, ia.vp, ia.z = proj.data_ptr(), 3744, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), z.data_ptr()
         ia.rot, ia.trans, ia.mask = rot.data_ptr(), trans.data_ptr(), self.mask.data_ptr()
@@ -381,13 +417,16 @@ class TrunkTrainer:
         import math
         half = 64
         dev = self.mask.device
-        self.time_freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(2056) / (half - 1))).to(dev)
+        key = ("time_freq", str(dev))
+        if key not in _DEVICE_CONSTANTS:         # host-computed once per device (an H2D copy cannot be graph-captured)
+            _DEVICE_CONSTANTS[key] = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(2056) / (half - 1))).to(dev)
+        self.time_freq = _DEVICE_CONSTANTS[key]
 
     def forward(self, t, rot_t, trans_t, ang_t, seq_t, node_embed, edge_embed):
         lib, B, L, sd, st = _capi.load(), self.B, self.L, self.sd, _capi.stream_ptr()
         rows, dev = B * L, self.mask.device
         f32 = lambda x, *shape: x.to(torch.float32).reshape(*shape).contiguous()
-        feat = torch.zeros(rows, 640, device=dev)
+        feat = _zeros(rows, 640, device=dev)
         ea = _capi.EmbedArgs()
         self.seq_t = seq_t.reshape(rows).contiguous()
         ne, tt, ang = f32(node_embed, rows, 128), f32(t, B), f32(ang_t, rows, 5)
@@ -472,7 +511,7 @@ class TrunkTrainer:
         w0 = sd["res_feat_mixer.0.weight"]
         K = w0.shape[1]
         feat = self.saved["feat"]
-        g_feat = torch.zeros(rows, 640, device=dev)
+        g_feat = _zeros(rows, 640, device=dev)
         _gemm(g_m1, 128, 1, w0, K, 1, g_feat, rows, K, 128, ldc=640)
         dW0 = torch.empty(128, K, device=dev)
         _gemm(g_m1, 1, 128, feat, 640, 1, dW0, 128, K, rows)
@@ -537,7 +576,7 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     dbo0 = e(64)
     _capi.check(lib.pf_colsum_f32(g_o1.data_ptr(), 64, P, 64, dbo0.data_ptr(), 0, st), "pf_colsum_f32")
     G["edge_embedder.out_mlp.0.weight"], G["edge_embedder.out_mlp.0.bias"] = dWo0, dbo0
-    t_aap, t_rel = torch.zeros(484, 64, device=dev), torch.zeros(65, 64, device=dev)
+    t_aap, t_rel = _zeros(484, 64, device=dev), _zeros(65, 64, device=dev)
     _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr(), 224, aap.data_ptr(), None, P, 64, t_aap.data_ptr(), st), "pf_embedding_bwd_atomic")
     _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr() + 4 * 64, 224, rel.data_ptr(), same.data_ptr(), P, 64, t_rel.data_ptr(), st), "pf_embedding_bwd_atomic")
     G["edge_embedder.aa_pair_embed.weight"], G["edge_embedder.relpos_embed.weight"] = t_aap, t_rel
@@ -547,7 +586,7 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     g_h1, G["edge_embedder.distance_embed.2.weight"], G["edge_embedder.distance_embed.2.bias"] = linear_bwd(saved["h1"], w("edge_embedder.distance_embed.2.weight"), g_fd)
     relu_bwd_(saved["h1"], g_h1)
     g_g, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], w("edge_embedder.distance_embed.0.weight"), g_h1)
-    t_c = torch.zeros(484, 225, device=dev)
+    t_c = _zeros(484, 225, device=dev)
     _capi.check(lib.pf_edge_distcoef_bwd(g_g.data_ptr(), saved["g"].data_ptr(), saved["d2"].data_ptr(), aap.data_ptr(),
                                          w("edge_embedder.aapair_to_distcoef.weight").data_ptr(), P, t_c.data_ptr(), st), "pf_edge_distcoef_bwd")
     G["edge_embedder.aapair_to_distcoef.weight"] = t_c

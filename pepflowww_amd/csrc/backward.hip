@@ -107,6 +107,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
             }
 }
 
+// zero fill as a KERNEL: a hipMemsetAsync captured into a hipGraph (memset node) was observed to race with the atomic
+// accumulation that follows it on replay (bias gradients of the graph-captured training step came out as garbage)
+__global__ __launch_bounds__(256) void zero_kernel(float* p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void zero2d_kernel(float* p, int M, int N, int ld) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)M * N) p[(i / N) * ld + i % N] = 0.f;
+}
+void zero_fill_2d(float* p, int M, int N, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(zero2d_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, p, M, N, ld);
+}
+void zero_fill(float* p, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+
 // rows are chunked over blockIdx.y (4096 rows each); a single chunk writes directly (deterministic), several chunks
 // add their partial sums atomically into the (pre-zeroed / accumulated) output
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int M, int N, float* out, int accumulate) {
@@ -115,8 +132,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int
     const int rows_per = (M + gridDim.y - 1) / gridDim.y;
     const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
     float s = 0.f;
-    if (n < N)
-        for (int m = m0 + part; m < m1; m += 4) s += x[(size_t)m * ld + n];
+    if (n < N) {
+        // 8 independent loads in flight per thread (one load per iteration is a chain of L2 round trips)
+        int m = m0 + part;
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; m + 28 < m1; m += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += x[(size_t)(m + 4 * u) * ld + n];
+        }
+        for (; m < m1; m += 4) s += x[(size_t)m * ld + n];
+        s += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
     if (part == 0 && n < N) {
@@ -279,6 +305,110 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(const float* qkv, con
         }
 #pragma unroll
         for (int c = 0; c < AD; ++c) { g_qkv[(rowb + j) * 384 + 128 + h * AD + c] = gk[c]; g_qkv[(rowb + j) * 384 + 256 + h * AD + c] = gv[c]; }
+    }
+}
+
+// Same computation with q / k / v / g_o of the (sample, head) staged in LDS (L <= 256: 4 x L x 33 floats) and TPR threads per
+// query / key row, each owning 32 / TPR of the head's features (partial dot products are combined with lane shuffles).
+// The global-memory form above ran one thread per row against L2: 450 us per call at B=16, L=128 (2 waves per workgroup).
+template <int TPR>
+__global__ __launch_bounds__(256) void seq_attn_bwd_lds_kernel(const float* qkv, const float* mask, const float* g_out, float* g_qkv,
+                                                               float* stats, int B, int L) {
+    constexpr int FC = AD / TPR, LDR = AD + 1;
+    extern __shared__ float sm[];
+    float* Qs = sm;
+    float* Ks = Qs + L * LDR;
+    float* Vs = Ks + L * LDR;
+    float* Gs = Vs + L * LDR;
+    float* Mk = Gs + L * LDR;                       // key mask
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const size_t rowb = (size_t)b * L;
+    const float scale = 0.17677669529663687f;     // 1/sqrt(32)
+    float* st = stats + ((size_t)blockIdx.x * L) * 3;     // per query: max, 1/sum, delta
+    for (int idx = threadIdx.x; idx < L * (AD / 4); idx += 256) {
+        const int row = idx / (AD / 4), c4 = idx % (AD / 4);
+        const float4 q = *reinterpret_cast<const float4*>(qkv + (rowb + row) * 384 + h * AD + 4 * c4);
+        const float4 k = *reinterpret_cast<const float4*>(qkv + (rowb + row) * 384 + 128 + h * AD + 4 * c4);
+        const float4 v = *reinterpret_cast<const float4*>(qkv + (rowb + row) * 384 + 256 + h * AD + 4 * c4);
+        const float4 g = *reinterpret_cast<const float4*>(g_out + (rowb + row) * 128 + h * AD + 4 * c4);
+        float* d;
+        d = Qs + row * LDR + 4 * c4; d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        d = Ks + row * LDR + 4 * c4; d[0] = k.x; d[1] = k.y; d[2] = k.z; d[3] = k.w;
+        d = Vs + row * LDR + 4 * c4; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d = Gs + row * LDR + 4 * c4; d[0] = g.x; d[1] = g.y; d[2] = g.z; d[3] = g.w;
+    }
+    for (int j = threadIdx.x; j < L; j += 256) Mk[j] = mask[rowb + j];
+    __syncthreads();
+    auto rsum = [](float v) {                      // sum over the TPR lanes of a row
+        if (TPR >= 2) v += __shfl_xor(v, 1);
+        if (TPR >= 4) v += __shfl_xor(v, 2);
+        return v;
+    };
+    const int sub = threadIdx.x % TPR, c0 = sub * FC;
+    // pass A: per query i -- row max, 1 / sum, delta_i = sum_j p_ij (g_o_i . v_j), g_q_i
+    for (int i0 = 0; i0 < L; i0 += 256 / TPR) {
+        const int i = i0 + threadIdx.x / TPR;
+        const int ic = i < L ? i : L - 1;             // (all lanes stay in the loops: the shuffles need their partners)
+        float q[FC], go[FC], gq[FC];
+#pragma unroll
+        for (int c = 0; c < FC; ++c) { q[c] = Qs[ic * LDR + c0 + c]; go[c] = Gs[ic * LDR + c0 + c]; gq[c] = 0.f; }
+        float mx = -3.0e38f;
+        for (int j = 0; j < L; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) sc += q[c] * Ks[j * LDR + c0 + c];
+            sc = rsum(sc);
+            if (Mk[j] >= 0.5f) mx = fmaxf(mx, sc * scale);
+        }
+        float sum = 0.f, dl = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float sc = 0.f, gp = 0.f;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) { sc += q[c] * Ks[j * LDR + c0 + c]; gp += go[c] * Vs[j * LDR + c0 + c]; }
+            sc = rsum(sc); gp = rsum(gp);
+            if (Mk[j] >= 0.5f) { const float e = expf(sc * scale - mx); sum += e; dl += e * gp; }
+        }
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        dl *= inv;
+        for (int j = 0; j < L; ++j) {
+            float sc = 0.f, gp = 0.f;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) { sc += q[c] * Ks[j * LDR + c0 + c]; gp += go[c] * Vs[j * LDR + c0 + c]; }
+            sc = rsum(sc); gp = rsum(gp);
+            const float gs = Mk[j] >= 0.5f ? expf(sc * scale - mx) * inv * (gp - dl) * scale : 0.f;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) gq[c] += gs * Ks[j * LDR + c0 + c];
+        }
+        if (i < L) {
+            if (sub == 0) { st[i * 3 + 0] = mx; st[i * 3 + 1] = inv; st[i * 3 + 2] = dl; }
+#pragma unroll
+            for (int c = 0; c < FC; ++c) g_qkv[(rowb + i) * 384 + h * AD + c0 + c] = gq[c];
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    // pass B: per key j -- g_k_j, g_v_j
+    for (int j0 = 0; j0 < L; j0 += 256 / TPR) {
+        const int j = j0 + threadIdx.x / TPR;
+        const int jc = j < L ? j : L - 1;
+        float k[FC], v[FC], gk[FC], gv[FC];
+#pragma unroll
+        for (int c = 0; c < FC; ++c) { k[c] = Ks[jc * LDR + c0 + c]; v[c] = Vs[jc * LDR + c0 + c]; gk[c] = 0.f; gv[c] = 0.f; }
+        const bool keep = Mk[jc] >= 0.5f;
+        for (int i = 0; i < L; ++i) {
+            float sc = 0.f, gp = 0.f;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) { sc += Qs[i * LDR + c0 + c] * k[c]; gp += Gs[i * LDR + c0 + c] * v[c]; }
+            sc = rsum(sc); gp = rsum(gp);
+            const float p = keep ? expf(sc * scale - st[i * 3 + 0]) * st[i * 3 + 1] : 0.f;
+            const float gs = p * (gp - st[i * 3 + 2]) * scale;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) { gk[c] += gs * Qs[i * LDR + c0 + c]; gv[c] += p * Gs[i * LDR + c0 + c]; }
+        }
+        if (j < L) {
+#pragma unroll
+            for (int c = 0; c < FC; ++c) { g_qkv[(rowb + j) * 384 + 128 + h * AD + c0 + c] = gk[c]; g_qkv[(rowb + j) * 384 + 256 + h * AD + c0 + c] = gv[c]; }
+        }
     }
 }
 
@@ -524,6 +654,21 @@ extern "C" int pf_add_inplace(float* dst, const float* src, long long n, pf_stre
 extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float* g_out, float* g_qkv, float* stats, int B, int L,
                                pf_stream_t stream) {
     if (!qkv || !mask || !g_out || !g_qkv || !stats || B <= 0 || L <= 0) return PF_E_BADARG;
+    if (L <= 256) {
+        const size_t lds = ((size_t)4 * L * (AD + 1) + L) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        if (L <= 64) hipLaunchKernelGGL(seq_attn_bwd_lds_kernel<4>, dim3((unsigned)(B * 4)), dim3(256), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
+        else if (L <= 128) hipLaunchKernelGGL(seq_attn_bwd_lds_kernel<2>, dim3((unsigned)(B * 4)), dim3(256), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
+        else hipLaunchKernelGGL(seq_attn_bwd_lds_kernel<1>, dim3((unsigned)(B * 4)), dim3(256), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(seq_attn_bwd_kernel, dim3((unsigned)(B * 4)), dim3(256), 0, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
     PF_CHECK_LAUNCH();
     return 0;
@@ -538,12 +683,14 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     const int TM = tall ? 128 : 64;
     const long long tiles = (long long)((a->M + TM - 1) / TM) * ((a->N + GT - 1) / GT);
     // long-K, few-tile products (dW = dy^T x over all pairs): split K over workgroups, partial sums by atomicAdd
-    if (nb == 1 && !a->bias && !a->relu && !a->residual && a->K >= 4096 && tiles < 256) {
-        long long want = (1024 + tiles - 1) / tiles, kmax = (a->K + 4 * GK - 1) / (4 * GK);
+    // (also the row-sized ones, K = B*L: without the split a 128 x 128 dW runs on 4 workgroups for ~115 us -- a quarter of
+    //  the training step was spent in such launches)
+    if (nb == 1 && !a->bias && !a->relu && !a->residual && a->K >= 512 && tiles < 256) {
+        long long want = ((a->K >= 4096 ? 1024 : 512) + tiles - 1) / tiles, kmax = (a->K + 4 * GK - 1) / (4 * GK);
         g.ksplit = (int)(want < kmax ? want : kmax);
         if (g.ksplit > 1 && !a->accumulate) {
-            if (a->ldc == a->N) { if (hipMemsetAsync(a->C, 0, (size_t)a->M * a->N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PF_E_BADARG; }
-            else g.ksplit = 1;            // strided C: keep the simple path
+            if (a->ldc == a->N) zero_fill(a->C, (size_t)a->M * a->N, (hipStream_t)stream);
+            else zero_fill_2d(a->C, a->M, a->N, a->ldc, (hipStream_t)stream);
         }
     }
     const int gz = g.ksplit > 1 ? g.ksplit : nb;
@@ -564,7 +711,7 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
 extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream) {
     if (!x || !out || M <= 0 || N <= 0) return PF_E_BADARG;
     const int chunks = M <= 512 ? 1 : (M + 255) / 256 > 1024 ? 1024 : (M + 255) / 256;
-    if (chunks > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PF_E_BADARG;
+    if (chunks > 1 && !accumulate) zero_fill(out, (size_t)N, (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
     PF_CHECK_LAUNCH();
     return 0;

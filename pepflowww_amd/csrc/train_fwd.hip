@@ -30,6 +30,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float (*red)[NV]) {
 }
 
 __global__ __launch_bounds__(256) void train_corrupt_kernel(pf_train_args a) {
+    if (a.seed_dev) a.seed = *a.seed_dev;                          // graph-captured steps: fresh seed per replay
     __shared__ float red[4][4];
     const int b = blockIdx.x, L = a.L;
     const size_t rowb = (size_t)b * L;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void train_corrupt_kernel(pf_train_args a) {
 
 // per-sample sums: [0] trans, [1] rot, [2] bb, [3] ce, [4] angle vf, [5] torsion, [6] n_gen, [7] n_angle
 __global__ __launch_bounds__(256) void train_losses_kernel(pf_train_args a) {
+    if (a.seed_dev) a.seed = *a.seed_dev;
     __shared__ float red[4][8];
     const int b = blockIdx.x, L = a.L;
     const size_t rowb = (size_t)b * L;
@@ -241,6 +243,11 @@ __device__ __forceinline__ void so3_log_bwd_dev(const float* M, const float* gw,
 
 // d(sum_k w_k loss_k) / d(pred_rot, pred_trans, pred_ang_raw, pred_logits); one workgroup per sample
 __global__ __launch_bounds__(256) void train_losses_bwd_kernel(pf_train_args a, pf_train_bwd_args g) {
+    if (a.seed_dev) a.seed = *a.seed_dev;
+    if (g.w_dev) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g.w[k] = g.w_dev[k];
+    }
     __shared__ float red[4][2];
     const int b = blockIdx.x, L = a.L;
     const size_t rowb = (size_t)b * L;

@@ -78,11 +78,13 @@ def encode(model, batch, save=None):
         dumps = dict(g=e(P, 225), d2=e(P, 225), h1=e(P, 64), cat=e(P, 224), o1=e(P, 64), o2=e(P, 64))
         ea.dump_g, ea.dump_d2, ea.dump_h1 = dumps["g"].data_ptr(), dumps["d2"].data_ptr(), dumps["h1"].data_ptr()
         ea.dump_cat, ea.dump_o1, ea.dump_o2 = dumps["cat"].data_ptr(), dumps["o1"].data_ptr(), dumps["o2"].data_ptr()
-        dumps["d2"].zero_()
+        dumps["d2"].fill_(0.0)
         save.update(dumps)
         save.update(feat=feat, n_h0=h0, n_h1=h1, n_h2=h2, mres=mres, ctx=ctx, aa=aa_c, res_nb=res_nb, chain_nb=chain_nb,
                     sample_structure=na.sample_structure, sample_sequence=na.sample_sequence)
     _capi.check(lib.pf_edge_features_fwd(C.byref(ea), _capi.stream_ptr()), "pf_edge_features_fwd")
-    torch.cuda.current_stream().synchronize()      # temporaries above must outlive the launches
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().synchronize()  # temporaries above must outlive the launches (inside a graph capture
+        #                                            they live in the graph's private pool for the graph's lifetime)
     return (rot1.view(B, L, 3, 3), trans1.view(B, L, 3), _f32(batch["torsion_angle"]), aa_c,
             node.view(B, L, 128), edge)

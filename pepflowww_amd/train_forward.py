@@ -21,11 +21,13 @@ def default_train_noise(B, L, generator=None):
 
 
 class TrainForward:
-    def __init__(self, engine, flags=(True, True), first_sample=0, seed=0):
+    def __init__(self, engine, flags=(True, True), first_sample=0, seed=0, seed_dev=None):
+        """seed_dev: optional int64 device tensor [1] the kernels read the Philox seed from at run time (instead of the
+        launch-time constant `seed`) -- used by the graph-captured training step."""
         self.eng, self.lib = engine, engine.lib
         B, L, dev = engine.B, engine.L, engine.device
         rows = B * L
-        e = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        e = lambda *s, dt=torch.float32: torch.full(s, 0, dtype=dt, device=dev)      # fill kernel, not a memset node
         self.rot1, self.trans1, self.ang1 = e(rows, 9), e(rows, 3), e(rows, 5)
         self.seq1, self.pred_seq = e(rows, dt=torch.int64), e(rows, dt=torch.int64)
         self.gen = e(rows)
@@ -39,6 +41,8 @@ class TrainForward:
         a.pred_ang_raw, a.pred_logits = engine.ang_raw.data_ptr(), engine.logits.data_ptr()
         a.pred_seq, a.per_sample, a.losses = self.pred_seq.data_ptr(), self.per_sample.data_ptr(), self.losses.data_ptr()
         a.expo, a.seed, a.first_sample = None, seed, first_sample
+        self._seed_dev = seed_dev
+        a.seed_dev = seed_dev.data_ptr() if seed_dev is not None else None
         a.B, a.L = B, L
         a.sample_structure, a.sample_sequence = (int(f) for f in flags)
         self.args = a
@@ -69,11 +73,17 @@ class TrainForward:
 
     def loss_grads(self, weights):
         """d(sum_k weights[k] * loss_k) / d(pred_rot, pred_trans, pred_ang_raw, pred_logits) -- the seed of the trunk
-        backward (train.py:121,133).  weights: dict keyed like the loss dict (learn_angle.yaml:37-43)."""
+        backward (train.py:121,133).  weights: dict keyed like the loss dict (learn_angle.yaml:37-43), or a float32
+        device tensor [6] in LOSS_KEYS order (read by the kernel at run time: no host round trip)."""
         dev, rows = self.eng.device, self.eng.rows
         g = _capi.TrainBwdArgs()
-        for i, k in enumerate(LOSS_KEYS):
-            g.w[i] = float(weights[k])
+        if torch.is_tensor(weights):
+            assert weights.dtype == torch.float32 and weights.numel() == 6 and weights.is_contiguous()
+            self._w_dev = weights
+            g.w_dev = weights.data_ptr()
+        else:
+            for i, k in enumerate(LOSS_KEYS):
+                g.w[i] = float(weights[k])
         out = {"d_rot": torch.empty(rows, 9, device=dev), "d_trans": torch.empty(rows, 3, device=dev),
                "d_ang": torch.empty(rows, 5, device=dev), "d_logits": torch.empty(rows, 20, device=dev)}
         g.d_rot, g.d_trans, g.d_ang, g.d_logits = (out[k].data_ptr() for k in ("d_rot", "d_trans", "d_ang", "d_logits"))

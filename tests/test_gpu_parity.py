@@ -946,6 +946,56 @@ def test_training_step_through_autograd(f4, f6, seeded_sd):
     assert l1 < l0, (l0, l1)
 
 
+def test_graphed_training_step_equals_eager(seeded_sd):
+    """GraphedTrainStep (whole step captured as one hipGraph, Philox seed and loss weights read from device memory) gives
+    the losses and the 407 gradients of the eager autograd step bit for bit, on the capture inputs and on a replay with
+    new batch / noise / seed; an in-place parameter update between replays is seen by the next replay."""
+    from pepflowww_amd.train_step import GraphedTrainStep
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.to(G.dev()).train()
+    B, L = 2, 32
+    w = O.LOSS_WEIGHTS
+
+    def inputs(seed):
+        batch = _to_dev(synth.make_pocket_batch(B, L, 6, seed=seed))
+        nz = synth.make_noise(B, L, 1, seed=seed + 1)
+        noise = {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(seed)), **{k: nz[k] for k in ("trans0", "rot0", "ang0", "simplex0")}}
+        return batch, noise
+
+    def eager(batch, noise, seed):
+        m.zero_grad(set_to_none=True)
+        ld = m(batch, noise=noise, seed=seed)
+        sum(w[k] * v for k, v in ld.items()).backward()
+        return {k: v.detach().clone() for k, v in ld.items()}, {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    b0, n0 = inputs(31)
+    step = GraphedTrainStep(m, b0, w)
+    for (batch, noise, seed) in ((b0, n0, 1234), (*inputs(57), 99)):
+        le, ge = eager(batch, noise, seed)
+        for _, p in m.named_parameters():
+            p.grad = None
+        lg = step(batch, noise=noise, seed=seed)
+        for n, p in m.named_parameters():
+            p.grad = step.grads.get(n)
+        for k in le:
+            assert torch.equal(le[k], lg[k]), (k, le[k].item(), lg[k].item())
+        bad = [n for n, p in m.named_parameters() if not torch.equal(ge[n], p.grad)]
+        # (split-K atomics: gradients that are accumulated atomically may differ in the last bits between runs)
+        # (linear_b.bias gradients are zero up to rounding -- softmax shift invariance -- hence the absolute floor)
+        off = [(n, (ge[n] - p.grad).abs().max().item(), ge[n].abs().max().item()) for n, p in m.named_parameters()]
+        off = [t for t in off if t[1] > 1e-5 * t[2] + 2e-7]
+        assert not off, (len(off), off[:5])
+    # parameters are read in place: a step along -grad changes the next replay's loss
+    l_before = sum(w[k] * v.item() for k, v in step(b0, noise=n0, seed=1234).items())
+    with torch.no_grad():
+        gn = torch.sqrt(sum((p.grad ** 2).sum() for p in m.parameters()))
+        for p in m.parameters():
+            p -= (1e-3 / gn) * p.grad
+    l_after = sum(w[k] * v.item() for k, v in step(b0, noise=n0, seed=1234).items())
+    assert l_after < l_before, (l_before, l_after)
+
+
 def test_training_gradients_are_shard_additive(seeded_sd):
     """Data-parallel training: per-sample losses are averaged over the batch, so the gradient of the full
     batch equals the mean of the gradients of its equal shards -- what the gradient all-reduce relies on."""

@@ -19,3 +19,13 @@ print('small fwd [2048,128]x[128,128]', t(lambda: Bk.linear_fwd(x2, w2), 20), 'u
 g = torch.randn(16, 8, 128, 128, device=dev); pr = torch.randn(2048, 3744, device=dev); gp = torch.empty(2048, 3744, device=dev)
 L = 128
 print('batched gA K (B*8 x [128x128]x[128x128])', t(lambda: Bk._gemm(g, L, 1, pr, 3744, 1, gp, L, 128, L, alpha=0.05, ldc=3744, b_off=1024, batch=(16, 8, (8*L*L, L*L), (L*3744, 256), (L*3744, 128))), 20), 'us')
+# library reference points (hipBLASLt / rocBLAS through torch.matmul) for the same shapes
+print('torch NT  [P,192]x[192,192]^T', t(lambda: torch.mm(x, w.t())), 'us')
+print('torch dx NN', t(lambda: torch.mm(dy, w)), 'us')
+print('torch dW TN', t(lambda: torch.mm(dy.t(), x)), 'us')
+print('torch colsum', t(lambda: dy.sum(0)), 'us')
+out = torch.empty(192, device=dev)
+import ctypes as C
+from pepflowww_amd import _capi
+lib = _capi.load()
+print('pf_colsum', t(lambda: lib.pf_colsum_f32(dy.data_ptr(), 192, P, 192, out.data_ptr(), 0, _capi.stream_ptr())), 'us')
