@@ -169,6 +169,7 @@ _SIGNATURES = {
     "pf_train_losses_bwd": ([C.POINTER(TrainArgs), C.POINTER(TrainBwdArgs), _fp], _i),
     "pf_gemm_f32": ([C.POINTER(GemmArgs), _fp], _i),
     "pf_colsum_f32": ([_fp, _i, _i, _i, _fp, _i, _fp], _i),
+    "pf_gemm_tn_wide": ([_fp, _i, _i, _fp, _i, _i, _fp, _i, C.c_longlong, _i, _fp, _i, _fp], _i),
     "pf_relu_bwd": ([_fp, _fp, C.c_longlong, _fp], _i),
     "pf_layernorm_bwd": ([C.POINTER(LayerNormBwdArgs), _fp], _i),
     "pf_layernorm_fwd": ([_fp, _fp, _fp, _fp, _i, _i, _fp], _i),

@@ -85,10 +85,15 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None):
     acc = dW is not None
     if dW is None:
         dW = torch.empty(N, K, device=x.device)
-    _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc)
     accb = db is not None
     if db is None:
         db = torch.empty(N, device=x.device)
+    if M >= SPLIT_MIN_ROWS and N <= 192 and K <= 192 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous():
+        # pair-sized: dW and db in ONE pass over dy and x (csrc/backward.hip: gemm_tn_wide_kernel)
+        _capi.check(lib.pf_gemm_tn_wide(dy.data_ptr(), N, N, x.data_ptr(), K, K, dW.data_ptr(), K, M, int(acc), db.data_ptr(), int(accb),
+                                        _capi.stream_ptr()), "pf_gemm_tn_wide")
+        return dx, dW, db
+    _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc)
     _capi.check(lib.pf_colsum_f32(dy.data_ptr(), N, M, N, db.data_ptr(), int(accb), _capi.stream_ptr()), "pf_colsum_f32")
     return dx, dW, db
 

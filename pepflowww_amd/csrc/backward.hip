@@ -107,6 +107,103 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
             }
 }
 
+// ---- wide TN product for weight gradients over all pairs:  C[M,N] (+)= A^T B,  A [R,M] (lda), B [R,N] (ldb), M, N <= 192, R = B*L*L.
+// The generic kernel tiles C 64 x 64 and splits K: every operand column block is then read once per tile of the OTHER
+// dimension (3 x 402 MB for a 192 x 192 dW -- it ran at the resulting HBM/L2 traffic, ~400 us).  Here one workgroup owns the
+// WHOLE C for its row range: A and B stream through LDS once (R x (M + N) x 4 bytes in total), 8 waves as 4 (m) x 2 (n) hold up
+// to 3 x 6 accumulator tiles each, partial sums are added atomically at the end.  Both MFMA operands are "row r, 16
+// consecutive columns" of the staged chunk, i.e. the natural layout (v_mfma_f32_16x16x4_f32: lane = column, lane >> 4 = r).
+// Optionally also the column sums of A (the bias gradient) from the staged chunks -- no separate pass over A.
+constexpr int WK = 32;                            // rows per staged chunk (64: slower, 12 float4 of staging per thread)
+constexpr int WLD = 192 + 16;                     // LDS row stride (floats): rows r, r+1 land 16 banks apart
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
+                                                           long long R, long long rows_per_wg, float* colsum_a) {
+    extern __shared__ __attribute__((aligned(16))) float wide_sm[];
+    float* As = wide_sm;
+    float* Bs = wide_sm + WK * WLD;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int MT = (M + 15) >> 4, NT = (N + 15) >> 4;
+    const int mt0 = wm * 3, nt0 = wn * 6;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    f32x4 acc[3][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f;
+    const int m4 = M >> 2, n4 = N >> 2, per = m4 + n4;            // float4 per row of [A | B]
+    constexpr int NLD = (WK * 96 + 511) / 512;                     // float4 per thread per chunk (6)
+    float4 stage[NLD];
+    auto fetch = [&](long long rb) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = tid + q * 512;
+            const int rr = idx / per, c = idx - rr * per;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < WK && rb + rr < r1)
+                v = c < m4 ? *reinterpret_cast<const float4*>(A + (size_t)(rb + rr) * lda + 4 * c)
+                           : *reinterpret_cast<const float4*>(B + (size_t)(rb + rr) * ldb + 4 * (c - m4));
+            stage[q] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = tid + q * 512;
+            const int rr = idx / per, c = idx - rr * per;
+            if (rr < WK) {
+                if (c < m4) *reinterpret_cast<float4*>(As + rr * WLD + 4 * c) = stage[q];
+                else *reinterpret_cast<float4*>(Bs + rr * WLD + 4 * (c - m4)) = stage[q];
+            }
+        }
+    };
+    // columns beyond M / N of the last 16-wide tile read as zero
+    for (int i = tid; i < WK * WLD; i += 512) { As[i] = 0.f; Bs[i] = 0.f; }
+    __syncthreads();
+    if (r0 < r1) fetch(r0);
+    for (long long rb = r0; rb < r1; rb += WK) {
+        commit();
+        __syncthreads();
+        if (rb + WK < r1) fetch(rb + WK);
+        if (colsum_a && (tid & 255) < M) {                          // two half-chunks of 16 rows, 256 threads each
+            float s8 = 0.f;
+            const float* ap = As + (tid >> 8) * (WK / 2) * WLD + (tid & 255);
+#pragma unroll
+            for (int r = 0; r < WK / 2; ++r) s8 += ap[r * WLD];
+            cs += s8;
+        }
+        const int col = lane & 15, kr = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < WK / 4; ++ks) {
+            float a[3], b[6];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = As[(4 * ks + kr) * WLD + 16 * (mt0 + i) + col];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) b[j] = Bs[(4 * ks + kr) * WLD + 16 * (nt0 + j) + col];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // C(m, n): accumulator register e of lane (n = lane & 15, g = lane >> 4) is row m = 4 g + e of the tile
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (mt0 + i >= MT || nt0 + j >= NT) continue;
+            const int n = 16 * (nt0 + j) + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 16 * (mt0 + i) + 4 * (lane >> 4) + e;
+                if (m < M && n < N) atomicAdd(C + (size_t)m * ldc + n, acc[i][j][e]);
+            }
+        }
+    if (colsum_a && (tid & 255) < M) atomicAdd(colsum_a + (tid & 255), cs);
+}
+
 // zero fill as a KERNEL: a hipMemsetAsync captured into a hipGraph (memset node) was observed to race with the atomic
 // accumulation that follows it on replay (bias gradients of the graph-captured training step came out as garbage)
 __global__ __launch_bounds__(256) void zero_kernel(float* p, size_t n) {
@@ -713,6 +810,27 @@ extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, i
     const int chunks = M <= 512 ? 1 : (M + 255) / 256 > 1024 ? 1024 : (M + 255) / 256;
     if (chunks > 1 && !accumulate) zero_fill(out, (size_t)N, (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out, accumulate);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, long long R,
+                               int accumulate, float* colsum_a, int colsum_accumulate, pf_stream_t stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || M > 192 || N > 192) return PF_E_BADARG;
+    if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return PF_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) { if (ldc == N) zero_fill(C, (size_t)M * N, s); else zero_fill_2d(C, M, N, ldc, s); }
+    if (colsum_a && !colsum_accumulate) zero_fill(colsum_a, (size_t)M, s);
+    long long nwg = (R + 4 * WK - 1) / (4 * WK);
+    static const long long cap = [] { const char* e = getenv("PF_TN_WGS"); return e ? atoll(e) : 256LL; }();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (nwg > cap) nwg = cap;
+    long long per = ((R + nwg - 1) / nwg + WK - 1) / WK * WK;
+    nwg = (R + per - 1) / per;
+    hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3((unsigned)nwg), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -29,3 +29,7 @@ import ctypes as C
 from pepflowww_amd import _capi
 lib = _capi.load()
 print('pf_colsum', t(lambda: lib.pf_colsum_f32(dy.data_ptr(), 192, P, 192, out.data_ptr(), 0, _capi.stream_ptr())), 'us')
+db = torch.empty(192, device=dev)
+print('pf_gemm_tn_wide dW + db', t(lambda: lib.pf_gemm_tn_wide(dy.data_ptr(), 192, 192, x.data_ptr(), 192, 192, dW.data_ptr(), 192, P, 0, db.data_ptr(), 0, _capi.stream_ptr())), 'us')
+ref = dy.t() @ x
+print('   max rel err dW', ((dW - ref).abs().max() / ref.abs().max()).item(), ' db', ((db - dy.sum(0)).abs().max() / dy.sum(0).abs().max()).item())
