@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 16
+#define PF_ABI_VERSION 17
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -121,6 +121,8 @@ typedef struct {
     /* optional: sqrt(1/3) (W_b z + b_b) precomputed per pair [B*L*L, 8] by the producer of z
      * (pf_edge_transition_fwd, bias_out): the bias pass over z is skipped, z is read once. */
     const float* bias;
+    /* optional (training forward): the attention probabilities [B,8,L,L] are also written out (saved for the backward) */
+    float* p_out;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
@@ -453,6 +455,13 @@ typedef struct {
     int B, L;
 } pf_ipa_bwd_args;
 int pf_ipa_bwd_rows(const pf_ipa_bwd_args* a, pf_stream_t stream);
+/* the same stage from SAVED probabilities (a->P written by pf_ipa_attn_fwd, p_out) and batched GEMMs issued by the host
+ * (pepflowww_amd/backward.py):  pf_ipa_bwd_opt: a->g_opt holds o_pt in the global frame (= P vp) on entry and its gradient
+ * on return, + g_frame_rows;  pf_ipa_bwd_pairterm: a->gA (holding g_P so far) += (W_dz^T g_o_pair) . z;
+ * pf_ipa_bwd_softmax: a->gA = P (g_P - sum_j P g_P) in place, + g_gamma_rows. */
+int pf_ipa_bwd_opt(const pf_ipa_bwd_args* a, pf_stream_t stream);
+int pf_ipa_bwd_pairterm(const pf_ipa_bwd_args* a, pf_stream_t stream);
+int pf_ipa_bwd_softmax(const pf_ipa_bwd_args* a, pf_stream_t stream);
 int pf_ipa_bwd_pairs(const pf_ipa_bwd_args* a, pf_stream_t stream);
 int pf_ipa_bwd_points(const pf_ipa_bwd_args* a, pf_stream_t stream);
 int pf_ipa_headw_bwd(const float* g_gamma, const float* head_w, float* g_head_w, pf_stream_t stream);

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -37,7 +37,7 @@ class IpaPointsArgs(C.Structure):
 class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
-                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp)]
+                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp)]
 
 
 class SeqAttnArgs(C.Structure):
@@ -187,6 +187,9 @@ _SIGNATURES = {
     "pf_et_concat_bwd": ([_fp, _fp, _i, _fp, _i, _i, _fp], _i),
     "pf_ipa_bwd_rows": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_bwd_pairs": ([C.POINTER(IpaBwdArgs), _fp], _i),
+    "pf_ipa_bwd_opt": ([C.POINTER(IpaBwdArgs), _fp], _i),
+    "pf_ipa_bwd_pairterm": ([C.POINTER(IpaBwdArgs), _fp], _i),
+    "pf_ipa_bwd_softmax": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_bwd_points": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_headw_bwd": ([_fp, _fp, _fp, _fp], _i),
     "pf_full_atom_fwd": ([C.POINTER(FullAtomArgs), _fp], _i),

@@ -281,9 +281,11 @@ class IpaBlock:
         ia.rot, ia.trans, ia.mask = rot.data_ptr(), trans.data_ptr(), self.mask.data_ptr()
         ia.w_b, ia.b_b, ia.w_dz, ia.b_dz = W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(), W[p + "down_z.weight"].data_ptr(), W[p + "down_z.bias"].data_ptr()
         ia.head_w, ia.feats, ia.B, ia.L = W[p + "head_weights"].data_ptr(), feats.data_ptr(), B, L
+        P = torch.empty(B, 8, L, L, device=dev)                # attention probabilities, saved for the backward
+        ia.p_out = P.data_ptr()
         _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
         out = row_mask_(linear_fwd(feats, W[p + "linear_out.weight"], W[p + "linear_out.bias"]), self.mask)
-        self.saved = dict(s=s, z=z, rot=rot, trans=trans, proj=proj, qp=qp, kp=kp, vp=vp, feats=feats)
+        self.saved = dict(s=s, z=z, rot=rot, trans=trans, proj=proj, qp=qp, kp=kp, vp=vp, feats=feats, P=P)
         return out
 
     def backward(self, g_out, g_z=None):
@@ -295,7 +297,7 @@ class IpaBlock:
         g = row_mask_(g_out.clone(), self.mask)
         g_feats, G[p + "linear_out.weight"], G[p + "linear_out.bias"] = linear_bwd(sv["feats"], W[p + "linear_out.weight"], g)
         e = lambda *shape: torch.empty(*shape, device=dev)
-        P, gA = e(B, 8, L, L), e(B, 8, L, L)
+        P, gA = sv["P"], e(B, 8, L, L)
         g_opt, g_frame, g_gam = e(rows, 288), e(rows, 12), e(rows, 8)
         g_bias, g_pz = e(rows * L, 8), e(rows * L, 16)
         acc_z = g_z is not None
@@ -312,10 +314,18 @@ class IpaBlock:
         a.g_bias, a.g_pz, a.g_z, a.accumulate_gz = g_bias.data_ptr(), g_pz.data_ptr(), g_z.data_ptr(), int(acc_z)
         a.g_qp, a.g_kp, a.g_vp, a.g_proj, a.B, a.L = g_qp.data_ptr(), g_kp.data_ptr(), g_vp.data_ptr(), g_proj.data_ptr(), B, L
         st = _capi.stream_ptr()
-        _capi.check(lib.pf_ipa_bwd_rows(C.byref(a), st), "pf_ipa_bwd_rows")
-        _capi.check(lib.pf_ipa_bwd_pairs(C.byref(a), st), "pf_ipa_bwd_pairs")
         LL, ldp = L * L, 3744
         bAh = (8 * LL, LL)                                  # gA / P slices: sample, head
+        # ---- row stage from the saved probabilities: g_P by three batched GEMMs, then the softmax backward ----
+        # o_pt (global frame) = P[b,h] VP[b,:,h,:]  -> g_opt buffer; pf_ipa_bwd_opt turns it into its gradient (+ frame gradients)
+        _gemm(P, L, 1, sv["vp"], 288, 1, g_opt, L, 36, L, ldc=288, batch=(B, 8, bAh, (L * 288, 36), (L * 288, 36)))
+        _capi.check(lib.pf_ipa_bwd_opt(C.byref(a), st), "pf_ipa_bwd_opt")
+        # g_P[b,h,i,j] = g_o[b,i,h,:] . V[b,j,h,:]  +  g_opt[b,i,h,:] . VP[b,j,h,:]  +  (W_dz^T g_o_pair[b,i,h]) . z[b,i,j]
+        _gemm(g_feats, 1536, 1, sv["proj"], 1, ldp, gA, L, L, 128, ldc=L, b_off=1024 + 128, batch=(B, 8, (L * 1536, 128), (L * ldp, 256), bAh))
+        _gemm(g_opt, 288, 1, sv["vp"], 1, 288, gA, L, L, 36, accumulate=True, ldc=L, batch=(B, 8, (L * 288, 36), (L * 288, 36), bAh))
+        _capi.check(lib.pf_ipa_bwd_pairterm(C.byref(a), st), "pf_ipa_bwd_pairterm")
+        _capi.check(lib.pf_ipa_bwd_softmax(C.byref(a), st), "pf_ipa_bwd_softmax")
+        _capi.check(lib.pf_ipa_bwd_pairs(C.byref(a), st), "pf_ipa_bwd_pairs")
         # g_q[b,i,h,:] = s_qk gA[b,h] K[b,:,h,:]            (A: [L x L] row-major; B(k=j, n=c) = proj[(b,j), 1024 + 256 h + c])
         _gemm(gA, L, 1, sv["proj"], ldp, 1, g_proj, L, 128, L, alpha=S_QK, ldc=ldp, b_off=1024, batch=(B, 8, bAh, (L * ldp, 256), (L * ldp, 128)))
         # g_k[b,j,h,:] = s_qk gA[b,h]^T Q[b,:,h,:]

@@ -350,6 +350,14 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
         }
     }
     __syncthreads();
+    if (a.p_out) {                                  // training forward: keep the probabilities for the backward
+        for (int idx = tid; idx < TI * HG * LP; idx += 64 * NW) {
+            const int rr = idx / LP, j = idx - rr * LP;
+            const int ti = rr / HG, hh = rr - ti * HG;
+            if (i0 + ti < L && j < L)
+                a.p_out[(((size_t)b * 8 + h0 + hh) * L + i0 + ti) * L + j] = S[rr * LDS_S + j];
+        }
+    }
 
     PROF(4);
     // ---- phase C: [o | o_pt] = P [V | Vp] on MFMA ----

@@ -160,47 +160,74 @@ __global__ __launch_bounds__(256) void ipa_bwd_rows_kernel(pf_ipa_bwd_args a, in
     }
 }
 
+// 64 consecutive pairs per workgroup.  Phase A: thread (pair, quarter) forms g_bias (2 heads) and g_pz (4 components) into
+// LDS (reads of gA / P coalesced over the pairs); phase B: 16 lanes per pair write g_z as float4 (256 B per pair contiguous)
+// -- one thread per pair writing 64 floats one by one made every store instruction touch 64 different lines.
 __global__ __launch_bounds__(256) void ipa_bwd_pairs_kernel(pf_ipa_bwd_args a) {
-    const long long pair = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int L = a.L;
+    __shared__ __attribute__((aligned(16))) float GB[64 * 8];
+    __shared__ __attribute__((aligned(16))) float GZ[64 * 16];
+    const int tid = threadIdx.x, L = a.L;
     const long long npairs = (long long)a.B * L * L;
-    if (pair >= npairs) return;
-    const int b = (int)(pair / ((long long)L * L));
-    const int rem = (int)(pair - (long long)b * L * L);
-    const int i = rem / L, j = rem - i * L;
-    float gb[8], gpz[16];
+    const long long p0 = (long long)blockIdx.x * 64;
+    {
+        const int pl = tid & 63, q = tid >> 6;
+        const long long pair = p0 + pl;
+        if (pair < npairs) {
+            const int b = (int)(pair / ((long long)L * L));
+            const int rem = (int)(pair - (long long)b * L * L);
+            const int i = rem / L, j = rem - i * L;
+            const float* gf = a.g_feats + ((size_t)b * L + i) * PF_IPA_FEATS + 1408;
+            float gpz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int d = 0; d < 16; ++d) gpz[d] = 0.f;
-    const float* gf = a.g_feats + ((size_t)b * L + i) * PF_IPA_FEATS + 1408;
+            for (int h = 0; h < 8; ++h) {
+                const size_t o = (((size_t)b * H + h) * L + i) * L + j;
+                const float pr = a.P[o];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-        const size_t o = (((size_t)b * H + h) * L + i) * L + j;
-        gb[h] = S_13 * a.gA[o];
-        const float p = a.P[o];
+                for (int d = 0; d < 4; ++d) gpz[d] += pr * gf[h * 16 + 4 * q + d];
+                if ((h >> 1) == q) GB[pl * 8 + h] = S_13 * a.gA[o];
+            }
 #pragma unroll
-        for (int d = 0; d < 16; ++d) gpz[d] += p * gf[h * 16 + d];
+            for (int d = 0; d < 4; ++d) GZ[pl * 16 + 4 * q + d] = gpz[d];
+        }
     }
+    __syncthreads();
+    const long long nvalid = min((long long)64, npairs - p0);
+    // g_bias [pairs,8] and g_pz [pairs,16]: contiguous for the 64 pairs
+    if (tid < 128 && (tid >> 1) < nvalid) *reinterpret_cast<float4*>(a.g_bias + p0 * 8 + 4 * tid) = *reinterpret_cast<const float4*>(GB + 4 * tid);
+    if ((tid >> 2) < nvalid) *reinterpret_cast<float4*>(a.g_pz + p0 * 16 + 4 * tid) = *reinterpret_cast<const float4*>(GZ + 4 * tid);
+    const int c4 = tid & 15;
+    float4 wb[8], wz[16];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) a.g_bias[pair * 8 + h] = gb[h];
+    for (int h = 0; h < 8; ++h) wb[h] = *reinterpret_cast<const float4*>(a.w_b + h * 64 + 4 * c4);
 #pragma unroll
-    for (int d = 0; d < 16; ++d) a.g_pz[pair * 16 + d] = gpz[d];
-    float* gz = a.g_z + pair * 64;
-    for (int c = 0; c < 64; ++c) {
-        float acc = 0.f;
+    for (int d = 0; d < 16; ++d) wz[d] = *reinterpret_cast<const float4*>(a.w_dz + d * 64 + 4 * c4);
+    for (int pl = tid >> 4; pl < nvalid; pl += 16) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int h = 0; h < 8; ++h) acc += a.w_b[h * 64 + c] * gb[h];
+        for (int h = 0; h < 8; ++h) {
+            const float g = GB[pl * 8 + h];
+            acc.x += wb[h].x * g; acc.y += wb[h].y * g; acc.z += wb[h].z * g; acc.w += wb[h].w * g;
+        }
 #pragma unroll
-        for (int d = 0; d < 16; ++d) acc += a.w_dz[d * 64 + c] * gpz[d];
-        gz[c] = acc + (a.accumulate_gz ? gz[c] : 0.f);
+        for (int d = 0; d < 16; ++d) {
+            const float g = GZ[pl * 16 + d];
+            acc.x += wz[d].x * g; acc.y += wz[d].y * g; acc.z += wz[d].z * g; acc.w += wz[d].w * g;
+        }
+        float4* dst = reinterpret_cast<float4*>(a.g_z + (p0 + pl) * 64 + 4 * c4);
+        if (a.accumulate_gz) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        *dst = acc;
     }
 }
 
-// one thread per residue: global point gradients -> raw projection gradients + frame gradients
-__global__ __launch_bounds__(64) void ipa_bwd_points_kernel(pf_ipa_bwd_args a) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+// one thread per (sample, head, residue) with the residue fastest: the column sums c_hj = sum_i g_a_hij are then coalesced
+// reads, the raw-projection gradients are disjoint per head, and the frame gradients of the 8 heads are added atomically
+// (one thread per residue looping over the heads ran 32 workgroups of one wave each: 330 us)
+__global__ __launch_bounds__(256) void ipa_bwd_points_kernel(pf_ipa_bwd_args a) {
     const int L = a.L;
-    if (r >= a.B * L) return;
-    const int b = r / L, j = r - b * L;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)a.B * H * L) return;
+    const int b = (int)(t / (H * L)), rem = (int)(t - (long long)b * H * L), h = rem / L, j = rem - h * L;
+    const int r = b * L + j;
     const float* R = a.rot + (size_t)r * 9;
     float gx[3] = {0.f, 0.f, 0.f}, gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float* gproj = a.g_proj + (size_t)r * a.ldp;
@@ -215,46 +242,164 @@ __global__ __launch_bounds__(64) void ipa_bwd_points_kernel(pf_ipa_bwd_args a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) graw[k] = R[k] * gp[0] + R[3 + k] * gp[1] + R[6 + k] * gp[2];
     };
-    for (int h = 0; h < H; ++h) {
-        const float gamma = softplusf(a.head_w[h]) * S_PT;
-        float csum = 0.f;                                   // c_hj = sum_i g_a_hij
-        const float* ga = a.gA + (((size_t)b * H + h) * L) * L + j;
-        for (int i = 0; i < L; ++i) csum += ga[(size_t)i * L];
-        for (int p = 0; p < PQ; ++p) {
-            // query points: g = gamma * (g_a KP)
-            float gp[3], raw[3], gr[3];
-            const int qi = h * PQ + p;                      // index inside an x/y/z block of linear_q_points (64 wide)
+    const float gamma = softplusf(a.head_w[h]) * S_PT;
+    float csum = 0.f;                                       // c_hj = sum_i g_a_hij
+    const float* ga = a.gA + (((size_t)b * H + h) * L) * L + j;
+    for (int i = 0; i < L; ++i) csum += ga[(size_t)i * L];
+    for (int p = 0; p < PQ; ++p) {
+        // query points: g = gamma * (g_a KP)
+        float gp[3], raw[3], gr[3];
+        const int qi = h * PQ + p;                          // index inside an x/y/z block of linear_q_points (64 wide)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) { gp[m] = gamma * a.g_qp[(size_t)r * 192 + h * 24 + p * 3 + m]; raw[m] = praw[3072 + m * 64 + qi]; }
-            one_point(gp, raw, gr);
+        for (int m = 0; m < 3; ++m) { gp[m] = gamma * a.g_qp[(size_t)r * 192 + h * 24 + p * 3 + m]; raw[m] = praw[3072 + m * 64 + qi]; }
+        one_point(gp, raw, gr);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) gproj[3072 + m * 64 + qi] = gr[m];
-            // key points: g = gamma * (g_a^T QP - c kp)
-            const int ki = h * (PQ + PV) + p;               // index inside a block of linear_kv_points (160 wide)
+        for (int m = 0; m < 3; ++m) gproj[3072 + m * 64 + qi] = gr[m];
+        // key points: g = gamma * (g_a^T QP - c kp)
+        const int ki = h * (PQ + PV) + p;                   // index inside a block of linear_kv_points (160 wide)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                gp[m] = gamma * (a.g_kp[(size_t)r * 192 + h * 24 + p * 3 + m] - csum * a.kp[(size_t)r * 192 + h * 24 + p * 3 + m]);
-                raw[m] = praw[3264 + m * 160 + ki];
-            }
-            one_point(gp, raw, gr);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) gproj[3264 + m * 160 + ki] = gr[m];
+        for (int m = 0; m < 3; ++m) {
+            gp[m] = gamma * (a.g_kp[(size_t)r * 192 + h * 24 + p * 3 + m] - csum * a.kp[(size_t)r * 192 + h * 24 + p * 3 + m]);
+            raw[m] = praw[3264 + m * 160 + ki];
         }
-        for (int p = 0; p < PV; ++p) {
-            float gp[3], raw[3], gr[3];
-            const int vi = h * (PQ + PV) + PQ + p;
+        one_point(gp, raw, gr);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) { gp[m] = a.g_vp[(size_t)r * 288 + h * 36 + p * 3 + m]; raw[m] = praw[3264 + m * 160 + vi]; }
-            one_point(gp, raw, gr);
+        for (int m = 0; m < 3; ++m) gproj[3264 + m * 160 + ki] = gr[m];
+    }
+    for (int p = 0; p < PV; ++p) {
+        float gp[3], raw[3], gr[3];
+        const int vi = h * (PQ + PV) + PQ + p;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) gproj[3264 + m * 160 + vi] = gr[m];
+        for (int m = 0; m < 3; ++m) { gp[m] = a.g_vp[(size_t)r * 288 + h * 36 + p * 3 + m]; raw[m] = praw[3264 + m * 160 + vi]; }
+        one_point(gp, raw, gr);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) gproj[3264 + m * 160 + vi] = gr[m];
+    }
+    float* o = a.g_frame_rows + (size_t)r * 12;             // accumulated onto the row stage's share
+#pragma unroll
+    for (int m = 0; m < 3; ++m) atomicAdd(o + m, gx[m]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) atomicAdd(o + 3 + k, gR[k]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The row stage from SAVED probabilities (pf_ipa_attn_fwd, p_out) + batched GEMMs issued by the host: the recomputing row
+// kernel above walks K / V / z of the sample with one thread per (head, key) against L2 (~680 us per block at B=16,
+// L=128); the three contractions that form g_P are plain [L x c] x [c x L] products and run on the MFMA GEMM instead.
+
+// pf_ipa_bwd_opt: one wave per residue row.  On entry g_opt[row, 288] = o_pt in the GLOBAL frame (= sum_j P vp); on return
+// the gradient w.r.t. it; g_frame_rows[row, 12] = frame gradients of local = R^T (o_pt - x) incl. the norm term.
+__global__ __launch_bounds__(256) void ipa_bwd_opt_kernel(pf_ipa_bwd_args a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.B * a.L) return;
+    const float* gf = a.g_feats + (size_t)row * PF_IPA_FEATS;
+    const float* Ri = a.rot + (size_t)row * 9;
+    const float* xi = a.trans + (size_t)row * 3;
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Ri[k];
+    const float x0 = xi[0], x1 = xi[1], x2 = xi[2];
+    float fr[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* op = a.g_opt + (size_t)row * 288;
+    for (int hp = lane; hp < H * PV; hp += 64) {
+        const float d[3] = {op[hp * 3] - x0, op[hp * 3 + 1] - x1, op[hp * 3 + 2] - x2};
+        const float lx = R[0] * d[0] + R[3] * d[1] + R[6] * d[2];
+        const float ly = R[1] * d[0] + R[4] * d[1] + R[7] * d[2];
+        const float lz = R[2] * d[0] + R[5] * d[1] + R[8] * d[2];
+        const float nrm = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+        const float gn = gf[1312 + hp] / nrm;
+        const float gl[3] = {gf[1024 + hp] + gn * lx, gf[1120 + hp] + gn * ly, gf[1216 + hp] + gn * lz};
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const float go = R[m * 3] * gl[0] + R[m * 3 + 1] * gl[1] + R[m * 3 + 2] * gl[2];   // g_opt (global), component m
+            op[hp * 3 + m] = go;
+            fr[m] -= go;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fr[3 + m * 3 + k] += d[m] * gl[k];
         }
     }
-    float* o = a.g_frame_rows + (size_t)r * 12;             // accumulated onto the rows kernel's share
 #pragma unroll
-    for (int m = 0; m < 3; ++m) o[m] += gx[m];
+    for (int k = 0; k < 12; ++k) fr[k] = wave_sum(fr[k]);
+    if (lane == 0) {
+        float* o = a.g_frame_rows + (size_t)row * 12;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[3 + k] += gR[k];
+        for (int k = 0; k < 12; ++k) o[k] = fr[k];
+    }
+}
+
+// pf_ipa_bwd_pairterm: one workgroup per query row (b, i):  gA[b,h,i,j] += u_h . z_ij,  u_h = W_dz^T g_o_pair[h]  (the
+// b_dz term is constant over j and drops out of the softmax backward).  16 lanes per pair, one float4 of z each.
+__global__ __launch_bounds__(256) void ipa_bwd_pairterm_kernel(pf_ipa_bwd_args a) {
+    __shared__ __attribute__((aligned(16))) float U[H * 64];
+    __shared__ float T[H * 16 * 17];                    // [h][pair of the pass][.] staging of the 16-lane partial sums
+    const int tid = threadIdx.x, L = a.L;
+    const int row = blockIdx.x, b = row / L, i = row - b * L;
+    const float* gf = a.g_feats + (size_t)row * PF_IPA_FEATS + 1408;
+    for (int o = tid; o < H * 64; o += 256) {
+        const int h = o >> 6, c = o & 63;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc += a.w_dz[d * 64 + c] * gf[h * 16 + d];
+        U[o] = acc;
+    }
+    __syncthreads();
+    const int pl = tid >> 4, c4 = tid & 15;
+    float4 u[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) u[h] = *reinterpret_cast<const float4*>(U + h * 64 + 4 * c4);
+    const float* zi = a.z + ((size_t)row * L) * 64;
+    for (int j0 = 0; j0 < L; j0 += 16) {
+        const int j = j0 + pl;
+        const float4 zv = *reinterpret_cast<const float4*>(zi + (size_t)(j < L ? j : L - 1) * 64 + 4 * c4);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float v = u[h].x * zv.x + u[h].y * zv.y + u[h].z * zv.z + u[h].w * zv.w;
+            v = row16_sum(v);
+            if (c4 == h) T[(h * 16 + pl) * 17] = v;    // (after row16_sum every lane of the 16 holds the sum)
+        }
+        __syncthreads();
+        if (tid < H * 16) {
+            const int h = tid >> 4, jj = j0 + (tid & 15);
+            if (jj < L) a.gA[(((size_t)b * H + h) * L + i) * L + jj] += T[(h * 16 + (tid & 15)) * 17];
+        }
+        __syncthreads();
+    }
+}
+
+// pf_ipa_bwd_softmax: one wave per (b, h, i):  g_a = P (g_P - sum_j P g_P) in place in gA;  g_gamma_rows[(b,i), h] =
+// -1/2 sum_j g_a sum_p |qp_i - kp_j|^2
+__global__ __launch_bounds__(256) void ipa_bwd_softmax_kernel(pf_ipa_bwd_args a) {
+    const int L = a.L;
+    const long long wr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wr >= (long long)a.B * H * L) return;
+    const int b = (int)(wr / (H * L)), rem = (int)(wr - (long long)b * H * L), h = rem / L, i = rem - h * L;
+    const size_t o = (((size_t)b * H + h) * L + i) * L;
+    const float* P = a.P + o;
+    float* gA = a.gA + o;
+    float dl = 0.f;
+    for (int j = lane; j < L; j += 64) dl += P[j] * gA[j];
+    dl = wave_sum(dl);
+    float q[24];
+    const float* qp = a.qp + ((size_t)b * L + i) * 192 + h * 24;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) q[c] = qp[c];
+    float gg = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float ga = P[j] * (gA[j] - dl);
+        gA[j] = ga;
+        const float* kp = a.kp + ((size_t)b * L + j) * 192 + h * 24;
+        float d2 = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 6; ++c4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kp + 4 * c4);
+            const float d0 = q[4 * c4] - k4.x, d1 = q[4 * c4 + 1] - k4.y, dd = q[4 * c4 + 2] - k4.z, d3 = q[4 * c4 + 3] - k4.w;
+            d2 += d0 * d0; d2 += d1 * d1; d2 += dd * dd; d2 += d3 * d3;
+        }
+        gg += ga * d2;
+    }
+    gg = wave_sum(gg);
+    if (lane == 0) a.g_gamma_rows[((size_t)b * L + i) * 8 + h] = -0.5f * gg;
 }
 
 __global__ void ipa_headw_bwd_kernel(const float* g_gamma, const float* head_w, float* g_head_w) {
@@ -283,17 +428,37 @@ extern "C" int pf_ipa_bwd_rows(const pf_ipa_bwd_args* a, pf_stream_t stream) {
     PF_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int pf_ipa_bwd_opt(const pf_ipa_bwd_args* a, pf_stream_t stream) {
+    if (!args_ok(a) || !a->g_opt || !a->g_frame_rows) return PF_E_BADARG;
+    const int rows = a->B * a->L;
+    hipLaunchKernelGGL(ipa_bwd_opt_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_ipa_bwd_pairterm(const pf_ipa_bwd_args* a, pf_stream_t stream) {
+    if (!args_ok(a)) return PF_E_BADARG;
+    hipLaunchKernelGGL(ipa_bwd_pairterm_kernel, dim3((unsigned)(a->B * a->L)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_ipa_bwd_softmax(const pf_ipa_bwd_args* a, pf_stream_t stream) {
+    if (!args_ok(a) || !a->g_gamma_rows) return PF_E_BADARG;
+    const long long nrow = (long long)a->B * H * a->L;
+    hipLaunchKernelGGL(ipa_bwd_softmax_kernel, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" int pf_ipa_bwd_pairs(const pf_ipa_bwd_args* a, pf_stream_t stream) {
     if (!args_ok(a) || !a->g_bias || !a->g_pz || !a->g_z) return PF_E_BADARG;
     const long long npairs = (long long)a->B * a->L * a->L;
-    hipLaunchKernelGGL(ipa_bwd_pairs_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(ipa_bwd_pairs_kernel, dim3((unsigned)((npairs + 63) / 64)), dim3(256), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int pf_ipa_bwd_points(const pf_ipa_bwd_args* a, pf_stream_t stream) {
     if (!args_ok(a) || !a->g_qp || !a->g_kp || !a->g_vp || !a->g_proj || !a->g_frame_rows) return PF_E_BADARG;
-    const int rows = a->B * a->L;
-    hipLaunchKernelGGL(ipa_bwd_points_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *a);
+    const long long nt = (long long)a->B * H * a->L;
+    hipLaunchKernelGGL(ipa_bwd_points_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;
 }
