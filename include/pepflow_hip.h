@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 17
+#define PF_ABI_VERSION 18
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -70,7 +70,10 @@ typedef struct {
     const float* residual; int ldr; /* [M, ldr] or NULL */
     const float* ln_gamma; const float* ln_beta; float ln_eps; /* NULL = no LayerNorm */
     const void* w_f16;              /* optional: W pre-split into fragment-order f16 hi/lo planes (engine.split_f16);
-                                       selects the split-precision MFMA path (bias / ReLU / row mask only, K % 32 == 0) */
+                                       selects the split-precision MFMA path (bias / ReLU / row mask / gate / residual,
+                                       K % 32 == 0, no LayerNorm) */
+    const float* gate; int ldg;     /* split path only, optional: y = gate[m,n] > 0 ? y : 0 before the residual is added
+                                       (backward of a ReLU fused into the dx product of the training path) */
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 
@@ -389,6 +392,8 @@ int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int
                     int accumulate, float* colsum_a, int colsum_accumulate, pf_stream_t stream);
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
 int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);                                /* dy *= (y > 0) */
+int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream);            /* dst = y > 0 ? src : 0 */
+int pf_add_out(const float* a, const float* b, float* dst, long long n, pf_stream_t stream);                 /* dst = a + b */
 /* nn.LayerNorm backward over the last dimension (N <= 256, eps 1e-5): dx; dgamma_rows[m,n] = dy xhat (optional;
  * dgamma = column sum of it, dbeta = column sum of dy -- pf_colsum_f32). */
 typedef struct { const float* x; const float* dy; const float* gamma; float* dx; float* dgamma_rows; int M, N; } pf_layernorm_bwd_args;

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -21,7 +21,7 @@ class LinearArgs(C.Structure):
     _fields_ = [("x", _fp), ("ldx", _i), ("w", _fp), ("ldw", _i), ("bias", _fp), ("y", _fp), ("ldy", _i),
                 ("M", _i), ("N", _i), ("K", _i), ("relu", _i), ("row_mask", _fp), ("mask_pre", _i),
                 ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
-                ("ln_eps", C.c_float), ("w_f16", _fp)]
+                ("ln_eps", C.c_float), ("w_f16", _fp), ("gate", _fp), ("ldg", _i)]
 
 
 class EmbedArgs(C.Structure):
@@ -171,6 +171,8 @@ _SIGNATURES = {
     "pf_colsum_f32": ([_fp, _i, _i, _i, _fp, _i, _fp], _i),
     "pf_gemm_tn_wide": ([_fp, _i, _i, _fp, _i, _i, _fp, _i, C.c_longlong, _i, _fp, _i, _fp], _i),
     "pf_relu_bwd": ([_fp, _fp, C.c_longlong, _fp], _i),
+    "pf_relu_gate": ([_fp, _fp, _fp, C.c_longlong, _fp], _i),
+    "pf_add_out": ([_fp, _fp, _fp, C.c_longlong, _fp], _i),
     "pf_layernorm_bwd": ([C.POINTER(LayerNormBwdArgs), _fp], _i),
     "pf_layernorm_fwd": ([_fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_row_mask": ([_fp, _fp, _i, _i, _fp], _i),

@@ -32,7 +32,7 @@ def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, l
 SPLIT_MIN_ROWS = 8192          # pair-sized products go to the split-precision kernel of the inference path
 
 
-def _linear_split(x, w, b=None, relu=False):
+def _linear_split(x, w, b=None, relu=False, gate=None, residual=None):
     """y = relu?(x W^T + b) on the split-precision f16 MFMA kernel (csrc/linear.hip, fp32-level accuracy): ~2.3x the rate
     of the fp32-MFMA GEMM on the [B*L*L, 192] products of EdgeTransition.  w: [N, K] fp32, K % 32 == 0, K <= 512."""
     from .engine import split_f16
@@ -44,8 +44,25 @@ def _linear_split(x, w, b=None, relu=False):
     a.x, a.ldx, a.w, a.ldw, a.w_f16 = x.data_ptr(), K, w.data_ptr(), K, w16.data_ptr()
     a.bias = b.data_ptr() if b is not None else None
     a.y, a.ldy, a.M, a.N, a.K, a.relu = y.data_ptr(), N, M, N, K, int(relu)
+    if gate is not None:                                        # y = gate > 0 ? y : 0   (ReLU backward fused into the product)
+        a.gate, a.ldg = gate.data_ptr(), N
+    if residual is not None:
+        a.residual, a.ldr = residual.data_ptr(), N
     _capi.check(_capi.load().pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
     return y
+
+
+def relu_gate(y, src):
+    """dst = src * (y > 0), out of place (one pass instead of clone + in-place)."""
+    dst = torch.empty_like(src)
+    _capi.check(_capi.load().pf_relu_gate(y.data_ptr(), src.data_ptr(), dst.data_ptr(), src.numel(), _capi.stream_ptr()), "pf_relu_gate")
+    return dst
+
+
+def add_out(a, b):
+    dst = torch.empty_like(a)
+    _capi.check(_capi.load().pf_add_out(a.data_ptr(), b.data_ptr(), dst.data_ptr(), a.numel(), _capi.stream_ptr()), "pf_add_out")
+    return dst
 
 
 def _split_ok(M, K):
@@ -56,8 +73,8 @@ def linear_fwd(x, w, b=None, relu=False, residual=None):
     """y = relu?(x W^T + b) + residual in ONE launch of the fp32 GEMM (the saved-activation forward of the training path)."""
     M, K = x.shape
     N = w.shape[0]
-    if residual is None and _split_ok(M, K) and w.is_contiguous():
-        return _linear_split(x, w, b, relu)
+    if _split_ok(M, K) and w.is_contiguous() and (residual is None or N % 4 == 0):
+        return _linear_split(x, w, b, relu, residual=residual)
     y = torch.empty(M, N, device=x.device)
     a = _capi.GemmArgs()
     a.A, a.sam, a.sak, a.B, a.sbk, a.sbn = x.data_ptr(), K, 1, w.data_ptr(), 1, K
@@ -70,18 +87,24 @@ def linear_fwd(x, w, b=None, relu=False, residual=None):
     return y
 
 
-def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None):
-    """Gradients of y = x W^T + b: dx = dy W, dW (+)= dy^T x, db (+)= colsum(dy).  dW/db given -> accumulated into."""
+def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residual=None):
+    """Gradients of y = x W^T + b: dx = dy W, dW (+)= dy^T x, db (+)= colsum(dy).  dW/db given -> accumulated into.
+    dx_gate / dx_residual: dx = (dy W) * (dx_gate > 0) + dx_residual (ReLU backward / skip connection fused; pair-sized
+    products fuse them into the GEMM epilogue)."""
     lib = _capi.load()
     M, K = x.shape
     N = w.shape[0]
     dx = None
     if need_dx:
-        if _split_ok(M, N) and dy.is_contiguous():
-            dx = _linear_split(dy, w.t().contiguous())          # dx = dy W = dy (W^T)^T
+        if _split_ok(M, N) and dy.is_contiguous() and K % 4 == 0:
+            dx = _linear_split(dy, w.t().contiguous(), gate=dx_gate, residual=dx_residual)     # dx = dy W = dy (W^T)^T
         else:
             dx = torch.empty(M, K, device=x.device)
             _gemm(dy, N, 1, w, K, 1, dx, M, K, N)
+            if dx_gate is not None:
+                relu_bwd_(dx_gate, dx)
+            if dx_residual is not None:
+                add_(dx, dx_residual)
     acc = dW is not None
     if dW is None:
         dW = torch.empty(N, K, device=x.device)
@@ -384,7 +407,7 @@ class EdgeTransitionBlock:
         _capi.check(lib.pf_et_concat(z.data_ptr(), n.data_ptr(), self.mask.data_ptr(), x.data_ptr(), em.data_ptr(), B, L, _capi.stream_ptr()), "pf_et_concat")
         h1 = linear_fwd(x, W[p + "trunk.0.weight"], W[p + "trunk.0.bias"], relu=True)
         h2 = linear_fwd(h1, W[p + "trunk.2.weight"], W[p + "trunk.2.bias"], relu=True)
-        u = add_(h2.clone(), x)                                  # final_layer(h2 + x)
+        u = add_out(h2, x)                                       # final_layer(h2 + x)
         y = linear_fwd(u, W[p + "final_layer.weight"], W[p + "final_layer.bias"])
         out = row_mask_(layernorm_fwd(y, W[p + "layer_norm.weight"], W[p + "layer_norm.bias"]), em)
         self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, u=u, y=y)
@@ -397,13 +420,9 @@ class EdgeTransitionBlock:
         g = row_mask_(g_out.clone(), sv["em"])
         g_y, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"] = layernorm_bwd(sv["y"], W[p + "layer_norm.weight"], g)
         g_u, G[p + "final_layer.weight"], G[p + "final_layer.bias"] = linear_bwd(sv["u"], W[p + "final_layer.weight"], g_y)
-        g_h2 = g_u.clone()
-        g_x = g_u                                                # skip connection h2 + x
-        relu_bwd_(sv["h2"], g_h2)
-        g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2)
-        relu_bwd_(sv["h1"], g_h1)
-        g_x1, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1)
-        add_(g_x, g_x1)
+        g_h2 = relu_gate(sv["h2"], g_u)                          # g_u also flows through the skip connection h2 + x
+        g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, dx_gate=sv["h1"])
+        g_x, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, dx_residual=g_u)
         acc = g_z is not None
         if g_z is None:
             g_z = torch.empty(B * L * L, 64, device=g_out.device)
@@ -579,10 +598,8 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     G["node_embedder.aatype_embed.weight"] = tg
     # ---- edge embedder
     ge = row_mask_(g_edge.clone(), mp)
-    g_o2, G["edge_embedder.out_mlp.4.weight"], G["edge_embedder.out_mlp.4.bias"] = linear_bwd(saved["o2"], w("edge_embedder.out_mlp.4.weight"), ge)
-    relu_bwd_(saved["o2"], g_o2)
-    g_o1, G["edge_embedder.out_mlp.2.weight"], G["edge_embedder.out_mlp.2.bias"] = linear_bwd(saved["o1"], w("edge_embedder.out_mlp.2.weight"), g_o2)
-    relu_bwd_(saved["o1"], g_o1)
+    g_o2, G["edge_embedder.out_mlp.4.weight"], G["edge_embedder.out_mlp.4.bias"] = linear_bwd(saved["o2"], w("edge_embedder.out_mlp.4.weight"), ge, dx_gate=saved["o2"])
+    g_o1, G["edge_embedder.out_mlp.2.weight"], G["edge_embedder.out_mlp.2.bias"] = linear_bwd(saved["o1"], w("edge_embedder.out_mlp.2.weight"), g_o2, dx_gate=saved["o1"])
     wo0 = w("edge_embedder.out_mlp.0.weight")                   # [64,218]; the concat tile is 224 wide
     g_cat = e(P, 224)
     _gemm(g_o1, 64, 1, wo0, 218, 1, g_cat, P, 218, 64, ldc=224)
@@ -598,8 +615,7 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     g_fd = e(P, 64)
     _capi.check(lib.pf_slice_relu_mask(g_cat.data_ptr(), 224, 128, saved["cat"].data_ptr(), 224, 128, sp.data_ptr(), g_fd.data_ptr(), P, 64, st),
                 "pf_slice_relu_mask")
-    g_h1, G["edge_embedder.distance_embed.2.weight"], G["edge_embedder.distance_embed.2.bias"] = linear_bwd(saved["h1"], w("edge_embedder.distance_embed.2.weight"), g_fd)
-    relu_bwd_(saved["h1"], g_h1)
+    g_h1, G["edge_embedder.distance_embed.2.weight"], G["edge_embedder.distance_embed.2.bias"] = linear_bwd(saved["h1"], w("edge_embedder.distance_embed.2.weight"), g_fd, dx_gate=saved["h1"])
     g_g, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], w("edge_embedder.distance_embed.0.weight"), g_h1)
     t_c = _zeros(484, 225, device=dev)
     _capi.check(lib.pf_edge_distcoef_bwd(g_g.data_ptr(), saved["g"].data_ptr(), saved["d2"].data_ptr(), aap.data_ptr(),

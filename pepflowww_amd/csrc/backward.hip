@@ -249,6 +249,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int
     }
 }
 
+__global__ __launch_bounds__(256) void relu_gate_kernel(const float4* y, const float4* src, float4* dst, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = y[i], v = src[i];
+    dst[i] = make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
+}
+__global__ __launch_bounds__(256) void add_out_kernel(const float4* a, const float4* b, float4* dst, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = a[i], y = b[i];
+    dst[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* y, float* dy, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
@@ -831,6 +843,20 @@ extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, i
     long long per = ((R + nwg - 1) / nwg + WK - 1) / WK * WK;
     nwg = (R + per - 1) / per;
     hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3((unsigned)nwg), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream) {
+    if (!y || !src || !dst || n <= 0 || (n & 3) || (((uintptr_t)y | (uintptr_t)src | (uintptr_t)dst) & 15)) return PF_E_BADARG;
+    hipLaunchKernelGGL(relu_gate_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pf_add_out(const float* a, const float* b, float* dst, long long n, pf_stream_t stream) {
+    if (!a || !b || !dst || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) & 15)) return PF_E_BADARG;
+    hipLaunchKernelGGL(add_out_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(dst), n / 4);
     PF_CHECK_LAUNCH();
     return 0;
 }

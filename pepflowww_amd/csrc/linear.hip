@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int
             const int n = n0 + wt * 16 + 4 * g + e;
             bias4[wt][e] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
         }
-    const bool vec_ok = (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
+    const bool vec_ok = (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0) &&
+                        (!p.residual || (p.ldr % 4 == 0 && ((uintptr_t)p.residual & 15) == 0)) &&
+                        (!p.gate || (p.ldg % 4 == 0 && ((uintptr_t)p.gate & 15) == 0));
     f32x4 am[2][4], ac[2][4];
     acc_zero<2, 4>(am);
     acc_zero<2, 4>(ac);
@@ -241,10 +243,24 @@ __global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int
                 }
                 float* dst = p.y + (size_t)m * p.ldy + n;
                 if (vec_ok && n + 3 < p.N) {             // one 16-byte store per lane (the store tail is issue-bound)
+                    if (p.gate) {
+                        const float4 gt = *reinterpret_cast<const float4*>(p.gate + (size_t)m * p.ldg + n);
+                        v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f; v[2] = gt.z > 0.f ? v[2] : 0.f; v[3] = gt.w > 0.f ? v[3] : 0.f;
+                    }
+                    if (p.residual) {
+                        const float4 rs = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
+                        v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                    }
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < p.N) dst[e] = v[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) {
+                            float t = v[e];
+                            if (p.gate) t = p.gate[(size_t)m * p.ldg + n + e] > 0.f ? t : 0.f;
+                            if (p.residual) t += p.residual[(size_t)m * p.ldr + n + e];
+                            dst[e] = t;
+                        }
                 }
             }
         }
@@ -262,7 +278,7 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
     if (a->ln_gamma && (a->N > BN || !a->ln_beta)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (a->w_f16) {                                   // split-precision path: plain Linear (+bias, ReLU, row mask)
-        if (a->K % 32 || a->residual || a->ln_gamma || a->K > 512) return PF_E_BADARG;   // x tile [64][K] must fit LDS
+        if (a->K % 32 || a->ln_gamma || a->K > 512) return PF_E_BADARG;   // x tile [64][K] must fit LDS
         const int Npad = (a->N + 15) / 16 * 16;
         dim3 grid((a->M + SP_BM - 1) / SP_BM, (Npad + SP_BN - 1) / SP_BN);
         const size_t lds = (size_t)2 * SP_BM * (a->K + 8) * sizeof(_Float16);
