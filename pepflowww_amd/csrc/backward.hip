@@ -420,7 +420,10 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(const float* qkv, con
 // Same computation with q / k / v / g_o of the (sample, head) staged in LDS (L <= 256: 4 x L x 33 floats) and TPR threads per
 // query / key row, each owning 32 / TPR of the head's features (partial dot products are combined with lane shuffles).
 // The global-memory form above ran one thread per row against L2: 450 us per call at B=16, L=128 (2 waves per workgroup).
-template <int TPR>
+// PASS 0: pass A for the query rows of chunk blockIdx.y (stats + g_q); PASS 1: pass B for the key rows of chunk blockIdx.y
+// (g_k, g_v; reads the stats of ALL queries, so it is a second launch).  One launch per pass with gridDim.y row chunks
+// instead of one workgroup per (sample, head) doing both: 64 workgroups -> 2 x 256 at B=16.
+template <int TPR, int PASS>
 __global__ __launch_bounds__(256) void seq_attn_bwd_lds_kernel(const float* qkv, const float* mask, const float* g_out, float* g_qkv,
                                                                float* stats, int B, int L) {
     constexpr int FC = AD / TPR, LDR = AD + 1;
@@ -451,11 +454,15 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_lds_kernel(const float* qkv,
     auto rsum = [](float v) {                      // sum over the TPR lanes of a row
         if (TPR >= 2) v += __shfl_xor(v, 1);
         if (TPR >= 4) v += __shfl_xor(v, 2);
+        if (TPR >= 8) v += __shfl_xor(v, 4);
         return v;
     };
     const int sub = threadIdx.x % TPR, c0 = sub * FC;
+    const int rows_per = (L + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int rbeg = (int)blockIdx.y * rows_per, rend = min(L, rbeg + rows_per);
     // pass A: per query i -- row max, 1 / sum, delta_i = sum_j p_ij (g_o_i . v_j), g_q_i
-    for (int i0 = 0; i0 < L; i0 += 256 / TPR) {
+    if (PASS == 0)
+    for (int i0 = rbeg; i0 < rend; i0 += 256 / TPR) {
         const int i = i0 + threadIdx.x / TPR;
         const int ic = i < L ? i : L - 1;             // (all lanes stay in the loops: the shuffles need their partners)
         float q[FC], go[FC], gq[FC];
@@ -488,16 +495,15 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_lds_kernel(const float* qkv,
 #pragma unroll
             for (int c = 0; c < FC; ++c) gq[c] += gs * Ks[j * LDR + c0 + c];
         }
-        if (i < L) {
+        if (i < rend) {
             if (sub == 0) { st[i * 3 + 0] = mx; st[i * 3 + 1] = inv; st[i * 3 + 2] = dl; }
 #pragma unroll
             for (int c = 0; c < FC; ++c) g_qkv[(rowb + i) * 384 + h * AD + c0 + c] = gq[c];
         }
     }
-    __syncthreads();
-    __threadfence_block();
     // pass B: per key j -- g_k_j, g_v_j
-    for (int j0 = 0; j0 < L; j0 += 256 / TPR) {
+    if (PASS == 1)
+    for (int j0 = rbeg; j0 < rend; j0 += 256 / TPR) {
         const int j = j0 + threadIdx.x / TPR;
         const int jc = j < L ? j : L - 1;
         float k[FC], v[FC], gk[FC], gv[FC];
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_lds_kernel(const float* qkv,
 #pragma unroll
             for (int c = 0; c < FC; ++c) { gk[c] += gs * Qs[i * LDR + c0 + c]; gv[c] += p * Gs[i * LDR + c0 + c]; }
         }
-        if (j < L) {
+        if (j < rend) {
 #pragma unroll
             for (int c = 0; c < FC; ++c) { g_qkv[(rowb + j) * 384 + 128 + h * AD + c0 + c] = gk[c]; g_qkv[(rowb + j) * 384 + 256 + h * AD + c0 + c] = gv[c]; }
         }
@@ -767,14 +773,26 @@ extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float*
         const size_t lds = ((size_t)4 * L * (AD + 1) + L) * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if (L <= 64) hipLaunchKernelGGL(seq_attn_bwd_lds_kernel<4>, dim3((unsigned)(B * 4)), dim3(256), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
-        else if (L <= 128) hipLaunchKernelGGL(seq_attn_bwd_lds_kernel<2>, dim3((unsigned)(B * 4)), dim3(256), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
-        else hipLaunchKernelGGL(seq_attn_bwd_lds_kernel<1>, dim3((unsigned)(B * 4)), dim3(256), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, stats, B, L);
+        // row chunks of 256 / TPR rows (every thread of a workgroup has a row): TPR = 8 (4 features per thread) while that
+        // still leaves the chip short of workgroups, else fewer threads per row
+        hipStream_t s = (hipStream_t)stream;
+        auto go = [&](auto k0, auto k1, int tpr) {
+            const int rows_per = 256 / tpr;
+            const dim3 grid((unsigned)(B * 4), (unsigned)((L + rows_per - 1) / rows_per));
+            hipLaunchKernelGGL(k0, grid, dim3(256), lds, s, qkv, mask, g_out, g_qkv, stats, B, L);
+            hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, qkv, mask, g_out, g_qkv, stats, B, L);
+        };
+        if ((long long)B * 4 * ((L + 63) / 64) < 512) go(seq_attn_bwd_lds_kernel<8, 0>, seq_attn_bwd_lds_kernel<8, 1>, 8);
+        else if ((long long)B * 4 * ((L + 127) / 128) < 512) go(seq_attn_bwd_lds_kernel<4, 0>, seq_attn_bwd_lds_kernel<4, 1>, 4);
+        else go(seq_attn_bwd_lds_kernel<2, 0>, seq_attn_bwd_lds_kernel<2, 1>, 2);
         PF_CHECK_LAUNCH();
         return 0;
     }

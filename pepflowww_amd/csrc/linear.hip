@@ -6,6 +6,7 @@
 // only its own 32 rows of W, so there is no redundant weight traffic inside a workgroup).
 // Replaces ipa_pytorch.Linear / nn.Linear + the elementwise tail the reference runs after it
 // (see include/pepflow_hip.h).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
@@ -175,8 +176,13 @@ int launch(const pf_linear_args& a, hipStream_t s) {
 // Tile = 64 rows x 128 features per workgroup (4 waves, 32 features each); the x tile is converted to hi/lo f16
 // planes on its way into LDS.  Epilogue: bias (+ReLU, + row mask).  Used for the IPA projection (N = 3744) and
 // the other plain Linears of the step; 3 f16 MFMAs of K=32 replace 8 fp32 MFMAs of K=4.
-constexpr int SP_BM = 64, SP_BN = 128;
-__global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int Npad) {
+// NWV waves per workgroup = 32 NWV features per workgroup.  NWV = 4 for wide outputs (IPA projection); NWV = 6 / 8 when the
+// whole output row (N <= 256) fits one workgroup: the x tile is then read and converted ONCE instead of once per
+// 128-feature block (the pair-sized [B*L*L,192] -> 192 products of the training path read x twice otherwise).
+constexpr int SP_BM = 64;
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p, int Npad) {
+    constexpr int SP_BN = 32 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, LDK = K + 8;
     _Float16* Xh = reinterpret_cast<_Float16*>(smem_raw);       // [64][K+8]
@@ -187,18 +193,35 @@ __global__ __launch_bounds__(256) void linear_split_kernel(pf_linear_args p, int
     const int n0 = blockIdx.y * SP_BN + wave * 32;
     const bool wave_on = n0 < Npad;
     const int kq = K >> 2;
-    for (int idx = tid; idx < SP_BM * kq; idx += 256) {
-        const int row = idx / kq, c4 = idx - row * kq;
-        const int m = m0 + row;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (m < p.M) {
-            const float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + 4 * c4);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    // x tile -> hi/lo planes: loads in batches of 4 per thread, all requested before the first conversion (clamped,
+    // unconditional: a guarded load inside the loop is issued, waited for and converted one at a time -- at pair-sized M
+    // the kernel then spends most of its time in that chain of HBM round trips)
+    {
+        constexpr int NT = 64 * NWV, UB = 8;
+        const int total = SP_BM * kq;
+        for (int base = 0; base < total; base += NT * UB) {
+            float4 t[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = min(base + tid + u * NT, total - 1);
+                const int row = idx / kq, c4 = idx - row * kq;
+                const int m = min(m0 + row, p.M - 1);
+                t[u] = *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + tid + u * NT;
+                if (idx < total) {
+                    const int row = idx / kq, c4 = idx - row * kq;
+                    const float keep = (m0 + row < p.M) ? 1.f : 0.f;
+                    const float v[4] = {t[u].x * keep, t[u].y * keep, t[u].z * keep, t[u].w * keep};
+                    half4 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<half4*>(Xh + row * LDK + 4 * c4) = hi;
+                    *reinterpret_cast<half4*>(Xl + row * LDK + 4 * c4) = lo;
+                }
+            }
         }
-        half4 hi, lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<half4*>(Xh + row * LDK + 4 * c4) = hi;
-        *reinterpret_cast<half4*>(Xl + row * LDK + 4 * c4) = lo;
     }
     __syncthreads();
     if (!wave_on) return;
@@ -280,14 +303,19 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
     if (a->w_f16) {                                   // split-precision path: plain Linear (+bias, ReLU, row mask)
         if (a->K % 32 || a->ln_gamma || a->K > 512) return PF_E_BADARG;   // x tile [64][K] must fit LDS
         const int Npad = (a->N + 15) / 16 * 16;
-        dim3 grid((a->M + SP_BM - 1) / SP_BM, (Npad + SP_BN - 1) / SP_BN);
         const size_t lds = (size_t)2 * SP_BM * (a->K + 8) * sizeof(_Float16);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)linear_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(linear_split_kernel, grid, dim3(256), lds, s, *a, Npad);
+        static const int wide = [] { const char* e = getenv("PF_LS_WIDE"); return e ? atoi(e) : 1; }();
+        const unsigned gm = wide ? (a->M + SP_BM - 1) / SP_BM : 0;
+        if (Npad > 128 && Npad <= 192 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<6>, dim3(gm, 1), dim3(384), lds, s, *a, Npad);
+        else if (Npad > 192 && Npad <= 256 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<8>, dim3(gm, 1), dim3(512), lds, s, *a, Npad);
+        else hipLaunchKernelGGL(linear_split_kernel<4>, dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         PF_CHECK_LAUNCH();
         return 0;
     }
