@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 18
+#define PF_ABI_VERSION 19
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -76,6 +76,10 @@ typedef struct {
                                        (backward of a ReLU fused into the dx product of the training path) */
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
+/* W [N,K] fp32 (ldw) -- or W^T when `transpose` (then w is [K,N], ldw >= N) -- to the fragment-order f16 hi/lo planes
+ * pf_linear_args.w_f16 expects ([2][ceil16(N)/16][K/32][64][8] f16, N zero-padded to 16): the device-side form of
+ * engine.split_f16, used per step by the training path (weights change every step).  Layout only. */
+int pf_split_pack_f16(const float* w, int ldw, int N, int K, int transpose, void* out, pf_stream_t stream);
 
 /* ---- input mixing features: ga.py:94 (cat) + ga.py:79-85 / utils.py:60-71 (time embedding) +
  * layers.py:92-113 (AngularEncoding, 12 funcs) + nn.Embedding lookup.

@@ -30,18 +30,70 @@ def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, l
 
 
 SPLIT_MIN_ROWS = 8192          # pair-sized products go to the split-precision kernel of the inference path
+import os
+TN_WIDE_MIN_ROWS = int(os.environ.get("PF_TN_WIDE_MIN_ROWS", "8192"))
 
 
-def _linear_split(x, w, b=None, relu=False, gate=None, residual=None):
+class GradArena:
+    """One zero-filled buffer per backward pass that the parameter gradients are carved from: the weight-gradient kernels
+    then ACCUMULATE into their slice and need no zero-fill launch of their own (there were ~330 of them per step)."""
+    current = None
+
+    def __init__(self, nfloats, device):
+        self.buf = torch.full((nfloats,), 0, dtype=torch.float32, device=device)     # fill kernel, not a memset node
+        self.used = 0
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4
+        if self.used + n4 > self.buf.numel():
+            return None
+        v = self.buf[self.used:self.used + n].view(*shape)
+        self.used += n4
+        return v
+
+    def __enter__(self):
+        GradArena.current = self
+        return self
+
+    def __exit__(self, *exc):
+        GradArena.current = None
+
+
+def _grad_buffer(*shape, device):
+    """-> (tensor, zeroed?)"""
+    ar = GradArena.current
+    if ar is not None:
+        v = ar.take(*shape)
+        if v is not None:
+            return v, True
+    return torch.empty(*shape, device=device), False
+
+
+def _split_pack(w, transpose=False):
+    """Fragment-order f16 hi/lo planes of W (or of W^T) for the split-precision kernel, one launch (csrc/linear.hip)."""
+    if transpose:
+        K, N = w.shape                    # W^T has N = w.shape[1] output rows and K = w.shape[0] inputs
+        N, K = w.shape[1], w.shape[0]
+    else:
+        N, K = w.shape
+    Np = (N + 15) // 16 * 16
+    out = torch.empty(2 * Np * K, dtype=torch.float16, device=w.device)
+    _capi.check(_capi.load().pf_split_pack_f16(w.data_ptr(), w.shape[1], N, K, int(transpose), out.data_ptr(), _capi.stream_ptr()), "pf_split_pack_f16")
+    return out
+
+
+def _linear_split(x, w, b=None, relu=False, gate=None, residual=None, w_transposed=False):
     """y = relu?(x W^T + b) on the split-precision f16 MFMA kernel (csrc/linear.hip, fp32-level accuracy): ~2.3x the rate
     of the fp32-MFMA GEMM on the [B*L*L, 192] products of EdgeTransition.  w: [N, K] fp32, K % 32 == 0, K <= 512."""
-    from .engine import split_f16
     M, K = x.shape
-    N = w.shape[0]
+    N = w.shape[1] if w_transposed else w.shape[0]
     y = torch.empty(M, N, device=x.device)
-    w16 = split_f16(w)
+    w16 = _split_pack(w, transpose=w_transposed)
     a = _capi.LinearArgs()
-    a.x, a.ldx, a.w, a.ldw, a.w_f16 = x.data_ptr(), K, w.data_ptr(), K, w16.data_ptr()
+    a.x, a.ldx, a.w, a.ldw, a.w_f16 = x.data_ptr(), K, w.data_ptr(), w.shape[1], w16.data_ptr()
     a.bias = b.data_ptr() if b is not None else None
     a.y, a.ldy, a.M, a.N, a.K, a.relu = y.data_ptr(), N, M, N, K, int(relu)
     if gate is not None:                                        # y = gate > 0 ? y : 0   (ReLU backward fused into the product)
@@ -97,7 +149,7 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
     dx = None
     if need_dx:
         if _split_ok(M, N) and dy.is_contiguous() and K % 4 == 0:
-            dx = _linear_split(dy, w.t().contiguous(), gate=dx_gate, residual=dx_residual)     # dx = dy W = dy (W^T)^T
+            dx = _linear_split(dy, w, gate=dx_gate, residual=dx_residual, w_transposed=True)   # dx = dy W = dy (W^T)^T
         else:
             dx = torch.empty(M, K, device=x.device)
             _gemm(dy, N, 1, w, K, 1, dx, M, K, N)
@@ -107,12 +159,12 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
                 add_(dx, dx_residual)
     acc = dW is not None
     if dW is None:
-        dW = torch.empty(N, K, device=x.device)
+        dW, acc = _grad_buffer(N, K, device=x.device)
     accb = db is not None
     if db is None:
-        db = torch.empty(N, device=x.device)
-    if M >= SPLIT_MIN_ROWS and N <= 192 and K <= 192 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous():
-        # pair-sized: dW and db in ONE pass over dy and x (csrc/backward.hip: gemm_tn_wide_kernel)
+        db, accb = _grad_buffer(N, device=x.device)
+    if M >= TN_WIDE_MIN_ROWS and N <= 192 and K <= 192 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous():
+        # dW and db in ONE pass over dy and x (csrc/backward.hip: gemm_tn_wide_kernel)
         _capi.check(lib.pf_gemm_tn_wide(dy.data_ptr(), N, N, x.data_ptr(), K, K, dW.data_ptr(), K, M, int(acc), db.data_ptr(), int(accb),
                                         _capi.stream_ptr()), "pf_gemm_tn_wide")
         return dx, dW, db

@@ -290,7 +290,44 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     }
 }
 
+// fp32 W[N,K] (ldw; or its transpose: W given as [K,N] when `transpose`) -> f16 hi/lo planes in fragment order
+// [2][Npad/16][K/32][64 lanes][8] (the layout engine.split_f16 documents): one thread per 8 consecutive k of one output row
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw, int N, int K, int transpose, _Float16* out, int Npad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int per_row = K / 8;
+    if (idx >= Npad * per_row) return;
+    const int n = idx / per_row, k8 = idx - n * per_row;            // output row n, k = 8 k8 .. 8 k8 + 7
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * k8 + e;
+        v[e] = n < N ? (transpose ? w[(size_t)k * ldw + n] : w[(size_t)n * ldw + k]) : 0.f;
+    }
+    half4 h0, l0, h1, l1;
+    const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    // [t = n / 16][s = k / 32][g = (k % 32) / 8][r = n % 16][8]
+    const int t = n >> 4, r = n & 15, sidx = k8 >> 2, g = k8 & 3;
+    const size_t o = ((((size_t)t * (K / 32) + sidx) * 4 + g) * 16 + r) * 8;
+    const size_t plane = (size_t)Npad * K;
+    *reinterpret_cast<half4*>(out + o) = h0;
+    *reinterpret_cast<half4*>(out + o + 4) = h1;
+    *reinterpret_cast<half4*>(out + plane + o) = l0;
+    *reinterpret_cast<half4*>(out + plane + o + 4) = l1;
+}
+
 }  // namespace
+
+extern "C" int pf_split_pack_f16(const float* w, int ldw, int N, int K, int transpose, void* out, pf_stream_t stream) {
+    if (!w || !out || N <= 0 || K <= 0 || K % 32) return PF_E_BADARG;
+    const int Npad = (N + 15) / 16 * 16;
+    const int n = Npad * (K / 8);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, transpose,
+                       reinterpret_cast<_Float16*>(out), Npad);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
     if (!a || !a->x || (!a->w && !a->w_f16) || !a->y || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;

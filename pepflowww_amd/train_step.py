@@ -6,7 +6,7 @@ torch here = autograd bookkeeping + buffers; all arithmetic is in libpepflow_hip
 import torch
 
 from . import _capi, featurize
-from .backward import TrunkTrainer, encoder_backward
+from .backward import GradArena, TrunkTrainer, encoder_backward
 from .train_forward import LOSS_KEYS, TrainForward, default_train_noise
 
 
@@ -46,9 +46,11 @@ def _step_backward(state, weights):
     """weights: dict of floats or float32 device tensor [6] (d total / d loss_k).  -> {parameter name: gradient}."""
     tf, tr, saved, sd, B, L = state
     g = tf.loss_grads(weights)
-    grads, g_node, g_edge = tr.backward(g["d_rot"], g["d_trans"], g["d_ang"], g["d_logits"])
-    grads = {"ga_encoder." + k: v for k, v in grads.items()}
-    grads.update(encoder_backward(sd, saved, g_node, g_edge, B, L))
+    nparam = sum(v.numel() + 4 for v in sd.values())
+    with GradArena(nparam, g["d_rot"].device):          # one zero fill for all weight gradients of the step
+        grads, g_node, g_edge = tr.backward(g["d_rot"], g["d_trans"], g["d_ang"], g["d_logits"])
+        grads = {"ga_encoder." + k: v for k, v in grads.items()}
+        grads.update(encoder_backward(sd, saved, g_node, g_edge, B, L))
     return grads
 
 
