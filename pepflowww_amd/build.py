@@ -10,6 +10,8 @@ LIB = os.path.join(LIBDIR, "libpepflow_hip.so")
 SOURCES = ["selftest.hip", "linear.hip", "edge_transition.hip", "edge_transition_v3.hip", "ipa_attn.hip", "node_ops.hip", "flow_step.hip", "encode.hip", "node_track.hip", "train_fwd.hip", "backward.hip", "ipa_bwd.hip", "full_atom.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# packed fp32 VALU instructions beside MFMAs are an anti-lever on gfx950 (MI355X_MICROARCH.md): no SLP packing in the MFMA-bound kernel
+EXTRA_FLAGS = {"edge_transition_v3.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -30,7 +32,7 @@ def build(force=False, verbose=True):
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -87,11 +87,29 @@ __device__ __forceinline__ half8 cat4(half4 a, half4 b) {
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
     return o;
 }
+#ifndef PF_ET_NO_FMA
+// lo = (v - hi) * 2048 as ONE fused op on top of v * 2048: fma(hi, -2048, v * 2048) -- every term is exact in fp32, so the
+// result is bit-identical to the three-op form (convert, subtract, scale); the compiler folds the f16 -> f32 extension of
+// hi into v_fma_mix_f32
+__device__ __forceinline__ void split4f(const float (&v)[4], half4& hi, half4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        lo[e] = (_Float16)__builtin_fmaf((float)h, -PF_LO_SCALE, v[e] * PF_LO_SCALE);
+    }
+}
+#define SPLIT4 split4f
+#define JOIN(m, c) __builtin_fmaf((c), LOI, (m))
+#else
+#define SPLIT4 split4
+#define JOIN(m, c) ((m) + (c) * LOI)
+#endif
 __device__ __forceinline__ void split8(const float4& a, const float4& b, half8& hi, half8& lo) {
     const float v0[4] = {a.x, a.y, a.z, a.w}, v1[4] = {b.x, b.y, b.z, b.w};
     half4 h0, l0, h1, l1;
-    split4(v0, h0, l0);
-    split4(v1, h1, l1);
+    SPLIT4(v0, h0, l0);
+    SPLIT4(v1, h1, l1);
     hi = cat4(h0, h1);
     lo = cat4(l0, l1);
 }
@@ -268,10 +286,10 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             if (tp != 3 && tp != 5) { ga0 = ldfrag(sl, kf0 + 4, lane); gb0 = ldfrag(sl, kf0 + 6, lane); }
             mac2(ga1, gb1, zh[1], zl[1], m0, c0, m1, c1);
             float4 v0, v1;
-            v0.x = fmaxf(m0[0] + c0[0] * LOI, 0.f); v0.y = fmaxf(m0[1] + c0[1] * LOI, 0.f);
-            v0.z = fmaxf(m0[2] + c0[2] * LOI, 0.f); v0.w = fmaxf(m0[3] + c0[3] * LOI, 0.f);
-            v1.x = fmaxf(m1[0] + c1[0] * LOI, 0.f); v1.y = fmaxf(m1[1] + c1[1] * LOI, 0.f);
-            v1.z = fmaxf(m1[2] + c1[2] * LOI, 0.f); v1.w = fmaxf(m1[3] + c1[3] * LOI, 0.f);
+            v0.x = fmaxf(JOIN(m0[0], c0[0]), 0.f); v0.y = fmaxf(JOIN(m0[1], c0[1]), 0.f);
+            v0.z = fmaxf(JOIN(m0[2], c0[2]), 0.f); v0.w = fmaxf(JOIN(m0[3], c0[3]), 0.f);
+            v1.x = fmaxf(JOIN(m1[0], c1[0]), 0.f); v1.y = fmaxf(JOIN(m1[1], c1[1]), 0.f);
+            v1.z = fmaxf(JOIN(m1[2], c1[2]), 0.f); v1.w = fmaxf(JOIN(m1[3], c1[3]), 0.f);
             split8(v0, v1, h1h[tp], h1l[tp]);
         }
         PROF3(5);
@@ -315,10 +333,10 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
                 mac2(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, c0, m1, c1);
             }
             float4 v0, v1;
-            v0.x = fmaxf(m0[0] + c0[0] * LOI, 0.f); v0.y = fmaxf(m0[1] + c0[1] * LOI, 0.f);
-            v0.z = fmaxf(m0[2] + c0[2] * LOI, 0.f); v0.w = fmaxf(m0[3] + c0[3] * LOI, 0.f);
-            v1.x = fmaxf(m1[0] + c1[0] * LOI, 0.f); v1.y = fmaxf(m1[1] + c1[1] * LOI, 0.f);
-            v1.z = fmaxf(m1[2] + c1[2] * LOI, 0.f); v1.w = fmaxf(m1[3] + c1[3] * LOI, 0.f);
+            v0.x = fmaxf(JOIN(m0[0], c0[0]), 0.f); v0.y = fmaxf(JOIN(m0[1], c0[1]), 0.f);
+            v0.z = fmaxf(JOIN(m0[2], c0[2]), 0.f); v0.w = fmaxf(JOIN(m0[3], c0[3]), 0.f);
+            v1.x = fmaxf(JOIN(m1[0], c1[0]), 0.f); v1.y = fmaxf(JOIN(m1[1], c1[1]), 0.f);
+            v1.z = fmaxf(JOIN(m1[2], c1[2]), 0.f); v1.w = fmaxf(JOIN(m1[3], c1[3]), 0.f);
             half8 xh, xl;
             split8(v0, v1, xh, xl);
             const Frag w0 = ldfrag(sl, 12, lane), w1 = ldfrag(sl, 13, lane), w2 = ldfrag(sl, 14, lane), w3 = ldfrag(sl, 15, lane);
@@ -332,10 +350,10 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         float y[16];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            y[4 * t + 0] = m3[t][0] + c3[t][0] * LOI;
-            y[4 * t + 1] = m3[t][1] + c3[t][1] * LOI;
-            y[4 * t + 2] = m3[t][2] + c3[t][2] * LOI;
-            y[4 * t + 3] = m3[t][3] + c3[t][3] * LOI;
+            y[4 * t + 0] = JOIN(m3[t][0], c3[t][0]);
+            y[4 * t + 1] = JOIN(m3[t][1], c3[t][1]);
+            y[4 * t + 2] = JOIN(m3[t][2], c3[t][2]);
+            y[4 * t + 3] = JOIN(m3[t][3], c3[t][3]);
         }
         float s = 0.f;
 #pragma unroll
