@@ -255,17 +255,18 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
         // its s_waitcnt drain the whole in-order vmcnt queue, i.e. the next tile's prefetch, every iteration.)
         float mi4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const int i = i0 + 4 * g + e; mi4[e] = (i < L) ? a.mask[rowb + i] : 0.f; }
+        for (int e = 0; e < 4; ++e) { const int i = i0 + 4 * g + e; mi4[e] = a.mask[rowb + min(i, L - 1)] * (i < L ? 1.f : 0.f); }
         for (int hq = 0; hq < HPW; ++hq) {
             const int hh = hh0 + hq, h = h0 + hh;
             const float gamma = softplusf(a.head_w[h]) * scale_pt;
             float4 qf[8];
             {
                 const int i = i0 + r;
+                // (unconditional loads from a clamped row: a select / branch around a load puts an s_waitcnt right behind it;
+                //  rows beyond L only produce logits that are never stored or are masked to -1e5)
                 const float* qrow = a.proj + (rowb + (i < L ? i : 0)) * a.ldp + h * C + 4 * g;
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    qf[s] = (i < L) ? *reinterpret_cast<const float4*>(qrow + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
             }
             // operands of key tile j0: 8 K fragments, 8 key points (24 floats), key mask; next tile prefetched
             auto loadk = [&](int j0, float4 (&kf)[8], float4 (&kp4)[6], float& mj) {
@@ -274,11 +275,10 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
                 const float* krow = a.proj + (rowb + (jok ? j : 0)) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
                 const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
 #pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8)
-                    kf[s8] = jok ? *reinterpret_cast<const float4*>(krow + 16 * s8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s8 = 0; s8 < 8; ++s8) kf[s8] = *reinterpret_cast<const float4*>(krow + 16 * s8);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) kp4[q] = *reinterpret_cast<const float4*>(kp + 4 * q);
-                mj = jok ? a.mask[rowb + j] : 0.f;
+                mj = a.mask[rowb + (jok ? j : 0)] * (jok ? 1.f : 0.f);
             };
             float4 kf[8], kp4[6];
             float mj;
