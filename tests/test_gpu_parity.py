@@ -649,6 +649,28 @@ def test_gemm_three_forms():
         G.assert_close(db, dy.sum(0), 2e-5, "db")
 
 
+
+@pytest.mark.parametrize("R,M,N", [(4096, 192, 192), (1000, 8, 64), (8192 + 24, 64, 192), (333, 16, 16)])
+def test_gemm_tn_wide(R, M, N):
+    """pf_gemm_tn_wide: C (+)= A^T B and column sums of A in one pass, against float64 (ragged row counts, narrow C,
+    accumulation onto existing contents)."""
+    from pepflowww_amd import _capi
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(R + M)
+    A, Bm = torch.randn(R, M, generator=g), torch.randn(R, N, generator=g)
+    C0, s0 = torch.randn(M, N, generator=g), torch.randn(M, generator=g)
+    ref = A.double().t() @ Bm.double()
+    for acc in (0, 1):
+        C, cs = cu(C0.clone()), cu(s0.clone())
+        a, b = cu(A), cu(Bm)
+        _capi.check(lib.pf_gemm_tn_wide(a.data_ptr(), M, M, b.data_ptr(), N, N, C.data_ptr(), N, R, acc, cs.data_ptr(), acc, _capi.stream_ptr()), "pf_gemm_tn_wide")
+        G.sync()
+        want = ref + (C0.double() if acc else 0)
+        wcs = A.double().sum(0) + (s0.double() if acc else 0)
+        assert (C.cpu().double() - want).abs().max() <= 2e-5 * want.abs().max(), (R, M, N, acc)
+        assert (cs.cpu().double() - wcs).abs().max() <= 2e-5 * wcs.abs().max() + 1e-5, (R, M, N, acc)
+
+
 def test_layernorm_and_relu_backward():
     from pepflowww_amd import backward as Bk
     g = torch.Generator().manual_seed(4)
@@ -746,14 +768,15 @@ def f6(golden_dir):
     return d
 
 
-def test_seq_attention_backward():
-    """pf_seq_attn_bwd against torch autograd on the unfused attention of the oracle (padding in one sample)."""
+@pytest.mark.parametrize("B,L", [(3, 37), (2, 130), (64, 128), (128, 64), (1, 300)])
+def test_seq_attention_backward(B, L):
+    """pf_seq_attn_bwd against torch autograd on the unfused attention of the oracle (padding in one sample); the shapes
+    cover the 8 / 4 / 2 threads-per-row LDS variants with ragged row chunks and the global-memory form (L > 256)."""
     from pepflowww_amd import backward as Bk
     g = torch.Generator().manual_seed(12)
-    B, L = 3, 37
     qkv = torch.randn(B, L, 384, generator=g).requires_grad_(True)
     mask = torch.ones(B, L)
-    mask[1, 30:] = 0
+    mask[B // 2, L - 7:] = 0
     go = torch.randn(B, L, 128, generator=g)
     q, k, v = [t.view(B, L, 4, 32).transpose(1, 2) for t in qkv.split(128, dim=-1)]
     att = (q @ k.transpose(-1, -2)) / math.sqrt(32)
