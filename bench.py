@@ -213,11 +213,12 @@ def bench_train(args, wl, dev, dist, rank, world):
     def step():
         if graphed is not None:
             graphed(None, noise=default_train_noise(B, L, gen), seed=20240227)
+            graphed.allreduce(dist)                              # one all-reduce over the flat gradient buffer, in place
         else:
             model.zero_grad(set_to_none=True)
             losses = model(batch, noise=default_train_noise(B, L, gen), seed=20240227, first_sample=first)
             sum(wts[k] * v for k, v in losses.items()).backward()
-        allreduce_gradients(model.parameters(), dist)
+            allreduce_gradients(model.parameters(), dist)
     for _ in range(W):
         step()
     torch.cuda.synchronize()

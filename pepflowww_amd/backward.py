@@ -54,6 +54,25 @@ class GradArena:
         self.used += n4
         return v
 
+    def owns(self, t):
+        b0 = self.buf.data_ptr()
+        return b0 <= t.data_ptr() < b0 + 4 * self.buf.numel()
+
+    def adopt(self, grads):
+        """Move every gradient that was produced outside the arena into it (small ones: LayerNorm, embeddings, head weights),
+        so that the whole gradient is ONE flat buffer: flat() is what a data-parallel step all-reduces, with no copies."""
+        for n, g in list(grads.items()):
+            if g is not None and not self.owns(g):
+                v = self.take(*g.shape)
+                if v is None:
+                    continue
+                v.copy_(g)
+                grads[n] = v
+        return grads
+
+    def flat(self):
+        return self.buf[:self.used]
+
     def __enter__(self):
         GradArena.current = self
         return self

@@ -107,10 +107,11 @@ def allreduce_gradients(parameters, dist=None):
     params = [p for p in parameters if p.grad is not None]
     if not params:
         return 0
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return sum(p.grad.numel() for p in params)              # one replica: the average is the gradient itself
     flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
     o = 0
     for p in params:
         n = p.grad.numel()

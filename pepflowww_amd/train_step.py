@@ -42,16 +42,18 @@ def _step_forward(model, sd, batch, noise, seed, first_sample, seed_dev=None):
     return tf.losses, (tf, tr, saved, sd, B, L)
 
 
-def _step_backward(state, weights):
+def _step_backward(state, weights, return_arena=False):
     """weights: dict of floats or float32 device tensor [6] (d total / d loss_k).  -> {parameter name: gradient}."""
     tf, tr, saved, sd, B, L = state
     g = tf.loss_grads(weights)
     nparam = sum(v.numel() + 4 for v in sd.values())
-    with GradArena(nparam, g["d_rot"].device):          # one zero fill for all weight gradients of the step
+    with GradArena(nparam, g["d_rot"].device) as arena:  # one zero fill for all weight gradients of the step
         grads, g_node, g_edge = tr.backward(g["d_rot"], g["d_trans"], g["d_ang"], g["d_logits"])
         grads = {"ga_encoder." + k: v for k, v in grads.items()}
         grads.update(encoder_backward(sd, saved, g_node, g_edge, B, L))
-    return grads
+        if return_arena:
+            arena.adopt(grads)
+    return (grads, arena) if return_arena else grads
 
 
 def _state_dict_f32(model, params=None):
@@ -127,7 +129,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             losses, state = _step_forward(model, sd, self.batch, self.noise, 0, first_sample, seed_dev=self.seed)
-            grads = _step_backward(state, self.weights)
+            grads, self.arena = _step_backward(state, self.weights, return_arena=True)
             self.losses = losses
             self.grads = {n: grads[n].reshape(sd[n].shape) for n in self.names if grads.get(n) is not None}
             del state
@@ -147,6 +149,17 @@ class GraphedTrainStep:
         self.seed.fill_(seed)
         self.graph.replay()
         return {k: self.losses[i] for i, k in enumerate(LOSS_KEYS)}
+
+    def allreduce(self, dist=None):
+        """Data-parallel step (train_ddp.py:94): average the gradients of the replicas IN PLACE with one all-reduce over the
+        flat gradient buffer every `.grad` is a view of (no flatten / copy-back).  No-op for a single replica."""
+        if dist is None:
+            import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            flat = self.arena.flat()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= dist.get_world_size()
+        return self.arena.used
 
 
 def training_forward(model, batch, noise=None, seed=None, first_sample=0):

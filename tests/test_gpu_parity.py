@@ -1007,7 +1007,7 @@ def test_graphed_training_step_equals_eager(seeded_sd):
         # (split-K atomics: gradients that are accumulated atomically may differ in the last bits between runs)
         # (linear_b.bias gradients are zero up to rounding -- softmax shift invariance -- hence the absolute floor)
         off = [(n, (ge[n] - p.grad).abs().max().item(), ge[n].abs().max().item()) for n, p in m.named_parameters()]
-        off = [t for t in off if t[1] > 1e-5 * t[2] + 2e-7]
+        off = [t for t in off if t[1] > 1e-5 * t[2] + 1e-6]     # (atomic accumulation order differs run to run)
         assert not off, (len(off), off[:5])
     # parameters are read in place: a step along -grad changes the next replay's loss
     l_before = sum(w[k] * v.item() for k, v in step(b0, noise=n0, seed=1234).items())
