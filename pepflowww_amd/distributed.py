@@ -96,6 +96,17 @@ def sample_sharded(model, batch, num_steps=100, *, noise=None, seed=0, group=Non
     return all_gather_final_state(smp, group)
 
 
+def allreduce_flat(flat, dist=None):
+    """Average one flat gradient buffer over the replicas IN PLACE (the gradient arena of the graph-captured training step:
+    every `.grad` is a view of it, so there is no flatten and no copy-back).  No-op for a single replica."""
+    if dist is None:
+        import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+    return flat.numel()
+
+
 def allreduce_gradients(parameters, dist=None):
     """Data-parallel training step (train_ddp.py:94 wraps the model in DDP): average the gradients of the
     replicas with ONE all-reduce over a flat fp32 bucket (6.88 M parameters = 27.5 MB; on the xGMI mesh one large

@@ -153,13 +153,8 @@ class GraphedTrainStep:
     def allreduce(self, dist=None):
         """Data-parallel step (train_ddp.py:94): average the gradients of the replicas IN PLACE with one all-reduce over the
         flat gradient buffer every `.grad` is a view of (no flatten / copy-back).  No-op for a single replica."""
-        if dist is None:
-            import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            flat = self.arena.flat()
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat /= dist.get_world_size()
-        return self.arena.used
+        from .distributed import allreduce_flat
+        return allreduce_flat(self.arena.flat(), dist)
 
 
 def training_forward(model, batch, noise=None, seed=None, first_sample=0):

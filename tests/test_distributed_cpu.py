@@ -114,3 +114,37 @@ def test_gradient_allreduce_two_ranks():
         assert n == 15 + 7
         assert torch.allclose(grads[0], torch.full((3, 5), 1.5)) and torch.allclose(grads[1], torch.full((7,), 3.0))
         assert grads[2] is None
+
+
+def _arena_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pepflowww_amd.backward import GradArena
+    from pepflowww_amd.distributed import allreduce_flat
+    ar = GradArena(64, torch.device("cpu"))
+    a, b = ar.take(3, 5), ar.take(7)                      # gradients carved from the arena (slices start 4-float aligned)
+    a += float(rank + 1)
+    b += 2.0 * (rank + 1)
+    grads = ar.adopt({"a": a, "b": b, "c": torch.full((2, 2), 10.0 * (rank + 1))})      # "c" was produced outside
+    n = allreduce_flat(ar.flat(), dist)
+    q.put((rank, n, {k: v.clone() for k, v in grads.items()}, ar.owns(grads["c"])))
+    dist.destroy_process_group()
+
+
+def test_gradient_arena_allreduce_two_ranks():
+    """The graph-captured training step keeps every gradient as a view of one flat arena; the data-parallel average is one
+    in-place all-reduce over it (GraphedTrainStep.allreduce), gloo, world size 2."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 7) % 1000)
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    for rank, n, grads, owned in res:
+        assert owned and n == 16 + 8 + 4                  # 15 -> 16, 7 -> 8 (alignment), 4
+        assert torch.allclose(grads["a"], torch.full((3, 5), 1.5)) and torch.allclose(grads["b"], torch.full((7,), 3.0))
+        assert torch.allclose(grads["c"], torch.full((2, 2), 15.0))
