@@ -152,6 +152,68 @@ __device__ __forceinline__ long long categorical_dev(const float* logit, const f
     return best;
 }
 
+// The same draw computed by EIGHT lanes per residue (sub = lane & 7; all eight lanes of the group must be active and hold
+// the same logits): lane q < 5 evaluates classes 4q..4q+3 (one Philox block, four expf / logf each); the softmax sum and the
+// arg-max scan run lane after lane in ascending class order, so every rounding and every tie is resolved exactly as in the
+// serial form above -- the result is bit-identical, the long scalar chain (60 exp/log per draw) is ~4x shorter.
+__device__ __forceinline__ long long categorical_oct(const float* logit, const float* expo, uint64_t seed, long long gsample,
+                                                     int draw, int res, int sub) {
+    float mx = logit[0];
+#pragma unroll
+    for (int k = 1; k < KCLS; ++k) mx = fmaxf(mx, logit[k]);
+    const int q = sub < 5 ? sub : 4;                      // lanes 5..7 shadow lane 4 (their results are never taken)
+    float lq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                         // logit[4q + k] without dynamic indexing of the register array
+        float v = logit[k];
+#pragma unroll
+        for (int t = 1; t < 5; ++t) v = (q == t) ? logit[4 * t + k] : v;
+        lq[k] = v;
+    }
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = expf(lq[k] - mx);
+    // sum = (((0 + e0) + e1) + ...) + e19, lane after lane
+    float run = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float in = __shfl(run, t == 0 ? 0 : t - 1, 8);
+        if (sub == t) {
+            run = (t == 0 ? 0.f : in) + e[0];
+            run += e[1]; run += e[2]; run += e[3];
+        }
+    }
+    const float sum = __shfl(run, 4, 8);
+    float E[4];
+    if (expo) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) E[k] = expo[4 * q + k];
+    } else {
+        uint32_t c[4] = {(uint32_t)(res * 5 + q), (uint32_t)draw, (uint32_t)gsample, (uint32_t)((uint64_t)gsample >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) E[k] = -logf(((float)(c[k] >> 8) + 0.5f) * 5.9604644775390625e-08f);   // u in (0,1)
+    }
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (e[k] / sum + 1e-8f) / E[k];
+    // arg-max scan in ascending class order with strict '>' (first maximum wins)
+    float bv = 0.f;
+    int best = 0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float in_bv = __shfl(bv, t == 0 ? 0 : t - 1, 8);
+        const int in_best = __shfl(best, t == 0 ? 0 : t - 1, 8);
+        if (sub == t) {
+            if (t == 0) { bv = v[0]; best = 0; }
+            else { bv = in_bv; best = in_best; if (v[0] > bv) { bv = v[0]; best = 4 * t; } }
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k] > bv) { bv = v[k]; best = 4 * t + k; }
+        }
+    }
+    return (long long)__shfl(best, 4, 8);
+}
+
 __device__ __forceinline__ float simplex_of(long long seq, int k) {   // seq_to_simplex, flow_model.py:108-109
     return (seq >= 0 && seq < KCLS && seq == k) ? SIMPLEX_K : -SIMPLEX_K;
 }

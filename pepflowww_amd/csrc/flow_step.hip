@@ -70,8 +70,12 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
 }
 
 // ---- one sampler step: post-process (291-312 / 349-370), record, Euler (316-343) ----
+// EIGHT lanes per residue: the three categorical draws are spread over them (categorical_oct); everything else is computed
+// redundantly by the eight lanes and stored by lane 0.  (One thread per residue ran ~8 k dependent scalar instructions:
+// 26 us per step on 4 workgroups at B*L = 1024.)
 __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const bool lead = sub == 0;
     const int n = a.B * a.L;
     if (row >= n) return;
     const int s = *a.step;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) lg[k] = a.pred_logits[(size_t)row * KCLS + k];
         const float* ex = a.expo ? a.expo + ((size_t)(1 + 2 * s) * nrow + row) * KCLS : nullptr;
-        seqp = categorical_dev(lg, ex, a.seed, gs, 1 + 2 * s, l);
+        seqp = categorical_oct(lg, ex, a.seed, gs, 1 + 2 * s, l, sub);
     }
 #pragma unroll
     for (int k = 0; k < KCLS; ++k) sxp[k] = simplex_of(seqp, k);
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) lg[k] = a.pred_logits[(size_t)row * KCLS + k];
         const float* ex = a.expo ? a.expo + ((size_t)(1 + 2 * s) * nrow + row) * KCLS : nullptr;
-        seq_for_mask = categorical_dev(lg, ex, a.seed, gs, 1 + 2 * s, l);
+        seq_for_mask = categorical_oct(lg, ex, a.seed, gs, 1 + 2 * s, l, sub);
     }
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
         angp[d] = v;
     }
     // record
-    {
+    if (lead) {
         const size_t o = (size_t)s * nrow + row;
 #pragma unroll
         for (int k = 0; k < 9; ++k) a.traj_rot[o * 9 + k] = Rp[k];
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
     for (int k = 0; k < 3; ++k) {
         const size_t o = (size_t)row * 3 + k;
         const float v = a.trans_t[o] + (xp[k] - a.trans0[o]) * dt;
-        a.trans_t[o] = bb ? v : a.trans1[o];
+        const float w = bb ? v : a.trans1[o];
+        if (lead) a.trans_t[o] = w;
     }
     // rotations (322-323): geodesic with rate 10
     {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
         for (int k = 0; k < 9; ++k) Rt[k] = a.rot_t[(size_t)row * 9 + k];
         if (bb) so3_geodesic_dev(Rt, Rp, dt * 10.f, Rn);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a.rot_t[(size_t)row * 9 + k] = bb ? Rn[k] : a.rot1[(size_t)row * 9 + k];
+        for (int k = 0; k < 9; ++k) { const float w = bb ? Rn[k] : a.rot1[(size_t)row * 9 + k]; if (lead) a.rot_t[(size_t)row * 9 + k] = w; }
     }
     // simplex + state sequence (328-330)
     float lg[KCLS];
@@ -155,16 +160,20 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
     for (int k = 0; k < KCLS; ++k) {
         const size_t o = (size_t)row * KCLS + k;
         lg[k] = a.simplex_t[o] + (sxp[k] - a.simplex0[o]) * dt;
-        a.simplex_t[o] = lg[k];
     }
     long long seqn = s1;
     long long seqn_mask = s1;
     if (gen) {
         const float* ex = a.expo ? a.expo + ((size_t)(2 + 2 * s) * nrow + row) * KCLS : nullptr;
-        seqn_mask = categorical_dev(lg, ex, a.seed, gs, 2 + 2 * s, l);
+        seqn_mask = categorical_oct(lg, ex, a.seed, gs, 2 + 2 * s, l, sub);
         seqn = a.sample_seq ? seqn_mask : s1;
     }
-    a.seq_t[row] = seqn;
+    // (the state is read by all eight lanes above and written only after the last read: wave-synchronous, lane 0 stores)
+    if (lead) {
+#pragma unroll
+        for (int k = 0; k < KCLS; ++k) a.simplex_t[(size_t)row * KCLS + k] = lg[k];
+        a.seq_t[row] = seqn;
+    }
     // angles (325-326, 332-333)
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
         float v = gen ? tor_geodesic_dev(a.ang_t[o], angp[d], dt) : a.ang1[o];
         if (!torsion_exists(seqn_mask, d)) v = 0.f;
         if (!a.sample_ang) v = a.ang1[o];
-        a.ang_t[o] = v;
+        if (lead) a.ang_t[o] = v;
     }
 }
 
@@ -237,7 +246,7 @@ extern "C" int pf_sampler_step(const pf_sampler_args* a, pf_stream_t stream) {
         !a->traj_trans || !a->traj_ang || !a->traj_seq || !a->traj_simplex)
         return PF_E_BADARG;
     const int n = a->B * a->L;
-    hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     hipLaunchKernelGGL(sampler_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
