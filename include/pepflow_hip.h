@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 19
+#define PF_ABI_VERSION 20
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -74,6 +74,11 @@ typedef struct {
                                        K % 32 == 0, no LayerNorm) */
     const float* gate; int ldg;     /* split path only, optional: y = gate[m,n] > 0 ? y : 0 before the residual is added
                                        (backward of a ReLU fused into the dx product of the training path) */
+    /* split path only, optional (IPA projection of the inference plan): output features n >= pt_col0 are point coordinates
+     * packed (x, y, z, 0) per point -- 64 query points (h*8+p) then 160 key/value points (h*20+p; p < 8 key, else value) --
+     * and are not stored to y: each point goes through the residue frame, R p + t (rigid_utils.py:1124-1150 via
+     * ipa_pytorch.py:360-388), straight into qp [M,192] / kp [M,192] / vp [M,288] (what pf_ipa_points_fwd produces). */
+    const float* pt_rot; const float* pt_trans; float* pt_qp; float* pt_kp; float* pt_vp; int pt_col0;
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 /* W [N,K] fp32 (ldw) -- or W^T when `transpose` (then w is [K,N], ldw >= N) -- to the fragment-order f16 hi/lo planes

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -21,7 +21,8 @@ class LinearArgs(C.Structure):
     _fields_ = [("x", _fp), ("ldx", _i), ("w", _fp), ("ldw", _i), ("bias", _fp), ("y", _fp), ("ldy", _i),
                 ("M", _i), ("N", _i), ("K", _i), ("relu", _i), ("row_mask", _fp), ("mask_pre", _i),
                 ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
-                ("ln_eps", C.c_float), ("w_f16", _fp), ("gate", _fp), ("ldg", _i)]
+                ("ln_eps", C.c_float), ("w_f16", _fp), ("gate", _fp), ("ldg", _i),
+                ("pt_rot", _fp), ("pt_trans", _fp), ("pt_qp", _fp), ("pt_kp", _fp), ("pt_vp", _fp), ("pt_col0", _i)]
 
 
 class EmbedArgs(C.Structure):

@@ -264,6 +264,23 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                     if (p.relu) v[e] = fmaxf(v[e], 0.f);
                     v[e] *= mk;
                 }
+                if (p.pt_rot && n >= p.pt_col0) {        // a point (x, y, z, 0): frame transform, scatter to qp / kp / vp
+                    const float* R = p.pt_rot + (size_t)m * 9;
+                    const float* T = p.pt_trans + (size_t)m * 3;
+                    const int pt = (n - p.pt_col0) >> 2;
+                    float* o;
+                    if (pt < 64) o = p.pt_qp + (size_t)m * 192 + pt * 3;
+                    else {
+                        const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20;
+                        o = (pp < 8) ? p.pt_kp + (size_t)m * 192 + (hh * 8 + pp) * 3 : p.pt_vp + (size_t)m * 288 + (hh * 12 + (pp - 8)) * 3;
+                    }
+                    if (pt < 224) {
+                        o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                        o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                        o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                    }
+                    continue;
+                }
                 float* dst = p.y + (size_t)m * p.ldy + n;
                 if (vec_ok && n + 3 < p.N) {             // one 16-byte store per lane (the store tail is issue-bound)
                     if (p.gate) {

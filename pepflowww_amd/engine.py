@@ -132,6 +132,20 @@ class PackedWeights:
             t[f"{b}.proj.b"] = torch.cat([g(p + "linear_q.bias"), g(p + "linear_kv.bias"),
                                           g(p + "linear_q_points.bias"), g(p + "linear_kv_points.bias")], 0).contiguous()
             t[f"{b}.proj.w16"] = split_f16(t[f"{b}.proj.w"])
+            # inference plan: point rows re-ordered to (x, y, z, 0) per point so that pf_linear_fwd applies the residue frames
+            # in its epilogue (pf_linear_args.pt_*): 3072 scalar features, 64 query points, 160 key/value points
+            wfull, bfull = t[f"{b}.proj.w"], t[f"{b}.proj.b"]
+            idx = []
+            for pt in range(64):
+                idx += [3072 + m * 64 + pt for m in range(3)] + [-1]
+            for hp in range(160):
+                idx += [3264 + m * 160 + hp for m in range(3)] + [-1]
+            idx_t = torch.tensor(idx, device=device)
+            wz = torch.cat([wfull, torch.zeros(1, 128, device=device)], 0)      # row -1 -> zeros
+            bz = torch.cat([bfull, torch.zeros(1, device=device)], 0)
+            wp = torch.cat([wfull[:3072], wz[idx_t]], 0).contiguous()           # [3968,128]
+            t[f"{b}.projp.w16"] = split_f16(wp)
+            t[f"{b}.projp.b"] = torch.cat([bfull[:3072], bz[idx_t]], 0).contiguous()
             for nm in ("linear_b", "down_z", "linear_out"):
                 t[f"{b}.{nm}.w"], t[f"{b}.{nm}.b"] = g(p + nm + ".weight"), g(p + nm + ".bias")
             t[f"{b}.linear_out.w16"] = split_f16(t[f"{b}.linear_out.w"])
@@ -263,13 +277,12 @@ class DenoiseEngine:
             """IPA projection + point transform of block b (reads s and the current frames only)."""
             rot = self.rot_t if b == 0 else self.rot
             trans = self.trans_t if b == 0 else self.trans
-            e = lin(self.s, w[f"{b}.proj.w"], w[f"{b}.proj.b"], self.proj, 3744, 128, w16=w[f"{b}.proj.w16"])
+            # projection with the frame transform of the points fused into its epilogue (no pf_ipa_points_fwd launch)
+            e = lin(self.s, w[f"{b}.proj.w"], w[f"{b}.projp.b"], self.proj, 3968, 128, w16=w[f"{b}.projp.w16"])
+            la = self._keep[-1]
+            la.pt_rot, la.pt_trans, la.pt_col0 = rot.data_ptr(), trans.data_ptr(), 3072
+            la.pt_qp, la.pt_kp, la.pt_vp = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr()
             plan.append(e + (lane,))
-            pa = _capi.IpaPointsArgs()
-            pa.proj, pa.ldp, pa.rot, pa.trans = self.proj.data_ptr(), 3744, rot.data_ptr(), trans.data_ptr()
-            pa.qp, pa.kp, pa.vp, pa.rows = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr(), rows
-            self._keep.append(pa)
-            plan.append((lib.pf_ipa_points_fwd, C.byref(pa), "pf_ipa_points_fwd", lane))
 
         emit_proj(0, 0)
         for b in range(N_BLOCKS):
