@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 20
+#define PF_ABI_VERSION 21
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -101,6 +101,20 @@ typedef struct {
     int B, L;
 } pf_embed_args;
 int pf_embed_inputs_fwd(const pf_embed_args* a, pf_stream_t stream);
+/* the same features, the two Linears of res_feat_mixer (ga.py:94-96: 640 -> 128 ReLU -> 128, masked) and the quaternion of
+ * the current frames (rigid_utils.py:208-227) in ONE launch (csrc/node_track.hip: input_mixer_kernel); w0_f16 / w2_f16 are
+ * the fragment-order f16 planes of mixer.0 (K padded 629 -> 640) and mixer.2 */
+typedef struct {
+    const float* node_embed; const float* seq_table; const int64_t* seqs; const float* t; const float* time_freq;
+    const float* ang_freq; const float* angles;                       /* as in pf_embed_args */
+    const void* w0_f16; const float* b0; const void* w2_f16; const float* b2;
+    const float* mask;         /* [B*L] */
+    const float* rot;          /* [B*L,9] current frames */
+    float* quat;               /* [B*L,4] */
+    float* s_out;              /* [B*L,128] */
+    int B, L;
+} pf_input_mixer_args;
+int pf_input_mixer_fwd(const pf_input_mixer_args* a, pf_stream_t stream);
 
 /* ---- rigid-body point projection: r.apply() on the IPA points, ipa_pytorch.py:360-387,
  * rigid_utils.py:1124 / 82-106.  proj row = [q|kv|q_pts|kv_pts]; outputs global-frame points. */

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -39,6 +39,12 @@ class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
                 ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp)]
+
+
+class InputMixerArgs(C.Structure):
+    _fields_ = [("node_embed", _fp), ("seq_table", _fp), ("seqs", _fp), ("t", _fp), ("time_freq", _fp), ("ang_freq", _fp),
+                ("angles", _fp), ("w0_f16", _fp), ("b0", _fp), ("w2_f16", _fp), ("b2", _fp), ("mask", _fp), ("rot", _fp),
+                ("quat", _fp), ("s_out", _fp), ("B", _i), ("L", _i)]
 
 
 class SeqAttnArgs(C.Structure):
@@ -152,6 +158,7 @@ _SIGNATURES = {
     "pf_selftest_lanes": ([_fp, _fp, _fp], _i),
     "pf_linear_fwd": ([C.POINTER(LinearArgs), _fp], _i),
     "pf_embed_inputs_fwd": ([C.POINTER(EmbedArgs), _fp], _i),
+    "pf_input_mixer_fwd": ([C.POINTER(InputMixerArgs), _fp], _i),
     "pf_ipa_points_fwd": ([C.POINTER(IpaPointsArgs), _fp], _i),
     "pf_ipa_attn_fwd": ([C.POINTER(IpaAttnArgs), _fp], _i),
     "pf_pair_bias_fwd": ([_fp, _fp, _fp, _fp, _i, _i, _fp], _i),

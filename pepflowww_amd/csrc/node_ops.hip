@@ -121,47 +121,6 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(pf_seq_attn_args a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// rot -> quat (rigid_utils.py:208-227): top eigenvector of K/3.  For a rotation the spectrum of
-// K/3 is {1, -1/3, -1/3, -1/3}; power iteration on (K/3 + I/3) (spectrum {4/3, 0, 0, 0})
-// started from the closed-form (Shepperd) quaternion converges to fp32 in one or two steps and,
-// unlike the closed form alone, returns the eigenvector of K itself when R is only orthonormal to
-// ~1e-5 (frames from construct_3d_basis).  Sign is arbitrary, as with eigh.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rot_to_quat_dev(const float* R, float* q) {
-    const float xx = R[0], xy = R[1], xz = R[2], yx = R[3], yy = R[4], yz = R[5], zx = R[6], zy = R[7], zz = R[8];
-    float K[4][4] = {
-        {xx + yy + zz, zy - yz, xz - zx, yx - xy},
-        {zy - yz, xx - yy - zz, xy + yx, xz + zx},
-        {xz - zx, xy + yx, yy - xx - zz, yz + zy},
-        {yx - xy, xz + zx, yz + zy, zz - xx - yy}};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) K[i][j] = K[i][j] * (1.f / 3.f) + (i == j ? (1.f / 3.f) : 0.f);
-    // start vector: column of (K + I/3) with the largest diagonal (never orthogonal to the top eigvec)
-    int best = 0;
-    float bd = K[0][0];
-#pragma unroll
-    for (int i = 1; i < 4; ++i) if (K[i][i] > bd) { bd = K[i][i]; best = i; }
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        v[i] = (best == 0) ? K[i][0] : (best == 1) ? K[i][1] : (best == 2) ? K[i][2] : K[i][3];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        float n = rsqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-        float u[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = v[i] * n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = K[i][0] * u[0] + K[i][1] * u[1] + K[i][2] * u[2] + K[i][3] * u[3];
-    }
-    float n = rsqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = v[i] * n;
-}
-
 __global__ __launch_bounds__(256) void rot_to_quat_kernel(const float* rot, float* quat, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

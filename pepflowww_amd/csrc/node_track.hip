@@ -592,7 +592,118 @@ __global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pf_input_mixer_fwd: the per-step input of the trunk in ONE launch (was embed + two Linears + rot_to_quat = 4 launches of
+// >= 4.7 us each at one wave of work per CU):  feat = [node_embed | seq_emb | time code | angle code] (ga.py:94,
+// utils.py:60-71, layers.py:92-113) built in LDS as hi/lo planes, s = mask * (W2 relu(W0 feat + b0) + b2)
+// (res_feat_mixer, ga.py:94-96) on the split-precision MFMA, quat = rot_to_quat(R_t) (rigid_utils.py:208-227).
+constexpr int LDF = 640 + 8;   // f16 row stride of the 640-wide feature planes
+__global__ __launch_bounds__(NTHR) void input_mixer_kernel(pf_input_mixer_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Planes Xf = {reinterpret_cast<_Float16*>(smem_raw), reinterpret_cast<_Float16*>(smem_raw) + TR * LDF};
+    Planes Xa = {Xf.l + TR * LDF, Xf.l + TR * LDF + TR * LDP};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * TR, M = a.B * a.L;
+    const int n = wave * 16 + 4 * g;
+    WSplit<1, 8> w0;
+    w0.init(a.w0_f16, 128, 640, wave * 16);
+    w0.prefetch();
+    const float4 b0 = *reinterpret_cast<const float4*>(a.b0 + n);
+    const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + n);
+    const int mr = m0 + r, mrc = mr < M ? mr : M - 1;
+    const float rmask = a.mask[mrc] * (mr < M ? 1.f : 0.f);
+    // the time code depends on the sample only: computed once per sample present in the tile (normally one) instead of once
+    // per row -- the large-argument sinf / cosf are the expensive part of this kernel
+    __shared__ float TC[2][128];
+    const int b_first = m0 / a.L, b_last = min(m0 + TR - 1, M - 1) / a.L;
+    const bool tc_shared = b_last - b_first < 2;
+    if (tc_shared && tid < 128 * (b_last - b_first + 1)) {
+        const int bi = tid >> 7, k = tid & 127;
+        const float tt = a.t[b_first + bi] * 2056.f;
+        TC[bi][k] = k < 64 ? sinf(tt * a.time_freq[k]) : cosf(tt * a.time_freq[k - 64]);
+    }
+    __syncthreads();
+    // ---- features of the 16 rows: 160 float4 groups per row, same formulas as embed_kernel (node_ops.hip) ----
+    for (int idx = tid; idx < TR * 160; idx += NTHR) {
+        const int row = idx / 160, c4 = idx - row * 160;
+        const int m = min(m0 + row, M - 1);
+        const int b = m / a.L;
+        float v[4];
+        if (c4 < 32) {
+            const float4 t = *reinterpret_cast<const float4*>(a.node_embed + (size_t)m * 128 + 4 * c4);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else if (c4 < 64) {
+            long long sq = a.seqs[m];
+            sq = sq < 0 ? 0 : (sq > 21 ? 21 : sq);
+            const float4 t = *reinterpret_cast<const float4*>(a.seq_table + sq * 128 + 4 * (c4 - 32));
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            const float tt = a.t[b] * 2056.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * c4 + e;
+                float x;
+                if (c < 384 && tc_shared) x = TC[b - b_first][c - 256];
+                else if (c < 320) x = sinf(tt * a.time_freq[c - 256]);
+                else if (c < 384) x = cosf(tt * a.time_freq[c - 320]);
+                else if (c < 629) {
+                    const int q = c - 384, d = q / 49, k = q - d * 49;
+                    const float ang = a.angles[(size_t)m * 5 + d];
+                    if (k == 0) x = ang;
+                    else if (k < 25) x = sinf(ang * a.ang_freq[k - 1]);
+                    else x = cosf(ang * a.ang_freq[k - 25]);
+                } else x = 0.f;
+                v[e] = x;
+            }
+        }
+        half4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<half4*>(Xf.h + row * LDF + 4 * c4) = hi;
+        *reinterpret_cast<half4*>(Xf.l + row * LDF + 4 * c4) = lo;
+    }
+    if (tid < TR && m0 + tid < M) {                       // quaternion of the current frames
+        float R[9], q[4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = a.rot[(size_t)(m0 + tid) * 9 + k];
+        rot_to_quat_dev(R, q);
+        *reinterpret_cast<float4*>(a.quat + (size_t)(m0 + tid) * 4) = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    __syncthreads();
+    f32x4 am[1], ac[1];
+    acc_zero1<1>(am, ac);
+    gemm_split16(w0, Xf.h, Xf.l, LDF, am, ac, 0, 20);
+    WSplit<1, 4> w2;
+    w2.init(a.w2_f16, 128, 128, wave * 16);
+    w2.prefetch();
+    {
+        const float v[4] = {fmaxf(join(am[0], ac[0], 0) + b0.x, 0.f), fmaxf(join(am[0], ac[0], 1) + b0.y, 0.f),
+                            fmaxf(join(am[0], ac[0], 2) + b0.z, 0.f), fmaxf(join(am[0], ac[0], 3) + b0.w, 0.f)};
+        put_planes(Xa, r, n, v);
+    }
+    __syncthreads();
+    acc_zero1<1>(am, ac);
+    gemm_split16(w2, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+    if (mr < M) {
+        float4 y;
+        y.x = (join(am[0], ac[0], 0) + b2.x) * rmask; y.y = (join(am[0], ac[0], 1) + b2.y) * rmask;
+        y.z = (join(am[0], ac[0], 2) + b2.z) * rmask; y.w = (join(am[0], ac[0], 3) + b2.w) * rmask;
+        *reinterpret_cast<float4*>(a.s_out + (size_t)mr * 128 + n) = y;
+    }
+}
+
 }  // namespace
+
+extern "C" int pf_input_mixer_fwd(const pf_input_mixer_args* a, pf_stream_t stream) {
+    if (!a || !a->node_embed || !a->seq_table || !a->seqs || !a->t || !a->time_freq || !a->ang_freq || !a->angles || !a->w0_f16 ||
+        !a->b0 || !a->w2_f16 || !a->b2 || !a->mask || !a->rot || !a->quat || !a->s_out || a->B <= 0 || a->L <= 0)
+        return PF_E_BADARG;
+    const int rows = a->B * a->L;
+    const size_t lds = (size_t)2 * TR * LDF * sizeof(_Float16) + (size_t)2 * TR * LDP * sizeof(_Float16);
+    hipLaunchKernelGGL(input_mixer_kernel, dim3((unsigned)((rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) {
     if (!a || !a->feats || !a->s_in || !a->mask || !a->w_out_f16 || !a->b_out || !a->ln_g || !a->ln_b || !a->w_in_f16 ||

@@ -114,6 +114,7 @@ class PackedWeights:
         t["mix0.w"] = torch.nn.functional.pad(w0, (0, 640 - w0.shape[1])).contiguous()
         t["mix0.b"] = g("res_feat_mixer.0.bias")
         t["mix2.w"], t["mix2.b"] = g("res_feat_mixer.2.weight"), g("res_feat_mixer.2.bias")
+        t["mix0.w16"], t["mix2.w16"] = split_f16(t["mix0.w"]), split_f16(t["mix2.w"])
         t["seq_table"] = g("current_seq_embedder.weight")
         t["ang_freq"] = g("angles_embedder.freq_bands")
         half = 64
@@ -263,15 +264,14 @@ class DenoiseEngine:
         B, L, rows = self.B, self.L, self.rows
         lin = self._linear
 
-        ea = _capi.EmbedArgs()
-        ea.node_embed, ea.seq_table, ea.seqs = self.node_embed.data_ptr(), w["seq_table"].data_ptr(), self.seq_t.data_ptr()
-        ea.t, ea.time_freq, ea.ang_freq = self.t.data_ptr(), w["time_freq"].data_ptr(), w["ang_freq"].data_ptr()
-        ea.angles, ea.out, ea.B, ea.L = self.ang_t.data_ptr(), self.feat.data_ptr(), B, L
-        self._keep.append(ea)
-        plan.append((lib.pf_embed_inputs_fwd, C.byref(ea), "pf_embed_inputs_fwd"))
-        plan.append(lin(self.feat, w["mix0.w"], w["mix0.b"], self.ta, 128, 640, relu=True))   # K=640: fp32 MFMA path
-        plan.append(lin(self.ta, w["mix2.w"], w["mix2.b"], self.s, 128, 128, mask_pre=True))
-        plan.append((lib.pf_rot_to_quat, (self.rot_t.data_ptr(), self.quat.data_ptr(), rows), "pf_rot_to_quat"))
+        # embed + res_feat_mixer (two Linears) + rot_to_quat: one launch (csrc/node_track.hip: input_mixer_kernel)
+        ma = _capi.InputMixerArgs()
+        ma.node_embed, ma.seq_table, ma.seqs = self.node_embed.data_ptr(), w["seq_table"].data_ptr(), self.seq_t.data_ptr()
+        ma.t, ma.time_freq, ma.ang_freq, ma.angles = self.t.data_ptr(), w["time_freq"].data_ptr(), w["ang_freq"].data_ptr(), self.ang_t.data_ptr()
+        ma.w0_f16, ma.b0, ma.w2_f16, ma.b2 = w["mix0.w16"].data_ptr(), w["mix0.b"].data_ptr(), w["mix2.w16"].data_ptr(), w["mix2.b"].data_ptr()
+        ma.mask, ma.rot, ma.quat, ma.s_out, ma.B, ma.L = self.mask.data_ptr(), self.rot_t.data_ptr(), self.quat.data_ptr(), self.s.data_ptr(), B, L
+        self._keep.append(ma)
+        plan.append((lib.pf_input_mixer_fwd, C.byref(ma), "pf_input_mixer_fwd"))
 
         def emit_proj(b, lane):
             """IPA projection + point transform of block b (reads s and the current frames only)."""
