@@ -65,6 +65,7 @@ class DeviceSampler:
         a.sample_bb, a.sample_ang, a.sample_seq = (int(f) for f in flags)
         self.args = a
         self.graph = None
+        self.graph_k = None
 
     def set_context(self, R1, x1, ang1, seq1, gen_mask):
         rows = self.eng.rows
@@ -94,27 +95,41 @@ class DeviceSampler:
         rc = self.lib.pf_sampler_step(C.byref(self.args), _capi.stream_ptr())
         _capi.check(rc, "pf_sampler_step")
 
-    def capture(self):
-        """Capture one step (network + flow update) into a hipGraph.  The engine must have run once
-        eagerly before (first-launch attribute setup must not happen under capture)."""
+    GRAPH_STEPS = 4          # steps per replayed graph: the host-side relaunch gap (~8 us) is paid once per replay
+
+    def _capture(self, k):
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
-                self._one_step()
+                for _ in range(k):
+                    self._one_step()
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = g
+        return g
+
+    def capture(self):
+        """Capture one step (network + flow update) into a hipGraph -- and GRAPH_STEPS consecutive steps into a second one:
+        the step counter and the time live on the device, so every step is the same graph.  The engine must have run once
+        eagerly before (first-launch attribute setup must not happen under capture)."""
+        self.graph = self._capture(1)
+        self.graph_k = self._capture(self.GRAPH_STEPS) if self.GRAPH_STEPS > 1 else None
 
     def run(self, n_steps=None, use_graph=True):
         n = self.N if n_steps is None else n_steps
-        if use_graph and self.graph is None:
-            self.capture()
-        for _ in range(n):
-            if use_graph:
-                self.graph.replay()
-            else:
+        if not use_graph:
+            for _ in range(n):
                 self._one_step()
+            return
+        if self.graph is None:
+            self.capture()
+        k = self.GRAPH_STEPS
+        if self.graph_k is not None:
+            for _ in range(n // k):
+                self.graph_k.replay()
+            n -= (n // k) * k
+        for _ in range(n):
+            self.graph.replay()
 
     def trajectory(self):
         """One D2H copy -> list of num_steps dicts of CPU tensors (flow_model.py:313-314,371-374)."""
