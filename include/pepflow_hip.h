@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 21
+#define PF_ABI_VERSION 22
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -323,7 +323,7 @@ typedef struct {
     float* traj_rot; float* traj_trans; float* traj_ang; int64_t* traj_seq; float* traj_simplex;
     /* time grid ts[num_steps] (torch.linspace(1e-2,1,N), flow_model.py:280) */
     const float* ts; int num_steps;
-    int* step;                     /* device step counter */
+    int* step;                     /* device int[2]: [0] step counter, [1] workgroup ticket of pf_sampler_step (zero between calls) */
     float* t_out;                  /* [B] time fed to the next network call */
     /* categorical noise: expo != NULL -> caller-supplied Exp(1) draws [2*num_steps,B*L,20];
      * NULL -> in-kernel Philox4x32-10 keyed by (seed, first_sample+b, draw, residue, class) */

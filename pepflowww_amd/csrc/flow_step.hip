@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
     }
     if (threadIdx.x == 0) {
         a.t_out[b] = a.ts[0];
-        if (b == 0) *a.step = 0;
+        if (b == 0) { a.step[0] = 0; a.step[1] = 0; }
     }
 }
 
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
 // EIGHT lanes per residue: the three categorical draws are spread over them (categorical_oct); everything else is computed
 // redundantly by the eight lanes and stored by lane 0.  (One thread per residue ran ~8 k dependent scalar instructions:
 // 26 us per step on 4 workgroups at B*L = 1024.)
-__global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
+__device__ __forceinline__ void sampler_step_body(const pf_sampler_args& a) {
     const int row = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
     const bool lead = sub == 0;
     const int n = a.B * a.L;
@@ -185,9 +185,19 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
     }
 }
 
-__global__ void sampler_bump_kernel(pf_sampler_args a) {
-    const int s = *a.step + 1;
-    if (threadIdx.x == 0) *a.step = s;
+// The step counter is bumped by the LAST workgroup to finish (ticket in step[1]): every workgroup has read step[0] long
+// before it takes its ticket, so no workgroup can see the new value; the next kernel sees it through the kernel boundary.
+// (A separate one-workgroup bump kernel cost a 4 us launch per step.)
+__global__ __launch_bounds__(256) void sampler_step_kernel(pf_sampler_args a) {
+    __shared__ int last;
+    const int s0 = *a.step;
+    sampler_step_body(a);
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(a.step + 1, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!last) return;
+    const int s = s0 + 1;
+    if (threadIdx.x == 0) { a.step[0] = s; a.step[1] = 0; }
     const int sc = s < a.num_steps ? s : a.num_steps - 1;
     for (int b = threadIdx.x; b < a.B; b += blockDim.x) a.t_out[b] = a.ts[sc];
 }
@@ -247,8 +257,6 @@ extern "C" int pf_sampler_step(const pf_sampler_args* a, pf_stream_t stream) {
         return PF_E_BADARG;
     const int n = a->B * a->L;
     hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, *a);
-    PF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sampler_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;
 }

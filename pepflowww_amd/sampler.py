@@ -48,7 +48,7 @@ class DeviceSampler:
         self.traj_ang, self.traj_simplex = e(num_steps, rows, 5), e(num_steps, rows, 20)
         self.traj_seq = e(num_steps, rows, dt=torch.int64)
         self.ts = torch.linspace(1e-2, 1.0, num_steps).to(dev)          # flow_model.py:280 (built on CPU, then H2D)
-        self.step = e(1, dt=torch.int32)
+        self.step = e(2, dt=torch.int32)                      # [0] step counter, [1] workgroup ticket
         self.expo = None
         a = _capi.SamplerArgs()
         a.rot1, a.trans1, a.ang1, a.seq1 = self.rot1.data_ptr(), self.trans1.data_ptr(), self.ang1.data_ptr(), self.seq1.data_ptr()
