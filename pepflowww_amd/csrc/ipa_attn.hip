@@ -481,13 +481,14 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
             const int ntile = LP >> 4;
             auto zfetch = [&](int it, float (&vb)[4][4]) {                 // B operands of one K=16 step: 4 column tiles
                 const int t4 = it / ntile, k0 = (it - t4 * ntile) * 16;
-                const float* zrow = a.z + ((rowb + i0 + wave * RPW + t4) * L) * 64 + r;
+                // MFMA column (tile ct, lane r) <-> pair feature 4 r + ct: the four operands of a key row are ONE float4
+                const float* zrow = a.z + ((rowb + i0 + wave * RPW + t4) * L) * 64 + 4 * r;
     #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     int j = k0 + 4 * g + t;
                     j = j < L ? j : L - 1;
-    #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) vb[ct][t] = zrow[(size_t)j * 64 + 16 * ct];
+                    const float4 zv = *reinterpret_cast<const float4*>(zrow + (size_t)j * 64);
+                    vb[0][t] = zv.x; vb[1][t] = zv.y; vb[2][t] = zv.z; vb[3][t] = zv.w;
                 }
             };
             float vc[4][4], vn[4][4];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
                 for (int ct = 0; ct < 4; ++ct)
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (4 * g + e < HG) zb[(4 * g + e) * 64 + 16 * ct + r] = zacc[ct][e];
+                        if (4 * g + e < HG) zb[(4 * g + e) * 64 + 4 * r + ct] = zacc[ct][e];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
