@@ -10,8 +10,8 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:40]))
 rows.sort()
-# find the last 10 occurrences of sampler_bump (step ends) and analyse the span between them
-ends = [i for i, r in enumerate(rows) if "sampler_bump" in r[2]]
+# find the last 10 occurrences of sampler_step (step ends) and analyse the span between them
+ends = [i for i, r in enumerate(rows) if "sampler_step" in r[2]]
 i0, i1 = ends[-11], ends[-1]
 seg = rows[i0 + 1:i1 + 1]
 span = seg[-1][1] - rows[i0][1]
