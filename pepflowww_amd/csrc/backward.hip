@@ -15,35 +15,66 @@ constexpr int GT = 64;        // C tile 64 x 64, 4 waves of 32 x 32
 constexpr int GK = 32;        // K chunk
 constexpr int LDT = GK + 4;   // LDS row stride (floats) of a [64][GK] operand tile (16-byte aligned rows)
 
-// stage a [NR rows][GK] tile of an operand X(row, k) = X[row*sr + k*sk] into LDS [row][k]; float4 global loads along the
-// unit-stride dimension when the layout allows it (vec), scalar otherwise
+// stage a [NR rows][GK] tile of an operand X(row, k) = X[row*sr + k*sk] into LDS [row][k] in two halves -- fetch (global ->
+// registers) and commit (registers -> LDS) -- so that the NEXT chunk's loads are in flight while the current one is
+// multiplied (the one-step form exposed one global round trip per 32-wide K chunk: ~19 us for a [2048,128] x [128,128]
+// product).  float4 global loads along the unit-stride dimension when the layout allows it (vec), scalar otherwise.
 template <int NR>
-__device__ __forceinline__ void stage_tile(const float* X, long long sr, long long sk, int row0, int nrows, int k0, int kend, float* T, bool vec) {
+__device__ __forceinline__ void stage_fetch(const float* X, long long sr, long long sk, int row0, int nrows, int k0, int kend, bool vec,
+                                            float (&v)[NR / 8]) {
     const int tid = threadIdx.x;
     if (vec && sk == 1) {                       // k contiguous: 8 float4 per row
 #pragma unroll
         for (int q = 0; q < NR / 32; ++q) {
             const int idx = tid + 256 * q, rr = idx >> 3, kq = (idx & 7) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + rr < nrows && k0 + kq < kend) v = *reinterpret_cast<const float4*>(X + (size_t)(row0 + rr) * sr + k0 + kq);
-            *reinterpret_cast<float4*>(T + rr * LDT + kq) = v;
+            const bool ok = row0 + rr < nrows && k0 + kq < kend;
+            const float4 t = *reinterpret_cast<const float4*>(X + (size_t)(ok ? row0 + rr : row0) * sr + (ok ? k0 + kq : k0));
+            const float f = ok ? 1.f : 0.f;
+            v[4 * q] = t.x * f; v[4 * q + 1] = t.y * f; v[4 * q + 2] = t.z * f; v[4 * q + 3] = t.w * f;
         }
-    } else if (vec && sr == 1) {                // rows contiguous: float4 over 4 rows at one k, transposed into LDS
+    } else if (vec && sr == 1) {                // rows contiguous: float4 over 4 rows at one k
 #pragma unroll
         for (int q = 0; q < NR / 32; ++q) {
             const int idx = tid + 256 * q, r4 = (idx % (NR / 4)) * 4, kk = idx / (NR / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r4 < nrows && k0 + kk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)(k0 + kk) * sk + row0 + r4);
-            T[(r4 + 0) * LDT + kk] = v.x; T[(r4 + 1) * LDT + kk] = v.y; T[(r4 + 2) * LDT + kk] = v.z; T[(r4 + 3) * LDT + kk] = v.w;
+            const bool ok = row0 + r4 < nrows && k0 + kk < kend;
+            const float4 t = *reinterpret_cast<const float4*>(X + (size_t)(ok ? k0 + kk : k0) * sk + (ok ? row0 + r4 : row0));
+            const float f = ok ? 1.f : 0.f;
+            v[4 * q] = t.x * f; v[4 * q + 1] = t.y * f; v[4 * q + 2] = t.z * f; v[4 * q + 3] = t.w * f;
         }
     } else {
+#pragma unroll
         for (int q = 0; q < NR / 8; ++q) {
             const int idx = tid + 256 * q;
             int rr, kk;
             if (sk == 1) { kk = idx & (GK - 1); rr = idx >> 5; } else { rr = idx % NR; kk = idx / NR; }
-            float v = 0.f;
-            if (row0 + rr < nrows && k0 + kk < kend) v = X[(size_t)(row0 + rr) * sr + (size_t)(k0 + kk) * sk];
-            T[rr * LDT + kk] = v;
+            float t = 0.f;
+            if (row0 + rr < nrows && k0 + kk < kend) t = X[(size_t)(row0 + rr) * sr + (size_t)(k0 + kk) * sk];
+            v[q] = t;
+        }
+    }
+}
+template <int NR>
+__device__ __forceinline__ void stage_commit(long long sr, long long sk, bool vec, float* T, const float (&v)[NR / 8]) {
+    const int tid = threadIdx.x;
+    if (vec && sk == 1) {
+#pragma unroll
+        for (int q = 0; q < NR / 32; ++q) {
+            const int idx = tid + 256 * q, rr = idx >> 3, kq = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(T + rr * LDT + kq) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+    } else if (vec && sr == 1) {                // transposed into LDS
+#pragma unroll
+        for (int q = 0; q < NR / 32; ++q) {
+            const int idx = tid + 256 * q, r4 = (idx % (NR / 4)) * 4, kk = idx / (NR / 4);
+            T[(r4 + 0) * LDT + kk] = v[4 * q]; T[(r4 + 1) * LDT + kk] = v[4 * q + 1]; T[(r4 + 2) * LDT + kk] = v[4 * q + 2]; T[(r4 + 3) * LDT + kk] = v[4 * q + 3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NR / 8; ++q) {
+            const int idx = tid + 256 * q;
+            int rr, kk;
+            if (sk == 1) { kk = idx & (GK - 1); rr = idx >> 5; } else { rr = idx % NR; kk = idx / NR; }
+            T[rr * LDT + kk] = v[q];
         }
     }
 }
@@ -73,10 +104,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
     const int wm = (wave >> 1) * 16 * MT, wn = (wave & 1) * 32;
     f32x4 acc[MT][2];
     acc_zero<MT, 2>(acc);
+    float ra[TM / 8], rb[GT / 8];
+    stage_fetch<TM>(p.A, p.sam, p.sak, m0, p.M, kbeg, kend, vecA != 0, ra);
+    stage_fetch<GT>(p.B, p.sbn, p.sbk, n0, p.N, kbeg, kend, vecB != 0, rb);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        stage_tile<TM>(p.A, p.sam, p.sak, m0, p.M, k0, kend, As, vecA != 0);
-        stage_tile<GT>(p.B, p.sbn, p.sbk, n0, p.N, k0, kend, Bs, vecB != 0);
+        stage_commit<TM>(p.sam, p.sak, vecA != 0, As, ra);
+        stage_commit<GT>(p.sbn, p.sbk, vecB != 0, Bs, rb);
         __syncthreads();
+        if (k0 + GK < kend) {                             // next chunk in flight under this chunk's MFMAs
+            stage_fetch<TM>(p.A, p.sam, p.sak, m0, p.M, k0 + GK, kend, vecA != 0, ra);
+            stage_fetch<GT>(p.B, p.sbn, p.sbk, n0, p.N, k0 + GK, kend, vecB != 0, rb);
+        }
 #pragma unroll
         for (int ks = 0; ks < GK; ks += 16) {            // one float4 per lane feeds 4 consecutive MFMA k-steps (k permutation)
             float4 a[MT], b[2];
