@@ -845,7 +845,9 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     pf_gemm_args g = *a;
     g.ksplit = 1;
     const bool tall = a->M >= 8192;                       // 128-row C tiles for the pair-sized products
-    const int TM = tall ? 128 : 64;
+    // row-sized products (M = B*L ~ 2048): 32-row tiles when 64-row ones would leave most CUs without a workgroup
+    const bool small = !tall && nb == 1 && (long long)((a->M + 63) / 64) * ((a->N + GT - 1) / GT) < 128 && a->M >= 256;
+    const int TM = tall ? 128 : (small ? 32 : 64);
     const long long tiles = (long long)((a->M + TM - 1) / TM) * ((a->N + GT - 1) / GT);
     // long-K, few-tile products (dW = dy^T x over all pairs): split K over workgroups, partial sums by atomicAdd
     // (also the row-sized ones, K = B*L: without the split a 128 x 128 dW runs on 4 workgroups for ~115 us -- a quarter of
@@ -869,6 +871,7 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     const int vA = vec_ok(a->A, a->sam, a->sak, a->M, a->bsA1, a->bsA2), vB = vec_ok(a->B, a->sbn, a->sbk, a->N, a->bsB1, a->bsB2);
     const dim3 grid((unsigned)((a->M + TM - 1) / TM), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz);
     if (tall) hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
+    else if (small) hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
     else hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
     PF_CHECK_LAUNCH();
     return 0;
