@@ -409,7 +409,7 @@ typedef struct {
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 /* weight gradient of a Linear over all pairs in one pass: C[M,N] (+)= A^T B with A = dy [R,M] (lda), B = x [R,N] (ldb),
- * M, N <= 192 (multiples of 4), and optionally colsum_a[M] (+)= column sums of A (the bias gradient).  One workgroup owns
+ * M <= 192, N <= 256 (multiples of 4), and optionally colsum_a[M] (+)= column sums of A (the bias gradient).  One workgroup owns
  * the whole C for its row range, so A and B are read once (csrc/backward.hip: gemm_tn_wide_kernel). */
 int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, long long R,
                     int accumulate, float* colsum_a, int colsum_accumulate, pf_stream_t stream);

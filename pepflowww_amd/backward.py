@@ -104,17 +104,17 @@ def _split_pack(w, transpose=False):
     return out
 
 
-def _linear_split(x, w, b=None, relu=False, gate=None, residual=None, w_transposed=False):
+def _linear_split(x, w, b=None, relu=False, gate=None, residual=None, w_transposed=False, out=None):
     """y = relu?(x W^T + b) on the split-precision f16 MFMA kernel (csrc/linear.hip, fp32-level accuracy): ~2.3x the rate
     of the fp32-MFMA GEMM on the [B*L*L, 192] products of EdgeTransition.  w: [N, K] fp32, K % 32 == 0, K <= 512."""
     M, K = x.shape
     N = w.shape[1] if w_transposed else w.shape[0]
-    y = torch.empty(M, N, device=x.device)
+    y = torch.empty(M, N, device=x.device) if out is None else out          # out: [M, ld >= N] (extra columns untouched)
     w16 = _split_pack(w, transpose=w_transposed)
     a = _capi.LinearArgs()
     a.x, a.ldx, a.w, a.ldw, a.w_f16 = x.data_ptr(), K, w.data_ptr(), w.shape[1], w16.data_ptr()
     a.bias = b.data_ptr() if b is not None else None
-    a.y, a.ldy, a.M, a.N, a.K, a.relu = y.data_ptr(), N, M, N, K, int(relu)
+    a.y, a.ldy, a.M, a.N, a.K, a.relu = y.data_ptr(), y.shape[1], M, N, K, int(relu)
     if gate is not None:                                        # y = gate > 0 ? y : 0   (ReLU backward fused into the product)
         a.gate, a.ldg = gate.data_ptr(), N
     if residual is not None:
@@ -673,11 +673,15 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     g_o1, G["edge_embedder.out_mlp.2.weight"], G["edge_embedder.out_mlp.2.bias"] = linear_bwd(saved["o1"], w("edge_embedder.out_mlp.2.weight"), g_o2, dx_gate=saved["o1"])
     wo0 = w("edge_embedder.out_mlp.0.weight")                   # [64,218]; the concat tile is 224 wide
     g_cat = e(P, 224)
-    _gemm(g_o1, 64, 1, wo0, 218, 1, g_cat, P, 218, 64, ldc=224)
-    dWo0 = e(64, 218)
-    _gemm(g_o1, 1, 64, saved["cat"], 224, 1, dWo0, 64, 218, P)
+    if _split_ok(P, 64):
+        _linear_split(g_o1, wo0, w_transposed=True, out=g_cat)                  # d cat = g_o1 W (split-precision kernel)
+    else:
+        _gemm(g_o1, 64, 1, wo0, 218, 1, g_cat, P, 218, 64, ldc=224)
+    dWp = e(64, 224)                                                            # against the 224-wide (zero-padded) concat tile
     dbo0 = e(64)
-    _capi.check(lib.pf_colsum_f32(g_o1.data_ptr(), 64, P, 64, dbo0.data_ptr(), 0, st), "pf_colsum_f32")
+    _capi.check(lib.pf_gemm_tn_wide(g_o1.data_ptr(), 64, 64, saved["cat"].data_ptr(), 224, 224, dWp.data_ptr(), 224, P, 0,
+                                    dbo0.data_ptr(), 0, st), "pf_gemm_tn_wide")
+    dWo0 = dWp[:, :218]
     G["edge_embedder.out_mlp.0.weight"], G["edge_embedder.out_mlp.0.bias"] = dWo0, dbo0
     t_aap, t_rel = _zeros(484, 64, device=dev), _zeros(65, 64, device=dev)
     _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr(), 224, aap.data_ptr(), None, P, 64, t_aap.data_ptr(), st), "pf_embedding_bwd_atomic")

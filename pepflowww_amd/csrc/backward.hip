@@ -153,25 +153,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
 // consecutive columns" of the staged chunk, i.e. the natural layout (v_mfma_f32_16x16x4_f32: lane = column, lane >> 4 = r).
 // Optionally also the column sums of A (the bias gradient) from the staged chunks -- no separate pass over A.
 constexpr int WK = 32;                            // rows per staged chunk (64: slower, 12 float4 of staging per thread)
-constexpr int WLD = 192 + 16;                     // LDS row stride (floats): rows r, r+1 land 16 banks apart
+constexpr int WLD = 192 + 16;                     // LDS row stride (floats) of A (and of B for N <= 192): rows r, r+1 land 16 banks apart
+// NTW = n tiles per wave: 6 (N <= 192) or 8 (N <= 256, e.g. the 224-wide concat tile of the edge embedder)
+template <int NTW>
 __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
                                                            long long R, long long rows_per_wg, float* colsum_a) {
     extern __shared__ __attribute__((aligned(16))) float wide_sm[];
+    constexpr int WLDB = 32 * NTW + 16;
     float* As = wide_sm;
     float* Bs = wide_sm + WK * WLD;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave & 3, wn = wave >> 2;
     const int MT = (M + 15) >> 4, NT = (N + 15) >> 4;
-    const int mt0 = wm * 3, nt0 = wn * 6;
+    const int mt0 = wm * 3, nt0 = wn * NTW;
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
-    f32x4 acc[3][6];
+    f32x4 acc[3][NTW];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float cs = 0.f;
     const int m4 = M >> 2, n4 = N >> 2, per = m4 + n4;            // float4 per row of [A | B]
-    constexpr int NLD = (WK * 96 + 511) / 512;                     // float4 per thread per chunk (6)
+    constexpr int NLD = (WK * (48 + 8 * NTW) + 511) / 512;         // float4 per thread per chunk (6 / 7)
     float4 stage[NLD];
     auto fetch = [&](long long rb) {
 #pragma unroll
@@ -192,12 +195,13 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int l
             const int rr = idx / per, c = idx - rr * per;
             if (rr < WK) {
                 if (c < m4) *reinterpret_cast<float4*>(As + rr * WLD + 4 * c) = stage[q];
-                else *reinterpret_cast<float4*>(Bs + rr * WLD + 4 * (c - m4)) = stage[q];
+                else *reinterpret_cast<float4*>(Bs + rr * WLDB + 4 * (c - m4)) = stage[q];
             }
         }
     };
     // columns beyond M / N of the last 16-wide tile read as zero
-    for (int i = tid; i < WK * WLD; i += 512) { As[i] = 0.f; Bs[i] = 0.f; }
+    for (int i = tid; i < WK * WLD; i += 512) As[i] = 0.f;
+    for (int i = tid; i < WK * WLDB; i += 512) Bs[i] = 0.f;
     __syncthreads();
     if (r0 < r1) fetch(r0);
     for (long long rb = r0; rb < r1; rb += WK) {
@@ -214,15 +218,15 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int l
         const int col = lane & 15, kr = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < WK / 4; ++ks) {
-            float a[3], b[6];
+            float a[3], b[NTW];
 #pragma unroll
             for (int i = 0; i < 3; ++i) a[i] = As[(4 * ks + kr) * WLD + 16 * (mt0 + i) + col];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) b[j] = Bs[(4 * ks + kr) * WLD + 16 * (nt0 + j) + col];
+            for (int j = 0; j < NTW; ++j) b[j] = Bs[(4 * ks + kr) * WLDB + 16 * (nt0 + j) + col];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int l
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (mt0 + i >= MT || nt0 + j >= NT) continue;
             const int n = 16 * (nt0 + j) + (lane & 15);
 #pragma unroll
@@ -886,7 +890,7 @@ extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, i
 }
 extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, long long R,
                                int accumulate, float* colsum_a, int colsum_accumulate, pf_stream_t stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || M > 192 || N > 192) return PF_E_BADARG;
+    if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || M > 192 || N > 256) return PF_E_BADARG;
     if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) { if (ldc == N) zero_fill(C, (size_t)M * N, s); else zero_fill_2d(C, M, N, ldc, s); }
@@ -895,13 +899,17 @@ extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, i
     static const long long cap = [] { const char* e = getenv("PF_TN_WGS"); return e ? atoll(e) : 256LL; }();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (nwg > cap) nwg = cap;
     long long per = ((R + nwg - 1) / nwg + WK - 1) / WK * WK;
     nwg = (R + per - 1) / per;
-    hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3((unsigned)nwg), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
+    if (N <= 192)
+        hipLaunchKernelGGL(gemm_tn_wide_kernel<6>, dim3((unsigned)nwg), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
+    else
+        hipLaunchKernelGGL(gemm_tn_wide_kernel<8>, dim3((unsigned)nwg), dim3(512), (size_t)WK * (WLD + 272) * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
     PF_CHECK_LAUNCH();
     return 0;
 }
