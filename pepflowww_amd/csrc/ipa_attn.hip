@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
         // ---- phase D2: zbar[h][c] = sum_j P[h][j] z[i][j][c] ; o_pair = W_dz zbar + b_dz ----
         {
             const int c4 = lane & 15, js = lane >> 4;
-            float* zb = ZB + wave * HG * 64;
+            float* zb = ZB + wave * 4 * HG * 64;                 // [4 rows][HG][64]
             // down_z row d = lane & 15 of this lane's o_pair outputs, kept in registers for all four query rows
             float4 wdz[16];
     #pragma unroll
@@ -566,52 +566,59 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
             };
             float4 zq[ZBATCH], zn[ZBATCH];
             if (nbt > 0) zload(0, zq);
-            float4 zacc[HG];
-            for (int bi = 0; bi < nbt; ++bi) {
-                if (bi + 1 < nbt) zload(bi + 1, zn);
-                const int t4 = bi / nbr, jb = (bi - t4 * nbr) * 4 * ZBATCH;
-                const int ti = wave * 4 + t4, i = i0 + ti;
-                if (jb == 0) {
+            // the four query rows of the wave are accumulated FIRST (one accumulator set per row, rows unrolled so that the sets
+            // stay in registers) and reduced / handed over / projected TOGETHER: done row by row, the tail -- 8 cross-lane sums,
+            // an LDS hand-off and a 16-output GEMV per head on half the lanes -- was a serial chain repeated four times
+            float4 zacc[4][HG];
+            int bi = 0;
 #pragma unroll
-                    for (int h = 0; h < HG; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            for (int t4 = 0; t4 < 4; ++t4) {
 #pragma unroll
-                for (int u = 0; u < ZBATCH; ++u) {
-                    const int jj = jb + 4 * u + js;
-                    const float keep = jj < L ? 1.f : 0.f;
+                for (int h = 0; h < HG; ++h) zacc[t4][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t4 < nrow) {                                              // wave-uniform
+                    const int ti = wave * 4 + t4;
+                    for (int b = 0; b < nbr; ++b, ++bi) {
+                        if (bi + 1 < nbt) zload(bi + 1, zn);
+                        const int jb = b * 4 * ZBATCH;
 #pragma unroll
-                    for (int h = 0; h < HG; ++h) {
-                        const float pw = S[(ti * HG + h) * LDS_S + (jj < L ? jj : 0)] * keep;
-                        zacc[h].x += pw * zq[u].x; zacc[h].y += pw * zq[u].y; zacc[h].z += pw * zq[u].z; zacc[h].w += pw * zq[u].w;
+                        for (int u = 0; u < ZBATCH; ++u) {
+                            const int jj = jb + 4 * u + js;
+                            const float keep = jj < L ? 1.f : 0.f;
+#pragma unroll
+                            for (int h = 0; h < HG; ++h) {
+                                const float pw = S[(ti * HG + h) * LDS_S + (jj < L ? jj : 0)] * keep;
+                                zacc[t4][h].x += pw * zq[u].x; zacc[t4][h].y += pw * zq[u].y;
+                                zacc[t4][h].z += pw * zq[u].z; zacc[t4][h].w += pw * zq[u].w;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < ZBATCH; ++u) zq[u] = zn[u];
                     }
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < ZBATCH; ++u) zq[u] = zn[u];
-                if (jb + 4 * ZBATCH < L) continue;                            // more batches of this row (wave-uniform)
+            for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
                 for (int h = 0; h < HG; ++h) {
-                    float4 v = zacc[h];
+                    float4 v = zacc[t4][h];
                     v.x = sum_xor32(sum_xor16(v.x)); v.y = sum_xor32(sum_xor16(v.y));
                     v.z = sum_xor32(sum_xor16(v.z)); v.w = sum_xor32(sum_xor16(v.w));
-                    if (js == 0) *reinterpret_cast<float4*>(zb + h * 64 + 4 * c4) = v;
+                    if (js == 0) *reinterpret_cast<float4*>(zb + (t4 * HG + h) * 64 + 4 * c4) = v;
                 }
-                // wave-private LDS hand-off: only the LDS counter has to drain (a workgroup fence would also wait for the
-                // z prefetch that is in flight)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                for (int o = lane; o < HG * 16; o += 64) {       // outputs (hh, d = lane & 15)
-                    const int hh = o >> 4, d = o & 15;
-                    float acc = bdz;
-                    const float* zz = zb + hh * 64;
+            // wave-private LDS hand-off: only the LDS counter has to drain
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (int o = lane; o < 4 * HG * 16; o += 64) {       // outputs (row t4, head hh, d = lane & 15)
+                const int t4 = o / (HG * 16), hh = (o >> 4) % HG, d = o & 15;
+                const int i = i0 + wave * 4 + t4;
+                float acc = bdz;
+                const float* zz = zb + (t4 * HG + hh) * 64;
     #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const float4 zv = *reinterpret_cast<const float4*>(zz + 4 * c);
-                        acc += wdz[c].x * zv.x; acc += wdz[c].y * zv.y; acc += wdz[c].z * zv.z; acc += wdz[c].w * zv.w;
-                    }
-                    a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
+                for (int c = 0; c < 16; ++c) {
+                    const float4 zv = *reinterpret_cast<const float4*>(zz + 4 * c);
+                    acc += wdz[c].x * zv.x; acc += wdz[c].y * zv.y; acc += wdz[c].z * zv.z; acc += wdz[c].w * zv.w;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
+                if (t4 < nrow) a.feats[(rowb + i) * PF_IPA_FEATS + 1408 + (h0 + hh) * 16 + d] = acc;
             }
         }
     }
@@ -622,7 +629,7 @@ template <int HG, int NW>
 int launch_attn(const pf_ipa_attn_args& a, hipStream_t s) {
     const int LP = (a.L + 15) / 16 * 16;
     const int LDS_S = LP + 4;
-    const size_t lds = ((size_t)TI * HG * LDS_S + TI * HG * 24 + TI * HG * 36 + NW * HG * 64) * sizeof(float);
+    const size_t lds = ((size_t)TI * HG * LDS_S + TI * HG * 24 + TI * HG * 36 + NW * HG * 64 * (HG < 4 ? 4 : 1)) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
     static bool attr_set = false;
     if (!attr_set) {
