@@ -125,6 +125,37 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
     const size_t rowb = (size_t)b * L;
 
     PROF(0);
+    // Phase B's first operands (the wave's Q fragments, its first key tile, masks, the head's point weight) are requested
+    // HERE: they come from the projection the previous kernel wrote (another XCD's L2 -> ~3 us), and requested at the top
+    // of phase B that latency sat in front of the first MFMA; now it runs under phases 0 / A'.
+    constexpr float scale_pt = 0.09622504486493763f;          // sqrt(1/(3*(8*9/2)))
+    const int b_hh0 = (wave / WPH) * HPW, b_tile_off = wave % WPH;
+    float4 qf0[8], kf0[8], kp40[6];
+    float mj0, mi4[4], hw0;
+    auto loadk_h = [&](int h, int j0, float4 (&kf)[8], float4 (&kp4)[6], float& mj) {
+        const int j = j0 + r;
+        const bool jok = j < L;
+        const float* krow = a.proj + (rowb + (jok ? j : 0)) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
+        const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) kf[s8] = *reinterpret_cast<const float4*>(krow + 16 * s8);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) kp4[q] = *reinterpret_cast<const float4*>(kp + 4 * q);
+        mj = a.mask[rowb + (jok ? j : 0)] * (jok ? 1.f : 0.f);
+    };
+    auto loadq_h = [&](int h, float4 (&qf)[8]) {
+        const int i = i0 + r;
+        // (unconditional loads from a clamped row: a select / branch around a load puts an s_waitcnt right behind it;
+        //  rows beyond L only produce logits that are never stored or are masked to -1e5)
+        const float* qrow = a.proj + (rowb + (i < L ? i : 0)) * a.ldp + h * C + 4 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+    };
+    loadq_h(h0 + b_hh0, qf0);
+    loadk_h(h0 + b_hh0, 16 * b_tile_off, kf0, kp40, mj0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = i0 + 4 * g + e; mi4[e] = a.mask[rowb + min(i, L - 1)] * (i < L ? 1.f : 0.f); }
+    hw0 = a.head_w[h0 + b_hh0];
     // ---- phase 0: query points of this head group -> LDS ----
     for (int idx = tid; idx < TI * HG * 24; idx += NTH) {
         const int ti = idx / (HG * 24), c = idx - ti * (HG * 24);
@@ -247,42 +278,34 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
     PROF(2);
     // ---- phase B: scalar qk (MFMA) + point term + mask ----
     const float scale_qk = 0.051031036307982884f;            // sqrt(1/(3*128))
-    const float scale_pt = 0.09622504486493763f;              // sqrt(1/(3*(8*9/2)))
     {
-        const int hh0 = (wave / WPH) * HPW;
-        const int tile_off = wave % WPH;
-        // query-row masks are tile-invariant: loaded ONCE.  (A global load issued inside the tile loop would make
-        // its s_waitcnt drain the whole in-order vmcnt queue, i.e. the next tile's prefetch, every iteration.)
-        float mi4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const int i = i0 + 4 * g + e; mi4[e] = a.mask[rowb + min(i, L - 1)] * (i < L ? 1.f : 0.f); }
+        const int hh0 = b_hh0;
+        const int tile_off = b_tile_off;
+        // (query-row masks are tile-invariant: loaded ONCE, at kernel entry.  A global load issued inside the tile loop would
+        // make its s_waitcnt drain the whole in-order vmcnt queue, i.e. the next tile's prefetch, every iteration.)
         for (int hq = 0; hq < HPW; ++hq) {
             const int hh = hh0 + hq, h = h0 + hh;
-            const float gamma = softplusf(a.head_w[h]) * scale_pt;
+            const float gamma = softplusf(hq == 0 ? hw0 : a.head_w[h]) * scale_pt;
             float4 qf[8];
-            {
-                const int i = i0 + r;
-                // (unconditional loads from a clamped row: a select / branch around a load puts an s_waitcnt right behind it;
-                //  rows beyond L only produce logits that are never stored or are masked to -1e5)
-                const float* qrow = a.proj + (rowb + (i < L ? i : 0)) * a.ldp + h * C + 4 * g;
+            if (hq == 0) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+                for (int s = 0; s < 8; ++s) qf[s] = qf0[s];
+            } else {
+                loadq_h(h, qf);
             }
             // operands of key tile j0: 8 K fragments, 8 key points (24 floats), key mask; next tile prefetched
-            auto loadk = [&](int j0, float4 (&kf)[8], float4 (&kp4)[6], float& mj) {
-                const int j = j0 + r;
-                const bool jok = j < L;
-                const float* krow = a.proj + (rowb + (jok ? j : 0)) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
-                const float* kp = a.kp + (rowb + (jok ? j : 0)) * 192 + h * 24;
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) kf[s8] = *reinterpret_cast<const float4*>(krow + 16 * s8);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) kp4[q] = *reinterpret_cast<const float4*>(kp + 4 * q);
-                mj = a.mask[rowb + (jok ? j : 0)] * (jok ? 1.f : 0.f);
-            };
+            auto loadk = [&](int j0, float4 (&kf)[8], float4 (&kp4)[6], float& mj) { loadk_h(h, j0, kf, kp4, mj); };
             float4 kf[8], kp4[6];
             float mj;
-            loadk(16 * tile_off, kf, kp4, mj);
+            if (hq == 0) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) kf[s8] = kf0[s8];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) kp4[q] = kp40[q];
+                mj = mj0;
+            } else {
+                loadk(16 * tile_off, kf, kp4, mj);
+            }
             for (int j0 = 16 * tile_off; j0 < LP; j0 += 16 * WPH) {
                 const int j = j0 + r;
                 const bool jok = j < L;
