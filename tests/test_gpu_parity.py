@@ -650,6 +650,29 @@ def test_gemm_three_forms():
 
 
 
+@pytest.mark.parametrize("N,K", [(192, 192), (218, 64), (64, 128), (3744, 128)])
+def test_split_pack_kernel_equals_host_packing(N, K):
+    """pf_split_pack_f16 (device-side fragment packing used per step by the training path) produces exactly the planes of
+    engine.split_f16, for W and for W^T given as [K, N]; and a split-precision Linear with gate / residual epilogue on them
+    matches float64."""
+    from pepflowww_amd import backward as Bk
+    from pepflowww_amd.engine import split_f16
+    g = torch.Generator().manual_seed(N + K)
+    w = torch.randn(N, K, generator=g) * 0.1
+    host = split_f16(cu(w)).reshape(-1)
+    dev_plain = Bk._split_pack(cu(w))
+    dev_t = Bk._split_pack(cu(w.t().contiguous()), transpose=True)
+    G.sync()
+    assert torch.equal(dev_plain.cpu(), host.cpu()) and torch.equal(dev_t.cpu(), host.cpu())
+    if N % 4 == 0:
+        M = 8192
+        x, gate, res = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+        y = Bk._linear_split(cu(x), cu(w), gate=cu(gate), residual=cu(res))
+        G.sync()
+        ref = (x.double() @ w.double().t()) * (gate > 0) + res.double()
+        assert (y.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
 @pytest.mark.parametrize("R,M,N", [(4096, 192, 192), (1000, 8, 64), (8192 + 24, 64, 192), (333, 16, 16)])
 def test_gemm_tn_wide(R, M, N):
     """pf_gemm_tn_wide: C (+)= A^T B and column sums of A in one pass, against float64 (ragged row counts, narrow C,
