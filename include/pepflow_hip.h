@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 22
+#define PF_ABI_VERSION 23
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -260,6 +260,9 @@ typedef struct {
      * from the normalised, masked z' while it is still in registers: bias_out [B*L*L, 8], wb_frags = linear_b
      * of the next block as 2 split-precision fragment pairs (pepflowww_amd.engine.pack_bias_frags), bb = its bias [8]. */
     float* bias_out; const void* wb_frags; const float* bb;
+    /* optional (persistent kernel only; all three or none): the training forward keeps what the backward needs --
+     * dump_h1 / dump_h2 [B*L*L,192] = relu(W1 x + b1), relu(W2 h1 + b2); dump_y [B*L*L,64] = the pre-LayerNorm output */
+    float* dump_h1; float* dump_h2; float* dump_y;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -59,7 +59,7 @@ class RigidUpdateArgs(C.Structure):
 class EdgeTransitionArgs(C.Structure):
     _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1z_f16", _fp), ("w2_f16", _fp), ("b2", _fp), ("wf_f16", _fp),
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
-                ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp)]
+                ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp)]
 
 
 class SamplerArgs(C.Structure):

@@ -462,12 +462,76 @@ def quat_to_rot_bwd(quat, g_rot, g_quat=None):
 
 
 # ------------------------------------------------------------------------------------------------- EdgeTransition
+_ET_STREAM_IDX = {}
+
+
+def _et_stream_index(device):
+    """engine.pack_et_stream as flat indices into cat([trunk.0.weight, trunk.2.weight, final_layer.weight]) -> [128, 512]:
+    fragment pair q holds, for lane l and slot e, the weight W[16 ft + (l & 15)][kidx[l >> 4][e]] (same stage order)."""
+    key = str(device)
+    if key in _ET_STREAM_IDX:
+        return _ET_STREAM_IDX[key]
+    kg, i8, lane = torch.arange(4)[:, None], torch.arange(8)[None, :], torch.arange(64)
+    ident = lambda st: 32 * st + 8 * kg + i8
+    perm = lambda st: 32 * st + 16 * (i8 >> 2) + 4 * kg + (i8 & 3)
+    OFF2, OFFF = 192 * 192, 2 * 192 * 192
+
+    def frag(base, ft, kidx):
+        rows = 16 * ft + (lane & 15)
+        return (base + rows[:, None] * 192 + kidx[lane >> 4]).reshape(-1)                     # [512]
+    out = []
+    for ft in range(12):
+        out += [frag(0, ft, ident(st)) for st in range(2)]
+    for t in range(4):
+        out += [frag(OFFF, t, ident(st)) for st in range(2)]
+    for c in range(6):
+        for ft in (2 * c, 2 * c + 1):
+            out += [frag(OFF2, ft, perm(k)) for k in range(6)]
+        out += [frag(OFFF, t, perm(c)) for t in range(4)]
+    idx = torch.stack(out).to(device)
+    assert idx.shape == (128, 512)
+    _ET_STREAM_IDX[key] = idx
+    return idx
+
+
 class EdgeTransitionBlock:
     """EdgeTransition of one trunk block (ipa_pytorch.py:233-248 + ga.py:118) in unfused, saved-activation form and its
     backward (the inference path uses the fused persistent kernel instead)."""
 
     def __init__(self, W, b, B, L, mask):
         self.W, self.b, self.B, self.L, self.mask = W, b, B, L, mask
+
+    # forward on the persistent inference kernel (with h1 / h2 / y dumps) instead of three Linears (PF_ET_FUSED_FWD=0: unfused)
+    FUSED_FORWARD = os.environ.get("PF_ET_FUSED_FWD", "1") != "0"
+
+    def _forward_fused(self, s, z, n, x, em):
+        """z' = mask * LN(Wf(h2 + x) + bf) by pf_edge_transition_fwd's persistent kernel, which also stores h1, h2 and the
+        pre-LayerNorm y for the backward (3 pair-sized Linears + LayerNorm + mask = ~1 ms per block otherwise)."""
+        lib, B, L, W, p = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}."
+        dev, P = s.device, B * L * L
+        w1, w2, wf = W[p + "trunk.0.weight"], W[p + "trunk.2.weight"], W[p + "final_layer.weight"]
+        b1, bf = W[p + "trunk.0.bias"], W[p + "final_layer.bias"]
+        # per-residue terms a | c | d | e (include/pepflow_hip.h, pf_edge_transition_args)
+        pre_w = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
+        pre_b = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
+        pre = linear_fwd(n, pre_w, pre_b)
+        # the 256 KiB fragment stream (engine.pack_et_stream) by one gather through a static index + the hi / lo split
+        idx = _et_stream_index(dev)
+        v = torch.cat([w1.reshape(-1), w2.reshape(-1), wf.reshape(-1)])[idx]                    # [128, 512]
+        hi = v.to(torch.float16)
+        lo = ((v - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+        stream = torch.stack([hi, lo], 1).contiguous()                                          # [128, 2, 512] f16
+        out, h1, h2, y = (torch.empty(P, 64, device=dev), torch.empty(P, 192, device=dev), torch.empty(P, 192, device=dev),
+                          torch.empty(P, 64, device=dev))
+        a = _capi.EdgeTransitionArgs()
+        a.z_in, a.z_out, a.pre = z.data_ptr(), out.data_ptr(), pre.data_ptr()
+        a.b2, a.ln_g, a.ln_b = W[p + "trunk.2.bias"].data_ptr(), W[p + "layer_norm.weight"].data_ptr(), W[p + "layer_norm.bias"].data_ptr()
+        a.mask, a.B, a.L, a.w_stream = self.mask.data_ptr(), B, L, stream.data_ptr()
+        a.dump_h1, a.dump_h2, a.dump_y = h1.data_ptr(), h2.data_ptr(), y.data_ptr()
+        _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
+        u = add_out(h2, x)
+        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, u=u, y=y)
+        return out
 
     def forward(self, s, z):
         lib, B, L, W, p = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}."
@@ -476,6 +540,8 @@ class EdgeTransitionBlock:
         x = torch.empty(B * L * L, 192, device=dev)
         em = torch.empty(B * L * L, device=dev)
         _capi.check(lib.pf_et_concat(z.data_ptr(), n.data_ptr(), self.mask.data_ptr(), x.data_ptr(), em.data_ptr(), B, L, _capi.stream_ptr()), "pf_et_concat")
+        if self.FUSED_FORWARD:
+            return self._forward_fused(s, z, n, x, em)
         h1 = linear_fwd(x, W[p + "trunk.0.weight"], W[p + "trunk.0.bias"], relu=True)
         h2 = linear_fwd(h1, W[p + "trunk.2.weight"], W[p + "trunk.2.bias"], relu=True)
         u = add_out(h2, x)                                       # final_layer(h2 + x)

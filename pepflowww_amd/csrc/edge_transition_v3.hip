@@ -117,6 +117,9 @@ __device__ __forceinline__ f32x4 add4(const float4& a, const float4& b) { return
 
 struct Tile { int b, i0, j0; };
 
+// DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
+// (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
+template <bool DUMP>
 __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         const Tile tl = tile_of(tile);
         const int i = tl.i0 + wave, j = tl.j0 + r;
         const bool valid = i < L && j < L;
+        const size_t pidx = (size_t)(tl.b * L + i) * L + j;
         half8 h1h[6], h1l[6];
         f32x4 m3[4], c3[4];
         half8 zh[2], zl[2];
@@ -290,6 +294,12 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             v0.z = fmaxf(JOIN(m0[2], c0[2]), 0.f); v0.w = fmaxf(JOIN(m0[3], c0[3]), 0.f);
             v1.x = fmaxf(JOIN(m1[0], c1[0]), 0.f); v1.y = fmaxf(JOIN(m1[1], c1[1]), 0.f);
             v1.z = fmaxf(JOIN(m1[2], c1[2]), 0.f); v1.w = fmaxf(JOIN(m1[3], c1[3]), 0.f);
+            if constexpr (DUMP) {
+                if (valid) {
+                    *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 4 * g) = v0;
+                    *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 16 + 4 * g) = v1;
+                }
+            }
             split8(v0, v1, h1h[tp], h1l[tp]);
         }
         PROF3(5);
@@ -338,6 +348,12 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             v1.x = fmaxf(JOIN(m1[0], c1[0]), 0.f); v1.y = fmaxf(JOIN(m1[1], c1[1]), 0.f);
             v1.z = fmaxf(JOIN(m1[2], c1[2]), 0.f); v1.w = fmaxf(JOIN(m1[3], c1[3]), 0.f);
             half8 xh, xl;
+            if constexpr (DUMP) {
+                if (valid) {
+                    *reinterpret_cast<float4*>(a.dump_h2 + pidx * 192 + 32 * c + 4 * g) = v0;
+                    *reinterpret_cast<float4*>(a.dump_h2 + pidx * 192 + 32 * c + 16 + 4 * g) = v1;
+                }
+            }
             split8(v0, v1, xh, xl);
             const Frag w0 = ldfrag(sl, 12, lane), w1 = ldfrag(sl, 13, lane), w2 = ldfrag(sl, 14, lane), w3 = ldfrag(sl, 15, lane);
             mac2(w0, w1, xh, xl, m3[0], c3[0], m3[1], c3[1]);
@@ -354,6 +370,13 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             y[4 * t + 1] = JOIN(m3[t][1], c3[t][1]);
             y[4 * t + 2] = JOIN(m3[t][2], c3[t][2]);
             y[4 * t + 3] = JOIN(m3[t][3], c3[t][3]);
+        }
+        if constexpr (DUMP) {
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    *reinterpret_cast<float4*>(a.dump_y + pidx * 64 + 16 * t + 4 * g) = make_float4(y[4 * t], y[4 * t + 1], y[4 * t + 2], y[4 * t + 3]);
+            }
         }
         float s = 0.f;
 #pragma unroll
@@ -375,7 +398,6 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             o4[t].z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk;
             o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk;
         }
-        const size_t pidx = (size_t)(tl.b * L + i) * L + j;
         if (valid) {
             float* zo = a.z_out + pidx * 64 + 4 * g;
 #pragma unroll
@@ -426,11 +448,17 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
     const int grid = (int)(nt < ncu ? nt : ncu);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
         attr_set = true;
     }
-    hipLaunchKernelGGL(edge_transition_v3_kernel, dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    if (a->dump_h1 || a->dump_h2 || a->dump_y) {
+        if (!a->dump_h1 || !a->dump_h2 || !a->dump_y) return PF_E_BADARG;
+        hipLaunchKernelGGL(edge_transition_v3_kernel<true>, dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    } else {
+        hipLaunchKernelGGL(edge_transition_v3_kernel<false>, dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    }
     PF_CHECK_LAUNCH();
     return 0;
 }

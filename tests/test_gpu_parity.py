@@ -890,7 +890,52 @@ def test_edge_transition_block_backward_vs_reference(f4, f5, f6, seeded_sd):
     assert abs(g_z.norm().item() - 0) > 0 and torch.isfinite(g_z).all() and torch.isfinite(g_s).all()
 
 
-def test_trunk_backward_vs_reference(f4, f5, f6, seeded_sd):
+@pytest.fixture
+def unfused_et_forward(monkeypatch):
+    """The comparisons against the REFERENCE's gradients run the training forward of EdgeTransition on the three stand-alone
+    Linears.  On the golden fixture batch the gradient is discontinuous at fp32 resolution: ANY 2e-6 perturbation of
+    EdgeTransition(0)'s output -- random noise on the unfused path or the fused kernel's different rounding -- moves the same
+    parameters by the same 2-4e-3 (tools/dev/dbg_cond.py), while the unfused path happens to round like the reference
+    (worst gradient-norm deviation 2e-5).  The fused training forward is pinned separately:
+    test_fused_edge_transition_training_forward."""
+    from pepflowww_amd import backward as Bk
+    monkeypatch.setattr(Bk.EdgeTransitionBlock, "FUSED_FORWARD", False)
+
+
+@pytest.mark.parametrize("B,L", [(2, 32), (3, 24), (2, 22)])
+def test_fused_edge_transition_training_forward(seeded_sd, B, L):
+    """Training forward of EdgeTransition on the persistent inference kernel with h1 / h2 / y dumps == the three stand-alone
+    Linears + LayerNorm + mask: output and every saved tensor to fp32 rounding, and the block's backward on either set of
+    saved tensors gives the same gradients."""
+    from pepflowww_amd import backward as Bk
+    W = {k[len("ga_encoder.trunk."):]: cu(v.float().contiguous()) for k, v in seeded_sd.items() if k.startswith("ga_encoder.trunk.")}
+    g = torch.Generator().manual_seed(B * 100 + L)
+    s, z = cu(torch.randn(B * L, 128, generator=g)), cu(torch.randn(B * L * L, 64, generator=g))
+    mask = torch.ones(B * L)
+    mask[-3:] = 0
+    mask[L // 2] = 0
+    mask = cu(mask)
+    g_out = cu(torch.randn(B * L * L, 64, generator=g))
+    res = {}
+    for fused in (False, True):
+        blk = Bk.EdgeTransitionBlock(W, 1, B, L, mask)
+        blk.FUSED_FORWARD = fused
+        out = blk.forward(s, z)
+        saved = {k: v.clone() for k, v in blk.saved.items()}
+        g_s, g_z, G_ = blk.backward(g_out.clone())
+        G.sync()
+        res[fused] = (out.clone(), saved, g_s.clone(), g_z.clone(), {k: v.clone() for k, v in G_.items()})
+    o0, sv0, gs0, gz0, G0 = res[False]
+    o1, sv1, gs1, gz1, G1 = res[True]
+    assert (o0 - o1).abs().max().item() <= 2e-5
+    for k in ("h1", "h2", "u", "y", "x", "em"):
+        assert (sv0[k] - sv1[k]).abs().max().item() <= 2e-5, k
+    assert (gs0 - gs1).abs().max() <= 1e-4 * gs0.abs().max() and (gz0 - gz1).abs().max() <= 1e-4 * gz0.abs().max()
+    for k in G0:
+        assert (G0[k] - G1[k]).abs().max() <= 1e-4 * G0[k].abs().max() + 1e-6, k
+
+
+def test_trunk_backward_vs_reference(f4, f5, f6, seeded_sd, unfused_et_forward):
     """The whole GAEncoder backward: saved-activation forward on the reference's corrupted state == reference predictions;
     backward seeded by pf_train_losses_bwd reproduces the reference's gradient norm of EVERY ga_encoder parameter and its
     d/d(node state entering block 0..5), d/d(pair tensor entering block 1) (golden F5/F6)."""
@@ -922,7 +967,7 @@ def test_trunk_backward_vs_reference(f4, f5, f6, seeded_sd):
     assert not missing, missing[:8]
 
 
-def test_full_training_backward_vs_reference(f4, f5, f6, model, seeded_sd):
+def test_full_training_backward_vs_reference(f4, f5, f6, model, seeded_sd, unfused_et_forward):
     """The complete training step forward + backward on the device: encode (with saved intermediates) -> corruption ->
     saved-activation trunk forward -> six losses -> loss / trunk / encoder backward.  The gradient norm of EVERY one of the
     407 parameters of the model matches the reference's autograd (train.py:121,133; golden F6)."""
@@ -949,17 +994,22 @@ def test_full_training_backward_vs_reference(f4, f5, f6, model, seeded_sd):
     grads = {"ga_encoder." + k: v for k, v in grads.items()}
     grads.update(Bk.encoder_backward(sd_dev, saved, g_node, g_edge, B, L))
     G.sync()
-    bad = []
+    bad, worst = [], 0.0
     for name, refn in f6["_gradnorm"].items():
         if name not in grads:
             bad.append((name, "missing"))
-        elif abs(grads[name].norm().item() - refn) > 3 * REL * refn + 2e-6:
+            continue
+        dev_rel = abs(grads[name].norm().item() - refn) / (refn + 1e-12)
+        if abs(grads[name].norm().item() - refn) > 2e-6:
+            worst = max(worst, dev_rel)
+        if abs(grads[name].norm().item() - refn) > 3 * REL * refn + 2e-6:
             bad.append((name, grads[name].norm().item(), refn))
-    assert not bad, (len(bad), bad[:8])
+    print("worst relative gradient-norm deviation:", worst)
+    assert not bad, (len(bad), worst, bad[:8])
     assert len(grads) == len(f6["_gradnorm"]) == 407
 
 
-def test_training_step_through_autograd(f4, f6, seeded_sd):
+def test_training_step_through_autograd(f4, f6, seeded_sd, unfused_et_forward):
     """The reference's training-loop code runs unchanged: model.train(); loss = sum_weighted(model(batch)); loss.backward()
     (train.py:117-145) -> .grad of all 407 parameters with the reference's norms; an SGD step on them lowers the loss."""
     m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
