@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 23
+#define PF_ABI_VERSION 24
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -413,9 +413,13 @@ typedef struct {
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 /* weight gradient of a Linear over all pairs in one pass: C[M,N] (+)= A^T B with A = dy [R,M] (lda), B = x [R,N] (ldb),
  * M <= 192, N <= 256 (multiples of 4), and optionally colsum_a[M] (+)= column sums of A (the bias gradient).  One workgroup owns
- * the whole C for its row range, so A and B are read once (csrc/backward.hip: gemm_tn_wide_kernel). */
+ * the whole C for its row range, so A and B are read once (csrc/backward.hip: gemm_tn_wide_kernel; for N <= 192 the product
+ * runs on the split-precision f16 MFMA with transposing LDS reads, gemm_tn_split_kernel).  workspace (optional, device memory
+ * private to the stream, workspace_elems >= 256 * (M * N + M) floats): the workgroups store their partial sums there and a
+ * second kernel adds them up; without it they accumulate with device-scope atomics (~55 us slower at 256 workgroups). */
 int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, long long R,
-                    int accumulate, float* colsum_a, int colsum_accumulate, pf_stream_t stream);
+                    int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems,
+                    pf_stream_t stream);
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
 int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);                                /* dy *= (y > 0) */
 int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream);            /* dst = y > 0 ? src : 0 */

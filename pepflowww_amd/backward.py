@@ -6,6 +6,17 @@ import ctypes as C
 import torch
 
 _DEVICE_CONSTANTS = {}
+_TN_WORKSPACES = {}
+
+
+def _tn_workspace(device):
+    """Partial-sum workspace of pf_gemm_tn_wide (256 workgroups x (192 x 256 + 192) floats), one per (device, stream): calls on
+    the same stream are ordered, calls on different streams must not share it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _TN_WORKSPACES.get(key)
+    if ws is None:
+        ws = _TN_WORKSPACES[key] = torch.empty(256 * (192 * 256 + 192), device=device)
+    return ws
 
 
 def _zeros(*shape, device, dtype=torch.float32):
@@ -184,8 +195,9 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
         db, accb = _grad_buffer(N, device=x.device)
     if M >= TN_WIDE_MIN_ROWS and N <= 192 and K <= 192 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous():
         # dW and db in ONE pass over dy and x (csrc/backward.hip: gemm_tn_wide_kernel)
+        ws = _tn_workspace(x.device)
         _capi.check(lib.pf_gemm_tn_wide(dy.data_ptr(), N, N, x.data_ptr(), K, K, dW.data_ptr(), K, M, int(acc), db.data_ptr(), int(accb),
-                                        _capi.stream_ptr()), "pf_gemm_tn_wide")
+                                        ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_wide")
         return dx, dW, db
     _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc)
     _capi.check(lib.pf_colsum_f32(dy.data_ptr(), N, M, N, db.data_ptr(), int(accb), _capi.stream_ptr()), "pf_colsum_f32")
@@ -745,8 +757,9 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
         _gemm(g_o1, 64, 1, wo0, 218, 1, g_cat, P, 218, 64, ldc=224)
     dWp = e(64, 224)                                                            # against the 224-wide (zero-padded) concat tile
     dbo0 = e(64)
+    ws = _tn_workspace(dev)
     _capi.check(lib.pf_gemm_tn_wide(g_o1.data_ptr(), 64, 64, saved["cat"].data_ptr(), 224, 224, dWp.data_ptr(), 224, P, 0,
-                                    dbo0.data_ptr(), 0, st), "pf_gemm_tn_wide")
+                                    dbo0.data_ptr(), 0, ws.data_ptr(), ws.numel(), st), "pf_gemm_tn_wide")
     dWo0 = dWp[:, :218]
     G["edge_embedder.out_mlp.0.weight"], G["edge_embedder.out_mlp.0.bias"] = dWo0, dbo0
     t_aap, t_rel = _zeros(484, 64, device=dev), _zeros(65, 64, device=dev)

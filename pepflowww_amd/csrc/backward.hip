@@ -5,6 +5,7 @@
 //   pf_colsum_f32      db += sum_m dy[m, :]
 //   pf_relu_bwd        dy *= (y > 0)
 //   pf_layernorm_bwd   dx, dgamma, dbeta of nn.LayerNorm (eps 1e-5) over the last dimension
+#include <utility>
 #include "common.h"
 #include "rigid_dev.h"
 #include "../../include/pepflow_hip.h"
@@ -157,7 +158,7 @@ constexpr int WLD = 192 + 16;                     // LDS row stride (floats) of 
 // NTW = n tiles per wave: 6 (N <= 192) or 8 (N <= 256, e.g. the 224-wide concat tile of the edge embedder)
 template <int NTW>
 __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
-                                                           long long R, long long rows_per_wg, float* colsum_a) {
+                                                           long long R, long long rows_per_wg, float* colsum_a, float* part) {
     extern __shared__ __attribute__((aligned(16))) float wide_sm[];
     constexpr int WLDB = 32 * NTW + 16;
     float* As = wide_sm;
@@ -240,10 +241,363 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const float* A, int l
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int m = 16 * (mt0 + i) + 4 * (lane >> 4) + e;
-                if (m < M && n < N) atomicAdd(C + (size_t)m * ldc + n, acc[i][j][e]);
+                if (m < M && n < N) {
+                    if (part) part[(size_t)blockIdx.x * (M * N + M) + m * N + n] = acc[i][j][e];
+                    else atomicAdd(C + (size_t)m * ldc + n, acc[i][j][e]);
+                }
             }
         }
-    if (colsum_a && (tid & 255) < M) atomicAdd(colsum_a + (tid & 255), cs);
+    if (colsum_a && (tid & 255) < M) {
+        if (part) {                                                  // the two half-chunk sums meet in LDS: one plain store per column
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(wide_sm);
+            if (tid >= 256) red[tid & 255] = cs;
+            __syncthreads();
+            if (tid < 256) part[(size_t)blockIdx.x * (M * N + M) + M * N + tid] = cs + red[tid];
+        } else atomicAdd(colsum_a + (tid & 255), cs);
+    }
+}
+
+// ---- the same product on the split-precision f16 MFMA: C (+)= A^T B with the CONTRACTED index (pair rows) as the MFMA K.
+// The staged chunk is kept K-major ([row][column] f16 hi / lo planes, i.e. as it comes from memory) and the operands are
+// fetched with gfx950's transposing LDS read ds_read_b64_tr_b16: with the address pattern row = R0 + ((l & 15) >> 2),
+// col = C0 + 4 (l & 3) lane l receives image[R0 .. R0+3][C0 + (l & 15)] -- four consecutive K values of its own output row
+// (profiles/r01/v6_mfma_microbench.txt, tr_read_probe) -- two reads per 8-element operand.  3 f16 MFMAs of K = 32 replace 8 fp32
+// MFMAs of K = 4 (5.3x less matrix time): the kernel is left with streaming A and B once.
+__device__ __forceinline__ half4 lds_tr_b16(unsigned addr) {
+    half4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// transposing read with the tile / plane / half offset as the instruction's immediate: one address register serves all operands
+template <int OFF>
+__device__ __forceinline__ half4 lds_tr_b16_imm(unsigned addr) {
+    half4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF, int HALF>                                           // 8 K values: rows 0..3 and 4..7 (HALF bytes further) of the lane's group
+__device__ __forceinline__ half8 lds_tr_op(unsigned addr) {
+    const half4 lo4 = lds_tr_b16_imm<OFF>(addr), hi4 = lds_tr_b16_imm<OFF + HALF>(addr);
+    half8 o;
+    o[0] = lo4[0]; o[1] = lo4[1]; o[2] = lo4[2]; o[3] = lo4[3]; o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
+    return o;
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+template <int NTW>
+__global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
+                                                            long long R, long long rows_per_wg, float* colsum_a, float* part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tn_sm[];
+    constexpr int SA = 192 + 8, SB = 32 * NTW + 8;                 // plane row strides in f16 (rows of 32 K values per chunk)
+    constexpr int BUF = 2 * WK * (SA + SB);                         // f16 elements of one buffer: [Ah | Al | Bh | Bl]
+    _Float16* P0 = reinterpret_cast<_Float16*>(tn_sm);              // two buffers: chunk n + 1 is converted while chunk n is multiplied
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int MT = (M + 15) >> 4, NT = (N + 15) >> 4;
+    const int mt0 = wm * 3, nt0 = wn * NTW;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    f32x4 am[3][NTW], ac[3][NTW];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) { am[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[i][j] = am[i][j]; }
+    // staging map, fixed for the kernel: float4 q of this thread is element (rr, 4 c) of the A chunk (NLA of them) or of the
+    // B chunk (NLB); the launcher hands this kernel whole 32-row chunks only, so no row needs a bounds test
+    const int m4 = M >> 2, n4 = N >> 2;
+    constexpr int NLA = WK * 48 / 512, NLB = WK * 8 * NTW / 512;
+    int ga[NLA], la[NLA], gb[NLB], lb[NLB];
+#pragma unroll
+    for (int q = 0; q < NLA; ++q) {
+        const int idx = tid + q * 512, rr = idx / m4, c = idx - rr * m4;
+        const bool ok = rr < WK;
+        ga[q] = ok ? rr * lda + 4 * c : 0;
+        la[q] = ok ? rr * SA + 4 * c : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < NLB; ++q) {
+        const int idx = tid + q * 512, rr = idx / n4, c = idx - rr * n4;
+        const bool ok = rr < WK;
+        gb[q] = ok ? rr * ldb + 4 * c : 0;
+        lb[q] = ok ? 2 * WK * SA + rr * SB + 4 * c : -1;
+    }
+    float4 sa[NLA], sb[NLB];
+    float4 cs4[NLA];                                                 // column sums of A (the bias gradient) straight from the fp32 staging registers
+#pragma unroll
+    for (int q = 0; q < NLA; ++q) cs4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](long long rb) {
+        const float* Ar = A + (size_t)rb * lda;
+        const float* Br = B + (size_t)rb * ldb;
+#pragma unroll
+        for (int q = 0; q < NLA; ++q) sa[q] = *reinterpret_cast<const float4*>(Ar + ga[q]);
+#pragma unroll
+        for (int q = 0; q < NLB; ++q) sb[q] = *reinterpret_cast<const float4*>(Br + gb[q]);
+    };
+    auto commit = [&](_Float16* buf) {
+#pragma unroll
+        for (int q = 0; q < NLA; ++q)
+            if (la[q] >= 0) {
+                const float v[4] = {sa[q].x, sa[q].y, sa[q].z, sa[q].w};
+                cs4[q].x += v[0]; cs4[q].y += v[1]; cs4[q].z += v[2]; cs4[q].w += v[3];
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<half4*>(buf + la[q]) = hi;
+                *reinterpret_cast<half4*>(buf + WK * SA + la[q]) = lo;
+            }
+#pragma unroll
+        for (int q = 0; q < NLB; ++q)
+            if (lb[q] >= 0) {
+                const float v[4] = {sb[q].x, sb[q].y, sb[q].z, sb[q].w};
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<half4*>(buf + lb[q]) = hi;
+                *reinterpret_cast<half4*>(buf + WK * SB + lb[q]) = lo;
+            }
+    };
+    // columns beyond M / N of the last 16-wide tile read as zero
+    for (int i = tid; i < 2 * BUF / 8; i += 512) reinterpret_cast<uint4*>(tn_sm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // operand addresses: K rows 8 g + ((l & 15) >> 2) (+ 4 for the second read), columns 4 (l & 3) of a 16-wide tile; the lo plane,
+    // the tile and the second read are immediates of the instruction
+    const int g = lane >> 4, rq = (lane & 15) >> 2, cq = 4 * (lane & 3);
+    const unsigned adA0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)P0 + ((8 * g + rq) * SA + cq + 16 * mt0) * 2;
+    const unsigned adB0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)P0 + (2 * WK * SA + (8 * g + rq) * SB + cq + 16 * nt0) * 2;
+    constexpr int PLA = WK * SA * 2, PLB = WK * SB * 2, HA = 4 * SA * 2, HB = 4 * SB * 2;
+    // (the transposing reads are inline asm: the compiler does not count them in lgkmcnt, so every operand passes through an
+    //  explicit wait that it depends on before its first MFMA.)  The wave's three A tiles stay in registers for the chunk, the
+    //  B tiles stream through two register sets one tile ahead
+    auto multiply = [&](unsigned adA, unsigned adB) {
+        constexpr int O = 0;
+        half8 ah[3], al[3], bh[2], bl[2];
+        static_for(std::make_integer_sequence<int, 3>{}, [&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            ah[i] = lds_tr_op<O + 32 * i, HA>(adA);
+            al[i] = lds_tr_op<O + PLA + 32 * i, HA>(adA);
+        });
+        bh[0] = lds_tr_op<O, HB>(adB);
+        bl[0] = lds_tr_op<O + PLB, HB>(adB);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+        static_for(std::make_integer_sequence<int, NTW>{}, [&](auto jj) {
+            constexpr int j = decltype(jj)::value, c = j & 1, n = c ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[c]), "+v"(bl[c]));
+            if constexpr (j + 1 < NTW) { bh[n] = lds_tr_op<O + 32 * (j + 1), HB>(adB); bl[n] = lds_tr_op<O + PLB + 32 * (j + 1), HB>(adB); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) am[i][j] = mfma_h(ah[i], bh[c], am[i][j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ac[i][j] = mfma_h(ah[i], bl[c], ac[i][j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ac[i][j] = mfma_h(al[i], bh[c], ac[i][j]);
+        });
+    };
+    // one barrier per chunk: a wave converts chunk n + 1 into the other buffer right after its MFMAs of chunk n, while slower
+    // waves of the SIMD are still multiplying
+    if (r0 < r1) {
+        fetch(r0);
+        commit(P0);
+        __syncthreads();
+        if (r0 + WK < r1) fetch(r0 + WK);
+    }
+    int cur = 0;
+    for (long long rb = r0; rb < r1; rb += WK, cur ^= 1) {
+        multiply(adA0 + cur * BUF * 2, adB0 + cur * BUF * 2);
+        if (rb + WK < r1) commit(P0 + (cur ^ 1) * BUF);
+        __syncthreads();
+        if (rb + 2 * WK < r1) fetch(rb + 2 * WK);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            if (mt0 + i >= MT || nt0 + j >= NT) continue;
+            const int n = 16 * (nt0 + j) + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 16 * (mt0 + i) + 4 * (lane >> 4) + e;
+                if (m < M && n < N) {
+                    const float v = am[i][j][e] + ac[i][j][e] * PF_LO_INV;
+                    if (part) part[(size_t)blockIdx.x * (M * N + M) + m * N + n] = v;
+                    else atomicAdd(C + (size_t)m * ldc + n, v);
+                }
+            }
+        }
+    if (colsum_a) {                                                  // the threads' column quads meet in LDS
+        float* red = reinterpret_cast<float*>(tn_sm);
+        __syncthreads();
+        if (tid < 192) red[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NLA; ++q)
+            if (la[q] >= 0) {
+                const int c = 4 * ((tid + q * 512) % m4);
+                atomicAdd(red + c, cs4[q].x); atomicAdd(red + c + 1, cs4[q].y); atomicAdd(red + c + 2, cs4[q].z); atomicAdd(red + c + 3, cs4[q].w);
+            }
+        __syncthreads();
+        if (tid < M) {
+            if (part) part[(size_t)blockIdx.x * (M * N + M) + M * N + tid] = red[tid];
+            else atomicAdd(colsum_a + tid, red[tid]);
+        }
+    }
+}
+
+// ---- the same split-precision product with the C columns divided among workgroups: 4-wave workgroups own a 48-column piece
+// of C (all M rows) for their row range, so a lane holds 3 x 3 x 2 accumulator tiles (72 registers) instead of 144, three
+// workgroups fit a CU and 3 x 30 KB of loads are in flight per CU where the whole-C form has one 49 KB chunk and stalls on it
+// (3.85 TB/s of stream).  The price: every piece converts the A chunk again (VALU) and reads it again -- from L2: the pieces
+// of one row range sit on the same XCD (blockIdx & 7) next to each other in dispatch order.
+template <int NTW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tn_piece_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
+                                                            long long R, long long rows_per_wg, int nranges, int npieces,
+                                                            float* colsum_a, float* part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tn_sm[];
+    constexpr int SA = 192 + 8, SB = 16 * NTW + 8;
+    _Float16* Ah = reinterpret_cast<_Float16*>(tn_sm);
+    _Float16* Al = Ah + WK * SA;
+    _Float16* Bh = Al + WK * SA;
+    _Float16* Bl = Bh + WK * SB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int grp = blockIdx.x >> 3, piece = grp % npieces, range = (grp / npieces) * 8 + (blockIdx.x & 7);
+    if (range >= nranges) return;
+    const int n0 = piece * 16 * NTW;                                 // first C column of this piece
+    const int MT = (M + 15) >> 4, NTP = min(NTW, (N - n0 + 15) >> 4);
+    const int mt0 = wave * 3;
+    const long long r0 = (long long)range * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    f32x4 am[3][NTW], ac[3][NTW];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) { am[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[i][j] = am[i][j]; }
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);                   // column sums of A from the fp32 staging registers (piece 0)
+    // staging map: a 64-lane row of float4 covers [A row (M / 4 lanes) | this piece's B columns (<= 12 lanes)], wave w takes
+    // rows w, w + 4, ... of the chunk -- one pointer, one stride and one LDS offset per lane describe all 8 loads
+    const int m4 = M >> 2, nb4 = min(4 * NTW, (N - n0) >> 2);
+    const bool in_a = lane < m4, in_b = !in_a && lane < m4 + nb4, lane_ok = in_a || in_b;
+    const int ldl = in_b ? ldb : lda;                                // row stride of this lane's operand
+    const float* pl = in_b ? B + (size_t)(r0 + wave) * ldb + n0 + 4 * (lane - m4) : A + (size_t)(r0 + wave) * lda + (in_a ? 4 * lane : 0);
+    _Float16* lh = in_b ? Bh + wave * SB + 4 * (lane - m4) : Ah + wave * SA + 4 * lane;       // hi plane; the lo plane sits lo_off behind
+    const int lo_off = in_b ? WK * SB : WK * SA, lstep = 4 * (in_b ? SB : SA);
+    constexpr int NLD = WK / 4;
+    float4 st[NLD];
+    auto fetch = [&]() {                                             // the chunk pl points at (lanes beyond the row re-read A: unused)
+        const float* pq = pl;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) { st[q] = *reinterpret_cast<const float4*>(pq); pq += 4 * (size_t)ldl; }
+        pl += (size_t)WK * ldl;
+    };
+    const bool do_cs = colsum_a && piece == 0 && in_a;
+    auto commit = [&]() {
+        if (lane_ok) {
+            _Float16* lq = lh;
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const float v[4] = {st[q].x, st[q].y, st[q].z, st[q].w};
+                if (do_cs) { cs4.x += v[0]; cs4.y += v[1]; cs4.z += v[2]; cs4.w += v[3]; }
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<half4*>(lq) = hi;
+                *reinterpret_cast<half4*>(lq + lo_off) = lo;
+                lq += lstep;
+            }
+        }
+    };
+    for (int i = tid; i < WK * SA; i += 256) { Ah[i] = (_Float16)0.f; Al[i] = (_Float16)0.f; }
+    for (int i = tid; i < WK * SB; i += 256) { Bh[i] = (_Float16)0.f; Bl[i] = (_Float16)0.f; }
+    __syncthreads();
+    // operand addresses: K rows 8 g + ((l & 15) >> 2) (+ 4 for the second read), columns 4 (l & 3) of a 16-wide tile; the lo plane,
+    // the tile and the second read are immediates
+    const int g = lane >> 4, rq = (lane & 15) >> 2, cq = 4 * (lane & 3);
+    const unsigned adA = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)Ah + ((8 * g + rq) * SA + cq + 16 * mt0) * 2;
+    const unsigned adB = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)Bh + ((8 * g + rq) * SB + cq) * 2;
+    constexpr int PLA = WK * SA * 2, PLB = WK * SB * 2, HA = 4 * SA * 2, HB = 4 * SB * 2;
+    if (r0 < r1) fetch();
+    for (long long rb = r0; rb < r1; rb += WK) {
+        commit();
+        __syncthreads();
+        if (rb + WK < r1) fetch();
+        if (mt0 < MT) {
+            // (the transposing reads are inline asm: the compiler does not count them in lgkmcnt, so every operand passes through
+            //  an explicit wait that it depends on before its first MFMA; tiles beyond M / N multiply the planes' zero columns)
+            half8 bh[NTW], bl[NTW], ah[3], al[3];
+            static_for(std::make_integer_sequence<int, NTW>{}, [&](auto j) {
+                bh[j] = lds_tr_op<32 * decltype(j)::value, HB>(adB);
+                bl[j] = lds_tr_op<PLB + 32 * decltype(j)::value, HB>(adB);
+            });
+            ah[0] = lds_tr_op<0, HA>(adA); al[0] = lds_tr_op<PLA, HA>(adA);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[j]), "+v"(bl[j]));
+            static_for(std::make_integer_sequence<int, 3>{}, [&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+                if constexpr (i + 1 < 3) { ah[i + 1] = lds_tr_op<32 * (i + 1), HA>(adA); al[i + 1] = lds_tr_op<PLA + 32 * (i + 1), HA>(adA); }
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) am[i][j] = mfma_h(ah[i], bh[j], am[i][j]);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) ac[i][j] = mfma_h(ah[i], bl[j], ac[i][j]);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) ac[i][j] = mfma_h(al[i], bh[j], ac[i][j]);
+            });
+        }
+        __syncthreads();
+    }
+    const size_t pbase = (size_t)range * (M * N + M);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            if (mt0 + i >= MT || j >= NTP) continue;
+            const int n = n0 + 16 * j + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 16 * (mt0 + i) + 4 * (lane >> 4) + e;
+                if (m < M && n < N) {
+                    const float v = am[i][j][e] + ac[i][j][e] * PF_LO_INV;
+                    if (part) part[pbase + m * N + n] = v;
+                    else atomicAdd(C + (size_t)m * ldc + n, v);
+                }
+            }
+        }
+    if (colsum_a && piece == 0) {                                    // the four waves' row subsets meet in LDS
+        float* red = reinterpret_cast<float*>(tn_sm);
+        if (in_a) *reinterpret_cast<float4*>(red + wave * 192 + 4 * lane) = cs4;
+        __syncthreads();
+        if (tid < M) {
+            const float v = (red[tid] + red[192 + tid]) + (red[384 + tid] + red[576 + tid]);
+            if (part) part[pbase + M * N + tid] = v;
+            else atomicAdd(colsum_a + tid, v);
+        }
+    }
+}
+
+// second stage of the workspace form: C (+)= sum over workgroups of their partial C, colsum likewise.  64 outputs x 4 groups
+// of workgroups per block, the four group sums meet in LDS.  (Replaces nwg x M x N device-scope atomics on the same M x N
+// addresses -- ~55 us of serialised read-modify-writes at 256 workgroups -- by one coalesced write and read of the partials.)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* part, int nwg, int M, int N, float* C, int ldc, int accumulate,
+                                                        float* colsum_a, int colsum_accumulate) {
+    __shared__ float red[4][64];
+    const int S = M * N + (colsum_a ? M : 0), stride = M * N + M;
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (o < S) {
+        const float* p = part + o;
+        int w = g;
+        for (; w + 12 < nwg; w += 16) {
+            s0 += p[(size_t)w * stride]; s1 += p[(size_t)(w + 4) * stride]; s2 += p[(size_t)(w + 8) * stride]; s3 += p[(size_t)(w + 12) * stride];
+        }
+        for (; w < nwg; w += 4) s0 += p[(size_t)w * stride];
+    }
+    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && o < S) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (o < M * N) {
+            float* c = C + (size_t)(o / N) * ldc + o % N;
+            *c = accumulate ? *c + v : v;
+        } else {
+            float* c = colsum_a + (o - M * N);
+            *c = colsum_accumulate ? *c + v : v;
+        }
+    }
 }
 
 // zero fill as a KERNEL: a hipMemsetAsync captured into a hipGraph (memset node) was observed to race with the atomic
@@ -889,28 +1243,59 @@ extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, i
     return 0;
 }
 extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, long long R,
-                               int accumulate, float* colsum_a, int colsum_accumulate, pf_stream_t stream) {
+                               int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems,
+                               pf_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || M > 192 || N > 256) return PF_E_BADARG;
     if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) { if (ldc == N) zero_fill(C, (size_t)M * N, s); else zero_fill_2d(C, M, N, ldc, s); }
-    if (colsum_a && !colsum_accumulate) zero_fill(colsum_a, (size_t)M, s);
-    long long nwg = (R + 4 * WK - 1) / (4 * WK);
     static const long long cap = [] { const char* e = getenv("PF_TN_WGS"); return e ? atoll(e) : 256LL; }();
+    static const int use_split = [] { const char* e = getenv("PF_TN_SPLIT"); return e ? atoi(e) : 1; }();
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (nwg > cap) nwg = cap;
-    long long per = ((R + nwg - 1) / nwg + WK - 1) / WK * WK;
-    nwg = (R + per - 1) / per;
-    if (N <= 192)
-        hipLaunchKernelGGL(gemm_tn_wide_kernel<6>, dim3((unsigned)nwg), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
+    // the split-precision kernels take whole 32-row chunks; a ragged tail (< 32 rows) goes through the fp32 kernel
+    const bool split = use_split && R >= WK;
+    const long long Rm = split ? R / WK * WK : R;                   // rows of the main launch
+    static const int use_piece = [] { const char* e = getenv("PF_TN_PIECE"); return e ? atoi(e) : 0; }();
+    const bool piece = split && (use_piece || N > 192);
+    const int npieces = piece ? (N + 47) / 48 : 1;
+    // workgroups: the whole-C kernels one per CU; the piece kernel three per CU (768 slots shared by the pieces)
+    long long nwg = (Rm + 4 * WK - 1) / (4 * WK);
+    const long long wcap = piece ? (cap * 3 / npieces) / 8 * 8 : cap;
+    if (nwg > wcap) nwg = wcap;
+    const long long per = ((Rm + nwg - 1) / nwg + WK - 1) / WK * WK;
+    nwg = (Rm + per - 1) / per;
+    // with a workspace the workgroups store their partial C / column sums and a second kernel adds them up; without one they
+    // accumulate atomically into a zeroed C
+    float* part = workspace && workspace_elems >= nwg * ((long long)M * N + M) && nwg > 1 ? workspace : nullptr;
+    if (!part) {
+        if (!accumulate) { if (ldc == N) zero_fill(C, (size_t)M * N, s); else zero_fill_2d(C, M, N, ldc, s); }
+        if (colsum_a && !colsum_accumulate) zero_fill(colsum_a, (size_t)M, s);
+    }
+    if (piece) {
+        const unsigned grid = (unsigned)((nwg + 7) / 8 * 8 * npieces);
+        hipLaunchKernelGGL(gemm_tn_piece_kernel<3>, dim3(grid), dim3(256), (size_t)2 * WK * (200 + 56) * sizeof(_Float16), s, A, lda, M, B, ldb, N, C, ldc, Rm, per, (int)nwg, npieces, colsum_a, part);
+    } else if (split)
+        hipLaunchKernelGGL(gemm_tn_split_kernel<6>, dim3((unsigned)nwg), dim3(512), (size_t)2 * 2 * WK * (200 + 200) * sizeof(_Float16), s, A, lda, M, B, ldb, N, C, ldc, Rm, per, colsum_a, part);
+    else if (N <= 192)
+        hipLaunchKernelGGL(gemm_tn_wide_kernel<6>, dim3((unsigned)nwg), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, Rm, per, colsum_a, part);
     else
-        hipLaunchKernelGGL(gemm_tn_wide_kernel<8>, dim3((unsigned)nwg), dim3(512), (size_t)WK * (WLD + 272) * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, R, per, colsum_a);
+        hipLaunchKernelGGL(gemm_tn_wide_kernel<8>, dim3((unsigned)nwg), dim3(512), (size_t)WK * (WLD + 272) * sizeof(float), s, A, lda, M, B, ldb, N, C, ldc, Rm, per, colsum_a, part);
     PF_CHECK_LAUNCH();
+    if (part) {
+        const int S = M * N + (colsum_a ? M : 0);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, s, part, (int)nwg, M, N, C, ldc, accumulate, colsum_a, colsum_accumulate);
+        PF_CHECK_LAUNCH();
+    }
+    if (Rm < R) {                                                   // ragged tail: one workgroup, atomically on top
+        if (N <= 192) hipLaunchKernelGGL(gemm_tn_wide_kernel<6>, dim3(1), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A + (size_t)Rm * lda, lda, M, B + (size_t)Rm * ldb, ldb, N, C, ldc, R - Rm, (long long)WK, colsum_a, (float*)nullptr);
+        else hipLaunchKernelGGL(gemm_tn_wide_kernel<8>, dim3(1), dim3(512), (size_t)WK * (WLD + 272) * sizeof(float), s, A + (size_t)Rm * lda, lda, M, B + (size_t)Rm * ldb, ldb, N, C, ldc, R - Rm, (long long)WK, colsum_a, (float*)nullptr);
+        PF_CHECK_LAUNCH();
+    }
     return 0;
 }
 extern "C" int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream) {

@@ -673,20 +673,23 @@ def test_split_pack_kernel_equals_host_packing(N, K):
         assert (y.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
 
 
-@pytest.mark.parametrize("R,M,N", [(4096, 192, 192), (1000, 8, 64), (8192 + 24, 64, 192), (333, 16, 16)])
-def test_gemm_tn_wide(R, M, N):
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("R,M,N", [(4096, 192, 192), (1000, 8, 64), (8192 + 24, 64, 192), (333, 16, 16), (40000 + 7, 192, 192), (5000, 64, 224), (17, 32, 32)])
+def test_gemm_tn_wide(R, M, N, use_ws):
     """pf_gemm_tn_wide: C (+)= A^T B and column sums of A in one pass, against float64 (ragged row counts, narrow C,
-    accumulation onto existing contents)."""
+    accumulation onto existing contents; atomic accumulation and the partial-sum workspace form; the split-precision kernel
+    for N <= 192, the fp32 kernel for the 256-wide form and for the < 32-row tail)."""
     from pepflowww_amd import _capi
     lib = _capi.load()
     g = torch.Generator().manual_seed(R + M)
     A, Bm = torch.randn(R, M, generator=g), torch.randn(R, N, generator=g)
     C0, s0 = torch.randn(M, N, generator=g), torch.randn(M, generator=g)
     ref = A.double().t() @ Bm.double()
+    ws = torch.full((256 * (M * N + M),), float("nan"), device="cuda") if use_ws else None
     for acc in (0, 1):
         C, cs = cu(C0.clone()), cu(s0.clone())
         a, b = cu(A), cu(Bm)
-        _capi.check(lib.pf_gemm_tn_wide(a.data_ptr(), M, M, b.data_ptr(), N, N, C.data_ptr(), N, R, acc, cs.data_ptr(), acc, _capi.stream_ptr()), "pf_gemm_tn_wide")
+        _capi.check(lib.pf_gemm_tn_wide(a.data_ptr(), M, M, b.data_ptr(), N, N, C.data_ptr(), N, R, acc, cs.data_ptr(), acc, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _capi.stream_ptr()), "pf_gemm_tn_wide")
         G.sync()
         want = ref + (C0.double() if acc else 0)
         wcs = A.double().sum(0) + (s0.double() if acc else 0)

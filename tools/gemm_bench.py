@@ -28,8 +28,10 @@ out = torch.empty(192, device=dev)
 import ctypes as C
 from pepflowww_amd import _capi
 lib = _capi.load()
+import os
+ws = None if os.environ.get('PF_TN_NOWS') else torch.empty(256 * (192 * 256 + 192), device='cuda')
 print('pf_colsum', t(lambda: lib.pf_colsum_f32(dy.data_ptr(), 192, P, 192, out.data_ptr(), 0, _capi.stream_ptr())), 'us')
 db = torch.empty(192, device=dev)
-print('pf_gemm_tn_wide dW + db', t(lambda: lib.pf_gemm_tn_wide(dy.data_ptr(), 192, 192, x.data_ptr(), 192, 192, dW.data_ptr(), 192, P, 0, db.data_ptr(), 0, _capi.stream_ptr())), 'us')
+print('pf_gemm_tn_wide dW + db', t(lambda: lib.pf_gemm_tn_wide(dy.data_ptr(), 192, 192, x.data_ptr(), 192, 192, dW.data_ptr(), 192, P, 0, db.data_ptr(), 0, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _capi.stream_ptr())), 'us')
 ref = dy.t() @ x
 print('   max rel err dW', ((dW - ref).abs().max() / ref.abs().max()).item(), ' db', ((db - dy.sum(0)).abs().max() / dy.sum(0).abs().max()).item())
