@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 24
+#define PF_ABI_VERSION 25
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -409,6 +409,9 @@ typedef struct {
     int batch1, batch2;
     long long bsA1, bsA2, bsB1, bsB2, bsC1, bsC2;
     int ksplit;                    /* internal (set by the launcher): split-K factor for long-K, few-tile products */
+    /* optional (no batching): rowsum_a[m] += sum_k A(m,k), added atomically -- the bias gradient db = column sums of dy falls
+     * out of the dW = dy^T x product (A = dy^T) without a pass of its own; must hold zeros or a running sum */
+    float* rowsum_a;
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 /* weight gradient of a Linear over all pairs in one pass: C[M,N] (+)= A^T B with A = dy [R,M] (lda), B = x [R,N] (ldb),
@@ -424,9 +427,11 @@ int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumula
 int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);                                /* dy *= (y > 0) */
 int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream);            /* dst = y > 0 ? src : 0 */
 int pf_add_out(const float* a, const float* b, float* dst, long long n, pf_stream_t stream);                 /* dst = a + b */
-/* nn.LayerNorm backward over the last dimension (N <= 256, eps 1e-5): dx; dgamma_rows[m,n] = dy xhat (optional;
- * dgamma = column sum of it, dbeta = column sum of dy -- pf_colsum_f32). */
-typedef struct { const float* x; const float* dy; const float* gamma; float* dx; float* dgamma_rows; int M, N; } pf_layernorm_bwd_args;
+/* nn.LayerNorm backward over the last dimension (N <= 256, eps 1e-5): dx; dgamma[n] += sum_m dy xhat and dbeta[n] += sum_m dy
+ * (optional, both or neither; accumulated atomically per workgroup, so they must hold zeros or a running sum);
+ * dgamma_rows[m,n] = dy xhat (optional, the unreduced contributions). */
+typedef struct { const float* x; const float* dy; const float* gamma; float* dx; float* dgamma_rows; int M, N;
+                 float* dgamma; float* dbeta; } pf_layernorm_bwd_args;
 int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream);
 int pf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int N, pf_stream_t stream);
 int pf_row_mask(float* x, const float* mask, int M, int N, pf_stream_t stream);        /* x[m,:] *= mask[m] */

@@ -27,13 +27,15 @@ def _zeros(*shape, device, dtype=torch.float32):
 from . import _capi
 
 
-def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None):
+def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None, rowsum=None):
     """C = alpha * A B (+ C).  Offsets in elements; batch = (n1, n2, (sA1, sA2), (sB1, sB2), (sC1, sC2)) for sample x head slices."""
     a = _capi.GemmArgs()
     a.A, a.sam, a.sak = A.data_ptr() + 4 * a_off, sam, sak
     a.B, a.sbk, a.sbn = Bm.data_ptr() + 4 * b_off, sbk, sbn
     a.C, a.ldc, a.M, a.N, a.K, a.accumulate = Cm.data_ptr() + 4 * c_off, (Cm.shape[-1] if ldc is None else ldc), M, N, K, int(accumulate)
     a.alpha = alpha
+    if rowsum is not None:                 # rowsum[m] += sum_k A(m, k) (zeroed buffer or running sum)
+        a.rowsum_a = rowsum.data_ptr()
     if batch is not None:
         a.batch1, a.batch2 = batch[0], batch[1]
         (a.bsA1, a.bsA2), (a.bsB1, a.bsB2), (a.bsC1, a.bsC2) = batch[2], batch[3], batch[4]
@@ -199,8 +201,11 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
         _capi.check(lib.pf_gemm_tn_wide(dy.data_ptr(), N, N, x.data_ptr(), K, K, dW.data_ptr(), K, M, int(acc), db.data_ptr(), int(accb),
                                         ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_wide")
         return dx, dW, db
-    _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc)
-    _capi.check(lib.pf_colsum_f32(dy.data_ptr(), N, M, N, db.data_ptr(), int(accb), _capi.stream_ptr()), "pf_colsum_f32")
+    if accb:       # db accumulates into a zeroed arena slice / a running sum: the dW product adds the column sums of dy itself
+        _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc, rowsum=db)
+    else:
+        _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc)
+        _capi.check(lib.pf_colsum_f32(dy.data_ptr(), N, M, N, db.data_ptr(), 0, _capi.stream_ptr()), "pf_colsum_f32")
     return dx, dW, db
 
 
@@ -212,13 +217,17 @@ def relu_bwd_(y, dy):
 def layernorm_bwd(x, gamma, dy):
     lib = _capi.load()
     M, N = x.shape
-    dx, rows = torch.empty_like(x), torch.empty_like(x)
+    dx = torch.empty_like(x)
+    # dgamma / dbeta are accumulated by the kernel itself (csrc/backward.hip: layernorm_bwd_kernel) into zeroed buffers
+    (dg, z1), (dbeta, z2) = _grad_buffer(N, device=x.device), _grad_buffer(N, device=x.device)
+    if not z1:
+        dg = _zeros(N, device=x.device)
+    if not z2:
+        dbeta = _zeros(N, device=x.device)
     a = _capi.LayerNormBwdArgs()
-    a.x, a.dy, a.gamma, a.dx, a.dgamma_rows, a.M, a.N = x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), rows.data_ptr(), M, N
+    a.x, a.dy, a.gamma, a.dx, a.dgamma_rows, a.M, a.N = x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), None, M, N
+    a.dgamma, a.dbeta = dg.data_ptr(), dbeta.data_ptr()
     _capi.check(lib.pf_layernorm_bwd(C.byref(a), _capi.stream_ptr()), "pf_layernorm_bwd")
-    dg, dbeta = torch.empty(N, device=x.device), torch.empty(N, device=x.device)
-    _capi.check(lib.pf_colsum_f32(rows.data_ptr(), N, M, N, dg.data_ptr(), 0, _capi.stream_ptr()), "pf_colsum_f32")
-    _capi.check(lib.pf_colsum_f32(dy.data_ptr(), N, M, N, dbeta.data_ptr(), 0, _capi.stream_ptr()), "pf_colsum_f32")
     return dx, dg, dbeta
 
 
@@ -446,9 +455,10 @@ class IpaBlock:
         # parameters of the pair projections: dW_b = g_bias^T z, dW_dz = g_pz^T z (K = pairs)
         for nm, gb, n in (("linear_b", g_bias, 8), ("down_z", g_pz, 16)):
             dW = e(n, 64)
-            _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L)
-            db = e(n)
-            _capi.check(lib.pf_colsum_f32(gb.data_ptr(), n, rows * L, n, db.data_ptr(), 0, st), "pf_colsum_f32")
+            db, zeroed = _grad_buffer(n, device=dev)
+            if not zeroed:
+                db = _zeros(n, device=dev)
+            _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L, rowsum=db)          # db = column sums of gb from the same pass
             G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
         gg = e(8)
         _capi.check(lib.pf_colsum_f32(g_gam.data_ptr(), 8, rows, 8, gg.data_ptr(), 0, st), "pf_colsum_f32")

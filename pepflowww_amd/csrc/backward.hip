@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
     const int wm = (wave >> 1) * 16 * MT, wn = (wave & 1) * 32;
     f32x4 acc[MT][2];
     acc_zero<MT, 2>(acc);
+    float rs = 0.f;                                         // row sum of A over this workgroup's K range (rowsum_a: n tile 0 only)
+    const bool do_rs = p.rowsum_a && blockIdx.y == 0 && tid < TM;
     float ra[TM / 8], rb[GT / 8];
     stage_fetch<TM>(p.A, p.sam, p.sak, m0, p.M, kbeg, kend, vecA != 0, ra);
     stage_fetch<GT>(p.B, p.sbn, p.sbk, n0, p.N, kbeg, kend, vecB != 0, rb);
@@ -115,6 +117,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
         if (k0 + GK < kend) {                             // next chunk in flight under this chunk's MFMAs
             stage_fetch<TM>(p.A, p.sam, p.sak, m0, p.M, k0 + GK, kend, vecA != 0, ra);
             stage_fetch<GT>(p.B, p.sbn, p.sbk, n0, p.N, k0 + GK, kend, vecB != 0, rb);
+        }
+        if (do_rs) {
+#pragma unroll
+            for (int k = 0; k < GK; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(As + tid * LDT + k);
+                rs += (v.x + v.y) + (v.z + v.w);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < GK; ks += 16) {            // one float4 per lane feeds 4 consecutive MFMA k-steps (k permutation)
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
                     *c = v + (p.accumulate ? *c : 0.f);
                 }
             }
+    if (do_rs && m0 + tid < p.M) atomicAdd(p.rowsum_a + m0 + tid, rs);
 }
 
 // ---- wide TN product for weight gradients over all pairs:  C[M,N] (+)= A^T B,  A [R,M] (lda), B [R,N] (ldb), M, N <= 192, R = B*L*L.
@@ -662,41 +672,63 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* y, float* dy
     if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
 }
 
-// one wave per row (N <= 256): xhat = (x - mean) rstd; dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_args p) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= p.M) return;
-    const float* x = p.x + (size_t)row * p.N;
-    const float* dy = p.dy + (size_t)row * p.N;
-    float xv[4], gv[4];
-    float s = 0.f;
+// one wave per row (N <= 256): xhat = (x - mean) rstd; dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma.
+// A wave walks `rpw` consecutive rows and keeps its lanes' dgamma = sum dy xhat and dbeta = sum dy in registers; the four
+// waves meet in LDS and the workgroup adds one value per column to dgamma / dbeta atomically (no [M,N] dgamma_rows round
+// trip through HBM and no column-sum launches behind every LayerNorm).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_args p, int rpw) {
+    __shared__ float red[2][4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * rpw;
+    float dgs[4] = {0.f, 0.f, 0.f, 0.f}, dbs[4] = {0.f, 0.f, 0.f, 0.f};
+    float gam[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; xv[c] = n < p.N ? x[n] : 0.f; s += xv[c]; }
-    const float mean = wave_sum(s) / (float)p.N;
-    float q = 0.f;
+    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; gam[c] = n < p.N ? p.gamma[n] : 0.f; }
+    for (int i = 0; i < rpw; ++i) {
+        const long long row = row0 + i;
+        if (row >= p.M) break;
+        const float* x = p.x + (size_t)row * p.N;
+        const float* dy = p.dy + (size_t)row * p.N;
+        float xv[4], gv[4], dv[4];
+        float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; const float d = n < p.N ? xv[c] - mean : 0.f; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / (float)p.N + 1e-5f);
-    float sg = 0.f, sgx = 0.f;
+        for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; xv[c] = n < p.N ? x[n] : 0.f; dv[c] = n < p.N ? dy[n] : 0.f; s += xv[c]; }
+        const float mean = wave_sum(s) / (float)p.N;
+        float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int n = lane + 64 * c;
-        const float xh = n < p.N ? (xv[c] - mean) * rstd : 0.f;
-        gv[c] = n < p.N ? dy[n] * p.gamma[n] : 0.f;
-        xv[c] = xh;
-        sg += gv[c];
-        sgx += gv[c] * xh;
-    }
-    sg = wave_sum(sg) / (float)p.N;
-    sgx = wave_sum(sgx) / (float)p.N;
+        for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; const float d = n < p.N ? xv[c] - mean : 0.f; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)p.N + 1e-5f);
+        float sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int n = lane + 64 * c;
-        if (n < p.N) {
-            p.dx[(size_t)row * p.N + n] = rstd * (gv[c] - sg - xv[c] * sgx);
-            if (p.dgamma_rows) {                       // per-row contributions; reduced over rows by pf_colsum_f32
-                p.dgamma_rows[(size_t)row * p.N + n] = dy[n] * xv[c];
+        for (int c = 0; c < 4; ++c) {
+            const int n = lane + 64 * c;
+            const float xh = n < p.N ? (xv[c] - mean) * rstd : 0.f;
+            gv[c] = dv[c] * gam[c];
+            xv[c] = xh;
+            sg += gv[c];
+            sgx += gv[c] * xh;
+            dgs[c] += dv[c] * xh;
+            dbs[c] += dv[c];
+        }
+        sg = wave_sum(sg) / (float)p.N;
+        sgx = wave_sum(sgx) / (float)p.N;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = lane + 64 * c;
+            if (n < p.N) {
+                p.dx[(size_t)row * p.N + n] = rstd * (gv[c] - sg - xv[c] * sgx);
+                if (p.dgamma_rows) p.dgamma_rows[(size_t)row * p.N + n] = dv[c] * xv[c];
             }
+        }
+    }
+    if (p.dgamma) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { red[0][wave][lane + 64 * c] = dgs[c]; red[1][wave][lane + 64 * c] = dbs[c]; }
+        __syncthreads();
+        const int n = threadIdx.x;
+        if (n < p.N) {
+            atomicAdd(p.dgamma + n, (red[0][0][n] + red[0][1][n]) + (red[0][2][n] + red[0][3][n]));
+            atomicAdd(p.dbeta + n, (red[1][0][n] + red[1][1][n]) + (red[1][2][n] + red[1][3][n]));
         }
     }
 }
@@ -1199,6 +1231,7 @@ extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float*
 
 extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    if (a->rowsum_a && (a->batch1 > 0 || a->batch2 > 0)) return PF_E_BADARG;
     const int nb = (a->batch1 > 0 ? a->batch1 : 1) * (a->batch2 > 0 ? a->batch2 : 1);
     pf_gemm_args g = *a;
     g.ksplit = 1;
@@ -1320,7 +1353,9 @@ extern "C" int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t s
 }
 extern "C" int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream) {
     if (!a || !a->x || !a->dy || !a->gamma || !a->dx || a->M <= 0 || a->N <= 0 || a->N > 256) return PF_E_BADARG;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((a->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    if ((a->dgamma != nullptr) != (a->dbeta != nullptr)) return PF_E_BADARG;
+    const int rpw = a->M >= 65536 ? 16 : a->M >= 8192 ? 4 : 1;      // rows per wave: enough workgroups for the chip, few enough atomics
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((a->M + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, (hipStream_t)stream, *a, rpw);
     PF_CHECK_LAUNCH();
     return 0;
 }
