@@ -673,6 +673,27 @@ def test_split_pack_kernel_equals_host_packing(N, K):
         assert (y.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,relu,epi", [(65536 + 37, 192, 192, False, True), (70000, 160, 64, True, False), (65536, 224, 128, False, True),
+                                            (66000, 192, 192, True, False)])
+def test_pair_sized_linear_split(M, N, K, relu, epi):
+    """The whole-row forms of the split-precision Linear at pair-sized row counts (csrc/linear.hip: linear_split_kernel<6 / 8>):
+    ragged last tile, an idle sixth wave (N = 160), the 8-wave form (N = 224), bias + ReLU, gate + residual epilogue --
+    against float64."""
+    from pepflowww_amd import backward as Bk
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    gate = torch.randn(M, N, generator=g) if epi else None
+    res = torch.randn(M, N, generator=g) if epi else None
+    y = Bk._linear_split(cu(x), cu(w), cu(b), relu=relu, gate=cu(gate) if epi else None, residual=cu(res) if epi else None)
+    G.sync()
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if epi:
+        ref = ref * (gate > 0) + res.double()
+    assert (y.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("R,M,N", [(4096, 192, 192), (1000, 8, 64), (8192 + 24, 64, 192), (333, 16, 16), (40000 + 7, 192, 192), (5000, 64, 224), (17, 32, 32)])
 def test_gemm_tn_wide(R, M, N, use_ws):
