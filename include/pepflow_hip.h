@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 25
+#define PF_ABI_VERSION 26
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -412,6 +412,9 @@ typedef struct {
     /* optional (no batching): rowsum_a[m] += sum_k A(m,k), added atomically -- the bias gradient db = column sums of dy falls
      * out of the dW = dy^T x product (A = dy^T) without a pass of its own; must hold zeros or a running sum */
     float* rowsum_a;
+    /* optional: C = gate[m,n] > 0 ? C : 0 before the residual is added (gate with C's leading dimension): the ReLU backward of
+     * the layer below, fused into dx = dy W */
+    const float* gate;
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
 /* weight gradient of a Linear over all pairs in one pass: C[M,N] (+)= A^T B with A = dy [R,M] (lda), B = x [R,N] (ldb),

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -92,7 +92,7 @@ class GemmArgs(C.Structure):
                 ("C", _fp), ("ldc", _i), ("M", _i), ("N", _i), ("K", _i), ("accumulate", _i),
                 ("bias", _fp), ("relu", _i), ("residual", _fp), ("alpha", C.c_float), ("batch1", _i), ("batch2", _i),
                 ("bsA1", C.c_longlong), ("bsA2", C.c_longlong), ("bsB1", C.c_longlong), ("bsB2", C.c_longlong),
-                ("bsC1", C.c_longlong), ("bsC2", C.c_longlong), ("ksplit", _i), ("rowsum_a", _fp)]
+                ("bsC1", C.c_longlong), ("bsC2", C.c_longlong), ("ksplit", _i), ("rowsum_a", _fp), ("gate", _fp)]
 
 
 class LayerNormBwdArgs(C.Structure):

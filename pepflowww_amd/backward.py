@@ -27,7 +27,7 @@ def _zeros(*shape, device, dtype=torch.float32):
 from . import _capi
 
 
-def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None, rowsum=None):
+def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None, rowsum=None, gate=None, residual=None):
     """C = alpha * A B (+ C).  Offsets in elements; batch = (n1, n2, (sA1, sA2), (sB1, sB2), (sC1, sC2)) for sample x head slices."""
     a = _capi.GemmArgs()
     a.A, a.sam, a.sak = A.data_ptr() + 4 * a_off, sam, sak
@@ -36,6 +36,10 @@ def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, l
     a.alpha = alpha
     if rowsum is not None:                 # rowsum[m] += sum_k A(m, k) (zeroed buffer or running sum)
         a.rowsum_a = rowsum.data_ptr()
+    if gate is not None:                   # C = gate > 0 ? C : 0, then + residual (both [M, ldc] like C)
+        a.gate = gate.data_ptr()
+    if residual is not None:
+        a.residual = residual.data_ptr()
     if batch is not None:
         a.batch1, a.batch2 = batch[0], batch[1]
         (a.bsA1, a.bsA2), (a.bsB1, a.bsB2), (a.bsC1, a.bsC2) = batch[2], batch[3], batch[4]
@@ -184,11 +188,7 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
             dx = _linear_split(dy, w, gate=dx_gate, residual=dx_residual, w_transposed=True)   # dx = dy W = dy (W^T)^T
         else:
             dx = torch.empty(M, K, device=x.device)
-            _gemm(dy, N, 1, w, K, 1, dx, M, K, N)
-            if dx_gate is not None:
-                relu_bwd_(dx_gate, dx)
-            if dx_residual is not None:
-                add_(dx, dx_residual)
+            _gemm(dy, N, 1, w, K, 1, dx, M, K, N, gate=dx_gate, residual=dx_residual)      # ReLU backward / skip fused in the epilogue
     acc = dW is not None
     if dW is None:
         dW, acc = _grad_buffer(N, K, device=x.device)
@@ -251,10 +251,8 @@ def mlp3_backward(x, ws, bs, dout):
     activations (fp32 GEMM), then three linear_bwd.  Returns (dx, [(dW, db)] * 3)."""
     h1 = linear_fwd(x, ws[0], bs[0], relu=True)
     h2 = linear_fwd(h1, ws[1], bs[1], relu=True)
-    d2, dW2, db2 = linear_bwd(h2, ws[2], dout)
-    relu_bwd_(h2, d2)
-    d1, dW1, db1 = linear_bwd(h1, ws[1], d2)
-    relu_bwd_(h1, d1)
+    d2, dW2, db2 = linear_bwd(h2, ws[2], dout, dx_gate=h2)
+    d1, dW1, db1 = linear_bwd(h1, ws[1], d2, dx_gate=h1)
     dx, dW0, db0 = linear_bwd(x, ws[0], d1)
     return dx, [(dW0, db0), (dW1, db1), (dW2, db2)]
 
@@ -338,27 +336,21 @@ class NodeTrackBlock:
         g = row_mask_(g_s3m.clone(), m)
         t = f"node_transition_{b}."
         g_h3, G[t + "ln.weight"], G[t + "ln.bias"] = layernorm_bwd(sv["h3"], self.p(t + "ln.weight"), g)
-        g_t2, G[t + "linear_3.weight"], G[t + "linear_3.bias"] = linear_bwd(sv["t2"], self.p(t + "linear_3.weight"), g_h3)
-        relu_bwd_(sv["t2"], g_t2)
-        g_t1, G[t + "linear_2.weight"], G[t + "linear_2.bias"] = linear_bwd(sv["t1"], self.p(t + "linear_2.weight"), g_t2)
-        relu_bwd_(sv["t1"], g_t1)
-        g_s2, G[t + "linear_1.weight"], G[t + "linear_1.bias"] = linear_bwd(sv["s2"], self.p(t + "linear_1.weight"), g_t1)
-        add_(g_s2, g_h3)                                        # residual s2 + t3
+        g_t2, G[t + "linear_3.weight"], G[t + "linear_3.bias"] = linear_bwd(sv["t2"], self.p(t + "linear_3.weight"), g_h3, dx_gate=sv["t2"])
+        g_t1, G[t + "linear_2.weight"], G[t + "linear_2.bias"] = linear_bwd(sv["t1"], self.p(t + "linear_2.weight"), g_t2, dx_gate=sv["t1"])
+        g_s2, G[t + "linear_1.weight"], G[t + "linear_1.bias"] = linear_bwd(sv["s2"], self.p(t + "linear_1.weight"), g_t1, dx_residual=g_h3)   # residual s2 + t3
         g_y, G[f"post_tfmr_{b}.weight"], G[f"post_tfmr_{b}.bias"] = linear_bwd(sv["tf"], self.p(f"post_tfmr_{b}.weight"), g_s2)
         g_s1 = g_s2                                             # residual s1 + post_tfmr(tf)
         for l in (1, 0):
             q = f"seq_tfmr_{b}.layers.{l}."
             a = sv[l]
             g_h2, G[q + "norm2.weight"], G[q + "norm2.bias"] = layernorm_bwd(a["h2"], self.p(q + "norm2.weight"), g_y)
-            g_f, G[q + "linear2.weight"], G[q + "linear2.bias"] = linear_bwd(a["f"], self.p(q + "linear2.weight"), g_h2)
-            relu_bwd_(a["f"], g_f)
-            g_x1, G[q + "linear1.weight"], G[q + "linear1.bias"] = linear_bwd(a["x1"], self.p(q + "linear1.weight"), g_f)
-            add_(g_x1, g_h2)                                    # residual x1 + ffn
+            g_f, G[q + "linear2.weight"], G[q + "linear2.bias"] = linear_bwd(a["f"], self.p(q + "linear2.weight"), g_h2, dx_gate=a["f"])
+            g_x1, G[q + "linear1.weight"], G[q + "linear1.bias"] = linear_bwd(a["x1"], self.p(q + "linear1.weight"), g_f, dx_residual=g_h2)   # residual x1 + ffn
             g_h, G[q + "norm1.weight"], G[q + "norm1.bias"] = layernorm_bwd(a["h"], self.p(q + "norm1.weight"), g_x1)
             g_att, G[q + "self_attn.out_proj.weight"], G[q + "self_attn.out_proj.bias"] = linear_bwd(a["att"], self.p(q + "self_attn.out_proj.weight"), g_h)
             g_qkv = seq_attn_bwd(a["qkv"], m, g_att, B, L)
-            g_x, G[q + "self_attn.in_proj_weight"], G[q + "self_attn.in_proj_bias"] = linear_bwd(a["x"], self.p(q + "self_attn.in_proj_weight"), g_qkv)
-            add_(g_x, g_h)                                      # residual x + mha
+            g_x, G[q + "self_attn.in_proj_weight"], G[q + "self_attn.in_proj_bias"] = linear_bwd(a["x"], self.p(q + "self_attn.in_proj_weight"), g_qkv, dx_residual=g_h)   # residual x + mha
             g_y = g_x
         add_(g_s1, g_y)
         g_a0, G[f"ipa_ln_{b}.weight"], G[f"ipa_ln_{b}.bias"] = layernorm_bwd(sv["a0"], self.p(f"ipa_ln_{b}.weight"), g_s1)
@@ -737,12 +729,9 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     # ---- node embedder: MLP 1157 -> 256 -> 128 -> 128 -> 128, * mres
     w = lambda k: model_sd[k]
     g = row_mask_(g_node.clone(), saved["mres"])
-    g2, G["node_embedder.mlp.6.weight"], G["node_embedder.mlp.6.bias"] = linear_bwd(saved["n_h2"], w("node_embedder.mlp.6.weight"), g)
-    relu_bwd_(saved["n_h2"], g2)
-    g1, G["node_embedder.mlp.4.weight"], G["node_embedder.mlp.4.bias"] = linear_bwd(saved["n_h1"], w("node_embedder.mlp.4.weight"), g2)
-    relu_bwd_(saved["n_h1"], g1)
-    g0, G["node_embedder.mlp.2.weight"], G["node_embedder.mlp.2.bias"] = linear_bwd(saved["n_h0"], w("node_embedder.mlp.2.weight"), g1)
-    relu_bwd_(saved["n_h0"], g0)
+    g2, G["node_embedder.mlp.6.weight"], G["node_embedder.mlp.6.bias"] = linear_bwd(saved["n_h2"], w("node_embedder.mlp.6.weight"), g, dx_gate=saved["n_h2"])
+    g1, G["node_embedder.mlp.4.weight"], G["node_embedder.mlp.4.bias"] = linear_bwd(saved["n_h1"], w("node_embedder.mlp.4.weight"), g2, dx_gate=saved["n_h1"])
+    g0, G["node_embedder.mlp.2.weight"], G["node_embedder.mlp.2.bias"] = linear_bwd(saved["n_h0"], w("node_embedder.mlp.2.weight"), g1, dx_gate=saved["n_h0"])
     w0 = w("node_embedder.mlp.0.weight")                        # [256,1157]; feat rows are 1168 wide
     K = w0.shape[1]
     g_feat = e(rows, 128)

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
                     if (p.ksplit > 1) { atomicAdd(c, v); continue; }
                     if (p.bias) v += p.bias[n];
                     if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.gate) v = p.gate[(size_t)m * p.ldc + n] > 0.f ? v : 0.f;
                     if (p.residual) v += p.residual[(size_t)m * p.ldc + n];
                     *c = v + (p.accumulate ? *c : 0.f);
                 }
@@ -1243,7 +1244,7 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     // long-K, few-tile products (dW = dy^T x over all pairs): split K over workgroups, partial sums by atomicAdd
     // (also the row-sized ones, K = B*L: without the split a 128 x 128 dW runs on 4 workgroups for ~115 us -- a quarter of
     //  the training step was spent in such launches)
-    if (nb == 1 && !a->bias && !a->relu && !a->residual && a->K >= 512 && tiles < 256) {
+    if (nb == 1 && !a->bias && !a->relu && !a->residual && !a->gate && a->K >= 512 && tiles < 256) {
         long long want = ((a->K >= 4096 ? 1024 : 512) + tiles - 1) / tiles, kmax = (a->K + 4 * GK - 1) / (4 * GK);
         g.ksplit = (int)(want < kmax ? want : kmax);
         if (g.ksplit > 1 && !a->accumulate) {
