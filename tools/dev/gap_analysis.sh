@@ -22,7 +22,10 @@ for s, e, n in rows[1:]:
     if g > 0:
         gap_after[(prev, n)] += g; cnt_after[(prev, n)] += 1
     if e > end: end = e; prev = n
-print(f"kernels {len(rows)}  span {span/1e6:.2f} ms  busy {busy/1e6:.2f} ms  idle {(span-busy)/1e6:.2f} ms")
+union = 0; ce = rows[0][0]
+for s, e, _ in rows:
+    if e > ce: union += e - max(s, ce); ce = e
+print(f"kernels {len(rows)}  span {span/1e6:.2f} ms  sum of durations {busy/1e6:.2f} ms  union (any kernel running) {union/1e6:.2f} ms  idle {(span-union)/1e6:.2f} ms")
 for (a, b), g in gap_after.most_common(25):
     print(f"{g/1e3:9.0f} us in {cnt_after[(a,b)]:5d} gaps (avg {g/cnt_after[(a,b)]/1e3:6.1f} us)  {a[:45]:45s} -> {b[:45]}")
 PY
