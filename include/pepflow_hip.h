@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 26
+#define PF_ABI_VERSION 27
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -434,7 +434,10 @@ int pf_add_out(const float* a, const float* b, float* dst, long long n, pf_strea
  * (optional, both or neither; accumulated atomically per workgroup, so they must hold zeros or a running sum);
  * dgamma_rows[m,n] = dy xhat (optional, the unreduced contributions). */
 typedef struct { const float* x; const float* dy; const float* gamma; float* dx; float* dgamma_rows; int M, N;
-                 float* dgamma; float* dbeta; } pf_layernorm_bwd_args;
+                 float* dgamma; float* dbeta;
+                 /* optional scratch private to the stream (>= (M / 64 + 1) * 2 N floats): pair-sized inputs then write per-workgroup
+                  * partial sums that a second kernel adds up, instead of thousands of atomics per column */
+                 float* workspace; long long workspace_elems; } pf_layernorm_bwd_args;
 int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream);
 int pf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int N, pf_stream_t stream);
 int pf_row_mask(float* x, const float* mask, int M, int N, pf_stream_t stream);        /* x[m,:] *= mask[m] */

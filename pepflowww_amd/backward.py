@@ -227,6 +227,9 @@ def layernorm_bwd(x, gamma, dy):
     a = _capi.LayerNormBwdArgs()
     a.x, a.dy, a.gamma, a.dx, a.dgamma_rows, a.M, a.N = x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), None, M, N
     a.dgamma, a.dbeta = dg.data_ptr(), dbeta.data_ptr()
+    if M >= 65536:
+        ws = _tn_workspace(x.device)
+        a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
     _capi.check(lib.pf_layernorm_bwd(C.byref(a), _capi.stream_ptr()), "pf_layernorm_bwd")
     return dx, dg, dbeta
 

@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* y, float* dy
 // A wave walks `rpw` consecutive rows and keeps its lanes' dgamma = sum dy xhat and dbeta = sum dy in registers; the four
 // waves meet in LDS and the workgroup adds one value per column to dgamma / dbeta atomically (no [M,N] dgamma_rows round
 // trip through HBM and no column-sum launches behind every LayerNorm).
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_args p, int rpw) {
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_args p, int rpw, float* part) {
     __shared__ float red[2][4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long row0 = ((long long)blockIdx.x * 4 + wave) * rpw;
@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_arg
     float gam[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; gam[c] = n < p.N ? p.gamma[n] : 0.f; }
+#pragma unroll 2
     for (int i = 0; i < rpw; ++i) {
         const long long row = row0 + i;
         if (row >= p.M) break;
@@ -728,9 +729,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_arg
         __syncthreads();
         const int n = threadIdx.x;
         if (n < p.N) {
-            atomicAdd(p.dgamma + n, (red[0][0][n] + red[0][1][n]) + (red[0][2][n] + red[0][3][n]));
-            atomicAdd(p.dbeta + n, (red[1][0][n] + red[1][1][n]) + (red[1][2][n] + red[1][3][n]));
+            const float dg = (red[0][0][n] + red[0][1][n]) + (red[0][2][n] + red[0][3][n]);
+            const float db = (red[1][0][n] + red[1][1][n]) + (red[1][2][n] + red[1][3][n]);
+            if (part) {                                            // many workgroups: partials, summed by ln_reduce_kernel
+                part[(size_t)blockIdx.x * 2 * p.N + n] = dg;
+                part[(size_t)blockIdx.x * 2 * p.N + p.N + n] = db;
+            } else {
+                atomicAdd(p.dgamma + n, dg);
+                atomicAdd(p.dbeta + n, db);
+            }
         }
+    }
+}
+
+// dgamma / dbeta += sum over workgroups of their partial column sums: block (x, y) sums slice y of the workgroups for 64 columns
+// (4 thread groups x unrolled loads), then one atomic per column and block (gridDim.y = 32 of them per column)
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* part, int nwg, int N, float* dgamma, float* dbeta) {
+    __shared__ float red[4][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int per = (nwg + (int)gridDim.y - 1) / (int)gridDim.y, w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    float s0 = 0.f, s1 = 0.f;
+    if (o < 2 * N) {
+        const float* q = part + o;
+        int w = w0 + g;
+        for (; w + 4 < w1; w += 8) { s0 += q[(size_t)w * 2 * N]; s1 += q[(size_t)(w + 4) * 2 * N]; }
+        for (; w < w1; w += 4) s0 += q[(size_t)w * 2 * N];
+    }
+    red[g][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && o < 2 * N) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(o < N ? dgamma + o : dbeta + (o - N), v);
     }
 }
 
@@ -1501,8 +1530,13 @@ extern "C" int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t s
 extern "C" int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream) {
     if (!a || !a->x || !a->dy || !a->gamma || !a->dx || a->M <= 0 || a->N <= 0 || a->N > 256) return PF_E_BADARG;
     if ((a->dgamma != nullptr) != (a->dbeta != nullptr)) return PF_E_BADARG;
-    const int rpw = a->M >= 65536 ? 16 : a->M >= 8192 ? 4 : 1;      // rows per wave: enough workgroups for the chip, few enough atomics
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((a->M + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, (hipStream_t)stream, *a, rpw);
+    // rows per wave: row-sized inputs keep >= 128 workgroups and add their column sums atomically (one atomic per column per
+    // workgroup: 512 workgroups on the same 128 addresses cost 15 us); pair-sized ones write partials that a second kernel sums
+    const int rpw = a->M >= 65536 ? 16 : a->M >= 1024 ? 4 : 1;
+    const unsigned nwg = (unsigned)((a->M + 4 * rpw - 1) / (4 * rpw));
+    float* part = a->dgamma && nwg > 256 && a->workspace && a->workspace_elems >= (long long)nwg * 2 * a->N ? a->workspace : nullptr;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, *a, rpw, part);
+    if (part) hipLaunchKernelGGL(ln_reduce_kernel, dim3((unsigned)((2 * a->N + 63) / 64), 32), dim3(256), 0, (hipStream_t)stream, part, (int)nwg, a->N, a->dgamma, a->dbeta);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -718,13 +718,16 @@ def test_gemm_tn_wide(R, M, N, use_ws):
         assert (cs.cpu().double() - wcs).abs().max() <= 2e-5 * wcs.abs().max() + 1e-5, (R, M, N, acc)
 
 
-def test_layernorm_and_relu_backward():
+@pytest.mark.parametrize("M,N", [(77, 128), (2048 + 3, 128), (65536 + 21, 64)])
+def test_layernorm_and_relu_backward(M, N):
+    """nn.LayerNorm backward with dgamma / dbeta accumulated by the kernel itself: one row per wave (small M), four rows per
+    wave + atomics (row-sized M), sixteen rows per wave + partial sums and a reduce kernel (pair-sized M)."""
     from pepflowww_amd import backward as Bk
     g = torch.Generator().manual_seed(4)
-    x = (torch.randn(77, 128, generator=g) * 2 + 0.3).requires_grad_(True)
-    gamma, beta = (torch.randn(128, generator=g) * 0.2 + 1).requires_grad_(True), torch.randn(128, generator=g).requires_grad_(True)
-    dy = torch.randn(77, 128, generator=g)
-    F.layer_norm(x, (128,), gamma, beta, 1e-5).backward(dy)
+    x = (torch.randn(M, N, generator=g) * 2 + 0.3).requires_grad_(True)
+    gamma, beta = (torch.randn(N, generator=g) * 0.2 + 1).requires_grad_(True), torch.randn(N, generator=g).requires_grad_(True)
+    dy = torch.randn(M, N, generator=g)
+    F.layer_norm(x.double(), (N,), gamma.double(), beta.double(), 1e-5).backward(dy.double())
     dx, dg, dbeta = Bk.layernorm_bwd(cu(x.detach()), cu(gamma.detach()), cu(dy))
     G.sync()
     G.assert_close(dx, x.grad, 2e-5, "LN dx")
