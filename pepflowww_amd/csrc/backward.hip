@@ -30,8 +30,7 @@ __device__ __forceinline__ void stage_fetch(const float* X, long long sr, long l
             const int idx = tid + 256 * q, rr = idx >> 3, kq = (idx & 7) * 4;
             const bool ok = row0 + rr < nrows && k0 + kq < kend;
             const float4 t = *reinterpret_cast<const float4*>(X + (size_t)(ok ? row0 + rr : row0) * sr + (ok ? k0 + kq : k0));
-            const float f = ok ? 1.f : 0.f;
-            v[4 * q] = t.x * f; v[4 * q + 1] = t.y * f; v[4 * q + 2] = t.z * f; v[4 * q + 3] = t.w * f;
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;        // raw: masked at commit (any use here waits for the load)
         }
     } else if (vec && sr == 1) {                // rows contiguous: float4 over 4 rows at one k
 #pragma unroll
@@ -39,8 +38,7 @@ __device__ __forceinline__ void stage_fetch(const float* X, long long sr, long l
             const int idx = tid + 256 * q, r4 = (idx % (NR / 4)) * 4, kk = idx / (NR / 4);
             const bool ok = row0 + r4 < nrows && k0 + kk < kend;
             const float4 t = *reinterpret_cast<const float4*>(X + (size_t)(ok ? k0 + kk : k0) * sk + (ok ? row0 + r4 : row0));
-            const float f = ok ? 1.f : 0.f;
-            v[4 * q] = t.x * f; v[4 * q + 1] = t.y * f; v[4 * q + 2] = t.z * f; v[4 * q + 3] = t.w * f;
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
         }
     } else {
 #pragma unroll
@@ -55,19 +53,23 @@ __device__ __forceinline__ void stage_fetch(const float* X, long long sr, long l
     }
 }
 template <int NR>
-__device__ __forceinline__ void stage_commit(long long sr, long long sk, bool vec, float* T, const float (&v)[NR / 8]) {
+__device__ __forceinline__ void stage_commit(long long sr, long long sk, bool vec, float* T, const float (&v)[NR / 8],
+                                             int row0, int nrows, int k0, int kend) {
     const int tid = threadIdx.x;
     if (vec && sk == 1) {
 #pragma unroll
         for (int q = 0; q < NR / 32; ++q) {
             const int idx = tid + 256 * q, rr = idx >> 3, kq = (idx & 7) * 4;
-            *reinterpret_cast<float4*>(T + rr * LDT + kq) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            const bool ok = row0 + rr < nrows && k0 + kq < kend;
+            *reinterpret_cast<float4*>(T + rr * LDT + kq) = ok ? make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else if (vec && sr == 1) {                // transposed into LDS
 #pragma unroll
         for (int q = 0; q < NR / 32; ++q) {
             const int idx = tid + 256 * q, r4 = (idx % (NR / 4)) * 4, kk = idx / (NR / 4);
-            T[(r4 + 0) * LDT + kk] = v[4 * q]; T[(r4 + 1) * LDT + kk] = v[4 * q + 1]; T[(r4 + 2) * LDT + kk] = v[4 * q + 2]; T[(r4 + 3) * LDT + kk] = v[4 * q + 3];
+            const bool ok = row0 + r4 < nrows && k0 + kk < kend;
+            T[(r4 + 0) * LDT + kk] = ok ? v[4 * q] : 0.f; T[(r4 + 1) * LDT + kk] = ok ? v[4 * q + 1] : 0.f;
+            T[(r4 + 2) * LDT + kk] = ok ? v[4 * q + 2] : 0.f; T[(r4 + 3) * LDT + kk] = ok ? v[4 * q + 3] : 0.f;
         }
     } else {
 #pragma unroll
@@ -80,9 +82,65 @@ __device__ __forceinline__ void stage_commit(long long sr, long long sk, bool ve
     }
 }
 
+// The same staging with everything that does not depend on the chunk computed ONCE per workgroup: per-thread base pointers,
+// LDS offsets and row validity.  With the index arithmetic (64-bit multiplies, three layout branches) inside the K loop a
+// chunk of the row-sized products cost ~1 us for 16 MFMAs -- 48 us for a [2048,1536] x [1536,128] product.
+// MODE: 0 = k contiguous, 1 = rows contiguous (transposed into LDS), -1 = decided at run time (incl. the scalar layout).  The
+// common layout pairs are compiled in: with run-time layout branches around the loads the compiler's wait-count pass gives
+// up at every join (s_waitcnt vmcnt(0) in front of each load) and nothing stays in flight.
+template <int NR, int MODE>
+struct Stage {
+    static constexpr int NV = NR / 32;          // float4 per thread per chunk in the vector layouts
+    const float* X; long long sr, sk;
+    const float* base[NV]; int lofs[NV], kq[NV]; bool rok[NV];
+    long long kstep;
+    int mode, row0, nrows, kvalid;
+    __device__ __forceinline__ void init(const float* X_, long long sr_, long long sk_, int row0_, int nrows_, bool vec, int kbeg) {
+        X = X_; sr = sr_; sk = sk_; row0 = row0_; nrows = nrows_; kvalid = kbeg;
+        mode = MODE >= 0 ? MODE : (vec && sk == 1) ? 0 : (vec && sr == 1) ? 1 : 2;
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = tid + 256 * q;
+            if ((MODE >= 0 ? MODE : mode) == 0) {                    // k contiguous: 8 float4 per row
+                const int rr = idx >> 3;
+                kq[q] = (idx & 7) * 4; rok[q] = row0 + rr < nrows; lofs[q] = rr * LDT + kq[q];
+                base[q] = X + (size_t)(rok[q] ? row0 + rr : row0) * sr;
+                kstep = 1;
+            } else {                            // rows contiguous: float4 over 4 rows at one k, transposed into LDS
+                const int r4 = (idx % (NR / 4)) * 4;
+                kq[q] = idx / (NR / 4); rok[q] = row0 + r4 < nrows; lofs[q] = r4 * LDT + kq[q];
+                base[q] = X + (rok[q] ? row0 + r4 : row0);
+                kstep = sk;
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend, float (&v)[NR / 8]) const {
+        if (MODE < 0 && mode == 2) { stage_fetch<NR>(X, sr, sk, row0, nrows, k0, kend, false, v); return; }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const bool ok = rok[q] && k0 + kq[q] < kend;
+            const float4 t = *reinterpret_cast<const float4*>(base[q] + (long long)(ok ? k0 + kq[q] : kvalid) * kstep);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;    // raw: masked at commit (any use here waits for the load)
+        }
+    }
+    __device__ __forceinline__ void commit(float* T, const float (&v)[NR / 8], int k0, int kend) const {
+        if (MODE < 0 && mode == 2) { stage_commit<NR>(sr, sk, false, T, v, row0, nrows, k0, kend); return; }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const bool ok = rok[q] && k0 + kq[q] < kend;
+            const float a = ok ? v[4 * q] : 0.f, b = ok ? v[4 * q + 1] : 0.f, c = ok ? v[4 * q + 2] : 0.f, d = ok ? v[4 * q + 3] : 0.f;
+            if ((MODE >= 0 ? MODE : mode) == 0) *reinterpret_cast<float4*>(T + lofs[q]) = make_float4(a, b, c, d);
+            else { T[lofs[q]] = a; T[lofs[q] + LDT] = b; T[lofs[q] + 2 * LDT] = c; T[lofs[q] + 3 * LDT] = d; }
+        }
+    }
+};
+
 // C[M,N] (ldc) = alpha sum_k A(m,k) B(k,n) (+ epilogue / + C);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
 // MT = 16-row tiles per wave along M: C tile (32 MT) x 64 per workgroup (MT = 4 for tall problems)
-template <int MT>
+// D = chunks of K in flight (register stages): the row-sized products of the step (M = B*L ~ 2048) are latency chains of
+// global round trips with one chunk of run-ahead.
+template <int MT, int D, int MA, int MB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA, int vecB) {
     constexpr int TM = 32 * MT;
     __shared__ __attribute__((aligned(16))) float As[TM * LDT];      // [m][k]
@@ -107,17 +165,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
     acc_zero<MT, 2>(acc);
     float rs = 0.f;                                         // row sum of A over this workgroup's K range (rowsum_a: n tile 0 only)
     const bool do_rs = p.rowsum_a && blockIdx.y == 0 && tid < TM;
-    float ra[TM / 8], rb[GT / 8];
-    stage_fetch<TM>(p.A, p.sam, p.sak, m0, p.M, kbeg, kend, vecA != 0, ra);
-    stage_fetch<GT>(p.B, p.sbn, p.sbk, n0, p.N, kbeg, kend, vecB != 0, rb);
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        stage_commit<TM>(p.sam, p.sak, vecA != 0, As, ra);
-        stage_commit<GT>(p.sbn, p.sbk, vecB != 0, Bs, rb);
-        __syncthreads();
-        if (k0 + GK < kend) {                             // next chunk in flight under this chunk's MFMAs
-            stage_fetch<TM>(p.A, p.sam, p.sak, m0, p.M, k0 + GK, kend, vecA != 0, ra);
-            stage_fetch<GT>(p.B, p.sbn, p.sbk, n0, p.N, k0 + GK, kend, vecB != 0, rb);
-        }
+    Stage<TM, MA> sa;
+    Stage<GT, MB> sb;
+    sa.init(p.A, p.sam, p.sak, m0, p.M, vecA != 0, kbeg);
+    sb.init(p.B, p.sbn, p.sbk, n0, p.N, vecB != 0, kbeg);
+    float ra[D][TM / 8], rb[D][GT / 8];
+    // Groups of D chunks.  Inside the steady-state loop every stage is committed, refilled D chunks ahead and multiplied
+    // UNCONDITIONALLY (a chunk beyond kend loads a valid address and is zeroed at commit): with conditional loads in the loop
+    // the wait-count pass cannot know how many are outstanding and drains them all (vmcnt(0)) at the loop header -- one exposed
+    // round trip per group.  The last group refills nothing and skips its empty stages.
+    auto multiply = [&]() {
         if (do_rs) {
 #pragma unroll
             for (int k = 0; k < GK; k += 4) {
@@ -126,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < GK; ks += 16) {            // one float4 per lane feeds 4 consecutive MFMA k-steps (k permutation)
+        for (int ks = 0; ks < GK; ks += 16) {                // one float4 per lane feeds 4 consecutive MFMA k-steps (k permutation)
             float4 a[MT], b[2];
 #pragma unroll
             for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(As + (wm + 16 * t + r) * LDT + ks + 4 * g);
@@ -134,7 +191,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
             for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * t + r) * LDT + ks + 4 * g);
             mfma_slice<MT, 2>(a, b, acc);
         }
-        __syncthreads();
+    };
+#pragma unroll
+    for (int st = 0; st < D; ++st)
+        if (kbeg + st * GK < kend) { sa.fetch(kbeg + st * GK, kend, ra[st]); sb.fetch(kbeg + st * GK, kend, rb[st]); }
+    int kb = kbeg;
+    for (; kb + D * GK < kend; kb += D * GK) {
+#pragma unroll
+        for (int st = 0; st < D; ++st) {
+            const int k0 = kb + st * GK;
+            sa.commit(As, ra[st], k0, kend);
+            sb.commit(Bs, rb[st], k0, kend);
+            lds_barrier();
+            sa.fetch(k0 + D * GK, kend, ra[st]);               // D chunks ahead, into the stage just emptied
+            sb.fetch(k0 + D * GK, kend, rb[st]);
+            multiply();
+            lds_barrier();
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < D; ++st) {
+        const int k0 = kb + st * GK;
+        if (k0 < kend) {                                       // (uniform)
+            sa.commit(As, ra[st], k0, kend);
+            sb.commit(Bs, rb[st], k0, kend);
+            lds_barrier();
+            multiply();
+            lds_barrier();
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1437,9 +1521,21 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     };
     const int vA = vec_ok(a->A, a->sam, a->sak, a->M, a->bsA1, a->bsA2), vB = vec_ok(a->B, a->sbn, a->sbk, a->N, a->bsB1, a->bsB2);
     const dim3 grid((unsigned)((a->M + TM - 1) / TM), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz);
-    if (tall) hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
-    else if (small) hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
-    else hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, vA, vB);
+    // operand layouts of the common products compiled in (see Stage): NT forward (0, 0), dx = dy W (0, 1), dW = dy^T x (1, 1)
+    const int mA = vA && a->sak == 1 ? 0 : vA && a->sam == 1 ? 1 : 2, mB = vB && a->sbk == 1 ? 0 : vB && a->sbn == 1 ? 1 : 2;
+    const int combo = (mA == 0 && mB == 0) ? 0 : (mA == 0 && mB == 1) ? 1 : (mA == 1 && mB == 1) ? 2 : 3;
+    const hipStream_t st = (hipStream_t)stream;
+#define PF_GEMM_LAUNCH(MT_, D_) \
+    switch (combo) { \
+        case 0: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, 0>), grid, dim3(256), 0, st, g, vA, vB); break; \
+        case 1: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, 1>), grid, dim3(256), 0, st, g, vA, vB); break; \
+        case 2: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 1, 1>), grid, dim3(256), 0, st, g, vA, vB); break; \
+        default: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, -1, -1>), grid, dim3(256), 0, st, g, vA, vB); break; \
+    }
+    if (tall) { PF_GEMM_LAUNCH(4, 2) }
+    else if (small) { PF_GEMM_LAUNCH(1, 4) }
+    else { PF_GEMM_LAUNCH(2, 4) }
+#undef PF_GEMM_LAUNCH
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -15,6 +15,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + barrier: it also waits for every outstanding
+// GLOBAL load (s_waitcnt vmcnt(0)), i.e. it drains a register prefetch that was meant to stay in flight across it -- a
+// K loop of "commit, barrier, fetch next, MFMAs, barrier" then exposes one full global round trip per chunk.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- cross-lane primitives on DPP / permlane (VALU speed) --------------------------------------------
 // hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, ~100 cycles of dependent latency per step);
 // the reductions in these kernels are latency chains, so they use DPP row operations for lanes within a
