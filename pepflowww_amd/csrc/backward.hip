@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (r0 < r1) fetch();
     for (long long rb = r0; rb < r1; rb += WK) {
         commit();
-        __syncthreads();
+        lds_barrier();
         if (rb + WK < r1) fetch();
         if (mt0 < MT) {
             // (the transposing reads are inline asm: the compiler does not count them in lgkmcnt, so every operand passes through
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int j = 0; j < NTW; ++j) ac[i][j] = mfma_h(al[i], bh[j], ac[i][j]);
             });
         }
-        __syncthreads();
+        lds_barrier();
     }
     const size_t pbase = (size_t)range * (M * N + M);
 #pragma unroll
