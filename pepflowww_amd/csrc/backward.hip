@@ -1523,16 +1523,17 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     const dim3 grid((unsigned)((a->M + TM - 1) / TM), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz);
     // operand layouts of the common products compiled in (see Stage): NT forward (0, 0), dx = dy W (0, 1), dW = dy^T x (1, 1)
     const int mA = vA && a->sak == 1 ? 0 : vA && a->sam == 1 ? 1 : 2, mB = vB && a->sbk == 1 ? 0 : vB && a->sbn == 1 ? 1 : 2;
-    const int combo = (mA == 0 && mB == 0) ? 0 : (mA == 0 && mB == 1) ? 1 : (mA == 1 && mB == 1) ? 2 : 3;
+    const int combo = (mA == 0 && mB == 0) ? 0 : (mA == 0 && mB == 1) ? 1 : (mA == 1 && mB == 1) ? 2 : mA == 0 ? 4 : 3;
     const hipStream_t st = (hipStream_t)stream;
 #define PF_GEMM_LAUNCH(MT_, D_) \
     switch (combo) { \
         case 0: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, 0>), grid, dim3(256), 0, st, g, vA, vB); break; \
         case 1: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, 1>), grid, dim3(256), 0, st, g, vA, vB); break; \
         case 2: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 1, 1>), grid, dim3(256), 0, st, g, vA, vB); break; \
+        case 4: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, -1>), grid, dim3(256), 0, st, g, vA, vB); break; \
         default: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, -1, -1>), grid, dim3(256), 0, st, g, vA, vB); break; \
     }
-    if (tall) { PF_GEMM_LAUNCH(4, 2) }
+    if (tall) { PF_GEMM_LAUNCH(4, 1) }
     else if (small) { PF_GEMM_LAUNCH(1, 4) }
     else { PF_GEMM_LAUNCH(2, 4) }
 #undef PF_GEMM_LAUNCH
