@@ -821,7 +821,8 @@ def f6(golden_dir):
 @pytest.mark.parametrize("B,L", [(3, 37), (2, 130), (64, 128), (128, 64), (1, 300)])
 def test_seq_attention_backward(B, L):
     """pf_seq_attn_bwd against torch autograd on the unfused attention of the oracle (padding in one sample); the shapes
-    cover the 8 / 4 / 2 threads-per-row LDS variants with ragged row chunks and the global-memory form (L > 256)."""
+    cover the MFMA form (L <= 128, ragged and full tiles), the threads-per-row LDS form (128 < L <= 256) and the
+    global-memory form (L > 256)."""
     from pepflowww_amd import backward as Bk
     g = torch.Generator().manual_seed(12)
     qkv = torch.randn(B, L, 384, generator=g).requires_grad_(True)
