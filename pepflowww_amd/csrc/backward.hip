@@ -1269,16 +1269,33 @@ __global__ __launch_bounds__(256) void et_concat_bwd_kernel(const float* gx, flo
     }
 }
 
-// nn.Embedding backward: table_grad[c, d] = sum over rows r with idx[r] == c of g[r*ldg + d]; one thread per (c, d),
-// deterministic (rows in order)
+// nn.Embedding backward: table_grad[c, d] = sum over rows r with idx[r] == c of g[r*ldg + d].  One workgroup per (class c, 32
+// columns): 8 row groups x 32 columns, each thread walks every 8th row (the index tested from a 4-row batch of loads), the
+// eight partial sums meet in LDS in a fixed order -- deterministic like the one-thread-per-(c, d) loop over all rows it
+// replaces (167 us at 2048 rows: 2048 dependent steps on 11 workgroups).
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* g, int ldg, const long long* idx, int rows, int ncls, int dim, float* tg) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ncls * dim) return;
-    const int c = t / dim, d = t - c * dim;
+    __shared__ float red[8][32];
+    const int chunks = (dim + 31) / 32;
+    const int c = blockIdx.x / chunks, d = (blockIdx.x - c * chunks) * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
     float acc = 0.f;
-    for (int r = 0; r < rows; ++r)
-        if (idx[r] == c) acc += g[(size_t)r * ldg + d];
-    tg[t] = acc;
+    for (int r0 = rg; r0 < rows; r0 += 32) {
+        long long id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int r = r0 + 8 * u; id[u] = r < rows ? idx[r] : -1; }
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int r = r0 + 8 * u; v[u] = (id[u] == c && d < dim) ? g[(size_t)r * ldg + d] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    red[rg][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (rg == 0 && d < dim) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+        tg[c * dim + d] = t;
+    }
 }
 
 // ---- encoder (node.py / edge.py) backward helpers --------------------------------------------------------------
@@ -1353,7 +1370,7 @@ __global__ __launch_bounds__(256) void quat_to_rot_bwd_kernel(const float* quat,
 
 extern "C" int pf_embedding_bwd(const float* g, int ldg, const int64_t* idx, int rows, int ncls, int dim, float* table_grad, pf_stream_t stream) {
     if (!g || !idx || !table_grad || rows <= 0 || ncls <= 0 || dim <= 0) return PF_E_BADARG;
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((ncls * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)(ncls * ((dim + 31) / 32))), dim3(256), 0, (hipStream_t)stream, g, ldg,
                        reinterpret_cast<const long long*>(idx), rows, ncls, dim, table_grad);
     PF_CHECK_LAUNCH();
     return 0;

@@ -718,6 +718,26 @@ def test_gemm_tn_wide(R, M, N, use_ws):
         assert (cs.cpu().double() - wcs).abs().max() <= 2e-5 * wcs.abs().max() + 1e-5, (R, M, N, acc)
 
 
+@pytest.mark.parametrize("rows,ncls,dim,ld", [(2048, 22, 128, 640), (333, 22, 128, 128), (50, 5, 40, 48)])
+def test_embedding_backward(rows, ncls, dim, ld):
+    """pf_embedding_bwd (nn.Embedding weight gradient, deterministic row-group form) against index_add in float64."""
+    from pepflowww_amd import _capi
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(rows + dim)
+    grad = torch.randn(rows, ld, generator=g)
+    idx = torch.randint(0, ncls, (rows,), generator=g)
+    out = torch.full((ncls, dim), float("nan"), device="cuda")
+    gd, idd = cu(grad), idx.cuda()
+    _capi.check(lib.pf_embedding_bwd(gd.data_ptr(), ld, idd.data_ptr(), rows, ncls, dim, out.data_ptr(), _capi.stream_ptr()), "pf_embedding_bwd")
+    G.sync()
+    ref = torch.zeros(ncls, dim, dtype=torch.float64).index_add_(0, idx, grad[:, :dim].double())
+    assert (out.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    out2 = torch.full((ncls, dim), float("nan"), device="cuda")
+    _capi.check(lib.pf_embedding_bwd(gd.data_ptr(), ld, idd.data_ptr(), rows, ncls, dim, out2.data_ptr(), _capi.stream_ptr()), "pf_embedding_bwd")
+    G.sync()
+    assert torch.equal(out, out2)                       # deterministic
+
+
 @pytest.mark.parametrize("M,N", [(77, 128), (2048 + 3, 128), (65536 + 21, 64)])
 def test_layernorm_and_relu_backward(M, N):
     """nn.LayerNorm backward with dgamma / dbeta accumulated by the kernel itself: one row per wave (small M), four rows per
