@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 27
+#define PF_ABI_VERSION 28
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -437,7 +437,9 @@ typedef struct { const float* x; const float* dy; const float* gamma; float* dx;
                  float* dgamma; float* dbeta;
                  /* optional scratch private to the stream (>= (M / 64 + 1) * 2 N floats): pair-sized inputs then write per-workgroup
                   * partial sums that a second kernel adds up, instead of thousands of atomics per column */
-                 float* workspace; long long workspace_elems; } pf_layernorm_bwd_args;
+                 float* workspace; long long workspace_elems;
+                 /* optional: dy[m, :] is multiplied by row_scale[m] on the way in (y * mask in the forward: no masked copy of dy) */
+                 const float* row_scale; } pf_layernorm_bwd_args;
 int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stream);
 int pf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int N, pf_stream_t stream);
 int pf_row_mask(float* x, const float* mask, int M, int N, pf_stream_t stream);        /* x[m,:] *= mask[m] */

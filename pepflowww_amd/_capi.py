@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -97,7 +97,7 @@ class GemmArgs(C.Structure):
 
 class LayerNormBwdArgs(C.Structure):
     _fields_ = [("x", _fp), ("dy", _fp), ("gamma", _fp), ("dx", _fp), ("dgamma_rows", _fp), ("M", _i), ("N", _i),
-                ("dgamma", _fp), ("dbeta", _fp), ("workspace", _fp), ("workspace_elems", C.c_longlong)]
+                ("dgamma", _fp), ("dbeta", _fp), ("workspace", _fp), ("workspace_elems", C.c_longlong), ("row_scale", _fp)]
 
 
 class RigidUpdateBwdArgs(C.Structure):

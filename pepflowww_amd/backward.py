@@ -214,7 +214,7 @@ def relu_bwd_(y, dy):
     return dy
 
 
-def layernorm_bwd(x, gamma, dy):
+def layernorm_bwd(x, gamma, dy, row_scale=None):
     lib = _capi.load()
     M, N = x.shape
     dx = torch.empty_like(x)
@@ -227,6 +227,8 @@ def layernorm_bwd(x, gamma, dy):
     a = _capi.LayerNormBwdArgs()
     a.x, a.dy, a.gamma, a.dx, a.dgamma_rows, a.M, a.N = x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), None, M, N
     a.dgamma, a.dbeta = dg.data_ptr(), dbeta.data_ptr()
+    if row_scale is not None:             # dy * row_scale[m] on the way in (the output row mask of the forward)
+        a.row_scale = row_scale.data_ptr()
     if M >= 65536:
         ws = _tn_workspace(x.device)
         a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
@@ -336,9 +338,8 @@ class NodeTrackBlock:
         s_in + ipa_embed * mask (i.e. d/d s_in contribution and, times mask, d/d ipa_embed)."""
         b, B, L, m, sv = self.b, self.B, self.L, self.mask, self.saved
         G = {}
-        g = row_mask_(g_s3m.clone(), m)
         t = f"node_transition_{b}."
-        g_h3, G[t + "ln.weight"], G[t + "ln.bias"] = layernorm_bwd(sv["h3"], self.p(t + "ln.weight"), g)
+        g_h3, G[t + "ln.weight"], G[t + "ln.bias"] = layernorm_bwd(sv["h3"], self.p(t + "ln.weight"), g_s3m, row_scale=m)
         g_t2, G[t + "linear_3.weight"], G[t + "linear_3.bias"] = linear_bwd(sv["t2"], self.p(t + "linear_3.weight"), g_h3, dx_gate=sv["t2"])
         g_t1, G[t + "linear_2.weight"], G[t + "linear_2.bias"] = linear_bwd(sv["t1"], self.p(t + "linear_2.weight"), g_t2, dx_gate=sv["t1"])
         g_s2, G[t + "linear_1.weight"], G[t + "linear_1.bias"] = linear_bwd(sv["s2"], self.p(t + "linear_1.weight"), g_t1, dx_residual=g_h3)   # residual s2 + t3
@@ -571,8 +572,7 @@ class EdgeTransitionBlock:
         """g_out: gradient w.r.t. the masked output pair tensor.  Returns (g_s, g_z_in, grads); g_z given -> accumulated into."""
         lib, B, L, W, p, sv = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}.", self.saved
         G = {}
-        g = row_mask_(g_out.clone(), sv["em"])
-        g_y, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"] = layernorm_bwd(sv["y"], W[p + "layer_norm.weight"], g)
+        g_y, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"] = layernorm_bwd(sv["y"], W[p + "layer_norm.weight"], g_out, row_scale=sv["em"])
         g_u, G[p + "final_layer.weight"], G[p + "final_layer.bias"] = linear_bwd(sv["u"], W[p + "final_layer.weight"], g_y)
         g_h2 = relu_gate(sv["h2"], g_u)                          # g_u also flows through the skip connection h2 + x
         g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, dx_gate=sv["h1"])

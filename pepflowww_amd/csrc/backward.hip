@@ -777,8 +777,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_arg
         const float* dy = p.dy + (size_t)row * p.N;
         float xv[4], gv[4], dv[4];
         float s = 0.f;
+        const float rsc = p.row_scale ? p.row_scale[row] : 1.f;     // dy of this row arrives scaled (the row mask of the layer's output)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; xv[c] = n < p.N ? x[n] : 0.f; dv[c] = n < p.N ? dy[n] : 0.f; s += xv[c]; }
+        for (int c = 0; c < 4; ++c) { const int n = lane + 64 * c; xv[c] = n < p.N ? x[n] : 0.f; dv[c] = n < p.N ? dy[n] * rsc : 0.f; s += xv[c]; }
         const float mean = wave_sum(s) / (float)p.N;
         float q = 0.f;
 #pragma unroll
