@@ -297,6 +297,53 @@ struct WPre {
     }
 };
 
+// gemm_split with a small register footprint (no next-step copy of the weight fragments -- the compiler sinks those loads to
+// their use anyway -- and the row tiles fed two at a time): lets the 6-/8-wave whole-row Linear fit 128 VGPRs, i.e. 4 waves per
+// SIMD, so that two of its workgroups ALWAYS fit a CU (6 waves land 2,2,1,1 on the SIMDs: at 3 waves per SIMD a second
+// workgroup only fits when the dispatcher happens to rotate it the right way).
+template <int WT, int PT>
+__device__ __forceinline__ void gemm_split_lowreg(const void* planes, int N, int Kw, int n0, int K,
+                                                  const _Float16* Xh, const _Float16* Xl, int ldx,
+                                                  f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT]) {
+    static_assert(PT % 2 == 0, "row tiles are fed in pairs");
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int wsteps = Kw >> 5, nst = K >> 5;
+    const _Float16* wh = reinterpret_cast<const _Float16*>(planes) + ((size_t)(n0 >> 4) * wsteps * 64 + lane) * 8;
+    const _Float16* wl = wh + (size_t)N * Kw;
+    const size_t tstride = (size_t)wsteps * 512;
+    const _Float16* xh = Xh + r * ldx + 8 * g;
+    const _Float16* xl = Xl + r * ldx + 8 * g;
+    for (int st = 0; st < nst; ++st) {
+        half8 bh[WT], bl[WT];
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+            bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)st * 512);
+            bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)st * 512);
+        }
+#pragma unroll
+        for (int p0 = 0; p0 < PT; p0 += 2) {
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ah[q] = *reinterpret_cast<const half8*>(xh + (p0 + q) * 16 * ldx + 32 * st);
+                al[q] = *reinterpret_cast<const half8*>(xl + (p0 + q) * 16 * ldx + 32 * st);
+            }
+#pragma unroll
+            for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) am[wt][p0 + q] = mfma_h(bh[wt], ah[q], am[wt][p0 + q]);
+#pragma unroll
+            for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ac[wt][p0 + q] = mfma_h(bh[wt], al[q], ac[wt][p0 + q]);
+#pragma unroll
+            for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ac[wt][p0 + q] = mfma_h(bl[wt], ah[q], ac[wt][p0 + q]);
+        }
+    }
+}
+
 template <int WT, int PT, bool SWZ = false>
 __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, int n0, int K,
                                            const _Float16* Xh, const _Float16* Xl, int ldx,

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     acc_zero<2, 4>(am);
     acc_zero<2, 4>(ac);
     if (n0 + 16 < Npad) {
-        gemm_split<2, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
+        if (NWV > 4) gemm_split_lowreg<2, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
+        else gemm_split<2, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
     } else {                                           // last feature tile of a ragged N: one tile only
         f32x4 bm[1][4], bc[1][4];
         acc_zero<1, 4>(bm);
