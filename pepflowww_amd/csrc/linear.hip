@@ -199,12 +199,17 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     {
         constexpr int NT = 64 * NWV, UB = 8;
         const int total = SP_BM * kq;
+        // (row, column quad) of float4 number idx = tid + j NT: when a row's quads divide the thread count the column is fixed
+        // per thread and the row advances by NT / kq -- no per-element integer division (8 + 8 of them per thread otherwise)
+        const bool reg = NT % kq == 0;
+        const int rstep = NT / kq, trow = tid / kq, tc4 = tid - trow * kq;
         for (int base = 0; base < total; base += NT * UB) {
             float4 t[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int idx = min(base + tid + u * NT, total - 1);
-                const int row = idx / kq, c4 = idx - row * kq;
+                int row, c4;
+                if (reg) { row = min(base / kq + trow + u * rstep, SP_BM - 1); c4 = tc4; } else { row = idx / kq; c4 = idx - row * kq; }
                 const int m = min(m0 + row, p.M - 1);
                 t[u] = *reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + 4 * c4);
             }
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
             for (int u = 0; u < UB; ++u) {
                 const int idx = base + tid + u * NT;
                 if (idx < total) {
-                    const int row = idx / kq, c4 = idx - row * kq;
+                    int row, c4;
+                    if (reg) { row = base / kq + trow + u * rstep; c4 = tc4; } else { row = idx / kq; c4 = idx - row * kq; }
                     const float keep = (m0 + row < p.M) ? 1.f : 0.f;
                     const float v[4] = {t[u].x * keep, t[u].y * keep, t[u].z * keep, t[u].w * keep};
                     half4 hi, lo;
