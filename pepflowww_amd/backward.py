@@ -209,6 +209,19 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
     return dx, dW, db
 
 
+def dw_accumulate(x, dy, dW):
+    """dW += dy^T x (a second input summed into the same Linear: W (x1 + x2))."""
+    M, K = x.shape
+    N = dy.shape[1]
+    if M >= TN_WIDE_MIN_ROWS and N <= 192 and K <= 256 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous():
+        ws = _tn_workspace(x.device)
+        _capi.check(_capi.load().pf_gemm_tn_wide(dy.data_ptr(), N, N, x.data_ptr(), K, K, dW.data_ptr(), K, M, 1, None, 0,
+                                                 ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_wide")
+    else:
+        _gemm(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=True)
+    return dW
+
+
 def relu_bwd_(y, dy):
     _capi.check(_capi.load().pf_relu_bwd(y.data_ptr(), dy.data_ptr(), y.numel(), _capi.stream_ptr()), "pf_relu_bwd")
     return dy
@@ -547,8 +560,7 @@ class EdgeTransitionBlock:
         a.mask, a.B, a.L, a.w_stream = self.mask.data_ptr(), B, L, stream.data_ptr()
         a.dump_h1, a.dump_h2, a.dump_y = h1.data_ptr(), h2.data_ptr(), y.data_ptr()
         _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
-        u = add_out(h2, x)
-        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, u=u, y=y)
+        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, y=y)     # (u = h2 + x is not kept: the backward uses h2 and x separately)
         return out
 
     def forward(self, s, z):
@@ -565,7 +577,7 @@ class EdgeTransitionBlock:
         u = add_out(h2, x)                                       # final_layer(h2 + x)
         y = linear_fwd(u, W[p + "final_layer.weight"], W[p + "final_layer.bias"])
         out = row_mask_(layernorm_fwd(y, W[p + "layer_norm.weight"], W[p + "layer_norm.bias"]), em)
-        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, u=u, y=y)
+        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, y=y)
         return out
 
     def backward(self, g_out, g_z=None):
@@ -573,7 +585,10 @@ class EdgeTransitionBlock:
         lib, B, L, W, p, sv = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}.", self.saved
         G = {}
         g_y, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"] = layernorm_bwd(sv["y"], W[p + "layer_norm.weight"], g_out, row_scale=sv["em"])
-        g_u, G[p + "final_layer.weight"], G[p + "final_layer.bias"] = linear_bwd(sv["u"], W[p + "final_layer.weight"], g_y)
+        # final_layer(h2 + x): dW = g_y^T h2 + g_y^T x as two passes accumulating into the same gradient -- cheaper than
+        # materialising u = h2 + x ([B L L, 192], one more pair-sized read-read-write) just to contract it once
+        g_u, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y)
+        G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
         g_h2 = relu_gate(sv["h2"], g_u)                          # g_u also flows through the skip connection h2 + x
         g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, dx_gate=sv["h1"])
         g_x, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, dx_residual=g_u)

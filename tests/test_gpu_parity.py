@@ -976,7 +976,7 @@ def test_fused_edge_transition_training_forward(seeded_sd, B, L):
     o0, sv0, gs0, gz0, G0 = res[False]
     o1, sv1, gs1, gz1, G1 = res[True]
     assert (o0 - o1).abs().max().item() <= 2e-5
-    for k in ("h1", "h2", "u", "y", "x", "em"):
+    for k in ("h1", "h2", "y", "x", "em"):
         assert (sv0[k] - sv1[k]).abs().max().item() <= 2e-5, k
     assert (gs0 - gs1).abs().max() <= 1e-4 * gs0.abs().max() and (gz0 - gz1).abs().max() <= 1e-4 * gz0.abs().max()
     for k in G0:
