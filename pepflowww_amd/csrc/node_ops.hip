@@ -1,5 +1,6 @@
 // Per-residue kernels of the denoise step: input feature assembly, sequence-transformer
 // attention core, rot->quat and the quaternion backbone update.
+#include <cstdlib>
 #include "common.h"
 #include "rigid_dev.h"
 #include "../../include/pepflow_hip.h"
@@ -121,6 +122,88 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(pf_seq_attn_args a) {
     }
 }
 
+// The same attention core on the matrix cores (L <= 128; the training forward runs it 12 times per step): one workgroup of 8
+// waves per (sample, head); S = Q K^T (fp32 MFMA, k-contiguous rows of both operands), masked softmax in the accumulator
+// registers (a row = 8 tiles x the 16 lanes of a lane group), P through one [128][132] LDS tile, O = P V.
+constexpr int SM_L = 128, SM_LDX = SM_L + 4;
+__global__ __launch_bounds__(512) void seq_attn_mfma_kernel(pf_seq_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;
+    float* Ks = Qs + SM_L * SA_LD;
+    float* Vs = Ks + SM_L * SA_LD;
+    float* X = Vs + SM_L * SA_LD;                   // [128][132] probabilities
+    float* Mk = X + SM_L * SM_LDX;
+    const int L = a.L, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const size_t rowb = (size_t)b * L;
+    const float scale = 0.17677669529663687f;     // 1/sqrt(32)
+    for (int idx = tid; idx < SM_L * 8; idx += 512) {
+        const int row = idx >> 3, c4 = idx & 7;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+        if (row < L) {
+            const float* src = a.qkv + (rowb + row) * 384 + h * 32 + 4 * c4;
+            q = *reinterpret_cast<const float4*>(src);
+            k = *reinterpret_cast<const float4*>(src + 128);
+            v = *reinterpret_cast<const float4*>(src + 256);
+        }
+        *reinterpret_cast<float4*>(Qs + row * SA_LD + 4 * c4) = q;
+        *reinterpret_cast<float4*>(Ks + row * SA_LD + 4 * c4) = k;
+        *reinterpret_cast<float4*>(Vs + row * SA_LD + 4 * c4) = v;
+    }
+    if (tid < SM_L) Mk[tid] = tid < L ? a.mask[rowb + tid] : 0.f;
+    __syncthreads();
+    const int i0 = 16 * wave;
+    f32x4 sc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) sc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 16) {
+        const float4 aq = *reinterpret_cast<const float4*>(Qs + (i0 + r) * SA_LD + ks + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const float4 bk = *reinterpret_cast<const float4*>(Ks + (16 * nt + r) * SA_LD + ks + 4 * g);
+            sc[nt] = mfma16(aq.x, bk.x, sc[nt]); sc[nt] = mfma16(aq.y, bk.y, sc[nt]); sc[nt] = mfma16(aq.z, bk.z, sc[nt]); sc[nt] = mfma16(aq.w, bk.w, sc[nt]);
+        }
+    }
+    auto gsum = [](float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; };
+    auto gmax = [](float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8)); return v; };
+    float keep[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) keep[nt] = Mk[16 * nt + r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                   // register e of lane (r, g) of tile nt = (query i0 + 4 g + e, key 16 nt + r)
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) if (keep[nt] >= 0.5f) mx = fmaxf(mx, sc[nt][e] * scale);
+        mx = gmax(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) { const float ev = keep[nt] >= 0.5f ? expf(sc[nt][e] * scale - mx) : 0.f; sc[nt][e] = ev; sum += ev; }
+        sum = gsum(sum);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) X[(i0 + 4 * g + e) * SM_LDX + 16 * nt + r] = sc[nt][e] * inv;
+    }
+    __syncthreads();                                // (each wave reads only its own 16 rows of X, but V rows of all)
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+    for (int ks = 0; ks < SM_L; ks += 16) {
+        const float4 p4 = *reinterpret_cast<const float4*>(X + (i0 + r) * SM_LDX + ks + 4 * g);
+        const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma16(pv[t], Vs[(ks + 4 * g + t) * SA_LD + 16 * nt + r], acc[nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + 4 * g + e;
+            if (i < L) a.out[(rowb + i) * 128 + h * 32 + 16 * nt + r] = acc[nt][e];
+        }
+}
+
 __global__ __launch_bounds__(256) void rot_to_quat_kernel(const float* rot, float* quat, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -166,6 +249,15 @@ extern "C" int pf_embed_inputs_fwd(const pf_embed_args* a, pf_stream_t stream) {
 
 extern "C" int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream) {
     if (!a || !a->qkv || !a->mask || !a->out || a->B <= 0 || a->L <= 0) return PF_E_BADARG;
+    static const int use_mfma = [] { const char* e = getenv("PF_SEQ_FWD_MFMA"); return e ? atoi(e) : 1; }();
+    if (use_mfma && a->L <= SM_L) {
+        const size_t ldm = ((size_t)3 * SM_L * SA_LD + SM_L * SM_LDX + SM_L) * sizeof(float);
+        static bool attr_m = false;
+        if (!attr_m) { (void)hipFuncSetAttribute((const void*)seq_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
+        hipLaunchKernelGGL(seq_attn_mfma_kernel, dim3((unsigned)(a->B * 4)), dim3(512), ldm, (hipStream_t)stream, *a);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = ((size_t)a->L * (2 * SA_LD + 1)) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
     static bool attr_set = false;

@@ -187,12 +187,14 @@ def test_rot_to_quat_and_rigid_update(f1):
     G.assert_close(x2, f1["upd2_x"].reshape(-1, 3), 2e-6, "trans after update 2")
 
 
-def test_seq_attention_core():
+@pytest.mark.parametrize("B,L", [(3, 37), (16, 128), (2, 16), (2, 150)])
+def test_seq_attention_core(B, L):
+    """pf_seq_attn_fwd against torch (key padding in one sample): the matrix-core form (L <= 128, ragged and full tiles) and the
+    streaming-softmax form (L > 128)."""
     g = torch.Generator().manual_seed(5)
-    B, L = 3, 37
     qkv = torch.randn(B * L, 384, generator=g)
     mask = torch.ones(B, L)
-    mask[1, 30:] = 0
+    mask[1, L - 7:] = 0
     q, k, v = [t.view(B, L, 4, 32).transpose(1, 2) for t in qkv.view(B, L, 384).split(128, -1)]
     att = (q @ k.transpose(-1, -2)) / math.sqrt(32)
     att = att.masked_fill((mask < 0.5)[:, None, None, :], float("-inf")).softmax(-1)
