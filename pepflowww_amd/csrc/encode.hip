@@ -143,9 +143,10 @@ __global__ __launch_bounds__(256) void node_features_kernel(pf_node_feat_args a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// edge features + MLPs: 64 flattened pairs per workgroup
+// edge features + MLPs: 32 flattened pairs per workgroup, 8 threads per pair
 // ------------------------------------------------------------------------------------------------
-constexpr int EP = 64;
+constexpr int EP = 32;      // pairs per workgroup: 49 KB of LDS (80 KB with the training dumps) = 3 (2) workgroups per CU; with 64 pairs it was one,
+                            // i.e. one wave per SIMD for a kernel that is a chain of dependent phases (1.15 ms at 262144 pairs)
 constexpr int LDF = 244;     // 240 + 4   (feature tile / concat tile row stride)
 constexpr int LDH = 68;
 
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
     const long long LL = (long long)L * L;
     const long long p0 = (long long)blockIdx.x * EP;
 
-    // per-thread pair for the feature phases: 4 threads per pair
-    const int prow = tid >> 2, sub = tid & 3;
+    // per-thread pair for the feature phases: 8 threads per pair
+    const int prow = tid >> 3, sub = tid & 7;
     long long pr = p0 + prow;
     const bool pok = pr < npairs;
     if (!pok) pr = npairs - 1;
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
         }
     };
     // ---- phase 1: Gaussian atom-pair distances (edge.py:83-89) ----
-    // The pair's atom positions and masks are staged in LDS first (the H1 / H2 area is idle here): its four threads issue their
-    // 30 loads back to back, and the 60-step feature loop then runs on LDS + one batched coefficient gather per 6 steps.  With
+    // The pair's atom positions and masks are staged in LDS first (the H1 / H2 area is idle here): its eight threads issue their
+    // 15 loads back to back, and the 30-step feature loop then runs on LDS + one batched coefficient gather per 6 steps.  With
     // the loads inside the loop every step waited for its own global round trip, on one wave per SIMD (1.3 ms at 262144 pairs).
     {
         float* stg = H1 + prow * 120;                              // [EP][120]: pos_i 45 | pos_j 45 | mask_i 15 | mask_j 15  (<= 2 EP LDH floats)
@@ -195,23 +196,23 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
         const float* posj = a.pos + (size_t)pj * A * 3;
         const float* mi = a.mask_atoms + (size_t)pi * A;
         const float* mj = a.mask_atoms + (size_t)pj * A;
-        float t[30];
+        float t[15];
 #pragma unroll
-        for (int q = 0; q < 30; ++q) {
-            const int k = sub + 4 * q;
+        for (int q = 0; q < 15; ++q) {
+            const int k = sub + 8 * q;
             t[q] = k < 45 ? posi[k] : k < 90 ? posj[k - 45] : k < 105 ? mi[k - 90] : mj[k - 105];
         }
 #pragma unroll
-        for (int q = 0; q < 30; ++q) stg[sub + 4 * q] = t[q];
+        for (int q = 0; q < 15; ++q) stg[sub + 8 * q] = t[q];
         __syncthreads();
         const float* coef = a.distcoef + (size_t)aap * 225;
-        for (int e0 = sub; e0 < 240; e0 += 24) {
+        for (int e0 = sub; e0 < 240; e0 += 48) {
             float cf[6];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) { const int e = e0 + 4 * u; cf[u] = coef[e < 225 ? e : 224]; }
+            for (int u = 0; u < 6; ++u) { const int e = e0 + 8 * u; cf[u] = coef[e < 225 ? e : 224]; }
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int e = e0 + 4 * u;
+                const int e = e0 + 8 * u;
                 float v = 0.f;
                 if (e < 225) {
                     const int ai = e / A, bj = e - ai * A;
@@ -231,13 +232,13 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
 
     // ---- GEMM1: distance_embed.0 (225 -> 64) + ReLU ----
     {
-        f32x4 acc[4][1];
-        acc_zero<4, 1>(acc);
-        gemm_ldsA_glbB<4, 1>(Ft, LDF, a.w_d0, 240, wave * 16, 64, 240, acc);
+        f32x4 acc[2][1];
+        acc_zero<2, 1>(acc);
+        gemm_ldsA_glbB<2, 1>(Ft, LDF, a.w_d0, 240, wave * 16, 64, 240, acc);
         const int n = wave * 16 + r;
         const float bias = a.b_d0[n];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
         const float same = (a.chain_nb[pi] == a.chain_nb[pj]) ? 1.f : 0.f;
         const float* ap = a.aapair_table + (size_t)aap * 64;
         const float* rp = a.relpos_table + (size_t)rel * 64;
-        for (int c = sub; c < 64; c += 4) {
+        for (int c = sub; c < 64; c += 8) {
             Ft[prow * LDF + c] = ap[c];
             Ft[prow * LDF + 64 + c] = rp[c] * same;
         }
@@ -269,13 +270,13 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
     }
     // ---- GEMM2: distance_embed.2 (64 -> 64) + ReLU, x pair structure mask -> concat cols 128..191 ----
     {
-        f32x4 acc[4][1];
-        acc_zero<4, 1>(acc);
-        gemm_ldsA_glbB<4, 1>(H1, LDH, a.w_d2, 64, wave * 16, 64, 64, acc);
+        f32x4 acc[2][1];
+        acc_zero<2, 1>(acc);
+        gemm_ldsA_glbB<2, 1>(H1, LDH, a.w_d2, 64, wave * 16, 64, 64, acc);
         const int n = wave * 16 + r;
         const float bias = a.b_d2[n];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = mt * 16 + g * 4 + e;
@@ -292,39 +293,39 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
 
     // ---- GEMM3..5: out_mlp (218 -> 64 -> 64 -> 64) ----
     {
-        f32x4 acc[4][1];
-        acc_zero<4, 1>(acc);
-        gemm_ldsA_glbB<4, 1>(Ft, LDF, a.w_o0, 224, wave * 16, 64, 224, acc);
+        f32x4 acc[2][1];
+        acc_zero<2, 1>(acc);
+        gemm_ldsA_glbB<2, 1>(Ft, LDF, a.w_o0, 224, wave * 16, 64, 224, acc);
         const int n = wave * 16 + r;
         const float bias = a.b_o0[n];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();
     dump_tile(a.dump_o1, H1, LDH, 64, 64);
     {
-        f32x4 acc[4][1];
-        acc_zero<4, 1>(acc);
-        gemm_ldsA_glbB<4, 1>(H1, LDH, a.w_o2, 64, wave * 16, 64, 64, acc);
+        f32x4 acc[2][1];
+        acc_zero<2, 1>(acc);
+        gemm_ldsA_glbB<2, 1>(H1, LDH, a.w_o2, 64, wave * 16, 64, 64, acc);
         const int n = wave * 16 + r;
         const float bias = a.b_o2[n];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) H2[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();
     dump_tile(a.dump_o2, H2, LDH, 64, 64);
     {
-        f32x4 acc[4][1];
-        acc_zero<4, 1>(acc);
-        gemm_ldsA_glbB<4, 1>(H2, LDH, a.w_o4, 64, wave * 16, 64, 64, acc);
+        f32x4 acc[2][1];
+        acc_zero<2, 1>(acc);
+        gemm_ldsA_glbB<2, 1>(H2, LDH, a.w_o4, 64, wave * 16, 64, 64, acc);
         const int n = wave * 16 + r;
         const float bias = a.b_o4[n];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = acc[mt][0][e] + bias;
     }
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
         if (pok) {
             const float mp = a.mres[pi] * a.mres[pj];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int n = 16 * sub + 4 * c;
+            for (int c = 0; c < 2; ++c) {
+                const int n = 8 * sub + 4 * c;
                 float4 t = *reinterpret_cast<const float4*>(H1 + prow * LDH + n);
                 t.x *= mp; t.y *= mp; t.z *= mp; t.w *= mp;
                 *reinterpret_cast<float4*>(a.out + (p0 + prow) * 64 + n) = t;
