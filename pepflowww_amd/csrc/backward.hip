@@ -827,6 +827,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(pf_layernorm_bwd_arg
     }
 }
 
+// N = 64 (the pair tensor): four rows per wave at a time -- 16 lanes x float4 per row, so one load instruction moves 1 KB
+// instead of 256 B and a wave has four rows of x and dy in flight (the one-row-per-wave form ran the pair-sized LayerNorms at
+// 2.3 TB/s).  Row sums are 16-lane butterflies; dgamma / dbeta partials as above.
+__global__ __launch_bounds__(256) void layernorm_bwd64_kernel(pf_layernorm_bwd_args p, int quads_per_wave, float* part) {
+    __shared__ float red[2][4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15, gr = lane >> 4;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * quads_per_wave * 4;
+    auto s16 = [](float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; };
+    const float4 gam = *reinterpret_cast<const float4*>(p.gamma + 4 * sub);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+#pragma unroll 2
+    for (int i = 0; i < quads_per_wave; ++i) {
+        const long long row = row0 + 4 * i + gr;
+        const bool ok = row < p.M;
+        const long long rc = ok ? row : p.M - 1;
+        const float4 x = *reinterpret_cast<const float4*>(p.x + (size_t)rc * 64 + 4 * sub);
+        float4 d = *reinterpret_cast<const float4*>(p.dy + (size_t)rc * 64 + 4 * sub);
+        const float rsc = !ok ? 0.f : p.row_scale ? p.row_scale[rc] : 1.f;
+        d.x *= rsc; d.y *= rsc; d.z *= rsc; d.w *= rsc;
+        const float mean = s16((x.x + x.y) + (x.z + x.w)) * (1.f / 64.f);
+        const float4 c = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
+        const float rstd = rsqrtf(s16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.f / 64.f) + 1e-5f);
+        const float4 xh = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
+        const float4 gv = make_float4(d.x * gam.x, d.y * gam.y, d.z * gam.z, d.w * gam.w);
+        const float sg = s16((gv.x + gv.y) + (gv.z + gv.w)) * (1.f / 64.f);
+        const float sgx = s16((gv.x * xh.x + gv.y * xh.y) + (gv.z * xh.z + gv.w * xh.w)) * (1.f / 64.f);
+        dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
+        db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+        if (ok)
+            *reinterpret_cast<float4*>(p.dx + (size_t)row * 64 + 4 * sub) =
+                make_float4(rstd * (gv.x - sg - xh.x * sgx), rstd * (gv.y - sg - xh.y * sgx), rstd * (gv.z - sg - xh.z * sgx), rstd * (gv.w - sg - xh.w * sgx));
+    }
+    if (p.dgamma) {
+        auto s4 = [](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };       // the wave's four row groups
+        dg.x = s4(dg.x); dg.y = s4(dg.y); dg.z = s4(dg.z); dg.w = s4(dg.w);
+        db.x = s4(db.x); db.y = s4(db.y); db.z = s4(db.z); db.w = s4(db.w);
+        if (gr == 0) { *reinterpret_cast<float4*>(&red[0][wave][4 * sub]) = dg; *reinterpret_cast<float4*>(&red[1][wave][4 * sub]) = db; }
+        __syncthreads();
+        const int n = threadIdx.x & 63, which = threadIdx.x >> 6;
+        if (which < 2) {
+            const float v = (red[which][0][n] + red[which][1][n]) + (red[which][2][n] + red[which][3][n]);
+            if (part) part[(size_t)blockIdx.x * 128 + which * 64 + n] = v;
+            else atomicAdd((which ? p.dbeta : p.dgamma) + n, v);
+        }
+    }
+}
+
 // dgamma / dbeta += sum over workgroups of their partial column sums: block (x, y) sums slice y of the workgroups for 64 columns
 // (4 thread groups x unrolled loads), then one atomic per column and block (gridDim.y = 32 of them per column)
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* part, int nwg, int N, float* dgamma, float* dbeta) {
@@ -1647,6 +1694,15 @@ extern "C" int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stre
     if ((a->dgamma != nullptr) != (a->dbeta != nullptr)) return PF_E_BADARG;
     // rows per wave: row-sized inputs keep >= 128 workgroups and add their column sums atomically (one atomic per column per
     // workgroup: 512 workgroups on the same 128 addresses cost 15 us); pair-sized ones write partials that a second kernel sums
+    if (a->N == 64 && a->M >= 65536 && !a->dgamma_rows && (((uintptr_t)a->x | (uintptr_t)a->dy | (uintptr_t)a->dx | (uintptr_t)a->gamma) & 15) == 0) {
+        const int qpw = 16;                                          // 64 rows per wave, 256 per workgroup
+        const unsigned nwg4 = (unsigned)((a->M + 255) / 256);
+        float* part4 = a->dgamma && a->workspace && a->workspace_elems >= (long long)nwg4 * 128 ? a->workspace : nullptr;
+        hipLaunchKernelGGL(layernorm_bwd64_kernel, dim3(nwg4), dim3(256), 0, (hipStream_t)stream, *a, qpw, part4);
+        if (part4) hipLaunchKernelGGL(ln_reduce_kernel, dim3(2, 32), dim3(256), 0, (hipStream_t)stream, part4, (int)nwg4, 64, a->dgamma, a->dbeta);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     const int rpw = a->M >= 65536 ? 16 : a->M >= 1024 ? 4 : 1;
     const unsigned nwg = (unsigned)((a->M + 4 * rpw - 1) / (4 * rpw));
     float* part = a->dgamma && nwg > 256 && a->workspace && a->workspace_elems >= (long long)nwg * 2 * a->N ? a->workspace : nullptr;

@@ -740,10 +740,11 @@ def test_embedding_backward(rows, ncls, dim, ld):
     assert torch.equal(out, out2)                       # deterministic
 
 
-@pytest.mark.parametrize("M,N", [(77, 128), (2048 + 3, 128), (65536 + 21, 64)])
+@pytest.mark.parametrize("M,N", [(77, 128), (2048 + 3, 128), (65536 + 21, 64), (65536 + 3, 128)])
 def test_layernorm_and_relu_backward(M, N):
     """nn.LayerNorm backward with dgamma / dbeta accumulated by the kernel itself: one row per wave (small M), four rows per
-    wave + atomics (row-sized M), sixteen rows per wave + partial sums and a reduce kernel (pair-sized M)."""
+    wave + atomics (row-sized M), the quad-row N = 64 form with partial sums and a reduce kernel (pair-sized M); and the
+    row-scale input (output row mask of the forward)."""
     from pepflowww_amd import backward as Bk
     g = torch.Generator().manual_seed(4)
     x = (torch.randn(M, N, generator=g) * 2 + 0.3).requires_grad_(True)
@@ -752,6 +753,14 @@ def test_layernorm_and_relu_backward(M, N):
     F.layer_norm(x.double(), (N,), gamma.double(), beta.double(), 1e-5).backward(dy.double())
     dx, dg, dbeta = Bk.layernorm_bwd(cu(x.detach()), cu(gamma.detach()), cu(dy))
     G.sync()
+    # the same with the output row mask folded in as a row scale of dy
+    rs = (torch.rand(M, generator=g) > 0.3).float()
+    dx2, dg2, db2 = Bk.layernorm_bwd(cu(x.detach()), cu(gamma.detach()), cu(dy), row_scale=cu(rs))
+    dx3, dg3, db3 = Bk.layernorm_bwd(cu(x.detach()), cu(gamma.detach()), cu(dy * rs[:, None]))
+    G.sync()
+    G.assert_close(dx2, dx3.cpu(), 1e-6, "LN dx (row scale)")
+    G.assert_close(dg2, dg3.cpu(), 2e-5, "LN dgamma (row scale)")
+    G.assert_close(db2, db3.cpu(), 2e-5, "LN dbeta (row scale)")
     G.assert_close(dx, x.grad, 2e-5, "LN dx")
     G.assert_close(dg, gamma.grad, 2e-5, "LN dgamma")
     G.assert_close(dbeta, beta.grad, 2e-5, "LN dbeta")
