@@ -1281,39 +1281,53 @@ __global__ __launch_bounds__(256) void rigid_update_bwd_kernel(pf_rigid_update_b
         for (int k = 0; k < 9; ++k) p.g_rot_in[(size_t)i * 9 + k] = gRo[k];
 }
 
-// EdgeTransition input x_ij = [z_ij | n_i | n_j] (ipa_pytorch.py:236-243) and the pair mask m_i m_j
+// EdgeTransition input x_ij = [z_ij | n_i | n_j] (ipa_pytorch.py:236-243) and the pair mask m_i m_j; one thread per float4
+// (the per-element form spent its time in 64-bit index divisions: 118 us for 268 MB)
 __global__ __launch_bounds__(256) void et_concat_kernel(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long tot = (long long)B * L * L * 192;
-    if (idx >= tot) return;
-    const long long pair = idx / 192;
-    const int c = (int)(idx - pair * 192);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long np = (long long)B * L * L;
+    if (t >= np * 48) return;
+    const long long pair = t / 48;
+    const int q = (int)(t - pair * 48);
     const int b = (int)(pair / ((long long)L * L));
     const int rem = (int)(pair - (long long)b * L * L);
     const int i = rem / L, j = rem - i * L;
-    x[idx] = c < 64 ? z[pair * 64 + c] : (c < 128 ? n[((size_t)b * L + i) * 64 + (c - 64)] : n[((size_t)b * L + j) * 64 + (c - 128)]);
-    if (c == 0 && emask) emask[pair] = mask[b * L + i] * mask[b * L + j];
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* n4 = reinterpret_cast<const float4*>(n);
+    reinterpret_cast<float4*>(x)[t] = q < 16 ? z4[pair * 16 + q] : (q < 32 ? n4[((size_t)b * L + i) * 16 + (q - 16)] : n4[((size_t)b * L + j) * 16 + (q - 32)]);
+    if (q == 0 && emask) emask[pair] = mask[b * L + i] * mask[b * L + j];
 }
-// reverse: g_z = g_x[:, :64] (+= optional), g_n[b,i] = sum_j g_x[(i,j), 64:128] + sum_j' g_x[(j',i), 128:192]; one thread per (b,i,c)
+// reverse: g_z = g_x[:, :64] (+= optional), g_n[b,i] = sum_j g_x[(i,j), 64:128] + sum_j' g_x[(j',i), 128:192]; float4 per thread,
+// the residue sums with 8 loads in flight (one at a time they were a chain of 2 L round trips per thread: 76 us)
 __global__ __launch_bounds__(256) void et_concat_bwd_kernel(const float* gx, float* gz, int accumulate_gz, float* gn, int B, int L) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long npz = (long long)B * L * L * 64;
-    if (idx < npz) {
-        const long long pair = idx >> 6;
-        const int c = (int)(idx & 63);
-        gz[idx] = gx[pair * 192 + c] + (accumulate_gz ? gz[idx] : 0.f);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npz = (long long)B * L * L * 16;
+    const float4* gx4 = reinterpret_cast<const float4*>(gx);
+    if (t < npz) {
+        const long long pair = t >> 4;
+        const int c4 = (int)(t & 15);
+        float4 v = gx4[pair * 48 + c4];
+        if (accumulate_gz) { const float4 o = reinterpret_cast<const float4*>(gz)[t]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        reinterpret_cast<float4*>(gz)[t] = v;
     }
-    const long long nn = (long long)B * L * 64;
-    if (idx < nn) {
-        const int c = (int)(idx & 63);
-        const long long r = idx >> 6;
+    const long long nn = (long long)B * L * 16;
+    if (t < nn) {
+        const int c4 = (int)(t & 15);
+        const long long r = t >> 4;
         const int b = (int)(r / L), i = (int)(r - (long long)b * L);
-        float acc = 0.f;
-        for (int j = 0; j < L; ++j) {
-            acc += gx[(((size_t)b * L + i) * L + j) * 192 + 64 + c];
-            acc += gx[(((size_t)b * L + j) * L + i) * 192 + 128 + c];
+        const float4* rowi = gx4 + (((size_t)b * L + i) * L) * 48 + 16 + c4;       // (i, j) for j = 0..L-1: stride 48
+        const float4* coli = gx4 + (((size_t)b * L) * L + i) * 48 + 32 + c4;       // (j, i): stride 48 L
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        auto add4 = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+        int j = 0;
+        for (; j + 4 <= L; j += 4) {
+            const float4 r0 = rowi[(size_t)j * 48], r1 = rowi[(size_t)(j + 1) * 48], r2 = rowi[(size_t)(j + 2) * 48], r3 = rowi[(size_t)(j + 3) * 48];
+            const float4 c0 = coli[(size_t)j * 48 * L], c1 = coli[(size_t)(j + 1) * 48 * L], c2 = coli[(size_t)(j + 2) * 48 * L], c3 = coli[(size_t)(j + 3) * 48 * L];
+            add4(a0, r0); add4(a1, r1); add4(a2, r2); add4(a3, r3);
+            add4(a0, c0); add4(a1, c1); add4(a2, c2); add4(a3, c3);
         }
-        gn[idx] = acc;
+        for (; j < L; ++j) { add4(a0, rowi[(size_t)j * 48]); add4(a0, coli[(size_t)j * 48 * L]); }
+        reinterpret_cast<float4*>(gn)[t] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
     }
 }
 
@@ -1462,14 +1476,16 @@ extern "C" int pf_edge_distcoef_bwd(const float* g_g, const float* gfeat, const 
 
 extern "C" int pf_et_concat(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L, pf_stream_t stream) {
     if (!z || !n || !mask || !x || B <= 0 || L <= 0) return PF_E_BADARG;
-    const long long tot = (long long)B * L * L * 192;
+    if ((((uintptr_t)z | (uintptr_t)n | (uintptr_t)x) & 15) != 0) return PF_E_BADARG;
+    const long long tot = (long long)B * L * L * 48;                 // float4 per thread
     hipLaunchKernelGGL(et_concat_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, n, mask, x, emask, B, L);
     PF_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int pf_et_concat_bwd(const float* gx, float* gz, int accumulate_gz, float* gn, int B, int L, pf_stream_t stream) {
     if (!gx || !gz || !gn || B <= 0 || L <= 0) return PF_E_BADARG;
-    const long long tot = (long long)B * L * L * 64;
+    if ((((uintptr_t)gx | (uintptr_t)gz | (uintptr_t)gn) & 15) != 0) return PF_E_BADARG;
+    const long long tot = (long long)B * L * L * 16;                 // float4 per thread (the first B L 16 threads also sum a residue)
     hipLaunchKernelGGL(et_concat_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gx, gz, accumulate_gz, gn, B, L);
     PF_CHECK_LAUNCH();
     return 0;
