@@ -1395,6 +1395,42 @@ __global__ __launch_bounds__(256) void embedding_bwd_atomic_kernel(const float* 
     const float v = g[r * ldg + d] * (scale ? scale[r] : 1.f);
     if (v != 0.f) atomicAdd(tg + (size_t)idx[r] * dim + d, v);
 }
+// The same for dim <= 64 with a workgroup-local table: the 128 consecutive rows of a workgroup hit few table rows (pairs in
+// (b, i, j) order: <= 22 pair-type rows, <= 65 relative positions), so they are summed in LDS -- rows [min idx, min idx + 65) -- and
+// flushed once per workgroup; rows outside that window fall back to global atomics.
+constexpr int EB_CHUNK = 128, EB_ROWS = 65;
+__global__ __launch_bounds__(256) void embedding_bwd_lds_kernel(const float* g, int ldg, const int* idx, const float* scale, long long rows,
+                                                                int dim, float* tg) {
+    __shared__ float T[EB_ROWS * 64];
+    __shared__ int ID[EB_CHUNK];
+    __shared__ int lo;
+    const long long r0 = (long long)blockIdx.x * EB_CHUNK;
+    const int nr = (int)min((long long)EB_CHUNK, rows - r0);
+    if (threadIdx.x == 0) lo = 0x7fffffff;
+    for (int k = threadIdx.x; k < EB_ROWS * 64; k += 256) T[k] = 0.f;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nr; k += 256) { const int v = idx[r0 + k]; ID[k] = v; atomicMin(&lo, v); }
+    __syncthreads();
+    const int base = lo;
+    for (int t = threadIdx.x; t < nr * 64; t += 256) {
+        const int rl = t >> 6, d = t & 63;
+        if (d < dim) {
+            const long long r = r0 + rl;
+            const float v = g[r * ldg + d] * (scale ? scale[r] : 1.f);
+            if (v != 0.f) {
+                const int slot = ID[rl] - base;
+                if (slot < EB_ROWS) atomicAdd(&T[slot * 64 + d], v);
+                else atomicAdd(tg + (size_t)ID[rl] * dim + d, v);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < EB_ROWS * 64; k += 256) {
+        const float v = T[k];
+        const int d = k & 63;
+        if (v != 0.f && d < dim) atomicAdd(tg + (size_t)(base + (k >> 6)) * dim + d, v);
+    }
+}
 // dst[p, c] = src[p*lds + off + c] * rowscale[p] * (ref[p*ldr + off_r + c] > 0)
 __global__ __launch_bounds__(256) void slice_relu_mask_kernel(const float* src, int lds_, int off, const float* ref, int ldr, int off_r,
                                                               const float* rowscale, float* dst, long long rows, int width) {
@@ -1475,8 +1511,12 @@ extern "C" int pf_edge_index(const int64_t* aa, const int64_t* res_nb, const int
 extern "C" int pf_embedding_bwd_atomic(const float* g, int ldg, const int* idx, const float* scale, long long rows, int dim, float* table_grad,
                                        pf_stream_t stream) {
     if (!g || !idx || !table_grad || rows <= 0 || dim <= 0) return PF_E_BADARG;
-    hipLaunchKernelGGL(embedding_bwd_atomic_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, idx, scale,
-                       rows, dim, table_grad);
+    if (dim <= 64 && rows >= 4096)
+        hipLaunchKernelGGL(embedding_bwd_lds_kernel, dim3((unsigned)((rows + EB_CHUNK - 1) / EB_CHUNK)), dim3(256), 0, (hipStream_t)stream, g, ldg, idx, scale,
+                           rows, dim, table_grad);
+    else
+        hipLaunchKernelGGL(embedding_bwd_atomic_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, idx, scale,
+                           rows, dim, table_grad);
     PF_CHECK_LAUNCH();
     return 0;
 }

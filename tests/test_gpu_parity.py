@@ -740,6 +740,27 @@ def test_embedding_backward(rows, ncls, dim, ld):
     assert torch.equal(out, out2)                       # deterministic
 
 
+@pytest.mark.parametrize("rows,ncls,spread", [(5000, 484, 22), (8192 + 77, 65, 65), (6000, 484, 484), (300, 65, 65)])
+def test_embedding_backward_atomic(rows, ncls, spread):
+    """pf_embedding_bwd_atomic (pair-sized table gradients with a row scale): the workgroup-local LDS form (index windows of 22 and
+    65 rows as the pair-type / relative-position tables produce them, and a spread wider than the window = global fallback) and the
+    per-element form (few rows), against index_add in float64; accumulates onto existing contents."""
+    from pepflowww_amd import _capi
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(rows + ncls)
+    grad = torch.randn(rows, 224, generator=g)
+    base = torch.randint(0, max(1, ncls - spread + 1), (rows // 128 + 1,), generator=g).repeat_interleave(128)[:rows]
+    idx = (base + torch.randint(0, spread, (rows,), generator=g)).clamp_(max=ncls - 1).to(torch.int32)
+    scale = (torch.rand(rows, generator=g) > 0.2).float()
+    t0 = torch.randn(ncls, 64, generator=g)
+    out = cu(t0.clone())
+    gd, idd, sc = cu(grad), idx.cuda(), cu(scale)
+    _capi.check(lib.pf_embedding_bwd_atomic(gd.data_ptr() + 4 * 64, 224, idd.data_ptr(), sc.data_ptr(), rows, 64, out.data_ptr(), _capi.stream_ptr()), "pf_embedding_bwd_atomic")
+    G.sync()
+    ref = t0.double().index_add_(0, idx.long(), (grad[:, 64:128] * scale[:, None]).double())
+    assert (out.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
 @pytest.mark.parametrize("M,N", [(77, 128), (2048 + 3, 128), (65536 + 21, 64), (65536 + 3, 128)])
 def test_layernorm_and_relu_backward(M, N):
     """nn.LayerNorm backward with dgamma / dbeta accumulated by the kernel itself: one row per wave (small M), four rows per
