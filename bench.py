@@ -7,15 +7,21 @@ what FlowModel.sample does per loop iteration (flow_model.py:287-343).  Inputs (
 weights, state) are resident in HBM when the timed region starts; encode() and the final D2H are
 outside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4]
-For N>1 launch with torch.distributed.run (one rank per GPU).  The path shards over independent
-samples: every rank runs the same per-GPU workload (weak scaling), no data-path collective; one
-RCCL all-gather of the final state closes the run (outside the timed loop, as in sample()).
-Prints ONE JSON line on rank 0.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg5] [--precision fp32|f16]
+Default workload: the 128-residue configuration BASELINE.json's metric / target is quoted on (per-GPU share of
+configs[3]: B=64 x L=128, fp32-parity arithmetic); at N=1 the line also carries a "secondary" entry for
+configs[1] (B=16 x L=64).
+For N>1 either launch with torch.distributed.run (one rank per GPU), or run `python bench.py --gpus N` directly:
+without WORLD_SIZE in the environment it re-executes itself under torch.distributed.run with N ranks on
+127.0.0.1.  The path shards over independent samples: every rank runs the same per-GPU workload (weak scaling),
+no data-path collective; one RCCL all-gather of the final state closes the run (outside the timed loop, as in
+sample()).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
 import sys
 import time
 
@@ -26,9 +32,13 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: B=16 synthetic 64-residue pockets (52 context + 12 generated), fp32
-    "cfg2": dict(B=16, L=64, n_gen=12, name="cfg2: B=16 x 64-residue synthetic pockets (52 ctx + 12 gen) per GPU, fp32"),
-    # BASELINE.json configs[3] per-GPU share: 64 x 128-residue pockets (112 + 16)
-    "cfg4": dict(B=64, L=128, n_gen=16, name="cfg4/GPU: B=64 x 128-residue synthetic pockets (112 ctx + 16 gen) per GPU, fp32"),
+    "cfg2": dict(B=16, L=64, n_gen=12, name="cfg2: B=16 x 64-residue synthetic pockets (52 ctx + 12 gen) per GPU"),
+    # BASELINE.json configs[2]: B=64 test-split-like pockets of VARIABLE length (receptor pocket 45..120 residues +
+    # peptide 3..25, pep_dataloader.py:53-54), padded to the longest; the real PepMerge split is not in the image
+    "cfg3": dict(B=64, L=None, n_gen=None, variable=True,
+                 name="cfg3: B=64 variable-length synthetic pockets (pocket 45-120 + peptide 3-25 residues, padded to the longest) per GPU"),
+    # BASELINE.json configs[3] per-GPU share: 64 x 128-residue pockets (112 + 16)  <- the configuration the metric is quoted on
+    "cfg4": dict(B=64, L=128, n_gen=16, name="cfg4/GPU: B=64 x 128-residue synthetic pockets (112 ctx + 16 gen) per GPU"),
     # BASELINE.json configs[4] per-GPU share: train_ddp-equivalent step (forward + 6 losses + backward [+ gradient all-reduce])
     "cfg5": dict(B=16, L=128, n_gen=16, name="cfg5/GPU: training step on B=16 x 128-residue synthetic pockets per GPU, fp32", train=True),
 }
@@ -36,62 +46,84 @@ TRAIN_FLOPS_PER_RES = 3 * 129.2e6   # forward 129.2 MFLOP per residue at L=128 (
 HBM_PEAK = 8.0e12            # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 MFMA_F32_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
 MFMA_F16_PEAK = 2.5e15       # FLOP/s dense f16/bf16 MFMA (MI355X_MICROARCH.md; 2:1-sparse marketing figure excluded)
-# EdgeTransition runs split-precision: every fp32 product = 3 f16 MFMA products (hi*hi, hi*lo, lo*hi), so the
-# ceiling for fp32-equivalent FLOPs on this kernel is the dense f16 peak / 3.
-ET_SPLIT = 3
+# fp32-parity mode: every fp32 product = 3 f16 MFMA products (hi*hi, hi*lo, lo*hi), so the ceiling for fp32-equivalent
+# FLOPs is the dense f16 peak / 3.  f16 mode: one MFMA product per product.
 ET_FLOPS_EXEC = 2 * (64 * 192 + 192 * 192 + 192 * 64 + 64 * 64)   # per pair, as executed (per-residue terms hoisted)
 ET_FLOPS_REF = 2 * (2 * 192 * 192 + 192 * 64)                      # per pair, SURVEY.md 8(d) (reference formulation)
 ET_BYTES = 512                                                       # per pair: read z + write z', fp32
+IPA_BYTES = 256                                                      # per pair: one read of z, fp32
+DTYPE = {"fp32": "f32 (fp32 storage and accumulation; matrix products as 3 x f16 split MFMA, ~22-bit operands)",
+         "f16": "f16 (single-pass f16 MFMA products, fp32 accumulation, fp32 geometry and pair storage)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    args = ap.parse_args()
+def variable_lengths(B, seed=114514):
+    """cfg3: per-sample true lengths = pocket U{45..120} + peptide U{3..25} (pep_dataloader.py:53-54)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pep = rng.integers(3, 26, size=B)
+    poc = rng.integers(45, 121, size=B)
+    return [int(a + b) for a, b in zip(poc, pep)], [int(p) for p in pep]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    if os.environ.get("PF_BENCH_SHARE_GPU"):              # test hook: several ranks on one GPU (single-GPU dev boxes)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")       # "nccl" = RCCL over xGMI on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def make_batch(wl, first):
+    from pepflowww_amd import synth
+    if wl.get("variable"):
+        lens, peps = variable_lengths(wl["B"], seed=114514 + first)
+        L = max(lens)
+        items = [synth.make_pocket_batch(1, L, peps[i], seed=114514 + first + i, lengths=[lens[i]]) for i in range(wl["B"])]
+        batch = {k: torch.cat([it[k] for it in items], 0) for k in items[0]}
+        return batch, wl["B"], L, sum(lens)
+    batch = synth.make_pocket_batch(wl["B"], wl["L"], wl["n_gen"], seed=114514 + first)
+    return batch, wl["B"], wl["L"], wl["B"] * wl["L"]
+
+
+def check_final_state(smp, batch, K_total):
+    """The state that was just timed must be a valid sample: finite, rotations in SO(3), angles wrapped, context pinned."""
+    eng = smp.eng
+    B, L = eng.B, eng.L
+    last = K_total - 1
+    R = smp.traj_rot[last].view(B, L, 3, 3)
+    x = smp.traj_trans[last].view(B, L, 3)
+    ang = smp.traj_ang[last].view(B, L, 5)
+    seq = smp.traj_seq[last].view(B, L)
+    ok = batch["res_mask"].to(R.device)
+    assert torch.isfinite(R[ok]).all() and torch.isfinite(x[ok]).all() and torch.isfinite(ang[ok]).all(), "non-finite state"
+    eye = torch.eye(3, device=R.device)
+    orth = (R[ok] @ R[ok].transpose(-1, -2) - eye).abs().max().item()
+    det = (torch.linalg.det(R[ok]) - 1).abs().max().item()
+    assert orth < 1e-3 and det < 1e-3, ("rotations left SO(3)", orth, det)
+    assert (ang[ok] >= 0).all() and (ang[ok] < 2 * math.pi + 1e-5).all(), "angles not wrapped"
+    gen = batch["generate_mask"].to(R.device) & ok
+    assert ((seq[gen] >= 0) & (seq[gen] < 20)).all(), "sequence out of range"
+    ctx = ok & ~batch["generate_mask"].to(R.device)
+    assert torch.equal(seq[ctx], batch["aa"].to(R.device)[ctx]), "context sequence moved"
+    return {"orthogonality_err": orth, "det_err": det}
+
+
+def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_kernels=True):
+    """W warm-up + K timed steps of the sampler on this rank's shard; returns (elapsed_s_max_over_ranks, info)."""
     import pepflowww_amd
     from pepflowww_amd import synth, _capi
     from pepflowww_amd.sampler import DeviceSampler
-    _capi.load()
-
-    wl = WORKLOADS[args.workload]
-    B, L = wl["B"], wl["L"]
-    K, W = args.steps, args.warmup
     NS = K + W
-    if wl.get("train"):
-        return bench_train(args, wl, dev, dist, rank, world)
     sd = synth.seeded_state_dict()
     model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
     model.load_state_dict(sd)
     model = model.to(dev).eval()
-    first = rank * B                                                 # contiguous batch shards, global sample ids
-    batch = synth.make_pocket_batch(B, L, wl["n_gen"], seed=114514 + first)
+    if precision != "fp32":
+        model.ga_encoder.set_precision(precision)
+    first = rank * wl["B"]                                           # contiguous batch shards, global sample ids
+    batch, B, L, n_real = make_batch(wl, first)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
-
+    info = {"B": B, "L": L, "real_residues": n_real, "sd": sd, "batch": batch}
     with torch.no_grad():
         R1, x1, ang1, seq1, node, edge = model.encode(dbatch)
         eng = model.ga_encoder.engine(B, L, dev)
@@ -101,7 +133,6 @@ def main():
         noise = {k: v for k, v in synth.make_noise(B, L, 1, seed=7, first_sample=first).items() if k != "expo"}
         eng.run()                                                    # eager warm-up (outside capture)
         smp.init_state(noise)
-        use_graph = not args.no_graph
         smp.run(W, use_graph=use_graph)                              # W untimed warm-up steps
         torch.cuda.synchronize()
         if dist is not None:
@@ -121,67 +152,159 @@ def main():
             # closing all-gather of the final state (one collective per sample() call)
             from pepflowww_amd.distributed import all_gather_final_state
             all_gather_final_state(smp)
+        info["validity"] = check_final_state(smp, batch, NS)
+        info["launches_per_step"] = eng.n_launches + 1
 
-        # ---- per-kernel timing of the dominant kernel (EdgeTransition) with HIP events on the launch stream ----
-        et_ms = []
-        evs = []
-        st = _capi.stream_ptr()
-        for _ in range(min(K, 10)):
-            for entry in eng.plan:
-                fn, a, name = entry[0], entry[1], entry[2]
-                if fn is None:
-                    continue
-                if name == "pf_edge_transition_fwd":
+        # ---- per-kernel timing with HIP events on the launch stream (10 eager steps of the plan) ----
+        if time_kernels:
+            evs = {}
+            st = _capi.stream_ptr()
+            for _ in range(min(K, 10)):
+                for entry in eng.plan:
+                    fn, a, name = entry[0], entry[1], entry[2]
+                    if fn is None:
+                        continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    rc = fn(a, st)
-                    e1.record()
-                    evs.append((e0, e1))
-                else:
                     rc = fn(*a, st) if isinstance(a, tuple) else fn(a, st)
-                assert rc == 0, name
-        torch.cuda.synchronize()
-        et_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
-    et_avg_s = sum(et_ms) / len(et_ms) * 1e-3
-    pairs = B * L * L
+                    e1.record()
+                    evs.setdefault(name, []).append((e0, e1))
+                    assert rc == 0, name
+            torch.cuda.synchronize()
+            n_it = min(K, 10)
+            info["kernel_us"] = {k: {"avg_launch_us": sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e3,
+                                     "launches_per_step": len(v) // n_it,
+                                     "us_per_step": sum(a.elapsed_time(b) for a, b in v) / n_it * 1e3} for k, v in evs.items()}
+    return elapsed, info
 
-    # HBM traffic of the dominant kernel from the PMC passes recorded under profiles/ (rocprofv3 cannot run inside
-    # this process); per launch, corrected as MI355X_MICROARCH.md prescribes.  None if no record for this workload.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-            traffic = json.load(f)[args.workload]["edge_transition_v3_kernel"]["hbm_bytes_corrected"]
-    except Exception:
-        pass
+
+def pmc_traffic(workload, precision):
+    """HBM bytes per launch of the two big kernels from the PMC passes recorded under profiles/ (rocprofv3 cannot run
+    inside this process; tools/pmc_traffic.sh regenerates the file); corrected as MI355X_MICROARCH.md prescribes."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
+                d = json.load(f)
+            key = workload if precision == "fp32" else f"{workload}_{precision}"
+            return d[key], f"profiles/{rnd}/pmc_traffic.json ({d.get('_commit', 'commit not recorded')})"
+        except Exception:
+            continue
+    return {}, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched the way the driver may launch it (`python bench.py --gpus N`): become N ranks, one per GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, cmd)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("PF_BENCH_SHARE_GPU"):              # test hook: several ranks on one GPU (single-GPU dev boxes)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")       # "nccl" = RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    from pepflowww_amd import _capi
+    _capi.load()
+
+    wl = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+    if wl.get("train"):
+        return bench_train(args, wl, dev, dist, rank, world)
+    use_graph = not args.no_graph
+    prec = args.precision
+    elapsed, info = run_sampler(wl, K, W, dev, dist, rank, world, use_graph, prec)
+    B, L = info["B"], info["L"]
+    pairs = B * L * L
+    split = 3 if prec == "fp32" else 1
 
     ms_per_step = elapsed / K * 1e3
     value = world * B * L * K / elapsed
     per_gpu = value / world
+    ku = info["kernel_us"]
+    et_s = ku["pf_edge_transition_fwd"]["avg_launch_us"] * 1e-6
+    ipa_s = ku["pf_ipa_attn_fwd"]["avg_launch_us"] * 1e-6
+    traffic, traffic_src = pmc_traffic(args.workload, prec)
+    t_et = (traffic.get("edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
+    t_ipa = (traffic.get("ipa_attn_kernel") or traffic.get("ipa_flash_kernel") or {}).get("hbm_bytes_corrected")
+    step_us = sum(v["us_per_step"] for v in ku.values())
+    share = {k: round(v["us_per_step"] / step_us, 3) for k, v in sorted(ku.items(), key=lambda kv: -kv[1]["us_per_step"])}
+    dominant = next(iter(share))
+    rf_et = {
+        "kernel": "edge_transition_v3_kernel (pf_edge_transition_fwd)", "bound": "mfma",
+        "achieved": pairs * ET_FLOPS_EXEC / et_s / 1e12, "peak": MFMA_F16_PEAK / split / 1e12, "unit": "TFLOP/s",
+        "frac": pairs * ET_FLOPS_EXEC * split / et_s / MFMA_F16_PEAK, "traffic": t_et,
+        "traffic_note": f"HBM bytes per launch from {traffic_src} (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair = {pairs * ET_BYTES} B",
+        "note": ("fp32-equivalent FLOPs; 3 f16 MFMA products per fp32 product (split precision), peak = 2.5 PF/3" if split == 3
+                 else "one f16 MFMA product per product, peak = 2.5 PF dense"),
+        "avg_launch_us": et_s * 1e6, "flops_per_pair_executed": ET_FLOPS_EXEC, "share_of_step": share.get("pf_edge_transition_fwd"),
+        "achieved_reference_flops": pairs * ET_FLOPS_REF / et_s / 1e12,
+        "hbm_achieved_GBps": pairs * ET_BYTES / et_s / 1e9,
+    }
+    rf_ipa = {
+        "kernel": "ipa attention (pf_ipa_attn_fwd)", "bound": "hbm",
+        "achieved": pairs * IPA_BYTES / ipa_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": pairs * IPA_BYTES / ipa_s / HBM_PEAK, "traffic": t_ipa,
+        "traffic_note": f"HBM bytes per launch from {traffic_src}; algorithmic = 256 B/pair (one read of z, SURVEY.md 8(d)) = {pairs * IPA_BYTES} B",
+        "avg_launch_us": ipa_s * 1e6, "share_of_step": share.get("pf_ipa_attn_fwd"),
+    }
     out = {
         "metric": "residues x denoise-steps / s",
         "value": value, "unit": "res*step/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded random pockets, seeded random-init weights)",
+        "dtype": DTYPE[prec], "data": "synthetic (seeded random pockets, seeded random-init weights)",
         "config": {"workload": wl["name"], "per_gpu_batch": B, "residues": L, "global_batch": world * B,
-                   "parallelism": f"batch-shard x{world}", "hipgraph": use_graph, "launches_per_step": eng.n_launches + 2},
-        "roofline": {
-            "kernel": "edge_transition_v3_kernel", "bound": "mfma",
-            "achieved": pairs * ET_FLOPS_EXEC / et_avg_s / 1e12, "peak": MFMA_F16_PEAK / ET_SPLIT / 1e12, "unit": "TFLOP/s",
-            "frac": pairs * ET_FLOPS_EXEC * ET_SPLIT / et_avg_s / MFMA_F16_PEAK, "traffic": traffic,
-            "traffic_note": "HBM bytes per launch from profiles/r01/pmc_traffic.json (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair",
-            "note": "fp32-equivalent FLOPs; 3 f16 MFMA products per fp32 product (split precision), peak = 2.5 PF/3",
-            "vs_fp32_mfma_peak": pairs * ET_FLOPS_EXEC / et_avg_s / MFMA_F32_PEAK,
-            "avg_launch_us": et_avg_s * 1e6, "flops_per_pair_executed": ET_FLOPS_EXEC,
-            "achieved_reference_flops": pairs * ET_FLOPS_REF / et_avg_s / 1e12,
-            "hbm_achieved_GBps": pairs * ET_BYTES / et_avg_s / 1e9,
-        },
+                   "parallelism": f"batch-shard x{world}", "hipgraph": use_graph, "launches_per_step": info["launches_per_step"],
+                   "precision": prec},
+        # dominant kernel of THIS workload first; the HBM-bound attention kernel beside it
+        "roofline": rf_et if dominant != "pf_ipa_attn_fwd" else rf_ipa,
+        "roofline_other": rf_ipa if dominant != "pf_ipa_attn_fwd" else rf_et,
+        "kernel_share_of_step": share,
         # whole-step view against the HBM roofline of BASELINE.md section 4 (4096*L algorithmic bytes per residue-step)
         "hbm_roofline": {"bytes_per_res_step": 4096 * L, "achieved_GBps": per_gpu * 4096 * L / 1e9,
                          "peak_GBps": HBM_PEAK / 1e9, "frac": per_gpu * 4096 * L / HBM_PEAK},
+        "final_state_check": info["validity"],
     }
+    if wl.get("variable"):
+        out["config"]["real_residues_per_gpu"] = info["real_residues"]
+        out["value_real_residues"] = world * info["real_residues"] * K / elapsed
+        out["value_note"] = "value counts padded residues (B x L_max, what the kernels process); value_real_residues counts unpadded ones"
 
+    if world == 1 and not args.no_secondary and args.workload != "cfg2":
+        e2, i2 = run_sampler(WORKLOADS["cfg2"], K, W, dev, None, 0, 1, use_graph, prec, time_kernels=True)
+        k2 = i2["kernel_us"]
+        out["secondary"] = {"workload": WORKLOADS["cfg2"]["name"], "value": 16 * 64 * K / e2, "unit": "res*step/s",
+                            "ms_per_step": e2 / K * 1e3, "steps": K,
+                            "hbm_roofline_frac": 16 * 64 * K / e2 * 4096 * 64 / HBM_PEAK,
+                            "kernel_us_per_step": {k: round(v["us_per_step"], 1) for k, v in k2.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sd, batch, B, L)
+        out["cpu_baseline"] = cpu_baseline(info["sd"], info["batch"], B, L)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -190,7 +313,7 @@ def main():
 
 def bench_train(args, wl, dev, dist, rank, world):
     """cfg5: one training step = model(batch) -> weighted loss -> backward (HIP backward kernels) -> for N > 1 one flat
-    gradient all-reduce (RCCL).  Correctness-first backward (fp32 GEMM building blocks): reported as measured."""
+    gradient all-reduce (RCCL)."""
     import pepflowww_amd
     from pepflowww_amd import synth
     from pepflowww_amd.distributed import allreduce_gradients
@@ -237,15 +360,23 @@ def bench_train(args, wl, dev, dist, rank, world):
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    grads = [p.grad for p in model.parameters() if p.grad is not None] if graphed is None else list(graphed.grads.values())
+    assert grads and all(torch.isfinite(g).all() for g in grads), "non-finite gradients in the timed step"
     value = world * B * L * K / elapsed
+    # the step's matrix products run as 3 x f16 split MFMA (pair-sized) and exact fp32 MFMA (row-sized): the ceiling of the
+    # dominant (pair-sized) part is the dense f16 peak / 3, the same ceiling as the inference line
+    peak = MFMA_F16_PEAK / 3
     out = {"metric": "residues x training-steps / s (forward + 6 losses + backward + gradient all-reduce)", "value": value,
            "unit": "res*step/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random pockets, seeded random-init weights)",
+           "scaling": "weak", "vs_baseline": None, "dtype": DTYPE["fp32"], "data": "synthetic (seeded random pockets, seeded random-init weights)",
            "config": {"workload": wl["name"], "per_gpu_batch": B, "residues": L, "global_batch": world * B,
                       "parallelism": f"data-parallel x{world}, one flat gradient all-reduce (27.5 MB)"},
            "roofline": {"kernel": "whole training step", "bound": "mfma", "achieved": value / world * TRAIN_FLOPS_PER_RES / 1e12,
-                        "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": value / world * TRAIN_FLOPS_PER_RES / MFMA_F32_PEAK,
-                        "traffic": None, "note": "correctness-first fp32 backward; flops = 3 x forward (SURVEY.md 8(d))"}}
+                        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": value / world * TRAIN_FLOPS_PER_RES / peak,
+                        "traffic": None,
+                        "note": "fp32-equivalent flops = 3 x forward (SURVEY.md 8(d)); ceiling = dense f16 MFMA peak / 3 (split-precision products), "
+                                "the same ceiling as the inference line; vs the exact-fp32 MFMA peak (157.3 TF) the fraction is "
+                                f"{value / world * TRAIN_FLOPS_PER_RES / MFMA_F32_PEAK:.3f}"}}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -254,20 +385,23 @@ def bench_train(args, wl, dev, dist, rank, world):
 
 def cpu_baseline(sd, batch, B, L):
     """The CPU oracle (kind 'port': restatement of the reference's PyTorch-CPU path, pinned to the reference by
-    tests/golden) timed on this box's host cores on a bounded sample of the same workload."""
+    tests/golden) timed on this box's host cores on a bounded sample of the same workload: the first `nb` samples of
+    the batch (samples are independent; the cost per residue-step depends on L, not on B), 2 sampler steps."""
     from oracle import pepflow_oracle as O
-    threads = torch.get_num_threads()
-    noise_steps = 4
     from pepflowww_amd import synth
-    noise = synth.make_noise(B, L, noise_steps, seed=7)
+    threads = torch.get_num_threads()
+    nb = min(B, max(1, 2048 // L))                                   # ~2048 residues per step
+    sub = {k: v[:nb] for k, v in batch.items()}
+    noise_steps = 2 if L > 64 else 4
+    noise = synth.make_noise(nb, L, noise_steps, seed=7)
     with torch.no_grad():
-        enc = O.encode(sd, batch)
-        O.sample(sd, batch, noise, 1, encoded=enc)                   # warm-up
+        enc = O.encode(sd, sub)
+        O.sample(sd, sub, noise, 1, encoded=enc)                     # warm-up
         t0 = time.perf_counter()
-        O.sample(sd, batch, noise, noise_steps, encoded=enc)
+        O.sample(sd, sub, noise, noise_steps, encoded=enc)
         dt = time.perf_counter() - t0
-    return {"value": B * L * noise_steps / dt, "unit": "res*step/s", "cores": threads, "kind": "port",
-            "sample": f"{noise_steps} sampler steps of the same B={B}, L={L} batch (oracle/pepflow_oracle.py, torch CPU fp32)",
+    return {"value": nb * L * noise_steps / dt, "unit": "res*step/s", "cores": threads, "kind": "port",
+            "sample": f"{noise_steps} sampler steps of the first {nb} samples of the same batch (L={L}; oracle/pepflow_oracle.py, torch CPU fp32)",
             "seconds": dt}
 
 

@@ -25,11 +25,22 @@ def shard_bounds(total, world, rank):
 
 
 def shard_batch(batch, world, rank):
+    """Slice a PaddingCollate batch (pepflow/utils/data.py:63-78) along the SAMPLE axis.
+    Tensors carry the sample on dim 0.  Collated lists come in two shapes: per-sample lists (`id`: B entries) and
+    per-residue lists of per-sample tuples (`chain_id`, `icode`: L entries, each a tuple of B strings) -- the latter are
+    sliced inside every tuple, never along the residue axis (which a plain `len(v) == B` test does whenever L == B)."""
     total = batch["aa"].shape[0]
     lo, hi = shard_bounds(total, world, rank)
     out = {}
     for k, v in batch.items():
-        out[k] = v[lo:hi] if isinstance(v, (torch.Tensor, list)) and len(v) == total else v
+        if isinstance(v, torch.Tensor):
+            out[k] = v[lo:hi] if v.dim() > 0 and v.shape[0] == total else v
+        elif isinstance(v, (list, tuple)) and len(v) > 0 and all(isinstance(e, (list, tuple)) and len(e) == total for e in v):
+            out[k] = [type(e)(e[lo:hi]) for e in v]
+        elif isinstance(v, (list, tuple)) and len(v) == total:
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v
     return out, lo, hi
 
 
@@ -58,42 +69,75 @@ def unpack_state(buf):
 
 
 def all_gather_packed(local, sizes, group=None):
-    """all-gather of per-rank [b_r, L, 38] buffers (ragged in b_r) into [sum b_r, L, 38]."""
+    """all-gather of per-rank [b_r, L, 38] buffers (ragged in b_r, b_r = 0 allowed) into [sum b_r, L, 38]."""
     world = dist.get_world_size(group)
-    bmax = max(sizes)
+    bmax = max(max(sizes), 1)
     pad = local
     if local.shape[0] < bmax:
         pad = torch.cat([local, local.new_zeros(bmax - local.shape[0], *local.shape[1:])], 0)
-    out = local.new_empty(world * bmax, *local.shape[1:])
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    pad = pad.contiguous()
+    if pad.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather (single-GPU dev boxes run the world-size-2 tests on it): staged through the host
+        out = pad.new_empty(world * bmax, *pad.shape[1:], device="cpu")
+        dist.all_gather_into_tensor(out, pad.cpu(), group=group)
+        out = out.to(pad.device)
+    else:
+        out = pad.new_empty(world * bmax, *pad.shape[1:])
+        dist.all_gather_into_tensor(out, pad, group=group)
     chunks = [out[r * bmax: r * bmax + sizes[r]] for r in range(world)]
     return torch.cat(chunks, 0)
 
 
 def all_gather_final_state(sampler, group=None):
     """Gather the last trajectory slot of a DeviceSampler from every rank (device tensors, RCCL)."""
-    eng = sampler.eng
-    B, L, last = eng.B, eng.L, sampler.N - 1
-    local = pack_state({"rotmats": sampler.traj_rot[last].view(B, L, 9), "trans": sampler.traj_trans[last].view(B, L, 3),
-                        "angles": sampler.traj_ang[last].view(B, L, 5), "seqs_simplex": sampler.traj_simplex[last].view(B, L, 20),
-                        "seqs": sampler.traj_seq[last].view(B, L)})
+    local = _final_state_of(sampler)
     world = dist.get_world_size(group)
     sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
-    sizes_t[dist.get_rank(group)] = B
+    sizes_t[dist.get_rank(group)] = local.shape[0]
     dist.all_reduce(sizes_t, group=group)
     return unpack_state(all_gather_packed(local, [int(s) for s in sizes_t.tolist()], group))
+
+
+def seeded_noise(lo, hi, L, seed):
+    """Initial noise of the GLOBAL samples [lo, hi) as a pure function of (seed, global sample index): one torch CPU
+    generator per sample, so a shard draws exactly the rows the unsharded run draws, for every world size."""
+    from .sampler import default_noise
+    parts = []
+    for i in range(lo, hi):
+        g = torch.Generator().manual_seed((int(seed) * 1000003 + i) % (2 ** 63 - 1))
+        parts.append(default_noise(1, L, generator=g))
+    if not parts:
+        z = default_noise(1, L, generator=torch.Generator().manual_seed(0))
+        return {k: v[:0] for k, v in z.items()}
+    return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+
+
+def _final_state_of(smp):
+    eng = smp.eng
+    B, L, last = eng.B, eng.L, smp.N - 1
+    return pack_state({"rotmats": smp.traj_rot[last].view(B, L, 9), "trans": smp.traj_trans[last].view(B, L, 3),
+                       "angles": smp.traj_ang[last].view(B, L, 5), "seqs_simplex": smp.traj_simplex[last].view(B, L, 20),
+                       "seqs": smp.traj_seq[last].view(B, L)})
 
 
 @torch.no_grad()
 def sample_sharded(model, batch, num_steps=100, *, noise=None, seed=0, group=None, **kw):
     """FlowModel.sample over a batch sharded across the process group; returns the gathered FINAL state
-    (dict of [B_total, L, ...] device tensors) on every rank."""
+    (dict of [B_total, L, ...] device tensors) on every rank.
+    noise=None: the initial noise is drawn per GLOBAL sample index from `seed` (seeded_noise), so the result does not
+    depend on the world size and equals `model.sample(batch, noise=None, seed=seed)` on one device.  A rank whose shard is
+    empty (B_total < world) skips sampling and contributes zero rows to the all-gather."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    total = batch["aa"].shape[0]
+    total, L = batch["aa"].shape[0], batch["aa"].shape[1]
     local, lo, hi = shard_batch(batch, world, rank)
-    nz = shard_noise(noise, lo, hi) if noise is not None else None
-    smp = model.sample(local, num_steps, noise=nz, seed=seed, first_sample=lo, return_sampler=True, **kw)
-    return all_gather_final_state(smp, group)
+    nz = shard_noise(noise, lo, hi) if noise is not None else seeded_noise(lo, hi, L, seed)
+    sizes = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
+    if hi > lo:
+        smp = model.sample(local, num_steps, noise=nz, seed=seed, first_sample=lo, return_sampler=True, **kw)
+        packed = _final_state_of(smp)
+    else:
+        packed = torch.zeros(0, L, PACK_WIDTH, dtype=torch.float32, device=batch["aa"].device)
+    return unpack_state(all_gather_packed(packed, sizes, group))
 
 
 def allreduce_flat(flat, dist=None):

@@ -83,8 +83,7 @@ def encode(model, batch, save=None):
         save.update(feat=feat, n_h0=h0, n_h1=h1, n_h2=h2, mres=mres, ctx=ctx, aa=aa_c, res_nb=res_nb, chain_nb=chain_nb,
                     sample_structure=na.sample_structure, sample_sequence=na.sample_sequence)
     _capi.check(lib.pf_edge_features_fwd(C.byref(ea), _capi.stream_ptr()), "pf_edge_features_fwd")
-    if not torch.cuda.is_current_stream_capturing():
-        torch.cuda.current_stream().synchronize()  # temporaries above must outlive the launches (inside a graph capture
-        #                                            they live in the graph's private pool for the graph's lifetime)
+    # (no host sync: every launch above is on torch's CURRENT stream and the caching allocator is stream-ordered for
+    #  tensors used on the stream that allocated them, so the temporaries cannot be recycled under the kernels)
     return (rot1.view(B, L, 3, 3), trans1.view(B, L, 3), _f32(batch["torsion_angle"]), aa_c,
             node.view(B, L, 128), edge)

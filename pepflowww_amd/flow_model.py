@@ -67,7 +67,8 @@ class FlowModel(nn.Module):
                noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False):
         """Reference signature + keyword-only extensions:
         noise        dict(rot0, trans0, ang0, simplex0[, expo]) of pre-drawn noise (parity tests);
-        seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator);
+        seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator); with noise=None an
+                     explicit seed also keys the initial noise per GLOBAL sample index (distributed.seeded_noise);
         first_sample global index of this shard's first sample (world-size independent RNG streams);
         use_graph    replay one captured hipGraph per step (default) or launch eagerly."""
         _capi.load()
@@ -76,12 +77,16 @@ class FlowModel(nn.Module):
         R1, x1, ang1, seq1, node, edge = self.encode(batch)
         eng = self.ga_encoder.engine(B, L, dev)
         eng.bind_context(node, edge, batch["res_mask"])
+        if noise is None:
+            if seed is None:
+                noise = default_noise(B, L)           # torch's global CPU generator, like the reference (flow_model.py:252-277)
+            else:                                      # explicit seed: per-global-sample streams (shard == slice of the full run)
+                from .distributed import seeded_noise
+                noise = seeded_noise(first_sample, first_sample + B, L, seed)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         smp = DeviceSampler(eng, num_steps, (sample_bb, sample_ang, sample_seq), first_sample, seed)
         smp.set_context(R1, x1, ang1, seq1, batch["generate_mask"])
-        if noise is None:
-            noise = default_noise(B, L)
         # eager warm-up of the network plan (kernel attribute setup happens outside graph capture)
         eng.run()
         smp.init_state(noise)

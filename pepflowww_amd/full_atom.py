@@ -48,7 +48,6 @@ def full_atom_reconstruction(R_bb, t_bb, angles, aa):
     Rf, tf = torch.empty(B, N, 6, 3, 3, device=dev), torch.empty(B, N, 6, 3, device=dev)
     a.pos14, a.frames_rot, a.frames_trans = pos14.data_ptr(), Rf.data_ptr(), tf.data_ptr()
     _capi.check(_capi.load().pf_full_atom_fwd(C.byref(a), _capi.stream_ptr()), "pf_full_atom_fwd")
-    torch.cuda.current_stream().synchronize()
     return pos14, Rf, tf
 
 
@@ -67,5 +66,4 @@ def reconstruct_sample(rotmats, trans, angles, seqs, generate_mask, pos_heavyato
     pos, mask = torch.empty(B, N, 15, 3, device=dev), torch.empty(B, N, 15, dtype=torch.uint8, device=dev)
     a.gen_mask, a.ctx_pos15, a.pos15_merged, a.mask15 = gen.data_ptr(), ctx.data_ptr(), pos.data_ptr(), mask.data_ptr()
     _capi.check(_capi.load().pf_full_atom_fwd(C.byref(a), _capi.stream_ptr()), "pf_full_atom_fwd")
-    torch.cuda.current_stream().synchronize()
     return pos, mask.bool()

@@ -183,8 +183,9 @@ class GAEncoder(nn.Module):
     def forward(self, t, rotmats_t, trans_t, angles_t, seqs_t, node_embed, edge_embed, generate_mask, res_mask):
         """Same positional signature as the reference (ga.py:87); generate_mask is unused there too."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise _capi.PepflowHipError("backward kernels are not built yet (SURVEY.md 8(f) rank 1): "
-                                        "run the denoise step under torch.no_grad()")
+            raise _capi.PepflowHipError("GAEncoder.forward called stand-alone carries no autograd graph: training goes through "
+                                        "FlowModel.forward (model(batch) -> six losses; pepflowww_amd/train_step.py holds the HIP "
+                                        "backward).  Call the denoise step under torch.no_grad() or in eval() mode")
         B, L = seqs_t.shape
         _capi.dptr(node_embed.contiguous(), name="node_embed")
         eng = self.engine(B, L, node_embed.device)

@@ -94,7 +94,7 @@ class GraphedTrainStep:
     with the GPU idle in between.  The graph removes the launch path: per step the host only refreshes the static
     input buffers (batch, noise, seed) and calls replay().  Parameters are read in place (fp32, contiguous), so an
     optimizer that updates them in place between replays is seen by the next replay; gradients land in static
-    tensors that are bound to `param.grad` once.
+    tensors that are (re-)bound to `param.grad` after every replay.
 
         step = GraphedTrainStep(model, batch, loss_weights)       # captures (same B, L for every later batch)
         losses = step(batch, noise=None)                          # replay; model.parameters() have .grad set
@@ -148,6 +148,10 @@ class GraphedTrainStep:
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=self.generator).item())
         self.seed.fill_(seed)
         self.graph.replay()
+        # optimizer.zero_grad() defaults to set_to_none=True: re-bind the static gradient tensors after every replay so that
+        # optimizer.step() / clip_grad_norm_ always see what the graph just wrote
+        for n, p in self.model.named_parameters():
+            p.grad = self.grads.get(n)
         return {k: self.losses[i] for i, k in enumerate(LOSS_KEYS)}
 
     def allreduce(self, dist=None):
