@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 28
+#define PF_ABI_VERSION 29
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -531,6 +531,22 @@ typedef struct {
     int rows;
 } pf_full_atom_args;
 int pf_full_atom_fwd(const pf_full_atom_args* a, pf_stream_t stream);
+
+/* ---- backbone-only reconstruction: reconstruct_backbone, pepflow/modules/common/geometry.py:446-489 (N, CA, C from the
+ * frame and the residue type's idealised coordinates, O from the psi frame with psi = dihedral(N_i, CA_i, C_i, N_{i+1}),
+ * 0 at C-termini per topology.py:5-25) and the merge of models_con/sample.py:77-82 (save_samples_bb).
+ * tab_bb [21,3,3], tab_o [21,3]: constants.py:878-887.  pos4 / the merged outputs may be NULL (not both). */
+typedef struct {
+    const float* rot; const float* trans;   /* [B*L,9], [B*L,3] */
+    const int64_t* aa; const int64_t* chain_nb; const int64_t* res_nb;   /* [B*L] */
+    const unsigned char* mask;              /* [B*L] res_mask */
+    const float* tab_bb; const float* tab_o;
+    float* pos4;                            /* [B*L,4,3]  N, CA, C, O */
+    const float* gen_mask; const float* ctx_pos15; const unsigned char* ctx_mask15;
+    float* pos15_merged; unsigned char* mask15;   /* where(generate, pad15(pos4) / first-4 mask, context) */
+    int B, L;
+} pf_backbone_atoms_args;
+int pf_backbone_atoms_fwd(const pf_backbone_atoms_args* a, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -660,3 +660,18 @@ def full_atom(R_bb, t_bb, angles, aa, tab):
     ta = torch.gather(t_all, 2, grp[..., None].expand(*grp.shape, 3))
     pos14 = (Ra @ tab["atom14_position"][aa][..., None])[..., 0] + ta
     return pos14, torch.stack(Rs, 2), torch.stack(ts, 2)
+
+
+def reconstruct_backbone(R, t, aa, chain_nb, res_nb, mask, tab):
+    """pepflow/modules/common/geometry.py:446-489 with get_backbone_dihedral_angles (352-390) and get_terminus_flag
+    (topology.py:5-25).  tab: dict(bb_coords [21,3,3], bb_oxygen [21,3]).  -> [N, L, 4, 3] (N, CA, C, O)."""
+    aa = aa.clamp(0, 20)
+    bb = torch.einsum("nlij,nlaj->nlai", R, tab["bb_coords"][aa]) + t[:, :, None, :]
+    consec = ((res_nb[:, 1:] - res_nb[:, :-1]).abs() == 1) & (chain_nb[:, 1:] == chain_nb[:, :-1]) & mask[:, :-1]
+    psi = dihedral(bb[:, :-1, 0], bb[:, :-1, 1], bb[:, :-1, 2], bb[:, 1:, 0])
+    psi = F.pad(psi * consec, (0, 1), value=0.0)
+    sn, cs = torch.sin(psi), torch.cos(psi)
+    o = tab["bb_oxygen"][aa]
+    q = torch.stack([o[..., 0], cs * o[..., 1] - sn * o[..., 2], sn * o[..., 1] + cs * o[..., 2]], -1)
+    O_pos = torch.einsum("nlij,nlj->nli", R, q) + t
+    return torch.cat([bb, O_pos[:, :, None, :]], 2)

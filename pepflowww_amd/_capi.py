@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -120,6 +120,12 @@ class FullAtomArgs(C.Structure):
                 ("gen_mask", _fp), ("ctx_pos15", _fp), ("pos15_merged", _fp), ("mask15", _fp), ("rows", _i)]
 
 
+class BackboneAtomsArgs(C.Structure):
+    _fields_ = [("rot", _fp), ("trans", _fp), ("aa", _fp), ("chain_nb", _fp), ("res_nb", _fp), ("mask", _fp), ("tab_bb", _fp),
+                ("tab_o", _fp), ("pos4", _fp), ("gen_mask", _fp), ("ctx_pos15", _fp), ("ctx_mask15", _fp), ("pos15_merged", _fp),
+                ("mask15", _fp), ("B", _i), ("L", _i)]
+
+
 class NodeFeatArgs(C.Structure):
     _fields_ = [("aa", _fp), ("res_nb", _fp), ("chain_nb", _fp), ("pos", _fp), ("mask_atoms", _fp), ("gen_mask", _fp),
                 ("aa_table", _fp), ("freq3", _fp), ("feat", _fp), ("rot1", _fp), ("trans1", _fp), ("mres", _fp),
@@ -205,6 +211,7 @@ _SIGNATURES = {
     "pf_ipa_bwd_points": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_headw_bwd": ([_fp, _fp, _fp, _fp], _i),
     "pf_full_atom_fwd": ([C.POINTER(FullAtomArgs), _fp], _i),
+    "pf_backbone_atoms_fwd": ([C.POINTER(BackboneAtomsArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),
     "pf_so3_log": ([_fp, _fp, _i, _fp], _i),
     "pf_so3_exp": ([_fp, _fp, _i, _fp], _i),

@@ -70,7 +70,88 @@ __global__ __launch_bounds__(256) void full_atom_kernel(pf_full_atom_args a) {
     }
 }
 
+// reconstruct_backbone (pepflow/modules/common/geometry.py:446-489): idealised N, CA, C of the residue type placed by the frame,
+// psi = dihedral(N_i, CA_i, C_i, N_{i+1}) (get_backbone_dihedral_angles 352-390; 0 at C-termini = chain break, last residue or
+// masked residue, topology.py:5-25), O placed by the psi frame R * Rx(psi).  One thread per residue; the neighbour's N is
+// rebuilt from the neighbour's frame.  Optional merge of sample.py:77-82 (save_samples_bb): 4 backbone atoms padded to 15,
+// context atoms / masks kept outside the generated region.
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ __launch_bounds__(256) void backbone_atoms_kernel(pf_backbone_atoms_args a) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int rows = a.B * a.L;
+    if (r >= rows) return;
+    const int l = r % a.L;
+    auto clampaa = [](long long v) { return v < 0 ? 0 : (v > 20 ? 20 : v); };
+    auto place = [&](int row, int atom, float* out) {
+        const float* R = a.rot + (size_t)row * 9;
+        const float* T = a.trans + (size_t)row * 3;
+        const float* q = a.tab_bb + ((size_t)clampaa(a.aa[row]) * 3 + atom) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = R[i * 3] * q[0] + R[i * 3 + 1] * q[1] + R[i * 3 + 2] * q[2] + T[i];
+    };
+    float P[4][3];
+    place(r, 0, P[0]); place(r, 1, P[1]); place(r, 2, P[2]);
+    float psi = 0.f;
+    if (l + 1 < a.L) {
+        const long long dn = a.res_nb[r + 1] - a.res_nb[r];
+        const bool consec = (dn == 1 || dn == -1) && a.chain_nb[r + 1] == a.chain_nb[r] && a.mask[r] != 0;
+        if (consec) {
+            float Nn[3];
+            place(r + 1, 0, Nn);
+            float v0[3], v1[3], v2[3], u1[3], u2[3], w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { v0[i] = P[2][i] - P[1][i]; v1[i] = P[0][i] - P[1][i]; v2[i] = Nn[i] - P[2][i]; }
+            cross3(v0, v1, u1); cross3(v0, v2, u2); cross3(v1, v2, w);
+            const float n1 = sqrtf(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+            const float n2 = sqrtf(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+            float c = (u1[0] / n1) * (u2[0] / n2) + (u1[1] / n1) * (u2[1] / n2) + (u1[2] / n1) * (u2[2] / n2);
+            c = fminf(fmaxf(c, -0.999999f), 0.999999f);
+            const float sd = w[0] * v0[0] + w[1] * v0[1] + w[2] * v0[2];
+            const float sg = sd > 0.f ? 1.f : (sd < 0.f ? -1.f : 0.f);
+            psi = sg * acosf(c);
+            if (!(psi == psi) || fabsf(psi) > 3.0e38f) psi = 0.f;       // nan_to_num
+        }
+    }
+    {
+        const float* R = a.rot + (size_t)r * 9;
+        const float* T = a.trans + (size_t)r * 3;
+        const float* o = a.tab_o + (size_t)clampaa(a.aa[r]) * 3;
+        const float sn = sinf(psi), cs = cosf(psi);
+        const float q[3] = {o[0], cs * o[1] - sn * o[2], sn * o[1] + cs * o[2]};       // Rx(psi) o
+#pragma unroll
+        for (int i = 0; i < 3; ++i) P[3][i] = R[i * 3] * q[0] + R[i * 3 + 1] * q[1] + R[i * 3 + 2] * q[2] + T[i];
+    }
+    if (a.pos4)
+#pragma unroll
+        for (int at = 0; at < 4; ++at)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a.pos4[((size_t)r * 4 + at) * 3 + i] = P[at][i];
+    if (a.pos15_merged) {
+        const bool gen = a.gen_mask[r] > 0.5f;
+        for (int at = 0; at < 15; ++at) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                a.pos15_merged[((size_t)r * 15 + at) * 3 + i] = gen ? (at < 4 ? P[at][i] : 0.f) : a.ctx_pos15[((size_t)r * 15 + at) * 3 + i];
+            if (a.mask15) a.mask15[(size_t)r * 15 + at] = gen ? (unsigned char)(at < 4) : a.ctx_mask15[(size_t)r * 15 + at];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int pf_backbone_atoms_fwd(const pf_backbone_atoms_args* a, pf_stream_t stream) {
+    if (!a || !a->rot || !a->trans || !a->aa || !a->chain_nb || !a->res_nb || !a->mask || !a->tab_bb || !a->tab_o || a->B <= 0 ||
+        a->L <= 0 || (!a->pos4 && !a->pos15_merged) || (a->pos15_merged && (!a->gen_mask || !a->ctx_pos15)) ||
+        (a->mask15 && (!a->pos15_merged || !a->ctx_mask15)))
+        return PF_E_BADARG;
+    const long rows = (long)a->B * a->L;
+    hipLaunchKernelGGL(backbone_atoms_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pf_full_atom_fwd(const pf_full_atom_args* a, pf_stream_t stream) {
     if (!a || !a->rot || !a->trans || !a->angles || !a->aa || !a->tab_rot || !a->tab_trans || !a->tab_group || !a->tab_pos ||

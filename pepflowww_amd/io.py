@@ -4,6 +4,7 @@
   * write_pdb                 -- pepflow/modules/protein/writers.py:10-88 (plain-text PDB records; the reference goes through
                                  Biopython, which this environment does not have)
   * export_samples            -- sample.py:96-120: full-atom reconstruction (HIP) + one PDB per sample + gt.pdb
+  * export_samples_bb         -- sample.py:68-94: backbone-only reconstruction (HIP) + one PDB per sample + gt.pdb
 """
 import math
 import os
@@ -93,14 +94,17 @@ def write_pdb(data, path):
                 full = {1: " %s  ", 2: " %s ", 3: " %s"}.get(len(name), "%s") % name
                 x, y, z = pos[r, a_i].tolist()
                 ic = str(data["icode"][r])[:1] if data.get("icode") is not None else " "
-                lines.append("ATOM  %5d %4s %3s %1s%4d%1s   %8.3f%8.3f%8.3f%6.2f%6.2f          %2s" %
-                             (serial, full, resnames[t], cid, int(resseq[r]), ic or " ", x, y, z, 1.0, 0.0, name[0].rjust(2)))
+                # PDB format v3.3 ATOM record, 80 columns: 1-6 record, 7-11 serial, 13-16 atom name, 17 altLoc, 18-20 resName,
+                # 22 chainID, 23-26 resSeq, 27 iCode, 31-54 x y z (8.3f), 55-60 occupancy, 61-66 tempFactor, 73-76 segID,
+                # 77-78 element (right-justified), 79-80 charge
+                lines.append("ATOM  %5d %4s %3s %1s%4d%1s   %8.3f%8.3f%8.3f%6.2f%6.2f      %4s%2s%2s" %
+                             (serial, full, resnames[t], cid, int(resseq[r]), ic or " ", x, y, z, 1.0, 0.0, "", name[0].rjust(2), ""))
                 serial += 1
                 last = (resnames[t], cid, int(resseq[r]), ic or " ")
         if last is not None:
-            lines.append("TER   %5d      %3s %1s%4d%1s" % (serial, *last))
+            lines.append(("TER   %5d      %3s %1s%4d%1s" % (serial, *last)).ljust(80))
             serial += 1
-    lines.append("END")
+    lines.append("END   ")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return len(lines)
@@ -114,6 +118,24 @@ def export_samples(samples, save_dir):
     dev = torch.device("cuda")
     pos, mask = reconstruct_sample(samples["rotmats"].to(dev), samples["trans"].to(dev), samples["angles"].to(dev), samples["seqs"].to(dev),
                                    batch["generate_mask"].to(dev), batch["pos_heavyatom"].to(dev))
+    pos, mask = pos.cpu(), mask.cpu()
+    chain_id = [c[0] if isinstance(c, (list, tuple)) else c for c in batch["chain_id"]]
+    meta = dict(chain_nb=batch["chain_nb"][0], chain_id=chain_id, resseq=batch["resseq"][0], icode=[" "] * len(chain_id))
+    for i in range(samples["seqs"].shape[0]):
+        write_pdb(dict(meta, aa=samples["seqs"][i].cpu(), mask_heavyatom=mask[i], pos_heavyatom=pos[i]), os.path.join(save_dir, f"sample_{i}.pdb"))
+    write_pdb(dict(meta, aa=batch["aa"][0], mask_heavyatom=batch["mask_heavyatom"][0][:, :15], pos_heavyatom=batch["pos_heavyatom"][0][:, :15]),
+              os.path.join(save_dir, "gt.pdb"))
+
+
+def export_samples_bb(samples, save_dir):
+    """sample.py:68-94 (save_samples_bb): backbone-only reconstruction (HIP, reconstruct_backbone) of the generated residues
+    merged with the context atoms, one PDB per sample + gt.pdb."""
+    from .full_atom import reconstruct_sample_bb
+    os.makedirs(save_dir, exist_ok=True)
+    batch = samples["batch"]
+    dev = torch.device("cuda")
+    pos, mask = reconstruct_sample_bb(samples["rotmats"].to(dev), samples["trans"].to(dev), samples["seqs"].to(dev), batch["chain_nb"],
+                                      batch["res_nb"], batch["res_mask"], batch["generate_mask"], batch["pos_heavyatom"], batch["mask_heavyatom"])
     pos, mask = pos.cpu(), mask.cpu()
     chain_id = [c[0] if isinstance(c, (list, tuple)) else c for c in batch["chain_id"]]
     meta = dict(chain_nb=batch["chain_nb"][0], chain_id=chain_id, resseq=batch["resseq"][0], icode=[" "] * len(chain_id))

@@ -22,39 +22,76 @@ import models_con.torus as torus  # noqa: E402
 from data import all_atom  # noqa: E402
 
 B, L = 3, 24
-batch = synth.make_pocket_batch(B, L, 7, seed=31337, lengths=[24, 20, 23])
-g = torch.Generator().manual_seed(8)
-nz = synth.make_noise(B, L, 1, seed=123)
-noise = {"t": torch.rand(B, 1, generator=g), "trans0": nz["trans0"], "rot0": nz["rot0"], "ang0": nz["ang0"],
-         "simplex0": nz["simplex0"]}
-rec = []
+import math as _m  # noqa: E402
 orig = dict(multinomial=torch.multinomial, rand=torch.rand, randn=torch.randn, randn_like=torch.randn_like,
             so3=fm.uniform_so3, tor=torus.tor_random_uniform)
 
 
-def multinomial_rec(c, n, *a, **k):
-    st = torch.get_rng_state()
-    out = orig["multinomial"](c, n, *a, **k)
-    torch.set_rng_state(st)
-    Ex = torch.empty_like(c).exponential_(1)
-    assert torch.equal(out[:, 0], torch.argmax(c / Ex, -1))
-    rec.append(Ex.reshape(B, L, 20).clone())
-    return out
+def run(batch_seed, noise_seed):
+    """One reference forward with recorded draws; also returns how far the step is from its discrete decision points:
+    the relative top-2 gap of every categorical draw on a generated residue (torch.multinomial == argmax(p / E)) and the
+    distance of every rotation angle entering the SO(3) log from its theta ~ 0 / theta ~ pi branch switches
+    (so3_utils.py:212-216).  A fixture sitting ON such a point has a training gradient that is discontinuous at fp32
+    resolution (round 1: a 2e-6 perturbation of one block's output moved some parameter gradients by 2-4e-3), which makes
+    an element-wise gradient comparison meaningless; the seeds below are chosen so that every margin is comfortable."""
+    batch = synth.make_pocket_batch(B, L, 7, seed=batch_seed, lengths=[24, 20, 23])
+    g = torch.Generator().manual_seed(8 + noise_seed - 123)
+    nz = synth.make_noise(B, L, 1, seed=noise_seed)
+    noise = {"t": torch.rand(B, 1, generator=g), "trans0": nz["trans0"], "rot0": nz["rot0"], "ang0": nz["ang0"],
+             "simplex0": nz["simplex0"]}
+    rec, gaps, thetas = [], [], []
+    gen = batch["generate_mask"].reshape(-1)
+
+    def multinomial_rec(c, n, *a, **k):
+        st = torch.get_rng_state()
+        out = orig["multinomial"](c, n, *a, **k)
+        torch.set_rng_state(st)
+        Ex = torch.empty_like(c).exponential_(1)
+        assert torch.equal(out[:, 0], torch.argmax(c / Ex, -1))
+        top = torch.topk(c / Ex, 2, dim=-1).values
+        gaps.append((1 - top[:, 1] / top[:, 0])[gen].min().item())
+        rec.append(Ex.reshape(B, L, 20).clone())
+        return out
+
+    enc_fwd = model.ga_encoder.forward
+
+    def ga_capture(t, rot_t, *a, **k):
+        out = enc_fwd(t, rot_t, *a, **k)
+        for tgt in (out[0],):
+            rel = rot_t.transpose(-1, -2) @ tgt
+            th = torch.acos(((rel.diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2).clamp(-1, 1))
+            thetas.append(th.reshape(-1)[gen])
+        return out
+
+    torch.multinomial = multinomial_rec
+    torch.rand = lambda *s, **k: noise["t"].clone()
+    torch.randn = lambda *s, **k: noise["trans0"].clone()
+    torch.randn_like = lambda x, **k: noise["simplex0"].clone()
+    fm.uniform_so3 = lambda nb, nr, device=None: noise["rot0"].clone()
+    torus.tor_random_uniform = lambda *s, dtype=None, device=None: noise["ang0"].clone()
+    model.ga_encoder.forward = ga_capture
+    torch.manual_seed(7)
+    try:
+        with torch.no_grad():
+            losses = model(batch)
+    finally:
+        torch.multinomial, torch.rand, torch.randn, torch.randn_like = orig["multinomial"], orig["rand"], orig["randn"], orig["randn_like"]
+        fm.uniform_so3, torus.tor_random_uniform = orig["so3"], orig["tor"]
+        model.ga_encoder.forward = enc_fwd
+    th = torch.cat(thetas)
+    margin = dict(draw_gap=min(gaps), theta_zero=th.min().item(), theta_pi=(_m.pi - th).min().item())
+    return batch, noise, rec, losses, margin
 
 
-torch.multinomial = multinomial_rec
-torch.rand = lambda *s, **k: noise["t"].clone()
-torch.randn = lambda *s, **k: noise["trans0"].clone()
-torch.randn_like = lambda x, **k: noise["simplex0"].clone()
-fm.uniform_so3 = lambda nb, nr, device=None: noise["rot0"].clone()
-torus.tor_random_uniform = lambda *s, dtype=None, device=None: noise["ang0"].clone()
-torch.manual_seed(7)
-try:
-    with torch.no_grad():
-        losses = model(batch)
-finally:
-    torch.multinomial, torch.rand, torch.randn, torch.randn_like = orig["multinomial"], orig["rand"], orig["randn"], orig["randn_like"]
-    fm.uniform_so3, torus.tor_random_uniform = orig["so3"], orig["tor"]
+for cand in range(64):
+    batch, noise, rec, losses, margin = run(31337 + cand, 123 + cand)
+    print("candidate", cand, margin)
+    if margin["draw_gap"] > 0.05 and margin["theta_zero"] > 0.05 and margin["theta_pi"] > 0.1:
+        break
+else:
+    raise SystemExit("no well-conditioned candidate found")
+g = torch.Generator().manual_seed(8 + cand)
+torch.rand(B, 1, generator=g)            # (the draw of t above; the KAT below continues the same stream)
 assert len(rec) == 2
 # idealised backbone KAT
 q = torch.randn(2, 5, 4, generator=g)
@@ -62,7 +99,8 @@ from openfold.utils import rigid_utils as ru  # noqa: E402
 Rb = ru.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
 xb = torch.randn(2, 5, 3, generator=g) * 4
 bb = all_atom.to_atom37(xb, Rb)[:, :, :3]
-out = {"expo": torch.stack(rec, 0), "bb_R": Rb, "bb_x": xb, "bb_out": bb}
+out = {"expo": torch.stack(rec, 0), "bb_R": Rb, "bb_x": xb, "bb_out": bb,
+       "margins": torch.tensor([margin["draw_gap"], margin["theta_zero"], margin["theta_pi"]])}
 out.update({k: v for k, v in noise.items()})
 out.update({"loss_" + k: v for k, v in losses.items()})
 out.update({"batch_" + k: v for k, v in batch.items()})

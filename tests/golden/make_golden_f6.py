@@ -86,6 +86,44 @@ for name, prm in model.named_parameters():                 # gradient norm of EV
     names.append(name)
     norms.append(float(prm.grad.norm()) if prm.grad is not None else float("nan"))
 out["param_gradnorms"] = torch.tensor(norms)
+# full gradient TENSORS: every parameter of <= 65536 elements entirely; larger ones through 8 seeded random projections
+# (fixed +-1 sign vectors, tests/gpu_util.sign_projections regenerates them) and a strided sample of 4096 elements --
+# a permuted / transposed / sign-flipped block inside a tensor keeps its norm but not these
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from grad_probe import probe  # noqa: E402
+for i, (name, prm) in enumerate(model.named_parameters()):
+    gflat = prm.grad.detach().reshape(-1)
+    if gflat.numel() <= 65536:
+        out[f"pg_{i}"] = prm.grad.detach()
+    else:
+        pr, smp = probe(gflat, i)
+        out[f"pp_{i}"] = pr
+        out[f"ps_{i}"] = smp
+# intrinsic fp32 noise of the REFERENCE's own gradient: the same step through the CPU restatement (oracle/, pinned to the
+# reference forward AND element-wise to these gradients by tests/test_oracle_golden.py) in float64.  Per parameter:
+# max|g_ref_fp32 - g_fp64| / max|g_fp64|.  The median is 6e-5, but the encoder's distance MLP sits at 2-3e-2 (long
+# cancelling sums over B*L*L pairs): no fp32 implementation can agree with the reference better than this on those tensors,
+# so the GPU tests bound |g_hip - g_ref| by 3e-4 + 3 x this figure.
+from oracle import pepflow_oracle as O  # noqa: E402
+dt = torch.float64
+sd64 = {k: (v.to(dt) if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point()) for k, v in synth.seeded_state_dict().items()}
+b64 = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in batch.items()}
+n64 = {k: v.to(dt) for k, v in noise.items()}
+n64["expo"] = T("expo").to(dt)
+bb_keep = O.BB_IDEAL
+O.BB_IDEAL = O.BB_IDEAL.to(dt)
+try:
+    l64 = O.forward_losses(sd64, b64, n64)
+    sum(float(w[k]) * v for k, v in l64.items()).backward()
+finally:
+    O.BB_IDEAL = bb_keep
+noise_lvl = []
+for name, prm in model.named_parameters():
+    g64 = sd64[name].grad
+    noise_lvl.append(float((prm.grad.detach().to(dt) - g64).abs().max() / g64.abs().max().clamp_min(1e-30)))
+out["param_fp32_noise"] = torch.tensor(noise_lvl)
+print("fp32 noise of the reference gradient: median %.2e, max (excluding the analytically-zero linear_b.bias) %.2e"
+      % (sorted(noise_lvl)[len(noise_lvl) // 2], max(v for n, v in zip(names, noise_lvl) if not n.endswith("linear_b.bias"))))
 import json  # noqa: E402
 json.dump(names, open(os.path.join(HERE, "f6_param_names.json"), "w"))
 np.savez_compressed(os.path.join(HERE, "f6_trunk_grads.npz"), **{k: v.detach().cpu().numpy() for k, v in out.items()})

@@ -160,3 +160,55 @@ def assert_close(a, b, rel=1e-4, what=""):
     assert torch.isfinite(a).all(), f"{what}: non-finite values"
     e = rel_err(a, b)
     assert e <= rel, f"{what}: max|a-b|/max|b| = {e:.3e} > {rel:.1e}"
+
+
+def assert_close_elementwise(a, b, atol, rtol, what=""):
+    """|a - b| <= atol + rtol * |b| for EVERY element (the max-normalised metric above lets small entries of a tensor with a
+    large dynamic range drift; this one does not)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    bad = (a - b).abs() > atol + rtol * b.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} elements outside atol={atol:g} + rtol={rtol:g}; worst |a-b| = {(a - b).abs().max().item():.3e}"
+
+
+def check_param_grads(grads, f6, base=3e-4, k_noise=3.0):
+    """Every parameter gradient against the REFERENCE's autograd gradient TENSOR (golden F6): parameters of <= 65536
+    elements element-wise (max-normalised), larger ones through 8 sign-vector projections + a strided 4096-element sample
+    (tests/grad_probe.py), and every gradient norm.  Tolerance per parameter = base + k_noise x the reference's own fp32
+    noise on that parameter (F6 'param_fp32_noise': |reference fp32 gradient - float64 gradient| / max, recorded by
+    make_golden_f6.py; median 6e-5, encoder distance MLP 2-5e-2).  linear_b.bias gradients are analytically zero (softmax
+    shift invariance): both sides hold rounding noise, bounded absolutely.  Returns (worst ratio err/tol, its name)."""
+    from grad_probe import probe
+    names = f6["_names"]
+    bad, worst = [], (0.0, None)
+    for i, name in enumerate(names):
+        if name is None:                      # not part of this check (subset of the model)
+            continue
+        if name not in grads or grads[name] is None:
+            bad.append((name, "missing"))
+            continue
+        g = grads[name].detach().float().cpu()
+        refn = f6["_gradnorm"][name]
+        if name.endswith("linear_b.bias"):
+            if g.abs().max().item() > 2e-5:
+                bad.append((name, "analytically zero gradient", g.abs().max().item()))
+            continue
+        tol = base + k_noise * float(f6["param_fp32_noise"][i])
+        if f"pg_{i}" in f6:
+            ref = f6[f"pg_{i}"]
+            if g.shape != ref.shape:
+                bad.append((name, "shape", tuple(g.shape), tuple(ref.shape)))
+                continue
+            err = ((g - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+        else:
+            pr, smp = probe(g.reshape(-1), i)
+            e_s = ((smp - f6[f"ps_{i}"]).abs().max() / f6[f"ps_{i}"].abs().max().clamp_min(1e-12)).item()
+            e_p = ((pr - f6[f"pp_{i}"]).abs().max() / max(refn, 1e-12)).item()      # |sign-projection| ~ ||g||_2
+            err = max(e_s, e_p)
+        err = max(err, abs(g.norm().item() - refn) / max(refn, 1e-12))
+        if err / tol > worst[0]:
+            worst = (err / tol, name)
+        if not err <= tol:
+            bad.append((name, err, tol))
+    assert not bad, (len(bad), bad[:8])
+    return worst

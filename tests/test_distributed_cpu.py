@@ -148,3 +148,89 @@ def test_gradient_arena_allreduce_two_ranks():
         assert owned and n == 16 + 8 + 4                  # 15 -> 16, 7 -> 8 (alignment), 4
         assert torch.allclose(grads["a"], torch.full((3, 5), 1.5)) and torch.allclose(grads["b"], torch.full((7,), 3.0))
         assert torch.allclose(grads["c"], torch.full((2, 2), 15.0))
+
+
+# ---- sample_sharded itself (host logic: batch / noise sharding, seeded per-sample noise, empty shards, closing all-gather) ----
+class _StubEng:
+    def __init__(self, B, L):
+        self.B, self.L = B, L
+
+
+class _StubSampler:
+    """Stands in for DeviceSampler: a 'final state' that is a pure function of the initial noise and the GLOBAL sample index."""
+
+    def __init__(self, batch, num_steps, noise, first_sample):
+        B, L = batch["aa"].shape
+        rows = B * L
+        self.eng, self.N = _StubEng(B, L), num_steps
+        gidx = (first_sample + torch.arange(B, dtype=torch.float32))[:, None].expand(B, L).reshape(rows, 1)
+        z = lambda *s: torch.zeros(num_steps, *s)
+        self.traj_rot, self.traj_trans, self.traj_ang = z(rows, 9), z(rows, 3), z(rows, 5)
+        self.traj_simplex, self.traj_seq = z(rows, 20), torch.zeros(num_steps, rows, dtype=torch.int64)
+        self.traj_rot[-1] = noise["rot0"].reshape(rows, 9)
+        self.traj_trans[-1] = noise["trans0"].reshape(rows, 3) + gidx
+        self.traj_ang[-1] = noise["ang0"].reshape(rows, 5)
+        self.traj_simplex[-1] = noise["simplex0"].reshape(rows, 20)
+        self.traj_seq[-1] = batch["aa"].clamp(max=19).reshape(rows)
+
+
+class _StubModel:
+    def sample(self, batch, num_steps, noise=None, seed=0, first_sample=0, return_sampler=False, **kw):
+        assert return_sampler and noise is not None
+        return _StubSampler(batch, num_steps, noise, first_sample)
+
+
+def _sharded_worker(rank, world, port, total, with_noise, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = 12
+        batch = synth.make_pocket_batch(total, L, 4, seed=3)
+        batch["id"] = [f"c{i}" for i in range(total)]
+        batch["chain_id"] = [tuple("AB"[(i + l) % 2] for i in range(total)) for l in range(L)]
+        noise = {k: v for k, v in synth.make_noise(total, L, 2, seed=5).items() if k != "expo"} if with_noise else None
+        out = D.sample_sharded(_StubModel(), batch, num_steps=3, noise=noise, seed=77)
+        q.put((rank, {k: v.clone() for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,with_noise", [(5, True), (4, False), (1, False)])
+def test_sample_sharded_gloo_world2(total, with_noise):
+    """sample_sharded end to end on two ranks: every rank returns the state an unsharded run produces -- with caller noise,
+    with noise=None (seeded per GLOBAL sample: ADVICE r1) and with an empty shard (1 sample on 2 ranks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, total, with_noise, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L = 12
+    batch = synth.make_pocket_batch(total, L, 4, seed=3)
+    noise = {k: v for k, v in synth.make_noise(total, L, 2, seed=5).items() if k != "expo"} if with_noise else D.seeded_noise(0, total, L, 77)
+    ref = D.unpack_state(D._final_state_of(_StubSampler(batch, 3, noise, 0)))
+    for rank, out in res:
+        for k in ref:
+            assert out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]), (rank, k)
+    if not with_noise and total > 1:                       # distinct samples draw distinct noise
+        assert not torch.equal(ref["rotmats"][0], ref["rotmats"][1])
+
+
+def test_shard_batch_structured_lists_and_square_batches():
+    """Collated per-residue lists (chain_id / icode: L tuples of B strings) are sliced inside the tuples -- also when L == B,
+    where a `len(v) == B` test would slice the residue axis."""
+    B = L = 4
+    batch = synth.make_pocket_batch(B, L, 2, seed=1)
+    batch["id"] = ["a", "b", "c", "d"]
+    batch["chain_id"] = [tuple(f"{l}{b}" for b in range(B)) for l in range(L)]
+    local, lo, hi = D.shard_batch(batch, 2, 1)
+    assert (lo, hi) == (2, 4) and local["aa"].shape == (2, L) and local["id"] == ["c", "d"]
+    assert len(local["chain_id"]) == L and local["chain_id"][1] == ("12", "13")
+    nz = D.seeded_noise(0, 4, L, 9)
+    part = D.seeded_noise(2, 4, L, 9)
+    for k in nz:
+        assert torch.equal(nz[k][2:], part[k]), k

@@ -1,0 +1,196 @@
+"""GPU parity at the shapes bench.py actually times (run on a real MI355X: `pytest -m gpu`).
+
+The kernels are shape-dispatched (attention variant by the number of query tiles, persistent vs tiled EdgeTransition,
+whole-row vs tiled Linears ...), so the small golden shapes do not exercise the code the benchmark runs.  Here:
+
+  * cfg4 per-GPU shape (BASELINE configs[3]): B=64 x L=128 sampler -- step 0 (teacher-forced: both sides start from the
+    same noise) element-wise against the CPU oracle, two free steps, zero sequence flips;
+  * cfg5 per-GPU shape (BASELINE configs[4]): B=16 x L=128 training step -- six losses and the gradient TENSOR of every
+    parameter against the oracle's autograd (pinned element-wise to the reference's gradients by
+    tests/test_oracle_golden.py::test_oracle_autograd_matches_reference_parameter_gradients);
+  * cfg3 shape (BASELINE configs[2]): B=64 variable-length pockets padded to the longest, fp32 mode vs the oracle on a
+    subset, f16 single-pass mode vs fp32 mode (deviation reported and bounded).
+"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(__file__))
+from oracle import pepflow_oracle as O  # noqa: E402  (checker only)
+import pepflowww_amd  # noqa: E402
+from pepflowww_amd import synth  # noqa: E402
+import gpu_util as G  # noqa: E402
+
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def model(seeded_sd):
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(seeded_sd, strict=True)
+    return m.to(G.dev()).eval()
+
+
+def cu(t):
+    return t.to(G.dev()).contiguous()
+
+
+def _oracle_chunk(sd, batch, noise, lo, hi, NS):
+    sub = {k: v[lo:hi] for k, v in batch.items()}
+    nz = {k: (v[:, lo:hi] if k == "expo" else v[lo:hi]).contiguous() for k, v in noise.items()}
+    with torch.no_grad():
+        return O.sample(sd, sub, nz, NS)
+
+
+def _compare_traj(traj, ref, lo, hi, NS, what):
+    flips = sum((traj[i]["seqs"][lo:hi] != ref[i]["seqs"]).sum().item() for i in range(NS))
+    assert flips == 0, f"{what}: {flips} sequence flips"
+    # step 0 is teacher-forced (same initial noise on both sides): max-normalised AND element-wise
+    G.assert_close(traj[0]["rotmats"][lo:hi], ref[0]["rotmats"], REL, f"{what} step 0 rotmats")
+    G.assert_close(traj[0]["trans"][lo:hi], ref[0]["trans"], REL, f"{what} step 0 trans")
+    G.assert_close_elementwise(traj[0]["rotmats"][lo:hi], ref[0]["rotmats"], 1e-4, 1e-4, f"{what} step 0 rotmats")
+    G.assert_close_elementwise(traj[0]["trans"][lo:hi], ref[0]["trans"], 5e-4, 1e-4, f"{what} step 0 trans (Angstrom)")
+    d = (traj[0]["angles"][lo:hi] - ref[0]["angles"]).abs()
+    assert torch.minimum(d, 2 * math.pi - d).max() < 3e-4, f"{what} step 0 angles"
+    assert torch.equal(traj[0]["seqs_simplex"][lo:hi], ref[0]["seqs_simplex"])
+    for i in range(1, NS):                       # free run
+        G.assert_close(traj[i]["rotmats"][lo:hi], ref[i]["rotmats"], 3 * REL, f"{what} step {i} rotmats")
+        G.assert_close(traj[i]["trans"][lo:hi], ref[i]["trans"], 3 * REL, f"{what} step {i} trans")
+        d = (traj[i]["angles"][lo:hi] - ref[i]["angles"]).abs()
+        assert torch.minimum(d, 2 * math.pi - d).max() < 1e-3, f"{what} step {i} angles"
+
+
+def test_cfg4_sampler_vs_oracle(model, seeded_sd):
+    """B=64 x L=128 (the bench default; attention runs its large-batch variant: 512 query tiles): the first and the last
+    16 samples are checked against the CPU oracle (samples are independent; the oracle needs ~10 s per step per 16 samples),
+    the whole batch for validity, and the same batch run as two B=32 shards must reproduce it bit for bit."""
+    B, L, NS = 64, 128, 3
+    batch = synth.make_pocket_batch(B, L, 16, seed=114514)
+    noise = synth.make_noise(B, L, NS, seed=3)
+    traj = model.sample({k: cu(v) for k, v in batch.items()}, num_steps=NS, noise=noise, use_graph=True)
+    last = traj[-1]
+    R = last["rotmats"]
+    assert torch.isfinite(R).all() and torch.isfinite(last["trans"]).all()
+    assert (R @ R.transpose(-1, -2) - torch.eye(3)).abs().max() < 1e-4 and (torch.linalg.det(R) - 1).abs().max() < 1e-4
+    for lo, hi in ((0, 16), (48, 64)):
+        ref = _oracle_chunk(seeded_sd, batch, noise, lo, hi, NS)
+        _compare_traj(traj, ref, lo, hi, NS, f"samples {lo}..{hi}")
+    for lo, hi in ((0, 32), (32, 64)):
+        sub = {k: cu(v[lo:hi]) for k, v in batch.items()}
+        nz = {k: (v[:, lo:hi] if k == "expo" else v[lo:hi]).contiguous() for k, v in noise.items()}
+        t = model.sample(sub, num_steps=NS, noise=nz, first_sample=lo)
+        for k in ("rotmats", "trans", "angles", "seqs"):
+            assert torch.equal(t[-1][k], last[k][lo:hi]), (k, lo)
+
+
+def test_cfg5_training_step_vs_oracle_autograd(seeded_sd):
+    """B=16 x L=128 training step (default path: fused EdgeTransition forward, mid-size attention variant): losses and
+    the gradient tensor of all 407 parameters against the oracle's autograd."""
+    from test_oracle_golden import oracle_param_grads
+    B, L = 16, 128
+    batch = synth.make_pocket_batch(B, L, 16, seed=2024)
+    nz = synth.make_noise(B, L, 1, seed=5)
+    noise = {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(3)), "trans0": nz["trans0"], "rot0": nz["rot0"],
+             "ang0": nz["ang0"], "simplex0": nz["simplex0"], "expo": nz["expo"][:2].clone()}
+    # keep every categorical draw away from its decision boundary (a flipped residue type changes the torsion mask of the
+    # angle losses -- a discontinuity no tolerance covers): widen draws whose top-2 gap is < 5 % on the oracle's forward
+    with torch.no_grad():
+        enc = O.encode(seeded_sd, batch)
+        for _ in range(3):
+            state = O.corrupt(batch, enc, noise)
+            preds = O.ga_encoder(seeded_sd, *state, enc[4], enc[5], batch["res_mask"].long())
+            sx = torch.where(batch["generate_mask"][..., None], (1 - state[0][..., None]) * (5.0 * noise["simplex0"]) +
+                             state[0][..., None] * O.seq_to_simplex(enc[3]), O.seq_to_simplex(enc[3]))
+            changed = 0
+            for d, p in ((0, torch.softmax(sx, -1)), (1, torch.softmax(preds[3], -1))):
+                sc = (p + 1e-8) / noise["expo"][d]
+                top = torch.topk(sc, 2, dim=-1)
+                tight = (1 - top.values[..., 1] / top.values[..., 0]) < 0.05
+                if tight.any():
+                    idx = top.indices[..., 0][tight]
+                    e = noise["expo"][d][tight]
+                    e[torch.arange(e.shape[0]), idx] *= 0.5          # the winner wins by more
+                    noise["expo"][d][tight] = e
+                    changed += int(tight.sum())
+            if not changed:
+                break
+    ref_g, ref_l = oracle_param_grads(seeded_sd, batch, noise)
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.to(G.dev()).train()
+    ld = m({k: cu(v) for k, v in batch.items()}, noise=noise)
+    for k, v in ld.items():
+        assert abs(v.item() - ref_l[k].item()) <= REL * abs(ref_l[k].item()), (k, v.item(), ref_l[k].item())
+    sum(O.LOSS_WEIGHTS[k] * v for k, v in ld.items()).backward()
+    G.sync()
+    # tolerance: the oracle's own fp32 gradient is noisy on the parameters whose gradient is a long cancelling sum over all
+    # B*L*L pairs (golden F6 'param_fp32_noise': encoder distance MLP 2-5e-2, everything else <= 5e-3): measured against
+    # the same step in float64 on the oracle, per parameter, here
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in seeded_sd.items()}
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    n64 = {k: v.double() for k, v in noise.items()}
+    keep = O.BB_IDEAL
+    O.BB_IDEAL = O.BB_IDEAL.double()
+    try:
+        g64, _ = oracle_param_grads(sd64, b64, n64)
+    finally:
+        O.BB_IDEAL = keep
+    bad, worst = [], (0.0, None)
+    for name, p in m.named_parameters():
+        g, r, r64 = p.grad.detach().float().cpu(), ref_g[name], g64[name]
+        assert g.shape == r.shape, name
+        if name.endswith("linear_b.bias"):
+            assert g.abs().max() < 5e-5, name
+            continue
+        scale = r64.abs().max().clamp_min(1e-12)
+        noise_lvl = ((r.double() - r64).abs().max() / scale).item()
+        err = ((g.double() - r64).abs().max() / scale).item()            # against the float64 truth
+        tol = 3e-4 + 3 * noise_lvl
+        if err / tol > worst[0]:
+            worst = (err / tol, name, err, noise_lvl)
+        if err > tol:
+            bad.append((name, err, noise_lvl))
+    print("cfg5 gradients vs float64 oracle, worst err/tol:", worst)
+    assert not bad, (len(bad), bad[:8])
+
+
+def test_cfg3_variable_length_batch(model, seeded_sd):
+    """BASELINE configs[2] shape: B=64 pockets of variable length (pocket 45-120 + peptide 3-25 residues) padded to the
+    longest.  fp32 mode: step 0 + a free step against the oracle on 8 of the samples (the shortest, the longest and six
+    in between), padding rows inert; f16 single-pass mode: deviation from the fp32 mode bounded and reported."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    wl = bench.WORKLOADS["cfg3"]
+    batch, B, L, n_real = bench.make_batch(wl, 0)
+    assert B == 64 and 48 <= min(batch["res_mask"].sum(1)) and L <= 145 and n_real < B * L
+    NS = 2
+    noise = synth.make_noise(B, L, NS, seed=11)
+    dbatch = {k: cu(v) for k, v in batch.items()}
+    traj = model.sample(dbatch, num_steps=NS, noise=noise)
+    lens = batch["res_mask"].sum(1)
+    order = torch.argsort(lens)
+    pick = sorted({int(order[0]), int(order[-1])} | {int(order[i]) for i in range(5, 64, 10)})
+    for b in pick:
+        ref = _oracle_chunk(seeded_sd, batch, noise, b, b + 1, NS)
+        n = int(lens[b])
+        sl = {k: [{kk: vv[b:b + 1, :n] for kk, vv in t.items()} for t in tr] for k, tr in (("a", traj), )}["a"]
+        rf = [{kk: vv[:, :n] for kk, vv in t.items()} for t in ref]
+        _compare_traj(sl, rf, 0, 1, NS, f"sample {b} (length {n})")
+    # f16 single-pass products: same inputs, same draws
+    model.ga_encoder.set_precision("f16")
+    try:
+        t16 = model.sample(dbatch, num_steps=NS, noise=noise)
+    finally:
+        model.ga_encoder.set_precision("fp32")
+    ok = batch["res_mask"]
+    e_rot = G.rel_err(t16[0]["rotmats"][ok], traj[0]["rotmats"][ok])
+    e_tr = G.rel_err(t16[0]["trans"][ok], traj[0]["trans"][ok])
+    flips = sum((t16[i]["seqs"] != traj[i]["seqs"])[ok].sum().item() for i in range(NS))
+    print(f"f16 single-pass vs fp32-parity mode, teacher-forced step: rotmats {e_rot:.2e}, trans {e_tr:.2e}; sequence flips over {NS} steps: {flips} of {int(ok.sum()) * NS}")
+    assert e_rot < 2e-2 and e_tr < 2e-2, (e_rot, e_tr)           # tolerance of the reduced-precision mode
+    assert flips <= 0.01 * int(ok.sum()) * NS

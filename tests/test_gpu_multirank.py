@@ -1,0 +1,72 @@
+"""Two ranks on ONE GPU (the GPU box has a single MI355X): the real sharded sampler and bench.py's self-spawning N>1 path.
+RCCL refuses two ranks on one device, so the collective backend here is gloo (the closing all-gather is staged through the
+host); everything else -- kernels, sharding, RNG keying, packing -- is the code the 8-GPU run executes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PF_ROOT"])
+import pepflowww_amd
+from pepflowww_amd import synth, distributed as D
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+m = pepflowww_amd.FlowModel(pepflowww_amd.default_config()); m.load_state_dict(synth.seeded_state_dict()); m = m.to("cuda:0").eval()
+B, L, NS = 5, 32, 3
+batch = {k: v.to("cuda:0") for k, v in synth.make_pocket_batch(B, L, 8, seed=21).items()}
+out = D.sample_sharded(m, batch, num_steps=NS, noise=None, seed=4321)
+if rank == 0:
+    full = m.sample(batch, num_steps=NS, noise=None, seed=4321)[-1]
+    ok = all(torch.equal(out[k].cpu().reshape(full[k].shape), full[k]) for k in ("rotmats", "trans", "angles", "seqs", "seqs_simplex"))
+    print("SHARDED_EQUALS_UNSHARDED", ok, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sample_sharded_two_ranks_one_gpu(tmp_path):
+    """sample_sharded(noise=None, seed=s) on 2 ranks (shards of 3 + 2 samples) == model.sample(noise=None, seed=s) unsharded,
+    bit for bit: per-global-sample noise and Philox streams, contiguous shards, one closing all-gather."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, PF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", env["MASTER_PORT"], str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "SHARDED_EQUALS_UNSHARDED True" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (how the driver may launch the scaling run) becomes
+    two ranks by itself and prints ONE JSON line with n_gpus = 2 and the whole-job aggregate."""
+    env = dict(os.environ, PF_BENCH_SHARE_GPU="1", PF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["steps"] == 3
+    assert abs(out["value"] - 2 * 16 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out and out["final_state_check"]["det_err"] < 1e-3

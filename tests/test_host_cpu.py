@@ -115,8 +115,8 @@ def test_trajectory_file_and_pdb_writer(tmp_path):
     write_pdb(data, str(p))
     lines = p.read_text().splitlines()
     atoms = [l for l in lines if l.startswith("ATOM")]
-    assert lines[-1] == "END" and sum(l.startswith("TER") for l in lines) == 2
-    assert all(len(l) == 78 for l in atoms)
+    assert lines[-1] == "END   " and sum(l.startswith("TER") for l in lines) == 2
+    assert all(len(l) == 80 for l in lines[:-1]) and lines[-1] == "END   "
     first_b = [l for l in atoms if l[21] == "B"][0]                     # chain_nb 0 is written first
     from pepflowww_amd.io import _names
     assert atoms[0] == first_b and first_b[17:20] == _names()[1][14] and int(first_b[22:26]) == 1
@@ -127,3 +127,25 @@ def test_trajectory_file_and_pdb_writer(tmp_path):
     save_trajectory(traj, {"aa": data["aa"][None]}, str(tmp_path / "t.pt"))
     back = load_trajectory(str(tmp_path / "t.pt"))
     assert torch.equal(back["rotmats"], traj["rotmats"]) and torch.equal(back["batch"]["aa"], data["aa"][None])
+
+
+def test_pdb_writer_matches_expected_text(tmp_path, golden_dir):
+    """write_pdb against a committed expected-text fixture authored from the PDB format v3.3 column table (ATOM / TER / END
+    records, 80 columns: negative and 4-digit residue numbers, insertion code, 4-character-field atom names of 1-3 letters,
+    coordinates at the %8.3f limits, chains ordered by chain_nb, serial numbers continuing over TER)."""
+    from pepflowww_amd.io import write_pdb
+    aa = torch.tensor([0, 18, 19])                       # ALA (chain A), TRP (chain A), TYR (chain B = chain_nb 0: written first)
+    pos = torch.zeros(3, 15, 3)
+    mask = torch.zeros(3, 15, dtype=torch.bool)
+    pos[2, 0] = torch.tensor([11.104, 6.134, -6.504]); pos[2, 1] = torch.tensor([11.639, 6.071, -5.147])
+    pos[2, 11] = torch.tensor([-123.456, 0.001, 999.999])
+    mask[2, [0, 1, 11]] = True
+    pos[0, 0] = torch.tensor([-0.5, 1.25, 2.0]); pos[0, 4] = torch.tensor([3.0, -4.0, 5.125])
+    mask[0, [0, 4]] = True
+    pos[1, 8] = torch.tensor([10.0, 20.0, 30.0])
+    mask[1, 8] = True
+    data = dict(aa=aa, pos_heavyatom=pos, mask_heavyatom=mask, chain_nb=torch.tensor([1, 1, 0]), chain_id=["A", "A", "B"],
+                resseq=torch.tensor([-5, 1234, 1]), icode=[" ", "A", " "])
+    p = tmp_path / "y.pdb"
+    write_pdb(data, str(p))
+    assert p.read_text() == open(os.path.join(golden_dir, "f10_pdb_expected.pdb")).read()

@@ -190,6 +190,47 @@ def test_loss_gradients_wrt_predictions(f4, f5, seeded_sd):
     close(gl, f5["d_pred_logits"], 1e-7, 1e-4)
 
 
+def oracle_param_grads(sd, batch, noise, weights=O.LOSS_WEIGHTS):
+    """d(weighted training loss)/d(every parameter) by torch autograd through the restatement (what train.py:121,133 does
+    through the reference).  Shared with the GPU parity tests (checker only)."""
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freq_bands") else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        losses = O.forward_losses(leaf, batch, noise)
+        sum(weights[k] * v for k, v in losses.items()).backward()
+    return {k: v.grad for k, v in leaf.items() if v.requires_grad and v.grad is not None}, {k: v.detach() for k, v in losses.items()}
+
+
+def test_oracle_autograd_matches_reference_parameter_gradients(f4, seeded_sd, golden_dir):
+    """The restatement's autograd gradient of EVERY parameter equals the reference's (golden F6: full tensors for parameters
+    of <= 65536 elements, sign projections + a strided sample for larger ones) element-wise -- this pins the oracle as the
+    gradient checker of the full-size GPU training test (tests/test_gpu_bigshape.py)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from grad_probe import probe
+    f6 = load(golden_dir, "f6_trunk_grads.npz")
+    names = json.load(open(os.path.join(golden_dir, "f6_param_names.json")))
+    batch = {k[6:]: v for k, v in f4.items() if k.startswith("batch_")}
+    noise = {k: f4[k] for k in ("t", "trans0", "rot0", "ang0", "simplex0", "expo")}
+    grads, _ = oracle_param_grads(seeded_sd, batch, noise)
+    assert len(names) == 407 and set(names) == set(grads)
+    worst = 0.0
+    for i, n in enumerate(names):
+        g = grads[n]
+        if n.endswith("linear_b.bias"):                      # analytically zero (softmax shift invariance): rounding noise
+            assert g.abs().max() < 2e-5
+            continue
+        if f"pg_{i}" in f6:
+            err = ((g - f6[f"pg_{i}"]).abs().max() / f6[f"pg_{i}"].abs().max()).item()
+        else:
+            pr, smp = probe(g.reshape(-1), i)
+            err = max(((smp - f6[f"ps_{i}"]).abs().max() / f6[f"ps_{i}"].abs().max()).item(),
+                      ((pr - f6[f"pp_{i}"]).abs().max() / f6["param_gradnorms"][i]).item())
+        worst = max(worst, err)
+        assert err < 1e-4, (n, err)
+    print("oracle autograd vs reference gradients, worst max-normalised error:", worst)
+
+
 def _rigid_tables():
     d = np.load(os.path.join(os.path.dirname(__file__), "..", "pepflowww_amd", "data", "rigid_groups.npz"))
     return {k: torch.from_numpy(d[k]) for k in d.files if d[k].dtype.kind != "U"}
@@ -202,3 +243,12 @@ def test_full_atom_reconstruction(golden_dir):
     close(pos14, f7["pos14"], 2e-5, 1e-5)
     close(Rr, f7["R_ret"], 1e-6, 1e-5)
     close(tr, f7["t_ret"], 2e-5, 1e-5)
+
+
+def test_reconstruct_backbone(golden_dir):
+    """pepflow/modules/common/geometry.py:reconstruct_backbone incl. a chain break, a numbering gap, a masked tail, UNK (golden F9)."""
+    f9 = load(golden_dir, "f9_backbone.npz")
+    d = np.load(os.path.join(os.path.dirname(__file__), "..", "pepflowww_amd", "data", "rigid_groups.npz"))
+    tab = {k: torch.from_numpy(d[k]) for k in ("bb_coords", "bb_oxygen")}
+    out = O.reconstruct_backbone(f9["R"], f9["t"], f9["aa"], f9["chain_nb"], f9["res_nb"], f9["mask"], tab)
+    close(out, f9["pos4"], 2e-5, 1e-5)

@@ -19,6 +19,7 @@ from pepflow.modules.protein import constants as K  # noqa: E402
 tab = dict(rotation=K.restype_rigid_group_rotation.float(), translation=K.restype_rigid_group_translation.float(),
            atom14_group=K.restype_heavyatom_to_rigid_group.long(), atom14_position=K.restype_heavyatom_rigid_group_positions.float(),
            heavyatom_mask=T.restype_to_heavyatom_masks, torsions_mask=T.torsions_mask,
+           bb_coords=K.backbone_atom_coordinates_tensor.float(), bb_oxygen=K.bb_oxygen_coordinate_tensor.float(),
            frames=torch.tensor([K.PSI_FRAME, K.CHI1_FRAME, K.CHI2_FRAME, K.CHI3_FRAME, K.CHI4_FRAME]))
 names = [[K.restype_to_heavyatom_names[K.AA(i)][j] if i < 21 else "" for j in range(15)] for i in range(22)]
 resnames = [str(K.AA(i)) for i in range(21)] + ["UNK"]
@@ -56,3 +57,17 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "f7_full_atom.npz"),
                     R=R.numpy(), t=t.numpy(), ang=ang.numpy(), aa=aa.numpy(), pos14=pos14.numpy(), R_ret=Rr.numpy(), t_ret=tr.numpy(),
                     mask=mask.numpy())
 print("pos14", tuple(pos14.shape), float(pos14.abs().max()))
+
+# golden F9: reconstruct_backbone (pepflow/modules/common/geometry.py:446-489) incl. a chain break, a masked tail and UNK
+from pepflow.modules.common.geometry import reconstruct_backbone  # noqa: E402
+chain_nb = torch.tensor([[1] * 13 + [0] * 8, [1] * 21, [0] * 10 + [1] * 11])
+res_nb = torch.cat([torch.arange(1, 14), torch.arange(1, 9)])[None].repeat(3, 1)
+res_nb[1] = torch.arange(1, 22)
+res_nb[1, 7:] += 2                                        # gap inside a chain
+res_nb[2] = torch.cat([torch.arange(1, 11), torch.arange(5, 16)])
+rmask = torch.ones(B, L, dtype=torch.bool)
+rmask[2, 17:] = False
+bb = reconstruct_backbone(R, t, aa, chain_nb, res_nb, rmask)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "f9_backbone.npz"), R=R.numpy(), t=t.numpy(), aa=aa.numpy(),
+                    chain_nb=chain_nb.numpy(), res_nb=res_nb.numpy(), mask=rmask.numpy(), pos4=bb.numpy())
+print("backbone", tuple(bb.shape), float(bb.abs().max()))
