@@ -5,7 +5,7 @@ TAG=${1:-v3}; cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 for W in cfg2 cfg4; do
   for C in FETCH_SIZE WRITE_SIZE; do
     OUT=gpurun_out/pt_${W}_$C; rm -rf $OUT
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --workload $W > $OUT.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --workload $W > $OUT.log 2>&1
   done
 done
 python - "$TAG" <<'PY'
