@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 29
+#define PF_ABI_VERSION 30
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -144,15 +144,19 @@ typedef struct {
     const float* head_w;           /* [8] raw (softplus applied inside) */
     float* feats;                  /* [B*L,1536] */
     int B, L;
-    /* optional: sqrt(1/3) (W_b z + b_b) precomputed per pair [B*L*L, 8] by the producer of z
-     * (pf_edge_transition_fwd, bias_out): the bias pass over z is skipped, z is read once. */
+    /* optional: sqrt(1/3) (W_b z + b_b) precomputed per pair, [B,8,L,L] (head-major), by the producer of z
+     * (pf_edge_transition_fwd bias_out, or pf_pair_bias_fwd): the bias pass over z is skipped, z is read once. */
     const float* bias;
-    /* optional (training forward): the attention probabilities [B,8,L,L] are also written out (saved for the backward) */
+    /* optional: the attention probabilities [B,8,L,L] are written here (the training backward keeps them).
+     * With BOTH bias and p_out set and L <= 256 the two-kernel form runs (csrc/ipa_split.hip: scores per (sample, head),
+     * then one streaming pass over z); otherwise the one-kernel form (csrc/ipa_attn.hip). */
     float* p_out;
+    int variant;                   /* 0 = automatic; 1 = force the one-kernel form; 2 = demand the two-kernel form (error if impossible) */
+    int head_group;                /* one-kernel form: 0 = head-group split by size; 2 / 4 / 8 = that variant */
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
- * sampler steps -> computed once per sample() call): bias [B*L*L, 8] = sqrt(1/3)(linear_b(z)), ipa_pytorch.py:393-404 */
+ * sampler steps -> computed once per sample() call): bias [B,8,L,L] = sqrt(1/3)(linear_b(z)), ipa_pytorch.py:393-404 */
 int pf_pair_bias_fwd(const float* z, const float* w_b, const float* b_b, float* bias, int B, int L, pf_stream_t stream);
 
 /* ---- sequence-transformer attention core (torch.nn.MultiheadAttention inside
@@ -257,7 +261,7 @@ typedef struct {
      * (csrc/edge_transition_v3.hip) and w1z_f16 / w2_f16 / wf_f16 may be NULL. */
     const void* w_stream;
     /* optional (persistent kernel only): also emit the NEXT block's IPA pair bias sqrt(1/3)(W_b z' + b_b)
-     * from the normalised, masked z' while it is still in registers: bias_out [B*L*L, 8], wb_frags = linear_b
+     * from the normalised, masked z' while it is still in registers: bias_out [B,8,L,L] (head-major), wb_frags = linear_b
      * of the next block as 2 split-precision fragment pairs (pepflowww_amd.engine.pack_bias_frags), bb = its bias [8]. */
     float* bias_out; const void* wb_frags; const float* bb;
     /* optional (persistent kernel only; all three or none): the training forward keeps what the backward needs --

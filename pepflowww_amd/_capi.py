@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -38,7 +38,8 @@ class IpaPointsArgs(C.Structure):
 class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
-                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp)]
+                ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp),
+                ("variant", _i), ("head_group", _i)]
 
 
 class InputMixerArgs(C.Structure):

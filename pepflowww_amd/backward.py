@@ -407,6 +407,12 @@ class IpaBlock:
         ia.head_w, ia.feats, ia.B, ia.L = W[p + "head_weights"].data_ptr(), feats.data_ptr(), B, L
         P = torch.empty(B, 8, L, L, device=dev)                # attention probabilities, saved for the backward
         ia.p_out = P.data_ptr()
+        # pair bias sqrt(1/3)(W_b z + b_b) [B,8,L,L] in its own pass: with it the two-kernel attention runs (z is then read once
+        # by the attention instead of twice)
+        pbias = torch.empty(B, 8, L, L, device=dev)
+        _capi.check(lib.pf_pair_bias_fwd(z.data_ptr(), W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(),
+                                         pbias.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
+        ia.bias = pbias.data_ptr()
         _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
         out = row_mask_(linear_fwd(feats, W[p + "linear_out.weight"], W[p + "linear_out.bias"]), self.mask)
         self.saved = dict(s=s, z=z, rot=rot, trans=trans, proj=proj, qp=qp, kp=kp, vp=vp, feats=feats, P=P)

@@ -421,12 +421,13 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             if (valid && g < 2) {
                 const float4 bb = *reinterpret_cast<const float4*>(Cs + 320 + 4 * g);
                 const float s13 = 0.57735026918962576f;   // sqrt(1/3), ipa_pytorch.py:404
-                float4 ob;
-                ob.x = s13 * ((bm[0] + bm2[0]) + (bc[0] + bc2[0]) * LOI + bb.x);
-                ob.y = s13 * ((bm[1] + bm2[1]) + (bc[1] + bc2[1]) * LOI + bb.y);
-                ob.z = s13 * ((bm[2] + bm2[2]) + (bc[2] + bc2[2]) * LOI + bb.z);
-                ob.w = s13 * ((bm[3] + bm2[3]) + (bc[3] + bc2[3]) * LOI + bb.w);
-                *reinterpret_cast<float4*>(a.bias_out + pidx * 8 + 4 * g) = ob;
+                // [B,8,L,L] head-major: the 16 lanes of a group write 64 contiguous bytes of one (head, row i)
+                float* bo = a.bias_out + (((size_t)tl.b * 8 + 4 * g) * L + i) * L + j;
+                const size_t hs = (size_t)L * L;
+                bo[0] = s13 * ((bm[0] + bm2[0]) + (bc[0] + bc2[0]) * LOI + bb.x);
+                bo[hs] = s13 * ((bm[1] + bm2[1]) + (bc[1] + bc2[1]) * LOI + bb.y);
+                bo[2 * hs] = s13 * ((bm[2] + bm2[2]) + (bc[2] + bc2[2]) * LOI + bb.z);
+                bo[3 * hs] = s13 * ((bm[3] + bm2[3]) + (bc[3] + bc2[3]) * LOI + bb.w);
             }
         }
         PROF3(14);

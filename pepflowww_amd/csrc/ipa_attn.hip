@@ -169,25 +169,12 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
     if (a.bias) {
         // ---- phase A': the producer of z already emitted sqrt(1/3)(W_b z + b_b) per pair ([B*L*L, 8]): copy this
         //      workgroup's heads into the score tile; z is then read only once (pair-value pass) ----
-        constexpr int Q4 = HG >= 4 ? HG / 4 : 1;      // float4 (or float2 for HG = 2) groups per pair
-        for (int idx = tid; idx < TI * LP * Q4; idx += NTH) {
-            const int q = idx % Q4, pj = idx / Q4;
-            const int j = pj % LP, ti = pj / LP;
+        // (bias layout [B,8,L,L], head-major: the layout the two-kernel form reads rows of; this one-kernel fallback gathers)
+        for (int idx = tid; idx < TI * HG * LP; idx += NTH) {
+            const int j = idx % LP, rr = idx / LP;
+            const int hh = rr % HG, ti = rr / HG;
             const int i = i0 + ti;
-            if (j < L && i < L) {
-                const float* bp = a.bias + ((rowb + i) * L + j) * 8 + h0 + 4 * q;
-                if constexpr (HG >= 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(bp);
-                    S[(ti * HG + 4 * q + 0) * LDS_S + j] = v.x; S[(ti * HG + 4 * q + 1) * LDS_S + j] = v.y;
-                    S[(ti * HG + 4 * q + 2) * LDS_S + j] = v.z; S[(ti * HG + 4 * q + 3) * LDS_S + j] = v.w;
-                } else {
-                    const float2 v = *reinterpret_cast<const float2*>(bp);
-                    S[(ti * HG + 0) * LDS_S + j] = v.x; S[(ti * HG + 1) * LDS_S + j] = v.y;
-                }
-            } else if (j < LP) {
-#pragma unroll
-                for (int h = 0; h < (HG >= 4 ? 4 : 2); ++h) S[(ti * HG + (HG >= 4 ? 4 * q : 0) + h) * LDS_S + j] = 0.f;
-            }
+            S[(ti * HG + hh) * LDS_S + j] = (j < L && i < L) ? a.bias[(((size_t)b * H + h0 + hh) * L + i) * L + j] : 0.f;
         }
     } else if constexpr (HG >= 4) {
         // ---- phase A: pair bias sqrt(1/3)(W_b z + b_b) as a [pairs x 64] x [64 x heads] GEMM on fp32 MFMA:
@@ -669,7 +656,7 @@ int launch_attn(const pf_ipa_attn_args& a, hipStream_t s) {
 
 // sqrt(1/3)(W_b z + b_b) per pair for a pair tensor that does not come out of EdgeTransition (block 0: the encoder's
 // edge_embed is constant over the sampler steps, so this runs ONCE per sample() call, not per step); one thread per pair
-__global__ __launch_bounds__(256) void pair_bias_kernel(const float* z, const float* w_b, const float* b_b, float* bias, long long npairs) {
+__global__ __launch_bounds__(256) void pair_bias_kernel(const float* z, const float* w_b, const float* b_b, float* bias, long long npairs, long long LL) {
     __shared__ float W[8 * 64 + 8];
     for (int i = threadIdx.x; i < 8 * 64 + 8; i += 256) W[i] = i < 512 ? w_b[i] : b_b[i - 512];
     __syncthreads();
@@ -687,15 +674,15 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* z, const fl
             acc[h] += W[h * 64 + 4 * c4] * v.x + W[h * 64 + 4 * c4 + 1] * v.y + W[h * 64 + 4 * c4 + 2] * v.z + W[h * 64 + 4 * c4 + 3] * v.w;
     }
     const float s13 = 0.57735026918962576f;
-    float4* o = reinterpret_cast<float4*>(bias + p * 8);
-    o[0] = make_float4(s13 * acc[0], s13 * acc[1], s13 * acc[2], s13 * acc[3]);
-    o[1] = make_float4(s13 * acc[4], s13 * acc[5], s13 * acc[6], s13 * acc[7]);
+    const long long bb = p / LL, ij = p - bb * LL;               // [B,8,L,L]: consecutive pairs -> consecutive floats per head
+#pragma unroll
+    for (int h = 0; h < 8; ++h) bias[(bb * 8 + h) * LL + ij] = s13 * acc[h];
 }
 
 extern "C" int pf_pair_bias_fwd(const float* z, const float* w_b, const float* b_b, float* bias, int B, int L, pf_stream_t stream) {
     if (!z || !w_b || !b_b || !bias || B <= 0 || L <= 0) return PF_E_BADARG;
     const long long np = (long long)B * L * L;
-    hipLaunchKernelGGL(pair_bias_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, w_b, b_b, bias, np);
+    hipLaunchKernelGGL(pair_bias_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, w_b, b_b, bias, np, (long long)L * L);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -709,6 +696,8 @@ extern "C" int pf_ipa_points_fwd(const pf_ipa_points_args* a, pf_stream_t stream
     return 0;
 }
 
+int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s);      // ipa_split.hip
+
 extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     if (!a || !a->proj || !a->qp || !a->kp || !a->vp || !a->z || !a->rot || !a->trans || !a->mask || !a->w_b ||
         !a->b_b || !a->w_dz || !a->b_dz || !a->head_w || !a->feats || a->B <= 0 || a->L <= 0 || a->ldp < PF_IPA_PROJ ||
@@ -718,14 +707,17 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     // S[16][HG][L] tile does not fit the 160 KiB LDS falls through to the next smaller HG (L <= ~290 / 600 / 1200)
     const long qt = (long)a->B * ((a->L + TI - 1) / TI);
     hipStream_t s = (hipStream_t)stream;
+    // two-kernel form (scores per (sample, head) + one streaming pass over z): whenever the caller supplies the pair bias and
+    // a probability buffer; a->variant == 1 forces the one-kernel form below (kept for L > 256 and for callers without buffers)
+    if (a->bias && a->p_out && a->L <= 256 && a->variant != 1) return pf_ipa_split_launch(a, s);
+    if (a->variant == 2) return PF_E_BADARG;                 // two-kernel form demanded but not possible
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
-    static const int nw8 = [] { const char* e = getenv("PF_IPA_NW"); return e ? atoi(e) : 8; }();
-    static const int force_hg = [] { const char* e = getenv("PF_IPA_HG"); return e ? atoi(e) : 0; }();   // dev: force a variant
+    const int force_hg = a->head_group;                      // 0 = by size; 2 / 4 / 8 = that head-group variant (tests)
     if (force_hg == 4) return launch_attn<4, 4>(*a, s);
     if (force_hg == 2) return launch_attn<2, 4>(*a, s);
     if (qt >= 256 || force_hg == 8) {
-        const int rc = nw8 == 8 ? launch_attn<8, 8>(*a, s) : launch_attn<8, 4>(*a, s);
+        const int rc = launch_attn<8, 8>(*a, s);
         if (rc != PF_E_TOOLARGE) return rc;
     }
     if (qt >= 128) { const int rc = launch_attn<4, 4>(*a, s); if (rc != PF_E_TOOLARGE) return rc; }

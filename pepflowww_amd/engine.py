@@ -214,8 +214,9 @@ class DenoiseEngine:
         self.quat, self.rot, self.trans = e(rows, 4), e(rows, 9), e(rows, 3)
         self.n64, self.pre = e(rows, 64), e(rows, 512)
         self.zbuf = e(B, L, L, 64)
-        self.pair_bias = e(B, L, L, 8)          # sqrt(1/3)(W_b z + b_b) of the next IPA block, written by EdgeTransition
-        self.pair_bias0 = e(B, L, L, 8)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
+        self.pair_bias = e(B, 8, L, L)          # sqrt(1/3)(W_b z + b_b) of the next IPA block (head-major), written by EdgeTransition
+        self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
+        self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -297,6 +298,7 @@ class DenoiseEngine:
             ia.w_dz, ia.b_dz = w[f"{b}.down_z.w"].data_ptr(), w[f"{b}.down_z.b"].data_ptr()
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
             ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
+            ia.p_out = self.attn_p.data_ptr()
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----

@@ -97,7 +97,9 @@ def rigid_update(quat, rot, trans, upd, mask):
     return qo, ro, to
 
 
-def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None):
+def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0):
+    """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
+    variant=1); head_group: force a head-group split of the one-kernel form."""
     lib = _capi.load()
     rows = B * L
     d = proj.device
@@ -112,6 +114,8 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.w_b, ia.b_b, ia.w_dz, ia.b_dz, ia.head_w = _p(w_b), _p(b_b), _p(w_dz), _p(b_dz), _p(head_w)
     ia.feats, ia.B, ia.L = _p(feats), B, L
     ia.bias = _p(bias)
+    ia.p_out = _p(p_out)
+    ia.variant, ia.head_group = variant, head_group
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
@@ -132,7 +136,7 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
     if next_bias is not None:                 # (linear_b.weight [8,64], linear_b.bias [8]) of the next IPA block
         from pepflowww_amd.engine import pack_bias_frags
         wbf = pack_bias_frags(next_bias[0])
-        bias = torch.full((z.shape[0], 8), float("nan"), device=z.device)
+        bias = torch.full((B, 8, L, L), float("nan"), device=z.device)
         a.bias_out, a.wb_frags, a.bb = _p(bias), _p(wbf), _p(next_bias[1])
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()

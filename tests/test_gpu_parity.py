@@ -203,34 +203,66 @@ def test_seq_attention_core(B, L):
 
 
 # ------------------------------------------------------------------ module level (golden F2)
-def _ipa_run(sd, pfx, s, z, R, x, mask, B, L, with_bias=False):
+def _ipa_run(sd, pfx, s, z, R, x, mask, B, L, form="fused", head_group=0):
+    """form: 'fused' one kernel, bias computed in-kernel | 'fused_bias' one kernel, bias supplied | 'split' two kernels."""
     g = lambda k: cu(sd[pfx + k])
     wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
     bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
     proj = G.linear(cu(s.reshape(B * L, 128)), cu(wproj), cu(bproj))
+    bias = p_out = None
+    if form != "fused":            # [B,8,L,L] head-major
+        bias = cu((math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"])).reshape(B, L, L, 8).permute(0, 3, 1, 2))
+    if form == "split":
+        p_out = torch.full((B, 8, L, L), float("nan"), device=G.dev())
     feats, pts = G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)),
                              g("linear_b.weight"), g("linear_b.bias"), g("down_z.weight"), g("down_z.bias"),
-                             g("head_weights"), B, L,
-                             bias=cu(math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"]).reshape(-1, 8))
-                             if with_bias else None)
+                             g("head_weights"), B, L, bias=bias, p_out=p_out, variant=2 if form == "split" else 1, head_group=head_group)
     out = G.linear(feats, g("linear_out.weight"), g("linear_out.bias"))
     return feats, out
 
 
-@pytest.mark.parametrize("with_bias", [False, True])
-def test_ipa_block(f2, seeded_sd, with_bias):
-    """with_bias: the pair bias arrives precomputed (as EdgeTransition emits it for blocks >= 1), z read once."""
+@pytest.mark.parametrize("form,head_group", [("fused", 0), ("fused_bias", 0), ("split", 0), ("fused", 8), ("fused_bias", 8), ("fused", 4), ("fused_bias", 4)])
+def test_ipa_block(f2, seeded_sd, form, head_group):
+    """One IPA block against the reference (golden F2 ipa0_out) and per output slice against the oracle, in every form the
+    launcher can pick: two kernels (scores + pair aggregation), and the one-kernel form in its 2- / 4- / 8-head-group variants
+    (normally chosen by batch size; forced here through pf_ipa_attn_args.head_group)."""
     b = _batch(f2)
     B, L = b["aa"].shape
     mask = b["res_mask"].float()
     pfx = "ga_encoder.trunk.ipa_0."
-    feats, out = _ipa_run(seeded_sd, pfx, f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask, B, L, with_bias)
+    feats, out = _ipa_run(seeded_sd, pfx, f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask, B, L, form, head_group)
     valid = mask.reshape(-1).bool()
     G.assert_close(out.cpu()[valid], f2["ipa0_out"].reshape(B * L, 128)[valid], REL, "IPA block vs reference")
     ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], f2["s_in"], f2["enc_edge"], f2["R_t"], f2["x_t"], mask)
     fr, fg = ref_feats.reshape(B * L, -1)[valid], feats.cpu()[valid]
     for name, sl in (("o", slice(0, 1024)), ("o_pt", slice(1024, 1312)), ("norm", slice(1312, 1408)), ("o_pair", slice(1408, 1536))):
         G.assert_close(fg[:, sl], fr[:, sl], REL, f"IPA feats[{name}] vs oracle")
+
+
+@pytest.mark.parametrize("B,L", [(1, 3), (2, 37), (3, 64), (1, 130), (2, 145), (1, 256), (1, 300)])
+def test_ipa_forms_agree_on_ragged_shapes(seeded_sd, B, L):
+    """Two-kernel form vs one-kernel form vs oracle on lengths that are not multiples of 4 / 16, padding inside a sample, the
+    three register-tile variants of the score kernel (L <= 64 / 128 / 256) and L > 256 (one-kernel fallback)."""
+    g = torch.Generator().manual_seed(100 * B + L)
+    pfx = "ga_encoder.trunk.ipa_2."
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    mask[-1, L - max(1, L // 5):] = 0
+    if L > 4:
+        mask[0, 2] = 0
+    ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], s, z, R, x, mask)
+    valid = mask.reshape(-1).bool()
+    feats = {}
+    for form in (("split",) if L <= 256 else ()) + ("fused_bias",):
+        feats[form], _ = _ipa_run(seeded_sd, pfx, s, z, R, x, mask, B, L, form)
+        G.assert_close(feats[form].cpu()[valid], ref_feats.reshape(B * L, -1)[valid], REL, f"{form} feats vs oracle")
+    if L > 256:          # the automatic choice must fall back instead of failing
+        with pytest.raises(_capi.PepflowHipError):
+            _ipa_run(seeded_sd, pfx, s, z, R, x, mask, B, L, "split")
 
 
 def _et_run(sd, pfx, s, z, mask, B, L, persistent=True):
@@ -277,7 +309,7 @@ def test_edge_transition_emits_next_pair_bias(f2, seeded_sd):
     em = (mask[:, None, :] * mask[:, :, None])[..., None]
     zref = f2["et0_out"] * em
     G.assert_close(out.view(B, L, L, 64), zref, REL, "z'")
-    G.assert_close(bias.view(B, L, L, 8), math.sqrt(1.0 / 3.0) * F.linear(zref, wb, bb), REL, "next block's pair bias")
+    G.assert_close(bias, (math.sqrt(1.0 / 3.0) * F.linear(zref, wb, bb)).permute(0, 3, 1, 2), REL, "next block's pair bias [B,8,L,L]")
 
 
 @pytest.mark.parametrize("persistent", [True, False])

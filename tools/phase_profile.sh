@@ -3,7 +3,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/pfprof/lib
-for f in selftest linear edge_transition edge_transition_v3 ipa_attn node_ops flow_step encode node_track train_fwd backward ipa_bwd full_atom; do
+for f in selftest linear edge_transition edge_transition_v3 ipa_attn ipa_split node_ops flow_step encode node_track train_fwd backward ipa_bwd full_atom; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPF_PROFILE -c $R/pepflowww_amd/csrc/$f.hip -o /tmp/pfprof/lib/$f.o &
 done
 wait

@@ -11,24 +11,31 @@ PASSES=(
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_MISC"
  "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_WAVES GRBM_GUI_ACTIVE"
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
 )
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-graph --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-secondary "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python - "$OUT" "$K" <<'PY'
 import csv, glob, sys, collections
-out, kern = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(list)
+out, kerns = sys.argv[1], sys.argv[2].split(",")          # several kernels (comma separated) share the passes
+rows = []
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        if kern in row["Kernel_Name"]:
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    rows += list(csv.DictReader(open(f)))
 with open(out + ".txt", "w") as fh:
-    for k in sorted(acc):
-        v = acc[k]
-        line = f"{k:36s} mean/launch {sum(v)/len(v):16.1f}   n={len(v)}"
-        print(line); fh.write(line + "\n")
+    for kern in kerns:
+        acc = collections.defaultdict(list)
+        for row in rows:
+            if kern in row["Kernel_Name"]:
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        fh.write(f"== {kern}\n"); print("==", kern)
+        for k in sorted(acc):
+            v = acc[k]
+            line = f"{k:36s} mean/launch {sum(v)/len(v):16.1f}   n={len(v)}"
+            print(line); fh.write(line + "\n")
 PY
 find $OUT -name "*kernel_trace*" -delete; find $OUT -name "*.csv" -size +4M -delete
