@@ -19,7 +19,7 @@
 #include "../../include/pepflow_hip.h"
 
 #ifdef PF_PROFILE
-__device__ long long g_prof_ipa[64];
+__device__ long long g_prof_ipa[64];      // [0..7] one-kernel form, [16..22] ipa_scores_kernel (ipa_split.hip)
 #define PROF(i) do { if (blockIdx.x == gridDim.x / 2 + 3 && threadIdx.x == 0) g_prof_ipa[i] = clock64(); } while (0)
 extern "C" int pf_debug_prof_ipa(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_ipa), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
@@ -709,8 +709,12 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     // two-kernel form (scores per (sample, head) + one streaming pass over z): whenever the caller supplies the pair bias and
     // a probability buffer; a->variant == 1 forces the one-kernel form below (kept for L > 256 and for callers without buffers)
-    if (a->bias && a->p_out && a->L <= 256 && a->variant != 1) return pf_ipa_split_launch(a, s);
-    if (a->variant == 2) return PF_E_BADARG;                 // two-kernel form demanded but not possible
+    // Measured (rocprofv3, profiles/r02): B=64, L=128: 190 us (scores 112 + pair 78) vs 198 us one-kernel; B=16, L=64: 31.5 us
+    // vs 29.0 us -- so the two-kernel form is the default from 256 query tiles up (where the one-kernel form would run its
+    // 8-head variant), or whenever the training path asks for the probabilities (p_out without the small-batch exception).
+    const bool can_split = a->bias && a->p_out && a->L <= 256;
+    if (a->variant == 2 && !can_split) return PF_E_BADARG;   // two-kernel form demanded but not possible
+    if (can_split && (a->variant == 2 || (a->variant == 0 && qt >= 256))) return pf_ipa_split_launch(a, s);
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
     const int force_hg = a->head_group;                      // 0 = by size; 2 / 4 / 8 = that head-group variant (tests)

@@ -29,7 +29,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     raw = C.CDLL(_capi.LIB_PATH)
     out = (C.c_longlong * 64)()
-    for sym, n in (("pf_debug_prof", 13), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_et3", 40)):
+    for sym, n in (("pf_debug_prof", 13), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 7), ("pf_debug_prof_et3", 40)):
         getattr(raw, sym)(out, 64)
         v = list(out)
         print(sym, "stamps (cycles rel.):", [x - v[0] for x in v[:n]])
