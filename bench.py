@@ -77,7 +77,7 @@ def make_batch(wl, first):
     from pepflowww_amd import synth
     if wl.get("variable"):
         lens, peps = variable_lengths(wl["B"], seed=114514 + first)
-        L = max(lens)
+        L = (max(lens) + 15) // 16 * 16          # padded to a multiple of 16, as FlowModel.sample() does internally
         items = [synth.make_pocket_batch(1, L, peps[i], seed=114514 + first + i, lengths=[lens[i]]) for i in range(wl["B"])]
         batch = {k: torch.cat([it[k] for it in items], 0) for k in items[0]}
         return batch, wl["B"], L, sum(lens)

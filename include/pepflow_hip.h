@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 30
+#define PF_ABI_VERSION 31
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -79,6 +79,7 @@ typedef struct {
      * and are not stored to y: each point goes through the residue frame, R p + t (rigid_utils.py:1124-1150 via
      * ipa_pytorch.py:360-388), straight into qp [M,192] / kp [M,192] / vp [M,288] (what pf_ipa_points_fwd produces). */
     const float* pt_rot; const float* pt_trans; float* pt_qp; float* pt_kp; float* pt_vp; int pt_col0;
+    int single_pass;                /* split path, 4-wave form only: 1 = f16 precision mode (one f16 MFMA per product, hi planes only) */
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 /* W [N,K] fp32 (ldw) -- or W^T when `transpose` (then w is [K,N], ldw >= N) -- to the fragment-order f16 hi/lo planes
@@ -267,6 +268,9 @@ typedef struct {
     /* optional (persistent kernel only; all three or none): the training forward keeps what the backward needs --
      * dump_h1 / dump_h2 [B*L*L,192] = relu(W1 x + b1), relu(W2 h1 + b2); dump_y [B*L*L,64] = the pre-LayerNorm output */
     float* dump_h1; float* dump_h2; float* dump_y;
+    /* persistent kernel only: 1 = f16 precision mode -- ONE f16 MFMA per product (hi planes only) instead of the three of the
+     * fp32-parity mode; fp32 accumulation, LayerNorm and storage unchanged.  Not combinable with the dumps. */
+    int single_pass;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 

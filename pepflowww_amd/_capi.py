@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -22,7 +22,8 @@ class LinearArgs(C.Structure):
                 ("M", _i), ("N", _i), ("K", _i), ("relu", _i), ("row_mask", _fp), ("mask_pre", _i),
                 ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("ln_eps", C.c_float), ("w_f16", _fp), ("gate", _fp), ("ldg", _i),
-                ("pt_rot", _fp), ("pt_trans", _fp), ("pt_qp", _fp), ("pt_kp", _fp), ("pt_vp", _fp), ("pt_col0", _i)]
+                ("pt_rot", _fp), ("pt_trans", _fp), ("pt_qp", _fp), ("pt_kp", _fp), ("pt_vp", _fp), ("pt_col0", _i),
+                ("single_pass", _i)]
 
 
 class EmbedArgs(C.Structure):
@@ -60,7 +61,8 @@ class RigidUpdateArgs(C.Structure):
 class EdgeTransitionArgs(C.Structure):
     _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1z_f16", _fp), ("w2_f16", _fp), ("b2", _fp), ("wf_f16", _fp),
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
-                ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp)]
+                ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp),
+                ("single_pass", _i)]
 
 
 class SamplerArgs(C.Structure):

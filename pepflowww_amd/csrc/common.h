@@ -301,7 +301,7 @@ struct WPre {
 // their use anyway -- and the row tiles fed two at a time): lets the 6-/8-wave whole-row Linear fit 128 VGPRs, i.e. 4 waves per
 // SIMD, so that two of its workgroups ALWAYS fit a CU (6 waves land 2,2,1,1 on the SIMDs: at 3 waves per SIMD a second
 // workgroup only fits when the dispatcher happens to rotate it the right way).
-template <int WT, int PT>
+template <int WT, int PT, bool SP = false>
 __device__ __forceinline__ void gemm_split_lowreg(const void* planes, int N, int Kw, int n0, int K,
                                                   const _Float16* Xh, const _Float16* Xl, int ldx,
                                                   f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT]) {
@@ -318,7 +318,7 @@ __device__ __forceinline__ void gemm_split_lowreg(const void* planes, int N, int
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) {
             bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)st * 512);
-            bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)st * 512);
+            if constexpr (!SP) bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)st * 512);
         }
 #pragma unroll
         for (int p0 = 0; p0 < PT; p0 += 2) {
@@ -326,25 +326,28 @@ __device__ __forceinline__ void gemm_split_lowreg(const void* planes, int N, int
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 ah[q] = *reinterpret_cast<const half8*>(xh + (p0 + q) * 16 * ldx + 32 * st);
-                al[q] = *reinterpret_cast<const half8*>(xl + (p0 + q) * 16 * ldx + 32 * st);
+                if constexpr (!SP) al[q] = *reinterpret_cast<const half8*>(xl + (p0 + q) * 16 * ldx + 32 * st);
             }
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) am[wt][p0 + q] = mfma_h(bh[wt], ah[q], am[wt][p0 + q]);
+            if constexpr (!SP) {
 #pragma unroll
-            for (int wt = 0; wt < WT; ++wt)
+                for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) ac[wt][p0 + q] = mfma_h(bh[wt], al[q], ac[wt][p0 + q]);
+                    for (int q = 0; q < 2; ++q) ac[wt][p0 + q] = mfma_h(bh[wt], al[q], ac[wt][p0 + q]);
 #pragma unroll
-            for (int wt = 0; wt < WT; ++wt)
+                for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) ac[wt][p0 + q] = mfma_h(bl[wt], ah[q], ac[wt][p0 + q]);
+                    for (int q = 0; q < 2; ++q) ac[wt][p0 + q] = mfma_h(bl[wt], ah[q], ac[wt][p0 + q]);
+            }
         }
     }
 }
 
-template <int WT, int PT, bool SWZ = false>
+// SP ("single pass", the f16 precision mode): hi planes only, one MFMA per product
+template <int WT, int PT, bool SWZ = false, bool SP = false>
 __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, int n0, int K,
                                            const _Float16* Xh, const _Float16* Xl, int ldx,
                                            f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT], const WPre<WT>* pre = nullptr) {
@@ -362,7 +365,7 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
         if (pre) { bh[wt] = pre->h[wt]; bl[wt] = pre->l[wt]; }
         else {
             bh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride);
-            bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
+            if constexpr (!SP) bl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride);
         }
     }
     const int nst = K >> 5;
@@ -371,14 +374,14 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt) {
                 nh[wt] = *reinterpret_cast<const half8*>(wh + wt * tstride + (size_t)(st + 1) * 512);
-                nl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)(st + 1) * 512);
+                if constexpr (!SP) nl[wt] = *reinterpret_cast<const half8*>(wl + wt * tstride + (size_t)(st + 1) * 512);
             }
         }
         half8 ah[PT], al[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             ah[pt] = *reinterpret_cast<const half8*>(xh + pt * 16 * ldx + 32 * st);
-            al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + 32 * st);
+            if constexpr (!SP) al[pt] = *reinterpret_cast<const half8*>(xl + pt * 16 * ldx + 32 * st);
         }
         // three passes: the two MFMAs that accumulate into acc_corr are WT*PT instructions apart (no back-to-back
         // dependency on one accumulator)
@@ -386,16 +389,18 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
         for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) am[wt][pt] = mfma_h(bh[wt], ah[pt], am[wt][pt]);
+        if constexpr (!SP) {
 #pragma unroll
-        for (int wt = 0; wt < WT; ++wt)
+            for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
+                for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
 #pragma unroll
-        for (int wt = 0; wt < WT; ++wt)
+            for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
+                for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
+        }
 #pragma unroll
-        for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; bl[wt] = nl[wt]; }
+        for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; if constexpr (!SP) bl[wt] = nl[wt]; }
     }
 }
 

@@ -67,20 +67,28 @@ __device__ __forceinline__ void stage_barrier() {
 #define GLDS4(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 4, 0, 0)
 
 struct Frag { half8 h, l; };
+// SP ("single pass", the f16 precision mode): only the hi planes exist for the arithmetic -- one MFMA per product instead of
+// three, no lo fragment reads, no lo conversions; fp32 accumulation, LayerNorm and storage as in the fp32-parity mode
+template <bool SP>
 __device__ __forceinline__ Frag ldfrag(const unsigned char* slot, int kf, int lane) {
     Frag f;
     f.h = *reinterpret_cast<const half8*>(slot + kf * KF + lane * 16);
-    f.l = *reinterpret_cast<const half8*>(slot + kf * KF + 1024 + lane * 16);
+    if constexpr (!SP) f.l = *reinterpret_cast<const half8*>(slot + kf * KF + 1024 + lane * 16);
     return f;
 }
 // two independent (main, corr) accumulator pairs per call; the two MFMAs into one corr accumulator are 4 issue slots apart
+template <bool SP>
 __device__ __forceinline__ void mac2(const Frag& w0, const Frag& w1, half8 xh, half8 xl, f32x4& m0, f32x4& c0, f32x4& m1, f32x4& c1) {
-    c0 = mfma_h(w0.h, xl, c0);
-    c1 = mfma_h(w1.h, xl, c1);
+    if constexpr (!SP) {
+        c0 = mfma_h(w0.h, xl, c0);
+        c1 = mfma_h(w1.h, xl, c1);
+    }
     m0 = mfma_h(w0.h, xh, m0);
     m1 = mfma_h(w1.h, xh, m1);
-    c0 = mfma_h(w0.l, xh, c0);
-    c1 = mfma_h(w1.l, xh, c1);
+    if constexpr (!SP) {
+        c0 = mfma_h(w0.l, xh, c0);
+        c1 = mfma_h(w1.l, xh, c1);
+    }
 }
 __device__ __forceinline__ half8 cat4(half4 a, half4 b) {
     half8 o;
@@ -105,21 +113,29 @@ __device__ __forceinline__ void split4f(const float (&v)[4], half4& hi, half4& l
 #define SPLIT4 split4
 #define JOIN(m, c) ((m) + (c) * LOI)
 #endif
+template <bool SP>
 __device__ __forceinline__ void split8(const float4& a, const float4& b, half8& hi, half8& lo) {
-    const float v0[4] = {a.x, a.y, a.z, a.w}, v1[4] = {b.x, b.y, b.z, b.w};
-    half4 h0, l0, h1, l1;
-    SPLIT4(v0, h0, l0);
-    SPLIT4(v1, h1, l1);
-    hi = cat4(h0, h1);
-    lo = cat4(l0, l1);
+    if constexpr (SP) {
+        hi[0] = (_Float16)a.x; hi[1] = (_Float16)a.y; hi[2] = (_Float16)a.z; hi[3] = (_Float16)a.w;
+        hi[4] = (_Float16)b.x; hi[5] = (_Float16)b.y; hi[6] = (_Float16)b.z; hi[7] = (_Float16)b.w;
+        lo = hi;                                                   // (never used)
+    } else {
+        const float v0[4] = {a.x, a.y, a.z, a.w}, v1[4] = {b.x, b.y, b.z, b.w};
+        half4 h0, l0, h1, l1;
+        SPLIT4(v0, h0, l0);
+        SPLIT4(v1, h1, l1);
+        hi = cat4(h0, h1);
+        lo = cat4(l0, l1);
+    }
 }
+template <bool SP> __device__ __forceinline__ float joinsp(float m, float c) { if constexpr (SP) return m; else return JOIN(m, c); }
 __device__ __forceinline__ f32x4 add4(const float4& a, const float4& b) { return (f32x4){a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
 struct Tile { int b, i0, j0; };
 
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
-template <bool DUMP>
+template <bool DUMP, bool SP>
 __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
                 for (int s = 0; s < 2; ++s) {
                     const float4 q0 = *reinterpret_cast<const float4*>(zs + 16 * ((8 * s + 2 * g) ^ r));
                     const float4 q1 = *reinterpret_cast<const float4*>(zs + 16 * ((8 * s + 2 * g + 1) ^ r));
-                    split8(q0, q1, zh[s], zl[s]);
+                    split8<SP>(q0, q1, zh[s], zl[s]);
                 }
                 mk = mkb[wave] * mkb[8 + r];
             }
@@ -284,23 +300,23 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             f32x4 m1 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp + 16), *reinterpret_cast<const float4*>(ce + 32 * tp + 16));
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
             // fragment reads run one K-step ahead of the MFMAs (within a ring stage)
-            if (tp == 0 || tp == 4) { ga0 = ldfrag(sl, kf0, lane); gb0 = ldfrag(sl, kf0 + 2, lane); }
-            const Frag ga1 = ldfrag(sl, kf0 + 1, lane), gb1 = ldfrag(sl, kf0 + 3, lane);
-            mac2(ga0, gb0, zh[0], zl[0], m0, c0, m1, c1);
-            if (tp != 3 && tp != 5) { ga0 = ldfrag(sl, kf0 + 4, lane); gb0 = ldfrag(sl, kf0 + 6, lane); }
-            mac2(ga1, gb1, zh[1], zl[1], m0, c0, m1, c1);
+            if (tp == 0 || tp == 4) { ga0 = ldfrag<SP>(sl, kf0, lane); gb0 = ldfrag<SP>(sl, kf0 + 2, lane); }
+            const Frag ga1 = ldfrag<SP>(sl, kf0 + 1, lane), gb1 = ldfrag<SP>(sl, kf0 + 3, lane);
+            mac2<SP>(ga0, gb0, zh[0], zl[0], m0, c0, m1, c1);
+            if (tp != 3 && tp != 5) { ga0 = ldfrag<SP>(sl, kf0 + 4, lane); gb0 = ldfrag<SP>(sl, kf0 + 6, lane); }
+            mac2<SP>(ga1, gb1, zh[1], zl[1], m0, c0, m1, c1);
             float4 v0, v1;
-            v0.x = fmaxf(JOIN(m0[0], c0[0]), 0.f); v0.y = fmaxf(JOIN(m0[1], c0[1]), 0.f);
-            v0.z = fmaxf(JOIN(m0[2], c0[2]), 0.f); v0.w = fmaxf(JOIN(m0[3], c0[3]), 0.f);
-            v1.x = fmaxf(JOIN(m1[0], c1[0]), 0.f); v1.y = fmaxf(JOIN(m1[1], c1[1]), 0.f);
-            v1.z = fmaxf(JOIN(m1[2], c1[2]), 0.f); v1.w = fmaxf(JOIN(m1[3], c1[3]), 0.f);
+            v0.x = fmaxf(joinsp<SP>(m0[0], c0[0]), 0.f); v0.y = fmaxf(joinsp<SP>(m0[1], c0[1]), 0.f);
+            v0.z = fmaxf(joinsp<SP>(m0[2], c0[2]), 0.f); v0.w = fmaxf(joinsp<SP>(m0[3], c0[3]), 0.f);
+            v1.x = fmaxf(joinsp<SP>(m1[0], c1[0]), 0.f); v1.y = fmaxf(joinsp<SP>(m1[1], c1[1]), 0.f);
+            v1.z = fmaxf(joinsp<SP>(m1[2], c1[2]), 0.f); v1.w = fmaxf(joinsp<SP>(m1[3], c1[3]), 0.f);
             if constexpr (DUMP) {
                 if (valid) {
                     *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 4 * g) = v0;
                     *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 16 + 4 * g) = v1;
                 }
             }
-            split8(v0, v1, h1h[tp], h1l[tp]);
+            split8<SP>(v0, v1, h1h[tp], h1l[tp]);
         }
         PROF3(5);
         {   // z part of the final layer (stage 1, fragment pairs 8..15): acc3[t] = d_i + e_j + Wf[:, :64] z  (bf folded into e)
@@ -312,10 +328,10 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const Frag w0 = ldfrag(sl, 8 + s, lane), w1 = ldfrag(sl, 10 + s, lane);
-                const Frag w2 = ldfrag(sl, 12 + s, lane), w3 = ldfrag(sl, 14 + s, lane);
-                mac2(w0, w1, zh[s], zl[s], m3[0], c3[0], m3[1], c3[1]);
-                mac2(w2, w3, zh[s], zl[s], m3[2], c3[2], m3[3], c3[3]);
+                const Frag w0 = ldfrag<SP>(sl, 8 + s, lane), w1 = ldfrag<SP>(sl, 10 + s, lane);
+                const Frag w2 = ldfrag<SP>(sl, 12 + s, lane), w3 = ldfrag<SP>(sl, 14 + s, lane);
+                mac2<SP>(w0, w1, zh[s], zl[s], m3[0], c3[0], m3[1], c3[1]);
+                mac2<SP>(w2, w3, zh[s], zl[s], m3[2], c3[2], m3[3], c3[3]);
             }
         }
         PROF3(6);
@@ -332,21 +348,21 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             f32x4 m0 = {b0.x, b0.y, b0.z, b0.w}, m1 = {b1.x, b1.y, b1.z, b1.w};      // accumulators start at b2
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
             Frag wa[2], wb[2];                 // fragment reads run one K-step ahead of the MFMAs that use them
-            wa[0] = ldfrag(sl, 0, lane);
-            wb[0] = ldfrag(sl, 6, lane);
+            wa[0] = ldfrag<SP>(sl, 0, lane);
+            wb[0] = ldfrag<SP>(sl, 6, lane);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 if (k < 5) {
-                    wa[(k + 1) & 1] = ldfrag(sl, k + 1, lane);
-                    wb[(k + 1) & 1] = ldfrag(sl, 7 + k, lane);
+                    wa[(k + 1) & 1] = ldfrag<SP>(sl, k + 1, lane);
+                    wb[(k + 1) & 1] = ldfrag<SP>(sl, 7 + k, lane);
                 }
-                mac2(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, c0, m1, c1);
+                mac2<SP>(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, c0, m1, c1);
             }
             float4 v0, v1;
-            v0.x = fmaxf(JOIN(m0[0], c0[0]), 0.f); v0.y = fmaxf(JOIN(m0[1], c0[1]), 0.f);
-            v0.z = fmaxf(JOIN(m0[2], c0[2]), 0.f); v0.w = fmaxf(JOIN(m0[3], c0[3]), 0.f);
-            v1.x = fmaxf(JOIN(m1[0], c1[0]), 0.f); v1.y = fmaxf(JOIN(m1[1], c1[1]), 0.f);
-            v1.z = fmaxf(JOIN(m1[2], c1[2]), 0.f); v1.w = fmaxf(JOIN(m1[3], c1[3]), 0.f);
+            v0.x = fmaxf(joinsp<SP>(m0[0], c0[0]), 0.f); v0.y = fmaxf(joinsp<SP>(m0[1], c0[1]), 0.f);
+            v0.z = fmaxf(joinsp<SP>(m0[2], c0[2]), 0.f); v0.w = fmaxf(joinsp<SP>(m0[3], c0[3]), 0.f);
+            v1.x = fmaxf(joinsp<SP>(m1[0], c1[0]), 0.f); v1.y = fmaxf(joinsp<SP>(m1[1], c1[1]), 0.f);
+            v1.z = fmaxf(joinsp<SP>(m1[2], c1[2]), 0.f); v1.w = fmaxf(joinsp<SP>(m1[3], c1[3]), 0.f);
             half8 xh, xl;
             if constexpr (DUMP) {
                 if (valid) {
@@ -354,10 +370,10 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
                     *reinterpret_cast<float4*>(a.dump_h2 + pidx * 192 + 32 * c + 16 + 4 * g) = v1;
                 }
             }
-            split8(v0, v1, xh, xl);
-            const Frag w0 = ldfrag(sl, 12, lane), w1 = ldfrag(sl, 13, lane), w2 = ldfrag(sl, 14, lane), w3 = ldfrag(sl, 15, lane);
-            mac2(w0, w1, xh, xl, m3[0], c3[0], m3[1], c3[1]);
-            mac2(w2, w3, xh, xl, m3[2], c3[2], m3[3], c3[3]);
+            split8<SP>(v0, v1, xh, xl);
+            const Frag w0 = ldfrag<SP>(sl, 12, lane), w1 = ldfrag<SP>(sl, 13, lane), w2 = ldfrag<SP>(sl, 14, lane), w3 = ldfrag<SP>(sl, 15, lane);
+            mac2<SP>(w0, w1, xh, xl, m3[0], c3[0], m3[1], c3[1]);
+            mac2<SP>(w2, w3, xh, xl, m3[2], c3[2], m3[3], c3[3]);
         }
         PROF3(13);
         slot = (slot + 1 == NSLOT) ? 0 : slot + 1;           // slot of the next tile's stage 0
@@ -366,10 +382,10 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         float y[16];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            y[4 * t + 0] = JOIN(m3[t][0], c3[t][0]);
-            y[4 * t + 1] = JOIN(m3[t][1], c3[t][1]);
-            y[4 * t + 2] = JOIN(m3[t][2], c3[t][2]);
-            y[4 * t + 3] = JOIN(m3[t][3], c3[t][3]);
+            y[4 * t + 0] = joinsp<SP>(m3[t][0], c3[t][0]);
+            y[4 * t + 1] = joinsp<SP>(m3[t][1], c3[t][1]);
+            y[4 * t + 2] = joinsp<SP>(m3[t][2], c3[t][2]);
+            y[4 * t + 3] = joinsp<SP>(m3[t][3], c3[t][3]);
         }
         if constexpr (DUMP) {
             if (valid) {
@@ -409,15 +425,13 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             const unsigned char* wb = smem + OFF_WB;
             f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bc = bm, bm2 = bm, bc2 = bm;
             half8 oh0, ol0, oh1, ol1;
-            split8(o4[0], o4[1], oh0, ol0);
-            split8(o4[2], o4[3], oh1, ol1);
-            const Frag f0 = ldfrag(wb, 0, lane), f1 = ldfrag(wb, 1, lane);
-            bc = mfma_h(f0.h, ol0, bc);
-            bc2 = mfma_h(f1.h, ol1, bc2);
+            split8<SP>(o4[0], o4[1], oh0, ol0);
+            split8<SP>(o4[2], o4[3], oh1, ol1);
+            const Frag f0 = ldfrag<SP>(wb, 0, lane), f1 = ldfrag<SP>(wb, 1, lane);
+            if constexpr (!SP) { bc = mfma_h(f0.h, ol0, bc); bc2 = mfma_h(f1.h, ol1, bc2); }
             bm = mfma_h(f0.h, oh0, bm);
             bm2 = mfma_h(f1.h, oh1, bm2);
-            bc = mfma_h(f0.l, oh0, bc);
-            bc2 = mfma_h(f1.l, oh1, bc2);
+            if constexpr (!SP) { bc = mfma_h(f0.l, oh0, bc); bc2 = mfma_h(f1.l, oh1, bc2); }
             if (valid && g < 2) {
                 const float4 bb = *reinterpret_cast<const float4*>(Cs + 320 + 4 * g);
                 const float s13 = 0.57735026918962576f;   // sqrt(1/3), ipa_pytorch.py:404
@@ -449,16 +463,19 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
     const int grid = (int)(nt < ncu ? nt : ncu);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
         attr_set = true;
     }
     if (a->dump_h1 || a->dump_h2 || a->dump_y) {
-        if (!a->dump_h1 || !a->dump_h2 || !a->dump_y) return PF_E_BADARG;
-        hipLaunchKernelGGL(edge_transition_v3_kernel<true>, dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+        if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass) return PF_E_BADARG;
+        hipLaunchKernelGGL((edge_transition_v3_kernel<true, false>), dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    } else if (a->single_pass) {
+        hipLaunchKernelGGL((edge_transition_v3_kernel<false, true>), dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
     } else {
-        hipLaunchKernelGGL(edge_transition_v3_kernel<false>, dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+        hipLaunchKernelGGL((edge_transition_v3_kernel<false, false>), dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
     }
     PF_CHECK_LAUNCH();
     return 0;

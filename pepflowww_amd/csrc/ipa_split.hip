@@ -289,10 +289,9 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 // instructions per row and thread): 77 - 82 us, PMC: VALU 50 % busy (a plain VALU instruction costs ~4 cycles per wave here),
 // waves parked 59 % of their cycles; a persistent variant with next-row prefetch and 3 workgroups per CU: 102 us.
 constexpr int ZW = 4;
-constexpr int ZG = 8;                          // key groups (float4 loads) per wave per batch: 4 waves x 8 groups x 4 keys = 128 keys
-template <int NB>                              // batches of 128 keys per row (L <= 128 NB)
+template <int NG>                              // key groups (4 keys = one float4 load per lane) per wave: 16 NG >= L, NG = 1..16
 __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
-    constexpr int LPZ = NB * 128;
+    constexpr int LPZ = 16 * NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -302,14 +301,12 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     const long row = blockIdx.x;                                 // b * L + i
     const long b = row / L, i = row - b * L;
     const float* zrow = a.z + (size_t)row * L * 64 + 4 * r;
-    float4 zq[NB][ZG];
+    float4 zq[NG];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int u = 0; u < ZG; ++u) {
-            const int j = 4 * (4 * (nb * ZG + u) + wave) + g;    // key group s = 4 (nb ZG + u) + wave
-            zq[nb][u] = *reinterpret_cast<const float4*>(zrow + (size_t)min(j, L - 1) * 64);
-        }
+    for (int u = 0; u < NG; ++u) {
+        const int j = 4 * (4 * u + wave) + g;                    // key group s = 4 u + wave
+        zq[u] = *reinterpret_cast<const float4*>(zrow + (size_t)min(j, L - 1) * 64);
+    }
     // down_z weights of the epilogue (wave 0: B operand W_dz[d = r][c = 4 s + g]) requested now, not at the end: the first version
     // fetched them in the epilogue, a ~1 us dependent round trip per workgroup after the last barrier -- with the scalar GEMV it cost
     // 19 of the kernel's 68 us (tools/dev/stream_bench.hip rebuilds the kernel stage by stage)
@@ -337,15 +334,13 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     const float* pl = PL + (r & 7) * LPZ + g;
     const float keep = r < 8 ? 1.f : 0.f;                        // MFMA rows 8..15 are padding
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int u = 0; u < ZG; ++u) {
-            const float pa = pl[4 * (4 * (nb * ZG + u) + wave)] * keep;
-            zacc[0] = mfma16(pa, zq[nb][u].x, zacc[0]);
-            zacc[1] = mfma16(pa, zq[nb][u].y, zacc[1]);
-            zacc[2] = mfma16(pa, zq[nb][u].z, zacc[2]);
-            zacc[3] = mfma16(pa, zq[nb][u].w, zacc[3]);
-        }
+    for (int u = 0; u < NG; ++u) {
+        const float pa = pl[4 * (4 * u + wave)] * keep;
+        zacc[0] = mfma16(pa, zq[u].x, zacc[0]);
+        zacc[1] = mfma16(pa, zq[u].y, zacc[1]);
+        zacc[2] = mfma16(pa, zq[u].z, zacc[2]);
+        zacc[3] = mfma16(pa, zq[u].w, zacc[3]);
+    }
     // D: lane (r = column within tile, g), register e -> head 4 g + e; column (tile ct, r) <-> channel 4 r + ct
     if (g < 2) {
         float* zb = ZBAR + wave * H * 64;
@@ -407,12 +402,17 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         PF_CHECK_LAUNCH();
     }
     if (rc) return rc;
-    const int nb = (L + 127) / 128;                              // batches of 128 keys
-    const size_t lds = ((size_t)8 * nb * 128 + ZW * 8 * 64) * sizeof(float);
+    const int ng = (L + 15) / 16;                                // key groups per wave
+    const size_t lds = ((size_t)8 * 16 * ng + ZW * 8 * 64) * sizeof(float);
     const long rows = (long)a->B * L;
-    if (nb > 2 || rows > 0x7fffffffL) return PF_E_TOOLARGE;
-    if (nb == 1) hipLaunchKernelGGL(ipa_pair_kernel<1>, dim3((unsigned)rows), dim3(64 * ZW), lds, s, *a);
-    else hipLaunchKernelGGL(ipa_pair_kernel<2>, dim3((unsigned)rows), dim3(64 * ZW), lds, s, *a);
+    if (ng > 16 || rows > 0x7fffffffL) return PF_E_TOOLARGE;
+    const dim3 grid((unsigned)rows), blk(64 * ZW);
+    switch (ng) {
+#define PF_PAIR_CASE(N) case N: hipLaunchKernelGGL(ipa_pair_kernel<N>, grid, blk, lds, s, *a); break;
+        PF_PAIR_CASE(1) PF_PAIR_CASE(2) PF_PAIR_CASE(3) PF_PAIR_CASE(4) PF_PAIR_CASE(5) PF_PAIR_CASE(6) PF_PAIR_CASE(7) PF_PAIR_CASE(8)
+        PF_PAIR_CASE(9) PF_PAIR_CASE(10) PF_PAIR_CASE(11) PF_PAIR_CASE(12) PF_PAIR_CASE(13) PF_PAIR_CASE(14) PF_PAIR_CASE(15) PF_PAIR_CASE(16)
+#undef PF_PAIR_CASE
+    }
     PF_CHECK_LAUNCH();
     return 0;
 }

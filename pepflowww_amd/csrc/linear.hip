@@ -180,7 +180,7 @@ int launch(const pf_linear_args& a, hipStream_t s) {
 // whole output row (N <= 256) fits one workgroup: the x tile is then read and converted ONCE instead of once per
 // 128-feature block (the pair-sized [B*L*L,192] -> 192 products of the training path read x twice otherwise).
 constexpr int SP_BM = 64;
-template <int NWV>
+template <int NWV, bool SP = false>
 __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p, int Npad) {
     constexpr int SP_BN = 32 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -222,9 +222,14 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                     const float keep = (m0 + row < p.M) ? 1.f : 0.f;
                     const float v[4] = {t[u].x * keep, t[u].y * keep, t[u].z * keep, t[u].w * keep};
                     half4 hi, lo;
-                    split4(v, hi, lo);
-                    *reinterpret_cast<half4*>(Xh + row * LDK + 4 * c4) = hi;
-                    *reinterpret_cast<half4*>(Xl + row * LDK + 4 * c4) = lo;
+                    if constexpr (SP) {
+                        hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+                        *reinterpret_cast<half4*>(Xh + row * LDK + 4 * c4) = hi;
+                    } else {
+                        split4(v, hi, lo);
+                        *reinterpret_cast<half4*>(Xh + row * LDK + 4 * c4) = hi;
+                        *reinterpret_cast<half4*>(Xl + row * LDK + 4 * c4) = lo;
+                    }
                 }
             }
         }
@@ -246,13 +251,13 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     acc_zero<2, 4>(am);
     acc_zero<2, 4>(ac);
     if (n0 + 16 < Npad) {
-        if (NWV > 4) gemm_split_lowreg<2, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
-        else gemm_split<2, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
+        if (NWV > 4) gemm_split_lowreg<2, 4, SP>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
+        else gemm_split<2, 4, false, SP>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
     } else {                                           // last feature tile of a ragged N: one tile only
         f32x4 bm[1][4], bc[1][4];
         acc_zero<1, 4>(bm);
         acc_zero<1, 4>(bc);
-        gemm_split<1, 4>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, bm, bc);
+        gemm_split<1, 4, false, SP>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, bm, bc);
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) { am[0][pt] = bm[0][pt]; ac[0][pt] = bc[0][pt]; }
     }
@@ -368,14 +373,15 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        static const int wide = [] { const char* e = getenv("PF_LS_WIDE"); return e ? atoi(e) : 1; }();
-        const unsigned gm = wide ? (a->M + SP_BM - 1) / SP_BM : 0;
+        const unsigned gm = (a->M + SP_BM - 1) / SP_BM;
         if (Npad > 128 && Npad <= 192 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<6>, dim3(gm, 1), dim3(384), lds, s, *a, Npad);
         else if (Npad > 192 && Npad <= 256 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<8>, dim3(gm, 1), dim3(512), lds, s, *a, Npad);
+        else if (a->single_pass) hipLaunchKernelGGL((linear_split_kernel<4, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         else hipLaunchKernelGGL(linear_split_kernel<4>, dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         PF_CHECK_LAUNCH();
         return 0;

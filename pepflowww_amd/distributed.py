@@ -115,9 +115,10 @@ def seeded_noise(lo, hi, L, seed):
 def _final_state_of(smp):
     eng = smp.eng
     B, L, last = eng.B, eng.L, smp.N - 1
-    return pack_state({"rotmats": smp.traj_rot[last].view(B, L, 9), "trans": smp.traj_trans[last].view(B, L, 3),
-                       "angles": smp.traj_ang[last].view(B, L, 5), "seqs_simplex": smp.traj_simplex[last].view(B, L, 20),
-                       "seqs": smp.traj_seq[last].view(B, L)})
+    Lo = getattr(smp, "L_out", L)                      # (FlowModel.sample pads the residue axis to x16 internally)
+    return pack_state({"rotmats": smp.traj_rot[last].view(B, L, 9)[:, :Lo], "trans": smp.traj_trans[last].view(B, L, 3)[:, :Lo],
+                       "angles": smp.traj_ang[last].view(B, L, 5)[:, :Lo], "seqs_simplex": smp.traj_simplex[last].view(B, L, 20)[:, :Lo],
+                       "seqs": smp.traj_seq[last].view(B, L)[:, :Lo]})
 
 
 @torch.no_grad()

@@ -11,6 +11,32 @@ from .sampler import DeviceSampler, default_noise
 from .train_forward import TrainForward, default_train_noise
 
 MAX_NUM_HEAVYATOMS = 15     # pepflow/modules/protein/constants.py:91
+_PAD_AA = 21                # constants.PAD_RESIDUE_INDEX (pepflow/utils/data.py:9-13)
+
+
+def _pad_residues(batch, noise, L0, L):
+    """Pad every per-residue tensor of the batch ([B, L0, ...]) and of the pre-drawn noise to L residues the way PaddingCollate
+    pads (zeros; aa -> 21; masks False).  Index plumbing only."""
+    import torch.nn.functional as F
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == L0:
+            pad = [0, 0] * (v.dim() - 2) + [0, L - L0]
+            out[k] = F.pad(v, pad, value=_PAD_AA if k == "aa" else 0)
+        else:
+            out[k] = v
+    nz = {}
+    for k, v in noise.items():
+        if v is None:
+            nz[k] = None
+        elif k == "expo":                                # [2N, B, L0, 20]; padded draws are never used (1.0 keeps p / E finite)
+            nz[k] = F.pad(v, (0, 0, 0, L - L0), value=1.0)
+        elif k == "rot0":                                # [B, L0, 3, 3]: identity frames on the padding
+            eye = torch.eye(3, dtype=v.dtype, device=v.device).expand(v.shape[0], L - L0, 3, 3)
+            nz[k] = torch.cat([v, eye], 1)
+        else:
+            nz[k] = F.pad(v, [0, 0] * (v.dim() - 2) + [0, L - L0])
+    return out, nz
 
 
 class FlowModel(nn.Module):
@@ -73,16 +99,23 @@ class FlowModel(nn.Module):
         use_graph    replay one captured hipGraph per step (default) or launch eagerly."""
         _capi.load()
         dev = batch["aa"].device
-        B, L = batch["aa"].shape
+        B, L0 = batch["aa"].shape
+        if noise is None:
+            if seed is None:
+                noise = default_noise(B, L0)          # torch's global CPU generator, like the reference (flow_model.py:252-277)
+            else:                                      # explicit seed: per-global-sample streams (shard == slice of the full run)
+                from .distributed import seeded_noise
+                noise = seeded_noise(first_sample, first_sample + B, L0, seed)
+        # Residue axis padded to a multiple of 16 internally (what PaddingCollate does to a shorter sample of a batch: pad values,
+        # res_mask False -- padded residues are inert, tests/test_gpu_parity.py ragged cases): every kernel then runs its
+        # full-tile path (16-row / 16-key tiles, float4 rows of the [B,8,L,L] buffers).  In-kernel random draws are keyed by
+        # (sample, residue), so the padding does not move any stream.  Outputs are cut back to L0.
+        L = (L0 + 15) // 16 * 16
+        if L != L0:
+            batch, noise = _pad_residues(batch, noise, L0, L)
         R1, x1, ang1, seq1, node, edge = self.encode(batch)
         eng = self.ga_encoder.engine(B, L, dev)
         eng.bind_context(node, edge, batch["res_mask"])
-        if noise is None:
-            if seed is None:
-                noise = default_noise(B, L)           # torch's global CPU generator, like the reference (flow_model.py:252-277)
-            else:                                      # explicit seed: per-global-sample streams (shard == slice of the full run)
-                from .distributed import seeded_noise
-                noise = seeded_noise(first_sample, first_sample + B, L, seed)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         smp = DeviceSampler(eng, num_steps, (sample_bb, sample_ang, sample_seq), first_sample, seed)
@@ -91,6 +124,7 @@ class FlowModel(nn.Module):
         eng.run()
         smp.init_state(noise)
         smp.run(num_steps, use_graph=use_graph)
+        smp.L_out = L0
         if return_sampler:
             return smp
         return smp.trajectory()

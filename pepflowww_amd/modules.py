@@ -172,11 +172,18 @@ class GAEncoder(nn.Module):
     def _param_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def set_precision(self, precision):
+        """'fp32' (default: reference parity 1e-4) or 'f16' (BASELINE configs[2]: single-pass f16 MFMA products in
+        EdgeTransition and the IPA projection; see DenoiseEngine)."""
+        assert precision in ("fp32", "f16"), precision
+        self._precision = precision
+
     def engine(self, B, L, device):
-        key = (B, L, str(device), self._param_version())
+        prec = getattr(self, "_precision", "fp32")
+        key = (B, L, str(device), self._param_version(), prec)
         if self._engine is None or self._engine_key != key:
             sd = {"ga_encoder." + k: v for k, v in self.state_dict().items()}
-            self._engine = DenoiseEngine(PackedWeights(sd, device), B, L, device)
+            self._engine = DenoiseEngine(PackedWeights(sd, device), B, L, device, precision=prec)
             self._engine_key = key
         return self._engine
 

@@ -134,12 +134,13 @@ class DeviceSampler:
     def trajectory(self):
         """One D2H copy -> list of num_steps dicts of CPU tensors (flow_model.py:313-314,371-374)."""
         B, L, N = self.eng.B, self.eng.L, self.N
-        rot = self.traj_rot.cpu().view(N, B, L, 3, 3)
-        trans = self.traj_trans.cpu().view(N, B, L, 3)
-        ang = self.traj_ang.cpu().view(N, B, L, 5)
-        seq = self.traj_seq.cpu().view(N, B, L)
-        sx = self.traj_simplex.cpu().view(N, B, L, 20)
-        R1, x1 = self.rot1.cpu().view(B, L, 3, 3), self.trans1.cpu().view(B, L, 3)
-        a1, s1 = self.ang1.cpu().view(B, L, 5), self.seq1.cpu().view(B, L)
+        Lo = getattr(self, "L_out", L)                 # FlowModel.sample pads the residue axis to x16 internally: cut back
+        rot = self.traj_rot.cpu().view(N, B, L, 3, 3)[:, :, :Lo]
+        trans = self.traj_trans.cpu().view(N, B, L, 3)[:, :, :Lo]
+        ang = self.traj_ang.cpu().view(N, B, L, 5)[:, :, :Lo]
+        seq = self.traj_seq.cpu().view(N, B, L)[:, :, :Lo]
+        sx = self.traj_simplex.cpu().view(N, B, L, 20)[:, :, :Lo]
+        R1, x1 = self.rot1.cpu().view(B, L, 3, 3)[:, :Lo], self.trans1.cpu().view(B, L, 3)[:, :Lo]
+        a1, s1 = self.ang1.cpu().view(B, L, 5)[:, :Lo], self.seq1.cpu().view(B, L)[:, :Lo]
         return [{"rotmats": rot[i], "trans": trans[i], "angles": ang[i], "seqs": seq[i], "seqs_simplex": sx[i],
                  "rotmats_1": R1, "trans_1": x1, "angles_1": a1, "seqs_1": s1} for i in range(N)]

@@ -167,7 +167,7 @@ def test_cfg3_variable_length_batch(model, seeded_sd):
     import bench
     wl = bench.WORKLOADS["cfg3"]
     batch, B, L, n_real = bench.make_batch(wl, 0)
-    assert B == 64 and 48 <= min(batch["res_mask"].sum(1)) and L <= 145 and n_real < B * L
+    assert B == 64 and 48 <= min(batch["res_mask"].sum(1)) and L <= 160 and L % 16 == 0 and n_real < B * L
     NS = 2
     noise = synth.make_noise(B, L, NS, seed=11)
     dbatch = {k: cu(v) for k, v in batch.items()}
@@ -178,7 +178,7 @@ def test_cfg3_variable_length_batch(model, seeded_sd):
     for b in pick:
         ref = _oracle_chunk(seeded_sd, batch, noise, b, b + 1, NS)
         n = int(lens[b])
-        sl = {k: [{kk: vv[b:b + 1, :n] for kk, vv in t.items()} for t in tr] for k, tr in (("a", traj), )}["a"]
+        sl = [{kk: vv[b:b + 1, :n] for kk, vv in t.items()} for t in traj]
         rf = [{kk: vv[:, :n] for kk, vv in t.items()} for t in ref]
         _compare_traj(sl, rf, 0, 1, NS, f"sample {b} (length {n})")
     # f16 single-pass products: same inputs, same draws
