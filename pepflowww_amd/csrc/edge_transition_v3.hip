@@ -41,10 +41,14 @@ namespace {
 
 constexpr int NCW = 8;                        // consumer waves = rows i of a tile
 constexpr int TJ = 16;                        // columns j of a tile
-constexpr int KF = 2048;                      // bytes of one fragment pair: hi 1 KiB | lo 1 KiB
-constexpr int STAGE_B = 16 * KF;              // 32 KiB ring stage = 16 fragment pairs
+constexpr int KF = 2048;                      // bytes of one fragment pair in the packed stream: hi 1 KiB | lo 1 KiB
+constexpr int STAGE_B = 16 * KF;              // 32 KiB stream / ring stage = 16 fragment pairs
 constexpr int NSTAGE = 8;                     // stages per tile (256 KiB of weights)
 constexpr int NSLOT = 3;
+// f16 mode (SP): the ring holds hi fragments only -- 16 KiB stages, 4 slots (stage in use + 3 stages of run-ahead)
+template <bool SP> constexpr int KFB = SP ? 1024 : KF;              // bytes of a fragment (pair) in the LDS ring
+template <bool SP> constexpr int STG = 16 * KFB<SP>;                // bytes of a ring stage
+template <bool SP> constexpr int NSL = SP ? 4 : NSLOT;
 constexpr int CE_STRIDE = 1056;               // bytes between c|e rows in LDS (1 KiB + 32: conflict-free b128 reads)
 constexpr int CE_PIECES = 17;                 // ceil(16 * 1056 / 1024)
 // LDS map (bytes)
@@ -72,7 +76,7 @@ struct Frag { half8 h, l; };
 template <bool SP>
 __device__ __forceinline__ Frag ldfrag(const unsigned char* slot, int kf, int lane) {
     Frag f;
-    f.h = *reinterpret_cast<const half8*>(slot + kf * KF + lane * 16);
+    f.h = *reinterpret_cast<const half8*>(slot + kf * KFB<SP> + lane * 16);
     if constexpr (!SP) f.l = *reinterpret_cast<const half8*>(slot + kf * KF + 1024 + lane * 16);
     return f;
 }
@@ -136,7 +140,7 @@ struct Tile { int b, i0, j0; };
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
 template <bool DUMP, bool SP>
-__global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
+__global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
     float* Cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -164,12 +168,65 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
     __syncthreads();
 
     if (wave == NCW) {
-        // ------------------- loader wave: weight stream -> LDS ring; next tile's z / pre / masks -> LDS -------------------
+        // ------------------- weight loader wave: weight stream -> LDS ring (LDS-DMA) -------------------
+        // (The tile inputs have their own loader wave below: with both in one wave the in-order vmcnt made every weight stage
+        //  wait for the HBM round trip of the z rows issued before it -- in the f16 mode, where a stage is ~0.5 us of consumer
+        //  work, the kernel ran at the loader's pace: PMC 57 % of all wave cycles parked, 263 us per launch at B=64, L=128.)
         const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w_stream) + lane * 16;
-        auto issue_w = [&](int stage, int slot, int k0, int k1) {
+        if constexpr (SP) {
+            // hi KiB of fragment pair k of a stage -> dense 16 KiB ring stage; three stages of run-ahead (48 pieces <= 63)
+            auto issue_w = [&](int stage, int slot) {
 #pragma unroll
-            for (int k = k0; k < k1; ++k) GLDS16(wsrc + stage * STAGE_B + k * 1024, ring + slot * STAGE_B + k * 1024);
-        };
+                for (int k = 0; k < 16; ++k) GLDS16(wsrc + stage * STAGE_B + k * KF, ring + slot * STG<true> + k * 1024);
+            };
+            issue_w(0, 0);
+            if (total_stages > 1) issue_w(1 % NSTAGE, 1);
+            if (total_stages > 2) issue_w(2 % NSTAGE, 2);
+            if (total_stages > 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (total_stages > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stage 0 complete
+            int st_next = 3 % NSTAGE, slot_next = 3;
+            for (int gs = 0; gs < total_stages; ++gs) {
+                stage_barrier();                                   // consumers: start stage gs; they are done with gs - 1
+                if (gs + 3 < total_stages) {
+                    issue_w(st_next, slot_next);
+                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // stage gs + 1 complete; gs + 2, gs + 3 may be in flight
+                    st_next = (st_next + 1 == NSTAGE) ? 0 : st_next + 1;
+                    slot_next = (slot_next + 1 == 4) ? 0 : slot_next + 1;
+                } else if (gs + 2 < total_stages) {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+        } else {
+            auto issue_w = [&](int stage, int slot, int k0, int k1) {
+#pragma unroll
+                for (int k = k0; k < k1; ++k) GLDS16(wsrc + stage * STAGE_B + k * 1024, ring + slot * STAGE_B + k * 1024);
+            };
+            issue_w(0, 0, 0, 32);
+            issue_w(1, 1, 0, 16);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // stage 0 complete
+            issue_w(1, 1, 16, 32);
+            int st_next = 2 % NSTAGE, slot_next = 2 % NSLOT;           // stream stage / ring slot of global stage gs + 2
+            for (int gs = 0; gs < total_stages; ++gs) {
+                // here: stage gs and everything issued before its last 16 pieces have landed
+                stage_barrier();                                       // consumers: start stage gs; they are done with gs - 1
+                if (gs + 2 < total_stages) {
+                    issue_w(st_next, slot_next, 0, 16);
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage gs + 1 complete
+                    issue_w(st_next, slot_next, 16, 32);
+                    st_next = (st_next + 1 == NSTAGE) ? 0 : st_next + 1;
+                    slot_next = (slot_next + 1 == NSLOT) ? 0 : slot_next + 1;
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+        }
+        return;
+    }
+    if (wave == NCW + 1) {
+        // ------------------- input loader wave: next tile's z rows / pre rows / masks -> LDS (LDS-DMA) -------------------
         // z piece k: consumer region k >> 2, pairs (k & 3) * 4 + (lane >> 4); 16-byte chunk q = lane & 15 of the LDS row
         // holds the global chunk q ^ pair (so that the consumers' fragment reads are bank-conflict free)
         auto issue_z = [&](const Tile& tl, int k0, int k1) {
@@ -210,44 +267,26 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             row = row < L ? row : L - 1;
             GLDS4(a.mask + tl.b * L + row, smem + OFF_MK);
         };
-
+        auto issue_all = [&](const Tile& tl) {                   // 32 + 8 + 17 + 1 = 58 pieces (the counter holds 63)
+            issue_z(tl, 0, 32);
+            issue_ad(tl);
+            issue_ce(tl, 0, CE_PIECES);
+            issue_mask(tl);
+        };
         int tile = blockIdx.x;
         Tile tl = tile_of(tile);
-        issue_z(tl, 0, 32);
-        issue_ad(tl);
-        issue_ce(tl, 0, CE_PIECES);
-        issue_mask(tl);                                            // 58 in flight (the counter holds 63)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue_w(0, 0, 0, 32);
-        issue_w(1, 1, 0, 16);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // stage 0 complete
-        issue_w(1, 1, 16, 32);
-        int st_next = 2 % NSTAGE, slot_next = 2 % NSLOT;           // stream stage / ring slot of global stage gs + 2
+        issue_all(tl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's inputs are in LDS before barrier 0
         int st_cur = 0;                                            // stage of the current tile the consumers are entering
         bool have_next = my_tiles > 1;
         if (have_next) tl = tile_of(tile + gridDim.x);
         for (int gs = 0; gs < total_stages; ++gs) {
-            // here: stage gs and everything issued before its last 16 pieces have landed
-            stage_barrier();                                       // consumers: start stage gs; they are done with gs - 1
-            if (gs + 2 < total_stages) {
-                issue_w(st_next, slot_next, 0, 16);
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage gs + 1 complete
-                issue_w(st_next, slot_next, 16, 32);
-                st_next = (st_next + 1 == NSTAGE) ? 0 : st_next + 1;
-                slot_next = (slot_next + 1 == NSLOT) ? 0 : slot_next + 1;
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            // next tile's inputs, spread over stages 2..6 (<= 13 pieces each, all complete before the next tile's first
-            // barrier): z rows were consumed right after barrier 0, pre rows / masks during stages 0-1
-            if (have_next) {
-                if (st_cur == 2) issue_z(tl, 0, 11);
-                else if (st_cur == 3) issue_z(tl, 11, 22);
-                else if (st_cur == 4) issue_z(tl, 22, 32);
-                else if (st_cur == 5) { issue_ad(tl); issue_ce(tl, 0, 5); }
-                else if (st_cur == 6) { issue_ce(tl, 5, CE_PIECES); issue_mask(tl); }
-            }
+            stage_barrier();
+            // after barrier 2 every consumer is past stages 0-1, the only readers of the z rows, pre rows and masks of the
+            // current tile: the next tile's inputs are requested now, all at once, and have five stages to land
+            if (have_next && st_cur == 2) issue_all(tl);
             if (++st_cur == NSTAGE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and are in LDS before the next tile's barrier 0
                 st_cur = 0;
                 tile += gridDim.x;
                 have_next = tile + (int)gridDim.x < ntiles;
@@ -282,7 +321,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
                 PROF3(tp == 0 ? 1 : 3);
                 stage_barrier();
                 PROF3(tp == 0 ? 2 : 4);
-                if (tp == 4) slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+                if (tp == 4) slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;
             }
             if (tp == 0) {            // this tile's z rows / mask are in LDS now
 #pragma unroll
@@ -293,7 +332,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
                 }
                 mk = mkb[wave] * mkb[8 + r];
             }
-            const unsigned char* sl = ring + slot * STAGE_B;
+            const unsigned char* sl = ring + slot * STG<SP>;
             const int kf0 = (tp < 4 ? tp * 4 : (tp - 4) * 4);         // tile 2tp: kf0, kf0+1 ; tile 2tp+1: kf0+2, kf0+3
             // accumulators start at a_i + c_j (b1 is folded into c)
             f32x4 m0 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp), *reinterpret_cast<const float4*>(ce + 32 * tp));
@@ -320,7 +359,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
         }
         PROF3(5);
         {   // z part of the final layer (stage 1, fragment pairs 8..15): acc3[t] = d_i + e_j + Wf[:, :64] z  (bf folded into e)
-            const unsigned char* sl = ring + slot * STAGE_B;
+            const unsigned char* sl = ring + slot * STG<SP>;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 m3[t] = add4(*reinterpret_cast<const float4*>(ad + 192 + 16 * t), *reinterpret_cast<const float4*>(ce + 192 + 16 * t));
@@ -341,8 +380,8 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             PROF3(7 + c);
             stage_barrier();
             PROF3(16 + c);
-            slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
-            const unsigned char* sl = ring + slot * STAGE_B;
+            slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;
+            const unsigned char* sl = ring + slot * STG<SP>;
             const float4 b0 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 4 * g);
             const float4 b1 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 16 + 4 * g);
             f32x4 m0 = {b0.x, b0.y, b0.z, b0.w}, m1 = {b1.x, b1.y, b1.z, b1.w};      // accumulators start at b2
@@ -376,7 +415,7 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             mac2<SP>(w2, w3, xh, xl, m3[2], c3[2], m3[3], c3[3]);
         }
         PROF3(13);
-        slot = (slot + 1 == NSLOT) ? 0 : slot + 1;           // slot of the next tile's stage 0
+        slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;           // slot of the next tile's stage 0
 
         // ---- LayerNorm over the 64 features (16 in this lane, the rest in lanes r + 16k), mask, store ----
         float y[16];
@@ -427,7 +466,14 @@ __global__ __launch_bounds__(64 * (NCW + 1), 1) void edge_transition_v3_kernel(p
             half8 oh0, ol0, oh1, ol1;
             split8<SP>(o4[0], o4[1], oh0, ol0);
             split8<SP>(o4[2], o4[3], oh1, ol1);
-            const Frag f0 = ldfrag<SP>(wb, 0, lane), f1 = ldfrag<SP>(wb, 1, lane);
+            // (the two linear_b fragment pairs keep the packed hi | lo layout in both modes)
+            Frag f0, f1;
+            f0.h = *reinterpret_cast<const half8*>(wb + lane * 16);
+            f1.h = *reinterpret_cast<const half8*>(wb + KF + lane * 16);
+            if constexpr (!SP) {
+                f0.l = *reinterpret_cast<const half8*>(wb + 1024 + lane * 16);
+                f1.l = *reinterpret_cast<const half8*>(wb + KF + 1024 + lane * 16);
+            }
             if constexpr (!SP) { bc = mfma_h(f0.h, ol0, bc); bc2 = mfma_h(f1.h, ol1, bc2); }
             bm = mfma_h(f0.h, oh0, bm);
             bm2 = mfma_h(f1.h, oh1, bm2);
@@ -471,11 +517,11 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
     }
     if (a->dump_h1 || a->dump_h2 || a->dump_y) {
         if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass) return PF_E_BADARG;
-        hipLaunchKernelGGL((edge_transition_v3_kernel<true, false>), dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+        hipLaunchKernelGGL((edge_transition_v3_kernel<true, false>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
     } else if (a->single_pass) {
-        hipLaunchKernelGGL((edge_transition_v3_kernel<false, true>), dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+        hipLaunchKernelGGL((edge_transition_v3_kernel<false, true>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
     } else {
-        hipLaunchKernelGGL((edge_transition_v3_kernel<false, false>), dim3((unsigned)grid), dim3(64 * (NCW + 1)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+        hipLaunchKernelGGL((edge_transition_v3_kernel<false, false>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
     }
     PF_CHECK_LAUNCH();
     return 0;
