@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 31
+#define PF_ABI_VERSION 32
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -86,6 +86,9 @@ int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
  * pf_linear_args.w_f16 expects ([2][ceil16(N)/16][K/32][64][8] f16, N zero-padded to 16): the device-side form of
  * engine.split_f16, used per step by the training path (weights change every step).  Layout only. */
 int pf_split_pack_f16(const float* w, int ldw, int N, int K, int transpose, void* out, pf_stream_t stream);
+/* the same, and *range_flag (device int, zeroed by the caller) is set to 1 if any |w| exceeds the f16 range (65504) or is not
+ * finite: the split representation cannot carry such a weight (the packed value saturates); callers treat it as an error */
+int pf_split_pack_f16_checked(const float* w, int ldw, int N, int K, int transpose, void* out, int* range_flag, pf_stream_t stream);
 
 /* ---- input mixing features: ga.py:94 (cat) + ga.py:79-85 / utils.py:60-71 (time embedding) +
  * layers.py:92-113 (AngularEncoding, 12 funcs) + nn.Embedding lookup.

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -213,6 +213,7 @@ _SIGNATURES = {
     "pf_ipa_bwd_softmax": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_bwd_points": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_headw_bwd": ([_fp, _fp, _fp, _fp], _i),
+    "pf_split_pack_f16_checked": ([_fp, _i, _i, _i, _i, _fp, _fp, _fp], _i),
     "pf_full_atom_fwd": ([C.POINTER(FullAtomArgs), _fp], _i),
     "pf_backbone_atoms_fwd": ([C.POINTER(BackboneAtomsArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),

@@ -108,6 +108,27 @@ def _grad_buffer(*shape, device):
     return torch.empty(*shape, device=device), False
 
 
+_RANGE_FLAGS = {}
+
+
+def _range_flag(device):
+    """Device int set to 1 by pf_split_pack_f16_checked when a weight leaves the f16 range of the split representation."""
+    key = str(device)
+    if key not in _RANGE_FLAGS:
+        _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _RANGE_FLAGS[key]
+
+
+def assert_weight_range(device):
+    """Raise if any weight packed since the last call was outside the f16 range (|w| <= 65504, finite).  One 4-byte D2H read:
+    called once per eager training step and at graph capture / on request for the graph-replayed step."""
+    f = _range_flag(device)
+    if int(f.item()):
+        f.zero_()
+        raise _capi.PepflowHipError("a weight left the f16 range (|w| <= 65504, finite) of the hi/lo split used by the MFMA kernels: "
+                                    "the split-precision products would saturate; rescale the layer")
+
+
 def _split_pack(w, transpose=False):
     """Fragment-order f16 hi/lo planes of W (or of W^T) for the split-precision kernel, one launch (csrc/linear.hip)."""
     if transpose:
@@ -117,7 +138,8 @@ def _split_pack(w, transpose=False):
         N, K = w.shape
     Np = (N + 15) // 16 * 16
     out = torch.empty(2 * Np * K, dtype=torch.float16, device=w.device)
-    _capi.check(_capi.load().pf_split_pack_f16(w.data_ptr(), w.shape[1], N, K, int(transpose), out.data_ptr(), _capi.stream_ptr()), "pf_split_pack_f16")
+    _capi.check(_capi.load().pf_split_pack_f16_checked(w.data_ptr(), w.shape[1], N, K, int(transpose), out.data_ptr(),
+                                                       _range_flag(w.device).data_ptr(), _capi.stream_ptr()), "pf_split_pack_f16_checked")
     return out
 
 
@@ -407,12 +429,14 @@ class IpaBlock:
         ia.head_w, ia.feats, ia.B, ia.L = W[p + "head_weights"].data_ptr(), feats.data_ptr(), B, L
         P = torch.empty(B, 8, L, L, device=dev)                # attention probabilities, saved for the backward
         ia.p_out = P.data_ptr()
-        # pair bias sqrt(1/3)(W_b z + b_b) [B,8,L,L] in its own pass: with it the two-kernel attention runs (z is then read once
-        # by the attention instead of twice)
-        pbias = torch.empty(B, 8, L, L, device=dev)
-        _capi.check(lib.pf_pair_bias_fwd(z.data_ptr(), W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(),
-                                         pbias.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
-        ia.bias = pbias.data_ptr()
+        # pair bias sqrt(1/3)(W_b z + b_b) [B,8,L,L] in its own pass when the launcher will pick the two-kernel attention (from 256
+        # query tiles up, L <= 256: z is then read once by the attention instead of twice); below that the one-kernel form
+        # computes the bias itself and the extra launch would only cost
+        if B * ((L + 15) // 16) >= 256 and L <= 256:
+            pbias = torch.empty(B, 8, L, L, device=dev)
+            _capi.check(lib.pf_pair_bias_fwd(z.data_ptr(), W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(),
+                                             pbias.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
+            ia.bias = pbias.data_ptr()
         _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
         out = row_mask_(linear_fwd(feats, W[p + "linear_out.weight"], W[p + "linear_out.bias"]), self.mask)
         self.saved = dict(s=s, z=z, rot=rot, trans=trans, proj=proj, qp=qp, kp=kp, vp=vp, feats=feats, P=P)

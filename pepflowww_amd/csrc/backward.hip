@@ -1592,8 +1592,7 @@ extern "C" int pf_add_inplace(float* dst, const float* src, long long n, pf_stre
 extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float* g_out, float* g_qkv, float* stats, int B, int L,
                                pf_stream_t stream) {
     if (!qkv || !mask || !g_out || !g_qkv || !stats || B <= 0 || L <= 0) return PF_E_BADARG;
-    static const int use_mfma = [] { const char* e = getenv("PF_SEQ_BWD_MFMA"); return e ? atoi(e) : 1; }();
-    if (use_mfma && L <= SQ_L) {
+    if (L <= SQ_L) {
         const size_t lds = ((size_t)4 * SQ_L * SQ_LDQ + SQ_L * SQ_LDX + SQ_L) * sizeof(float);
         static bool attr_m = false;
         if (!attr_m) { (void)hipFuncSetAttribute((const void*)seq_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
@@ -1698,8 +1697,8 @@ extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, i
     if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || M > 192 || N > 256) return PF_E_BADARG;
     if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    static const long long cap = [] { const char* e = getenv("PF_TN_WGS"); return e ? atoll(e) : 256LL; }();
-    static const int use_split = [] { const char* e = getenv("PF_TN_SPLIT"); return e ? atoi(e) : 1; }();
+    constexpr long long cap = 256;                  // workgroups of the whole-C kernels: one per CU
+    constexpr int use_split = 1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1710,8 +1709,7 @@ extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, i
     // the split-precision kernels take whole 32-row chunks; a ragged tail (< 32 rows) goes through the fp32 kernel
     const bool split = use_split && R >= WK;
     const long long Rm = split ? R / WK * WK : R;                   // rows of the main launch
-    static const int use_piece = [] { const char* e = getenv("PF_TN_PIECE"); return e ? atoi(e) : 0; }();
-    const bool piece = split && (use_piece || N > 192);
+    const bool piece = split && N > 192;
     const int npieces = piece ? (N + 47) / 48 : 1;
     // workgroups: the whole-C kernels one per CU; the piece kernel three per CU (768 slots shared by the pieces)
     long long nwg = (Rm + 4 * WK - 1) / (4 * WK);

@@ -191,14 +191,27 @@ constexpr float PF_LO_SCALE = 2048.f, PF_LO_INV = 1.f / 2048.f;
 __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// Range of the split representation: hi = f16(x) needs |x| <= 65504 (the largest finite f16).  Weights are checked when they are
+// packed (engine.split_f16 / pf_split_pack_f16 refuse anything larger); ACTIVATIONS saturate at +-65504 here instead of turning
+// into inf (an fp32 reference would carry on with the large value: beyond 6.5e4 the two differ, and INTEGRATION.md says so).
+// Below ~6e-8 (f16 subnormal range of hi) lo carries the value: relative precision degrades gradually towards 2^-24 absolute.
+constexpr float PF_F16_MAX = 65504.f;
+#ifndef PF_SPLIT_SATURATE
+#define PF_SPLIT_SATURATE 1
+#endif
 __device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (_Float16)v[e];
+#if PF_SPLIT_SATURATE
+        const float vc = fminf(fmaxf(v[e], -PF_F16_MAX), PF_F16_MAX);
+#else
+        const float vc = v[e];
+#endif
+        const _Float16 h = (_Float16)vc;
         hi[e] = h;
         // (v - hi) * 2048 as fma(hi, -2048, v * 2048): every term is exact in fp32, so this is bit-identical to convert /
         // subtract / scale, one instruction shorter, and the f16 -> f32 extension of hi folds into v_fma_mix
-        lo[e] = (_Float16)__builtin_fmaf((float)h, -PF_LO_SCALE, v[e] * PF_LO_SCALE);
+        lo[e] = (_Float16)__builtin_fmaf((float)h, -PF_LO_SCALE, vc * PF_LO_SCALE);
     }
 }
 __device__ __forceinline__ float join(f32x4 m, f32x4 c, int e) { return m[e] + c[e] * PF_LO_INV; }

@@ -288,12 +288,12 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
 extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream) {
     if (!a || !a->z_in || !a->z_out || !a->pre || !a->b2 || !a->ln_g || !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
         return PF_E_BADARG;
-    static const int force_tiled = [] { const char* e = getenv("PF_ET_TILE"); return e ? atoi(e) : 0; }();
-    if (a->w_stream && !force_tiled) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);
+    if (a->w_stream) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);
+    if (a->single_pass) return PF_E_BADARG;                      // the f16 mode exists in the persistent kernel only
     if (!a->w1z_f16 || !a->w2_f16 || !a->wf_f16) return PF_E_BADARG;
     const long long npairs = (long long)a->B * a->L * a->L;
-    // tile shape: PF_ET_TILE=64x1 (64 pairs, 4 waves), 64x2 (64 pairs, 8 waves), 32 (32 pairs, 4 waves; default)
-    const int mode = force_tiled ? force_tiled : 642;
+    // tile shape of the tiled (fallback) kernel: 64 pairs, 8 waves (the 64 x 4-wave and 32-pair forms measured the same)
+    const int mode = 642;
     const int P = mode == 32 ? 32 : 64;
     const long long nblk = (npairs + P - 1) / P;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
 
 // fp32 W[N,K] (ldw; or its transpose: W given as [K,N] when `transpose`) -> f16 hi/lo planes in fragment order
 // [2][Npad/16][K/32][64 lanes][8] (the layout engine.split_f16 documents): one thread per 8 consecutive k of one output row
-__global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw, int N, int K, int transpose, _Float16* out, int Npad) {
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw, int N, int K, int transpose, _Float16* out, int Npad, int* range_flag) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int per_row = K / 8;
     if (idx >= Npad * per_row) return;
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw
     for (int e = 0; e < 8; ++e) {
         const int k = 8 * k8 + e;
         v[e] = n < N ? (transpose ? w[(size_t)k * ldw + n] : w[(size_t)n * ldw + k]) : 0.f;
+        if (range_flag && !(fabsf(v[e]) <= PF_F16_MAX)) *range_flag = 1;      // (also catches NaN / inf); the value saturates below
     }
     half4 h0, l0, h1, l1;
     const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
@@ -348,12 +349,22 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw
 
 }  // namespace
 
+extern "C" int pf_split_pack_f16_checked(const float* w, int ldw, int N, int K, int transpose, void* out, int* range_flag, pf_stream_t stream) {
+    if (!w || !out || N <= 0 || K <= 0 || K % 32) return PF_E_BADARG;
+    const int Npad = (N + 15) / 16 * 16;
+    const int n = Npad * (K / 8);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, transpose,
+                       reinterpret_cast<_Float16*>(out), Npad, range_flag);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pf_split_pack_f16(const float* w, int ldw, int N, int K, int transpose, void* out, pf_stream_t stream) {
     if (!w || !out || N <= 0 || K <= 0 || K % 32) return PF_E_BADARG;
     const int Npad = (N + 15) / 16 * 16;
     const int n = Npad * (K / 8);
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, transpose,
-                       reinterpret_cast<_Float16*>(out), Npad);
+                       reinterpret_cast<_Float16*>(out), Npad, (int*)nullptr);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -249,8 +249,7 @@ extern "C" int pf_embed_inputs_fwd(const pf_embed_args* a, pf_stream_t stream) {
 
 extern "C" int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream) {
     if (!a || !a->qkv || !a->mask || !a->out || a->B <= 0 || a->L <= 0) return PF_E_BADARG;
-    static const int use_mfma = [] { const char* e = getenv("PF_SEQ_FWD_MFMA"); return e ? atoi(e) : 1; }();
-    if (use_mfma && a->L <= SM_L) {
+    if (a->L <= SM_L) {
         const size_t ldm = ((size_t)3 * SM_L * SA_LD + SM_L * SM_LDX + SM_L) * sizeof(float);
         static bool attr_m = false;
         if (!attr_m) { (void)hipFuncSetAttribute((const void*)seq_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }

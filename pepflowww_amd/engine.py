@@ -25,6 +25,17 @@ def _f32(t):
 LO_SCALE = 2048.0
 
 
+F16_MAX = 65504.0
+
+
+def check_f16_range(w, name="weight"):
+    """The hi plane of the split representation is an f16: |w| must not exceed 65504 (and must be finite).  Trained PepFlow
+    weights are O(1); a checkpoint that violates this cannot run in split precision and is refused loudly here."""
+    if w.numel() and not bool(torch.isfinite(w).all() and w.abs().max() <= F16_MAX):
+        raise _capi.PepflowHipError(f"{name}: values outside the f16 range (|w| <= {F16_MAX:g}, finite) cannot be carried by the "
+                                    "hi/lo f16 split of the MFMA kernels; rescale the layer or run it through pf_linear_fwd without w_f16")
+
+
 def split_f16(w):
     """fp32 matrix [N, K] -> f16 hi/lo planes in MFMA FRAGMENT ORDER for the split-precision kernels.
 
@@ -36,6 +47,7 @@ def split_f16(w):
     w = _f32(w)
     N, K = w.shape
     assert K % 32 == 0, K
+    check_f16_range(w)
     Np = (N + 15) // 16 * 16
     if Np != N:
         w = torch.nn.functional.pad(w, (0, 0, 0, Np - N))
@@ -52,6 +64,7 @@ def _frag_pair(W, ft, kidx):
     lane = torch.arange(64, device=W.device)
     rows = 16 * ft + (lane & 15)
     v = W[rows[:, None], kidx[(lane >> 4)]]                     # [64, 8]
+    check_f16_range(v)
     hi = v.to(torch.float16)
     lo = ((v - hi.to(torch.float32)) * LO_SCALE).to(torch.float16)
     return torch.cat([hi.reshape(-1), lo.reshape(-1)])

@@ -78,6 +78,8 @@ class _TrainStepFn(torch.autograd.Function):
         sd = state[3]
         w = dict(zip(LOSS_KEYS, g_losses.detach().to(torch.float32).tolist()))        # d total / d loss_k (the loss weights)
         grads = _step_backward(state, w)
+        from .backward import assert_weight_range
+        assert_weight_range(g_losses.device)             # (eager path: one 4-byte read per step)
         ctx.state = None
         out = []
         for n in names:
@@ -135,6 +137,13 @@ class GraphedTrainStep:
             del state
         for n, p in model.named_parameters():
             p.grad = self.grads.get(n)
+        self.check_weight_range()
+
+    def check_weight_range(self):
+        """Weights are re-packed into f16 hi/lo planes inside every replay; call this (one 4-byte D2H read) whenever the
+        parameters may have left the f16 range (|w| <= 65504) -- it is called once at capture."""
+        from .backward import assert_weight_range
+        assert_weight_range(self.seed.device)
 
     def __call__(self, batch=None, noise=None, seed=None):
         """Refresh the static inputs (given ones only), replay, -> dict of the six losses (views of a static tensor)."""

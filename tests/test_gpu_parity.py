@@ -1251,3 +1251,44 @@ def test_reconstruct_backbone_vs_reference(golden_dir):
     first4 = torch.zeros(B, N, 15, dtype=torch.bool)
     first4[:, :, :4] = True
     assert torch.equal(mask.cpu(), torch.where(gen[:, :, None], first4, cmask))
+
+
+# ------------------------------------------------------------------ range of the f16 hi/lo split (weakness 5)
+def test_split_precision_range_is_guarded():
+    """x = hi + lo/2048 with f16 planes covers |x| <= 65504.  Weights outside are REFUSED (host packer raises, device packer sets
+    its flag); activations saturate at +-65504 instead of becoming inf; inside the range the product keeps fp32-level accuracy
+    from 6e4 down to 1e-6 (where the f16 subnormals of the planes start to cost relative precision)."""
+    import ctypes as C
+    from pepflowww_amd.engine import split_f16, F16_MAX
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(128, 128, generator=g) / math.sqrt(128)
+    big = w.clone()
+    big[3, 5] = 7.0e4
+    with pytest.raises(_capi.PepflowHipError):
+        split_f16(cu(big))
+    with pytest.raises(_capi.PepflowHipError):
+        split_f16(cu(w * float("nan")))
+    flag = torch.zeros(1, dtype=torch.int32, device=G.dev())
+    out = torch.empty(2 * 128 * 128, dtype=torch.float16, device=G.dev())
+    lib = _capi.load()
+    for mat, expect in ((w, 0), (big, 1)):
+        flag.zero_()
+        m = cu(mat)
+        _capi.check(lib.pf_split_pack_f16_checked(m.data_ptr(), 128, 128, 128, 0, out.data_ptr(), flag.data_ptr(), _capi.stream_ptr()), "pack")
+        assert int(flag.item()) == expect
+    # activations: in range at every magnitude -> fp32-level accuracy
+    x = torch.randn(100, 128, generator=g)
+    for scale, tol in ((6.0e4 / 5, 5e-6), (1.0e4, 5e-6), (1.0, 5e-6), (1e-3, 5e-6), (1e-6, 2e-3)):
+        xs = x * scale
+        y = G.linear(cu(xs), cu(w), None, split=True)
+        ref = (xs.double() @ w.double().T).float()
+        e = G.rel_err(y, ref)
+        assert e <= tol, (scale, e)
+    # beyond the range: saturation (finite, monotone), never inf / nan
+    xs = x.clone()
+    xs[0] = 1.0e5
+    xs[1] = -3.0e6
+    y = G.linear(cu(xs), cu(w), None, split=True).cpu()
+    assert torch.isfinite(y).all()
+    sat = xs.clamp(-F16_MAX, F16_MAX)
+    G.assert_close(y, (sat.double() @ w.double().T).float(), 1e-5, "saturated rows")
