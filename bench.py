@@ -252,7 +252,7 @@ def main():
     ipa_s = ku["pf_ipa_attn_fwd"]["avg_launch_us"] * 1e-6
     traffic, traffic_src = pmc_traffic(args.workload, prec)
     t_et = (traffic.get("edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
-    t_ipa = (traffic.get("ipa_attn_kernel") or traffic.get("ipa_flash_kernel") or {}).get("hbm_bytes_corrected")
+    t_ipa = (traffic.get("ipa_two_kernel_form") or traffic.get("ipa_attn_kernel") or {}).get("hbm_bytes_corrected")
     step_us = sum(v["us_per_step"] for v in ku.values())
     share = {k: round(v["us_per_step"] / step_us, 3) for k, v in sorted(ku.items(), key=lambda kv: -kv[1]["us_per_step"])}
     dominant = next(iter(share))

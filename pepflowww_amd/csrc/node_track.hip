@@ -37,6 +37,9 @@ constexpr int TR = 16;         // rows per workgroup
 constexpr int LDX = 132;       // fp32 LDS row stride of the 128-wide tiles
 constexpr int LDP = 136;       // f16 row stride of the 128-wide hi/lo planes (272 B)
 constexpr int NTHR = 512;
+#ifndef PF_NT_MINW
+#define PF_NT_MINW 2               // minimum waves per SIMD asked of the register allocator (2 = one 8-wave workgroup per CU)
+#endif
 
 // A [16][128] activation tile as two f16 planes
 struct Planes { _Float16* h; _Float16* l; };
@@ -108,7 +111,7 @@ __device__ __forceinline__ void put_planes(Planes p, int r, int n, const float (
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
+__global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_head_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int CK = 256, LDC = CK + 8;      // feats chunk width (8 K-steps = the weight ring depth), f16 stride
     _Float16* Ch = reinterpret_cast<_Float16*>(smem_raw);     // [2 buffers][2 planes][16][LDC]
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(NTHR) void node_head_kernel(pf_node_head_args a) {
 
 // ------------------------------------------------------------------------------------------------
 template <bool LAST>
-__global__ __launch_bounds__(NTHR) void node_tfmr_kernel(pf_node_tfmr_args a, int LP, int LDS_S) {
+__global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfmr_args a, int LP, int LDS_S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T0 = smem;                       // [16][LDX] fp32
     float* T1 = T0 + TR * LDX;

@@ -1,31 +1,44 @@
 #!/bin/bash
-# HBM traffic of the two big kernels (run ON the GPU box through gpurun): separate rocprofv3 --pmc passes for
-# FETCH_SIZE and WRITE_SIZE (only with --kernel-trace) -> gpurun_out/pmc_traffic_<tag>.json
-TAG=${1:-v3}; cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+# HBM traffic of the big kernels (run ON the GPU box through gpurun): separate rocprofv3 --pmc passes for FETCH_SIZE and
+# WRITE_SIZE (only with --kernel-trace) -> gpurun_out/pmc_traffic_<tag>.json (copy to profiles/rNN/pmc_traffic.json)
+TAG=${1:-r02}; COMMIT=${2:-unknown}; cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 for W in cfg2 cfg4; do
-  for C in FETCH_SIZE WRITE_SIZE; do
-    OUT=gpurun_out/pt_${W}_$C; rm -rf $OUT
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --workload $W > $OUT.log 2>&1
+  for P in fp32 f16; do
+    [ $W = cfg2 ] && [ $P = f16 ] && continue
+    for C in FETCH_SIZE WRITE_SIZE; do
+      OUT=gpurun_out/pt_${W}_${P}_$C; rm -rf $OUT
+      rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --workload $W --precision $P > $OUT.log 2>&1
+    done
   done
 done
-python - "$TAG" <<'PY'
+python - "$TAG" "$COMMIT" <<'PY'
 import csv, glob, json, sys, collections
-tag = sys.argv[1]
-res = {"_how": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE, separate pass) --kernel-trace --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-graph [--workload cfg4]; per-kernel average of Counter_Value (KiB). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B for wide coalesced 16 B/lane reads -> doubled; WRITE_SIZE as reported."}
+tag, commit = sys.argv[1], sys.argv[2]
+res = {"_commit": commit,
+       "_how": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE, separate pass) --kernel-trace --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-graph --workload W --precision P; per-kernel average of Counter_Value (KiB). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B for wide coalesced 16 B/lane reads -> doubled; WRITE_SIZE as reported."}
+KEYS = ("edge_transition_v3_kernel", "edge_transition_kernel", "ipa_attn_kernel", "ipa_scores_kernel", "ipa_pair_kernel", "linear_split_kernel", "node_tfmr_kernel", "node_head_kernel")
 for W in ("cfg2", "cfg4"):
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for C in ("FETCH_SIZE", "WRITE_SIZE"):
-        for f in glob.glob(f"gpurun_out/pt_{W}_{C}/**/*counter_collection.csv", recursive=True):
-            for row in csv.DictReader(open(f)):
-                k = row["Kernel_Name"]
-                for key in ("edge_transition_v3_kernel", "edge_transition_kernel", "ipa_attn_kernel"):
-                    if key in k and row["Counter_Name"] == C:
-                        acc[key][C].append(float(row["Counter_Value"]))
-    res[W] = {}
-    for key, d in acc.items():
-        f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
-        w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
-        res[W][key] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_corrected": int((2 * f + w) * 1024), "launches": len(d["FETCH_SIZE"])}
+    for P in ("fp32", "f16"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for C in ("FETCH_SIZE", "WRITE_SIZE"):
+            for f in glob.glob(f"gpurun_out/pt_{W}_{P}_{C}/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"]
+                    for key in KEYS:
+                        if key + "<" in k or key + "(" in k:
+                            if row["Counter_Name"] == C:
+                                acc[key][C].append(float(row["Counter_Value"]))
+        if not acc:
+            continue
+        name = W if P == "fp32" else f"{W}_{P}"
+        res[name] = {}
+        for key, d in acc.items():
+            f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
+            w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
+            res[name][key] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_corrected": int((2 * f + w) * 1024), "launches": len(d["FETCH_SIZE"])}
+        if "ipa_scores_kernel" in res[name] and "ipa_pair_kernel" in res[name]:
+            a, b = res[name]["ipa_scores_kernel"], res[name]["ipa_pair_kernel"]
+            res[name]["ipa_two_kernel_form"] = {"hbm_bytes_corrected": a["hbm_bytes_corrected"] + b["hbm_bytes_corrected"], "note": "ipa_scores_kernel + ipa_pair_kernel (one pf_ipa_attn_fwd call)"}
 json.dump(res, open(f"gpurun_out/pmc_traffic_{tag}.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
