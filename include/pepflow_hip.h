@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 32
+#define PF_ABI_VERSION 33
+#define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -80,6 +81,13 @@ typedef struct {
      * ipa_pytorch.py:360-388), straight into qp [M,192] / kp [M,192] / vp [M,288] (what pf_ipa_points_fwd produces). */
     const float* pt_rot; const float* pt_trans; float* pt_qp; float* pt_kp; float* pt_vp; int pt_col0;
     int single_pass;                /* split path, 4-wave form only: 1 = f16 precision mode (one f16 MFMA per product, hi planes only) */
+    /* split path with pt_* set (IPA projection of the inference plan), optional: write the attention operands as f16 planes
+     * instead of fp32 `y` / `pt_vp` (csrc/ipa_split.hip consumes them; L = att_L must be a multiple of 16, M = B L):
+     *   att_qk : per row [q 1024 | k 8 x 128] channels; fp32 mode: 4096 f16 per row, channel octets interleaved (hi8 | lo8);
+     *            f16 mode (single_pass): 2048 f16 per row, hi only
+     *   att_vt : values TRANSPOSED per (sample, head): [B][8][PF_ATT_VROWS = 128 channels + 36 point coordinates][L keys];
+     *            fp32 mode: key octets interleaved (hi8 | lo8), 2 L f16 per row; f16 mode: L f16 per row */
+    void* att_qk; void* att_vt; int att_L;
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 /* W [N,K] fp32 (ldw) -- or W^T when `transpose` (then w is [K,N], ldw >= N) -- to the fragment-order f16 hi/lo planes
@@ -156,6 +164,10 @@ typedef struct {
      * then one streaming pass over z); otherwise the one-kernel form (csrc/ipa_attn.hip). */
     float* p_out;
     int variant;                   /* 0 = automatic; 1 = force the one-kernel form; 2 = demand the two-kernel form (error if impossible) */
+    /* optional (two-kernel form, L % 16 == 0): the q / k / v operands as the f16 planes pf_linear_fwd (att_*) wrote; the score
+     * kernel then runs its products on the f16 matrix instruction (3-MFMA split in the fp32 mode, att_mode = 1; single pass in
+     * the f16 mode, att_mode = 2) and `proj` / `vp` are not read */
+    const void* att_qk; const void* att_vt; int att_mode;
     int head_group;                /* one-kernel form: 0 = head-group split by size; 2 / 4 / 8 = that variant */
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);

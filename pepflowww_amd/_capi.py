@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -23,7 +23,7 @@ class LinearArgs(C.Structure):
                 ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("ln_eps", C.c_float), ("w_f16", _fp), ("gate", _fp), ("ldg", _i),
                 ("pt_rot", _fp), ("pt_trans", _fp), ("pt_qp", _fp), ("pt_kp", _fp), ("pt_vp", _fp), ("pt_col0", _i),
-                ("single_pass", _i)]
+                ("single_pass", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_L", _i)]
 
 
 class EmbedArgs(C.Structure):
@@ -40,7 +40,7 @@ class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
                 ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp),
-                ("variant", _i), ("head_group", _i)]
+                ("variant", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_mode", _i), ("head_group", _i)]
 
 
 class InputMixerArgs(C.Structure):

@@ -360,7 +360,10 @@ __device__ __forceinline__ void gemm_split_lowreg(const void* planes, int N, int
 }
 
 // SP ("single pass", the f16 precision mode): hi planes only, one MFMA per product
-template <int WT, int PT, bool SWZ = false, bool SP = false>
+// SWAP: the product is computed as rows x features (activations as the A operand) -- a lane's four accumulator registers are
+// then four consecutive ROWS (16 pt + 4 (lane>>4) + e) of ONE feature (n0 + 16 wt + (lane&15)): the layout a transposed
+// store wants (value rows of the attention, csrc/linear.hip).  A and B fragments share one per-lane layout, so this is free.
+template <int WT, int PT, bool SWZ = false, bool SP = false, bool SWAP = false>
 __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, int n0, int K,
                                            const _Float16* Xh, const _Float16* Xl, int ldx,
                                            f32x4 (&am)[WT][PT], f32x4 (&ac)[WT][PT], const WPre<WT>* pre = nullptr) {
@@ -401,16 +404,16 @@ __device__ __forceinline__ void gemm_split(const void* planes, int N, int Kw, in
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) am[wt][pt] = mfma_h(bh[wt], ah[pt], am[wt][pt]);
+            for (int pt = 0; pt < PT; ++pt) am[wt][pt] = SWAP ? mfma_h(ah[pt], bh[wt], am[wt][pt]) : mfma_h(bh[wt], ah[pt], am[wt][pt]);
         if constexpr (!SP) {
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bh[wt], al[pt], ac[wt][pt]);
+                for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = SWAP ? mfma_h(al[pt], bh[wt], ac[wt][pt]) : mfma_h(bh[wt], al[pt], ac[wt][pt]);
 #pragma unroll
             for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = mfma_h(bl[wt], ah[pt], ac[wt][pt]);
+                for (int pt = 0; pt < PT; ++pt) ac[wt][pt] = SWAP ? mfma_h(ah[pt], bl[wt], ac[wt][pt]) : mfma_h(bl[wt], ah[pt], ac[wt][pt]);
         }
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) { bh[wt] = nh[wt]; if constexpr (!SP) bl[wt] = nl[wt]; }

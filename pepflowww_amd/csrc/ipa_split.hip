@@ -280,6 +280,277 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     PROFS(6);
 }
 
+// ---- score kernel on f16 operand planes (pf_ipa_attn_args.att_qk / att_vt, written by the projection's epilogue) ----
+// Same structure and arithmetic as ipa_scores_kernel; the two products run on v_mfma_f32_16x16x32_f16:
+//   MODE 1 (fp32 parity): operands are hi / lo f16 planes, every product = 3 MFMAs (hi hi, hi lo, lo hi), the result
+//           acc_main + acc_corr / 2048 -- 12 MFMAs of 16 cycles per 16-key tile for K Q^T instead of 32 fp32 MFMAs of 32 cycles,
+//           33 per 32 keys for P [V | V_pts] instead of 88; the probabilities are split when they are read back from LDS;
+//   MODE 2 (f16 mode): hi planes only, one MFMA per product.
+// Requires L % 16 == 0 (FlowModel.sample pads to that); keys are walked in 32-key steps in the second product (a trailing
+// half step multiplies zero probabilities with whatever the value rows hold there -- the value buffer is zero-initialised
+// and 32 keys longer than its last row).
+template <int MODE>
+__global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int SLD) {
+    constexpr bool SPLIT = MODE == 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = a.L;                             // multiple of 16
+    const int L32 = (L + 31) & ~31;
+    float* KP = smem;                              // [L][KPS] key points of this head (global frame)
+    float* MJ = KP + L * KPS;                      // [L] key mask
+    float* SW = MJ + L;                            // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = lid % nrb;
+    const int h = (lid / nrb) % H;
+    const int b = lid / (nrb * H);
+    const size_t rowb = (size_t)b * L;
+    const int i0 = rb * rows_per_block + wave * 16;
+    const int kt = L >> 4;
+    const bool wave_on = i0 < L;
+    const int iq = i0 + r;                         // (< L: L is a multiple of 16)
+    PROFS(0);
+
+    constexpr int RS = SPLIT ? 4096 : 2048;        // f16 per row of the q | k planes
+    const _Float16* qk = reinterpret_cast<const _Float16*>(a.att_qk);
+    // fragment of channels 32 s + 8 g .. + 7 of (row, first channel c0)
+    auto ldfrag = [&](const _Float16* row, int c0, int s, half8& fh, half8& fl) {
+        if constexpr (SPLIT) {                      // channel octets interleaved (hi8 | lo8): loads are operands as they arrive
+            fh = *reinterpret_cast<const half8*>(row + ((c0 + 32 * s + 8 * g) >> 3) * 16);
+            fl = *reinterpret_cast<const half8*>(row + ((c0 + 32 * s + 8 * g) >> 3) * 16 + 8);
+        } else {
+            fh = *reinterpret_cast<const half8*>(row + c0 + 32 * s + 8 * g);
+        }
+    };
+    half8 qh[4], ql[4];
+    {
+        const _Float16* qrow = qk + (rowb + (wave_on ? iq : 0)) * RS;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) ldfrag(qrow, h * C, s4, qh[s4], ql[s4]);
+    }
+    float4 qp4[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(a.qp + (rowb + (wave_on ? iq : 0)) * 192 + h * 24 + 4 * q);
+    const float mi = a.mask[rowb + (wave_on ? iq : 0)];
+    const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
+    const int KC0 = (SPLIT ? 1024 : 1024) + h * C;                              // first k channel of the head in the plane row
+    auto loadk = [&](int t, half8 (&kh)[4], half8 (&kl)[4]) {
+        const _Float16* krow = qk + (rowb + 16 * t + r) * RS;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) ldfrag(krow, KC0, s4, kh[s4], kl[s4]);
+    };
+    half8 kh[4], kl[4], nh[4], nl[4];
+    if (wave_on) loadk(0, kh, kl);
+
+    for (int idx = tid; idx < L * 6; idx += blockDim.x) {
+        const int j = idx / 6, q = idx - j * 6;
+        *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = *reinterpret_cast<const float4*>(a.kp + (rowb + j) * 192 + h * 24 + 4 * q);
+    }
+    for (int j = tid; j < L; j += blockDim.x) MJ[j] = a.mask[rowb + j];
+    __syncthreads();
+    if (!wave_on) return;
+    PROFS(1);
+
+    const float scale_qk = 0.051031036307982884f;               // sqrt(1/(3*128)), ipa_pytorch.py:399
+    const float* brow = a.bias + (((size_t)b * H + h) * L + iq) * L;
+    float* srow = SW + (size_t)wave * 16 * SLD + r * SLD;
+    float mx = -3.0e38f;
+    auto qk_tile = [&](int t, const half8 (&kh)[4], const half8 (&kl)[4], const float4& bv) {
+        const int jb = 16 * t + 4 * g;
+        const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f}, ac2 = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {                       // S^T tile: A = key rows, B = query rows
+            am = mfma_h(kh[s4], qh[s4], am);
+            if constexpr (SPLIT) {
+                ac = mfma_h(kh[s4], ql[s4], ac);
+                ac2 = mfma_h(kl[s4], qh[s4], ac2);
+            }
+        }
+        if constexpr (SPLIT) ac += ac2;
+        float sv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = jb + e;
+            const float* kp = KP + j * KPS;                       // same address across the 16 lanes of a group: LDS broadcast
+            f32x2 d2 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const float4 kq = *reinterpret_cast<const float4*>(kp + 4 * q);
+                const f32x2 da = (f32x2){qp4[q].x, qp4[q].y} - (f32x2){kq.x, kq.y};
+                const f32x2 db = (f32x2){qp4[q].z, qp4[q].w} - (f32x2){kq.z, kq.w};
+                d2 = __builtin_elementwise_fma(da, da, d2);
+                d2 = __builtin_elementwise_fma(db, db, d2);
+            }
+            const float qkv = SPLIT ? am[e] + ac[e] * PF_LO_INV : am[e];
+            float v = qkv * scale_qk + bj[e];
+            v = v + (-0.5f) * (gamma * (d2[0] + d2[1]));
+            v = v + 1e5f * (mi * MJ[j] - 1.f);
+            sv[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        *reinterpret_cast<float4*>(srow + jb) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+    };
+    {
+        // two tiles per trip, fragment / bias buffers alternating (no copies).  The scheduling barriers keep a tile's loads a
+        // whole tile of work ahead of their use: left alone, hipcc pulls the next tile's MFMAs up into this tile's VALU section
+        // (waiting for loads it issued ~200 cycles earlier) and fetches the bias row right in front of its use
+        float4 bc = *reinterpret_cast<const float4*>(brow + 4 * g), bn;
+        int t = 0;
+        for (; t + 1 < kt; t += 2) {
+            loadk(t + 1, nh, nl);
+            bn = *reinterpret_cast<const float4*>(brow + 16 * (t + 1) + 4 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            qk_tile(t, kh, kl, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            loadk(min(t + 2, kt - 1), kh, kl);
+            bc = *reinterpret_cast<const float4*>(brow + 16 * min(t + 2, kt - 1) + 4 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            qk_tile(t + 1, nh, nl, bn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt & 1) qk_tile(kt - 1, kh, kl, bc);
+    }
+    PROFS(2);
+    // ---- softmax over the keys of query r (its keys sit in the 4 lanes r, r+16, r+32, r+48) ----
+    mx = max_xor32(max_xor16(mx));
+    float sum = 0.f;
+    for (int t = 0; t < kt; ++t) {
+        float4 v = *reinterpret_cast<const float4*>(srow + 16 * t + 4 * g);
+        v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);
+        sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+        *reinterpret_cast<float4*>(srow + 16 * t + 4 * g) = v;
+    }
+    if (L32 > L) *reinterpret_cast<float4*>(srow + L + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);   // trailing half step: zero weights
+    sum = sum_xor32(sum_xor16(sum));
+    const float inv = 1.f / sum;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the second product reads other lanes' columns of row r
+    __builtin_amdgcn_wave_barrier();
+    PROFS(3);
+    float* prow = a.p_out + (((size_t)b * H + h) * L + iq) * L;
+
+    // ---- [o | o_pt] = P [V | V_pts]: A = P (lane (r = query, g): keys 32 s + 8 g .. + 7), B = transposed value rows
+    //      (tile n, lane r) -> value channel 8 r + n for n < 8 (a lane's eight outputs of a query are consecutive floats),
+    //      point coordinate 16 (n - 8) + r for n = 8..10 ----
+    constexpr int NTC = 11;
+    constexpr int VRS = SPLIT ? 2 : 1;                           // f16 per key in a value row
+    const _Float16* vt = reinterpret_cast<const _Float16*>(a.att_vt) + ((size_t)b * H + h) * PF_ATT_VROWS * (size_t)(VRS * L);
+    int vrow[NTC];
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) vrow[n] = n < 8 ? 8 * r + n : min(128 + 16 * (n - 8) + r, PF_ATT_VROWS - 1);
+    auto loadv = [&](int s32, half8 (&vh)[NTC], half8 (&vl)[NTC]) {
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) {
+            if constexpr (SPLIT) {
+                const _Float16* p = vt + (size_t)vrow[n] * (2 * L) + (4 * s32 + g) * 16;
+                vh[n] = *reinterpret_cast<const half8*>(p);
+                vl[n] = *reinterpret_cast<const half8*>(p + 8);
+            } else {
+                vh[n] = *reinterpret_cast<const half8*>(vt + (size_t)vrow[n] * L + 32 * s32 + 8 * g);
+            }
+        }
+    };
+    f32x4 Om[NTC], Oc[NTC];
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) { Om[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; Oc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int ns = L32 >> 5;
+    auto pv_step = [&](int s32, const half8 (&vh)[NTC], const half8 (&vl)[NTC]) {
+        float4 p0 = *reinterpret_cast<const float4*>(srow + 32 * s32 + 8 * g);
+        float4 p1 = *reinterpret_cast<const float4*>(srow + 32 * s32 + 8 * g + 4);
+        p0.x *= inv; p0.y *= inv; p0.z *= inv; p0.w *= inv;
+        p1.x *= inv; p1.y *= inv; p1.z *= inv; p1.w *= inv;
+        if (32 * s32 + 8 * g < L) {                              // (false only in a trailing half step)
+            *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g) = p0;
+            *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g + 4) = p1;
+        }
+        half8 ph, pl;
+        {
+            const float v0[4] = {p0.x, p0.y, p0.z, p0.w}, v1[4] = {p1.x, p1.y, p1.z, p1.w};
+            half4 h0, l0, h1, l1;
+            if constexpr (SPLIT) {
+                split4(v0, h0, l0);
+                split4(v1, h1, l1);
+                pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h0[e] = (_Float16)v0[e]; h1[e] = (_Float16)v1[e]; }
+            }
+            ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) Om[n] = mfma_h(ph, vh[n], Om[n]);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int n = 0; n < NTC; ++n) Oc[n] = mfma_h(ph, vl[n], Oc[n]);
+#pragma unroll
+            for (int n = 0; n < NTC; ++n) Oc[n] = mfma_h(pl, vh[n], Oc[n]);
+        }
+    };
+    if constexpr (SPLIT) {
+        // (two fragment sets of 88 registers do not fit: one set, requested a step ahead of the previous step's MFMAs by order)
+        for (int s32 = 0; s32 < ns; ++s32) {
+            half8 vh[NTC], vl[NTC];
+            loadv(s32, vh, vl);
+            pv_step(s32, vh, vl);
+        }
+    } else {
+        half8 va[NTC], vb2[NTC], vdummy[NTC];
+        loadv(0, va, vdummy);
+        int s32 = 0;
+        for (; s32 + 1 < ns; s32 += 2) {
+            loadv(s32 + 1, vb2, vdummy);
+            __builtin_amdgcn_sched_barrier(0);
+            pv_step(s32, va, vdummy);
+            __builtin_amdgcn_sched_barrier(0);
+            loadv(min(s32 + 2, ns - 1), va, vdummy);
+            __builtin_amdgcn_sched_barrier(0);
+            pv_step(s32 + 1, vb2, vdummy);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ns & 1) pv_step(ns - 1, va, vdummy);
+    }
+    PROFS(4);
+    // D layout: lane (r = column, g), register e -> query 4 g + e
+    float* opt = SW + (size_t)wave * 16 * SLD;                   // (the wave's score region is dead now)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                             // (every lane is done reading its probabilities)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ti = 4 * g + e, i = i0 + ti;
+        float o[NTC];
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) o[n] = SPLIT ? Om[n][e] + Oc[n][e] * PF_LO_INV : Om[n][e];
+        float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * C + 8 * r;
+        *reinterpret_cast<float4*>(f) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(f + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        opt[ti * 36 + r] = o[8];
+        opt[ti * 36 + 16 + r] = o[9];
+        if (r < 4) opt[ti * 36 + 32 + r] = o[10];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private LDS hand-off
+    __builtin_amdgcn_wave_barrier();
+    PROFS(5);
+    // ---- o_pt -> local frame (invert_apply, ipa_pytorch.py:455) + norms (458) ----
+    for (int idx = lane; idx < 16 * PV; idx += 64) {
+        const int ti = idx / PV, p = idx - ti * PV;
+        const int i = i0 + ti;
+        const float* R = a.rot + (rowb + i) * 9;
+        const float* T = a.trans + (rowb + i) * 3;
+        const float* o = opt + ti * 36 + p * 3;
+        const float x = o[0] - T[0], y = o[1] - T[1], z = o[2] - T[2];
+        const float lx = R[0] * x + R[3] * y + R[6] * z;     // R^T (o - t)
+        const float ly = R[1] * x + R[4] * y + R[7] * z;
+        const float lz = R[2] * x + R[5] * y + R[8] * z;
+        float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * PV + p;
+        f[1024] = lx;
+        f[1120] = ly;
+        f[1216] = lz;
+        f[1312] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+    }
+    PROFS(6);
+}
+
 // Pair aggregation: zbar[h][c] = sum_j P[b,h,i,j] z[b,i,j,c];  o_pair[h][d] = W_dz[d] . zbar[h] + b_dz[d].  One workgroup (4 waves) per
 // query row (b, i); the contraction over keys runs on the matrix cores ([heads padded to 16] x [4 keys] x [16 channels] fp32 MFMA):
 // the cross-lane reduction over keys is then part of the instruction.
@@ -395,7 +666,25 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if ((L & 3) == 0)
+        if (a->att_qk && a->att_vt && (a->att_mode == 1 || a->att_mode == 2) && (L & 15) == 0) {
+            const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
+            const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
+            int wm = (int)((160 * 1024 - fixed16) / pw16);
+            wm = wm > WMAX ? WMAX : wm;
+            if (wm < 1) return PF_E_TOOLARGE;
+            const int nrb16 = (tiles + wm - 1) / wm, wpb16 = (tiles + nrb16 - 1) / nrb16;
+            const size_t lds16 = fixed16 + wpb16 * pw16;
+            static bool attr16 = false;
+            if (!attr16) {
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr16 = true;
+            }
+            if (a->att_mode == 1)
+                hipLaunchKernelGGL(ipa_scores16_kernel<1>, dim3((unsigned)(a->B * H * nrb16)), dim3(64 * wpb16), lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+            else
+                hipLaunchKernelGGL(ipa_scores16_kernel<2>, dim3((unsigned)(a->B * H * nrb16)), dim3(64 * wpb16), lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+        } else if ((L & 3) == 0)
             hipLaunchKernelGGL(ipa_scores_kernel<true>, dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
         else
             hipLaunchKernelGGL(ipa_scores_kernel<false>, dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);

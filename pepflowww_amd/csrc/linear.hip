@@ -180,7 +180,7 @@ int launch(const pf_linear_args& a, hipStream_t s) {
 // whole output row (N <= 256) fits one workgroup: the x tile is then read and converted ONCE instead of once per
 // 128-feature block (the pair-sized [B*L*L,192] -> 192 products of the training path read x twice otherwise).
 constexpr int SP_BM = 64;
-template <int NWV, bool SP = false>
+template <int NWV, bool SP = false, bool ATT = false>       // ATT: attention operand planes (pf_linear_args.att_*), compiled separately
 __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p, int Npad) {
     constexpr int SP_BN = 32 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -250,6 +250,41 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     f32x4 am[2][4], ac[2][4];
     acc_zero<2, 4>(am);
     acc_zero<2, 4>(ac);
+    // ---- attention operand planes (inference plan, pf_linear_args.att_*): q / k rows as f16 planes, v TRANSPOSED per (sample, head)
+    //      so that the score kernel feeds them to v_mfma_f32_16x16x32_f16 without conversions (csrc/ipa_split.hip) ----
+    constexpr bool att = ATT;
+    const int AL = p.att_L;
+    if (att && n0 >= 1024 && n0 < 3072 && (((n0 - 1024) >> 7) & 1)) {
+        // value features: rows x features product (SWAP) -> lane (r = feature, g) holds rows 4 g + e: 8-byte transposed stores
+        gemm_split<2, 4, false, SP, true>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
+        _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt) {
+            const int n = n0 + wt * 16 + r;
+            const float bn = p.bias ? p.bias[n] : 0.f;
+            const int hd = (n - 1024) >> 8, c = ((n - 1024) & 255) - 128;
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const int mq = m0 + pt * 16 + 4 * g;               // four consecutive rows of one sample (L % 4 == 0)
+                if (mq >= p.M) continue;
+                const int bs = mq / AL, j = mq - bs * AL;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (SP ? am[wt][pt][e] : am[wt][pt][e] + ac[wt][pt][e] * PF_LO_INV) + bn;
+                half4 hi, lo;
+                if constexpr (SP) {
+                    hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+                    *reinterpret_cast<half4*>(vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * AL + j) = hi;
+                } else {
+                    split4(v, hi, lo);
+                    _Float16* d = vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * (2 * AL) + (j >> 3) * 16 + (j & 7);
+                    *reinterpret_cast<half4*>(d) = hi;
+                    *reinterpret_cast<half4*>(d + 8) = lo;
+                }
+            }
+        }
+        return;
+    }
     if (n0 + 16 < Npad) {
         if (NWV > 4) gemm_split_lowreg<2, 4, SP>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
         else gemm_split<2, 4, false, SP>(p.w_f16, Npad, K, n0, K, Xh, Xl, LDK, am, ac);
@@ -286,10 +321,50 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                         const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20;
                         o = (pp < 8) ? p.pt_kp + (size_t)m * 192 + (hh * 8 + pp) * 3 : p.pt_vp + (size_t)m * 288 + (hh * 12 + (pp - 8)) * 3;
                     }
-                    if (pt < 224) {
-                        o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
-                        o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
-                        o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                    if constexpr (!ATT) {
+                        if (pt < 224) {
+                            o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                            o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                            o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                        }
+                    } else if (pt < 224) {
+                        const float ox = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                        const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                        const float oz = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                        const bool vpoint = pt >= 64 && (pt - 64) % 20 >= 8;
+                        if (!vpoint) { o[0] = ox; o[1] = oy; o[2] = oz; }
+                        else {                    // value points: rows 128 + 3 p + xyz of the head's transposed value block
+                            const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20 - 8;
+                            const int bs = m / AL, j = m - bs * AL;
+                            const float ov[4] = {ox, oy, oz, 0.f};
+                            half4 hi, lo;
+                            _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
+                            if constexpr (SP) {
+                                _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * AL + j;
+                                d[0] = (_Float16)ox; d[AL] = (_Float16)oy; d[2 * AL] = (_Float16)oz;
+                            } else {
+                                split4(ov, hi, lo);
+                                _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * (2 * AL) + (j >> 3) * 16 + (j & 7);
+                                d[0] = hi[0]; d[8] = lo[0];
+                                d[2 * AL] = hi[1]; d[2 * AL + 8] = lo[1];
+                                d[4 * AL] = hi[2]; d[4 * AL + 8] = lo[2];
+                            }
+                        }
+                    }
+                    continue;
+                }
+                if (att && n < 3072) {                    // q / k features -> f16 planes of the attention
+                    _Float16* qk = reinterpret_cast<_Float16*>(p.att_qk);
+                    const int kc = n < 1024 ? n : 1024 + ((n - 1024) >> 8) * 128 + ((n - 1024) & 255);   // q channel | 1024 + k channel
+                    half4 hi, lo;
+                    if constexpr (SP) {
+                        hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+                        *reinterpret_cast<half4*>(qk + (size_t)m * 2048 + kc) = hi;
+                    } else {                              // channel octets interleaved (hi8 | lo8): the consumer's two 16-byte loads
+                        split4(v, hi, lo);                //  per K-step are MFMA operands as they arrive (no re-packing)
+                        _Float16* d = qk + (size_t)m * 4096 + (kc >> 3) * 16 + (kc & 7);
+                        *reinterpret_cast<half4*>(d) = hi;
+                        *reinterpret_cast<half4*>(d + 8) = lo;
                     }
                     continue;
                 }
@@ -370,7 +445,8 @@ extern "C" int pf_split_pack_f16(const float* w, int ldw, int N, int K, int tran
 }
 
 extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
-    if (!a || !a->x || (!a->w && !a->w_f16) || !a->y || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    if (!a || !a->x || (!a->w && !a->w_f16) || (!a->y && !a->att_qk) || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    if (a->att_qk && (!a->att_vt || !a->w_f16 || !a->pt_rot || a->pt_col0 != 3072 || a->att_L <= 0 || a->att_L % 16 || a->M % a->att_L)) return PF_E_BADARG;
     if (a->K % 16 || a->ldx % 4 || a->ldx < a->K) return PF_E_BADARG;
     if (!a->w_f16 && (a->ldw % 4 || a->ldw < a->K || ((uintptr_t)a->w & 15))) return PF_E_BADARG;
     if ((uintptr_t)a->x & 15) return PF_E_BADARG;
@@ -385,6 +461,8 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
@@ -392,6 +470,8 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         const unsigned gm = (a->M + SP_BM - 1) / SP_BM;
         if (Npad > 128 && Npad <= 192 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<6>, dim3(gm, 1), dim3(384), lds, s, *a, Npad);
         else if (Npad > 192 && Npad <= 256 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<8>, dim3(gm, 1), dim3(512), lds, s, *a, Npad);
+        else if (a->att_qk && a->single_pass) hipLaunchKernelGGL((linear_split_kernel<4, true, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
+        else if (a->att_qk) hipLaunchKernelGGL((linear_split_kernel<4, false, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         else if (a->single_pass) hipLaunchKernelGGL((linear_split_kernel<4, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         else hipLaunchKernelGGL(linear_split_kernel<4>, dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         PF_CHECK_LAUNCH();

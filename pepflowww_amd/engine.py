@@ -237,6 +237,17 @@ class DenoiseEngine:
         self.pair_bias = e(B, 8, L, L)          # sqrt(1/3)(W_b z + b_b) of the next IPA block (head-major), written by EdgeTransition
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
+        # attention operands as f16 planes (written by the projection's epilogue, read by the f16-operand score kernel), f16 mode
+        # only: used where the two-kernel attention runs (>= 256 query tiles, L <= 256) and L is a multiple of 16 (sample() pads
+        # to that).  In the fp32 mode the split (hi / lo) form of the same kernels is bit-compatible with the parity bar but not
+        # faster -- measured at B=64, L=128: score kernel 113 k vs 111 k cycles per workgroup (its QK phase is bound by the
+        # point-distance VALU work, not by the MFMAs; its PV phase has no room for a second fragment set in 256 VGPRs) and the
+        # projection 88 vs 77 us (transposed 8-byte stores + hi / lo splits of every output) -- so the fp32 mode keeps fp32 operands.
+        self.att_planes = precision == "f16" and (L % 16 == 0) and (L <= 256) and (B * (L // 16) >= 256)
+        if self.att_planes:
+            split = self.precision == "fp32"
+            self.att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=device)
+            self.att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=device)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -304,6 +315,8 @@ class DenoiseEngine:
             la.single_pass = int(self.precision == "f16")
             la.pt_rot, la.pt_trans, la.pt_col0 = rot.data_ptr(), trans.data_ptr(), 3072
             la.pt_qp, la.pt_kp, la.pt_vp = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr()
+            if self.att_planes:
+                la.att_qk, la.att_vt, la.att_L = self.att_qk.data_ptr(), self.att_vt.data_ptr(), L
             plan.append(e + (lane,))
 
         emit_proj(0, 0)
@@ -320,6 +333,8 @@ class DenoiseEngine:
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
             ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
             ia.p_out = self.attn_p.data_ptr()
+            if self.att_planes:
+                ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----

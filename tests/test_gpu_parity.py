@@ -265,6 +265,65 @@ def test_ipa_forms_agree_on_ragged_shapes(seeded_sd, B, L):
             _ipa_run(seeded_sd, pfx, s, z, R, x, mask, B, L, "split")
 
 
+@pytest.mark.parametrize("B,L", [(2, 32), (3, 48), (1, 144)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_ipa_on_f16_operand_planes(seeded_sd, B, L, mode):
+    """The projection writing the attention operands as f16 planes (pf_linear_args.att_*: q / k rows, values transposed per
+    (sample, head)) + the score kernel on the f16 matrix instruction (pf_ipa_attn_args.att_*), against the oracle:
+    mode 1 = hi / lo split (fp32 parity bar), mode 2 = single pass (the f16 precision mode the engine uses; its own bound)."""
+    import ctypes as C
+    from pepflowww_amd.engine import PackedWeights
+    lib = _capi.load()
+    dev = G.dev()
+    blk = 1
+    pfx = f"ga_encoder.trunk.ipa_{blk}."
+    g = torch.Generator().manual_seed(10 * L + mode)
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    mask[-1, L - 5:] = 0
+    ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], s, z, R, x, mask)
+    W = PackedWeights(seeded_sd, dev)
+    rows = B * L
+    sd_, Rd, xd, md = cu(s.reshape(rows, 128)), cu(R.reshape(rows, 9)), cu(x.reshape(rows, 3)), cu(mask.reshape(rows))
+    proj = torch.full((rows, 3744), float("nan"), device=dev)
+    qp, kp, vp = (torch.full((rows, n), float("nan"), device=dev) for n in (192, 192, 288))
+    split = mode == 1
+    att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=dev)
+    att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=dev)
+    la = _capi.LinearArgs()
+    la.x, la.ldx, la.w, la.ldw = sd_.data_ptr(), 128, W[f"{blk}.proj.w"].data_ptr(), 128
+    la.w_f16, la.bias = W[f"{blk}.projp.w16"].data_ptr(), W[f"{blk}.projp.b"].data_ptr()
+    la.y, la.ldy, la.M, la.N, la.K = proj.data_ptr(), 3744, rows, 3968, 128
+    la.pt_rot, la.pt_trans, la.pt_col0 = Rd.data_ptr(), xd.data_ptr(), 3072
+    la.pt_qp, la.pt_kp, la.pt_vp = qp.data_ptr(), kp.data_ptr(), vp.data_ptr()
+    la.single_pass, la.att_qk, la.att_vt, la.att_L = int(not split), att_qk.data_ptr(), att_vt.data_ptr(), L
+    _capi.check(lib.pf_linear_fwd(C.byref(la), _capi.stream_ptr()), "pf_linear_fwd")
+    bias = cu((math.sqrt(1.0 / 3.0) * F.linear(z, seeded_sd[pfx + "linear_b.weight"], seeded_sd[pfx + "linear_b.bias"])).permute(0, 3, 1, 2))
+    p_out = torch.full((B, 8, L, L), float("nan"), device=dev)
+    feats = torch.full((rows, 1536), float("nan"), device=dev)
+    zd = cu(z)
+    gg = lambda k: cu(seeded_sd[pfx + k])
+    keep = [gg("linear_b.weight"), gg("linear_b.bias"), gg("down_z.weight"), gg("down_z.bias"), gg("head_weights")]
+    ia = _capi.IpaAttnArgs()
+    ia.proj, ia.ldp, ia.qp, ia.kp, ia.vp, ia.z = proj.data_ptr(), 3744, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), zd.data_ptr()
+    ia.rot, ia.trans, ia.mask = Rd.data_ptr(), xd.data_ptr(), md.data_ptr()
+    ia.w_b, ia.b_b, ia.w_dz, ia.b_dz, ia.head_w = (t.data_ptr() for t in keep)
+    ia.feats, ia.B, ia.L, ia.bias, ia.p_out, ia.variant = feats.data_ptr(), B, L, bias.data_ptr(), p_out.data_ptr(), 2
+    ia.att_qk, ia.att_vt, ia.att_mode = att_qk.data_ptr(), att_vt.data_ptr(), mode
+    _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
+    G.sync()
+    valid = mask.reshape(-1).bool()
+    tol = REL if split else 3e-3
+    fr, fg = ref_feats.reshape(rows, -1)[valid], feats.cpu()[valid]
+    for name, sl in (("o", slice(0, 1024)), ("o_pt", slice(1024, 1312)), ("norm", slice(1312, 1408)), ("o_pair", slice(1408, 1536))):
+        G.assert_close(fg[:, sl], fr[:, sl], tol, f"mode {mode} feats[{name}] vs oracle")
+    assert torch.isnan(vp).all()                     # the value points went to the transposed f16 block only
+
+
 def _et_run(sd, pfx, s, z, mask, B, L, persistent=True):
     g = lambda k: sd[pfx + k]
     n64 = G.linear(cu(s.reshape(B * L, 128)), cu(g("initial_embed.weight")), cu(g("initial_embed.bias")))
