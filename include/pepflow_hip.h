@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 33
+#define PF_ABI_VERSION 34
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -125,6 +125,7 @@ typedef struct {
     float* quat;               /* [B*L,4] */
     float* s_out;              /* [B*L,128] */
     int B, L;
+    int single_pass;           /* 1 = f16 precision mode: one f16 MFMA per product (hi weight planes only) */
 } pf_input_mixer_args;
 int pf_input_mixer_fwd(const pf_input_mixer_args* a, pf_stream_t stream);
 
@@ -198,6 +199,7 @@ typedef struct {
     float* s_ipa;                  /* [rows,128] */
     float* qkv;                    /* [rows,384] */
     int rows;
+    int single_pass;               /* 1 = f16 precision mode: one f16 MFMA per product (hi weight planes only) */
 } pf_node_head_args;
 int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream);
 
@@ -234,6 +236,8 @@ typedef struct {
     const void* h_w[2][3]; const float* h_b[2][3];
     float* logits_out;             /* [B*L,20] */
     float* ang_out;                /* [B*L,5] (before the % 2pi of ga.py:125) */
+    int single_pass;               /* 1 = f16 precision mode: one f16 MFMA per product (hi weight planes only); the attention core,
+                                      LayerNorms, residuals and the frame update stay fp32 */
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
 

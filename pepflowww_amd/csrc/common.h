@@ -222,7 +222,7 @@ __device__ __forceinline__ float join(f32x4 m, f32x4 c, int e) { return m[e] + c
 // row (lane & 15): biases/residuals load as float4 and the re-split result is stored with 8-byte writes.
 // Weight planes are stored in FRAGMENT ORDER by the host (engine.split_f16): [2 planes][N/16][K/32][64 lanes][8 f16],
 // so each operand load of a wave is one contiguous 1 KiB block; rows beyond N are zero-padded by the packer.
-template <int WT, int D>
+template <int WT, int D, bool SP = false>      // SP (f16 mode): hi plane only
 struct WSplit {
     const _Float16* wh[WT];
     const _Float16* wl[WT];
@@ -245,7 +245,7 @@ struct WSplit {
 #pragma unroll
         for (int wt = 0; wt < WT; ++wt) {
             dh[wt] = *reinterpret_cast<const half8*>(wh[wt] + (size_t)step * 512);
-            dl[wt] = *reinterpret_cast<const half8*>(wl[wt] + (size_t)step * 512);
+            if constexpr (!SP) dl[wt] = *reinterpret_cast<const half8*>(wl[wt] + (size_t)step * 512);
         }
     }
     __device__ __forceinline__ void prefetch() {
@@ -257,8 +257,8 @@ struct WSplit {
 
 // am/ac[WT] += W-slab x X[16 rows][32*count K-columns starting at K-step step0];  Xh/Xl: LDS planes whose
 // column 0 is K-step step0 (step0 % D == 0).
-template <int WT, int D>
-__device__ __forceinline__ void gemm_split16(WSplit<WT, D>& ws, const _Float16* Xh, const _Float16* Xl, int ldx,
+template <int WT, int D, bool SP>
+__device__ __forceinline__ void gemm_split16(WSplit<WT, D, SP>& ws, const _Float16* Xh, const _Float16* Xl, int ldx,
                                              f32x4 (&am)[WT], f32x4 (&ac)[WT], int step0, int count) {
     const int lane = threadIdx.x & 63;
     const int off = (lane & 15) * ldx + 8 * (lane >> 4);
@@ -268,12 +268,15 @@ __device__ __forceinline__ void gemm_split16(WSplit<WT, D>& ws, const _Float16* 
             if (base + u < count) {
                 const int st = step0 + base + u;
                 const half8 xh = *reinterpret_cast<const half8*>(Xh + off + 32 * (base + u));
-                const half8 xl = *reinterpret_cast<const half8*>(Xl + off + 32 * (base + u));
+                half8 xl;
+                if constexpr (!SP) xl = *reinterpret_cast<const half8*>(Xl + off + 32 * (base + u));
 #pragma unroll
                 for (int wt = 0; wt < WT; ++wt) {
                     am[wt] = mfma_h(ws.rh[u][wt], xh, am[wt]);
-                    ac[wt] = mfma_h(ws.rh[u][wt], xl, ac[wt]);
-                    ac[wt] = mfma_h(ws.rl[u][wt], xh, ac[wt]);
+                    if constexpr (!SP) {
+                        ac[wt] = mfma_h(ws.rh[u][wt], xl, ac[wt]);
+                        ac[wt] = mfma_h(ws.rl[u][wt], xh, ac[wt]);
+                    }
                 }
                 if (st + D < ws.nsteps) ws.load(st + D, ws.rh[u], ws.rl[u]);
             }

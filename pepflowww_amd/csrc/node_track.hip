@@ -111,6 +111,7 @@ __device__ __forceinline__ void put_planes(Planes p, int r, int n, const float (
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool SP>
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_head_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int CK = 256, LDC = CK + 8;      // feats chunk width (8 K-steps = the weight ring depth), f16 stride
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
     const int m0 = blockIdx.x * TR, M = a.rows;
     const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
 
-    WSplit<1, 8> ws;
+    WSplit<1, 8, SP> ws;
     ws.init(a.w_out_f16, 128, PF_IPA_FEATS, wave * 16);
     ws.prefetch();
     // small per-lane operands
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
         if (c + 1 < NCH) commit(c + 1);
         __syncthreads();
     }
-    WSplit<3, 4> wq;                                      // next stage's weights: in_proj of tfmr layer 0
+    WSplit<3, 4, SP> wq;                                      // next stage's weights: in_proj of tfmr layer 0
     wq.init(a.w_in_f16, 384, 128, wave * 48);
     wq.prefetch();
     {
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool LAST>
+template <bool LAST, bool SP>
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfmr_args a, int LP, int LDS_S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T0 = smem;                       // [16][LDX] fp32
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     };
     float vb[4][4];
     vload(0, vb);
-    WSplit<1, 4> ws;
+    WSplit<1, 4, SP> ws;
     ws.init(a.w_o_f16, 128, 128, wave * 16);
     ws.prefetch();
     LnParams ln1, ln2, ln3;
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     acc_zero1<1>(am, ac);
     gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
     if constexpr (!LAST) {
-        WSplit<3, 4> wq;
+        WSplit<3, 4, SP> wq;
         wq.init(a.w_in_next_f16, 384, 128, wave * 48);
         wq.prefetch();
         {
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         const bool do_bb = wave == 0, do_init = a.has_et && wave >= 4;
         if (do_bb) { ws.init(a.w_bb_f16, 16, 128, 0); ws.prefetch(); }
         else if (do_init) { ws.init(a.w_init_f16, 64, 128, (wave - 4) * 16); ws.prefetch(); }
-        WSplit<4, 2> wp;
+        WSplit<4, 2, SP> wp;
         if (a.has_et) { wp.init(a.w_pre_f16, PF_ET_PRE, 64, wave * 64); wp.prefetch(); }
         {
             const float4 s0 = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
 // utils.py:60-71, layers.py:92-113) built in LDS as hi/lo planes, s = mask * (W2 relu(W0 feat + b0) + b2)
 // (res_feat_mixer, ga.py:94-96) on the split-precision MFMA, quat = rot_to_quat(R_t) (rigid_utils.py:208-227).
 constexpr int LDF = 640 + 8;   // f16 row stride of the 640-wide feature planes
+template <bool SP>
 __global__ __launch_bounds__(NTHR) void input_mixer_kernel(pf_input_mixer_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Planes Xf = {reinterpret_cast<_Float16*>(smem_raw), reinterpret_cast<_Float16*>(smem_raw) + TR * LDF};
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(NTHR) void input_mixer_kernel(pf_input_mixer_args a
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * TR, M = a.B * a.L;
     const int n = wave * 16 + 4 * g;
-    WSplit<1, 8> w0;
+    WSplit<1, 8, SP> w0;
     w0.init(a.w0_f16, 128, 640, wave * 16);
     w0.prefetch();
     const float4 b0 = *reinterpret_cast<const float4*>(a.b0 + n);
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(NTHR) void input_mixer_kernel(pf_input_mixer_args a
     f32x4 am[1], ac[1];
     acc_zero1<1>(am, ac);
     gemm_split16(w0, Xf.h, Xf.l, LDF, am, ac, 0, 20);
-    WSplit<1, 4> w2;
+    WSplit<1, 4, SP> w2;
     w2.init(a.w2_f16, 128, 128, wave * 16);
     w2.prefetch();
     {
@@ -703,7 +705,8 @@ extern "C" int pf_input_mixer_fwd(const pf_input_mixer_args* a, pf_stream_t stre
         return PF_E_BADARG;
     const int rows = a->B * a->L;
     const size_t lds = (size_t)2 * TR * LDF * sizeof(_Float16) + (size_t)2 * TR * LDP * sizeof(_Float16);
-    hipLaunchKernelGGL(input_mixer_kernel, dim3((unsigned)((rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    if (a->single_pass) hipLaunchKernelGGL(input_mixer_kernel<true>, dim3((unsigned)((rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(input_mixer_kernel<false>, dim3((unsigned)((rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -714,7 +717,8 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
         return PF_E_BADARG;
     const size_t lds = (size_t)2 * 2 * TR * 264 * sizeof(_Float16) + (size_t)TR * LDX * sizeof(float) +
                        (size_t)2 * TR * LDP * sizeof(_Float16);
-    hipLaunchKernelGGL(node_head_kernel, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    if (a->single_pass) hipLaunchKernelGGL(node_head_kernel<true>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(node_head_kernel<false>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -743,14 +747,17 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
     const int tiles = (a->L + TR - 1) / TR;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (a->last)
-        hipLaunchKernelGGL(node_tfmr_kernel<true>, dim3((unsigned)(a->B * tiles)), dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
-    else
-        hipLaunchKernelGGL(node_tfmr_kernel<false>, dim3((unsigned)(a->B * tiles)), dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+    const dim3 grid((unsigned)(a->B * tiles));
+    if (a->last && a->single_pass) hipLaunchKernelGGL((node_tfmr_kernel<true, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+    else if (a->last) hipLaunchKernelGGL((node_tfmr_kernel<true, false>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+    else if (a->single_pass) hipLaunchKernelGGL((node_tfmr_kernel<false, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+    else hipLaunchKernelGGL((node_tfmr_kernel<false, false>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -204,9 +204,10 @@ class PackedWeights:
 class DenoiseEngine:
     # precision of the matrix products of the step:
     #   "fp32": every product = 3 f16 MFMAs on hi/lo split operands (~22-bit operands, fp32 accumulate): reference parity 1e-4
-    #   "f16" : BASELINE configs[2] mode -- EdgeTransition (85 % of the step's flops) and the IPA projection run ONE f16 MFMA per
-    #           product (hi planes only); accumulation, LayerNorm, softmax, geometry, the pair tensor and the node track stay
-    #           fp32 / fp32-split.  Measured deviation from the fp32 mode: tests/test_gpu_bigshape.py, DESIGN.md section 4
+    #   "f16" : BASELINE configs[2] mode -- EdgeTransition (85 % of the step's flops), the IPA projection, the attention products
+    #           (f16 operand planes) and the Linears of the node track run ONE f16 MFMA per product (hi planes only);
+    #           accumulation, LayerNorm, softmax, residual streams, geometry and the pair tensor stay fp32.  Measured deviation
+    #           from the fp32 mode: tests/test_gpu_bigshape.py, DESIGN.md section 3.8
     def __init__(self, weights, B, L, device, precision="fp32"):
         assert precision in ("fp32", "f16"), precision
         self.precision = precision
@@ -302,6 +303,7 @@ class DenoiseEngine:
         ma.t, ma.time_freq, ma.ang_freq, ma.angles = self.t.data_ptr(), w["time_freq"].data_ptr(), w["ang_freq"].data_ptr(), self.ang_t.data_ptr()
         ma.w0_f16, ma.b0, ma.w2_f16, ma.b2 = w["mix0.w16"].data_ptr(), w["mix0.b"].data_ptr(), w["mix2.w16"].data_ptr(), w["mix2.b"].data_ptr()
         ma.mask, ma.rot, ma.quat, ma.s_out, ma.B, ma.L = self.mask.data_ptr(), self.rot_t.data_ptr(), self.quat.data_ptr(), self.s.data_ptr(), B, L
+        ma.single_pass = int(self.precision == "f16")
         self._keep.append(ma)
         plan.append((lib.pf_input_mixer_fwd, C.byref(ma), "pf_input_mixer_fwd"))
 
@@ -344,6 +346,7 @@ class DenoiseEngine:
             ha.ln_g, ha.ln_b = w[f"{b}.ipa_ln.w"].data_ptr(), w[f"{b}.ipa_ln.b"].data_ptr()
             ha.w_in_f16, ha.b_in = w[f"{b}.0.in.w16"].data_ptr(), w[f"{b}.0.in.b"].data_ptr()
             ha.s_ipa, ha.qkv, ha.rows = self.s.data_ptr(), self.qkv.data_ptr(), rows
+            ha.single_pass = int(self.precision == "f16")
             self._keep.append(ha)
             plan.append((lib.pf_node_head_fwd, C.byref(ha), "pf_node_head_fwd"))
             for l in range(2):
@@ -357,6 +360,7 @@ class DenoiseEngine:
                 ta.w_2_f16, ta.b_2 = w[f"{b}.{l}.linear2.w16"].data_ptr(), w[f"{b}.{l}.linear2.b"].data_ptr()
                 ta.n2_g, ta.n2_b = w[f"{b}.{l}.norm2.w"].data_ptr(), w[f"{b}.{l}.norm2.b"].data_ptr()
                 ta.B, ta.L = B, L
+                ta.single_pass = int(self.precision == "f16")
                 if l == 0:
                     ta.last = 0
                     ta.w_in_next_f16, ta.b_in_next = w[f"{b}.1.in.w16"].data_ptr(), w[f"{b}.1.in.b"].data_ptr()
