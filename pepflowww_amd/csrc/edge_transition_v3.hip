@@ -283,8 +283,16 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         for (int gs = 0; gs < total_stages; ++gs) {
             stage_barrier();
             // after barrier 2 every consumer is past stages 0-1, the only readers of the z rows, pre rows and masks of the
-            // current tile: the next tile's inputs are requested now, all at once, and have five stages to land
-            if (have_next && st_cur == 2) issue_all(tl);
+            // current tile.  The next tile's inputs are requested over stages 2..6, <= 13 pieces each: all 58 at once (first
+            // version of this wave) put an HBM burst in front of the weight loader's L2 traffic on the same CU -- phase stamps
+            // showed the consumers waiting 2.5 k and 1.4 k cycles at the barriers of stages 3 and 4 (f16 mode, 16.4 k per tile)
+            if (have_next) {
+                if (st_cur == 2) issue_z(tl, 0, 11);
+                else if (st_cur == 3) issue_z(tl, 11, 22);
+                else if (st_cur == 4) issue_z(tl, 22, 32);
+                else if (st_cur == 5) { issue_ad(tl); issue_ce(tl, 0, 5); }
+                else if (st_cur == 6) { issue_ce(tl, 5, CE_PIECES); issue_mask(tl); }
+            }
             if (++st_cur == NSTAGE) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and are in LDS before the next tile's barrier 0
                 st_cur = 0;

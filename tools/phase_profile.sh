@@ -18,6 +18,7 @@ from pepflowww_amd import synth, _capi
 lib = _capi.load()
 dev = torch.device("cuda:0")
 m = pepflowww_amd.FlowModel(pepflowww_amd.default_config()); m.load_state_dict(synth.seeded_state_dict()); m = m.to(dev).eval()
+m.ga_encoder.set_precision(os.environ.get('PPREC', 'fp32'))
 B, L = int(os.environ.get('PB', 16)), int(os.environ.get('PL', 64))
 batch = {k: v.to(dev) for k, v in synth.make_pocket_batch(B, L, 12).items()}
 with torch.no_grad():
