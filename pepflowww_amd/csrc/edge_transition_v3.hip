@@ -28,13 +28,21 @@
 #include "../../include/pepflow_hip.h"
 
 #ifdef PF_PROFILE
-__device__ long long g_prof_et3[64];
-#define PROF3(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && it == 1) g_prof_et3[i] = clock64(); } while (0)
+#ifndef PF_PROF_IT
+#define PF_PROF_IT 1
+#endif
+__device__ long long g_prof_et3[256];
+#define PROF3(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && it == PF_PROF_IT) g_prof_et3[i] = clock64(); } while (0)
+// loader waves: arrival at the barrier of global stage gs (second tile of the block: gs 8..15) -> slots base + gs - 8
+#define PROFW(base) do { if (blockIdx.x == gridDim.x / 2 && lane == 0 && it == PF_PROF_IT) g_prof_et3[(base) + wave] = clock64(); } while (0)
+#define PROFL(base, gs) do { if (blockIdx.x == gridDim.x / 2 && lane == 0 && (gs) >= 8 * PF_PROF_IT && (gs) < 8 * PF_PROF_IT + 8) g_prof_et3[(base) + (gs) - 8 * PF_PROF_IT] = clock64(); } while (0)
 extern "C" int pf_debug_prof_et3(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_et3), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
 }
 #else
 #define PROF3(i)
+#define PROFW(base)
+#define PROFL(base, gs)
 #endif
 
 namespace {
@@ -68,6 +76,13 @@ __device__ __forceinline__ void stage_barrier() {
     asm volatile("" ::: "memory");
 }
 #define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// LDS-DMA with a uniform (SGPR) base + 32-bit per-lane offset, written out: hipcc turns the builtin into 64-bit VALU address
+// arithmetic (plus a generic-pointer null check) per piece.  m0 = LDS byte address of the piece (lane l lands at + 16 l).
+__device__ __forceinline__ void glds16u(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+#define LDSADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
+#define GLDS16U(sbase, voff, dst) glds16u((sbase), (voff), lds0 + (unsigned)(dst))
 #define GLDS4(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 4, 0, 0)
 
 struct Frag { half8 h, l; };
@@ -147,6 +162,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
+    const unsigned lds0 = LDSADDR(smem);
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // blockIdx.x, + gridDim.x, ...
     const int total_stages = my_tiles * NSTAGE;
     auto tile_of = [&](int t) {
@@ -167,17 +183,21 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             reinterpret_cast<float4*>(smem + OFF_WB)[i] = reinterpret_cast<const float4*>(a.wb_frags)[i];
     __syncthreads();
 
+#ifdef PF_PROFILE
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) g_prof_et3[144 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+#endif
     if (wave == NCW) {
         // ------------------- weight loader wave: weight stream -> LDS ring (LDS-DMA) -------------------
         // (The tile inputs have their own loader wave below: with both in one wave the in-order vmcnt made every weight stage
         //  wait for the HBM round trip of the z rows issued before it -- in the f16 mode, where a stage is ~0.5 us of consumer
         //  work, the kernel ran at the loader's pace: PMC 57 % of all wave cycles parked, 263 us per launch at B=64, L=128.)
-        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w_stream) + lane * 16;
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w_stream);
+        const unsigned wl = lane * 16;
         if constexpr (SP) {
             // hi KiB of fragment pair k of a stage -> dense 16 KiB ring stage; three stages of run-ahead (48 pieces <= 63)
             auto issue_w = [&](int stage, int slot) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) GLDS16(wsrc + stage * STAGE_B + k * KF, ring + slot * STG<true> + k * 1024);
+                for (int k = 0; k < 16; ++k) GLDS16U(wsrc + stage * STAGE_B + k * KF, wl, slot * STG<true> + k * 1024);
             };
             issue_w(0, 0);
             if (total_stages > 1) issue_w(1 % NSTAGE, 1);
@@ -187,6 +207,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stage 0 complete
             int st_next = 3 % NSTAGE, slot_next = 3;
             for (int gs = 0; gs < total_stages; ++gs) {
+                PROFL(24, gs);
                 stage_barrier();                                   // consumers: start stage gs; they are done with gs - 1
                 if (gs + 3 < total_stages) {
                     issue_w(st_next, slot_next);
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         } else {
             auto issue_w = [&](int stage, int slot, int k0, int k1) {
 #pragma unroll
-                for (int k = k0; k < k1; ++k) GLDS16(wsrc + stage * STAGE_B + k * 1024, ring + slot * STAGE_B + k * 1024);
+                for (int k = k0; k < k1; ++k) GLDS16U(wsrc + stage * STAGE_B + k * 1024, wl, slot * STAGE_B + k * 1024);
             };
             issue_w(0, 0, 0, 32);
             issue_w(1, 1, 0, 16);
@@ -211,6 +232,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             int st_next = 2 % NSTAGE, slot_next = 2 % NSLOT;           // stream stage / ring slot of global stage gs + 2
             for (int gs = 0; gs < total_stages; ++gs) {
                 // here: stage gs and everything issued before its last 16 pieces have landed
+                PROFL(24, gs);
                 stage_barrier();                                       // consumers: start stage gs; they are done with gs - 1
                 if (gs + 2 < total_stages) {
                     issue_w(st_next, slot_next, 0, 16);
@@ -227,39 +249,51 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     }
     if (wave == NCW + 1) {
         // ------------------- input loader wave: next tile's z rows / pre rows / masks -> LDS (LDS-DMA) -------------------
-        // z piece k: consumer region k >> 2, pairs (k & 3) * 4 + (lane >> 4); 16-byte chunk q = lane & 15 of the LDS row
-        // holds the global chunk q ^ pair (so that the consumers' fragment reads are bank-conflict free)
-        auto issue_z = [&](const Tile& tl, int k0, int k1) {
-            const int q = lane & 15;
-            for (int k = k0; k < k1; ++k) {
-                const int rr = (k & 3) * 4 + (lane >> 4);
-                int i = tl.i0 + (k >> 2), j = tl.j0 + rr;
+        // All addresses are (uniform row base) + (per-lane 32-bit offset): the scalar unit forms the bases, the vector unit only
+        // the four z offsets of a tile (column clamp + swizzle) -- the per-piece 64-bit VALU address arithmetic of the first
+        // version made this wave the last to arrive at the barriers of stages 3..7 in the f16 mode.
+        // z piece 4 * row + m: consumer region `row`, pairs rr = m * 4 + (lane >> 4); 16-byte chunk q = lane & 15 of the LDS
+        // row holds the global chunk q ^ rr (so that the consumers' fragment reads are bank-conflict free)
+        const int q = lane & 15;
+        const int off16 = lane * 16;
+        const unsigned ad_off = off16 < 768 ? off16 : 1536 + (off16 - 768);          // [a 768 B | d 256 B] of a pre row
+        const unsigned ce_off = off16 < 768 ? 768 + off16 : 1792 + (off16 - 768);    // [c 768 B | e 256 B]
+        const unsigned char* zg = reinterpret_cast<const unsigned char*>(a.z_in);
+        const unsigned char* pg = reinterpret_cast<const unsigned char*>(a.pre);
+        unsigned zoff[4];
+        auto prep_z = [&](const Tile& tl) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int rr = m * 4 + (lane >> 4);
+                int jr = rr;
+                jr = tl.j0 + jr < L ? jr : L - 1 - tl.j0;
+                zoff[m] = (unsigned)(jr * 256 + 16 * (q ^ rr));
+            }
+        };
+        auto issue_z = [&](const Tile& tl, int row0, int row1) {
+#pragma unroll
+            for (int row = row0; row < row1; ++row) {
+                int i = tl.i0 + row;
                 i = i < L ? i : L - 1;
-                j = j < L ? j : L - 1;
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.z_in + ((size_t)(tl.b * L + i) * L + j) * 64) + 16 * (q ^ rr);
-                GLDS16(src, smem + OFF_Z + k * 1024);
+                const unsigned char* base = zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 256;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) GLDS16U(base, zoff[m], OFF_Z + (4 * row + m) * 1024);
             }
         };
         auto issue_ad = [&](const Tile& tl) {                    // 8 pieces: row i0 + k, [a | d]
-            const int off = lane * 16;
-            const int soff = off < 768 ? off : 1536 + (off - 768);
+#pragma unroll
             for (int k = 0; k < NCW; ++k) {
                 int i = tl.i0 + k;
                 i = i < L ? i : L - 1;
-                GLDS16(reinterpret_cast<const unsigned char*>(a.pre + (size_t)(tl.b * L + i) * PF_ET_PRE) + soff, smem + OFF_AD + k * 1024);
+                GLDS16U(pg + (size_t)(tl.b * L + i) * (PF_ET_PRE * 4), ad_off, OFF_AD + k * 1024);
             }
         };
-        auto issue_ce = [&](const Tile& tl, int k0, int k1) {    // 17 pieces over 16 padded rows [c | e | pad]
+        auto issue_ce = [&](const Tile& tl, int k0, int k1) {    // 16 pieces: row j0 + k, [c | e] (the 32-byte pad is never read)
+#pragma unroll
             for (int k = k0; k < k1; ++k) {
-                const int pos = k * 1024 + lane * 16;
-                int row = pos / CE_STRIDE;
-                int off = pos - row * CE_STRIDE;
-                row = row < TJ ? row : TJ - 1;
-                off = off < 1024 ? off : 0;
-                int j = tl.j0 + row;
+                int j = tl.j0 + k;
                 j = j < L ? j : L - 1;
-                const int soff = off < 768 ? 768 + off : 1792 + (off - 768);
-                GLDS16(reinterpret_cast<const unsigned char*>(a.pre + (size_t)(tl.b * L + j) * PF_ET_PRE) + soff, smem + OFF_CE + k * 1024);
+                GLDS16U(pg + (size_t)(tl.b * L + j) * (PF_ET_PRE * 4), ce_off, OFF_CE + k * CE_STRIDE);
             }
         };
         auto issue_mask = [&](const Tile& tl) {                  // lanes 0-7: mask_i, 8-23: mask_j
@@ -267,10 +301,11 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             row = row < L ? row : L - 1;
             GLDS4(a.mask + tl.b * L + row, smem + OFF_MK);
         };
-        auto issue_all = [&](const Tile& tl) {                   // 32 + 8 + 17 + 1 = 58 pieces (the counter holds 63)
-            issue_z(tl, 0, 32);
+        auto issue_all = [&](const Tile& tl) {                   // 32 + 8 + 16 + 1 = 57 pieces (the counter holds 63)
+            prep_z(tl);
+            issue_z(tl, 0, 8);
             issue_ad(tl);
-            issue_ce(tl, 0, CE_PIECES);
+            issue_ce(tl, 0, TJ);
             issue_mask(tl);
         };
         int tile = blockIdx.x;
@@ -281,17 +316,18 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         bool have_next = my_tiles > 1;
         if (have_next) tl = tile_of(tile + gridDim.x);
         for (int gs = 0; gs < total_stages; ++gs) {
+            PROFL(32, gs);
             stage_barrier();
             // after barrier 2 every consumer is past stages 0-1, the only readers of the z rows, pre rows and masks of the
             // current tile.  The next tile's inputs are requested over stages 2..6, <= 13 pieces each: all 58 at once (first
             // version of this wave) put an HBM burst in front of the weight loader's L2 traffic on the same CU -- phase stamps
             // showed the consumers waiting 2.5 k and 1.4 k cycles at the barriers of stages 3 and 4 (f16 mode, 16.4 k per tile)
             if (have_next) {
-                if (st_cur == 2) issue_z(tl, 0, 11);
-                else if (st_cur == 3) issue_z(tl, 11, 22);
-                else if (st_cur == 4) issue_z(tl, 22, 32);
-                else if (st_cur == 5) { issue_ad(tl); issue_ce(tl, 0, 5); }
-                else if (st_cur == 6) { issue_ce(tl, 5, CE_PIECES); issue_mask(tl); }
+                if (st_cur == 2) { prep_z(tl); issue_z(tl, 0, 3); }
+                else if (st_cur == 3) issue_z(tl, 3, 6);
+                else if (st_cur == 4) issue_z(tl, 6, 8);
+                else if (st_cur == 5) { issue_ad(tl); issue_ce(tl, 0, 4); }
+                else if (st_cur == 6) { issue_ce(tl, 4, TJ); issue_mask(tl); }
             }
             if (++st_cur == NSTAGE) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and are in LDS before the next tile's barrier 0
@@ -327,6 +363,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         for (int tp = 0; tp < 6; ++tp) {
             if (tp == 0 || tp == 4) {
                 PROF3(tp == 0 ? 1 : 3);
+                PROFW(64 + 8 * (tp == 0 ? 0 : 1));
                 stage_barrier();
                 PROF3(tp == 0 ? 2 : 4);
                 if (tp == 4) slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;
@@ -386,6 +423,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             PROF3(7 + c);
+            PROFW(64 + 8 * (2 + c));
             stage_barrier();
             PROF3(16 + c);
             slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;
@@ -499,6 +537,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             }
         }
         PROF3(14);
+        PROFW(64 + 64);
     }
 }
 
