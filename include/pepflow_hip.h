@@ -278,7 +278,9 @@ typedef struct {
     int B, L;
     /* optional: the three matrices as ONE 256 KiB stream of 128 fragment pairs in consumption order
      * (pepflowww_amd.engine.pack_et_stream).  When set, the persistent LDS-ring kernel is used
-     * (csrc/edge_transition_v3.hip) and w1z_f16 / w2_f16 / wf_f16 may be NULL. */
+     * (csrc/edge_transition_v3.hip) and w1z_f16 / w2_f16 / wf_f16 may be NULL.  The lo halves of the stream (and of
+     * wb_frags) are f16(w - hi) UNSCALED -- this kernel adds all three products into one accumulator -- unlike the
+     * w - hi times 2048 of every other split-precision operand (pf_split_pack_f16). */
     const void* w_stream;
     /* optional (persistent kernel only): also emit the NEXT block's IPA pair bias sqrt(1/3)(W_b z' + b_b)
      * from the normalised, masked z' while it is still in registers: bias_out [B,8,L,L] (head-major), wb_frags = linear_b

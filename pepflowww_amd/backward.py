@@ -580,7 +580,8 @@ class EdgeTransitionBlock:
         idx = _et_stream_index(dev)
         v = torch.cat([w1.reshape(-1), w2.reshape(-1), wf.reshape(-1)])[idx]                    # [128, 512]
         hi = v.to(torch.float16)
-        lo = ((v - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+        from .engine import ET_LO_SCALE
+        lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
         stream = torch.stack([hi, lo], 1).contiguous()                                          # [128, 2, 512] f16
         out, h1, h2, y = (torch.empty(P, 64, device=dev), torch.empty(P, 192, device=dev), torch.empty(P, 192, device=dev),
                           torch.empty(P, 64, device=dev))

@@ -68,7 +68,6 @@ constexpr int OFF_CS = OFF_MK + 256;          // LayerNorm gamma[64] | beta[64] 
 constexpr int CONST_F = 64 + 64 + 192 + 16;
 constexpr int OFF_WB = OFF_CS + CONST_F * 4;  // 2 fragment pairs of the next block's linear_b (heads padded to 16)
 constexpr int LDS_BYTES = OFF_WB + 2 * KF;
-constexpr float LOI = PF_LO_INV;
 
 __device__ __forceinline__ void stage_barrier() {
     asm volatile("" ::: "memory");
@@ -95,18 +94,22 @@ __device__ __forceinline__ Frag ldfrag(const unsigned char* slot, int kf, int la
     if constexpr (!SP) f.l = *reinterpret_cast<const half8*>(slot + kf * KF + 1024 + lane * 16);
     return f;
 }
-// two independent (main, corr) accumulator pairs per call; the two MFMAs into one corr accumulator are 4 issue slots apart
+// two independent accumulators per call.  fp32-parity mode: x = hi + lo with lo = f16(x - hi) UNSCALED (gfx950's f16 MFMA
+// honours subnormal operands, tools/dev/mfma_denorm.hip), so the three products w_hi x_lo + w_hi x_hi + w_lo x_hi go into
+// ONE fp32 accumulator -- no separate correction accumulator, no join, no 2048 scaling in the re-split of the activations
+// (the other split-precision kernels keep lo * 2048 in a second accumulator: they are not VALU-bound).  Operand resolution:
+// relative 2^-22 for |x| >= 0.25, absolute 2^-25 below (the f16 subnormal grid of lo).
 template <bool SP>
-__device__ __forceinline__ void mac2(const Frag& w0, const Frag& w1, half8 xh, half8 xl, f32x4& m0, f32x4& c0, f32x4& m1, f32x4& c1) {
+__device__ __forceinline__ void mac2(const Frag& w0, const Frag& w1, half8 xh, half8 xl, f32x4& m0, f32x4& m1) {
     if constexpr (!SP) {
-        c0 = mfma_h(w0.h, xl, c0);
-        c1 = mfma_h(w1.h, xl, c1);
+        m0 = mfma_h(w0.h, xl, m0);
+        m1 = mfma_h(w1.h, xl, m1);
     }
     m0 = mfma_h(w0.h, xh, m0);
     m1 = mfma_h(w1.h, xh, m1);
     if constexpr (!SP) {
-        c0 = mfma_h(w0.l, xh, c0);
-        c1 = mfma_h(w1.l, xh, c1);
+        m0 = mfma_h(w0.l, xh, m0);
+        m1 = mfma_h(w1.l, xh, m1);
     }
 }
 __device__ __forceinline__ half8 cat4(half4 a, half4 b) {
@@ -114,24 +117,16 @@ __device__ __forceinline__ half8 cat4(half4 a, half4 b) {
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
     return o;
 }
-#ifndef PF_ET_NO_FMA
-// lo = (v - hi) * 2048 as ONE fused op on top of v * 2048: fma(hi, -2048, v * 2048) -- every term is exact in fp32, so the
-// result is bit-identical to the three-op form (convert, subtract, scale); the compiler folds the f16 -> f32 extension of
-// hi into v_fma_mix_f32
-__device__ __forceinline__ void split4f(const float (&v)[4], half4& hi, half4& lo) {
+// hi = f16(v), lo = f16(v - hi): v - hi is exact in fp32; the compiler folds the f16 -> f32 extension of hi and the f16
+// rounding of the result into one v_fma_mix{lo,hi}_f16
+__device__ __forceinline__ void split4u(const float (&v)[4], half4& hi, half4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const _Float16 h = (_Float16)v[e];
         hi[e] = h;
-        lo[e] = (_Float16)__builtin_fmaf((float)h, -PF_LO_SCALE, v[e] * PF_LO_SCALE);
+        lo[e] = (_Float16)__builtin_fmaf((float)h, -1.0f, v[e]);
     }
 }
-#define SPLIT4 split4f
-#define JOIN(m, c) __builtin_fmaf((c), LOI, (m))
-#else
-#define SPLIT4 split4
-#define JOIN(m, c) ((m) + (c) * LOI)
-#endif
 template <bool SP>
 __device__ __forceinline__ void split8(const float4& a, const float4& b, half8& hi, half8& lo) {
     if constexpr (SP) {
@@ -141,13 +136,12 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, half8& 
     } else {
         const float v0[4] = {a.x, a.y, a.z, a.w}, v1[4] = {b.x, b.y, b.z, b.w};
         half4 h0, l0, h1, l1;
-        SPLIT4(v0, h0, l0);
-        SPLIT4(v1, h1, l1);
+        split4u(v0, h0, l0);
+        split4u(v1, h1, l1);
         hi = cat4(h0, h1);
         lo = cat4(l0, l1);
     }
 }
-template <bool SP> __device__ __forceinline__ float joinsp(float m, float c) { if constexpr (SP) return m; else return JOIN(m, c); }
 __device__ __forceinline__ f32x4 add4(const float4& a, const float4& b) { return (f32x4){a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
 struct Tile { int b, i0, j0; };
@@ -354,7 +348,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         const bool valid = i < L && j < L;
         const size_t pidx = (size_t)(tl.b * L + i) * L + j;
         half8 h1h[6], h1l[6];
-        f32x4 m3[4], c3[4];
+        f32x4 m3[4];
         half8 zh[2], zl[2];
         float mk = 0.f;
         // ---- stages 0-1: GEMM1 (12 feature tiles, two at a time) then the z part of GEMM3 ----
@@ -382,18 +376,17 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             // accumulators start at a_i + c_j (b1 is folded into c)
             f32x4 m0 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp), *reinterpret_cast<const float4*>(ce + 32 * tp));
             f32x4 m1 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp + 16), *reinterpret_cast<const float4*>(ce + 32 * tp + 16));
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
             // fragment reads run one K-step ahead of the MFMAs (within a ring stage)
             if (tp == 0 || tp == 4) { ga0 = ldfrag<SP>(sl, kf0, lane); gb0 = ldfrag<SP>(sl, kf0 + 2, lane); }
             const Frag ga1 = ldfrag<SP>(sl, kf0 + 1, lane), gb1 = ldfrag<SP>(sl, kf0 + 3, lane);
-            mac2<SP>(ga0, gb0, zh[0], zl[0], m0, c0, m1, c1);
+            mac2<SP>(ga0, gb0, zh[0], zl[0], m0, m1);
             if (tp != 3 && tp != 5) { ga0 = ldfrag<SP>(sl, kf0 + 4, lane); gb0 = ldfrag<SP>(sl, kf0 + 6, lane); }
-            mac2<SP>(ga1, gb1, zh[1], zl[1], m0, c0, m1, c1);
+            mac2<SP>(ga1, gb1, zh[1], zl[1], m0, m1);
             float4 v0, v1;
-            v0.x = fmaxf(joinsp<SP>(m0[0], c0[0]), 0.f); v0.y = fmaxf(joinsp<SP>(m0[1], c0[1]), 0.f);
-            v0.z = fmaxf(joinsp<SP>(m0[2], c0[2]), 0.f); v0.w = fmaxf(joinsp<SP>(m0[3], c0[3]), 0.f);
-            v1.x = fmaxf(joinsp<SP>(m1[0], c1[0]), 0.f); v1.y = fmaxf(joinsp<SP>(m1[1], c1[1]), 0.f);
-            v1.z = fmaxf(joinsp<SP>(m1[2], c1[2]), 0.f); v1.w = fmaxf(joinsp<SP>(m1[3], c1[3]), 0.f);
+            v0.x = fmaxf(m0[0], 0.f); v0.y = fmaxf(m0[1], 0.f);
+            v0.z = fmaxf(m0[2], 0.f); v0.w = fmaxf(m0[3], 0.f);
+            v1.x = fmaxf(m1[0], 0.f); v1.y = fmaxf(m1[1], 0.f);
+            v1.z = fmaxf(m1[2], 0.f); v1.w = fmaxf(m1[3], 0.f);
             if constexpr (DUMP) {
                 if (valid) {
                     *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 4 * g) = v0;
@@ -408,14 +401,13 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 m3[t] = add4(*reinterpret_cast<const float4*>(ad + 192 + 16 * t), *reinterpret_cast<const float4*>(ce + 192 + 16 * t));
-                c3[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag w0 = ldfrag<SP>(sl, 8 + s, lane), w1 = ldfrag<SP>(sl, 10 + s, lane);
                 const Frag w2 = ldfrag<SP>(sl, 12 + s, lane), w3 = ldfrag<SP>(sl, 14 + s, lane);
-                mac2<SP>(w0, w1, zh[s], zl[s], m3[0], c3[0], m3[1], c3[1]);
-                mac2<SP>(w2, w3, zh[s], zl[s], m3[2], c3[2], m3[3], c3[3]);
+                mac2<SP>(w0, w1, zh[s], zl[s], m3[0], m3[1]);
+                mac2<SP>(w2, w3, zh[s], zl[s], m3[2], m3[3]);
             }
         }
         PROF3(6);
@@ -431,7 +423,6 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             const float4 b0 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 4 * g);
             const float4 b1 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 16 + 4 * g);
             f32x4 m0 = {b0.x, b0.y, b0.z, b0.w}, m1 = {b1.x, b1.y, b1.z, b1.w};      // accumulators start at b2
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
             Frag wa[2], wb[2];                 // fragment reads run one K-step ahead of the MFMAs that use them
             wa[0] = ldfrag<SP>(sl, 0, lane);
             wb[0] = ldfrag<SP>(sl, 6, lane);
@@ -441,13 +432,13 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                     wa[(k + 1) & 1] = ldfrag<SP>(sl, k + 1, lane);
                     wb[(k + 1) & 1] = ldfrag<SP>(sl, 7 + k, lane);
                 }
-                mac2<SP>(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, c0, m1, c1);
+                mac2<SP>(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, m1);
             }
             float4 v0, v1;
-            v0.x = fmaxf(joinsp<SP>(m0[0], c0[0]), 0.f); v0.y = fmaxf(joinsp<SP>(m0[1], c0[1]), 0.f);
-            v0.z = fmaxf(joinsp<SP>(m0[2], c0[2]), 0.f); v0.w = fmaxf(joinsp<SP>(m0[3], c0[3]), 0.f);
-            v1.x = fmaxf(joinsp<SP>(m1[0], c1[0]), 0.f); v1.y = fmaxf(joinsp<SP>(m1[1], c1[1]), 0.f);
-            v1.z = fmaxf(joinsp<SP>(m1[2], c1[2]), 0.f); v1.w = fmaxf(joinsp<SP>(m1[3], c1[3]), 0.f);
+            v0.x = fmaxf(m0[0], 0.f); v0.y = fmaxf(m0[1], 0.f);
+            v0.z = fmaxf(m0[2], 0.f); v0.w = fmaxf(m0[3], 0.f);
+            v1.x = fmaxf(m1[0], 0.f); v1.y = fmaxf(m1[1], 0.f);
+            v1.z = fmaxf(m1[2], 0.f); v1.w = fmaxf(m1[3], 0.f);
             half8 xh, xl;
             if constexpr (DUMP) {
                 if (valid) {
@@ -457,8 +448,8 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             }
             split8<SP>(v0, v1, xh, xl);
             const Frag w0 = ldfrag<SP>(sl, 12, lane), w1 = ldfrag<SP>(sl, 13, lane), w2 = ldfrag<SP>(sl, 14, lane), w3 = ldfrag<SP>(sl, 15, lane);
-            mac2<SP>(w0, w1, xh, xl, m3[0], c3[0], m3[1], c3[1]);
-            mac2<SP>(w2, w3, xh, xl, m3[2], c3[2], m3[3], c3[3]);
+            mac2<SP>(w0, w1, xh, xl, m3[0], m3[1]);
+            mac2<SP>(w2, w3, xh, xl, m3[2], m3[3]);
         }
         PROF3(13);
         slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;           // slot of the next tile's stage 0
@@ -467,10 +458,10 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         float y[16];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            y[4 * t + 0] = joinsp<SP>(m3[t][0], c3[t][0]);
-            y[4 * t + 1] = joinsp<SP>(m3[t][1], c3[t][1]);
-            y[4 * t + 2] = joinsp<SP>(m3[t][2], c3[t][2]);
-            y[4 * t + 3] = joinsp<SP>(m3[t][3], c3[t][3]);
+            y[4 * t + 0] = m3[t][0];
+            y[4 * t + 1] = m3[t][1];
+            y[4 * t + 2] = m3[t][2];
+            y[4 * t + 3] = m3[t][3];
         }
         if constexpr (DUMP) {
             if (valid) {
@@ -508,7 +499,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             // pair bias of the NEXT IPA block from z' while it is in registers: one more 64 -> 8(16) split-precision GEMM with
             // z' as the B operand (same K permutation as the other register-resident activations); heads 4*(lane>>4)+e
             const unsigned char* wb = smem + OFF_WB;
-            f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bc = bm, bm2 = bm, bc2 = bm;
+            f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bm2 = bm;
             half8 oh0, ol0, oh1, ol1;
             split8<SP>(o4[0], o4[1], oh0, ol0);
             split8<SP>(o4[2], o4[3], oh1, ol1);
@@ -520,20 +511,20 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 f0.l = *reinterpret_cast<const half8*>(wb + 1024 + lane * 16);
                 f1.l = *reinterpret_cast<const half8*>(wb + KF + 1024 + lane * 16);
             }
-            if constexpr (!SP) { bc = mfma_h(f0.h, ol0, bc); bc2 = mfma_h(f1.h, ol1, bc2); }
+            if constexpr (!SP) { bm = mfma_h(f0.h, ol0, bm); bm2 = mfma_h(f1.h, ol1, bm2); }
             bm = mfma_h(f0.h, oh0, bm);
             bm2 = mfma_h(f1.h, oh1, bm2);
-            if constexpr (!SP) { bc = mfma_h(f0.l, oh0, bc); bc2 = mfma_h(f1.l, oh1, bc2); }
+            if constexpr (!SP) { bm = mfma_h(f0.l, oh0, bm); bm2 = mfma_h(f1.l, oh1, bm2); }
             if (valid && g < 2) {
                 const float4 bb = *reinterpret_cast<const float4*>(Cs + 320 + 4 * g);
                 const float s13 = 0.57735026918962576f;   // sqrt(1/3), ipa_pytorch.py:404
                 // [B,8,L,L] head-major: the 16 lanes of a group write 64 contiguous bytes of one (head, row i)
                 float* bo = a.bias_out + (((size_t)tl.b * 8 + 4 * g) * L + i) * L + j;
                 const size_t hs = (size_t)L * L;
-                bo[0] = s13 * ((bm[0] + bm2[0]) + (bc[0] + bc2[0]) * LOI + bb.x);
-                bo[hs] = s13 * ((bm[1] + bm2[1]) + (bc[1] + bc2[1]) * LOI + bb.y);
-                bo[2 * hs] = s13 * ((bm[2] + bm2[2]) + (bc[2] + bc2[2]) * LOI + bb.z);
-                bo[3 * hs] = s13 * ((bm[3] + bm2[3]) + (bc[3] + bc2[3]) * LOI + bb.w);
+                bo[0] = s13 * ((bm[0] + bm2[0]) + bb.x);
+                bo[hs] = s13 * ((bm[1] + bm2[1]) + bb.y);
+                bo[2 * hs] = s13 * ((bm[2] + bm2[2]) + bb.z);
+                bo[3 * hs] = s13 * ((bm[3] + bm2[3]) + bb.w);
             }
         }
         PROF3(14);

@@ -58,15 +58,21 @@ def split_f16(w):
     return frag.contiguous()
 
 
+# The persistent EdgeTransition kernel keeps lo = f16(w - hi) UNSCALED (three products into one accumulator, see
+# csrc/edge_transition_v3.hip): operands resolve to 2^-22 relative above 0.25 and to the f16 subnormal grid (2^-25 absolute)
+# below.  Every other split-precision kernel uses lo * LO_SCALE.
+ET_LO_SCALE = 1.0
+
+
 def _frag_pair(W, ft, kidx):
-    """One fragment pair (hi 512 f16 | lo 512 f16) of feature tile ft: lane (row = lane & 15, kg = lane >> 4) holds
-    W[16 ft + row][kidx[kg, 0..7]]."""
+    """One fragment pair (hi 512 f16 | lo 512 f16, lo = f16((w - hi) * ET_LO_SCALE)) of feature tile ft: lane (row = lane & 15,
+    kg = lane >> 4) holds W[16 ft + row][kidx[kg, 0..7]]."""
     lane = torch.arange(64, device=W.device)
     rows = 16 * ft + (lane & 15)
     v = W[rows[:, None], kidx[(lane >> 4)]]                     # [64, 8]
     check_f16_range(v)
     hi = v.to(torch.float16)
-    lo = ((v - hi.to(torch.float32)) * LO_SCALE).to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
     return torch.cat([hi.reshape(-1), lo.reshape(-1)])
 
 
