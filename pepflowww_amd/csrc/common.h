@@ -283,6 +283,37 @@ __device__ __forceinline__ void gemm_split16(WSplit<WT, D, SP>& ws, const _Float
         }
     }
 }
+// the same with RT row tiles of 16 per weight fragment: one fragment load from L2 feeds RT x 3 MFMAs (the node-track kernels are
+// bound by the L2 -> CU weight stream: every 16-row workgroup re-reads every matrix)
+template <int WT, int D, bool SP, int RT>
+__device__ __forceinline__ void gemm_split16r(WSplit<WT, D, SP>& ws, const _Float16* Xh, const _Float16* Xl, int ldx,
+                                              f32x4 (&am)[RT][WT], f32x4 (&ac)[RT][WT], int step0, int count) {
+    const int lane = threadIdx.x & 63;
+    const int off = (lane & 15) * ldx + 8 * (lane >> 4);
+    for (int base = 0; base < count; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (base + u < count) {
+                const int st = step0 + base + u;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const half8 xh = *reinterpret_cast<const half8*>(Xh + rt * 16 * ldx + off + 32 * (base + u));
+                    half8 xl;
+                    if constexpr (!SP) xl = *reinterpret_cast<const half8*>(Xl + rt * 16 * ldx + off + 32 * (base + u));
+#pragma unroll
+                    for (int wt = 0; wt < WT; ++wt) {
+                        am[rt][wt] = mfma_h(ws.rh[u][wt], xh, am[rt][wt]);
+                        if constexpr (!SP) {
+                            ac[rt][wt] = mfma_h(ws.rh[u][wt], xl, ac[rt][wt]);
+                            ac[rt][wt] = mfma_h(ws.rl[u][wt], xh, ac[rt][wt]);
+                        }
+                    }
+                }
+                if (st + D < ws.nsteps) ws.load(st + D, ws.rh[u], ws.rl[u]);
+            }
+        }
+    }
+}
 template <int WT> __device__ __forceinline__ void acc_zero1(f32x4 (&a)[WT], f32x4 (&b)[WT]) {
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) { a[wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; b[wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }

@@ -54,9 +54,10 @@ __device__ __forceinline__ void ln_load(LnParams& p, const float* __restrict__ g
     p.g[0] = g0.x; p.g[1] = g0.y; p.g[2] = g0.z; p.g[3] = g0.w; p.g[4] = g1.x; p.g[5] = g1.y; p.g[6] = g1.z; p.g[7] = g1.w;
     p.b[0] = b0.x; p.b[1] = b0.y; p.b[2] = b0.z; p.b[3] = b0.w; p.b[4] = b1.x; p.b[5] = b1.y; p.b[6] = b1.z; p.b[7] = b1.w;
 }
+template <int ROWS = 16>
 __device__ __forceinline__ void ln_tile(float* T, const LnParams& p, float mk, Planes out, int m0, int M, float* gout) {
     const int tid = threadIdx.x;
-    if (tid < 256) {
+    if (tid < 16 * ROWS) {
         const int row = tid >> 4, sub = tid & 15, m = m0 + row;
         float v[8];
         {
@@ -198,6 +199,119 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
             y.x = join(qm[wt], qc[wt], 0) + bias_in[wt].x; y.y = join(qm[wt], qc[wt], 1) + bias_in[wt].y;
             y.z = join(qm[wt], qc[wt], 2) + bias_in[wt].z; y.w = join(qm[wt], qc[wt], 3) + bias_in[wt].w;
             *reinterpret_cast<float4*>(a.qkv + (size_t)mr * 384 + wave * 48 + wt * 16 + 4 * g) = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_head for large batches: 32 rows per workgroup.  The 16-row form re-reads linear_out (768 KiB of hi | lo planes) and in_proj
+// (192 KiB) from L2 once per 16 rows -- 0.5 GB of L2 -> CU traffic at 8192 rows, which is what its 38 us were; here every weight
+// fragment feeds two row tiles.  The feats tile is staged chunk by chunk (one chunk of loads in flight under the MFMAs of the
+// previous one) instead of being requested whole at entry (96 VGPRs at 32 rows).
+constexpr int TR2 = 32;
+template <bool SP>
+__global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_head_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int CK = 256, LDC = CK + 8;      // feats chunk width (8 K-steps = the weight ring depth), f16 stride
+    _Float16* Ch = reinterpret_cast<_Float16*>(smem_raw);     // [2 buffers][2 planes][32][LDC]
+    float* X = reinterpret_cast<float*>(smem_raw + 2 * 2 * TR2 * LDC * sizeof(_Float16));   // [32][LDX] fp32
+    Planes Xa = {reinterpret_cast<_Float16*>(X + TR2 * LDX), reinterpret_cast<_Float16*>(X + TR2 * LDX) + TR2 * LDP};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * TR2, M = a.rows;
+    const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
+
+    WSplit<1, 8, SP> ws;
+    ws.init(a.w_out_f16, 128, PF_IPA_FEATS, wave * 16);
+    ws.prefetch();
+    LnParams lnp;
+    ln_load(lnp, a.ln_g, a.ln_b);
+    const float4 bias_out = *reinterpret_cast<const float4*>(a.b_out + n);
+    float4 bias_in[3];
+#pragma unroll
+    for (int wt = 0; wt < 3; ++wt) bias_in[wt] = *reinterpret_cast<const float4*>(a.b_in + wave * 48 + wt * 16 + 4 * g);
+    float rmask_ld[2];
+    float4 rres_ld[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int mr = m0 + rt * 16 + r;
+        const int mrc = mr < M ? mr : M - 1;
+        rmask_ld[rt] = a.mask[mrc];
+        rres_ld[rt] = *reinterpret_cast<const float4*>(a.s_in + (size_t)mrc * 128 + n);
+    }
+    // chunk c of the feats tile: 32 rows x 256 columns = 2048 float4, 4 per thread; a wave reads one row's KiB per instruction
+    constexpr int NCH = PF_IPA_FEATS / CK;
+    float4 st[2][4];
+    auto fetch = [&](int c, float4 (&d)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + u * NTHR, row = idx >> 6, c4 = idx & 63;
+            const int m = m0 + row < M ? m0 + row : M - 1;
+            d[u] = *reinterpret_cast<const float4*>(a.feats + (size_t)m * PF_IPA_FEATS + c * CK + 4 * c4);
+        }
+    };
+    auto commit = [&](int c, const float4 (&d)[4]) {
+        _Float16* bh = Ch + (c & 1) * 2 * TR2 * LDC;
+        _Float16* bl = bh + TR2 * LDC;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + u * NTHR, row = idx >> 6, c4 = idx & 63;
+            const float4 sv = sel4(m0 + row < M, d[u]);
+            const float v[4] = {sv.x, sv.y, sv.z, sv.w};
+            half4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<half4*>(bh + row * LDC + 4 * c4) = hi;
+            *reinterpret_cast<half4*>(bl + row * LDC + 4 * c4) = lo;
+        }
+    };
+    fetch(0, st[0]);
+    fetch(1, st[1]);
+    commit(0, st[0]);
+    __syncthreads();
+    f32x4 am[2][1], ac[2][1];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) acc_zero1<1>(am[rt], ac[rt]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 2 < NCH) fetch(c + 2, st[c & 1]);             // (its buffer was committed one iteration ago)
+        const _Float16* bh = Ch + (c & 1) * 2 * TR2 * LDC;
+        gemm_split16r<1, 8, SP, 2>(ws, bh, bh + TR2 * LDC, LDC, am, ac, c * 8, 8);
+        if (c + 1 < NCH) commit(c + 1, st[(c + 1) & 1]);
+        __syncthreads();
+    }
+    WSplit<3, 4, SP> wq;                                      // next stage's weights: in_proj of tfmr layer 0
+    wq.init(a.w_in_f16, 384, 128, wave * 48);
+    wq.prefetch();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int mr = m0 + rt * 16 + r;
+        const float rmask = rmask_ld[rt] * (mr < M ? 1.f : 0.f);
+        const float4 rres = sel4(mr < M, rres_ld[rt]);
+        float4 y;
+        y.x = (join(am[rt][0], ac[rt][0], 0) + bias_out.x) * rmask + rres.x;
+        y.y = (join(am[rt][0], ac[rt][0], 1) + bias_out.y) * rmask + rres.y;
+        y.z = (join(am[rt][0], ac[rt][0], 2) + bias_out.z) * rmask + rres.z;
+        y.w = (join(am[rt][0], ac[rt][0], 3) + bias_out.w) * rmask + rres.w;
+        *reinterpret_cast<float4*>(X + (rt * 16 + r) * LDX + n) = y;
+    }
+    __syncthreads();
+    ln_tile<TR2>(X, lnp, 1.f, Xa, m0, M, a.s_ipa);
+    __syncthreads();
+    f32x4 qm[2][3], qc[2][3];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) acc_zero1<3>(qm[rt], qc[rt]);
+    gemm_split16r<3, 4, SP, 2>(wq, Xa.h, Xa.l, LDP, qm, qc, 0, 4);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int mr = m0 + rt * 16 + r;
+        if (mr < M) {
+#pragma unroll
+            for (int wt = 0; wt < 3; ++wt) {
+                float4 y;
+                y.x = join(qm[rt][wt], qc[rt][wt], 0) + bias_in[wt].x; y.y = join(qm[rt][wt], qc[rt][wt], 1) + bias_in[wt].y;
+                y.z = join(qm[rt][wt], qc[rt][wt], 2) + bias_in[wt].z; y.w = join(qm[rt][wt], qc[rt][wt], 3) + bias_in[wt].w;
+                *reinterpret_cast<float4*>(a.qkv + (size_t)mr * 384 + wave * 48 + wt * 16 + 4 * g) = y;
+            }
         }
     }
 }
@@ -717,6 +831,20 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
         return PF_E_BADARG;
     const size_t lds = (size_t)2 * 2 * TR * 264 * sizeof(_Float16) + (size_t)TR * LDX * sizeof(float) +
                        (size_t)2 * TR * LDP * sizeof(_Float16);
+    if (a->rows >= 256 * TR2) {                  // a workgroup per CU even at 32 rows: halve the L2 -> CU weight stream
+        const size_t lds2 = (size_t)2 * 2 * TR2 * 264 * sizeof(_Float16) + (size_t)TR2 * LDX * sizeof(float) + (size_t)2 * TR2 * LDP * sizeof(_Float16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)node_head32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)node_head32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        const dim3 grid((unsigned)((a->rows + TR2 - 1) / TR2));
+        if (a->single_pass) hipLaunchKernelGGL(node_head32_kernel<true>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(node_head32_kernel<false>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     if (a->single_pass) hipLaunchKernelGGL(node_head_kernel<true>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(node_head_kernel<false>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
