@@ -186,6 +186,10 @@ __device__ __forceinline__ void gemm_ldsA_glbB(const float* __restrict__ A_lds, 
 // Weights are pre-split on the host ([2][N][K] f16 planes); activations are split when written to LDS.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+// exp for softmax arguments (x <= 0 after the row maximum is subtracted): v_mul + v_exp_f32 instead of the 15-instruction
+// correctly-rounded expf.  Error: ~1 ulp of v_exp_f32 plus |x| * 2^-24 from the rounded product -- < 1e-6 relative where the
+// result matters (x > -20); results below 2^-126 flush to zero.
+__device__ __forceinline__ float exp_softmax(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 constexpr float PF_LO_SCALE = 2048.f, PF_LO_INV = 1.f / 2048.f;
 
 __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void ipa_attn_kernel(pf_ipa_attn_args a, i
             for (int j = sub; j < L; j += 8) m = fmaxf(m, sp[j]);
             m = fmaxf(m, lane_xor1(m)); m = fmaxf(m, lane_xor2(m)); m = fmaxf(m, lane_xor4(m));
             float sum = 0.f;
-            for (int j = sub; j < L; j += 8) { const float e = expf(sp[j] - m); sp[j] = e; sum += e; }
+            for (int j = sub; j < L; j += 8) { const float e = exp_softmax(sp[j] - m); sp[j] = e; sum += e; }
             sum += lane_xor1(sum); sum += lane_xor2(sum); sum += lane_xor4(sum);
             const float inv = 1.f / sum;
             for (int j = sub; j < L; j += 8) sp[j] *= inv;

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     float sum = 0.f;
     for (int t = 0; t < kt; ++t) {
         float4 v = *reinterpret_cast<const float4*>(srow + 16 * t);
-        v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);
+        v.x = exp_softmax(v.x - mx); v.y = exp_softmax(v.y - mx); v.z = exp_softmax(v.z - mx); v.w = exp_softmax(v.w - mx);
         sum += v.x; sum += v.y; sum += v.z; sum += v.w;
         *reinterpret_cast<float4*>(srow + 16 * t) = v;
     }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     float sum = 0.f;
     for (int t = 0; t < kt; ++t) {
         float4 v = *reinterpret_cast<const float4*>(srow + 16 * t + 4 * g);
-        v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);
+        v.x = exp_softmax(v.x - mx); v.y = exp_softmax(v.y - mx); v.z = exp_softmax(v.z - mx); v.w = exp_softmax(v.w - mx);
         sum += v.x; sum += v.y; sum += v.z; sum += v.w;
         *reinterpret_cast<float4*>(srow + 16 * t + 4 * g) = v;
     }

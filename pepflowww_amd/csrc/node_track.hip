@@ -23,7 +23,10 @@
 
 #ifdef PF_PROFILE
 __device__ long long g_prof[64];
-#define PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] = clock64(); } while (0)
+#ifndef PF_PROF_LAST
+#define PF_PROF_LAST 1
+#endif
+#define PROF(i) do { if (LAST == (PF_PROF_LAST != 0) && blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] = clock64(); } while (0)
 extern "C" int pf_debug_prof(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
 }
@@ -349,24 +352,28 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         q0 = *reinterpret_cast<const float4*>(qrow);
         q1 = *reinterpret_cast<const float4*>(qrow + 16);
     }
-    // K rows of the first key block and the V operands of the first PV block: requested before everything else --
-    // they gate the first MFMAs, and vmcnt completes in order (for L <= 64 these are ALL the K/V loads)
+    // q, then the K rows of this wave's first TWO key blocks (all of them for L <= 128), then the V operands of the first two PV
+    // blocks: requested before everything else and in THIS order (the compiler otherwise sinks the q / K loads below ~50 weight
+    // and bias loads, and vmcnt completes in order: the first MFMA then waited for all of them -- 5 k cycles at entry, and the
+    // second block's K loads were requested right in front of the MFMAs that needed them, another 2 k)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int par = wave >> 2;
-    float4 kf0[2], kf1[2];
-    float kfm[2];
     auto kload = [&](int j0, float4 (&k0)[2], float4 (&k1)[2], float (&km)[2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = j0 + 32 * t + r;
-            const bool jok = j < L;
-            const float* krow = a.qkv + (rowb + (jok ? j : 0)) * 384 + 128 + h * 32 + 4 * g;
-            k0[t] = *reinterpret_cast<const float4*>(krow);              // (clamped row; masked out through km)
+            const int jc = j < L ? j : L - 1;                            // (clamped row; masked out at the use)
+            const float* krow = a.qkv + (rowb + jc) * 384 + 128 + h * 32 + 4 * g;
+            k0[t] = *reinterpret_cast<const float4*>(krow);
             k1[t] = *reinterpret_cast<const float4*>(krow + 16);
-            km[t] = a.mask[rowb + (jok ? j : 0)] * (jok ? 1.f : 0.f);
+            km[t] = a.mask[rowb + jc];
         }
     };
-    kload(16 * par, kf0, kf1, kfm);
+    float4 kfA0[2], kfA1[2], kfB0[2], kfB1[2];
+    float kfAm[2], kfBm[2];
+    kload(16 * par, kfA0, kfA1, kfAm);
+    kload(16 * par + 64, kfB0, kfB1, kfBm);
+    asm volatile("" ::: "memory");
     const int ct = wave >> 2;
     const float* vcol = a.qkv + rowb * 384 + 256 + h * 32 + ct * 16 + r;
     auto vload = [&](int k0, float (&vb)[4][4]) {
@@ -379,8 +386,10 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                 vb[s4][t] = vcol[(size_t)j * 384];
             }
     };
-    float vb[4][4];
-    vload(0, vb);
+    float vbA[4][4], vbB[4][4];
+    vload(0, vbA);
+    vload(64, vbB);
+    asm volatile("" ::: "memory");
     WSplit<1, 4, SP> ws;
     ws.init(a.w_o_f16, 128, 128, wave * 16);
     ws.prefetch();
@@ -393,24 +402,26 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     float4 bias_post = z4, bias_t1 = z4, bias_t2 = z4, bias_t3 = z4, bias_bb = z4, bias_init = z4;
     float4 bias_in[3] = {z4, z4, z4}, bias_pre[4] = {z4, z4, z4, z4};
     const int mrc = mr < M ? mr : M - 1;
-    const float4 rres = sel4(mr < M, *reinterpret_cast<const float4*>(a.resid + (size_t)mrc * 128 + n));
-    float4 rsipa = z4;
-    float lnmask = 1.f;                       // row mask of the LayerNorm lane's row (tail LayerNorm only)
+    // (loaded raw; the out-of-range select is applied at the use -- a multiply here makes the wave wait for the load here)
+    const float4 rres_ld = *reinterpret_cast<const float4*>(a.resid + (size_t)mrc * 128 + n);
+    float4 rsipa_ld = z4;
+    float lnmask_ld = 1.f;                    // row mask of the LayerNorm lane's row (tail LayerNorm only)
+    const int lnrow = m0 + ((tid & 255) >> 4);
     if (LAST) {
-        rsipa = sel4(mr < M, *reinterpret_cast<const float4*>(a.s_ipa + (size_t)mrc * 128 + n));
+        rsipa_ld = *reinterpret_cast<const float4*>(a.s_ipa + (size_t)mrc * 128 + n);
         bias_post = *reinterpret_cast<const float4*>(a.b_post + n);
         bias_t1 = *reinterpret_cast<const float4*>(a.b_t1 + n);
         bias_t2 = *reinterpret_cast<const float4*>(a.b_t2 + n);
         bias_t3 = *reinterpret_cast<const float4*>(a.b_t3 + n);
         // b_bb is padded to 8 floats by the caller: ONE load (two masked loads into the same registers made the
         // compiler drain vmcnt(0) -- i.e. every prefetch issued above -- in wave 0 before it could go on)
-        bias_bb = sel4(wave == 0 && g < 2, *reinterpret_cast<const float4*>(a.b_bb + 4 * (g & 1)));
+        bias_bb = *reinterpret_cast<const float4*>(a.b_bb + 4 * (g & 1));     // (used by wave 0, g < 2 only)
         if (a.has_et) {
             bias_init = *reinterpret_cast<const float4*>(a.b_init + (wave & 3) * 16 + 4 * g);
 #pragma unroll
             for (int wt = 0; wt < 4; ++wt) bias_pre[wt] = *reinterpret_cast<const float4*>(a.b_pre + wave * 64 + wt * 16 + 4 * g);
         }
-        { const int m = m0 + ((tid & 255) >> 4); const float mv = a.mask[m < M ? m : M - 1]; lnmask = mv * (m < M ? 1.f : 0.f); }
+        lnmask_ld = a.mask[lnrow < M ? lnrow : M - 1];
     } else {
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) bias_in[wt] = *reinterpret_cast<const float4*>(a.b_in_next + wave * 48 + wt * 16 + 4 * g);
@@ -420,43 +431,71 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     // ---- attention scores (exact fp32 MFMA): wave -> head h = w&3, key tiles of parity w>>2 ----
     {
         const float scale = 0.17677669529663687f;   // 1/sqrt(32)
-        for (int j0 = 16 * par; j0 < LP; j0 += 64) {
-            float4 kn0[2], kn1[2];
-            float knm[2];
-            const bool more = j0 + 64 < LP;
-            if (more) kload(j0 + 64, kn0, kn1, knm);
+        auto score_block = [&](int j0, const float4 (&k0)[2], const float4 (&k1)[2], const float (&km)[2]) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int j = j0 + 32 * t + r;
                 if (j0 + 32 * t < LP) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma16(q0.x, kf0[t].x, acc); acc = mfma16(q0.y, kf0[t].y, acc); acc = mfma16(q0.z, kf0[t].z, acc); acc = mfma16(q0.w, kf0[t].w, acc);
-                    acc = mfma16(q1.x, kf1[t].x, acc); acc = mfma16(q1.y, kf1[t].y, acc); acc = mfma16(q1.z, kf1[t].z, acc); acc = mfma16(q1.w, kf1[t].w, acc);
-                    const bool keep = kfm[t] > 0.5f;              // key padding mask
+                    acc = mfma16(q0.x, k0[t].x, acc); acc = mfma16(q0.y, k0[t].y, acc); acc = mfma16(q0.z, k0[t].z, acc); acc = mfma16(q0.w, k0[t].w, acc);
+                    acc = mfma16(q1.x, k1[t].x, acc); acc = mfma16(q1.y, k1[t].y, acc); acc = mfma16(q1.z, k1[t].z, acc); acc = mfma16(q1.w, k1[t].w, acc);
+                    const bool keep = j < L && km[t] > 0.5f;       // key padding mask
 #pragma unroll
                     for (int e = 0; e < 4; ++e) S[((4 * g + e) * 4 + h) * LDS_S + j] = keep ? acc[e] * scale : -3.0e38f;
                 }
             }
-            if (more) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) { kf0[t] = kn0[t]; kf1[t] = kn1[t]; kfm[t] = knm[t]; }
-            }
+        };
+        score_block(16 * par, kfA0, kfA1, kfAm);
+        if (16 * par + 64 < LP) score_block(16 * par + 64, kfB0, kfB1, kfBm);
+        for (int j0 = 16 * par + 128; j0 < LP; j0 += 64) {        // L > 128: not prefetched
+            float4 kn0[2], kn1[2];
+            float knm[2];
+            kload(j0, kn0, kn1, knm);
+            score_block(j0, kn0, kn1, knm);
         }
     }
     __syncthreads();
     PROF(2);
-    // softmax: the 64 (ti,h) rows, 8 rows per wave at once, 8 lanes per row
+    // softmax: the 64 (ti,h) rows, 8 rows per wave at once, 8 lanes per row.  A lane's share of the row (float4 groups 8 apart)
+    // is read into registers in one go: three dependent LDS round trips per element (max, exp + sum, scale) cost 7 k cycles.
     {
         const int sub = lane & 7;
         float* sp = S + (wave * 8 + (lane >> 3)) * LDS_S;
-        float m = -3.0e38f;
-        for (int j = sub; j < LP; j += 8) m = fmaxf(m, sp[j]);
-        m = fmaxf(m, lane_xor1(m)); m = fmaxf(m, lane_xor2(m)); m = fmaxf(m, lane_xor4(m));
-        float sum = 0.f;
-        for (int j = sub; j < LP; j += 8) { const float e = (sp[j] > -1.0e38f) ? expf(sp[j] - m) : 0.f; sp[j] = e; sum += e; }
-        sum += lane_xor1(sum); sum += lane_xor2(sum); sum += lane_xor4(sum);
-        const float inv = 1.f / sum;
-        for (int j = sub; j < LP; j += 8) sp[j] *= inv;
+        if (LP <= 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = 4 * sub + 32 * u;
+                v[u] = j < LP ? *reinterpret_cast<const float4*>(sp + j) : make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            }
+            float m = -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+            m = fmaxf(m, lane_xor1(m)); m = fmaxf(m, lane_xor2(m)); m = fmaxf(m, lane_xor4(m));
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u].x = (v[u].x > -1.0e38f) ? exp_softmax(v[u].x - m) : 0.f; v[u].y = (v[u].y > -1.0e38f) ? exp_softmax(v[u].y - m) : 0.f;
+                v[u].z = (v[u].z > -1.0e38f) ? exp_softmax(v[u].z - m) : 0.f; v[u].w = (v[u].w > -1.0e38f) ? exp_softmax(v[u].w - m) : 0.f;
+                sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            }
+            sum += lane_xor1(sum); sum += lane_xor2(sum); sum += lane_xor4(sum);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = 4 * sub + 32 * u;
+                if (j < LP) *reinterpret_cast<float4*>(sp + j) = make_float4(v[u].x * inv, v[u].y * inv, v[u].z * inv, v[u].w * inv);
+            }
+        } else {
+            float m = -3.0e38f;
+            for (int j = sub; j < LP; j += 8) m = fmaxf(m, sp[j]);
+            m = fmaxf(m, lane_xor1(m)); m = fmaxf(m, lane_xor2(m)); m = fmaxf(m, lane_xor4(m));
+            float sum = 0.f;
+            for (int j = sub; j < LP; j += 8) { const float e = (sp[j] > -1.0e38f) ? exp_softmax(sp[j] - m) : 0.f; sp[j] = e; sum += e; }
+            sum += lane_xor1(sum); sum += lane_xor2(sum); sum += lane_xor4(sum);
+            const float inv = 1.f / sum;
+            for (int j = sub; j < LP; j += 8) sp[j] *= inv;
+        }
     }
     __syncthreads();
     PROF(3);
@@ -464,9 +503,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* prow = S + (r * 4 + h) * LDS_S + 4 * g;
-        for (int k0 = 0; k0 < LP; k0 += 64) {
-            float vn[4][4];
-            if (k0 + 64 < LP) vload(k0 + 64, vn);
+        auto pv_block = [&](int k0, const float (&vb)[4][4]) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (k0 + 16 * s4 < LP) {
@@ -475,12 +512,13 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                     acc = mfma16(pa.z, vb[s4][2], acc); acc = mfma16(pa.w, vb[s4][3], acc);
                 }
             }
-            if (k0 + 64 < LP) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) vb[s4][t] = vn[s4][t];
-            }
+        };
+        pv_block(0, vbA);
+        if (64 < LP) pv_block(64, vbB);
+        for (int k0 = 128; k0 < LP; k0 += 64) {                   // L > 128: not prefetched
+            float vn[4][4];
+            vload(k0, vn);
+            pv_block(k0, vn);
         }
         const int col = h * 32 + ct * 16 + r;             // standard D layout: rows 4g+e, column r
 #pragma unroll
@@ -499,9 +537,12 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
     ws.init(a.w_1_f16, 128, 128, wave * 16);
     ws.prefetch();
-    *reinterpret_cast<float4*>(T1 + r * LDX + n) =
-        make_float4(join(am[0], ac[0], 0) + bias_o.x + rres.x, join(am[0], ac[0], 1) + bias_o.y + rres.y,
-                    join(am[0], ac[0], 2) + bias_o.z + rres.z, join(am[0], ac[0], 3) + bias_o.w + rres.w);
+    {
+        const float4 rres = sel4(mr < M, rres_ld);
+        *reinterpret_cast<float4*>(T1 + r * LDX + n) =
+            make_float4(join(am[0], ac[0], 0) + bias_o.x + rres.x, join(am[0], ac[0], 1) + bias_o.y + rres.y,
+                        join(am[0], ac[0], 2) + bias_o.z + rres.z, join(am[0], ac[0], 3) + bias_o.w + rres.w);
+    }
     __syncthreads();
     ln_tile(T1, ln1, 1.f, Xb, m0, M, nullptr);
     __syncthreads();
@@ -578,6 +619,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         ws.init(a.w_t1_f16, 128, 128, wave * 16);
         ws.prefetch();
         {
+            const float4 rsipa = sel4(mr < M, rsipa_ld);
             const float v[4] = {join(am[0], ac[0], 0) + bias_post.x + rsipa.x, join(am[0], ac[0], 1) + bias_post.y + rsipa.y,
                                 join(am[0], ac[0], 2) + bias_post.z + rsipa.z, join(am[0], ac[0], 3) + bias_post.w + rsipa.w};
             *reinterpret_cast<float4*>(T1 + r * LDX + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -620,7 +662,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                             join(am[0], ac[0], 2) + bias_t3.z + s0.z, join(am[0], ac[0], 3) + bias_t3.w + s0.w);
         }
         __syncthreads();
-        ln_tile(T0, ln3, lnmask, Xb, m0, M, a.s_out);               // s_new (masked) -> global + planes Xb
+        ln_tile(T0, ln3, lnmask_ld * (lnrow < M ? 1.f : 0.f), Xb, m0, M, a.s_out);               // s_new (masked) -> global + planes Xb
         __syncthreads();
         if (do_bb || do_init) {
             acc_zero1<1>(am, ac);
