@@ -569,6 +569,7 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     const int L = a.L;
     float* PL = smem;                                            // [8][LPZ] probabilities of this row (0 beyond L)
     float* ZBAR = PL + 8 * LPZ;                                  // [4 waves][8][64] partial zbar
+    float* WL = ZBAR + ZW * 8 * 64;                              // [4 quarters][64 lanes] float4: W_dz operands of wave 0
     const long row = blockIdx.x;                                 // b * L + i
     const long b = row / L, i = row - b * L;
     const float* zrow = a.z + (size_t)row * L * 64 + 4 * r;
@@ -581,10 +582,11 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     // down_z weights of the epilogue (wave 0: B operand W_dz[d = r][c = 4 s + g]) requested now, not at the end: the first version
     // fetched them in the epilogue, a ~1 us dependent round trip per workgroup after the last barrier -- with the scalar GEMV it cost
     // 19 of the kernel's 68 us (tools/dev/stream_bench.hip rebuilds the kernel stage by stage)
-    float wdz[16];
-#pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) wdz[s4] = a.w_dz[r * 64 + 4 * s4 + g];
-    const float bdz = a.b_dz[r];
+    // (K-step s4, slot g <-> channel c = 16 g + s4: a lane's 16 operands are 64 contiguous bytes of row d = r.  With c = 4 s4 + g
+    //  they were 16 dword loads touching 16 lines each, in every wave of every row's workgroup: more address work for the texture
+    //  path than the z stream itself -- 77 us per launch at B=64, L=128.  Now wave w fetches quarter w (ONE float4 per lane) and
+    //  passes it to wave 0 through LDS: 58 - 60 us either way.)
+    const float4 wq4 = *reinterpret_cast<const float4*>(a.w_dz + r * 64 + 16 * g + 4 * wave);    const float bdz = a.b_dz[r];
     if ((L & 3) == 0) {
         for (int idx = tid; idx < LPZ * 2; idx += 64 * ZW) {    // float4 pieces of the 8 head rows
             const int hh = idx / (LPZ / 4), j = 4 * (idx - hh * (LPZ / 4));
@@ -598,6 +600,7 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
             PL[idx] = j < L ? a.p_out[((b * H + hh) * L + i) * L + j] : 0.f;
         }
     }
+    *reinterpret_cast<float4*>(WL + (wave * 64 + lane) * 4) = wq4;
     __syncthreads();
     f32x4 zacc[4];
 #pragma unroll
@@ -626,12 +629,18 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
         f32x4 oacc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) oacc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* zs = ZBAR + (r & 7) * 64 + g;
+        float wdz[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w4 = *reinterpret_cast<const float4*>(WL + (q * 64 + lane) * 4);
+            wdz[4 * q] = w4.x; wdz[4 * q + 1] = w4.y; wdz[4 * q + 2] = w4.z; wdz[4 * q + 3] = w4.w;
+        }
+        const float* zs = ZBAR + (r & 7) * 64 + 16 * g;
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
-            float za = zs[4 * s4];
+            float za = zs[s4];
 #pragma unroll
-            for (int q = 1; q < ZW; ++q) za += zs[q * H * 64 + 4 * s4];
+            for (int q = 1; q < ZW; ++q) za += zs[q * H * 64 + s4];
             oacc[s4 & 3] = mfma16(za * keep, wdz[s4], oacc[s4 & 3]);
         }
         // D: lane (r = d, g), register e -> head 4 g + e
@@ -692,7 +701,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     }
     if (rc) return rc;
     const int ng = (L + 15) / 16;                                // key groups per wave
-    const size_t lds = ((size_t)8 * 16 * ng + ZW * 8 * 64) * sizeof(float);
+    const size_t lds = ((size_t)8 * 16 * ng + ZW * 8 * 64 + 4 * 64 * 4) * sizeof(float);
     const long rows = (long)a->B * L;
     if (ng > 16 || rows > 0x7fffffffL) return PF_E_TOOLARGE;
     const dim3 grid((unsigned)rows), blk(64 * ZW);
