@@ -47,27 +47,35 @@ extern "C" int pf_debug_prof_et3(long long* out, int n) {
 
 namespace {
 
-constexpr int NCW = 8;                        // consumer waves = rows i of a tile
+#ifndef PF_ET_SP_NP
+#define PF_ET_SP_NP 2                     // rows per consumer wave in the f16 mode
+#endif
+constexpr int NCW = 8;                        // consumer waves
 constexpr int TJ = 16;                        // columns j of a tile
 constexpr int KF = 2048;                      // bytes of one fragment pair in the packed stream: hi 1 KiB | lo 1 KiB
 constexpr int STAGE_B = 16 * KF;              // 32 KiB stream / ring stage = 16 fragment pairs
 constexpr int NSTAGE = 8;                     // stages per tile (256 KiB of weights)
-constexpr int NSLOT = 3;
-// f16 mode (SP): the ring holds hi fragments only -- 16 KiB stages, 4 slots (stage in use + 3 stages of run-ahead)
+// f16 mode (SP): the ring holds hi fragments only -- 16 KiB stages
 template <bool SP> constexpr int KFB = SP ? 1024 : KF;              // bytes of a fragment (pair) in the LDS ring
 template <bool SP> constexpr int STG = 16 * KFB<SP>;                // bytes of a ring stage
-template <bool SP> constexpr int NSL = SP ? 4 : NSLOT;
 constexpr int CE_STRIDE = 1056;               // bytes between c|e rows in LDS (1 KiB + 32: conflict-free b128 reads)
-constexpr int CE_PIECES = 17;                 // ceil(16 * 1056 / 1024)
-// LDS map (bytes)
-constexpr int OFF_Z = NSLOT * STAGE_B;        // z rows of the tile, [8 waves][16 pairs][256 B], chunk-swizzled
-constexpr int OFF_AD = OFF_Z + NCW * 4096;    // [8][a 768 B | d 256 B]
-constexpr int OFF_CE = OFF_AD + NCW * 1024;   // [16][c 768 B | e 256 B | pad 32]
-constexpr int OFF_MK = OFF_CE + CE_PIECES * 1024;   // mask_i[8] | mask_j[16]
-constexpr int OFF_CS = OFF_MK + 256;          // LayerNorm gamma[64] | beta[64] | b2[192] | b_b[8] (+pad)
 constexpr int CONST_F = 64 + 64 + 192 + 16;
-constexpr int OFF_WB = OFF_CS + CONST_F * 4;  // 2 fragment pairs of the next block's linear_b (heads padded to 16)
-constexpr int LDS_BYTES = OFF_WB + 2 * KF;
+// NP = rows i per consumer wave: a tile is (NCW NP) rows x 16 columns, ONE weight fragment read from LDS feeds the MFMAs of
+// 16 NP pairs.  fp32-parity mode: NP = 1 (NP = 2 needs 239 VGPRs: 4 consumer waves x 32 pairs measured 427 vs 389 us).
+// f16 mode: NP = 2 (155 VGPRs) -- its stages were paced by the LDS fragment traffic (1 KiB per MFMA and wave).
+template <bool SP, int NP> struct Map {
+    static constexpr int TI = NCW * NP;                        // rows i of a tile
+    static constexpr int NSL = SP ? (NP == 2 ? 3 : 4) : 3;     // ring slots (stage in use + NSL - 1 stages of run-ahead)
+    // LDS map (bytes)
+    static constexpr int OFF_Z = (SP && NP == 2) ? 3 * STG<true> : 3 * STAGE_B;   // z rows, [TI][16 pairs][256 B], chunk-swizzled
+    static constexpr int OFF_AD = OFF_Z + TI * 4096;           // [TI][a 768 B | d 256 B]
+    static constexpr int OFF_CE = OFF_AD + TI * 1024;          // [16][c 768 B | e 256 B | pad 32]
+    static constexpr int OFF_MK = OFF_CE + 17 * 1024;          // mask_i[TI] | mask_j[16]
+    static constexpr int OFF_CS = OFF_MK + 256;                // LayerNorm gamma[64] | beta[64] | b2[192] | b_b[8] (+pad)
+    static constexpr int OFF_WB = OFF_CS + CONST_F * 4;        // 2 fragment pairs of the next block's linear_b (heads padded to 16)
+    static constexpr int LDS_BYTES = OFF_WB + 2 * KF;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
 
 __device__ __forceinline__ void stage_barrier() {
     asm volatile("" ::: "memory");
@@ -148,8 +156,11 @@ struct Tile { int b, i0, j0; };
 
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
-template <bool DUMP, bool SP>
+template <bool DUMP, bool SP, int NP>
 __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
+    using M = Map<SP, NP>;
+    constexpr int TI = M::TI, NSLr = M::NSL, OFF_Z = M::OFF_Z, OFF_AD = M::OFF_AD, OFF_CE = M::OFF_CE, OFF_MK = M::OFF_MK,
+                  OFF_CS = M::OFF_CS, OFF_WB = M::OFF_WB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
     float* Cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         tl.b = t / per;
         const int rem = t - tl.b * per;
         const int ib = rem / njb;
-        tl.i0 = ib * NCW;
+        tl.i0 = ib * TI;
         tl.j0 = (rem - ib * njb) * TJ;
         return tl;
     };
@@ -188,27 +199,28 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w_stream);
         const unsigned wl = lane * 16;
         if constexpr (SP) {
-            // hi KiB of fragment pair k of a stage -> dense 16 KiB ring stage; three stages of run-ahead (48 pieces <= 63)
+            // hi KiB of fragment pair k of a stage -> dense 16 KiB ring stage; NSL - 1 stages of run-ahead (<= 48 pieces <= 63)
+            constexpr int RA = NSLr - 1;
             auto issue_w = [&](int stage, int slot) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) GLDS16U(wsrc + stage * STAGE_B + k * KF, wl, slot * STG<true> + k * 1024);
             };
-            issue_w(0, 0);
-            if (total_stages > 1) issue_w(1 % NSTAGE, 1);
-            if (total_stages > 2) issue_w(2 % NSTAGE, 2);
-            if (total_stages > 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (total_stages > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stage 0 complete
-            int st_next = 3 % NSTAGE, slot_next = 3;
+#pragma unroll
+            for (int q = 0; q < RA; ++q) issue_w(q, q);                // (total_stages >= 8 > RA)
+            if constexpr (RA == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // stage 0 complete
+            int st_next = RA % NSTAGE, slot_next = RA;
             for (int gs = 0; gs < total_stages; ++gs) {
                 PROFL(24, gs);
                 stage_barrier();                                   // consumers: start stage gs; they are done with gs - 1
-                if (gs + 3 < total_stages) {
+                if (gs + RA < total_stages) {
                     issue_w(st_next, slot_next);
-                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // stage gs + 1 complete; gs + 2, gs + 3 may be in flight
+                    // stage gs + 1 complete; the later ones may be in flight
+                    if constexpr (RA == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     st_next = (st_next + 1 == NSTAGE) ? 0 : st_next + 1;
-                    slot_next = (slot_next + 1 == 4) ? 0 : slot_next + 1;
-                } else if (gs + 2 < total_stages) {
+                    slot_next = (slot_next + 1 == NSLr) ? 0 : slot_next + 1;
+                } else if (RA == 3 && gs + 2 < total_stages) {
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             issue_w(1, 1, 0, 16);
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // stage 0 complete
             issue_w(1, 1, 16, 32);
-            int st_next = 2 % NSTAGE, slot_next = 2 % NSLOT;           // stream stage / ring slot of global stage gs + 2
+            int st_next = 2 % NSTAGE, slot_next = 2 % NSLr;           // stream stage / ring slot of global stage gs + 2
             for (int gs = 0; gs < total_stages; ++gs) {
                 // here: stage gs and everything issued before its last 16 pieces have landed
                 PROFL(24, gs);
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage gs + 1 complete
                     issue_w(st_next, slot_next, 16, 32);
                     st_next = (st_next + 1 == NSTAGE) ? 0 : st_next + 1;
-                    slot_next = (slot_next + 1 == NSLOT) ? 0 : slot_next + 1;
+                    slot_next = (slot_next + 1 == NSLr) ? 0 : slot_next + 1;
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -274,9 +286,9 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 for (int m = 0; m < 4; ++m) GLDS16U(base, zoff[m], OFF_Z + (4 * row + m) * 1024);
             }
         };
-        auto issue_ad = [&](const Tile& tl) {                    // 8 pieces: row i0 + k, [a | d]
+        auto issue_ad = [&](const Tile& tl) {                    // TI pieces: row i0 + k, [a | d]
 #pragma unroll
-            for (int k = 0; k < NCW; ++k) {
+            for (int k = 0; k < TI; ++k) {
                 int i = tl.i0 + k;
                 i = i < L ? i : L - 1;
                 GLDS16U(pg + (size_t)(tl.b * L + i) * (PF_ET_PRE * 4), ad_off, OFF_AD + k * 1024);
@@ -290,14 +302,14 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 GLDS16U(pg + (size_t)(tl.b * L + j) * (PF_ET_PRE * 4), ce_off, OFF_CE + k * CE_STRIDE);
             }
         };
-        auto issue_mask = [&](const Tile& tl) {                  // lanes 0-7: mask_i, 8-23: mask_j
-            int row = lane < 8 ? tl.i0 + lane : tl.j0 + ((lane - 8) & 15);
+        auto issue_mask = [&](const Tile& tl) {                  // lanes 0 .. TI-1: mask_i, TI .. TI+15: mask_j
+            int row = lane < TI ? tl.i0 + lane : tl.j0 + ((lane - TI) & 15);
             row = row < L ? row : L - 1;
             GLDS4(a.mask + tl.b * L + row, smem + OFF_MK);
         };
-        auto issue_all = [&](const Tile& tl) {                   // 32 + 8 + 16 + 1 = 57 pieces (the counter holds 63)
-            prep_z(tl);
-            issue_z(tl, 0, 8);
+        auto issue_all = [&](const Tile& tl) {                   // 4 TI + TI + 16 + 1 pieces (57 / 97; the counter holds 63: the
+            prep_z(tl);                                          //  issue simply waits for the oldest ones beyond that)
+            issue_z(tl, 0, TI);
             issue_ad(tl);
             issue_ce(tl, 0, TJ);
             issue_mask(tl);
@@ -317,9 +329,9 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             // version of this wave) put an HBM burst in front of the weight loader's L2 traffic on the same CU -- phase stamps
             // showed the consumers waiting 2.5 k and 1.4 k cycles at the barriers of stages 3 and 4 (f16 mode, 16.4 k per tile)
             if (have_next) {
-                if (st_cur == 2) { prep_z(tl); issue_z(tl, 0, 3); }
-                else if (st_cur == 3) issue_z(tl, 3, 6);
-                else if (st_cur == 4) issue_z(tl, 6, 8);
+                if (st_cur == 2) { prep_z(tl); issue_z(tl, 0, 3 * TI / 8); }
+                else if (st_cur == 3) issue_z(tl, 3 * TI / 8, 6 * TI / 8);
+                else if (st_cur == 4) issue_z(tl, 6 * TI / 8, TI);
                 else if (st_cur == 5) { issue_ad(tl); issue_ce(tl, 0, 4); }
                 else if (st_cur == 6) { issue_ce(tl, 4, TJ); issue_mask(tl); }
             }
@@ -335,8 +347,9 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     }
 
     // ---------------------------------- consumer waves ----------------------------------
-    const unsigned char* zs = smem + OFF_Z + wave * 4096 + r * 256;           // this lane's pair row (chunk-swizzled)
-    const float* ad = reinterpret_cast<const float*>(smem + OFF_AD + wave * 1024) + 4 * g;          // a_i | d_i, features 4g..
+    // wave w <-> rows i0 + NP w + p (p < NP), lane & 15 <-> column j0 + r
+    const unsigned char* zs = smem + OFF_Z + (NP * wave) * 4096 + r * 256;          // this lane's pair rows (chunk-swizzled)
+    const float* ad = reinterpret_cast<const float*>(smem + OFF_AD + (NP * wave) * 1024) + 4 * g;   // a_i | d_i, features 4g..
     const float* ce = reinterpret_cast<const float*>(smem + OFF_CE + r * CE_STRIDE) + 4 * g;        // c_j | e_j
     const float* mkb = reinterpret_cast<const float*>(smem + OFF_MK);
     int slot = 0;
@@ -344,13 +357,20 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     for (int it = 0; it < my_tiles; ++it, tile += gridDim.x) {
         PROF3(0);
         const Tile tl = tile_of(tile);
-        const int i = tl.i0 + wave, j = tl.j0 + r;
-        const bool valid = i < L && j < L;
-        const size_t pidx = (size_t)(tl.b * L + i) * L + j;
-        half8 h1h[6], h1l[6];
-        f32x4 m3[4];
-        half8 zh[2], zl[2];
-        float mk = 0.f;
+        const int j = tl.j0 + r;
+        int iv[NP];
+        bool valid[NP];
+        size_t pidx[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            iv[p] = tl.i0 + NP * wave + p;
+            valid[p] = iv[p] < L && j < L;
+            pidx[p] = (size_t)(tl.b * L + iv[p]) * L + j;
+        }
+        half8 h1h[NP][6], h1l[NP][6];
+        f32x4 m3[NP][4];
+        half8 zh[NP][2], zl[NP][2];
+        float mk[NP];
         // ---- stages 0-1: GEMM1 (12 feature tiles, two at a time) then the z part of GEMM3 ----
         Frag ga0, gb0;
 #pragma unroll
@@ -360,54 +380,70 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 PROFW(64 + 8 * (tp == 0 ? 0 : 1));
                 stage_barrier();
                 PROF3(tp == 0 ? 2 : 4);
-                if (tp == 4) slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;
+                if (tp == 4) slot = (slot + 1 == NSLr) ? 0 : slot + 1;
             }
             if (tp == 0) {            // this tile's z rows / mask are in LDS now
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const float4 q0 = *reinterpret_cast<const float4*>(zs + 16 * ((8 * s + 2 * g) ^ r));
-                    const float4 q1 = *reinterpret_cast<const float4*>(zs + 16 * ((8 * s + 2 * g + 1) ^ r));
-                    split8<SP>(q0, q1, zh[s], zl[s]);
+                for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float4 q0 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g) ^ r));
+                        const float4 q1 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g + 1) ^ r));
+                        split8<SP>(q0, q1, zh[p][s], zl[p][s]);
+                    }
+                    mk[p] = mkb[NP * wave + p] * mkb[TI + r];
                 }
-                mk = mkb[wave] * mkb[8 + r];
             }
             const unsigned char* sl = ring + slot * STG<SP>;
             const int kf0 = (tp < 4 ? tp * 4 : (tp - 4) * 4);         // tile 2tp: kf0, kf0+1 ; tile 2tp+1: kf0+2, kf0+3
-            // accumulators start at a_i + c_j (b1 is folded into c)
-            f32x4 m0 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp), *reinterpret_cast<const float4*>(ce + 32 * tp));
-            f32x4 m1 = add4(*reinterpret_cast<const float4*>(ad + 32 * tp + 16), *reinterpret_cast<const float4*>(ce + 32 * tp + 16));
             // fragment reads run one K-step ahead of the MFMAs (within a ring stage)
             if (tp == 0 || tp == 4) { ga0 = ldfrag<SP>(sl, kf0, lane); gb0 = ldfrag<SP>(sl, kf0 + 2, lane); }
             const Frag ga1 = ldfrag<SP>(sl, kf0 + 1, lane), gb1 = ldfrag<SP>(sl, kf0 + 3, lane);
-            mac2<SP>(ga0, gb0, zh[0], zl[0], m0, m1);
-            if (tp != 3 && tp != 5) { ga0 = ldfrag<SP>(sl, kf0 + 4, lane); gb0 = ldfrag<SP>(sl, kf0 + 6, lane); }
-            mac2<SP>(ga1, gb1, zh[1], zl[1], m0, m1);
-            float4 v0, v1;
-            v0.x = fmaxf(m0[0], 0.f); v0.y = fmaxf(m0[1], 0.f);
-            v0.z = fmaxf(m0[2], 0.f); v0.w = fmaxf(m0[3], 0.f);
-            v1.x = fmaxf(m1[0], 0.f); v1.y = fmaxf(m1[1], 0.f);
-            v1.z = fmaxf(m1[2], 0.f); v1.w = fmaxf(m1[3], 0.f);
-            if constexpr (DUMP) {
-                if (valid) {
-                    *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 4 * g) = v0;
-                    *reinterpret_cast<float4*>(a.dump_h1 + pidx * 192 + 32 * tp + 16 + 4 * g) = v1;
-                }
+            // accumulators start at a_i + c_j (b1 is folded into c)
+            const float4 ce0 = *reinterpret_cast<const float4*>(ce + 32 * tp), ce1 = *reinterpret_cast<const float4*>(ce + 32 * tp + 16);
+            f32x4 m0[NP], m1[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                m0[p] = add4(*reinterpret_cast<const float4*>(ad + p * 256 + 32 * tp), ce0);
+                m1[p] = add4(*reinterpret_cast<const float4*>(ad + p * 256 + 32 * tp + 16), ce1);
             }
-            split8<SP>(v0, v1, h1h[tp], h1l[tp]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) mac2<SP>(ga0, gb0, zh[p][0], zl[p][0], m0[p], m1[p]);
+            if (tp != 3 && tp != 5) { ga0 = ldfrag<SP>(sl, kf0 + 4, lane); gb0 = ldfrag<SP>(sl, kf0 + 6, lane); }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) mac2<SP>(ga1, gb1, zh[p][1], zl[p][1], m0[p], m1[p]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float4 v0, v1;
+                v0.x = fmaxf(m0[p][0], 0.f); v0.y = fmaxf(m0[p][1], 0.f); v0.z = fmaxf(m0[p][2], 0.f); v0.w = fmaxf(m0[p][3], 0.f);
+                v1.x = fmaxf(m1[p][0], 0.f); v1.y = fmaxf(m1[p][1], 0.f); v1.z = fmaxf(m1[p][2], 0.f); v1.w = fmaxf(m1[p][3], 0.f);
+                if constexpr (DUMP) {
+                    if (valid[p]) {
+                        *reinterpret_cast<float4*>(a.dump_h1 + pidx[p] * 192 + 32 * tp + 4 * g) = v0;
+                        *reinterpret_cast<float4*>(a.dump_h1 + pidx[p] * 192 + 32 * tp + 16 + 4 * g) = v1;
+                    }
+                }
+                split8<SP>(v0, v1, h1h[p][tp], h1l[p][tp]);
+            }
         }
         PROF3(5);
         {   // z part of the final layer (stage 1, fragment pairs 8..15): acc3[t] = d_i + e_j + Wf[:, :64] z  (bf folded into e)
             const unsigned char* sl = ring + slot * STG<SP>;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                m3[t] = add4(*reinterpret_cast<const float4*>(ad + 192 + 16 * t), *reinterpret_cast<const float4*>(ce + 192 + 16 * t));
+                const float4 e4 = *reinterpret_cast<const float4*>(ce + 192 + 16 * t);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) m3[p][t] = add4(*reinterpret_cast<const float4*>(ad + p * 256 + 192 + 16 * t), e4);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag w0 = ldfrag<SP>(sl, 8 + s, lane), w1 = ldfrag<SP>(sl, 10 + s, lane);
                 const Frag w2 = ldfrag<SP>(sl, 12 + s, lane), w3 = ldfrag<SP>(sl, 14 + s, lane);
-                mac2<SP>(w0, w1, zh[s], zl[s], m3[0], m3[1]);
-                mac2<SP>(w2, w3, zh[s], zl[s], m3[2], m3[3]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    mac2<SP>(w0, w1, zh[p][s], zl[p][s], m3[p][0], m3[p][1]);
+                    mac2<SP>(w2, w3, zh[p][s], zl[p][s], m3[p][2], m3[p][3]);
+                }
             }
         }
         PROF3(6);
@@ -418,11 +454,13 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             PROFW(64 + 8 * (2 + c));
             stage_barrier();
             PROF3(16 + c);
-            slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;
+            slot = (slot + 1 == NSLr) ? 0 : slot + 1;
             const unsigned char* sl = ring + slot * STG<SP>;
             const float4 b0 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 4 * g);
             const float4 b1 = *reinterpret_cast<const float4*>(Cs + 128 + 32 * c + 16 + 4 * g);
-            f32x4 m0 = {b0.x, b0.y, b0.z, b0.w}, m1 = {b1.x, b1.y, b1.z, b1.w};      // accumulators start at b2
+            f32x4 m0[NP], m1[NP];                                                    // accumulators start at b2
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { m0[p] = (f32x4){b0.x, b0.y, b0.z, b0.w}; m1[p] = (f32x4){b1.x, b1.y, b1.z, b1.w}; }
             Frag wa[2], wb[2];                 // fragment reads run one K-step ahead of the MFMAs that use them
             wa[0] = ldfrag<SP>(sl, 0, lane);
             wb[0] = ldfrag<SP>(sl, 6, lane);
@@ -432,99 +470,104 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                     wa[(k + 1) & 1] = ldfrag<SP>(sl, k + 1, lane);
                     wb[(k + 1) & 1] = ldfrag<SP>(sl, 7 + k, lane);
                 }
-                mac2<SP>(wa[k & 1], wb[k & 1], h1h[k], h1l[k], m0, m1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) mac2<SP>(wa[k & 1], wb[k & 1], h1h[p][k], h1l[p][k], m0[p], m1[p]);
             }
-            float4 v0, v1;
-            v0.x = fmaxf(m0[0], 0.f); v0.y = fmaxf(m0[1], 0.f);
-            v0.z = fmaxf(m0[2], 0.f); v0.w = fmaxf(m0[3], 0.f);
-            v1.x = fmaxf(m1[0], 0.f); v1.y = fmaxf(m1[1], 0.f);
-            v1.z = fmaxf(m1[2], 0.f); v1.w = fmaxf(m1[3], 0.f);
-            half8 xh, xl;
-            if constexpr (DUMP) {
-                if (valid) {
-                    *reinterpret_cast<float4*>(a.dump_h2 + pidx * 192 + 32 * c + 4 * g) = v0;
-                    *reinterpret_cast<float4*>(a.dump_h2 + pidx * 192 + 32 * c + 16 + 4 * g) = v1;
-                }
-            }
-            split8<SP>(v0, v1, xh, xl);
             const Frag w0 = ldfrag<SP>(sl, 12, lane), w1 = ldfrag<SP>(sl, 13, lane), w2 = ldfrag<SP>(sl, 14, lane), w3 = ldfrag<SP>(sl, 15, lane);
-            mac2<SP>(w0, w1, xh, xl, m3[0], m3[1]);
-            mac2<SP>(w2, w3, xh, xl, m3[2], m3[3]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float4 v0, v1;
+                v0.x = fmaxf(m0[p][0], 0.f); v0.y = fmaxf(m0[p][1], 0.f); v0.z = fmaxf(m0[p][2], 0.f); v0.w = fmaxf(m0[p][3], 0.f);
+                v1.x = fmaxf(m1[p][0], 0.f); v1.y = fmaxf(m1[p][1], 0.f); v1.z = fmaxf(m1[p][2], 0.f); v1.w = fmaxf(m1[p][3], 0.f);
+                half8 xh, xl;
+                if constexpr (DUMP) {
+                    if (valid[p]) {
+                        *reinterpret_cast<float4*>(a.dump_h2 + pidx[p] * 192 + 32 * c + 4 * g) = v0;
+                        *reinterpret_cast<float4*>(a.dump_h2 + pidx[p] * 192 + 32 * c + 16 + 4 * g) = v1;
+                    }
+                }
+                split8<SP>(v0, v1, xh, xl);
+                mac2<SP>(w0, w1, xh, xl, m3[p][0], m3[p][1]);
+                mac2<SP>(w2, w3, xh, xl, m3[p][2], m3[p][3]);
+            }
         }
         PROF3(13);
-        slot = (slot + 1 == NSL<SP>) ? 0 : slot + 1;           // slot of the next tile's stage 0
+        slot = (slot + 1 == NSLr) ? 0 : slot + 1;              // slot of the next tile's stage 0
 
         // ---- LayerNorm over the 64 features (16 in this lane, the rest in lanes r + 16k), mask, store ----
-        float y[16];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            y[4 * t + 0] = m3[t][0];
-            y[4 * t + 1] = m3[t][1];
-            y[4 * t + 2] = m3[t][2];
-            y[4 * t + 3] = m3[t][3];
-        }
-        if constexpr (DUMP) {
-            if (valid) {
+        for (int p = 0; p < NP; ++p) {
+            float y[16];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    *reinterpret_cast<float4*>(a.dump_y + pidx * 64 + 16 * t + 4 * g) = make_float4(y[4 * t], y[4 * t + 1], y[4 * t + 2], y[4 * t + 3]);
+            for (int t = 0; t < 4; ++t) {
+                y[4 * t + 0] = m3[p][t][0];
+                y[4 * t + 1] = m3[p][t][1];
+                y[4 * t + 2] = m3[p][t][2];
+                y[4 * t + 3] = m3[p][t][3];
             }
-        }
-        float s = 0.f;
+            if constexpr (DUMP) {
+                if (valid[p]) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) s += (y[e] + y[e + 1]) + (y[e + 2] + y[e + 3]);
-        s = sum_xor32(sum_xor16(s));
-        const float mean = s * (1.f / 64.f);
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { const float d = y[e] - mean; q += d * d; }
-        q = sum_xor32(sum_xor16(q));
-        const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
-        float4 o4[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 gm = *reinterpret_cast<const float4*>(Cs + 16 * t + 4 * g);
-            const float4 bt = *reinterpret_cast<const float4*>(Cs + 64 + 16 * t + 4 * g);
-            o4[t].x = ((y[4 * t + 0] - mean) * rstd * gm.x + bt.x) * mk;
-            o4[t].y = ((y[4 * t + 1] - mean) * rstd * gm.y + bt.y) * mk;
-            o4[t].z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk;
-            o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk;
-        }
-        if (valid) {
-            float* zo = a.z_out + pidx * 64 + 4 * g;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(zo + 16 * t) = o4[t];
-        }
-        if (a.bias_out) {
-            // pair bias of the NEXT IPA block from z' while it is in registers: one more 64 -> 8(16) split-precision GEMM with
-            // z' as the B operand (same K permutation as the other register-resident activations); heads 4*(lane>>4)+e
-            const unsigned char* wb = smem + OFF_WB;
-            f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bm2 = bm;
-            half8 oh0, ol0, oh1, ol1;
-            split8<SP>(o4[0], o4[1], oh0, ol0);
-            split8<SP>(o4[2], o4[3], oh1, ol1);
-            // (the two linear_b fragment pairs keep the packed hi | lo layout in both modes)
-            Frag f0, f1;
-            f0.h = *reinterpret_cast<const half8*>(wb + lane * 16);
-            f1.h = *reinterpret_cast<const half8*>(wb + KF + lane * 16);
-            if constexpr (!SP) {
-                f0.l = *reinterpret_cast<const half8*>(wb + 1024 + lane * 16);
-                f1.l = *reinterpret_cast<const half8*>(wb + KF + 1024 + lane * 16);
+                    for (int t = 0; t < 4; ++t)
+                        *reinterpret_cast<float4*>(a.dump_y + pidx[p] * 64 + 16 * t + 4 * g) = make_float4(y[4 * t], y[4 * t + 1], y[4 * t + 2], y[4 * t + 3]);
+                }
             }
-            if constexpr (!SP) { bm = mfma_h(f0.h, ol0, bm); bm2 = mfma_h(f1.h, ol1, bm2); }
-            bm = mfma_h(f0.h, oh0, bm);
-            bm2 = mfma_h(f1.h, oh1, bm2);
-            if constexpr (!SP) { bm = mfma_h(f0.l, oh0, bm); bm2 = mfma_h(f1.l, oh1, bm2); }
-            if (valid && g < 2) {
-                const float4 bb = *reinterpret_cast<const float4*>(Cs + 320 + 4 * g);
-                const float s13 = 0.57735026918962576f;   // sqrt(1/3), ipa_pytorch.py:404
-                // [B,8,L,L] head-major: the 16 lanes of a group write 64 contiguous bytes of one (head, row i)
-                float* bo = a.bias_out + (((size_t)tl.b * 8 + 4 * g) * L + i) * L + j;
-                const size_t hs = (size_t)L * L;
-                bo[0] = s13 * ((bm[0] + bm2[0]) + bb.x);
-                bo[hs] = s13 * ((bm[1] + bm2[1]) + bb.y);
-                bo[2 * hs] = s13 * ((bm[2] + bm2[2]) + bb.z);
-                bo[3 * hs] = s13 * ((bm[3] + bm2[3]) + bb.w);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) s += (y[e] + y[e + 1]) + (y[e + 2] + y[e + 3]);
+            s = sum_xor32(sum_xor16(s));
+            const float mean = s * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float d = y[e] - mean; q += d * d; }
+            q = sum_xor32(sum_xor16(q));
+            const float rstd = rsqrtf(q * (1.f / 64.f) + 1e-5f);
+            float4 o4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 gm = *reinterpret_cast<const float4*>(Cs + 16 * t + 4 * g);
+                const float4 bt = *reinterpret_cast<const float4*>(Cs + 64 + 16 * t + 4 * g);
+                o4[t].x = ((y[4 * t + 0] - mean) * rstd * gm.x + bt.x) * mk[p];
+                o4[t].y = ((y[4 * t + 1] - mean) * rstd * gm.y + bt.y) * mk[p];
+                o4[t].z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk[p];
+                o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk[p];
+            }
+            if (valid[p]) {
+                float* zo = a.z_out + pidx[p] * 64 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(zo + 16 * t) = o4[t];
+            }
+            if (a.bias_out) {
+                // pair bias of the NEXT IPA block from z' while it is in registers: one more 64 -> 8(16) split-precision GEMM with
+                // z' as the B operand (same K permutation as the other register-resident activations); heads 4*(lane>>4)+e
+                const unsigned char* wb = smem + OFF_WB;
+                f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bm2 = bm;
+                half8 oh0, ol0, oh1, ol1;
+                split8<SP>(o4[0], o4[1], oh0, ol0);
+                split8<SP>(o4[2], o4[3], oh1, ol1);
+                // (the two linear_b fragment pairs keep the packed hi | lo layout in both modes)
+                Frag f0, f1;
+                f0.h = *reinterpret_cast<const half8*>(wb + lane * 16);
+                f1.h = *reinterpret_cast<const half8*>(wb + KF + lane * 16);
+                if constexpr (!SP) {
+                    f0.l = *reinterpret_cast<const half8*>(wb + 1024 + lane * 16);
+                    f1.l = *reinterpret_cast<const half8*>(wb + KF + 1024 + lane * 16);
+                }
+                if constexpr (!SP) { bm = mfma_h(f0.h, ol0, bm); bm2 = mfma_h(f1.h, ol1, bm2); }
+                bm = mfma_h(f0.h, oh0, bm);
+                bm2 = mfma_h(f1.h, oh1, bm2);
+                if constexpr (!SP) { bm = mfma_h(f0.l, oh0, bm); bm2 = mfma_h(f1.l, oh1, bm2); }
+                if (valid[p] && g < 2) {
+                    const float4 bb = *reinterpret_cast<const float4*>(Cs + 320 + 4 * g);
+                    const float s13 = 0.57735026918962576f;   // sqrt(1/3), ipa_pytorch.py:404
+                    // [B,8,L,L] head-major: the 16 lanes of a group write 64 contiguous bytes of one (head, row i)
+                    float* bo = a.bias_out + (((size_t)tl.b * 8 + 4 * g) * L + iv[p]) * L + j;
+                    const size_t hs = (size_t)L * L;
+                    bo[0] = s13 * ((bm[0] + bm2[0]) + bb.x);
+                    bo[hs] = s13 * ((bm[1] + bm2[1]) + bb.y);
+                    bo[2 * hs] = s13 * ((bm[2] + bm2[2]) + bb.z);
+                    bo[3 * hs] = s13 * ((bm[3] + bm2[3]) + bb.w);
+                }
             }
         }
         PROF3(14);
@@ -535,32 +578,34 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 }  // namespace
 
 // launcher used by pf_edge_transition_fwd (edge_transition.hip) when args.w_stream is set
-int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
-    const int nib = (a->L + NCW - 1) / NCW, njb = (a->L + TJ - 1) / TJ;
+template <bool DUMP, bool SP, int NP>
+static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
+    using M = Map<SP, NP>;
+    const int nib = (a->L + M::TI - 1) / M::TI, njb = (a->L + TJ - 1) / TJ;
     const long long nt = (long long)a->B * nib * njb;
     if (nt > 0x7fffffffLL || (long long)a->B * a->L > 0x7fffffffLL) return PF_E_TOOLARGE;
+    const int grid = (int)(nt < ncu ? nt : ncu);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
+            return PF_E_BADARG;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n > 0 ? n : 256;
     }();
-    const int grid = (int)(nt < ncu ? nt : ncu);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return PF_E_BADARG;
-        attr_set = true;
-    }
     if (a->dump_h1 || a->dump_h2 || a->dump_y) {
         if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass) return PF_E_BADARG;
-        hipLaunchKernelGGL((edge_transition_v3_kernel<true, false>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
-    } else if (a->single_pass) {
-        hipLaunchKernelGGL((edge_transition_v3_kernel<false, true>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
-    } else {
-        hipLaunchKernelGGL((edge_transition_v3_kernel<false, false>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), LDS_BYTES, stream, *a, (int)nt, nib, njb);
+        return et3_launch<true, false, 1>(a, stream, ncu);
     }
-    PF_CHECK_LAUNCH();
-    return 0;
+    if (a->single_pass) return et3_launch<false, true, PF_ET_SP_NP>(a, stream, ncu);
+    return et3_launch<false, false, 1>(a, stream, ncu);
 }
