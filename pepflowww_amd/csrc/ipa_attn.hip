@@ -709,12 +709,12 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     // two-kernel form (scores per (sample, head) + one streaming pass over z): whenever the caller supplies the pair bias and
     // a probability buffer; a->variant == 1 forces the one-kernel form below (kept for L > 256 and for callers without buffers)
-    // Measured (rocprofv3, profiles/r02): B=64, L=128: 190 us (scores 112 + pair 78) vs 198 us one-kernel; B=16, L=64: 31.5 us
-    // vs 29.0 us -- so the two-kernel form is the default from 256 query tiles up (where the one-kernel form would run its
-    // 8-head variant), or whenever the training path asks for the probabilities (p_out without the small-batch exception).
+    // Measured (rocprofv3, profiles/r02): B=64, L=128: 172 us (scores 112 + pair 60) vs 198 us one-kernel; B=16, L=64: 20.3 + 6 us
+    // vs 30.8 us.  The choice depends on L ONLY (not on the batch): the two forms sum in different orders, and a batch shard must
+    // reproduce the unsharded run bit for bit (tests/test_gpu_parity.py::test_full_size_shard_equals_unsharded).
     const bool can_split = a->bias && a->p_out && a->L <= 256;
     if (a->variant == 2 && !can_split) return PF_E_BADARG;   // two-kernel form demanded but not possible
-    if (can_split && (a->variant == 2 || (a->variant == 0 && qt >= 256))) return pf_ipa_split_launch(a, s);
+    if (can_split && (a->variant == 2 || (a->variant == 0 && a->L >= 64))) return pf_ipa_split_launch(a, s);
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
     const int force_hg = a->head_group;                      // 0 = by size; 2 / 4 / 8 = that head-group variant (tests)

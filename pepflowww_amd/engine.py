@@ -245,12 +245,12 @@ class DenoiseEngine:
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
         # attention operands as f16 planes (written by the projection's epilogue, read by the f16-operand score kernel), f16 mode
-        # only: used where the two-kernel attention runs (>= 256 query tiles, L <= 256) and L is a multiple of 16 (sample() pads
+        # only: used where the two-kernel attention runs (64 <= L <= 256, a rule in L alone) and L is a multiple of 16 (sample() pads
         # to that).  In the fp32 mode the split (hi / lo) form of the same kernels is bit-compatible with the parity bar but not
         # faster -- measured at B=64, L=128: score kernel 113 k vs 111 k cycles per workgroup (its QK phase is bound by the
         # point-distance VALU work, not by the MFMAs; its PV phase has no room for a second fragment set in 256 VGPRs) and the
         # projection 88 vs 77 us (transposed 8-byte stores + hi / lo splits of every output) -- so the fp32 mode keeps fp32 operands.
-        self.att_planes = precision == "f16" and (L % 16 == 0) and (L <= 256) and (B * (L // 16) >= 256)
+        self.att_planes = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
         if self.att_planes:
             split = self.precision == "fp32"
             self.att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=device)

@@ -9,5 +9,5 @@ X=""; [ $F = edge_transition_v3 ] && X=-fno-slp-vectorize
 objs=""; for f in pepflowww_amd/lib/*.o; do [ "$f" != "pepflowww_amd/lib/$F.o" ] && objs="$objs $f"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o pepflowww_amd/lib/libpepflow_hip.so $objs /tmp/expx.o
 echo "== $F [$FLAGS] $P"
-bash tools/dev/ks4.sh $P
+W=${W:-cfg4} bash tools/dev/ks4.sh $P
 cp /tmp/orig.so pepflowww_amd/lib/libpepflow_hip.so
