@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 34
+#define PF_ABI_VERSION 35
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -292,8 +292,15 @@ typedef struct {
     /* persistent kernel only: 1 = f16 precision mode -- ONE f16 MFMA per product (hi planes only) instead of the three of the
      * fp32-parity mode; fp32 accumulation, LayerNorm and storage unchanged.  Not combinable with the dumps. */
     int single_pass;
+    /* optional (persistent kernel only): work list of the tiles that contain at least one unmasked pair.  A tile covers
+     * pf_edge_transition_tile_rows(single_pass) rows i x 16 columns j of one sample; tile id = (b * nib + ib) * njb + jb with
+     * nib = ceil(L / rows), njb = ceil(L / 16).  tile_list[0 .. *n_tiles) are processed, the others are NOT TOUCHED: z' of a fully
+     * masked tile is exactly zero in the reference (ga.py:118), so the caller keeps those parts of z_out (and bias_out) zeroed.
+     * Both pointers are device memory (the count is read by the kernel: no host synchronisation, graph-safe). */
+    const int* tile_list; const int* n_tiles;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
+int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */
 
 /* ---- encode(): once-per-call context featurisation (FlowModel.encode, flow_model.py:75-93) -------
  * node features: NodeEmbedder.forward up to the MLP input (node.py:35-99): aa embedding, per-aa-type

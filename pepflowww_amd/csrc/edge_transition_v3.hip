@@ -168,10 +168,14 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
     const unsigned lds0 = LDSADDR(smem);
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // blockIdx.x, + gridDim.x, ...
+    // work list (pf_edge_transition_args.tile_list): only tiles with an unmasked pair; the count lives in device memory
+    const int nwork = a.n_tiles ? min(__builtin_amdgcn_readfirstlane(*a.n_tiles), ntiles) : ntiles;
+    if ((int)blockIdx.x >= nwork) return;
+    const int my_tiles = (nwork - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // blockIdx.x, + gridDim.x, ...
     const int total_stages = my_tiles * NSTAGE;
-    auto tile_of = [&](int t) {
+    auto tile_of = [&](int w) {
         Tile tl;
+        const int t = a.tile_list ? __builtin_amdgcn_readfirstlane(a.tile_list[w]) : w;
         const int per = nib * njb;
         tl.b = t / per;
         const int rem = t - tl.b * per;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and are in LDS before the next tile's barrier 0
                 st_cur = 0;
                 tile += gridDim.x;
-                have_next = tile + (int)gridDim.x < ntiles;
+                have_next = tile + (int)gridDim.x < nwork;
                 if (have_next) tl = tile_of(tile + gridDim.x);
             }
         }
@@ -596,7 +600,10 @@ static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int 
     return 0;
 }
 
+extern "C" int pf_edge_transition_tile_rows(int single_pass) { return single_pass ? Map<true, PF_ET_SP_NP>::TI : Map<false, 1>::TI; }
+
 int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
+    if ((a->tile_list != nullptr) != (a->n_tiles != nullptr)) return PF_E_BADARG;
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;

@@ -244,6 +244,12 @@ class DenoiseEngine:
         self.pair_bias = e(B, 8, L, L)          # sqrt(1/3)(W_b z + b_b) of the next IPA block (head-major), written by EdgeTransition
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
+        # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
+        # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
+        self.et_rows = int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
+        self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
+        self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
+        self.et_ntiles = e(1, dt=torch.int32)
         # attention operands as f16 planes (written by the projection's epilogue, read by the f16-operand score kernel), f16 mode
         # only: used where the two-kernel attention runs (64 <= L <= 256, a rule in L alone) and L is a multiple of 16 (sample() pads
         # to that).  In the fp32 mode the split (hi / lo) form of the same kernels is bit-compatible with the parity bar but not
@@ -285,6 +291,7 @@ class DenoiseEngine:
         B, L = self.B, self.L
         self.node_embed.copy_(node_embed.reshape(B * L, 128))
         self.mask.copy_(res_mask.reshape(B * L).to(torch.float32))
+        self._refresh_work_lists(res_mask.reshape(B, L))
         ee = edge_embed
         if ee.dtype != torch.float32 or not ee.is_contiguous():
             ee = ee.to(torch.float32).contiguous()
@@ -295,6 +302,21 @@ class DenoiseEngine:
                                               self.pair_bias0.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
         if rebuild:
             self._build_plan()
+
+    def _refresh_work_lists(self, mask):
+        """Active EdgeTransition tiles from the residue mask [B,L] (all on the device, graph-safe: the kernels read list and count
+        from the same buffers on every replay).  z' of a tile without an unmasked pair is exactly zero (ga.py:118) and the
+        attention never looks at it, so such tiles are neither read nor written: their part of zbuf / pair_bias stays zero."""
+        B, L, R, nib, njb = self.B, self.L, self.et_rows, self.et_nib, self.et_njb
+        m = mask.to(torch.bool)
+        rows = torch.nn.functional.pad(m, (0, nib * R - L)).view(B, nib, R).any(-1)
+        cols = torch.nn.functional.pad(m, (0, njb * 16 - L)).view(B, njb, 16).any(-1)
+        active = (rows[:, :, None] & cols[:, None, :]).reshape(-1)
+        order = torch.sort((~active).to(torch.int8), stable=True).indices            # active tiles first, in tile order
+        self.et_tiles.copy_(order.to(torch.int32))
+        self.et_ntiles.copy_(active.sum().to(torch.int32).reshape(1))
+        self.zbuf.zero_()
+        self.pair_bias.zero_()
 
     def _build_plan(self):
         w, lib = self.w, self.lib
@@ -409,6 +431,7 @@ class DenoiseEngine:
                 et.bb = w[f"{b + 1}.linear_b.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")
+                et.tile_list, et.n_tiles = self.et_tiles.data_ptr(), self.et_ntiles.data_ptr()
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
                 plan.append((None, None, "join", 0))
