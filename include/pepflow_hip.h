@@ -170,6 +170,10 @@ typedef struct {
      * the f16 mode, att_mode = 2) and `proj` / `vp` are not read */
     const void* att_qk; const void* att_vt; int att_mode;
     int head_group;                /* one-kernel form: 0 = head-group split by size; 2 / 4 / 8 = that variant */
+    /* optional (two-kernel form): key_end[b] = 1 + the last unmasked residue of sample b (device memory, int32 [B]).  Keys and
+     * query rows from key_end[b] on are skipped: their probabilities are exactly zero (mask term -1e5, ipa_pytorch.py:427-430) and
+     * the outputs of masked query rows are multiplied by the mask afterwards (ga.py:104); feats / p_out there are NOT written. */
+    const int* key_end;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the

@@ -64,12 +64,14 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int b = lid / (nrb * H);
     const size_t rowb = (size_t)b * L;
     const int i0 = rb * rows_per_block + wave * 16;
-    const int kt = LP >> 4, ktf = L >> 4;          // key tiles, full key tiles
-    const bool wave_on = i0 < L;
+    // Le: keys / query rows from here on are masked (pf_ipa_attn_args.key_end; L without it): nothing beyond is read or written
+    const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
+    const int kt = (Le + 15) >> 4, ktf = Le >> 4;  // key tiles, full key tiles
+    const bool wave_on = i0 < Le;
     PROFS(0);
 
     // ---- operands of this wave's 16 queries, requested first (they come from the projection kernel's output) ----
-    const int iq = min(i0 + r, L - 1);             // lanes beyond L duplicate row L - 1 exactly
+    const int iq = max(min(i0 + r, Le - 1), 0);    // lanes beyond Le duplicate row Le - 1 exactly
     const float* qrow = a.proj + (rowb + iq) * a.ldp + h * C + 4 * g;
     float4 qf[8];
 #pragma unroll
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
     const float* kbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + 4 * g;
     auto loadk = [&](int t, float4 (&kf)[8]) {
-        const float* krow = kbase + (size_t)min(16 * t + r, L - 1) * a.ldp;
+        const float* krow = kbase + (size_t)min(16 * t + r, Le - 1) * a.ldp;
 #pragma unroll
         for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
     };
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
             float v = acc[e] * scale_qk + bj[e];
             v = v + (-0.5f) * (gamma * (d2[0] + d2[1]));
             v = v + 1e5f * (mi * MJ[j] - 1.f);
-            if constexpr (TAIL) v = j < L ? v : -3.0e38f;
+            if constexpr (TAIL) v = j < Le ? v : -3.0e38f;
             sv[e] = v;
             mx = fmaxf(mx, v);
         }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     auto loadv = [&](int t, float (&vb)[NTC][4]) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const size_t j = (size_t)min(16 * t + 4 * g + tt, L - 1);
+            const size_t j = (size_t)min(16 * t + 4 * g + tt, Le - 1);
             const float* vrow = vbase + j * a.ldp;
             const float4 x = *reinterpret_cast<const float4*>(vrow), y = *reinterpret_cast<const float4*>(vrow + 4);
             vb[0][tt] = x.x; vb[1][tt] = x.y; vb[2][tt] = x.z; vb[3][tt] = x.w;
@@ -216,10 +218,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         } else if constexpr (!TAIL) {
             prow[jb] = p.x; prow[jb + 1] = p.y; prow[jb + 2] = p.z; prow[jb + 3] = p.w;
         } else {
-            if (jb < L) prow[jb] = p.x;
-            if (jb + 1 < L) prow[jb + 1] = p.y;
-            if (jb + 2 < L) prow[jb + 2] = p.z;
-            if (jb + 3 < L) prow[jb + 3] = p.w;
+            if (jb < Le) prow[jb] = p.x;
+            if (jb + 1 < Le) prow[jb + 1] = p.y;
+            if (jb + 2 < Le) prow[jb + 2] = p.z;
+            if (jb + 3 < Le) prow[jb + 3] = p.w;
         }
         // consecutive MFMAs go to different accumulators (11 independent chains per key sub-step)
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     float* opt = SW + (size_t)wave * 16 * SLD;                   // (the wave's score region is dead now)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int ti = 4 * g + e, i = min(i0 + ti, L - 1);       // (duplicates of row L - 1 store identical values)
+        const int ti = 4 * g + e, i = min(i0 + ti, Le - 1);      // (duplicates of row Le - 1 store identical values)
         float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * C + 8 * r;
         *reinterpret_cast<float4*>(f) = make_float4(O[0][e], O[1][e], O[2][e], O[3][e]);
         *reinterpret_cast<float4*>(f + 4) = make_float4(O[4][e], O[5][e], O[6][e], O[7][e]);
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     // ---- o_pt -> local frame (invert_apply, ipa_pytorch.py:455) + norms (458) ----
     for (int idx = lane; idx < 16 * PV; idx += 64) {
         const int ti = idx / PV, p = idx - ti * PV;
-        const int i = min(i0 + ti, L - 1);
+        const int i = min(i0 + ti, Le - 1);
         const float* R = a.rot + (rowb + i) * 9;
         const float* T = a.trans + (rowb + i) * 3;
         const float* o = opt + ti * 36 + p * 3;
@@ -294,7 +296,6 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     constexpr bool SPLIT = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;                             // multiple of 16
-    const int L32 = (L + 31) & ~31;
     float* KP = smem;                              // [L][KPS] key points of this head (global frame)
     float* MJ = KP + L * KPS;                      // [L] key mask
     float* SW = MJ + L;                            // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
@@ -307,8 +308,11 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     const int b = lid / (nrb * H);
     const size_t rowb = (size_t)b * L;
     const int i0 = rb * rows_per_block + wave * 16;
-    const int kt = L >> 4;
-    const bool wave_on = i0 < L;
+    // LK: keys / query rows from here on (a multiple of 16) are masked (pf_ipa_attn_args.key_end): neither read nor written
+    const int LK = a.key_end ? min((__builtin_amdgcn_readfirstlane(a.key_end[b]) + 15) & ~15, L) : L;
+    const int L32 = (LK + 31) & ~31;
+    const int kt = LK >> 4;
+    const bool wave_on = i0 < LK;
     const int iq = i0 + r;                         // (< L: L is a multiple of 16)
     PROFS(0);
 
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         sum += v.x; sum += v.y; sum += v.z; sum += v.w;
         *reinterpret_cast<float4*>(srow + 16 * t + 4 * g) = v;
     }
-    if (L32 > L) *reinterpret_cast<float4*>(srow + L + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);   // trailing half step: zero weights
+    if (L32 > LK) *reinterpret_cast<float4*>(srow + LK + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);   // trailing half step: zero weights
     sum = sum_xor32(sum_xor16(sum));
     const float inv = 1.f / sum;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the second product reads other lanes' columns of row r
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         float4 p1 = *reinterpret_cast<const float4*>(srow + 32 * s32 + 8 * g + 4);
         p0.x *= inv; p0.y *= inv; p0.z *= inv; p0.w *= inv;
         p1.x *= inv; p1.y *= inv; p1.z *= inv; p1.w *= inv;
-        if (32 * s32 + 8 * g < L) {                              // (false only in a trailing half step)
+        if (32 * s32 + 8 * g < LK) {                             // (false only in a trailing half step)
             *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g) = p0;
             *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g + 4) = p1;
         }
@@ -572,12 +576,17 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     float* WL = ZBAR + ZW * 8 * 64;                              // [4 quarters][64 lanes] float4: W_dz operands of wave 0
     const long row = blockIdx.x;                                 // b * L + i
     const long b = row / L, i = row - b * L;
+    // keys / query rows from Le on are masked (pf_ipa_attn_args.key_end): a masked row does nothing, an unmasked one reads the
+    // z rows of its first nge = ceil(Le / 16) key groups of 16 only (wave-uniform guards around the loads)
+    const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
+    if (i >= Le) return;
+    const int nge = (Le + 15) >> 4;
     const float* zrow = a.z + (size_t)row * L * 64 + 4 * r;
     float4 zq[NG];
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
         const int j = 4 * (4 * u + wave) + g;                    // key group s = 4 u + wave
-        zq[u] = *reinterpret_cast<const float4*>(zrow + (size_t)min(j, L - 1) * 64);
+        if (u < nge) zq[u] = *reinterpret_cast<const float4*>(zrow + (size_t)min(j, L - 1) * 64);
     }
     // down_z weights of the epilogue (wave 0: B operand W_dz[d = r][c = 4 s + g]) requested now, not at the end: the first version
     // fetched them in the epilogue, a ~1 us dependent round trip per workgroup after the last barrier -- with the scalar GEMV it cost
@@ -591,13 +600,18 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
         for (int idx = tid; idx < LPZ * 2; idx += 64 * ZW) {    // float4 pieces of the 8 head rows
             const int hh = idx / (LPZ / 4), j = 4 * (idx - hh * (LPZ / 4));
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < L) v = *reinterpret_cast<const float4*>(a.p_out + ((b * H + hh) * L + i) * L + j);
+            if (j < Le) {
+                v = *reinterpret_cast<const float4*>(a.p_out + ((b * H + hh) * L + i) * L + j);
+                if (j + 1 >= Le) v.y = 0.f;                      // (the score kernel does not write beyond key Le - 1)
+                if (j + 2 >= Le) v.z = 0.f;
+                if (j + 3 >= Le) v.w = 0.f;
+            }
             *reinterpret_cast<float4*>(PL + hh * LPZ + j) = v;
         }
     } else {
         for (int idx = tid; idx < LPZ * 8; idx += 64 * ZW) {
             const int hh = idx / LPZ, j = idx - hh * LPZ;
-            PL[idx] = j < L ? a.p_out[((b * H + hh) * L + i) * L + j] : 0.f;
+            PL[idx] = j < Le ? a.p_out[((b * H + hh) * L + i) * L + j] : 0.f;
         }
     }
     *reinterpret_cast<float4*>(WL + (wave * 64 + lane) * 4) = wq4;
@@ -609,11 +623,13 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     const float keep = r < 8 ? 1.f : 0.f;                        // MFMA rows 8..15 are padding
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
-        const float pa = pl[4 * (4 * u + wave)] * keep;
-        zacc[0] = mfma16(pa, zq[u].x, zacc[0]);
-        zacc[1] = mfma16(pa, zq[u].y, zacc[1]);
-        zacc[2] = mfma16(pa, zq[u].z, zacc[2]);
-        zacc[3] = mfma16(pa, zq[u].w, zacc[3]);
+        if (u < nge) {
+            const float pa = pl[4 * (4 * u + wave)] * keep;
+            zacc[0] = mfma16(pa, zq[u].x, zacc[0]);
+            zacc[1] = mfma16(pa, zq[u].y, zacc[1]);
+            zacc[2] = mfma16(pa, zq[u].z, zacc[2]);
+            zacc[3] = mfma16(pa, zq[u].w, zacc[3]);
+        }
     }
     // D: lane (r = column within tile, g), register e -> head 4 g + e; column (tile ct, r) <-> channel 4 r + ct
     if (g < 2) {

@@ -250,6 +250,7 @@ class DenoiseEngine:
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
         self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
         self.et_ntiles = e(1, dt=torch.int32)
+        self.key_end = e(B, dt=torch.int32)     # pf_ipa_attn_args.key_end: 1 + last unmasked residue of each sample
         # attention operands as f16 planes (written by the projection's epilogue, read by the f16-operand score kernel), f16 mode
         # only: used where the two-kernel attention runs (64 <= L <= 256, a rule in L alone) and L is a multiple of 16 (sample() pads
         # to that).  In the fp32 mode the split (hi / lo) form of the same kernels is bit-compatible with the parity bar but not
@@ -315,6 +316,7 @@ class DenoiseEngine:
         order = torch.sort((~active).to(torch.int8), stable=True).indices            # active tiles first, in tile order
         self.et_tiles.copy_(order.to(torch.int32))
         self.et_ntiles.copy_(active.sum().to(torch.int32).reshape(1))
+        self.key_end.copy_((m.to(torch.int32) * torch.arange(1, L + 1, device=m.device, dtype=torch.int32)).amax(-1))
         self.zbuf.zero_()
         self.pair_bias.zero_()
 
@@ -363,6 +365,7 @@ class DenoiseEngine:
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
             ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
             ia.p_out = self.attn_p.data_ptr()
+            ia.key_end = self.key_end.data_ptr()
             if self.att_planes:
                 ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
             self._keep.append(ia)
