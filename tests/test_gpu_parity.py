@@ -533,6 +533,53 @@ def test_ga_encoder_ragged_shapes_vs_oracle(model, seeded_sd, B, L, lengths):
     assert torch.minimum(d, 2 * math.pi - d).max() < 3e-4
 
 
+def _encoder_case(seeded_sd, batch, resm, seed):
+    B, L = resm.shape
+    g = torch.Generator().manual_seed(seed)
+    R1, x1, ang1, seq1, node, edge = O.encode(seeded_sd, batch)
+    t = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    q = torch.randn(B, L, 4, generator=g)
+    R_t = O.so3_geodesic(t[..., None], R1, O.quat_to_rot(q / q.norm(dim=-1, keepdim=True)))
+    x_t = x1 + torch.randn(B, L, 3, generator=g)
+    ang_t = torch.rand(B, L, 5, generator=g) * 2 * math.pi
+    seq_t = torch.randint(0, 20, (B, L), generator=g)
+    return t, R_t, x_t, ang_t, seq_t, node, edge
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_masked_tiles_and_keys_are_skipped_exactly(model, seeded_sd, precision):
+    """Work lists of the padded-batch path (EdgeTransition tile list, IPA key_end): masks with HOLES (a whole 16-residue block
+    masked inside a sample, single masked residues), trailing padding of different lengths, a fully masked sample -- and the same
+    engine re-bound to a DIFFERENT mask afterwards (parts of z it skipped before are live now and vice versa).  Unmasked
+    residues must match the oracle as in the dense case."""
+    B, L = 4, 96
+    batch = synth.make_pocket_batch(B, L, 6, seed=4242, lengths=[96, 70, 33, 96])
+    masks = []
+    m = batch["res_mask"].clone()
+    m[0, 32:48] = False; m[0, 5] = False; m[0, 80:] = False          # block hole + single hole + trailing
+    m[3, :] = False; m[3, 10:20] = True                               # almost everything masked
+    masks.append(m)
+    m2 = batch["res_mask"].clone()
+    m2[1, :16] = False                                                # leading block masked, trailing padding from lengths
+    m2[2, :] = False                                                  # a fully masked sample
+    masks.append(m2)
+    model.ga_encoder.set_precision(precision)
+    try:
+        for k, resm in enumerate(masks):
+            t, R_t, x_t, ang_t, seq_t, node, edge = _encoder_case(seeded_sd, batch, resm, 7 + k)
+            ref = O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, node, edge, resm.long())
+            out = model.ga_encoder(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t), cu(node), cu(edge), cu(batch["generate_mask"].long()), cu(resm.long()))
+            G.sync()
+            valid = resm
+            tol = REL if precision == "fp32" else 2e-2
+            G.assert_close(out[0].cpu()[valid], ref[0][valid], tol, f"rotmats[{k}]")
+            G.assert_close(out[1].cpu()[valid], ref[1][valid], tol, f"trans[{k}]")
+            G.assert_close(out[3].cpu()[valid], ref[3][valid], 2 * tol if precision == "fp32" else 5e-2, f"logits[{k}]")
+            assert all(torch.isfinite(o).all() for o in out)
+    finally:
+        model.ga_encoder.set_precision("fp32")
+
+
 def test_encode_ragged_vs_oracle(model, seeded_sd):
     batch = synth.make_pocket_batch(3, 21, 5, seed=77, lengths=[21, 13, 20])
     ref = O.encode(seeded_sd, batch)
