@@ -123,7 +123,9 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
     first = rank * wl["B"]                                           # contiguous batch shards, global sample ids
     batch, B, L, n_real = make_batch(wl, first)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
-    info = {"B": B, "L": L, "real_residues": n_real, "sd": sd, "batch": batch}
+    # unmasked pairs sum_b len_b^2: what the pair-sized kernels have to process (masked tiles / keys are skipped, engine work lists)
+    real_pairs = int((batch["res_mask"].sum(-1).to(torch.int64) ** 2).sum())
+    info = {"B": B, "L": L, "real_residues": n_real, "real_pairs": real_pairs, "sd": sd, "batch": batch}
     with torch.no_grad():
         R1, x1, ang1, seq1, node, edge = model.encode(dbatch)
         eng = model.ga_encoder.engine(B, L, dev)
@@ -241,7 +243,7 @@ def main():
     prec = args.precision
     elapsed, info = run_sampler(wl, K, W, dev, dist, rank, world, use_graph, prec)
     B, L = info["B"], info["L"]
-    pairs = B * L * L
+    pairs = info["real_pairs"]                  # = B * L * L unless the batch is padded (cfg3): rooflines count unmasked pairs only
     split = 3 if prec == "fp32" else 1
 
     ms_per_step = elapsed / K * 1e3
@@ -287,14 +289,17 @@ def main():
         "roofline_other": rf_ipa if dominant != "pf_ipa_attn_fwd" else rf_et,
         "kernel_share_of_step": share,
         # whole-step view against the HBM roofline of BASELINE.md section 4 (4096*L algorithmic bytes per residue-step)
-        "hbm_roofline": {"bytes_per_res_step": 4096 * L, "achieved_GBps": per_gpu * 4096 * L / 1e9,
-                         "peak_GBps": HBM_PEAK / 1e9, "frac": per_gpu * 4096 * L / HBM_PEAK},
+        # (4096 B per unmasked PAIR and step = 16 passes over its 256 B of z; equals 4096 * L per residue-step for an unpadded batch)
+        "hbm_roofline": {"bytes_per_res_step": 4096 * L, "bytes_per_step": 4096 * pairs, "achieved_GBps": 4096 * pairs * K / elapsed / 1e9,
+                         "peak_GBps": HBM_PEAK / 1e9, "frac": 4096 * pairs * K / elapsed / HBM_PEAK},
         "final_state_check": info["validity"],
     }
     if wl.get("variable"):
         out["config"]["real_residues_per_gpu"] = info["real_residues"]
         out["value_real_residues"] = world * info["real_residues"] * K / elapsed
-        out["value_note"] = "value counts padded residues (B x L_max, what the kernels process); value_real_residues counts unpadded ones"
+        out["config"]["unmasked_pairs_per_gpu"] = pairs
+        out["value_note"] = ("value counts padded residues (B x L_max, the shape the batch has); value_real_residues counts unpadded ones; "
+                             "the rooflines count unmasked pairs (masked EdgeTransition tiles and attention keys are skipped)")
 
     if world == 1 and not args.no_secondary and args.workload != "cfg2":
         e2, i2 = run_sampler(WORKLOADS["cfg2"], K, W, dev, None, 0, 1, use_graph, prec, time_kernels=True)
