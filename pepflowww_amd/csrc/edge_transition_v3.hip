@@ -135,6 +135,19 @@ __device__ __forceinline__ void split4u(const float (&v)[4], half4& hi, half4& l
         lo[e] = (_Float16)__builtin_fmaf((float)h, -1.0f, v[e]);
     }
 }
+// f16 mode: ReLU AFTER the rounding to f16, as a packed signed-integer max with 0 (v_pk_max_i16: negative f16 values are negative
+// int16 bit patterns, -0.0 included; rounding is monotonic and keeps the sign, so the result equals f16(max(v, 0))) -- four
+// v_cvt_pk + four v_pk_max per eight values instead of eight v_max_f32 + four v_cvt_pk
+typedef short short8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8 relu_cvt8(const f32x4& a, const f32x4& b) {
+    half8 h;
+    h[0] = (_Float16)a[0]; h[1] = (_Float16)a[1]; h[2] = (_Float16)a[2]; h[3] = (_Float16)a[3];
+    h[4] = (_Float16)b[0]; h[5] = (_Float16)b[1]; h[6] = (_Float16)b[2]; h[7] = (_Float16)b[3];
+    short8v sv = __builtin_bit_cast(short8v, h);
+    const short8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+    sv = __builtin_elementwise_max(sv, z);
+    return __builtin_bit_cast(half8, sv);
+}
 template <bool SP>
 __device__ __forceinline__ void split8(const float4& a, const float4& b, half8& hi, half8& lo) {
     if constexpr (SP) {
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             for (int p = 0; p < NP; ++p) mac2<SP>(ga1, gb1, zh[p][1], zl[p][1], m0[p], m1[p]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
+                if constexpr (SP) { h1h[p][tp] = relu_cvt8(m0[p], m1[p]); continue; }
                 float4 v0, v1;
                 v0.x = fmaxf(m0[p][0], 0.f); v0.y = fmaxf(m0[p][1], 0.f); v0.z = fmaxf(m0[p][2], 0.f); v0.w = fmaxf(m0[p][3], 0.f);
                 v1.x = fmaxf(m1[p][0], 0.f); v1.y = fmaxf(m1[p][1], 0.f); v1.z = fmaxf(m1[p][2], 0.f); v1.w = fmaxf(m1[p][3], 0.f);
@@ -480,6 +494,12 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             const Frag w0 = ldfrag<SP>(sl, 12, lane), w1 = ldfrag<SP>(sl, 13, lane), w2 = ldfrag<SP>(sl, 14, lane), w3 = ldfrag<SP>(sl, 15, lane);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
+                if constexpr (SP) {
+                    const half8 xr = relu_cvt8(m0[p], m1[p]);
+                    mac2<SP>(w0, w1, xr, xr, m3[p][0], m3[p][1]);
+                    mac2<SP>(w2, w3, xr, xr, m3[p][2], m3[p][3]);
+                    continue;
+                }
                 float4 v0, v1;
                 v0.x = fmaxf(m0[p][0], 0.f); v0.y = fmaxf(m0[p][1], 0.f); v0.z = fmaxf(m0[p][2], 0.f); v0.w = fmaxf(m0[p][3], 0.f);
                 v1.x = fmaxf(m1[p][0], 0.f); v1.y = fmaxf(m1[p][1], 0.f); v1.z = fmaxf(m1[p][2], 0.f); v1.w = fmaxf(m1[p][3], 0.f);
