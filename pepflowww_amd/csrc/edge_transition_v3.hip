@@ -484,6 +484,15 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             wb[0] = ldfrag<SP>(sl, 6, lane);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
+                // issue priority (fp32 mode): the second-dispatched half of the consumers (waves 4-7) loses the VALU / MFMA
+                // arbitration on its SIMD to the older wave and reached every stage barrier ~350 cycles after it (arrival stamps,
+                // tools/phase_profile.sh) while the older wave sat parked; raised for the last third of a stage, the two finish
+                // together: 397 -> 388 us (same box).  (Raised for the whole kernel the halves just swap roles; in the f16 mode
+                // the flip costs: 198 -> 252 us.)
+                if constexpr (!SP) {
+                    if (k == 0) __builtin_amdgcn_s_setprio(0);
+                    if (k == 4 && wave >= NCW / 2) __builtin_amdgcn_s_setprio(1);
+                }
                 if (k < 5) {
                     wa[(k + 1) & 1] = ldfrag<SP>(sl, k + 1, lane);
                     wb[(k + 1) & 1] = ldfrag<SP>(sl, 7 + k, lane);
