@@ -97,7 +97,7 @@ def rigid_update(quat, rot, trans, upd, mask):
     return qo, ro, to
 
 
-def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0):
+def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
     variant=1); head_group: force a head-group split of the one-kernel form."""
     lib = _capi.load()
@@ -116,17 +116,19 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.bias = _p(bias)
     ia.p_out = _p(p_out)
     ia.variant, ia.head_group = variant, head_group
+    ia.key_end = _p(key_end)                  # int32 [B]: 1 + last unmasked residue (two-kernel form skips what lies beyond)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
 
 
-def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None):
+def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
     persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes)."""
     from pepflowww_amd.engine import split_f16, pack_et_stream
     lib = _capi.load()
-    out = z if inplace else torch.full_like(z, float("nan"))
+    if out is None:
+        out = z if inplace else torch.full_like(z, float("nan"))
     w1s, w2s, wfs = split_f16(w1[:, :64]), split_f16(w2), split_f16(wf)
     a = _capi.EdgeTransitionArgs()
     a.z_in, a.z_out, a.pre, a.w1z_f16, a.w2_f16, a.b2, a.wf_f16 = _p(z), _p(out), _p(pre), _p(w1s), _p(w2s), _p(b2), _p(wfs)
@@ -138,6 +140,8 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
         wbf = pack_bias_frags(next_bias[0])
         bias = torch.full((B, 8, L, L), float("nan"), device=z.device)
         a.bias_out, a.wb_frags, a.bb = _p(bias), _p(wbf), _p(next_bias[1])
+    if tile_list is not None:                 # (int32 list of active tile ids, int32 [1] count): pf_edge_transition_args.tile_list
+        a.tile_list, a.n_tiles = _p(tile_list[0]), _p(tile_list[1])
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()
     return (out, bias) if next_bias is not None else out

@@ -382,6 +382,88 @@ def test_edge_transition_ragged_tail(seeded_sd, persistent, B, L):
     G.assert_close(out.view(B, L, L, 64), ref, REL, "EdgeTransition ragged")
 
 
+def test_edge_transition_tile_list_through_the_c_abi(seeded_sd):
+    """pf_edge_transition_args.tile_list / n_tiles: listed tiles equal the run without a list, unlisted tiles are not touched;
+    a list that covers exactly the tiles with an unmasked pair reproduces the oracle on every unmasked pair."""
+    B, L = 2, 40
+    rows = _capi.load().pf_edge_transition_tile_rows(0)
+    nib, njb = (L + rows - 1) // rows, (L + 15) // 16
+    g = torch.Generator().manual_seed(31)
+    s, z = torch.randn(B, L, 128, generator=g), torch.randn(B, L, L, 64, generator=g)
+    mask = torch.ones(B, L)
+    mask[0, 16:32] = 0
+    mask[1, 24:] = 0
+    pfx = "ga_encoder.trunk.edge_transition_1."
+    full = _et_run(seeded_sd, pfx, s, z, mask, B, L)
+    m = mask.bool()
+    ra = torch.nn.functional.pad(m, (0, nib * rows - L)).view(B, nib, rows).any(-1)
+    ca = torch.nn.functional.pad(m, (0, njb * 16 - L)).view(B, njb, 16).any(-1)
+    active = (ra[:, :, None] & ca[:, None, :]).reshape(-1)
+    ids = torch.nonzero(active).reshape(-1).to(torch.int32)
+    assert 0 < ids.numel() < active.numel()
+    lst = torch.cat([ids, torch.full((active.numel() - ids.numel(),), -1, dtype=torch.int32)])
+    sentinel = 12345.0
+    gq = lambda k: seeded_sd[pfx + k]
+    n64 = G.linear(cu(s.reshape(B * L, 128)), cu(gq("initial_embed.weight")), cu(gq("initial_embed.bias")))
+    w1, b1, wf, bf = gq("trunk.0.weight"), gq("trunk.0.bias"), gq("final_layer.weight"), gq("final_layer.bias")
+    pre = G.linear(n64, cu(torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()),
+                   cu(torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0)))
+    out = torch.full((B * L * L, 64), sentinel, device=G.dev())
+    G.edge_transition(cu(z.reshape(-1, 64)), pre, cu(w1), cu(gq("trunk.2.weight")), cu(gq("trunk.2.bias")), cu(wf),
+                      cu(gq("layer_norm.weight")), cu(gq("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
+                      tile_list=(cu(lst), cu(torch.tensor([ids.numel()], dtype=torch.int32))), out=out)
+    out = out.cpu().view(B, nib * 0 + L, L, 64)
+    full = full.cpu().view(B, L, L, 64)
+    tile_active = active.view(B, nib, njb)
+    for b in range(B):
+        for ib in range(nib):
+            for jb in range(njb):
+                blk = (b, slice(ib * rows, min(L, (ib + 1) * rows)), slice(jb * 16, min(L, (jb + 1) * 16)))
+                if tile_active[b, ib, jb]:
+                    assert torch.equal(out[blk], full[blk]), (b, ib, jb)
+                else:
+                    assert (out[blk] == sentinel).all(), (b, ib, jb)
+    ref = O.edge_transition(seeded_sd, pfx[:-1], s, z)
+    em = (m[:, None, :] & m[:, :, None])
+    G.assert_close(out[em], ref[em], REL, "unmasked pairs vs oracle")
+
+
+def test_ipa_key_end_through_the_c_abi(seeded_sd):
+    """pf_ipa_attn_args.key_end: the two-kernel form with the per-sample key ends equals the run without them on every unmasked
+    query row (bit for bit in P's support), and leaves feats of rows beyond key_end untouched."""
+    B, L = 3, 80
+    g = torch.Generator().manual_seed(77)
+    pfx = "ga_encoder.trunk.ipa_3."
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    mask[0, 50:] = 0          # key_end 50 (not a multiple of 4)
+    mask[1, 33:] = 0
+    mask[1, 7] = 0            # a hole inside
+    mask[2, :] = 0
+    mask[2, 3:9] = 1          # key_end 9
+    kend = (mask.to(torch.int32) * torch.arange(1, L + 1, dtype=torch.int32)).amax(-1)
+    gq = lambda k: cu(seeded_sd[pfx + k])
+    sd = seeded_sd
+    wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    proj = G.linear(cu(s.reshape(B * L, 128)), cu(wproj), cu(bproj))
+    bias = cu((math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"])).reshape(B, L, L, 8).permute(0, 3, 1, 2))
+    run = lambda ke: G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)),
+                                 gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"),
+                                 B, L, bias=bias, p_out=torch.zeros(B, 8, L, L, device=G.dev()), variant=2, key_end=ke)[0].cpu()
+    dense, skipped = run(None), run(cu(kend))
+    valid = mask.reshape(-1).bool()
+    G.assert_close(skipped[valid], dense[valid], 1e-6, "key_end vs dense on unmasked rows")
+    ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], s, z, R, x, mask)
+    G.assert_close(skipped[valid], ref_feats.reshape(B * L, -1)[valid], REL, "key_end vs oracle")
+    beyond = (torch.arange(L)[None, :] >= kend[:, None]).reshape(-1)
+    assert torch.isnan(skipped[beyond]).all() and not torch.isnan(dense[beyond]).any()
+
+
 def test_encode_matches_reference(f2, model):
     b = {k: cu(v) for k, v in _batch(f2).items()}
     R1, x1, ang1, seq1, node, edge = model.encode(b)
