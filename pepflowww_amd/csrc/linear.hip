@@ -394,6 +394,159 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     }
 }
 
+// ---- wide row Linear, K = 128 (the IPA projection of the inference plan at >= 8192 rows): one workgroup = 32 rows x ALL output
+// features.  The tiled kernel above runs this shape as 3968 workgroups that each stage the same 64 x 128 x tile again (31 times
+// per tile) and then write 32 KiB: phase stamps of one workgroup -- 16 k cycles until its x tile is staged, up to 36 k more at the
+// barrier, 3 k of MFMAs, 48 k for its eight store instructions -- show a kernel made of chip-wide synchronized load and store
+// bursts (80 us for 10 us of matrix work and 21 us of stores at the measured 6.2 TB/s).  Here the x tile is staged ONCE per
+// workgroup, every wave keeps its B operands (32 rows x K = 128) in registers for the whole kernel and streams weight tiles
+// (32 features = 16 fragments, next tile's loads in flight under this tile's MFMAs and stores) with no barrier after the first:
+// the eight waves drift apart and loads, MFMAs and stores of different waves overlap.
+#ifndef PF_WR_ROT
+#define PF_WR_ROT 7
+#endif
+constexpr int WR_BM = 32, WR_K = 128, WR_LDK = WR_K + 8;
+template <bool SP>
+__global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int Npad) {
+    __shared__ __attribute__((aligned(16))) _Float16 Xh[WR_BM * WR_LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 Xl[WR_BM * WR_LDK];
+    __shared__ float RT[WR_BM * 12];                           // rotation | translation of the tile's rows (point columns)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * WR_BM;
+    {   // x tile -> hi / lo planes: 1024 float4, two per thread, both requested before the first conversion
+        float4 t[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 512, row = idx >> 5, c4 = idx & 31;
+            t[u] = *reinterpret_cast<const float4*>(p.x + (size_t)min(m0 + row, p.M - 1) * p.ldx + 4 * c4);
+        }
+        if (p.pt_rot && tid < WR_BM * 3) {                     // 12 floats per row as three float4-sized pieces (9 + 3)
+            const int row = tid / 3, q = tid - row * 3, m = min(m0 + row, p.M - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * q + e;
+                RT[row * 12 + k] = k < 9 ? p.pt_rot[(size_t)m * 9 + k] : p.pt_trans[(size_t)m * 3 + (k - 9)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 512, row = idx >> 5, c4 = idx & 31;
+            const float keep = (m0 + row < p.M) ? 1.f : 0.f;
+            const float v[4] = {t[u].x * keep, t[u].y * keep, t[u].z * keep, t[u].w * keep};
+            half4 hi, lo;
+            if constexpr (SP) {
+                hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+                *reinterpret_cast<half4*>(Xh + row * WR_LDK + 4 * c4) = hi;
+            } else {
+                split4(v, hi, lo);
+                *reinterpret_cast<half4*>(Xh + row * WR_LDK + 4 * c4) = hi;
+                *reinterpret_cast<half4*>(Xl + row * WR_LDK + 4 * c4) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    // this wave's B operands: rows 16 rt + r, K-step ks, slots 8 g .. + 7
+    half8 xh[2][4], xl[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            xh[rt][ks] = *reinterpret_cast<const half8*>(Xh + (rt * 16 + r) * WR_LDK + 32 * ks + 8 * g);
+            if constexpr (!SP) xl[rt][ks] = *reinterpret_cast<const half8*>(Xl + (rt * 16 + r) * WR_LDK + 32 * ks + 8 * g);
+        }
+    const _Float16* whp = reinterpret_cast<const _Float16*>(p.w_f16);
+    const _Float16* wlp = whp + (size_t)Npad * WR_K;
+    const int ntile2 = Npad >> 5;                              // 32-feature tiles (Npad % 32 == 0 is checked by the launcher)
+    struct WT { half8 h[2][4], l[2][4]; };
+    auto loadw = [&](int t2, WT& w) {
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const size_t off = ((size_t)((2 * t2 + wt) * 4 + ks) * 64 + lane) * 8;
+                w.h[wt][ks] = *reinterpret_cast<const half8*>(whp + off);
+                if constexpr (!SP) w.l[wt][ks] = *reinterpret_cast<const half8*>(wlp + off);
+            }
+    };
+    const bool vec_ok = (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
+    auto tile = [&](int t2, const WT& w) {
+        f32x4 am[2][2], ac[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) { am[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    am[rt][wt] = mfma_h(w.h[wt][ks], xh[rt][ks], am[rt][wt]);
+                    if constexpr (!SP) {
+                        ac[rt][wt] = mfma_h(w.h[wt][ks], xl[rt][ks], ac[rt][wt]);
+                        ac[rt][wt] = mfma_h(w.l[wt][ks], xh[rt][ks], ac[rt][wt]);
+                    }
+                }
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt) {
+            const int n = (2 * t2 + wt) * 16 + 4 * g;
+            float b4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = rt * 16 + r, m = m0 + row;
+                if (m >= p.M) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (SP ? am[rt][wt][e] : am[rt][wt][e] + ac[rt][wt][e] * PF_LO_INV) + b4[e];
+                if (p.pt_rot && n >= p.pt_col0) {        // a point (x, y, z, 0): frame transform, scatter to qp / kp / vp
+                    const float* R = RT + row * 12;
+                    const float* T = R + 9;
+                    const int pt = (n - p.pt_col0) >> 2;
+                    if (pt < 224) {
+                        float* o;
+                        if (pt < 64) o = p.pt_qp + (size_t)m * 192 + pt * 3;
+                        else {
+                            const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20;
+                            o = (pp < 8) ? p.pt_kp + (size_t)m * 192 + (hh * 8 + pp) * 3 : p.pt_vp + (size_t)m * 288 + (hh * 12 + (pp - 8)) * 3;
+                        }
+                        o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                        o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                        o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                    }
+                    continue;
+                }
+                float* dst = p.y + (size_t)m * p.ldy + n;
+                if (vec_ok && n + 3 < p.N) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[e] = v[e];
+                }
+            }
+        }
+    };
+    // tiles wave, wave + 8, ...: two per trip, the fragment buffers alternating (no "current = next" copies); the trailing loads
+    // re-read a valid tile
+    // (every workgroup starts at a different tile, PF_WR_ROT apart: all 256 of them walking the weight matrix in the same order
+    //  at the same time hammer the same L2 channels -- 59 us; rotated 50-51 us.  Non-temporal output stores: no change.)
+    WT wa, wb;
+    const int rot = (int)((blockIdx.x * (unsigned)PF_WR_ROT) % (unsigned)ntile2);
+    auto tid2 = [&](int i) { int t = i + rot; return t >= ntile2 ? t - ntile2 : t; };   // i < ntile2
+    int i2 = wave;
+    if (i2 >= ntile2) return;
+    loadw(tid2(i2), wa);
+    for (; i2 + 8 < ntile2; i2 += 16) {
+        loadw(tid2(i2 + 8), wb);
+        tile(tid2(i2), wa);
+        loadw(tid2(min(i2 + 16, ntile2 - 1)), wa);
+        tile(tid2(i2 + 8), wb);
+    }
+    if (i2 < ntile2) tile(tid2(i2), wa);
+}
+
 // fp32 W[N,K] (ldw; or its transpose: W given as [K,N] when `transpose`) -> f16 hi/lo planes in fragment order
 // [2][Npad/16][K/32][64 lanes][8] (the layout engine.split_f16 documents): one thread per 8 consecutive k of one output row
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw, int N, int K, int transpose, _Float16* out, int Npad, int* range_flag) {
@@ -466,6 +619,15 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
+        }
+        // the IPA projection of large batches: rows-persistent form (one workgroup = 32 rows x all features)
+        if (a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->att_qk && !a->relu && !a->row_mask &&
+            !a->residual && !a->gate) {
+            const dim3 grid((a->M + WR_BM - 1) / WR_BM);
+            if (a->single_pass) hipLaunchKernelGGL(linear_rows_kernel<true>, grid, dim3(512), 0, s, *a, Npad);
+            else hipLaunchKernelGGL(linear_rows_kernel<false>, grid, dim3(512), 0, s, *a, Npad);
+            PF_CHECK_LAUNCH();
+            return 0;
         }
         const unsigned gm = (a->M + SP_BM - 1) / SP_BM;
         if (Npad > 128 && Npad <= 192 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<6>, dim3(gm, 1), dim3(384), lds, s, *a, Npad);
