@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
 #define PF_WR_ROT 7
 #endif
 constexpr int WR_BM = 32, WR_K = 128, WR_LDK = WR_K + 8;
-template <bool SP>
+template <bool SP, bool ATT = false>           // ATT: attention operand planes (pf_linear_args.att_*), as in linear_split_kernel
 __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int Npad) {
     __shared__ __attribute__((aligned(16))) _Float16 Xh[WR_BM * WR_LDK];
     __shared__ __attribute__((aligned(16))) _Float16 Xl[WR_BM * WR_LDK];
@@ -470,12 +470,57 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
             }
     };
     const bool vec_ok = (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
+    const int AL = p.att_L;
     auto tile = [&](int t2, const WT& w) {
         f32x4 am[2][2], ac[2][2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int wt = 0; wt < 2; ++wt) { am[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const int n0 = 32 * t2;
+        if (ATT && n0 >= 1024 && n0 < 3072 && (((n0 - 1024) >> 7) & 1)) {
+            // value features: rows x features product (operands swapped) -> lane (r = feature, g) holds rows 4 g + e of a row
+            // tile: transposed 8-byte stores into att_vt
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        am[rt][wt] = mfma_h(xh[rt][ks], w.h[wt][ks], am[rt][wt]);
+                        if constexpr (!SP) {
+                            ac[rt][wt] = mfma_h(xl[rt][ks], w.h[wt][ks], ac[rt][wt]);
+                            ac[rt][wt] = mfma_h(xh[rt][ks], w.l[wt][ks], ac[rt][wt]);
+                        }
+                    }
+            _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) {
+                const int n = n0 + wt * 16 + r;
+                const float bn = p.bias ? p.bias[n] : 0.f;
+                const int hd = (n - 1024) >> 8, c = ((n - 1024) & 255) - 128;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int mq = m0 + rt * 16 + 4 * g;                // four consecutive rows of one sample (L % 4 == 0)
+                    if (mq >= p.M) continue;
+                    const int bs = mq / AL, j = mq - bs * AL;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (SP ? am[rt][wt][e] : am[rt][wt][e] + ac[rt][wt][e] * PF_LO_INV) + bn;
+                    half4 hi, lo;
+                    if constexpr (SP) {
+                        hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+                        *reinterpret_cast<half4*>(vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * AL + j) = hi;
+                    } else {
+                        split4(v, hi, lo);
+                        _Float16* d = vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * (2 * AL) + (j >> 3) * 16 + (j & 7);
+                        *reinterpret_cast<half4*>(d) = hi;
+                        *reinterpret_cast<half4*>(d + 8) = lo;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -506,15 +551,50 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                     const float* T = R + 9;
                     const int pt = (n - p.pt_col0) >> 2;
                     if (pt < 224) {
-                        float* o;
-                        if (pt < 64) o = p.pt_qp + (size_t)m * 192 + pt * 3;
-                        else {
-                            const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20;
-                            o = (pp < 8) ? p.pt_kp + (size_t)m * 192 + (hh * 8 + pp) * 3 : p.pt_vp + (size_t)m * 288 + (hh * 12 + (pp - 8)) * 3;
+                        const float ox = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                        const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                        const float oz = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                        const bool vpoint = pt >= 64 && (pt - 64) % 20 >= 8;
+                        if (ATT && vpoint) {      // value points: rows 128 + 3 p + xyz of the head's transposed value block
+                            const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20 - 8;
+                            const int bs = m / AL, j = m - bs * AL;
+                            _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
+                            if constexpr (SP) {
+                                _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * AL + j;
+                                d[0] = (_Float16)ox; d[AL] = (_Float16)oy; d[2 * AL] = (_Float16)oz;
+                            } else {
+                                const float ov[4] = {ox, oy, oz, 0.f};
+                                half4 hi, lo;
+                                split4(ov, hi, lo);
+                                _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * (2 * AL) + (j >> 3) * 16 + (j & 7);
+                                d[0] = hi[0]; d[8] = lo[0];
+                                d[2 * AL] = hi[1]; d[2 * AL + 8] = lo[1];
+                                d[4 * AL] = hi[2]; d[4 * AL + 8] = lo[2];
+                            }
+                        } else {
+                            float* o;
+                            if (pt < 64) o = p.pt_qp + (size_t)m * 192 + pt * 3;
+                            else {
+                                const int hp = pt - 64, hh = hp / 20, pp = hp - hh * 20;
+                                o = (pp < 8) ? p.pt_kp + (size_t)m * 192 + (hh * 8 + pp) * 3 : p.pt_vp + (size_t)m * 288 + (hh * 12 + (pp - 8)) * 3;
+                            }
+                            o[0] = ox; o[1] = oy; o[2] = oz;
                         }
-                        o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
-                        o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
-                        o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                    }
+                    continue;
+                }
+                if (ATT && n < 3072) {                    // q / k features -> f16 planes of the attention
+                    _Float16* qk = reinterpret_cast<_Float16*>(p.att_qk);
+                    const int kc = n < 1024 ? n : 1024 + ((n - 1024) >> 8) * 128 + ((n - 1024) & 255);   // q channel | 1024 + k channel
+                    half4 hi, lo;
+                    if constexpr (SP) {
+                        hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+                        *reinterpret_cast<half4*>(qk + (size_t)m * 2048 + kc) = hi;
+                    } else {                              // channel octets interleaved (hi8 | lo8)
+                        split4(v, hi, lo);
+                        _Float16* d = qk + (size_t)m * 4096 + (kc >> 3) * 16 + (kc & 7);
+                        *reinterpret_cast<half4*>(d) = hi;
+                        *reinterpret_cast<half4*>(d + 8) = lo;
                     }
                     continue;
                 }
@@ -621,10 +701,12 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
             attr_set = true;
         }
         // the IPA projection of large batches: rows-persistent form (one workgroup = 32 rows x all features)
-        if (a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->att_qk && !a->relu && !a->row_mask &&
-            !a->residual && !a->gate) {
+        if (a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->relu && !a->row_mask &&
+            !a->residual && !a->gate &&
+            (!a->att_qk || (a->single_pass && a->pt_rot && a->att_vt && a->att_L > 0 && a->att_L % 16 == 0))) {   // (planes: f16 mode only -- 256 VGPRs + spills in split form)
             const dim3 grid((a->M + WR_BM - 1) / WR_BM);
-            if (a->single_pass) hipLaunchKernelGGL(linear_rows_kernel<true>, grid, dim3(512), 0, s, *a, Npad);
+            if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true>), grid, dim3(512), 0, s, *a, Npad);
+            else if (a->single_pass) hipLaunchKernelGGL(linear_rows_kernel<true>, grid, dim3(512), 0, s, *a, Npad);
             else hipLaunchKernelGGL(linear_rows_kernel<false>, grid, dim3(512), 0, s, *a, Npad);
             PF_CHECK_LAUNCH();
             return 0;
