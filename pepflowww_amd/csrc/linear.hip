@@ -701,7 +701,11 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
             attr_set = true;
         }
         // the IPA projection of large batches: rows-persistent form (one workgroup = 32 rows x all features)
-        if (a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->relu && !a->row_mask &&
+        // ... when its workgroups fill whole rounds of the 256 CUs (>= 90 %): one workgroup is ~1/256 of the launch, so 288 of them
+        // (B=64, L=144) would take two rounds -- the tiled kernel below is faster there
+        const long nwg_rows = (a->M + WR_BM - 1) / WR_BM;
+        const bool rows_fit = nwg_rows * 10 >= ((nwg_rows + 255) / 256) * 256 * 9;
+        if (rows_fit && a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->relu && !a->row_mask &&
             !a->residual && !a->gate &&
             (!a->att_qk || (a->single_pass && a->pt_rot && a->att_vt && a->att_L > 0 && a->att_L % 16 == 0))) {   // (planes: f16 mode only -- 256 VGPRs + spills in split form)
             const dim3 grid((a->M + WR_BM - 1) / WR_BM);
