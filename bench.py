@@ -130,6 +130,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
         R1, x1, ang1, seq1, node, edge = model.encode(dbatch)
         eng = model.ga_encoder.engine(B, L, dev)
         eng.bind_context(node, edge, dbatch["res_mask"])
+        info["z16"] = bool(getattr(eng, "z16", False))
         smp = DeviceSampler(eng, NS, (True, True, True), first_sample=first, seed=20240227)
         smp.set_context(R1, x1, ang1, seq1, dbatch["generate_mask"])
         noise = {k: v for k, v in synth.make_noise(B, L, 1, seed=7, first_sample=first).items() if k != "expo"}
@@ -245,6 +246,7 @@ def main():
     B, L = info["B"], info["L"]
     pairs = info["real_pairs"]                  # = B * L * L unless the batch is padded (cfg3): rooflines count unmasked pairs only
     split = 3 if prec == "fp32" else 1
+    zb = 2304 if info.get("z16") else 4096      # algorithmic HBM bytes per unmasked pair and step (see hbm_roofline below)
 
     ms_per_step = elapsed / K * 1e3
     value = world * B * L * K / elapsed
@@ -289,9 +291,12 @@ def main():
         "roofline_other": rf_ipa if dominant != "pf_ipa_attn_fwd" else rf_et,
         "kernel_share_of_step": share,
         # whole-step view against the HBM roofline of BASELINE.md section 4 (4096*L algorithmic bytes per residue-step)
-        # (4096 B per unmasked PAIR and step = 16 passes over its 256 B of z; equals 4096 * L per residue-step for an unpadded batch)
-        "hbm_roofline": {"bytes_per_res_step": 4096 * L, "bytes_per_step": 4096 * pairs, "achieved_GBps": 4096 * pairs * K / elapsed / 1e9,
-                         "peak_GBps": HBM_PEAK / 1e9, "frac": 4096 * pairs * K / elapsed / HBM_PEAK},
+        # (fp32 pair tensor: 4096 B per unmasked PAIR and step = 16 passes over its 256 B of z; equals 4096 * L per residue-step for an
+        #  unpadded batch.  f16 mode with the pair tensor of blocks 1..5 stored as f16 (engine.z16): block 0 reads the fp32 edge
+        #  embedding twice and writes f16 (640 B), blocks 1-4 read twice and write once (384 B each), block 5 reads once (128 B) = 2304 B)
+        "hbm_roofline": {"bytes_per_pair_step": zb, "bytes_per_res_step": zb * L, "bytes_per_step": zb * pairs,
+                         "achieved_GBps": zb * pairs * K / elapsed / 1e9, "peak_GBps": HBM_PEAK / 1e9, "frac": zb * pairs * K / elapsed / HBM_PEAK,
+                         "pair_tensor": "f16 (blocks 1-5)" if zb != 4096 else "fp32"},
         "final_state_check": info["validity"],
     }
     if wl.get("variable"):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 35
+#define PF_ABI_VERSION 36
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -174,6 +174,7 @@ typedef struct {
      * query rows from key_end[b] on are skipped: their probabilities are exactly zero (mask term -1e5, ipa_pytorch.py:427-430) and
      * the outputs of masked query rows are multiplied by the mask afterwards (ga.py:104); feats / p_out there are NOT written. */
     const int* key_end;
+    int z_f16;                     /* two-kernel form: z is [B,L,L,64] f16 (the f16 mode's pair tensor, see pf_edge_transition_args) */
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
@@ -302,6 +303,9 @@ typedef struct {
      * masked tile is exactly zero in the reference (ga.py:118), so the caller keeps those parts of z_out (and bias_out) zeroed.
      * Both pointers are device memory (the count is read by the kernel: no host synchronisation, graph-safe). */
     const int* tile_list; const int* n_tiles;
+    /* f16 mode only (single_pass): the pair tensor stored as f16 -- z_in / z_out then point to [B*L*L,64] f16 (same element order).
+     * z_out_f16 alone (block 0: fp32 edge embedding in, f16 out) or both. */
+    int z_in_f16, z_out_f16;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */

@@ -169,8 +169,10 @@ struct Tile { int b, i0, j0; };
 
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
-template <bool DUMP, bool SP, int NP>
+// ZI / ZO (f16 mode only): the pair tensor is read / written as f16 (pf_edge_transition_args.z_in_f16 / z_out_f16)
+template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false>
 __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
+    static_assert(SP || (!ZI && !ZO), "f16 pair tensor: f16 mode only");
     using M = Map<SP, NP>;
     constexpr int TI = M::TI, NSLr = M::NSL, OFF_Z = M::OFF_Z, OFF_AD = M::OFF_AD, OFF_CE = M::OFF_CE, OFF_MK = M::OFF_MK,
                   OFF_CS = M::OFF_CS, OFF_WB = M::OFF_WB;
@@ -283,14 +285,26 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         const unsigned ce_off = off16 < 768 ? 768 + off16 : 1792 + (off16 - 768);    // [c 768 B | e 256 B]
         const unsigned char* zg = reinterpret_cast<const unsigned char*>(a.z_in);
         const unsigned char* pg = reinterpret_cast<const unsigned char*>(a.pre);
+        // ZI: f16 rows of 128 B: piece 2 * row + m = pairs pp = 8 m + (lane >> 3), 16-byte chunk lane & 7 holds the global chunk
+        // (lane & 7) ^ (pp & 7)
         unsigned zoff[4];
         auto prep_z = [&](const Tile& tl) {
+            if constexpr (ZI) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int rr = m * 4 + (lane >> 4);
-                int jr = rr;
-                jr = tl.j0 + jr < L ? jr : L - 1 - tl.j0;
-                zoff[m] = (unsigned)(jr * 256 + 16 * (q ^ rr));
+                for (int m = 0; m < 2; ++m) {
+                    const int pp = m * 8 + (lane >> 3);
+                    int jr = pp;
+                    jr = tl.j0 + jr < L ? jr : L - 1 - tl.j0;
+                    zoff[m] = (unsigned)(jr * 128 + 16 * ((lane & 7) ^ (pp & 7)));
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int rr = m * 4 + (lane >> 4);
+                    int jr = rr;
+                    jr = tl.j0 + jr < L ? jr : L - 1 - tl.j0;
+                    zoff[m] = (unsigned)(jr * 256 + 16 * (q ^ rr));
+                }
             }
         };
         auto issue_z = [&](const Tile& tl, int row0, int row1) {
@@ -298,9 +312,15 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             for (int row = row0; row < row1; ++row) {
                 int i = tl.i0 + row;
                 i = i < L ? i : L - 1;
-                const unsigned char* base = zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 256;
+                if constexpr (ZI) {
+                    const unsigned char* base = zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 128;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) GLDS16U(base, zoff[m], OFF_Z + (4 * row + m) * 1024);
+                    for (int m = 0; m < 2; ++m) GLDS16U(base, zoff[m], OFF_Z + (2 * row + m) * 1024);
+                } else {
+                    const unsigned char* base = zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 256;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) GLDS16U(base, zoff[m], OFF_Z + (4 * row + m) * 1024);
+                }
             }
         };
         auto issue_ad = [&](const Tile& tl) {                    // TI pieces: row i0 + k, [a | d]
@@ -404,9 +424,14 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 for (int p = 0; p < NP; ++p) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const float4 q0 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g) ^ r));
-                        const float4 q1 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g + 1) ^ r));
-                        split8<SP>(q0, q1, zh[p][s], zl[p][s]);
+                        if constexpr (ZI) {       // f16 rows: the 16-byte chunk IS the MFMA operand
+                            zh[p][s] = *reinterpret_cast<const half8*>(smem + OFF_Z + (NP * wave + p) * 2048 + r * 128 + 16 * ((4 * s + g) ^ (r & 7)));
+                            zl[p][s] = zh[p][s];
+                        } else {
+                            const float4 q0 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g) ^ r));
+                            const float4 q1 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g + 1) ^ r));
+                            split8<SP>(q0, q1, zh[p][s], zl[p][s]);
+                        }
                     }
                     mk[p] = mkb[NP * wave + p] * mkb[TI + r];
                 }
@@ -566,9 +591,19 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk[p];
             }
             if (valid[p]) {
-                float* zo = a.z_out + pidx[p] * 64 + 4 * g;
+                if constexpr (ZO) {
+                    _Float16* zo = reinterpret_cast<_Float16*>(a.z_out) + pidx[p] * 64 + 4 * g;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(zo + 16 * t) = o4[t];
+                    for (int t = 0; t < 4; ++t) {
+                        half4 h;
+                        h[0] = (_Float16)o4[t].x; h[1] = (_Float16)o4[t].y; h[2] = (_Float16)o4[t].z; h[3] = (_Float16)o4[t].w;
+                        *reinterpret_cast<half4*>(zo + 16 * t) = h;
+                    }
+                } else {
+                    float* zo = a.z_out + pidx[p] * 64 + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(zo + 16 * t) = o4[t];
+                }
             }
             if (a.bias_out) {
                 // pair bias of the NEXT IPA block from z' while it is in registers: one more 64 -> 8(16) split-precision GEMM with
@@ -611,7 +646,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 }  // namespace
 
 // launcher used by pf_edge_transition_fwd (edge_transition.hip) when args.w_stream is set
-template <bool DUMP, bool SP, int NP>
+template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false>
 static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
     using M = Map<SP, NP>;
     const int nib = (a->L + M::TI - 1) / M::TI, njb = (a->L + TJ - 1) / TJ;
@@ -620,11 +655,11 @@ static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int 
     const int grid = (int)(nt < ncu ? nt : ncu);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
         attr_set = true;
     }
-    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -642,6 +677,12 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
         if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass) return PF_E_BADARG;
         return et3_launch<true, false, 1>(a, stream, ncu);
     }
-    if (a->single_pass) return et3_launch<false, true, PF_ET_SP_NP>(a, stream, ncu);
+    if ((a->z_in_f16 || a->z_out_f16) && !a->single_pass) return PF_E_BADARG;   // f16 pair tensor: f16 mode only
+    if (a->single_pass) {
+        if (a->z_in_f16 && a->z_out_f16) return et3_launch<false, true, PF_ET_SP_NP, true, true>(a, stream, ncu);
+        if (a->z_out_f16) return et3_launch<false, true, PF_ET_SP_NP, false, true>(a, stream, ncu);
+        if (a->z_in_f16) return PF_E_BADARG;
+        return et3_launch<false, true, PF_ET_SP_NP>(a, stream, ncu);
+    }
     return et3_launch<false, false, 1>(a, stream, ncu);
 }

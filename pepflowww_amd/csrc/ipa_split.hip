@@ -564,7 +564,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
 // instructions per row and thread): 77 - 82 us, PMC: VALU 50 % busy (a plain VALU instruction costs ~4 cycles per wave here),
 // waves parked 59 % of their cycles; a persistent variant with next-row prefetch and 3 workgroups per CU: 102 us.
 constexpr int ZW = 4;
-template <int NG>                              // key groups (4 keys = one float4 load per lane) per wave: 16 NG >= L, NG = 1..16
+template <int NG, bool Z16 = false>            // key groups (4 keys = one float4 load per lane) per wave: 16 NG >= L, NG = 1..16; Z16: z is f16
 __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     constexpr int LPZ = 16 * NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -582,11 +582,16 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     if (i >= Le) return;
     const int nge = (Le + 15) >> 4;
     const float* zrow = a.z + (size_t)row * L * 64 + 4 * r;
+    const _Float16* zrow16 = reinterpret_cast<const _Float16*>(a.z) + (size_t)row * L * 64 + 4 * r;
     float4 zq[NG];
+    half4 zq16[NG];
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
         const int j = 4 * (4 * u + wave) + g;                    // key group s = 4 u + wave
-        if (u < nge) zq[u] = *reinterpret_cast<const float4*>(zrow + (size_t)min(j, L - 1) * 64);
+        if (u < nge) {
+            if constexpr (Z16) zq16[u] = *reinterpret_cast<const half4*>(zrow16 + (size_t)min(j, L - 1) * 64);
+            else zq[u] = *reinterpret_cast<const float4*>(zrow + (size_t)min(j, L - 1) * 64);
+        }
     }
     // down_z weights of the epilogue (wave 0: B operand W_dz[d = r][c = 4 s + g]) requested now, not at the end: the first version
     // fetched them in the epilogue, a ~1 us dependent round trip per workgroup after the last barrier -- with the scalar GEMV it cost
@@ -625,6 +630,7 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     for (int u = 0; u < NG; ++u) {
         if (u < nge) {
             const float pa = pl[4 * (4 * u + wave)] * keep;
+            if constexpr (Z16) zq[u] = make_float4((float)zq16[u][0], (float)zq16[u][1], (float)zq16[u][2], (float)zq16[u][3]);
             zacc[0] = mfma16(pa, zq[u].x, zacc[0]);
             zacc[1] = mfma16(pa, zq[u].y, zacc[1]);
             zacc[2] = mfma16(pa, zq[u].z, zacc[2]);
@@ -722,7 +728,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     if (ng > 16 || rows > 0x7fffffffL) return PF_E_TOOLARGE;
     const dim3 grid((unsigned)rows), blk(64 * ZW);
     switch (ng) {
-#define PF_PAIR_CASE(N) case N: hipLaunchKernelGGL(ipa_pair_kernel<N>, grid, blk, lds, s, *a); break;
+#define PF_PAIR_CASE(N) case N: if (a->z_f16) hipLaunchKernelGGL((ipa_pair_kernel<N, true>), grid, blk, lds, s, *a); else hipLaunchKernelGGL(ipa_pair_kernel<N>, grid, blk, lds, s, *a); break;
         PF_PAIR_CASE(1) PF_PAIR_CASE(2) PF_PAIR_CASE(3) PF_PAIR_CASE(4) PF_PAIR_CASE(5) PF_PAIR_CASE(6) PF_PAIR_CASE(7) PF_PAIR_CASE(8)
         PF_PAIR_CASE(9) PF_PAIR_CASE(10) PF_PAIR_CASE(11) PF_PAIR_CASE(12) PF_PAIR_CASE(13) PF_PAIR_CASE(14) PF_PAIR_CASE(15) PF_PAIR_CASE(16)
 #undef PF_PAIR_CASE

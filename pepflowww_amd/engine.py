@@ -240,7 +240,10 @@ class DenoiseEngine:
         self.upd = e(rows, 8)
         self.quat, self.rot, self.trans = e(rows, 4), e(rows, 9), e(rows, 3)
         self.n64, self.pre = e(rows, 64), e(rows, 512)
-        self.zbuf = e(B, L, L, 64)
+        # pair tensor of blocks 1..5: fp32; f16 in the f16 mode wherever the two-kernel attention runs (its only other reader is the
+        # EdgeTransition kernel): halves the HBM-bound pair aggregation's traffic
+        self.z16 = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
+        self.zbuf = e(B, L, L, 64, dt=torch.float16 if self.z16 else torch.float32)
         self.pair_bias = e(B, 8, L, L)          # sqrt(1/3)(W_b z + b_b) of the next IPA block (head-major), written by EdgeTransition
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
@@ -366,6 +369,7 @@ class DenoiseEngine:
             ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
             ia.p_out = self.attn_p.data_ptr()
             ia.key_end = self.key_end.data_ptr()
+            ia.z_f16 = int(self.z16 and b > 0)
             if self.att_planes:
                 ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
             self._keep.append(ia)
@@ -435,6 +439,7 @@ class DenoiseEngine:
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")
                 et.tile_list, et.n_tiles = self.et_tiles.data_ptr(), self.et_ntiles.data_ptr()
+                et.z_in_f16, et.z_out_f16 = int(self.z16 and b > 0), int(self.z16)
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
                 plan.append((None, None, "join", 0))
