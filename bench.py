@@ -246,7 +246,7 @@ def main():
     B, L = info["B"], info["L"]
     pairs = info["real_pairs"]                  # = B * L * L unless the batch is padded (cfg3): rooflines count unmasked pairs only
     split = 3 if prec == "fp32" else 1
-    zb = 2304 if info.get("z16") else 4096      # algorithmic HBM bytes per unmasked pair and step (see hbm_roofline below)
+    zb = 2048 if info.get("z16") else 4096      # algorithmic HBM bytes per unmasked pair and step (see hbm_roofline below)
 
     ms_per_step = elapsed / K * 1e3
     value = world * B * L * K / elapsed
@@ -292,11 +292,11 @@ def main():
         "kernel_share_of_step": share,
         # whole-step view against the HBM roofline of BASELINE.md section 4 (4096*L algorithmic bytes per residue-step)
         # (fp32 pair tensor: 4096 B per unmasked PAIR and step = 16 passes over its 256 B of z; equals 4096 * L per residue-step for an
-        #  unpadded batch.  f16 mode with the pair tensor of blocks 1..5 stored as f16 (engine.z16): block 0 reads the fp32 edge
-        #  embedding twice and writes f16 (640 B), blocks 1-4 read twice and write once (384 B each), block 5 reads once (128 B) = 2304 B)
+        #  unpadded batch.  f16 mode with the pair tensor stored as f16 (engine.z16; the caller's fp32 edge embedding is converted
+        #  once per call): 16 passes over 128 B = 2048 B)
         "hbm_roofline": {"bytes_per_pair_step": zb, "bytes_per_res_step": zb * L, "bytes_per_step": zb * pairs,
                          "achieved_GBps": zb * pairs * K / elapsed / 1e9, "peak_GBps": HBM_PEAK / 1e9, "frac": zb * pairs * K / elapsed / HBM_PEAK,
-                         "pair_tensor": "f16 (blocks 1-5)" if zb != 4096 else "fp32"},
+                         "pair_tensor": "f16" if zb != 4096 else "fp32"},
         "final_state_check": info["validity"],
     }
     if wl.get("variable"):

@@ -244,6 +244,7 @@ class DenoiseEngine:
         # EdgeTransition kernel): halves the HBM-bound pair aggregation's traffic
         self.z16 = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
         self.zbuf = e(B, L, L, 64, dt=torch.float16 if self.z16 else torch.float32)
+        self.edge16 = e(B, L, L, 64, dt=torch.float16) if self.z16 else None    # f16 copy of the caller's edge embedding (bind_context)
         self.pair_bias = e(B, 8, L, L)          # sqrt(1/3)(W_b z + b_b) of the next IPA block (head-major), written by EdgeTransition
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
@@ -302,6 +303,8 @@ class DenoiseEngine:
         _capi.dptr(ee, name="edge_embed")
         rebuild = self.plan is None or self.edge_embed is None or self.edge_embed.data_ptr() != ee.data_ptr()
         self.edge_embed = ee
+        if self.z16:                            # one conversion per call (the reference re-reads the fp32 tensor in every step)
+            self.edge16.copy_(ee.reshape(B, L, L, 64))
         _capi.check(self.lib.pf_pair_bias_fwd(ee.data_ptr(), self.w["0.linear_b.w"].data_ptr(), self.w["0.linear_b.b"].data_ptr(),
                                               self.pair_bias0.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
         if rebuild:
@@ -358,7 +361,7 @@ class DenoiseEngine:
         for b in range(N_BLOCKS):
             rot = self.rot_t if b == 0 else self.rot
             trans = self.trans_t if b == 0 else self.trans
-            z_in = self.edge_embed if b == 0 else self.zbuf
+            z_in = (self.edge16 if self.z16 else self.edge_embed) if b == 0 else self.zbuf
             ia = _capi.IpaAttnArgs()
             ia.proj, ia.ldp = self.proj.data_ptr(), 3744
             ia.qp, ia.kp, ia.vp = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr()
@@ -369,7 +372,7 @@ class DenoiseEngine:
             ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
             ia.p_out = self.attn_p.data_ptr()
             ia.key_end = self.key_end.data_ptr()
-            ia.z_f16 = int(self.z16 and b > 0)
+            ia.z_f16 = int(self.z16)
             if self.att_planes:
                 ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
             self._keep.append(ia)
@@ -439,7 +442,7 @@ class DenoiseEngine:
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")
                 et.tile_list, et.n_tiles = self.et_tiles.data_ptr(), self.et_ntiles.data_ptr()
-                et.z_in_f16, et.z_out_f16 = int(self.z16 and b > 0), int(self.z16)
+                et.z_in_f16, et.z_out_f16 = int(self.z16), int(self.z16)
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
                 plan.append((None, None, "join", 0))
