@@ -5,6 +5,7 @@
                                  Biopython, which this environment does not have)
   * export_samples            -- sample.py:96-120: full-atom reconstruction (HIP) + one PDB per sample + gt.pdb
   * export_samples_bb         -- sample.py:68-94: backbone-only reconstruction (HIP) + one PDB per sample + gt.pdb
+  * PepDataset                -- models_con/pep_dataloader.py:87-196: the LMDB structure cache as a dataset (read side)
 """
 import math
 import os
@@ -49,6 +50,37 @@ class PaddingCollate:
             d["res_mask"] = torch.arange(n) < ln
             out.append(d)
         return default_collate(out)
+
+
+class PepDataset:
+    """Read side of the reference's dataset (pep_dataloader.py:87-196): `<dataset_dir>/<name>_structure_cache.lmdb`, one entry per
+    complex (key = id, value = pickled dict of tensors / lists as `preprocess_structure` wrote it); `ids` in key order, `__getitem__`
+    unpickles and applies `transform`.  The cache is read with `pepflowww_amd.lmdb_reader` (pure Python: no `lmdb` module here --
+    see its header for what that means for format parity).  Building the cache from PDB files (`_preprocess_structures`,
+    Biopython + joblib) is not provided: a missing cache raises."""
+
+    def __init__(self, structure_dir=None, dataset_dir="./Data/", name="pep", transform=None, reset=False):
+        from .lmdb_reader import LmdbReader
+        if reset:
+            raise NotImplementedError("rebuilding the structure cache from PDB files is not part of this package")
+        self.structure_dir, self.dataset_dir, self.name, self.transform = structure_dir, dataset_dir, name, transform
+        path = os.path.join(dataset_dir, f"{name}_structure_cache.lmdb")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: structure cache not found (it is written by the reference's preprocessing)")
+        self._db = LmdbReader(path)
+        self.db_ids = [k.decode() for k in self._db.keys()]
+
+    def __len__(self):
+        return len(self.db_ids)
+
+    def __getitem__(self, index):
+        import pickle
+        raw = self._db.get(self.db_ids[index].encode())
+        data = pickle.loads(raw)
+        return self.transform(data) if self.transform is not None else data
+
+    def close(self):
+        self._db.close()
 
 
 def save_trajectory(final_step, batch, path):

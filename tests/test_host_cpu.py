@@ -149,3 +149,65 @@ def test_pdb_writer_matches_expected_text(tmp_path, golden_dir):
     p = tmp_path / "y.pdb"
     write_pdb(data, str(p))
     assert p.read_text() == open(os.path.join(golden_dir, "f10_pdb_expected.pdb")).read()
+
+
+# ------------------------------------------------------------------ LMDB structure cache (read side)
+def _lmdb_items():
+    import pickle
+    items = {}
+    g = torch.Generator().manual_seed(5)
+    for i in range(260):                               # several leaf pages + a branch level
+        n = 5 + i % 7
+        items[f"{i:04d}_pdb".encode()] = pickle.dumps({"id": f"{i:04d}_pdb", "aa": torch.randint(0, 20, (n,), generator=g),
+                                                      "pos_heavyatom": torch.randn(n, 15, 3, generator=g)})
+    items[b"big_one"] = pickle.dumps({"id": "big_one", "aa": torch.arange(300), "pos_heavyatom": torch.randn(300, 15, 3, generator=g)})
+    items[b"a"] = b"x"                                 # tiny value, smallest key
+    items[b"zzzz_last"] = bytes(range(256)) * 40       # 10 KiB: overflow run of three pages
+    return items
+
+
+def test_lmdb_reader_walks_leaf_branch_and_overflow_pages(tmp_path):
+    from pepflowww_amd.lmdb_reader import LmdbReader, LmdbFormatError
+    from lmdb_fixture import write_lmdb
+    items = _lmdb_items()
+    path = str(tmp_path / "t.lmdb")
+    write_lmdb(path, items)
+    with LmdbReader(path) as db:
+        assert len(db) == len(items) and db.page_size == 4096
+        assert db.keys() == sorted(items)              # key order = memcmp order
+        for k, v in items.items():
+            assert db.get(k) == v
+        assert db.get(b"missing") is None and db.get(b"0000") is None and db.get(b"zzzzz") is None
+        assert dict(db.items()) == items
+    # a three-level tree (tiny pages), an empty database, and a file that is not LMDB
+    write_lmdb(path, items, psize=512)
+    with LmdbReader(path) as db:
+        assert db.keys() == sorted(items) and db.get(b"zzzz_last") == items[b"zzzz_last"] and db.get(b"0100_pdb") == items[b"0100_pdb"]
+    write_lmdb(path, {})
+    with LmdbReader(path) as db:
+        assert len(db) == 0 and db.keys() == [] and db.get(b"a") is None
+    with open(path, "wb") as f:
+        f.write(b"\0" * 8192)
+    with pytest.raises(LmdbFormatError):
+        LmdbReader(path)
+
+
+def test_pep_dataset_reads_the_structure_cache(tmp_path):
+    """pep_dataloader.py:87-196 read side: ids in key order, items unpickled, transform applied, collate-able."""
+    import pickle
+    from pepflowww_amd.io import PepDataset, PaddingCollate
+    from lmdb_fixture import write_lmdb
+    items = {k: v for k, v in _lmdb_items().items() if k.endswith(b"_pdb") or k == b"big_one"}
+    write_lmdb(str(tmp_path / "pep_structure_cache.lmdb"), items)
+    ds = PepDataset(dataset_dir=str(tmp_path), name="pep")
+    assert len(ds) == len(items) and ds.db_ids == sorted(k.decode() for k in items)
+    d = ds[3]
+    ref = pickle.loads(items[ds.db_ids[3].encode()])
+    assert d["id"] == ref["id"] and torch.equal(d["aa"], ref["aa"]) and torch.equal(d["pos_heavyatom"], ref["pos_heavyatom"])
+    assert ds[len(ds) - 1]["id"] == "big_one" and ds[len(ds) - 1]["aa"].shape == (300,)
+    ds2 = PepDataset(dataset_dir=str(tmp_path), name="pep", transform=lambda x: {**x, "n": x["aa"].numel()})
+    assert ds2[0]["n"] == ds2[0]["aa"].numel()
+    batch = PaddingCollate(eight=True)([{k: v for k, v in ds[i].items() if k != "id"} for i in range(4)])
+    assert batch["aa"].shape[0] == 4 and batch["aa"].shape[1] % 8 == 0 and batch["res_mask"].dtype == torch.bool
+    with pytest.raises(FileNotFoundError):
+        PepDataset(dataset_dir=str(tmp_path), name="absent")
