@@ -7,22 +7,23 @@
 // machine mapping, built around what the PMC counters showed for the tiled kernel (waves parked 67 % of their time
 // at barriers / load latencies between three short GEMM phases, 260 KB of weights re-streamed from L2 per 64 pairs,
 // 2 KB of per-residue gathers per pair):
-//   * one PERSISTENT workgroup per CU: 8 consumer waves + 1 loader wave, tiles of 8 rows i x 16 columns j
-//     (consumer wave w <-> row i0 + w, lane & 15 <-> column j0 + r);
-//   * a consumer keeps every activation of its 16 pairs in REGISTERS for the whole tile: the MFMA result layout
+//   * one PERSISTENT workgroup per CU: 8 consumer waves + a weight-loader wave + an input-loader wave; tiles of (8 NP) rows i x
+//     16 columns j (consumer wave w <-> rows i0 + NP w + p, lane & 15 <-> column j0 + r; NP = 1, or 2 in the f16 mode);
+//   * a consumer keeps every activation of its 16 NP pairs in REGISTERS for the whole tile: the MFMA result layout
 //     (4 consecutive features of one pair per lane) is directly the B-operand layout of the next GEMM under a
 //     fixed permutation of its K index, so the host packs W2 / Wf with that permutation and the activations never
 //     touch LDS -- no inter-GEMM barriers, no LDS round trip;
-//   * the 256 KB weight set is a linear stream of 128 fragment pairs (hi|lo, 2 KB each) in exactly the order the
-//     consumers use them; the loader wave pushes it through a 3-slot x 32 KB LDS ring with LDS-DMA
-//     (global_load_lds: no VGPRs, no ds_write), one s_barrier per 32 KB stage, two stages of run-ahead; each weight
-//     byte leaves L2 once per 128 pairs and is read by the 8 consumers as conflict-free 1 KiB ds_read_b128 fragments;
-//   * the loader also DMAs the NEXT tile's z rows (32 KB, source-swizzled so the fragment reads are conflict-free),
-//     its 8 a|d and 16 c|e rows of `pre` (2-D tile: 24 KB instead of 128 KB of gathers) and its masks while the
-//     consumers compute: a consumer issues NO global load at all, only its 4 output stores per tile;
-//   * GEMM2 -> GEMM3 are fused per 32-feature chunk (h2 never exists as a whole): < 168 VGPRs, 9 waves per CU;
-//   * loader and consumers use disjoint memory paths (LDS-DMA vs ds_read / stores), so neither side's s_waitcnt
-//     drains the other's queue (vmcnt is per wave).
+//   * the 256 KB weight set is a linear stream of 128 fragment pairs (hi|lo, 2 KB each; lo UNSCALED, see mac2) in exactly the
+//     order the consumers use them; the weight loader pushes it through a 3-slot LDS ring with LDS-DMA (global_load_lds: no
+//     VGPRs, no ds_write; scalar base + lane offset addressing), one s_barrier per stage, two stages of run-ahead; each weight
+//     byte leaves L2 once per tile and is read by the 8 consumers as conflict-free 1 KiB ds_read_b128 fragments;
+//   * the input loader DMAs the NEXT tile's z rows (source-swizzled so the fragment reads are conflict-free; fp32, or f16 rows
+//     that ARE the MFMA operand in the f16 mode), its a|d and c|e rows of `pre` (2-D tile instead of per-pair gathers) and its
+//     masks while the consumers compute: a consumer issues NO global load at all, only its output stores;
+//   * GEMM2 -> GEMM3 are fused per 32-feature chunk (h2 never exists as a whole): <= 168 VGPRs, 10 waves per CU;
+//   * loaders and consumers use disjoint memory paths (LDS-DMA vs ds_read / stores), and weights and inputs separate waves, so
+//     nobody's s_waitcnt drains somebody else's queue (vmcnt is per wave and completes in order);
+//   * optional work list (tile_list / n_tiles): tiles without an unmasked pair are skipped.
 #include <cstdlib>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
