@@ -464,6 +464,50 @@ def test_ipa_key_end_through_the_c_abi(seeded_sd):
     assert torch.isnan(skipped[beyond]).all() and not torch.isnan(dense[beyond]).any()
 
 
+@pytest.mark.parametrize("M", [8192, 8192 + 256 * 32 - 5])
+def test_linear_rows_persistent_projection(M):
+    """pf_linear_fwd's rows-persistent kernel (K = 128, wide N, whole rounds of 256 workgroups): plain columns vs a float64
+    product, point columns (x, y, z, 0) through the residue frames vs R p + t, ragged last row tile; and the tiled kernel on the
+    same inputs (M - 64 rows) agrees with it."""
+    g = torch.Generator().manual_seed(M)
+    N, K, C0 = 3968, 128, 3072
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    q = torch.randn(M, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True)).reshape(M, 9)
+    T = torch.randn(M, 3, generator=g) * 10
+    import ctypes as C
+    from pepflowww_amd.engine import split_f16
+    lib = _capi.load()
+
+    def run(rows):
+        y = torch.full((rows, C0), float("nan"), device=G.dev())
+        qp, kp, vp = (torch.full((rows, n), float("nan"), device=G.dev()) for n in (192, 192, 288))
+        a = _capi.LinearArgs()
+        xs, ws, bs, Rs, Ts, w16 = cu(x[:rows]), cu(w), cu(b), cu(R[:rows]), cu(T[:rows]), split_f16(cu(w))
+        a.x, a.ldx, a.w, a.ldw, a.bias = G._p(xs), K, G._p(ws), K, G._p(bs)
+        a.y, a.ldy, a.M, a.N, a.K = G._p(y), C0, rows, N, K
+        a.w_f16 = G._p(w16)
+        a.pt_rot, a.pt_trans, a.pt_qp, a.pt_kp, a.pt_vp, a.pt_col0 = G._p(Rs), G._p(Ts), G._p(qp), G._p(kp), G._p(vp), C0
+        _capi.check(lib.pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
+        G.sync()
+        return y.cpu(), qp.cpu(), kp.cpu(), vp.cpu()
+
+    y, qp, kp, vp = run(M)
+    ref = (x.double() @ w.double().t() + b.double())
+    G.assert_close(y, ref[:, :C0].float(), 2e-6, "plain columns")
+    pts = ref[:, C0:].reshape(M, 224, 4)[..., :3]                            # packed (x, y, z, 0)
+    glob = (torch.einsum("mij,mpj->mpi", R.reshape(M, 3, 3).double(), pts) + T.double()[:, None, :]).float()
+    G.assert_close(qp.reshape(M, 64, 3), glob[:, :64], 2e-6, "query points")
+    kv = glob[:, 64:].reshape(M, 8, 20, 3)
+    G.assert_close(kp.reshape(M, 8, 8, 3), kv[:, :, :8], 2e-6, "key points")
+    G.assert_close(vp.reshape(M, 8, 12, 3), kv[:, :, 8:], 2e-6, "value points")
+    y2, qp2, kp2, vp2 = run(M - 64)                                          # not a whole round of workgroups: tiled kernel
+    G.assert_close(y2, y[: M - 64], 1e-6, "tiled vs rows-persistent")
+    G.assert_close(vp2, vp[: M - 64], 1e-6, "tiled vs rows-persistent (points)")
+
+
 def test_encode_matches_reference(f2, model):
     b = {k: cu(v) for k, v in _batch(f2).items()}
     R1, x1, ang1, seq1, node, edge = model.encode(b)
