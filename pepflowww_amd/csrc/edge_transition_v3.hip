@@ -64,12 +64,13 @@ constexpr int CONST_F = 64 + 64 + 192 + 16;
 // NP = rows i per consumer wave: a tile is (NCW NP) rows x 16 columns, ONE weight fragment read from LDS feeds the MFMAs of
 // 16 NP pairs.  fp32-parity mode: NP = 1 (NP = 2 needs 239 VGPRs: 4 consumer waves x 32 pairs measured 427 vs 389 us).
 // f16 mode: NP = 2 (155 VGPRs) -- its stages were paced by the LDS fragment traffic (1 KiB per MFMA and wave).
-template <bool SP, int NP> struct Map {
+template <bool SP, int NP, bool ZI = false> struct Map {
     static constexpr int TI = NCW * NP;                        // rows i of a tile
-    static constexpr int NSL = SP ? (NP == 2 ? 3 : 4) : 3;     // ring slots (stage in use + NSL - 1 stages of run-ahead)
+    static constexpr int NSL = SP ? ((NP == 2 && !ZI) ? 3 : 4) : 3;   // ring slots (stage in use + NSL - 1 stages of run-ahead; 3 vs 4
+                                                                      // measured the same in the f16 mode)
     // LDS map (bytes)
-    static constexpr int OFF_Z = (SP && NP == 2) ? 3 * STG<true> : 3 * STAGE_B;   // z rows, [TI][16 pairs][256 B], chunk-swizzled
-    static constexpr int OFF_AD = OFF_Z + TI * 4096;           // [TI][a 768 B | d 256 B]
+    static constexpr int OFF_Z = SP ? NSL * STG<true> : 3 * STAGE_B;   // z rows, [TI][16 pairs][256 B (128 B: f16)], chunk-swizzled
+    static constexpr int OFF_AD = OFF_Z + TI * (ZI ? 2048 : 4096);   // [TI][a 768 B | d 256 B]
     static constexpr int OFF_CE = OFF_AD + TI * 1024;          // [16][c 768 B | e 256 B | pad 32]
     static constexpr int OFF_MK = OFF_CE + 17 * 1024;          // mask_i[TI] | mask_j[16]
     static constexpr int OFF_CS = OFF_MK + 256;                // LayerNorm gamma[64] | beta[64] | b2[192] | b_b[8] (+pad)
@@ -174,7 +175,7 @@ struct Tile { int b, i0, j0; };
 template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false>
 __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     static_assert(SP || (!ZI && !ZO), "f16 pair tensor: f16 mode only");
-    using M = Map<SP, NP>;
+    using M = Map<SP, NP, ZI>;
     constexpr int TI = M::TI, NSLr = M::NSL, OFF_Z = M::OFF_Z, OFF_AD = M::OFF_AD, OFF_CE = M::OFF_CE, OFF_MK = M::OFF_MK,
                   OFF_CS = M::OFF_CS, OFF_WB = M::OFF_WB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 // launcher used by pf_edge_transition_fwd (edge_transition.hip) when args.w_stream is set
 template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false>
 static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
-    using M = Map<SP, NP>;
+    using M = Map<SP, NP, ZI>;
     const int nib = (a->L + M::TI - 1) / M::TI, njb = (a->L + TJ - 1) / TJ;
     const long long nt = (long long)a->B * nib * njb;
     if (nt > 0x7fffffffLL || (long long)a->B * a->L > 0x7fffffffLL) return PF_E_TOOLARGE;
