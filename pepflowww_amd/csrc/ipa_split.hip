@@ -37,6 +37,7 @@ constexpr int OFF_KV = 1024;
 #endif
 constexpr int WMAX = PF_IPA_WMAX;             // waves (16-query tiles) per score workgroup
 constexpr int KPS = 28;                       // LDS row stride (floats) of a key's 24 point coordinates: 16-byte aligned rows
+constexpr int VPS = 36;                       // ... of a key's 36 value-point coordinates (fp32 score kernel)
 
 __device__ __forceinline__ float softplusf2(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int L = a.L;
     float* KP = smem;                              // [LP][KPS] key points of this head (global frame)
     float* MJ = KP + LP * KPS;                     // [LP] key mask (0 beyond L)
-    float* SW = MJ + LP;                           // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
+    float* VP = MJ + LP;                           // [LP][36] value points of this head (global frame)
+    float* SW = VP + LP * VPS;                     // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -97,6 +99,12 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = v;
     }
     for (int j = tid; j < LP; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + j] : 0.f;
+    // value points of the head -> LDS as well: read per key tile they were 12 dword loads per lane and tile in every wave (4-8 cache
+    // lines per instruction); with the value loads below they made up 25 of the kernel's 114 us (what-if build without them: 89)
+    for (int idx = tid; idx < LP * 9; idx += blockDim.x) {
+        const int j = idx / 9, q = idx - j * 9;
+        *reinterpret_cast<float4*>(VP + j * VPS + 4 * q) = *reinterpret_cast<const float4*>(a.vp + (rowb + min(j, L - 1)) * 288 + h * 36 + 4 * q);
+    }
     __syncthreads();
     if (!wave_on) return;
     PROFS(1);
@@ -185,22 +193,23 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     float* prow = a.p_out + (((size_t)b * H + h) * L + iq) * L;
 
     // ---- [o | o_pt] = P [V | V_pts]: A = P (this lane: query r, key 16 t + 4 g + tt in MFMA tt), B = value rows.
-    //      V column of (tile n, lane r) = 8 r + n: a lane's 8 operands of one key are consecutive floats (two float4 loads),
-    //      and so are its 8 outputs of a query; the 36 point coordinates use 3 more tiles (column 16 (n - 8) + r).
+    //      V column of (tile n, lane r) = 4 r + n (n < 4), 64 + 4 r + n - 4 (n = 4..7): a load instruction of the 16 lanes of a key
+    //      reads 256 contiguous bytes (with column 8 r + n the two float4 loads of a key touched every line twice); a lane's
+    //      outputs of a query are two float4.  The 36 point coordinates (LDS) use 3 more tiles (column 16 (n - 8) + r).
     //      The normalised probabilities are written out ([B,8,L,L]) on the way ----
     constexpr int NTC = 11;
-    const float* vbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + C + 8 * r;
-    const float* vpbase = a.vp + rowb * 288 + h * 36 + (r < 4 ? 32 + r : 0);
-    const float* vpb2 = a.vp + rowb * 288 + h * 36 + r;
+    const float* vbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + C + 4 * r;
+    const float* vp0 = VP + r;
+    const float* vp2 = VP + (r < 4 ? 32 + r : 0);
     auto loadv = [&](int t, float (&vb)[NTC][4]) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const size_t j = (size_t)min(16 * t + 4 * g + tt, Le - 1);
-            const float* vrow = vbase + j * a.ldp;
-            const float4 x = *reinterpret_cast<const float4*>(vrow), y = *reinterpret_cast<const float4*>(vrow + 4);
+            const int j = min(16 * t + 4 * g + tt, Le - 1);
+            const float* vrow = vbase + (size_t)j * a.ldp;
+            const float4 x = *reinterpret_cast<const float4*>(vrow), y = *reinterpret_cast<const float4*>(vrow + 64);
             vb[0][tt] = x.x; vb[1][tt] = x.y; vb[2][tt] = x.z; vb[3][tt] = x.w;
             vb[4][tt] = y.x; vb[5][tt] = y.y; vb[6][tt] = y.z; vb[7][tt] = y.w;
-            vb[8][tt] = vpb2[j * 288]; vb[9][tt] = vpb2[j * 288 + 16]; vb[10][tt] = vpbase[j * 288];   // (tile 10: columns 32..35 only)
+            vb[8][tt] = vp0[j * VPS]; vb[9][tt] = vp0[j * VPS + 16]; vb[10][tt] = vp2[j * VPS];   // (tile 10: columns 32..35 only)
         }
     };
     f32x4 O[NTC];
@@ -252,9 +261,9 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ti = 4 * g + e, i = min(i0 + ti, Le - 1);      // (duplicates of row Le - 1 store identical values)
-        float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * C + 8 * r;
+        float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * C + 4 * r;
         *reinterpret_cast<float4*>(f) = make_float4(O[0][e], O[1][e], O[2][e], O[3][e]);
-        *reinterpret_cast<float4*>(f + 4) = make_float4(O[4][e], O[5][e], O[6][e], O[7][e]);
+        *reinterpret_cast<float4*>(f + 64) = make_float4(O[4][e], O[5][e], O[6][e], O[7][e]);
         opt[ti * 36 + r] = O[8][e];
         opt[ti * 36 + 16 + r] = O[9][e];
         if (r < 4) opt[ti * 36 + 32 + r] = O[10][e];
@@ -684,7 +693,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         const int LP = (L + 15) & ~15, SLD = LP + 4 < 36 ? 36 : LP + 4;   // (the region later holds the wave's [16][36] o_pt)
         const int tiles = LP >> 4;                               // 16-row query tiles
         // waves (query tiles) per workgroup: <= 8, and the score regions must fit the 160 KiB LDS next to the key points
-        const size_t fixed = ((size_t)LP * KPS + LP) * sizeof(float), per_wave = (size_t)16 * SLD * sizeof(float);
+        const size_t fixed = ((size_t)LP * KPS + LP + (size_t)LP * VPS) * sizeof(float), per_wave = (size_t)16 * SLD * sizeof(float);
         int wmax = (int)((160 * 1024 - fixed) / per_wave);
         wmax = wmax > WMAX ? WMAX : wmax;
         if (wmax < 1) return PF_E_TOOLARGE;
