@@ -320,15 +320,19 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_h
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool LAST, bool SP>
+// RT: 16-row tiles per workgroup.  RT = 2 when the 16-row form would need more than one round of workgroups (B * ceil(L / 16) >
+// 256 CUs; these kernels are one workgroup per CU): every weight fragment and every K / V operand then feeds two row tiles, and
+// the chain of ~13 dependent stages is walked once per 32 rows instead of twice in a row.
+template <bool LAST, bool SP, int RT>
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfmr_args a, int LP, int LDS_S) {
+    constexpr int TR = 16 * RT;             // rows per workgroup (shadows the file-level 16)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* T0 = smem;                       // [16][LDX] fp32
+    float* T0 = smem;                       // [TR][LDX] fp32
     float* T1 = T0 + TR * LDX;
-    float* U = T1 + TR * LDX;               // [16][8] backbone update
+    float* U = T1 + TR * LDX;               // [TR][8] backbone update
     _Float16* pl = reinterpret_cast<_Float16*>(U + TR * 8);
     Planes Xa = {pl, pl + TR * LDP}, Xb = {pl + 2 * TR * LDP, pl + 3 * TR * LDP};
-    float* S = reinterpret_cast<float*>(pl + 4 * TR * LDP);   // [16][4][LDS_S] attention scores / probabilities
+    float* S = reinterpret_cast<float*>(pl + 4 * TR * LDP);   // [TR][4][LDS_S] attention scores / probabilities
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
@@ -340,17 +344,20 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     const int m0 = (int)rowb + i0;           // global row of tile row 0
     const int M = (int)rowb + L;             // rows of this sample end here (tile rows beyond are padding)
     const int n = wave * 16 + 4 * g;         // this lane's 4 consecutive output features in the 128-wide stages
-    const int mr = m0 + r;                   // ... of this activation row
+    int mr[RT];                              // ... of these activation rows (row tile rt, tile row r)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) mr[rt] = m0 + 16 * rt + r;
 
     PROF(0);
     // ---- everything small is requested NOW ----
     const int h = wave & 3;
-    float4 q0, q1;
-    {
-        const int i = i0 + r;
+    float4 q0[RT], q1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int i = i0 + 16 * rt + r;
         const float* qrow = a.qkv + (rowb + (i < L ? i : 0)) * 384 + h * 32 + 4 * g;
-        q0 = *reinterpret_cast<const float4*>(qrow);
-        q1 = *reinterpret_cast<const float4*>(qrow + 16);
+        q0[rt] = *reinterpret_cast<const float4*>(qrow);
+        q1[rt] = *reinterpret_cast<const float4*>(qrow + 16);
     }
     // q, then the K rows of this wave's first TWO key blocks (all of them for L <= 128), then the V operands of the first two PV
     // blocks: requested before everything else and in THIS order (the compiler otherwise sinks the q / K loads below ~50 weight
@@ -401,14 +408,18 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                  bias_2 = *reinterpret_cast<const float4*>(a.b_2 + n);
     float4 bias_post = z4, bias_t1 = z4, bias_t2 = z4, bias_t3 = z4, bias_bb = z4, bias_init = z4;
     float4 bias_in[3] = {z4, z4, z4}, bias_pre[4] = {z4, z4, z4, z4};
-    const int mrc = mr < M ? mr : M - 1;
     // (loaded raw; the out-of-range select is applied at the use -- a multiply here makes the wave wait for the load here)
-    const float4 rres_ld = *reinterpret_cast<const float4*>(a.resid + (size_t)mrc * 128 + n);
-    float4 rsipa_ld = z4;
+    float4 rres_ld[RT], rsipa_ld[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int mrc = mr[rt] < M ? mr[rt] : M - 1;
+        rres_ld[rt] = *reinterpret_cast<const float4*>(a.resid + (size_t)mrc * 128 + n);
+        rsipa_ld[rt] = LAST ? *reinterpret_cast<const float4*>(a.s_ipa + (size_t)mrc * 128 + n) : z4;
+    }
     float lnmask_ld = 1.f;                    // row mask of the LayerNorm lane's row (tail LayerNorm only)
-    const int lnrow = m0 + ((tid & 255) >> 4);
-    if (LAST) {
-        rsipa_ld = *reinterpret_cast<const float4*>(a.s_ipa + (size_t)mrc * 128 + n);
+    const int lnrow = m0 + ((tid & (16 * TR - 1)) >> 4);
+    // (RT = 2: requested after the attention core instead, where the K / V operand registers are free again -- 23 spills otherwise)
+    auto load_tail_consts = [&]() {
         bias_post = *reinterpret_cast<const float4*>(a.b_post + n);
         bias_t1 = *reinterpret_cast<const float4*>(a.b_t1 + n);
         bias_t2 = *reinterpret_cast<const float4*>(a.b_t2 + n);
@@ -422,6 +433,9 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             for (int wt = 0; wt < 4; ++wt) bias_pre[wt] = *reinterpret_cast<const float4*>(a.b_pre + wave * 64 + wt * 16 + 4 * g);
         }
         lnmask_ld = a.mask[lnrow < M ? lnrow : M - 1];
+    };
+    if (LAST) {
+        if (RT == 1) load_tail_consts();
     } else {
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) bias_in[wt] = *reinterpret_cast<const float4*>(a.b_in_next + wave * 48 + wt * 16 + 4 * g);
@@ -436,12 +450,15 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             for (int t = 0; t < 2; ++t) {
                 const int j = j0 + 32 * t + r;
                 if (j0 + 32 * t < LP) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma16(q0.x, k0[t].x, acc); acc = mfma16(q0.y, k0[t].y, acc); acc = mfma16(q0.z, k0[t].z, acc); acc = mfma16(q0.w, k0[t].w, acc);
-                    acc = mfma16(q1.x, k1[t].x, acc); acc = mfma16(q1.y, k1[t].y, acc); acc = mfma16(q1.z, k1[t].z, acc); acc = mfma16(q1.w, k1[t].w, acc);
                     const bool keep = j < L && km[t] > 0.5f;       // key padding mask
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) S[((4 * g + e) * 4 + h) * LDS_S + j] = keep ? acc[e] * scale : -3.0e38f;
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = mfma16(q0[rt].x, k0[t].x, acc); acc = mfma16(q0[rt].y, k0[t].y, acc); acc = mfma16(q0[rt].z, k0[t].z, acc); acc = mfma16(q0[rt].w, k0[t].w, acc);
+                        acc = mfma16(q1[rt].x, k1[t].x, acc); acc = mfma16(q1[rt].y, k1[t].y, acc); acc = mfma16(q1[rt].z, k1[t].z, acc); acc = mfma16(q1[rt].w, k1[t].w, acc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) S[((16 * rt + 4 * g + e) * 4 + h) * LDS_S + j] = keep ? acc[e] * scale : -3.0e38f;
+                    }
                 }
             }
         };
@@ -456,11 +473,12 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     }
     __syncthreads();
     PROF(2);
-    // softmax: the 64 (ti,h) rows, 8 rows per wave at once, 8 lanes per row.  A lane's share of the row (float4 groups 8 apart)
+    // softmax: the 64 RT (ti,h) rows, 8 rows per wave at once, 8 lanes per row.  A lane's share of the row (float4 groups 8 apart)
     // is read into registers in one go: three dependent LDS round trips per element (max, exp + sum, scale) cost 7 k cycles.
-    {
+#pragma unroll
+    for (int ps = 0; ps < RT; ++ps) {
         const int sub = lane & 7;
-        float* sp = S + (wave * 8 + (lane >> 3)) * LDS_S;
+        float* sp = S + ((ps * 8 + wave) * 8 + (lane >> 3)) * LDS_S;
         if (LP <= 256) {
             float4 v[8];
 #pragma unroll
@@ -501,15 +519,20 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     PROF(3);
     // ---- P V (fp32 MFMA): wave -> head h = w&3, 16-column tile ct = w>>2 of the head's 32 dims -> planes Xa ----
     {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* prow = S + (r * 4 + h) * LDS_S + 4 * g;
         auto pv_block = [&](int k0, const float (&vb)[4][4]) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (k0 + 16 * s4 < LP) {
-                    const float4 pa = *reinterpret_cast<const float4*>(prow + k0 + 16 * s4);
-                    acc = mfma16(pa.x, vb[s4][0], acc); acc = mfma16(pa.y, vb[s4][1], acc);
-                    acc = mfma16(pa.z, vb[s4][2], acc); acc = mfma16(pa.w, vb[s4][3], acc);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float4 pa = *reinterpret_cast<const float4*>(prow + rt * 64 * LDS_S + k0 + 16 * s4);
+                        acc[rt] = mfma16(pa.x, vb[s4][0], acc[rt]); acc[rt] = mfma16(pa.y, vb[s4][1], acc[rt]);
+                        acc[rt] = mfma16(pa.z, vb[s4][2], acc[rt]); acc[rt] = mfma16(pa.w, vb[s4][3], acc[rt]);
+                    }
                 }
             }
         };
@@ -522,82 +545,105 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         }
         const int col = h * 32 + ct * 16 + r;             // standard D layout: rows 4g+e, column r
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const _Float16 hi = (_Float16)acc[e];
-            Xa.h[(4 * g + e) * LDP + col] = hi;
-            Xa.l[(4 * g + e) * LDP + col] = (_Float16)((acc[e] - (float)hi) * PF_LO_SCALE);
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 hi = (_Float16)acc[rt][e];
+                Xa.h[(16 * rt + 4 * g + e) * LDP + col] = hi;
+                Xa.l[(16 * rt + 4 * g + e) * LDP + col] = (_Float16)((acc[rt][e] - (float)hi) * PF_LO_SCALE);
+            }
     }
+    if (LAST && RT == 2) load_tail_consts();
     __syncthreads();
     PROF(4);
 
-    f32x4 am[1], ac[1];
+    f32x4 am[RT][1], ac[RT][1];
+    auto zero = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc_zero1<1>(am[rt], ac[rt]);
+    };
+    // v[e] = am/ac of row tile rt joined + bias
+    auto joined = [&](int rt, const float4& bias, float (&v)[4]) {
+        v[0] = join(am[rt][0], ac[rt][0], 0) + bias.x; v[1] = join(am[rt][0], ac[rt][0], 1) + bias.y;
+        v[2] = join(am[rt][0], ac[rt][0], 2) + bias.z; v[3] = join(am[rt][0], ac[rt][0], 3) + bias.w;
+    };
+    auto relu4 = [](float (&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    };
     // ---- out_proj + residual -> T1 (fp32) ; LN1 -> u: T1 + planes Xb ----
-    acc_zero1<1>(am, ac);
-    gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+    zero();
+    gemm_split16r<1, 4, SP, RT>(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
     ws.init(a.w_1_f16, 128, 128, wave * 16);
     ws.prefetch();
-    {
-        const float4 rres = sel4(mr < M, rres_ld);
-        *reinterpret_cast<float4*>(T1 + r * LDX + n) =
-            make_float4(join(am[0], ac[0], 0) + bias_o.x + rres.x, join(am[0], ac[0], 1) + bias_o.y + rres.y,
-                        join(am[0], ac[0], 2) + bias_o.z + rres.z, join(am[0], ac[0], 3) + bias_o.w + rres.w);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const float4 rres = sel4(mr[rt] < M, rres_ld[rt]);
+        float v[4];
+        joined(rt, bias_o, v);
+        *reinterpret_cast<float4*>(T1 + (16 * rt + r) * LDX + n) = make_float4(v[0] + rres.x, v[1] + rres.y, v[2] + rres.z, v[3] + rres.w);
     }
     __syncthreads();
-    ln_tile(T1, ln1, 1.f, Xb, m0, M, nullptr);
+    ln_tile<TR>(T1, ln1, 1.f, Xb, m0, M, nullptr);
     __syncthreads();
     PROF(5);
     // ---- linear1 + ReLU -> planes Xa ----
-    acc_zero1<1>(am, ac);
-    gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
+    zero();
+    gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
     ws.init(a.w_2_f16, 128, 128, wave * 16);
     ws.prefetch();
-    {
-        const float v[4] = {fmaxf(join(am[0], ac[0], 0) + bias_1.x, 0.f), fmaxf(join(am[0], ac[0], 1) + bias_1.y, 0.f),
-                            fmaxf(join(am[0], ac[0], 2) + bias_1.z, 0.f), fmaxf(join(am[0], ac[0], 3) + bias_1.w, 0.f)};
-        put_planes(Xa, r, n, v);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float v[4];
+        joined(rt, bias_1, v);
+        relu4(v);
+        put_planes(Xa, 16 * rt + r, n, v);
     }
     __syncthreads();
     PROF(6);
     // ---- linear2 + residual (u = T1) -> T0 ; LN2 -> v: planes Xb (+ global v_out) ----
-    acc_zero1<1>(am, ac);
-    gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+    zero();
+    gemm_split16r<1, 4, SP, RT>(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+    // T0 = linear2 + bias + u
+    auto lin2_to_t0 = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float4 u = *reinterpret_cast<const float4*>(T1 + (16 * rt + r) * LDX + n);
+            float v[4];
+            joined(rt, bias_2, v);
+            *reinterpret_cast<float4*>(T0 + (16 * rt + r) * LDX + n) = make_float4(v[0] + u.x, v[1] + u.y, v[2] + u.z, v[3] + u.w);
+        }
+    };
     if constexpr (!LAST) {
         WSplit<3, 4, SP> wq;
         wq.init(a.w_in_next_f16, 384, 128, wave * 48);
         wq.prefetch();
-        {
-            const float4 u = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
-            *reinterpret_cast<float4*>(T0 + r * LDX + n) =
-                make_float4(join(am[0], ac[0], 0) + bias_2.x + u.x, join(am[0], ac[0], 1) + bias_2.y + u.y,
-                            join(am[0], ac[0], 2) + bias_2.z + u.z, join(am[0], ac[0], 3) + bias_2.w + u.w);
-        }
+        lin2_to_t0();
         __syncthreads();
-        ln_tile(T0, ln2, 1.f, Xb, m0, M, a.v_out);
+        ln_tile<TR>(T0, ln2, 1.f, Xb, m0, M, a.v_out);
         __syncthreads();
         PROF(7);
-        f32x4 qm[3], qc[3];
-        acc_zero1<3>(qm, qc);
-        gemm_split16(wq, Xb.h, Xb.l, LDP, qm, qc, 0, 4);
-        if (mr < M) {
+        f32x4 qm[RT][3], qc[RT][3];
 #pragma unroll
-            for (int wt = 0; wt < 3; ++wt) {
-                float4 y;
-                y.x = join(qm[wt], qc[wt], 0) + bias_in[wt].x; y.y = join(qm[wt], qc[wt], 1) + bias_in[wt].y;
-                y.z = join(qm[wt], qc[wt], 2) + bias_in[wt].z; y.w = join(qm[wt], qc[wt], 3) + bias_in[wt].w;
-                *reinterpret_cast<float4*>(a.qkv_out + (size_t)mr * 384 + wave * 48 + wt * 16 + 4 * g) = y;
+        for (int rt = 0; rt < RT; ++rt) acc_zero1<3>(qm[rt], qc[rt]);
+        gemm_split16r<3, 4, SP, RT>(wq, Xb.h, Xb.l, LDP, qm, qc, 0, 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (mr[rt] < M) {
+#pragma unroll
+                for (int wt = 0; wt < 3; ++wt) {
+                    float4 y;
+                    y.x = join(qm[rt][wt], qc[rt][wt], 0) + bias_in[wt].x; y.y = join(qm[rt][wt], qc[rt][wt], 1) + bias_in[wt].y;
+                    y.z = join(qm[rt][wt], qc[rt][wt], 2) + bias_in[wt].z; y.w = join(qm[rt][wt], qc[rt][wt], 3) + bias_in[wt].w;
+                    *reinterpret_cast<float4*>(a.qkv_out + (size_t)mr[rt] * 384 + wave * 48 + wt * 16 + 4 * g) = y;
+                }
             }
         }
         PROF(8);
     } else {
         ws.init(a.w_post_f16, 128, 128, wave * 16);
         ws.prefetch();
-        {
-            const float4 u = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
-            *reinterpret_cast<float4*>(T0 + r * LDX + n) =
-                make_float4(join(am[0], ac[0], 0) + bias_2.x + u.x, join(am[0], ac[0], 1) + bias_2.y + u.y,
-                            join(am[0], ac[0], 2) + bias_2.z + u.z, join(am[0], ac[0], 3) + bias_2.w + u.w);
-        }
+        lin2_to_t0();
         // frame of this row (rigid update at the very end) requested early as well
         float4 fq = make_float4(1.f, 0.f, 0.f, 0.f);
         float fR[9], fx[3], fmask = 0.f;
@@ -611,70 +657,79 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             fmask = a.mask[m];
         }
         __syncthreads();
-        ln_tile(T0, ln2, 1.f, Xb, m0, M, nullptr);
+        ln_tile<TR>(T0, ln2, 1.f, Xb, m0, M, nullptr);
         __syncthreads();
         // ---- s = s_ipa + post_tfmr(v) -> T1 (fp32) + planes Xa                 (ga.py:107) ----
-        acc_zero1<1>(am, ac);
-        gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
+        zero();
+        gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
         ws.init(a.w_t1_f16, 128, 128, wave * 16);
         ws.prefetch();
-        {
-            const float4 rsipa = sel4(mr < M, rsipa_ld);
-            const float v[4] = {join(am[0], ac[0], 0) + bias_post.x + rsipa.x, join(am[0], ac[0], 1) + bias_post.y + rsipa.y,
-                                join(am[0], ac[0], 2) + bias_post.z + rsipa.z, join(am[0], ac[0], 3) + bias_post.w + rsipa.w};
-            *reinterpret_cast<float4*>(T1 + r * LDX + n) = make_float4(v[0], v[1], v[2], v[3]);
-            put_planes(Xa, r, n, v);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float4 rsipa = sel4(mr[rt] < M, rsipa_ld[rt]);
+            float v[4];
+            joined(rt, bias_post, v);
+            v[0] += rsipa.x; v[1] += rsipa.y; v[2] += rsipa.z; v[3] += rsipa.w;
+            *reinterpret_cast<float4*>(T1 + (16 * rt + r) * LDX + n) = make_float4(v[0], v[1], v[2], v[3]);
+            put_planes(Xa, 16 * rt + r, n, v);
         }
         __syncthreads();
         // ---- StructureModuleTransition: relu(l1) -> Xb, relu(l2) -> Xa, l3 + s -> T0, LN, * mask ----
-        acc_zero1<1>(am, ac);
-        gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+        zero();
+        gemm_split16r<1, 4, SP, RT>(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
         ws.init(a.w_t2_f16, 128, 128, wave * 16);
         ws.prefetch();
-        {
-            const float v[4] = {fmaxf(join(am[0], ac[0], 0) + bias_t1.x, 0.f), fmaxf(join(am[0], ac[0], 1) + bias_t1.y, 0.f),
-                                fmaxf(join(am[0], ac[0], 2) + bias_t1.z, 0.f), fmaxf(join(am[0], ac[0], 3) + bias_t1.w, 0.f)};
-            put_planes(Xb, r, n, v);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float v[4];
+            joined(rt, bias_t1, v);
+            relu4(v);
+            put_planes(Xb, 16 * rt + r, n, v);
         }
         __syncthreads();
-        acc_zero1<1>(am, ac);
-        gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
+        zero();
+        gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
         ws.init(a.w_t3_f16, 128, 128, wave * 16);
         ws.prefetch();
-        {
-            const float v[4] = {fmaxf(join(am[0], ac[0], 0) + bias_t2.x, 0.f), fmaxf(join(am[0], ac[0], 1) + bias_t2.y, 0.f),
-                                fmaxf(join(am[0], ac[0], 2) + bias_t2.z, 0.f), fmaxf(join(am[0], ac[0], 3) + bias_t2.w, 0.f)};
-            put_planes(Xa, r, n, v);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float v[4];
+            joined(rt, bias_t2, v);
+            relu4(v);
+            put_planes(Xa, 16 * rt + r, n, v);
         }
         __syncthreads();
-        acc_zero1<1>(am, ac);
-        gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+        zero();
+        gemm_split16r<1, 4, SP, RT>(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
         // next stage streams: wave 0 -> backbone update (6 outputs), waves 4..7 -> EdgeTransition initial_embed (64)
         const bool do_bb = wave == 0, do_init = a.has_et && wave >= 4;
         if (do_bb) { ws.init(a.w_bb_f16, 16, 128, 0); ws.prefetch(); }
         else if (do_init) { ws.init(a.w_init_f16, 64, 128, (wave - 4) * 16); ws.prefetch(); }
         WSplit<4, 2, SP> wp;
         if (a.has_et) { wp.init(a.w_pre_f16, PF_ET_PRE, 64, wave * 64); wp.prefetch(); }
-        {
-            const float4 s0 = *reinterpret_cast<const float4*>(T1 + r * LDX + n);
-            *reinterpret_cast<float4*>(T0 + r * LDX + n) =
-                make_float4(join(am[0], ac[0], 0) + bias_t3.x + s0.x, join(am[0], ac[0], 1) + bias_t3.y + s0.y,
-                            join(am[0], ac[0], 2) + bias_t3.z + s0.z, join(am[0], ac[0], 3) + bias_t3.w + s0.w);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float4 s0 = *reinterpret_cast<const float4*>(T1 + (16 * rt + r) * LDX + n);
+            float v[4];
+            joined(rt, bias_t3, v);
+            *reinterpret_cast<float4*>(T0 + (16 * rt + r) * LDX + n) = make_float4(v[0] + s0.x, v[1] + s0.y, v[2] + s0.z, v[3] + s0.w);
         }
         __syncthreads();
-        ln_tile(T0, ln3, lnmask_ld * (lnrow < M ? 1.f : 0.f), Xb, m0, M, a.s_out);               // s_new (masked) -> global + planes Xb
+        ln_tile<TR>(T0, ln3, lnmask_ld * (lnrow < M ? 1.f : 0.f), Xb, m0, M, a.s_out);           // s_new (masked) -> global + planes Xb
         __syncthreads();
         if (do_bb || do_init) {
-            acc_zero1<1>(am, ac);
-            gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
-            const float v[4] = {join(am[0], ac[0], 0), join(am[0], ac[0], 1), join(am[0], ac[0], 2), join(am[0], ac[0], 3)};
-            if (do_bb) {
-                if (g < 2)
-                    *reinterpret_cast<float4*>(U + r * 8 + 4 * g) =
-                        make_float4(v[0] + bias_bb.x, v[1] + bias_bb.y, v[2] + bias_bb.z, v[3] + bias_bb.w);
-            } else {
-                const float w[4] = {v[0] + bias_init.x, v[1] + bias_init.y, v[2] + bias_init.z, v[3] + bias_init.w};
-                put_planes(Xa, r, (wave - 4) * 16 + 4 * g, w);      // n64 -> planes Xa columns 0..63
+            zero();
+            gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float v[4];
+                if (do_bb) {
+                    joined(rt, bias_bb, v);
+                    if (g < 2) *reinterpret_cast<float4*>(U + (16 * rt + r) * 8 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    joined(rt, bias_init, v);
+                    put_planes(Xa, 16 * rt + r, (wave - 4) * 16 + 4 * g, v);      // n64 -> planes Xa columns 0..63
+                }
             }
         }
         __syncthreads();
@@ -692,16 +747,20 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         }
         // ---- EdgeTransition per-residue terms pre[rows,512] = W_pre n64 + b_pre  (K = 64) ----
         if (a.has_et) {
-            f32x4 pm[4], pc[4];
-            acc_zero1<4>(pm, pc);
-            gemm_split16(wp, Xa.h, Xa.l, LDP, pm, pc, 0, 2);
-            if (mr < M) {
+            f32x4 pm[RT][4], pc[RT][4];
 #pragma unroll
-                for (int wt = 0; wt < 4; ++wt) {
-                    float4 y;
-                    y.x = join(pm[wt], pc[wt], 0) + bias_pre[wt].x; y.y = join(pm[wt], pc[wt], 1) + bias_pre[wt].y;
-                    y.z = join(pm[wt], pc[wt], 2) + bias_pre[wt].z; y.w = join(pm[wt], pc[wt], 3) + bias_pre[wt].w;
-                    *reinterpret_cast<float4*>(a.pre + (size_t)mr * PF_ET_PRE + wave * 64 + wt * 16 + 4 * g) = y;
+            for (int rt = 0; rt < RT; ++rt) acc_zero1<4>(pm[rt], pc[rt]);
+            gemm_split16r<4, 2, SP, RT>(wp, Xa.h, Xa.l, LDP, pm, pc, 0, 2);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if (mr[rt] < M) {
+#pragma unroll
+                    for (int wt = 0; wt < 4; ++wt) {
+                        float4 y;
+                        y.x = join(pm[rt][wt], pc[rt][wt], 0) + bias_pre[wt].x; y.y = join(pm[rt][wt], pc[rt][wt], 1) + bias_pre[wt].y;
+                        y.z = join(pm[rt][wt], pc[rt][wt], 2) + bias_pre[wt].z; y.w = join(pm[rt][wt], pc[rt][wt], 3) + bias_pre[wt].w;
+                        *reinterpret_cast<float4*>(a.pre + (size_t)mr[rt] * PF_ET_PRE + wave * 64 + wt * 16 + 4 * g) = y;
+                    }
                 }
             }
         } else if (a.logits_out) {
@@ -714,36 +773,43 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                 ws.init(a.h_w[net][0], 128, 128, wave * 16);
                 ws.prefetch();
                 const float4 hb0 = *reinterpret_cast<const float4*>(a.h_b[net][0] + n), hb1 = *reinterpret_cast<const float4*>(a.h_b[net][1] + n);
-                acc_zero1<1>(am, ac);
-                gemm_split16(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
+                zero();
+                gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
                 ws.init(a.h_w[net][1], 128, 128, wave * 16);
                 ws.prefetch();
-                {
-                    const float v[4] = {fmaxf(join(am[0], ac[0], 0) + hb0.x, 0.f), fmaxf(join(am[0], ac[0], 1) + hb0.y, 0.f),
-                                        fmaxf(join(am[0], ac[0], 2) + hb0.z, 0.f), fmaxf(join(am[0], ac[0], 3) + hb0.w, 0.f)};
-                    put_planes(Xa, r, n, v);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float v[4];
+                    joined(rt, hb0, v);
+                    relu4(v);
+                    put_planes(Xa, 16 * rt + r, n, v);
                 }
                 __syncthreads();
-                acc_zero1<1>(am, ac);
-                gemm_split16(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
+                zero();
+                gemm_split16r<1, 4, SP, RT>(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
                 if (wave < ntile) { ws.init(a.h_w[net][2], 16 * ntile, 128, wave * 16); ws.prefetch(); }
-                {
-                    const float v[4] = {fmaxf(join(am[0], ac[0], 0) + hb1.x, 0.f), fmaxf(join(am[0], ac[0], 1) + hb1.y, 0.f),
-                                        fmaxf(join(am[0], ac[0], 2) + hb1.z, 0.f), fmaxf(join(am[0], ac[0], 3) + hb1.w, 0.f)};
-                    put_planes(Xc, r, n, v);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float v[4];
+                    joined(rt, hb1, v);
+                    relu4(v);
+                    put_planes(Xc, 16 * rt + r, n, v);
                 }
                 __syncthreads();
                 if (wave < ntile) {
                     const float4 hb2 = *reinterpret_cast<const float4*>(a.h_b[net][2] + n);   // bias padded to 32 by the caller
-                    acc_zero1<1>(am, ac);
-                    gemm_split16(ws, Xc.h, Xc.l, LDP, am, ac, 0, 4);
-                    if (mr < M) {
-                        float* op = (net ? a.ang_out : a.logits_out) + (size_t)mr * nout;
-                        const float v[4] = {join(am[0], ac[0], 0) + hb2.x, join(am[0], ac[0], 1) + hb2.y,
-                                            join(am[0], ac[0], 2) + hb2.z, join(am[0], ac[0], 3) + hb2.w};
+                    zero();
+                    gemm_split16r<1, 4, SP, RT>(ws, Xc.h, Xc.l, LDP, am, ac, 0, 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < nout) op[n + e] = v[e];
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (mr[rt] < M) {
+                            float* op = (net ? a.ang_out : a.logits_out) + (size_t)mr[rt] * nout;
+                            float v[4];
+                            joined(rt, hb2, v);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < nout) op[n + e] = v[e];
+                        }
                     }
                 }
                 __syncthreads();                               // planes Xa / Xc are rewritten by the second head
@@ -911,23 +977,31 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
     }
     const int LP = (a->L + 15) / 16 * 16;
     const int LDS_S = LP + 4;
-    const size_t lds = ((size_t)2 * TR * LDX + TR * 8 + (size_t)TR * 4 * LDS_S) * sizeof(float) +
-                       (size_t)4 * TR * LDP * sizeof(_Float16);
+    // 32 rows per workgroup when the 16-row form would not fit one round of workgroups (one per CU)
+    const int tiles16 = (a->L + 15) / 16;
+    const int RTn = ((long)a->B * tiles16 > 256 && a->L > 16) ? 2 : 1;
+    const int TRn = 16 * RTn;
+    const size_t lds = ((size_t)2 * TRn * LDX + TRn * 8 + (size_t)TRn * 4 * LDS_S) * sizeof(float) +
+                       (size_t)4 * TRn * LDP * sizeof(_Float16);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
-    const int tiles = (a->L + TR - 1) / TR;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    const int tiles = (a->L + TRn - 1) / TRn;
     const dim3 grid((unsigned)(a->B * tiles));
-    if (a->last && a->single_pass) hipLaunchKernelGGL((node_tfmr_kernel<true, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
-    else if (a->last) hipLaunchKernelGGL((node_tfmr_kernel<true, false>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
-    else if (a->single_pass) hipLaunchKernelGGL((node_tfmr_kernel<false, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
-    else hipLaunchKernelGGL((node_tfmr_kernel<false, false>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+    const int variant = (RTn == 2 ? 4 : 0) + (a->last ? 2 : 0) + (a->single_pass ? 1 : 0);
+    static bool attr_set[8] = {};
+#define PF_NT_CASE(V, LASTV, SPV, RTV)                                                                                           \
+    case V:                                                                                                                      \
+        if (!attr_set[V]) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<LASTV, SPV, RTV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                               \
+            attr_set[V] = true;                                                                                                  \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((node_tfmr_kernel<LASTV, SPV, RTV>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);      \
+        break;
+    switch (variant) {
+        PF_NT_CASE(0, false, false, 1) PF_NT_CASE(1, false, true, 1) PF_NT_CASE(2, true, false, 1) PF_NT_CASE(3, true, true, 1)
+        PF_NT_CASE(4, false, false, 2) PF_NT_CASE(5, false, true, 2) PF_NT_CASE(6, true, false, 2) PF_NT_CASE(7, true, true, 2)
+    }
+#undef PF_NT_CASE
     PF_CHECK_LAUNCH();
     return 0;
 }

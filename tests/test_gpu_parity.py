@@ -633,9 +633,11 @@ def test_philox_sampling_is_world_size_invariant(model):
 
 
 # ------------------------------------------------------------------ ragged shapes / edge cases
-@pytest.mark.parametrize("B,L,lengths", [(1, 37, [30]), (3, 17, [17, 9, 16]), (2, 80, [80, 61]), (1, 130, [121]), (5, 16, None)])
+@pytest.mark.parametrize("B,L,lengths", [(1, 37, [30]), (3, 17, [17, 9, 16]), (2, 80, [80, 61]), (1, 130, [121]), (5, 16, None),
+                                         (44, 90, [90 - (i * 7) % 40 for i in range(44)])])
 def test_ga_encoder_ragged_shapes_vs_oracle(model, seeded_sd, B, L, lengths):
-    """Lengths that are not multiples of the 16-row / 64-pair tiles, padding inside a sample, L > 128."""
+    """Lengths that are not multiples of the 16-row / 64-pair tiles, padding inside a sample, L > 128; the last case has more than
+    256 16-row tiles (the node-track kernels switch to 32 rows per workgroup there) with a partial last tile in every sample."""
     batch = synth.make_pocket_batch(B, L, 6, seed=1000 + L, lengths=lengths)
     g = torch.Generator().manual_seed(L)
     enc = O.encode(seeded_sd, batch)
