@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 36
+#define PF_ABI_VERSION 37
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -175,6 +175,10 @@ typedef struct {
      * the outputs of masked query rows are multiplied by the mask afterwards (ga.py:104); feats / p_out there are NOT written. */
     const int* key_end;
     int z_f16;                     /* two-kernel form: z is [B,L,L,64] f16 (the f16 mode's pair tensor, see pf_edge_transition_args) */
+    /* optional (two-kernel form): dz [B,L,L,16] fp32 = W_dz z without the bias (pf_edge_transition_args.dz_out, or pf_linear_fwd
+     * of z for a pair tensor EdgeTransition did not produce): the pair aggregation sum_j P (W_dz z_j) + b_dz reads it instead of
+     * z (which may then be NULL) */
+    const float* dz;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
@@ -306,6 +310,12 @@ typedef struct {
     /* f16 mode only (single_pass): the pair tensor stored as f16 -- z_in / z_out then point to [B*L*L,64] f16 (same element order).
      * z_out_f16 alone (block 0: fp32 edge embedding in, f16 out) or both. */
     int z_in_f16, z_out_f16;
+    /* optional (persistent kernel, with bias_out): also emit the NEXT block's pair values W_dz z' (down_z, ipa_pytorch.py:440,
+     * WITHOUT its bias) as dz_out [B*L*L,16] fp32, so that the next pf_ipa_attn_fwd (its `dz`) reads 64 bytes per pair instead
+     * of the 256 of z'.  wb_frags then holds 6 KiB: the 2 fragment pairs of [linear_b (8 rows); down_z rows 0..7] followed by
+     * rows 8..15 of down_z as 2 half fragments (pepflowww_amd.engine.pack_bias_frags(w_b, w_dz)).  Skipped tiles (tile_list)
+     * are not touched: the caller keeps them zeroed. */
+    float* dz_out;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */

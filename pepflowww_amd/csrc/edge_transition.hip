@@ -289,7 +289,7 @@ extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_strea
     if (!a || !a->z_in || !a->z_out || !a->pre || !a->b2 || !a->ln_g || !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
         return PF_E_BADARG;
     if (a->w_stream) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);
-    if (a->single_pass) return PF_E_BADARG;                      // the f16 mode exists in the persistent kernel only
+    if (a->single_pass || a->dz_out) return PF_E_BADARG;         // the f16 mode / dz_out exist in the persistent kernel only
     if (!a->w1z_f16 || !a->w2_f16 || !a->wf_f16) return PF_E_BADARG;
     const long long npairs = (long long)a->B * a->L * a->L;
     // tile shape of the tiled (fallback) kernel: 64 pairs, 8 waves (the 64 x 4-wave and 32-pair forms measured the same)

@@ -75,7 +75,9 @@ template <bool SP, int NP, bool ZI = false> struct Map {
     static constexpr int OFF_MK = OFF_CE + 17 * 1024;          // mask_i[TI] | mask_j[16]
     static constexpr int OFF_CS = OFF_MK + 256;                // LayerNorm gamma[64] | beta[64] | b2[192] | b_b[8] (+pad)
     static constexpr int OFF_WB = OFF_CS + CONST_F * 4;        // 2 fragment pairs of the next block's linear_b (heads padded to 16)
-    static constexpr int LDS_BYTES = OFF_WB + 2 * KF;
+    // (+ 2 KiB in the f16 mode: rows 8..15 of the next block's down_z as half fragments, see dz_out; the fp32-parity mode has no
+    //  LDS left and keeps them in 16 registers)
+    static constexpr int LDS_BYTES = OFF_WB + 2 * KF + (SP ? 2048 : 0);
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -172,7 +174,7 @@ struct Tile { int b, i0, j0; };
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
 // ZI / ZO (f16 mode only): the pair tensor is read / written as f16 (pf_edge_transition_args.z_in_f16 / z_out_f16)
-template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false>
+template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false, bool DZ = false>   // DZ: also emit dz_out
 __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     static_assert(SP || (!ZI && !ZO), "f16 pair tensor: f16 mode only");
     using M = Map<SP, NP, ZI>;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     for (int i = tid; i < CONST_F; i += blockDim.x)
         Cs[i] = i < 64 ? a.ln_g[i] : (i < 128 ? a.ln_b[i - 64] : (i < 320 ? a.b2[i - 128] : (a.bias_out && i < 328 ? a.bb[i - 320] : 0.f)));
     if (a.bias_out)
-        for (int i = tid; i < 2 * KF / 16; i += blockDim.x)
+        for (int i = tid; i < (2 * KF + (SP && DZ ? 2048 : 0)) / 16; i += blockDim.x)
             reinterpret_cast<float4*>(smem + OFF_WB)[i] = reinterpret_cast<const float4*>(a.wb_frags)[i];
     __syncthreads();
 
@@ -391,6 +393,21 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
     const float* ad = reinterpret_cast<const float*>(smem + OFF_AD + (NP * wave) * 1024) + 4 * g;   // a_i | d_i, features 4g..
     const float* ce = reinterpret_cast<const float*>(smem + OFF_CE + r * CE_STRIDE) + 4 * g;        // c_j | e_j
     const float* mkb = reinterpret_cast<const float*>(smem + OFF_MK);
+    // dz_out: rows 8..15 of the next block's down_z as two half fragments (32 lanes x 16 B per plane; lane (r, g) reads the
+    // operand of row r & 7: MFMA rows 8..15 of that tile are not used).  fp32-parity mode: in registers for the whole kernel.
+    const unsigned dzl = ((g << 3) | (r & 7)) * 16;
+    Frag dzf[2];
+    dzf[0].h = dzf[0].l = dzf[1].h = dzf[1].l = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (!SP && DZ) {
+        {
+            const unsigned char* wd = reinterpret_cast<const unsigned char*>(a.wb_frags) + 2 * KF;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dzf[s2].h = *reinterpret_cast<const half8*>(wd + s2 * 1024 + dzl);
+                dzf[s2].l = *reinterpret_cast<const half8*>(wd + s2 * 1024 + 512 + dzl);
+            }
+        }
+    }
     int slot = 0;
     int tile = blockIdx.x;
     for (int it = 0; it < my_tiles; ++it, tile += gridDim.x) {
@@ -638,6 +655,29 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                     bo[2 * hs] = s13 * ((bm[2] + bm2[2]) + bb.z);
                     bo[3 * hs] = s13 * ((bm[3] + bm2[3]) + bb.w);
                 }
+                if constexpr (DZ) {
+                    // pair values W_dz z' of the next block (no bias): channels 0..7 are rows 8..15 of the tile above (lanes g = 2, 3),
+                    // channels 8..15 one more tile (lanes g = 0, 1); ONE store instruction = the 16 pairs' 1 KiB, contiguous
+                    Frag d0 = dzf[0], d1 = dzf[1];
+                    if constexpr (SP) {
+                        d0.h = *reinterpret_cast<const half8*>(wb + 2 * KF + dzl);
+                        d1.h = *reinterpret_cast<const half8*>(wb + 2 * KF + 1024 + dzl);
+                    }
+                    f32x4 dm = {0.f, 0.f, 0.f, 0.f}, dm2 = dm;
+                    if constexpr (!SP) { dm = mfma_h(d0.h, ol0, dm); dm2 = mfma_h(d1.h, ol1, dm2); }
+                    dm = mfma_h(d0.h, oh0, dm);
+                    dm2 = mfma_h(d1.h, oh1, dm2);
+                    if constexpr (!SP) { dm = mfma_h(d0.l, oh0, dm); dm2 = mfma_h(d1.l, oh1, dm2); }
+                    if (valid[p]) {
+                        const bool up = g >= 2;
+                        float4 v;
+                        v.x = up ? bm[0] + bm2[0] : dm[0] + dm2[0];
+                        v.y = up ? bm[1] + bm2[1] : dm[1] + dm2[1];
+                        v.z = up ? bm[2] + bm2[2] : dm[2] + dm2[2];
+                        v.w = up ? bm[3] + bm2[3] : dm[3] + dm2[3];
+                        *reinterpret_cast<float4*>(a.dz_out + pidx[p] * 16 + ((4 * g + 8) & 15)) = v;
+                    }
+                }
             }
         }
         PROF3(14);
@@ -648,7 +688,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 }  // namespace
 
 // launcher used by pf_edge_transition_fwd (edge_transition.hip) when args.w_stream is set
-template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false>
+template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false, bool DZ = false>
 static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
     using M = Map<SP, NP, ZI>;
     const int nib = (a->L + M::TI - 1) / M::TI, njb = (a->L + TJ - 1) / TJ;
@@ -657,11 +697,11 @@ static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int 
     const int grid = (int)(nt < ncu ? nt : ncu);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO, DZ>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
         attr_set = true;
     }
-    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO, DZ>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -670,21 +710,25 @@ extern "C" int pf_edge_transition_tile_rows(int single_pass) { return single_pas
 
 int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
     if ((a->tile_list != nullptr) != (a->n_tiles != nullptr)) return PF_E_BADARG;
+    if (a->dz_out && (!a->bias_out || !a->wb_frags)) return PF_E_BADARG;        // dz_out rides on the pair-bias tile
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n > 0 ? n : 256;
     }();
     if (a->dump_h1 || a->dump_h2 || a->dump_y) {
-        if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass) return PF_E_BADARG;
+        if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass || a->dz_out) return PF_E_BADARG;
         return et3_launch<true, false, 1>(a, stream, ncu);
     }
     if ((a->z_in_f16 || a->z_out_f16) && !a->single_pass) return PF_E_BADARG;   // f16 pair tensor: f16 mode only
+    const bool dz = a->dz_out != nullptr;
     if (a->single_pass) {
-        if (a->z_in_f16 && a->z_out_f16) return et3_launch<false, true, PF_ET_SP_NP, true, true>(a, stream, ncu);
-        if (a->z_out_f16) return et3_launch<false, true, PF_ET_SP_NP, false, true>(a, stream, ncu);
+        if (a->z_in_f16 && a->z_out_f16)
+            return dz ? et3_launch<false, true, PF_ET_SP_NP, true, true, true>(a, stream, ncu) : et3_launch<false, true, PF_ET_SP_NP, true, true>(a, stream, ncu);
+        if (a->z_out_f16)
+            return dz ? et3_launch<false, true, PF_ET_SP_NP, false, true, true>(a, stream, ncu) : et3_launch<false, true, PF_ET_SP_NP, false, true>(a, stream, ncu);
         if (a->z_in_f16) return PF_E_BADARG;
-        return et3_launch<false, true, PF_ET_SP_NP>(a, stream, ncu);
+        return dz ? et3_launch<false, true, PF_ET_SP_NP, false, false, true>(a, stream, ncu) : et3_launch<false, true, PF_ET_SP_NP>(a, stream, ncu);
     }
-    return et3_launch<false, false, 1>(a, stream, ncu);
+    return dz ? et3_launch<false, false, 1, false, false, true>(a, stream, ncu) : et3_launch<false, false, 1>(a, stream, ncu);
 }

@@ -683,6 +683,81 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
     }
 }
 
+// Pair aggregation on the pair VALUES dz = W_dz z (pf_ipa_attn_args.dz: written by the EdgeTransition kernel that produced z, 64
+// bytes per pair instead of the 256 of z):  o_pair[h][c] = b_dz[c] + sum_j P[h][j] dz[i][j][c].  One wave per query row, four rows
+// per workgroup, no workgroup barrier; the contraction over keys is a [heads padded to 16] x [4 keys] x [16 channels] fp32 MFMA.
+//   B operand of lane (r = channel, g): dz[i][key][r] with key = 16 u + 4 t + g in MFMA (u, t): the 64 lanes of one load
+//   instruction read 256 CONTIGUOUS bytes (dword each);  A operand: P[h = r][16 u + 4 t + g], staged in LDS in the order
+//   [h][u][g][t] so that a lane reads its four t as one float4.
+// (A VALU form -- float4 loads, lane = 4 channels of a key, 32 partial sums per lane reduced over 16 lanes -- measured 28 us at
+//  B=64, L=128, of which ~290 of ~700 instructions per row were the cross-lane reduction.)
+template <int NG>                              // 16-key groups: 16 NG >= L
+__global__ __launch_bounds__(256) void ipa_pair_dz_kernel(pf_ipa_attn_args a) {
+    constexpr int LPZ = 16 * NG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int L = a.L;
+    const long row = (long)blockIdx.x * 4 + wave;                // b * L + i
+    if (row >= (long)a.B * L) return;
+    const long b = row / L, i = row - b * L;
+    const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
+    if (i >= Le) return;                                         // (wave-uniform; nothing below synchronises the workgroup)
+    const int nge = (Le + 15) >> 4;
+    float* PL = smem + wave * 8 * LPZ;                           // [8][LPZ] probabilities of this row (0 from Le on), permuted
+    const float* drow = a.dz + (size_t)row * L * 16 + r;
+    float bv[NG][4];
+#pragma unroll
+    for (int u = 0; u < NG; ++u)
+        if (u < nge) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[u][t] = drow[(size_t)min(16 * u + 4 * t + g, L - 1) * 16];
+        }
+    const float bdz = a.b_dz[r];
+    if ((L & 3) == 0) {
+        for (int idx = lane; idx < LPZ * 2; idx += 64) {         // float4 pieces of the 8 head rows: keys j .. j + 3 = slots g = 0 .. 3
+            const int hh = idx / (LPZ / 4), j = 4 * (idx - hh * (LPZ / 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < Le) {
+                v = *reinterpret_cast<const float4*>(a.p_out + ((b * H + hh) * L + i) * L + j);
+                if (j + 1 >= Le) v.y = 0.f;                      // (the score kernel does not write beyond key Le - 1)
+                if (j + 2 >= Le) v.z = 0.f;
+                if (j + 3 >= Le) v.w = 0.f;
+            }
+            float* d = PL + hh * LPZ + (j & ~15) + ((j >> 2) & 3);
+            d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+        }
+    } else {
+        for (int idx = lane; idx < LPZ * 8; idx += 64) {
+            const int hh = idx / LPZ, j = idx - hh * LPZ;
+            PL[hh * LPZ + (j & ~15) + 4 * (j & 3) + ((j >> 2) & 3)] = j < Le ? a.p_out[((b * H + hh) * L + i) * L + j] : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private LDS hand-off
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* pl = PL + (r & 7) * LPZ + 4 * g;
+    const float keep = r < 8 ? 1.f : 0.f;                        // MFMA rows 8..15 are padding
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        if (u < nge) {
+            const float4 pa = *reinterpret_cast<const float4*>(pl + 16 * u);   // (keys from Le on: P = 0 times a clamped, finite row)
+            acc[0] = mfma16(pa.x * keep, bv[u][0], acc[0]);
+            acc[1] = mfma16(pa.y * keep, bv[u][1], acc[1]);
+            acc[2] = mfma16(pa.z * keep, bv[u][2], acc[2]);
+            acc[3] = mfma16(pa.w * keep, bv[u][3], acc[3]);
+        }
+    }
+    // D: lane (r = channel, g), register e -> head 4 g + e
+    if (g < 2) {
+        float* f = a.feats + (size_t)row * PF_IPA_FEATS + 1408 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[(4 * g + e) * 16] = ((acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e])) + bdz;
+    }
+}
+
 }  // namespace
 
 // two-kernel IPA (called by pf_ipa_attn_fwd, ipa_attn.hip): requires a->bias and a->p_out, L <= 256
@@ -735,6 +810,19 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     const size_t lds = ((size_t)8 * 16 * ng + ZW * 8 * 64 + 4 * 64 * 4) * sizeof(float);
     const long rows = (long)a->B * L;
     if (ng > 16 || rows > 0x7fffffffL) return PF_E_TOOLARGE;
+    if (a->dz) {
+        const dim3 gridd((unsigned)((rows + 3) / 4));
+        const size_t ldsd = (size_t)4 * 8 * 16 * ng * sizeof(float);
+        switch (ng) {
+#define PF_PAIRDZ_CASE(N) case N: hipLaunchKernelGGL(ipa_pair_dz_kernel<N>, gridd, dim3(256), ldsd, s, *a); break;
+            PF_PAIRDZ_CASE(1) PF_PAIRDZ_CASE(2) PF_PAIRDZ_CASE(3) PF_PAIRDZ_CASE(4) PF_PAIRDZ_CASE(5) PF_PAIRDZ_CASE(6) PF_PAIRDZ_CASE(7)
+            PF_PAIRDZ_CASE(8) PF_PAIRDZ_CASE(9) PF_PAIRDZ_CASE(10) PF_PAIRDZ_CASE(11) PF_PAIRDZ_CASE(12) PF_PAIRDZ_CASE(13)
+            PF_PAIRDZ_CASE(14) PF_PAIRDZ_CASE(15) PF_PAIRDZ_CASE(16)
+#undef PF_PAIRDZ_CASE
+        }
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     const dim3 grid((unsigned)rows), blk(64 * ZW);
     switch (ng) {
 #define PF_PAIR_CASE(N) case N: if (a->z_f16) hipLaunchKernelGGL((ipa_pair_kernel<N, true>), grid, blk, lds, s, *a); else hipLaunchKernelGGL(ipa_pair_kernel<N>, grid, blk, lds, s, *a); break;

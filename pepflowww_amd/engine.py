@@ -105,16 +105,27 @@ def pack_et_stream(w1z, w2, wf):
     return stream
 
 
-def pack_bias_frags(w_b):
-    """IPA linear_b [8,64] (heads zero-padded to 16 rows) as the 2 fragment pairs (K-steps, permuted K order) the
-    persistent EdgeTransition kernel uses to emit the next block's pair bias.  Layout/packing only."""
+def pack_bias_frags(w_b, w_dz=None):
+    """IPA linear_b [8,64] as the 2 fragment pairs (K-steps, permuted K order) the persistent EdgeTransition kernel uses to emit
+    the next block's pair bias (4 KiB).  Rows 8..15 of that 16-row tile are zero, or -- with w_dz [16,64] (down_z of the same
+    block; pf_edge_transition_args.dz_out) -- its rows 0..7; rows 8..15 of w_dz follow as 2 HALF fragments (2 KiB): per K-step
+    hi [32 lanes][8] | lo [32 lanes][8], lane = 8 kg + row.  Layout/packing only."""
     w = _f32(w_b)
     assert w.shape == (8, 64)
-    w = torch.nn.functional.pad(w, (0, 0, 0, 8))
     kg = torch.arange(4, device=w.device)[:, None]
     i8 = torch.arange(8, device=w.device)[None, :]
     perm = lambda s: 32 * s + 16 * (i8 >> 2) + 4 * kg + (i8 & 3)
-    return torch.cat([_frag_pair(w, 0, perm(s)) for s in range(2)]).contiguous()
+    if w_dz is None:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 8))
+        return torch.cat([_frag_pair(w, 0, perm(s)) for s in range(2)]).contiguous()
+    wd = _f32(w_dz)
+    assert wd.shape == (16, 64)
+    out = [_frag_pair(torch.cat([w, wd[:8]], 0).contiguous(), 0, perm(s)) for s in range(2)]
+    wb = torch.nn.functional.pad(wd[8:], (0, 0, 0, 8)).contiguous()
+    for s in range(2):
+        f = _frag_pair(wb, 0, perm(s)).view(2, 4, 16, 8)[:, :, :8, :]          # [hi | lo][kg][row < 8][8]
+        out.append(f.reshape(-1))
+    return torch.cat(out).contiguous()
 
 
 class PackedWeights:
@@ -197,7 +208,7 @@ class PackedWeights:
                 t[f"{b}.et.w1z16"], t[f"{b}.et.wf16"] = split_f16(w1[:, :64]), split_f16(wf)
                 t[f"{b}.et.w216"], t[f"{b}.et.b2"] = split_f16(g(q + "trunk.2.weight")), g(q + "trunk.2.bias")
                 t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
-                t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"))
+                t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
                 t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
@@ -247,6 +258,10 @@ class DenoiseEngine:
         self.edge16 = e(B, L, L, 64, dt=torch.float16) if self.z16 else None    # f16 copy of the caller's edge embedding (bind_context)
         self.pair_bias = e(B, 8, L, L)          # sqrt(1/3)(W_b z + b_b) of the next IPA block (head-major), written by EdgeTransition
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
+        # pair values W_dz z of the next IPA block (no bias), written by EdgeTransition next to the pair bias wherever the two-kernel
+        # attention runs: its pair aggregation then reads 64 bytes per pair instead of z (256; 128 in the f16 mode)
+        self.pair_dz = e(B, L, L, 16) if 64 <= L <= 256 else None
+        self.pair_dz0 = e(B, L, L, 16) if 64 <= L <= 256 else None      # ... of block 0 (from edge_embed, in bind_context)
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
         # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
@@ -307,6 +322,11 @@ class DenoiseEngine:
             self.edge16.copy_(ee.reshape(B, L, L, 64))
         _capi.check(self.lib.pf_pair_bias_fwd(ee.data_ptr(), self.w["0.linear_b.w"].data_ptr(), self.w["0.linear_b.b"].data_ptr(),
                                               self.pair_bias0.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
+        if self.pair_dz0 is not None:           # block 0's pair values W_dz edge_embed (no bias), once per call like its pair bias
+            la = _capi.LinearArgs()
+            la.x, la.ldx, la.w, la.ldw = ee.data_ptr(), 64, self.w["0.down_z.w"].data_ptr(), 64
+            la.y, la.ldy, la.M, la.N, la.K = self.pair_dz0.data_ptr(), 16, B * L * L, 16, 64
+            _capi.check(self.lib.pf_linear_fwd(C.byref(la), _capi.stream_ptr()), "pf_linear_fwd (down_z of edge_embed)")
         if rebuild:
             self._build_plan()
 
@@ -325,6 +345,8 @@ class DenoiseEngine:
         self.key_end.copy_((m.to(torch.int32) * torch.arange(1, L + 1, device=m.device, dtype=torch.int32)).amax(-1))
         self.zbuf.zero_()
         self.pair_bias.zero_()
+        if self.pair_dz is not None:
+            self.pair_dz.zero_()
 
     def _build_plan(self):
         w, lib = self.w, self.lib
@@ -373,6 +395,8 @@ class DenoiseEngine:
             ia.p_out = self.attn_p.data_ptr()
             ia.key_end = self.key_end.data_ptr()
             ia.z_f16 = int(self.z16)
+            if self.pair_dz is not None:
+                ia.dz = (self.pair_dz if b > 0 else self.pair_dz0).data_ptr()     # EdgeTransition(b - 1) / bind_context
             if self.att_planes:
                 ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
             self._keep.append(ia)
@@ -443,6 +467,8 @@ class DenoiseEngine:
                 et.single_pass = int(self.precision == "f16")
                 et.tile_list, et.n_tiles = self.et_tiles.data_ptr(), self.et_ntiles.data_ptr()
                 et.z_in_f16, et.z_out_f16 = int(self.z16), int(self.z16)
+                if self.pair_dz is not None:
+                    et.dz_out = self.pair_dz.data_ptr()
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
                 plan.append((None, None, "join", 0))

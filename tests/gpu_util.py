@@ -97,9 +97,11 @@ def rigid_update(quat, rot, trans, upd, mask):
     return qo, ro, to
 
 
-def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None):
+def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None,
+              dz=None):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
-    variant=1); head_group: force a head-group split of the one-kernel form."""
+    variant=1); head_group: force a head-group split of the one-kernel form; dz: [B,L,L,16] pair values W_dz z (no bias) for the
+    two-kernel form's pair aggregation (z may then be None)."""
     lib = _capi.load()
     rows = B * L
     d = proj.device
@@ -117,14 +119,17 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.p_out = _p(p_out)
     ia.variant, ia.head_group = variant, head_group
     ia.key_end = _p(key_end)                  # int32 [B]: 1 + last unmasked residue (two-kernel form skips what lies beyond)
+    ia.dz = _p(dz)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
 
 
-def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None):
+def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None,
+                    next_dz=None, single_pass=False):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
-    persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes)."""
+    persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes).
+    next_dz: down_z.weight [16,64] of the next IPA block (with next_bias): also returns dz [B,L,L,16] = W_dz z'."""
     from pepflowww_amd.engine import split_f16, pack_et_stream
     lib = _capi.load()
     if out is None:
@@ -137,13 +142,19 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
     a.w_stream = _p(ws)
     if next_bias is not None:                 # (linear_b.weight [8,64], linear_b.bias [8]) of the next IPA block
         from pepflowww_amd.engine import pack_bias_frags
-        wbf = pack_bias_frags(next_bias[0])
+        wbf = pack_bias_frags(next_bias[0], next_dz)
         bias = torch.full((B, 8, L, L), float("nan"), device=z.device)
         a.bias_out, a.wb_frags, a.bb = _p(bias), _p(wbf), _p(next_bias[1])
+        if next_dz is not None:
+            dz = torch.full((B, L, L, 16), float("nan"), device=z.device)
+            a.dz_out = _p(dz)
+    a.single_pass = int(single_pass)
     if tile_list is not None:                 # (int32 list of active tile ids, int32 [1] count): pf_edge_transition_args.tile_list
         a.tile_list, a.n_tiles = _p(tile_list[0]), _p(tile_list[1])
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()
+    if next_dz is not None:
+        return out, bias, dz
     return (out, bias) if next_bias is not None else out
 
 

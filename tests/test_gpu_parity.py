@@ -464,6 +464,80 @@ def test_ipa_key_end_through_the_c_abi(seeded_sd):
     assert torch.isnan(skipped[beyond]).all() and not torch.isnan(dense[beyond]).any()
 
 
+@pytest.mark.parametrize("single_pass", [False, True])
+def test_edge_transition_emits_next_pair_values(f2, seeded_sd, single_pass):
+    """pf_edge_transition_args.dz_out: W_dz z' of the NEXT IPA block (no bias) from z' in registers, next to the pair bias; z' and
+    the bias are what they are without it."""
+    b = _batch(f2)
+    B, L = b["aa"].shape
+    sd, pfx = seeded_sd, "ga_encoder.trunk.edge_transition_0."
+    g = lambda k: sd[pfx + k]
+    mask = b["res_mask"].float()
+    n64 = G.linear(cu(f2["et0_in_s"].reshape(B * L, 128)), cu(g("initial_embed.weight")), cu(g("initial_embed.bias")))
+    w1, b1, wf, bf = g("trunk.0.weight"), g("trunk.0.bias"), g("final_layer.weight"), g("final_layer.bias")
+    wpre = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
+    bpre = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0)
+    pre = G.linear(n64, cu(wpre), cu(bpre))
+    wb, bb = sd["ga_encoder.trunk.ipa_1.linear_b.weight"], sd["ga_encoder.trunk.ipa_1.linear_b.bias"]
+    wdz = sd["ga_encoder.trunk.ipa_1.down_z.weight"]
+    run = lambda nd: G.edge_transition(cu(f2["enc_edge"].reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")),
+                                       cu(wf), cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
+                                       next_bias=(cu(wb), cu(bb)), next_dz=nd, single_pass=single_pass)
+    out0, bias0 = run(None)
+    out, bias, dz = run(cu(wdz))
+    assert torch.equal(out, out0) and torch.equal(bias, bias0)
+    em = (mask[:, None, :] * mask[:, :, None])[..., None]
+    zref = f2["et0_out"] * em
+    tol = REL if not single_pass else 2e-2
+    G.assert_close(out.view(B, L, L, 64), zref, tol, "z'")
+    G.assert_close(dz, F.linear(zref, wdz), tol, "next block's pair values [B,L,L,16]")
+    # against the kernel's own z' the 64 -> 16 map itself is exact to the operand split
+    G.assert_close(dz, F.linear(out.view(B, L, L, 64).cpu(), wdz), REL if not single_pass else 2e-3, "dz vs W_dz z' of the same run")
+
+
+def test_ipa_pair_values_through_the_c_abi(seeded_sd):
+    """pf_ipa_attn_args.dz: the two-kernel form aggregating the pair VALUES W_dz z (64 B per pair) equals the run that reads z --
+    dense, with key ends (ragged L, holes), and with z = NULL."""
+    B, L = 3, 90
+    g = torch.Generator().manual_seed(78)
+    pfx = "ga_encoder.trunk.ipa_2."
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    mask[0, 50:] = 0
+    mask[1, 77:] = 0
+    mask[1, 7] = 0
+    mask[2, :] = 0
+    mask[2, 3:9] = 1
+    kend = (mask.to(torch.int32) * torch.arange(1, L + 1, dtype=torch.int32)).amax(-1)
+    gq = lambda k: cu(seeded_sd[pfx + k])
+    sd = seeded_sd
+    wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    proj = G.linear(cu(s.reshape(B * L, 128)), cu(wproj), cu(bproj))
+    bias = cu((math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"])).reshape(B, L, L, 8).permute(0, 3, 1, 2))
+    dz = cu(F.linear(z, sd[pfx + "down_z.weight"]).contiguous())
+    run = lambda zz, dd, ke: G.ipa_feats(proj, zz, cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)),
+                                         gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"),
+                                         B, L, bias=bias, p_out=torch.zeros(B, 8, L, L, device=G.dev()), variant=2, key_end=ke, dz=dd)[0].cpu()
+    valid = mask.reshape(-1).bool()
+    ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], s, z, R, x, mask)
+    for ke in (None, cu(kend)):
+        from_z, from_dz = run(cu(z), None, ke), run(None, dz, ke)
+        G.assert_close(from_dz[valid], from_z[valid], 1e-5, "pair values vs z")
+        assert torch.equal(from_dz[valid][:, :1408], from_z[valid][:, :1408])        # everything but o_pair is the same code
+        G.assert_close(from_dz[valid], ref_feats.reshape(B * L, -1)[valid], REL, "pair values vs oracle")
+    beyond = (torch.arange(L)[None, :] >= kend[:, None]).reshape(-1)
+    assert torch.isnan(from_dz[beyond]).all()
+    # the one-kernel form has no pair-value path
+    with pytest.raises(Exception):
+        G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)), gq("linear_b.weight"), gq("linear_b.bias"),
+                    gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"), B, L, variant=1, dz=dz)
+
+
 @pytest.mark.parametrize("M", [8192, 8192 + 256 * 32 - 5])
 def test_linear_rows_persistent_projection(M):
     """pf_linear_fwd's rows-persistent kernel (K = 128, wide N, whole rounds of 256 workgroups): plain columns vs a float64
