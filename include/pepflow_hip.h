@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 37
+#define PF_ABI_VERSION 38
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -179,6 +179,7 @@ typedef struct {
      * of z for a pair tensor EdgeTransition did not produce): the pair aggregation sum_j P (W_dz z_j) + b_dz reads it instead of
      * z (which may then be NULL) */
     const float* dz;
+    int dz_f16;                    /* dz is [B,L,L,16] f16 (the f16 mode: pf_edge_transition_args.dz_out_f16) */
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
@@ -316,6 +317,7 @@ typedef struct {
      * rows 8..15 of down_z as 2 half fragments (pepflowww_amd.engine.pack_bias_frags(w_b, w_dz)).  Skipped tiles (tile_list)
      * are not touched: the caller keeps them zeroed. */
     float* dz_out;
+    int dz_out_f16;                /* f16 mode only (single_pass): dz_out points to [B*L*L,16] f16 */
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */

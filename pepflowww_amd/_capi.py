@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -40,7 +40,7 @@ class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
                 ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp),
-                ("variant", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_mode", _i), ("head_group", _i), ("key_end", _fp), ("z_f16", _i), ("dz", _fp)]
+                ("variant", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_mode", _i), ("head_group", _i), ("key_end", _fp), ("z_f16", _i), ("dz", _fp), ("dz_f16", _i)]
 
 
 class InputMixerArgs(C.Structure):
@@ -62,7 +62,7 @@ class EdgeTransitionArgs(C.Structure):
     _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1z_f16", _fp), ("w2_f16", _fp), ("b2", _fp), ("wf_f16", _fp),
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
                 ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp),
-                ("single_pass", _i), ("tile_list", _fp), ("n_tiles", _fp), ("z_in_f16", _i), ("z_out_f16", _i), ("dz_out", _fp)]
+                ("single_pass", _i), ("tile_list", _fp), ("n_tiles", _fp), ("z_in_f16", _i), ("z_out_f16", _i), ("dz_out", _fp), ("dz_out_f16", _i)]
 
 
 class SamplerArgs(C.Structure):

@@ -675,7 +675,17 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                         v.y = up ? bm[1] + bm2[1] : dm[1] + dm2[1];
                         v.z = up ? bm[2] + bm2[2] : dm[2] + dm2[2];
                         v.w = up ? bm[3] + bm2[3] : dm[3] + dm2[3];
-                        *reinterpret_cast<float4*>(a.dz_out + pidx[p] * 16 + ((4 * g + 8) & 15)) = v;
+                        if constexpr (SP) {                      // (f16 mode: f16 pair values when the caller says so)
+                            if (a.dz_out_f16) {
+                                half4 hv;
+                                hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+                                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(a.dz_out) + pidx[p] * 16 + ((4 * g + 8) & 15)) = hv;
+                            } else {
+                                *reinterpret_cast<float4*>(a.dz_out + pidx[p] * 16 + ((4 * g + 8) & 15)) = v;
+                            }
+                        } else {
+                            *reinterpret_cast<float4*>(a.dz_out + pidx[p] * 16 + ((4 * g + 8) & 15)) = v;
+                        }
                     }
                 }
             }
@@ -711,6 +721,7 @@ extern "C" int pf_edge_transition_tile_rows(int single_pass) { return single_pas
 int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
     if ((a->tile_list != nullptr) != (a->n_tiles != nullptr)) return PF_E_BADARG;
     if (a->dz_out && (!a->bias_out || !a->wb_frags)) return PF_E_BADARG;        // dz_out rides on the pair-bias tile
+    if (a->dz_out_f16 && !(a->dz_out && a->single_pass)) return PF_E_BADARG;
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;

@@ -715,6 +715,7 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     const bool can_split = a->bias && a->p_out && a->L <= 256;
     if (a->variant == 2 && !can_split) return PF_E_BADARG;   // two-kernel form demanded but not possible
     if (a->z_f16 && !(can_split && a->variant != 1 && a->L >= 64)) return PF_E_BADARG;   // f16 pair tensor: two-kernel form only
+    if (a->dz_f16 && !a->dz) return PF_E_BADARG;
     if (a->dz && !(can_split && a->variant != 1 && a->L >= 64)) return PF_E_BADARG;      // pair values: two-kernel form only
     if (can_split && (a->variant == 2 || (a->variant == 0 && a->L >= 64))) return pf_ipa_split_launch(a, s);
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs

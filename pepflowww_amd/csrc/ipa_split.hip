@@ -691,7 +691,7 @@ __global__ __launch_bounds__(64 * ZW) void ipa_pair_kernel(pf_ipa_attn_args a) {
 //   [h][u][g][t] so that a lane reads its four t as one float4.
 // (A VALU form -- float4 loads, lane = 4 channels of a key, 32 partial sums per lane reduced over 16 lanes -- measured 28 us at
 //  B=64, L=128, of which ~290 of ~700 instructions per row were the cross-lane reduction.)
-template <int NG>                              // 16-key groups: 16 NG >= L
+template <int NG, bool D16 = false>            // 16-key groups: 16 NG >= L; D16: dz is f16
 __global__ __launch_bounds__(256) void ipa_pair_dz_kernel(pf_ipa_attn_args a) {
     constexpr int LPZ = 16 * NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -706,12 +706,18 @@ __global__ __launch_bounds__(256) void ipa_pair_dz_kernel(pf_ipa_attn_args a) {
     const int nge = (Le + 15) >> 4;
     float* PL = smem + wave * 8 * LPZ;                           // [8][LPZ] probabilities of this row (0 from Le on), permuted
     const float* drow = a.dz + (size_t)row * L * 16 + r;
+    const _Float16* drow16 = reinterpret_cast<const _Float16*>(a.dz) + (size_t)row * L * 16 + r;
     float bv[NG][4];
+    _Float16 bv16[NG][4];
 #pragma unroll
     for (int u = 0; u < NG; ++u)
         if (u < nge) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[u][t] = drow[(size_t)min(16 * u + 4 * t + g, L - 1) * 16];
+            for (int t = 0; t < 4; ++t) {
+                const size_t off = (size_t)min(16 * u + 4 * t + g, L - 1) * 16;
+                if constexpr (D16) bv16[u][t] = drow16[off];
+                else bv[u][t] = drow[off];
+            }
         }
     const float bdz = a.b_dz[r];
     if ((L & 3) == 0) {
@@ -744,6 +750,10 @@ __global__ __launch_bounds__(256) void ipa_pair_dz_kernel(pf_ipa_attn_args a) {
     for (int u = 0; u < NG; ++u) {
         if (u < nge) {
             const float4 pa = *reinterpret_cast<const float4*>(pl + 16 * u);   // (keys from Le on: P = 0 times a clamped, finite row)
+            if constexpr (D16) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[u][t] = (float)bv16[u][t];
+            }
             acc[0] = mfma16(pa.x * keep, bv[u][0], acc[0]);
             acc[1] = mfma16(pa.y * keep, bv[u][1], acc[1]);
             acc[2] = mfma16(pa.z * keep, bv[u][2], acc[2]);
@@ -814,7 +824,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         const dim3 gridd((unsigned)((rows + 3) / 4));
         const size_t ldsd = (size_t)4 * 8 * 16 * ng * sizeof(float);
         switch (ng) {
-#define PF_PAIRDZ_CASE(N) case N: hipLaunchKernelGGL(ipa_pair_dz_kernel<N>, gridd, dim3(256), ldsd, s, *a); break;
+#define PF_PAIRDZ_CASE(N) case N: if (a->dz_f16) hipLaunchKernelGGL((ipa_pair_dz_kernel<N, true>), gridd, dim3(256), ldsd, s, *a); else hipLaunchKernelGGL((ipa_pair_dz_kernel<N, false>), gridd, dim3(256), ldsd, s, *a); break;
             PF_PAIRDZ_CASE(1) PF_PAIRDZ_CASE(2) PF_PAIRDZ_CASE(3) PF_PAIRDZ_CASE(4) PF_PAIRDZ_CASE(5) PF_PAIRDZ_CASE(6) PF_PAIRDZ_CASE(7)
             PF_PAIRDZ_CASE(8) PF_PAIRDZ_CASE(9) PF_PAIRDZ_CASE(10) PF_PAIRDZ_CASE(11) PF_PAIRDZ_CASE(12) PF_PAIRDZ_CASE(13)
             PF_PAIRDZ_CASE(14) PF_PAIRDZ_CASE(15) PF_PAIRDZ_CASE(16)

@@ -260,8 +260,10 @@ class DenoiseEngine:
         self.pair_bias0 = e(B, 8, L, L)         # ... of block 0 (edge_embed is per-call context: computed in bind_context)
         # pair values W_dz z of the next IPA block (no bias), written by EdgeTransition next to the pair bias wherever the two-kernel
         # attention runs: its pair aggregation then reads 64 bytes per pair instead of z (256; 128 in the f16 mode)
-        self.pair_dz = e(B, L, L, 16) if 64 <= L <= 256 else None
-        self.pair_dz0 = e(B, L, L, 16) if 64 <= L <= 256 else None      # ... of block 0 (from edge_embed, in bind_context)
+        dzt = torch.float16 if self.z16 else torch.float32               # (f16 in the f16 mode, like the pair tensor itself)
+        self.pair_dz = e(B, L, L, 16, dt=dzt) if 64 <= L <= 256 else None
+        self.pair_dz0 = e(B, L, L, 16, dt=dzt) if 64 <= L <= 256 else None   # ... of block 0 (from edge_embed, in bind_context)
+        self._dz0_f32 = e(B, L, L, 16) if (self.z16 and self.pair_dz0 is not None) else None
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
         # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
@@ -325,8 +327,11 @@ class DenoiseEngine:
         if self.pair_dz0 is not None:           # block 0's pair values W_dz edge_embed (no bias), once per call like its pair bias
             la = _capi.LinearArgs()
             la.x, la.ldx, la.w, la.ldw = ee.data_ptr(), 64, self.w["0.down_z.w"].data_ptr(), 64
-            la.y, la.ldy, la.M, la.N, la.K = self.pair_dz0.data_ptr(), 16, B * L * L, 16, 64
+            y = self._dz0_f32 if self.z16 else self.pair_dz0
+            la.y, la.ldy, la.M, la.N, la.K = y.data_ptr(), 16, B * L * L, 16, 64
             _capi.check(self.lib.pf_linear_fwd(C.byref(la), _capi.stream_ptr()), "pf_linear_fwd (down_z of edge_embed)")
+            if self.z16:
+                self.pair_dz0.copy_(y)          # storage conversion, like edge16
         if rebuild:
             self._build_plan()
 
@@ -397,6 +402,7 @@ class DenoiseEngine:
             ia.z_f16 = int(self.z16)
             if self.pair_dz is not None:
                 ia.dz = (self.pair_dz if b > 0 else self.pair_dz0).data_ptr()     # EdgeTransition(b - 1) / bind_context
+                ia.dz_f16 = int(self.z16)
             if self.att_planes:
                 ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
             self._keep.append(ia)
@@ -468,7 +474,7 @@ class DenoiseEngine:
                 et.tile_list, et.n_tiles = self.et_tiles.data_ptr(), self.et_ntiles.data_ptr()
                 et.z_in_f16, et.z_out_f16 = int(self.z16), int(self.z16)
                 if self.pair_dz is not None:
-                    et.dz_out = self.pair_dz.data_ptr()
+                    et.dz_out, et.dz_out_f16 = self.pair_dz.data_ptr(), int(self.z16)
                 self._keep.append(et)
                 plan.append((lib.pf_edge_transition_fwd, C.byref(et), "pf_edge_transition_fwd"))
                 plan.append((None, None, "join", 0))

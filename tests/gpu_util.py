@@ -120,13 +120,14 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.variant, ia.head_group = variant, head_group
     ia.key_end = _p(key_end)                  # int32 [B]: 1 + last unmasked residue (two-kernel form skips what lies beyond)
     ia.dz = _p(dz)
+    ia.dz_f16 = int(dz is not None and dz.dtype == torch.float16)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
 
 
 def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None,
-                    next_dz=None, single_pass=False):
+                    next_dz=None, single_pass=False, dz_f16=False):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
     persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes).
     next_dz: down_z.weight [16,64] of the next IPA block (with next_bias): also returns dz [B,L,L,16] = W_dz z'."""
@@ -146,8 +147,8 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
         bias = torch.full((B, 8, L, L), float("nan"), device=z.device)
         a.bias_out, a.wb_frags, a.bb = _p(bias), _p(wbf), _p(next_bias[1])
         if next_dz is not None:
-            dz = torch.full((B, L, L, 16), float("nan"), device=z.device)
-            a.dz_out = _p(dz)
+            dz = torch.full((B, L, L, 16), float("nan"), device=z.device, dtype=torch.float16 if dz_f16 else torch.float32)
+            a.dz_out, a.dz_out_f16 = _p(dz), int(dz_f16)
     a.single_pass = int(single_pass)
     if tile_list is not None:                 # (int32 list of active tile ids, int32 [1] count): pf_edge_transition_args.tile_list
         a.tile_list, a.n_tiles = _p(tile_list[0]), _p(tile_list[1])

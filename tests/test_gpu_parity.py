@@ -493,6 +493,11 @@ def test_edge_transition_emits_next_pair_values(f2, seeded_sd, single_pass):
     G.assert_close(dz, F.linear(zref, wdz), tol, "next block's pair values [B,L,L,16]")
     # against the kernel's own z' the 64 -> 16 map itself is exact to the operand split
     G.assert_close(dz, F.linear(out.view(B, L, L, 64).cpu(), wdz), REL if not single_pass else 2e-3, "dz vs W_dz z' of the same run")
+    if single_pass:                             # f16 storage of the same values (dz_out_f16)
+        dz16 = G.edge_transition(cu(f2["enc_edge"].reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")),
+                                 cu(wf), cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
+                                 next_bias=(cu(wb), cu(bb)), next_dz=cu(wdz), single_pass=True, dz_f16=True)[2]
+        assert dz16.dtype == torch.float16 and torch.equal(dz16, dz.to(torch.float16))
 
 
 def test_ipa_pair_values_through_the_c_abi(seeded_sd):
@@ -532,6 +537,8 @@ def test_ipa_pair_values_through_the_c_abi(seeded_sd):
         G.assert_close(from_dz[valid], ref_feats.reshape(B * L, -1)[valid], REL, "pair values vs oracle")
     beyond = (torch.arange(L)[None, :] >= kend[:, None]).reshape(-1)
     assert torch.isnan(from_dz[beyond]).all()
+    from_dz16 = run(None, dz.to(torch.float16), cu(kend))                          # f16 storage (the f16 mode)
+    G.assert_close(from_dz16[valid], from_z[valid], 2e-3, "f16 pair values vs z")
     # the one-kernel form has no pair-value path
     with pytest.raises(Exception):
         G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)), gq("linear_b.weight"), gq("linear_b.bias"),
