@@ -768,6 +768,100 @@ __global__ __launch_bounds__(256) void ipa_pair_dz_kernel(pf_ipa_attn_args a) {
     }
 }
 
+// The same for f16 pair values (f16 mode): 2-byte loads are as many load instructions as 4-byte ones and the MFMA form above
+// gained nothing from the halved traffic (27 us at B=64, L=128).  Here a lane loads FOUR channels of a key as one half4 (a wave
+// load = 16 keys = 512 contiguous bytes), multiplies on the VALU (8 heads x 4 channels of partial sums per lane) and the 16 key
+// slots are summed by a butterfly that halves the number of live sums per step (32 -> 16 -> 8 -> 4 -> 2: ~110 instructions
+// instead of ~290 for 32 full reductions); a lane ends with two channels of one head.
+//   lane: key slot ks = (lane & 3) | (lane >> 4) << 2, channel quad q = (lane >> 2) & 3   (slot bits = lane bits 0, 1, 4, 5:
+//   xor 1 / xor 2 are single DPP moves, xor 16 / xor 32 the permlane swaps)
+template <int NG>
+__global__ __launch_bounds__(256) void ipa_pair_dz16_kernel(pf_ipa_attn_args a) {
+    constexpr int LPZ = 16 * NG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ks = (lane & 3) | ((lane >> 4) << 2), q = (lane >> 2) & 3;
+    const int L = a.L;
+    const long row = (long)blockIdx.x * 4 + wave;                // b * L + i
+    if (row >= (long)a.B * L) return;
+    const long b = row / L, i = row - b * L;
+    const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
+    if (i >= Le) return;                                         // (wave-uniform; nothing below synchronises the workgroup)
+    const int nge = (Le + 15) >> 4;
+    float* PL = smem + wave * 8 * LPZ;                           // [8][LPZ] probabilities of this row (0 from Le on)
+    const _Float16* drow = reinterpret_cast<const _Float16*>(a.dz) + (size_t)row * L * 16 + 4 * q;
+    half4 d[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u)
+        if (u < nge) d[u] = *reinterpret_cast<const half4*>(drow + (size_t)min(16 * u + ks, L - 1) * 16);
+    if ((L & 3) == 0) {
+        for (int idx = lane; idx < LPZ * 2; idx += 64) {         // float4 pieces of the 8 head rows
+            const int hh = idx / (LPZ / 4), j = 4 * (idx - hh * (LPZ / 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < Le) {
+                v = *reinterpret_cast<const float4*>(a.p_out + ((b * H + hh) * L + i) * L + j);
+                if (j + 1 >= Le) v.y = 0.f;                      // (the score kernel does not write beyond key Le - 1)
+                if (j + 2 >= Le) v.z = 0.f;
+                if (j + 3 >= Le) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(PL + hh * LPZ + j) = v;
+        }
+    } else {
+        for (int idx = lane; idx < LPZ * 8; idx += 64) {
+            const int hh = idx / LPZ, j = idx - hh * LPZ;
+            PL[idx] = j < Le ? a.p_out[((b * H + hh) * L + i) * L + j] : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private LDS hand-off
+    __builtin_amdgcn_wave_barrier();
+    float v[32];                                                 // v[4 h + t]: head h, channel 4 q + t
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        if (u < nge) {
+            const float d0 = (float)d[u][0], d1 = (float)d[u][1], d2 = (float)d[u][2], d3 = (float)d[u][3];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float ph = PL[h * LPZ + 16 * u + ks];       // (keys from Le on: P = 0 times a clamped, finite row)
+                v[4 * h] += ph * d0; v[4 * h + 1] += ph * d1; v[4 * h + 2] += ph * d2; v[4 * h + 3] += ph * d3;
+            }
+        }
+    }
+    // butterfly over the key slots: slot bit 0 (lane bit 0) splits on head bit 2, bit 1 on head bit 1, lane bit 4 on head bit 0,
+    // lane bit 5 on channel bit 1
+    float w[16], x[8], y[4], z2[2];
+    {
+        const bool hi = lane & 1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float send = hi ? v[k] : v[k + 16], keep = hi ? v[k + 16] : v[k];
+            w[k] = keep + lane_xor1(send);
+        }
+    }
+    {
+        const bool hi = lane & 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float send = hi ? w[k] : w[k + 8], keep = hi ? w[k + 8] : w[k];
+            x[k] = keep + lane_xor2(send);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                // rows 0, 2 (lane bit 4 = 0) keep x[k], rows 1, 3 keep x[k + 4]
+        auto rr = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[k]), __float_as_uint(x[k + 4]), false, false);
+        y[k] = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                                // lanes 0..31 keep y[k], lanes 32..63 keep y[k + 2]
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(y[k]), __float_as_uint(y[k + 2]), false, false);
+        z2[k] = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+    const int h = ((lane & 1) << 2) | (lane & 2) | ((lane >> 4) & 1), c = 4 * q + 2 * (lane >> 5);
+    const float2 bd = *reinterpret_cast<const float2*>(a.b_dz + c);
+    *reinterpret_cast<float2*>(a.feats + (size_t)row * PF_IPA_FEATS + 1408 + h * 16 + c) = make_float2(z2[0] + bd.x, z2[1] + bd.y);
+}
+
 }  // namespace
 
 // two-kernel IPA (called by pf_ipa_attn_fwd, ipa_attn.hip): requires a->bias and a->p_out, L <= 256
@@ -824,7 +918,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         const dim3 gridd((unsigned)((rows + 3) / 4));
         const size_t ldsd = (size_t)4 * 8 * 16 * ng * sizeof(float);
         switch (ng) {
-#define PF_PAIRDZ_CASE(N) case N: if (a->dz_f16) hipLaunchKernelGGL((ipa_pair_dz_kernel<N, true>), gridd, dim3(256), ldsd, s, *a); else hipLaunchKernelGGL((ipa_pair_dz_kernel<N, false>), gridd, dim3(256), ldsd, s, *a); break;
+#define PF_PAIRDZ_CASE(N) case N: if (a->dz_f16) hipLaunchKernelGGL(ipa_pair_dz16_kernel<N>, gridd, dim3(256), ldsd, s, *a); else hipLaunchKernelGGL((ipa_pair_dz_kernel<N, false>), gridd, dim3(256), ldsd, s, *a); break;
             PF_PAIRDZ_CASE(1) PF_PAIRDZ_CASE(2) PF_PAIRDZ_CASE(3) PF_PAIRDZ_CASE(4) PF_PAIRDZ_CASE(5) PF_PAIRDZ_CASE(6) PF_PAIRDZ_CASE(7)
             PF_PAIRDZ_CASE(8) PF_PAIRDZ_CASE(9) PF_PAIRDZ_CASE(10) PF_PAIRDZ_CASE(11) PF_PAIRDZ_CASE(12) PF_PAIRDZ_CASE(13)
             PF_PAIRDZ_CASE(14) PF_PAIRDZ_CASE(15) PF_PAIRDZ_CASE(16)
