@@ -405,23 +405,27 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
 #ifndef PF_WR_ROT
 #define PF_WR_ROT 7
 #endif
+// NRT = 4 (64 rows per workgroup, 16-feature weight tiles, the features divided among gridDim.y = 2 workgroups): the kernel is
+// bound by the L2 -> CU weight stream (256 workgroups x 2 MiB per launch at 32 rows); with 64 rows every fragment feeds four row
+// tiles and that stream is halved, at the same number of workgroups.
 constexpr int WR_BM = 32, WR_K = 128, WR_LDK = WR_K + 8;
-template <bool SP, bool ATT = false>           // ATT: attention operand planes (pf_linear_args.att_*), as in linear_split_kernel
+template <bool SP, bool ATT = false, int NRT = 2, int NWT = 2>   // ATT: attention operand planes (pf_linear_args.att_*), as in linear_split_kernel
 __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int Npad) {
-    __shared__ __attribute__((aligned(16))) _Float16 Xh[WR_BM * WR_LDK];
-    __shared__ __attribute__((aligned(16))) _Float16 Xl[WR_BM * WR_LDK];
-    __shared__ float RT[WR_BM * 12];                           // rotation | translation of the tile's rows (point columns)
+    constexpr int BM = 16 * NRT, TW = 16 * NWT;                // rows per workgroup, features per weight tile
+    __shared__ __attribute__((aligned(16))) _Float16 Xh[BM * WR_LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 Xl[BM * WR_LDK];
+    __shared__ float RT[BM * 12];                              // rotation | translation of the tile's rows (point columns)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * WR_BM;
-    {   // x tile -> hi / lo planes: 1024 float4, two per thread, both requested before the first conversion
-        float4 t[2];
+    const int m0 = blockIdx.x * BM;
+    {   // x tile -> hi / lo planes: 32 float4 per row, NRT per thread, all requested before the first conversion
+        float4 t[NRT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NRT; ++u) {
             const int idx = tid + u * 512, row = idx >> 5, c4 = idx & 31;
             t[u] = *reinterpret_cast<const float4*>(p.x + (size_t)min(m0 + row, p.M - 1) * p.ldx + 4 * c4);
         }
-        if (p.pt_rot && tid < WR_BM * 3) {                     // 12 floats per row as three float4-sized pieces (9 + 3)
+        if (p.pt_rot && tid < BM * 3) {                     // 12 floats per row as three float4-sized pieces (9 + 3)
             const int row = tid / 3, q = tid - row * 3, m = min(m0 + row, p.M - 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NRT; ++u) {
             const int idx = tid + u * 512, row = idx >> 5, c4 = idx & 31;
             const float keep = (m0 + row < p.M) ? 1.f : 0.f;
             const float v[4] = {t[u].x * keep, t[u].y * keep, t[u].z * keep, t[u].w * keep};
@@ -447,9 +451,9 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
     }
     __syncthreads();
     // this wave's B operands: rows 16 rt + r, K-step ks, slots 8 g .. + 7
-    half8 xh[2][4], xl[2][4];
+    half8 xh[NRT][4], xl[NRT][4];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             xh[rt][ks] = *reinterpret_cast<const half8*>(Xh + (rt * 16 + r) * WR_LDK + 32 * ks + 8 * g);
@@ -457,14 +461,15 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
         }
     const _Float16* whp = reinterpret_cast<const _Float16*>(p.w_f16);
     const _Float16* wlp = whp + (size_t)Npad * WR_K;
-    const int ntile2 = Npad >> 5;                              // 32-feature tiles (Npad % 32 == 0 is checked by the launcher)
-    struct WT { half8 h[2][4], l[2][4]; };
+    // TW-feature tiles of this workgroup: [tbase, tbase + ntile2) (Npad % (TW gridDim.y) == 0 is checked by the launcher)
+    const int ntile2 = Npad / (TW * (int)gridDim.y), tbase = blockIdx.y * ntile2;
+    struct WT { half8 h[NWT][4], l[NWT][4]; };
     auto loadw = [&](int t2, WT& w) {
 #pragma unroll
-        for (int wt = 0; wt < 2; ++wt)
+        for (int wt = 0; wt < NWT; ++wt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const size_t off = ((size_t)((2 * t2 + wt) * 4 + ks) * 64 + lane) * 8;
+                const size_t off = ((size_t)((NWT * t2 + wt) * 4 + ks) * 64 + lane) * 8;
                 w.h[wt][ks] = *reinterpret_cast<const half8*>(whp + off);
                 if constexpr (!SP) w.l[wt][ks] = *reinterpret_cast<const half8*>(wlp + off);
             }
@@ -472,21 +477,21 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
     const bool vec_ok = (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
     const int AL = p.att_L;
     auto tile = [&](int t2, const WT& w) {
-        f32x4 am[2][2], ac[2][2];
+        f32x4 am[NRT][NWT], ac[NRT][NWT];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int wt = 0; wt < 2; ++wt) { am[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        const int n0 = 32 * t2;
+            for (int wt = 0; wt < NWT; ++wt) { am[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[rt][wt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const int n0 = TW * t2;
         if (ATT && n0 >= 1024 && n0 < 3072 && (((n0 - 1024) >> 7) & 1)) {
             // value features: rows x features product (operands swapped) -> lane (r = feature, g) holds rows 4 g + e of a row
             // tile: transposed 8-byte stores into att_vt
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int wt = 0; wt < 2; ++wt)
+                for (int wt = 0; wt < NWT; ++wt)
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
+                    for (int rt = 0; rt < NRT; ++rt) {
                         am[rt][wt] = mfma_h(xh[rt][ks], w.h[wt][ks], am[rt][wt]);
                         if constexpr (!SP) {
                             ac[rt][wt] = mfma_h(xl[rt][ks], w.h[wt][ks], ac[rt][wt]);
@@ -495,12 +500,12 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                     }
             _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
 #pragma unroll
-            for (int wt = 0; wt < 2; ++wt) {
+            for (int wt = 0; wt < NWT; ++wt) {
                 const int n = n0 + wt * 16 + r;
                 const float bn = p.bias ? p.bias[n] : 0.f;
                 const int hd = (n - 1024) >> 8, c = ((n - 1024) & 255) - 128;
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
+                for (int rt = 0; rt < NRT; ++rt) {
                     const int mq = m0 + rt * 16 + 4 * g;                // four consecutive rows of one sample (L % 4 == 0)
                     if (mq >= p.M) continue;
                     const int bs = mq / AL, j = mq - bs * AL;
@@ -524,9 +529,9 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int wt = 0; wt < 2; ++wt)
+            for (int wt = 0; wt < NWT; ++wt)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
+                for (int rt = 0; rt < NRT; ++rt) {
                     am[rt][wt] = mfma_h(w.h[wt][ks], xh[rt][ks], am[rt][wt]);
                     if constexpr (!SP) {
                         ac[rt][wt] = mfma_h(w.h[wt][ks], xl[rt][ks], ac[rt][wt]);
@@ -534,13 +539,13 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                     }
                 }
 #pragma unroll
-        for (int wt = 0; wt < 2; ++wt) {
-            const int n = (2 * t2 + wt) * 16 + 4 * g;
+        for (int wt = 0; wt < NWT; ++wt) {
+            const int n = (NWT * t2 + wt) * 16 + 4 * g;
             float b4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) b4[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < NRT; ++rt) {
                 const int row = rt * 16 + r, m = m0 + row;
                 if (m >= p.M) continue;
                 float v[4];
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
     //  at the same time hammer the same L2 channels -- 59 us; rotated 50-51 us.  Non-temporal output stores: no change.)
     WT wa, wb;
     const int rot = (int)((blockIdx.x * (unsigned)PF_WR_ROT) % (unsigned)ntile2);
-    auto tid2 = [&](int i) { int t = i + rot; return t >= ntile2 ? t - ntile2 : t; };   // i < ntile2
+    auto tid2 = [&](int i) { int t = i + rot; return tbase + (t >= ntile2 ? t - ntile2 : t); };   // i < ntile2
     int i2 = wave;
     if (i2 >= ntile2) return;
     loadw(tid2(i2), wa);
@@ -708,6 +713,17 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         if (rows_fit && a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->relu && !a->row_mask &&
             !a->residual && !a->gate &&
             (!a->att_qk || (a->single_pass && a->pt_rot && a->att_vt && a->att_L > 0 && a->att_L % 16 == 0))) {   // (planes: f16 mode only -- 256 VGPRs + spills in split form)
+            // 64-row form (two workgroups per 64 rows, half of the features each) when it also fills whole rounds
+            const long nwg64 = (a->M + 63) / 64 * 2;
+            static const int rows64 = [] { const char* e = getenv("PF_WR_ROWS64"); return e ? atoi(e) : 1; }();
+            if (rows64 && Npad % 32 == 0 && nwg64 * 10 >= ((nwg64 + 255) / 256) * 256 * 9) {
+                const dim3 grid64((unsigned)((a->M + 63) / 64), 2);
+                if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true, 4, 1>), grid64, dim3(512), 0, s, *a, Npad);
+                else if (a->single_pass) hipLaunchKernelGGL((linear_rows_kernel<true, false, 4, 1>), grid64, dim3(512), 0, s, *a, Npad);
+                else hipLaunchKernelGGL((linear_rows_kernel<false, false, 4, 1>), grid64, dim3(512), 0, s, *a, Npad);
+                PF_CHECK_LAUNCH();
+                return 0;
+            }
             const dim3 grid((a->M + WR_BM - 1) / WR_BM);
             if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true>), grid, dim3(512), 0, s, *a, Npad);
             else if (a->single_pass) hipLaunchKernelGGL(linear_rows_kernel<true>, grid, dim3(512), 0, s, *a, Npad);
