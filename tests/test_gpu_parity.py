@@ -789,6 +789,25 @@ def test_masked_tiles_and_keys_are_skipped_exactly(model, seeded_sd, precision):
         model.ga_encoder.set_precision("fp32")
 
 
+def test_f16_mode_at_a_length_that_is_not_a_multiple_of_16(model, seeded_sd):
+    """f16 mode with L = 70: the pair tensor stays fp32 there (engine.z16 needs L % 16 == 0) while the two-kernel attention and the
+    pair values (fp32 storage, emitted by the single-pass EdgeTransition kernel) are in use -- vs the oracle at the f16 tolerance."""
+    B, L = 3, 70
+    batch = synth.make_pocket_batch(B, L, 6, seed=707, lengths=[70, 41, 66])
+    resm = batch["res_mask"]
+    t, R_t, x_t, ang_t, seq_t, node, edge = _encoder_case(seeded_sd, batch, resm, 11)
+    ref = O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, node, edge, resm.long())
+    model.ga_encoder.set_precision("f16")
+    try:
+        out = model.ga_encoder(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t), cu(node), cu(edge), cu(batch["generate_mask"].long()), cu(resm.long()))
+        G.sync()
+    finally:
+        model.ga_encoder.set_precision("fp32")
+    G.assert_close(out[0].cpu()[resm], ref[0][resm], 2e-2, "rotmats")
+    G.assert_close(out[1].cpu()[resm], ref[1][resm], 2e-2, "trans")
+    G.assert_close(out[3].cpu()[resm], ref[3][resm], 5e-2, "logits")
+
+
 def test_encode_ragged_vs_oracle(model, seeded_sd):
     batch = synth.make_pocket_batch(3, 21, 5, seed=77, lengths=[21, 13, 20])
     ref = O.encode(seeded_sd, batch)
