@@ -264,7 +264,8 @@ def main():
         "kernel": "edge_transition_v3_kernel (pf_edge_transition_fwd)", "bound": "mfma",
         "achieved": pairs * ET_FLOPS_EXEC / et_s / 1e12, "peak": MFMA_F16_PEAK / split / 1e12, "unit": "TFLOP/s",
         "frac": pairs * ET_FLOPS_EXEC * split / et_s / MFMA_F16_PEAK, "traffic": t_et,
-        "traffic_note": f"HBM bytes per launch from {traffic_src} (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair = {pairs * ET_BYTES} B",
+        "traffic_note": f"HBM bytes per launch from {traffic_src} (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair = {pairs * ET_BYTES} B "
+                        "(+ 96 B/pair the kernel also writes for the NEXT attention block: 32 B pair bias + 64 B pair values, 32 as f16)",
         "note": ("fp32-equivalent FLOPs; 3 f16 MFMA products per fp32 product (split precision), peak = 2.5 PF/3" if split == 3
                  else "one f16 MFMA product per product, peak = 2.5 PF dense"),
         "avg_launch_us": et_s * 1e6, "flops_per_pair_executed": ET_FLOPS_EXEC, "share_of_step": share.get("pf_edge_transition_fwd"),
