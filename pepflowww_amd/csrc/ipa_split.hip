@@ -13,6 +13,10 @@
 //   ipa_pair_kernel    one wave per query row: zbar[h][c] = sum_j P[h][j] z[i][j][c] streamed at HBM rate (z is read exactly once
 //        per block, 256 B/pair = the algorithmic traffic of the step), then o_pair = W_dz zbar + b_dz (linear in z, so the
 //        [B,L,L,16] pair_z tensor of the reference never exists).
+//   ipa_pair_dz_kernel / ipa_pair_dz16_kernel   the same aggregation on the pair VALUES dz = W_dz z (pf_ipa_attn_args.dz, [B,L,L,16]
+//        fp32 / f16) that the EdgeTransition kernel producing z emits from its registers (pf_edge_transition_args.dz_out): here
+//        that tensor DOES exist, because writing 64 B per pair once and reading it once is cheaper than reading the 256 B of z
+//        a second time (62.7 -> 26 us per block at B=64, L=128).
 #include <type_traits>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
