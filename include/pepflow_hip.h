@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 38
+#define PF_ABI_VERSION 39
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -88,6 +88,12 @@ typedef struct {
      *   att_vt : values TRANSPOSED per (sample, head): [B][8][PF_ATT_VROWS = 128 channels + 36 point coordinates][L keys];
      *            fp32 mode: key octets interleaved (hi8 | lo8), 2 L f16 per row; f16 mode: L f16 per row */
     void* att_qk; void* att_vt; int att_L;
+    /* optional (split path): the rows are [B][key_L] residues and key_end[b] (device memory, int32 [B]) = 1 + the last unmasked
+     * residue of sample b (the same list as pf_ipa_attn_args.key_end).  A row tile that lies entirely at or beyond its samples'
+     * key ends is SKIPPED: x is not read, y / the point and attention outputs of those rows are NOT written (their consumers skip
+     * the same rows; the caller keeps the buffers finite).  active_rows (host side hint, 0 = unknown) = sum of key_end: lets the
+     * launcher pick the rows-persistent kernel when the ACTIVE tiles fit whole rounds of workgroups. */
+    const int* key_end; int key_L; int active_rows;
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 /* W [N,K] fp32 (ldw) -- or W^T when `transpose` (then w is [K,N], ldw >= N) -- to the fragment-order f16 hi/lo planes
@@ -210,6 +216,8 @@ typedef struct {
     float* qkv;                    /* [rows,384] */
     int rows;
     int single_pass;               /* 1 = f16 precision mode: one f16 MFMA per product (hi weight planes only) */
+    /* optional: rows = [B][key_L]; row tiles entirely at or beyond their samples' key_end[b] are skipped (see pf_linear_args) */
+    const int* key_end; int key_L;
 } pf_node_head_args;
 int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream);
 
@@ -248,6 +256,9 @@ typedef struct {
     float* ang_out;                /* [B*L,5] (before the % 2pi of ga.py:125) */
     int single_pass;               /* 1 = f16 precision mode: one f16 MFMA per product (hi weight planes only); the attention core,
                                       LayerNorms, residuals and the frame update stay fp32 */
+    /* optional: query-row tiles that start at or beyond key_end[b] of their sample are skipped -- nothing of theirs is written
+     * (s_out, frames, pre, qkv_out, v_out, logits_out, ang_out keep what they held; see pf_linear_args.key_end) */
+    const int* key_end;
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -23,7 +23,7 @@ class LinearArgs(C.Structure):
                 ("mask_post", _i), ("residual", _fp), ("ldr", _i), ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("ln_eps", C.c_float), ("w_f16", _fp), ("gate", _fp), ("ldg", _i),
                 ("pt_rot", _fp), ("pt_trans", _fp), ("pt_qp", _fp), ("pt_kp", _fp), ("pt_vp", _fp), ("pt_col0", _i),
-                ("single_pass", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_L", _i)]
+                ("single_pass", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_L", _i), ("key_end", _fp), ("key_L", _i), ("active_rows", _i)]
 
 
 class EmbedArgs(C.Structure):
@@ -146,7 +146,7 @@ class EdgeFeatArgs(C.Structure):
 
 class NodeHeadArgs(C.Structure):
     _fields_ = [("feats", _fp), ("s_in", _fp), ("mask", _fp), ("w_out_f16", _fp), ("b_out", _fp), ("ln_g", _fp),
-                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i), ("single_pass", _i)]
+                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i), ("single_pass", _i), ("key_end", _fp), ("key_L", _i)]
 
 
 class NodeTfmrArgs(C.Structure):
@@ -159,7 +159,7 @@ class NodeTfmrArgs(C.Structure):
                 ("b_bb", _fp), ("s_out", _fp), ("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp),
                 ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("has_et", _i),
                 ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i),
-                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i)]
+                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp)]
 
 
 _SIGNATURES = {

@@ -62,6 +62,20 @@ __device__ __forceinline__ float max_xor32(float v) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// Row tiles of padded batches (pf_linear_args / pf_node_*_args.key_end): rows are [B][L] residues, key_end[b] = 1 + the last unmasked
+// residue of sample b.  True if every row of [m0, m0 + n) (clipped to M) lies at or beyond its sample's key end: such a tile is
+// skipped by its workgroup (uniform over the workgroup: a few scalar loads, no barrier).
+__device__ __forceinline__ bool pf_rows_all_masked(const int* __restrict__ key_end, int L, int m0, int n, int M) {
+    if (!key_end) return false;
+    const int mend = m0 + n < M ? m0 + n : M;
+    int m = m0;
+    while (m < mend) {
+        const int b = m / L, i = m - b * L;
+        if (i < key_end[b]) return false;
+        m = (b + 1) * L;
+    }
+    return true;
+}
 // sum / max over the 16 lanes of a row (every lane gets the result); same tree as xor 8,4,2,1
 __device__ __forceinline__ float row16_sum(float v) {
     v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v);

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * SP_BM;
+    if (pf_rows_all_masked(p.key_end, p.key_L, m0, SP_BM, p.M)) return;   // padded batch: nothing of this row tile is consumed
     const int n0 = blockIdx.y * SP_BN + wave * 32;
     const bool wave_on = n0 < Npad;
     const int kq = K >> 2;
@@ -417,7 +418,15 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
     __shared__ float RT[BM * 12];                              // rotation | translation of the tile's rows (point columns)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    // padded batch (key_end, launched with gridDim.x = B ceil(L / BM)): row tiles per SAMPLE; a tile that starts at or beyond the
+    // sample's key end does nothing (see node_head32_kernel)
+    int m0 = blockIdx.x * BM;
+    if (p.key_end) {
+        const int tps = (p.key_L + BM - 1) / BM, b = blockIdx.x / tps, i0 = (blockIdx.x - b * tps) * BM;
+        if (i0 >= p.key_end[b]) return;
+        m0 = b * p.key_L + i0;
+        p.M = (b + 1) * p.key_L;               // rows of the next sample are that sample's tiles' business
+    }
     {   // x tile -> hi / lo planes: 32 float4 per row, NRT per thread, all requested before the first conversion
         float4 t[NRT];
 #pragma unroll
@@ -708,28 +717,44 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         // the IPA projection of large batches: rows-persistent form (one workgroup = 32 rows x all features)
         // ... when its workgroups fill whole rounds of the 256 CUs (>= 90 %): one workgroup is ~1/256 of the launch, so 288 of them
         // (B=64, L=144) would take two rounds -- the tiled kernel below is faster there
-        const long nwg_rows = (a->M + WR_BM - 1) / WR_BM;
-        const bool rows_fit = nwg_rows * 10 >= ((nwg_rows + 255) / 256) * 256 * 9;
+        // Padded batch with key ends: the rows-persistent kernel tiles it per SAMPLE and tiles beyond a sample's key end exit at
+        // once, so only the ACTIVE tiles count -- estimated from the caller's active_rows as half a partial tile per sample more
+        // than their share of the rows.  Such an estimate must leave 10 % of one round free: the active tiles are spread unevenly
+        // over the XCDs, and at 250 of 256 some XCD gets more than one per CU -- a second, unloaded round (72 vs 50 us measured).
+        const bool per_sample = a->key_end && a->key_L > 0 && a->M % a->key_L == 0;
+        const long nsamp = per_sample ? a->M / a->key_L : 0;
+        auto grid_tiles = [&](int bm) { return per_sample ? nsamp * ((a->key_L + bm - 1) / bm) : (long)((a->M + bm - 1) / bm); };
+        auto fits = [&](int bm, int split) {       // workgroups of bm rows, `split` per row tile
+            const long all = grid_tiles(bm) * split;
+            const long est = per_sample && a->active_rows > 0 ? ((long)a->active_rows / bm + (nsamp + 1) / 2) * split : all;
+            if (est < all) return est >= 128 && est <= 230;
+            return all <= 256 ? all >= 128 : all * 10 >= ((all + 255) / 256) * 256 * 9;
+        };
+        pf_linear_args ar = *a;                                     // (key_end only in the per-sample form)
+        if (!per_sample) ar.key_end = nullptr;
+        const bool fit32 = fits(WR_BM, 1), fit64 = fits(64, 2);
+        const bool rows_fit = fit32 || fit64;
         if (rows_fit && a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->relu && !a->row_mask &&
             !a->residual && !a->gate &&
             (!a->att_qk || (a->single_pass && a->pt_rot && a->att_vt && a->att_L > 0 && a->att_L % 16 == 0))) {   // (planes: f16 mode only -- 256 VGPRs + spills in split form)
-            // 64-row form (two workgroups per 64 rows, half of the features each) when it also fills whole rounds
-            const long nwg64 = (a->M + 63) / 64 * 2;
+            // 64-row form (two workgroups per 64 rows, half of the features each) when it also fits
             static const int rows64 = [] { const char* e = getenv("PF_WR_ROWS64"); return e ? atoi(e) : 1; }();
-            if (rows64 && Npad % 32 == 0 && nwg64 * 10 >= ((nwg64 + 255) / 256) * 256 * 9) {
-                const dim3 grid64((unsigned)((a->M + 63) / 64), 2);
-                if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true, 4, 1>), grid64, dim3(512), 0, s, *a, Npad);
-                else if (a->single_pass) hipLaunchKernelGGL((linear_rows_kernel<true, false, 4, 1>), grid64, dim3(512), 0, s, *a, Npad);
-                else hipLaunchKernelGGL((linear_rows_kernel<false, false, 4, 1>), grid64, dim3(512), 0, s, *a, Npad);
+            if (rows64 && Npad % 32 == 0 && fit64) {
+                const dim3 grid64((unsigned)grid_tiles(64), 2);
+                if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
+                else if (a->single_pass) hipLaunchKernelGGL((linear_rows_kernel<true, false, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
+                else hipLaunchKernelGGL((linear_rows_kernel<false, false, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
                 PF_CHECK_LAUNCH();
                 return 0;
             }
-            const dim3 grid((a->M + WR_BM - 1) / WR_BM);
-            if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true>), grid, dim3(512), 0, s, *a, Npad);
-            else if (a->single_pass) hipLaunchKernelGGL(linear_rows_kernel<true>, grid, dim3(512), 0, s, *a, Npad);
-            else hipLaunchKernelGGL(linear_rows_kernel<false>, grid, dim3(512), 0, s, *a, Npad);
-            PF_CHECK_LAUNCH();
-            return 0;
+            if (fit32) {
+                const dim3 grid((unsigned)grid_tiles(WR_BM));
+                if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true>), grid, dim3(512), 0, s, ar, Npad);
+                else if (a->single_pass) hipLaunchKernelGGL(linear_rows_kernel<true>, grid, dim3(512), 0, s, ar, Npad);
+                else hipLaunchKernelGGL(linear_rows_kernel<false>, grid, dim3(512), 0, s, ar, Npad);
+                PF_CHECK_LAUNCH();
+                return 0;
+            }
         }
         const unsigned gm = (a->M + SP_BM - 1) / SP_BM;
         if (Npad > 128 && Npad <= 192 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<6>, dim3(gm, 1), dim3(384), lds, s, *a, Npad);

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * TR, M = a.rows;
+    if (pf_rows_all_masked(a.key_end, a.key_L, m0, TR, M)) return;         // padded batch: nothing of this row tile is consumed
     const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
 
     WSplit<1, 8, SP> ws;
@@ -221,7 +222,16 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_h
     Planes Xa = {reinterpret_cast<_Float16*>(X + TR2 * LDX), reinterpret_cast<_Float16*>(X + TR2 * LDX) + TR2 * LDP};
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * TR2, M = a.rows;
+    // padded batch (key_end): row tiles per SAMPLE (grid = B ceil(L / 32)), a tile that starts at or beyond the sample's key end
+    // does nothing -- with flat tiles ~1 partial tile per sample more stayed active, and the active tiles must stay below one per CU
+    // on every XCD (a second round costs a full unloaded workgroup latency, ~14 us)
+    int m0 = blockIdx.x * TR2, M = a.rows;
+    if (a.key_end) {
+        const int tps = (a.key_L + TR2 - 1) / TR2, b = blockIdx.x / tps, i0 = (blockIdx.x - b * tps) * TR2;
+        if (i0 >= a.key_end[b]) return;
+        m0 = b * a.key_L + i0;
+        M = (b + 1) * a.key_L;                 // rows of the next sample are that sample's tiles' business
+    }
     const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
 
     WSplit<1, 8, SP> ws;
@@ -337,10 +347,14 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
     const int tiles = (L + TR - 1) / TR;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);   // the query tiles of one sample share its K/V: same XCD/L2
+    // the query tiles of one sample share its K/V: same XCD / L2 -- but not in a padded batch (key_end): the ACTIVE tiles must be
+    // spread evenly over the XCDs there (8 whole samples per XCD put > 32 active tiles on some XCD = a second round)
+    const int lid = a.key_end ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / tiles;
     const int i0 = (lid - b * tiles) * TR;
     const size_t rowb = (size_t)b * L;
+    // padded batch: a query tile at or beyond the sample's last unmasked residue does nothing (pf_node_tfmr_args.key_end)
+    if (a.key_end && i0 >= __builtin_amdgcn_readfirstlane(a.key_end[b])) return;
     const int m0 = (int)rowb + i0;           // global row of tile row 0
     const int M = (int)rowb + L;             // rows of this sample end here (tile rows beyond are padding)
     const int n = wave * 16 + 4 * g;         // this lane's 4 consecutive output features in the 128-wide stages
@@ -947,7 +961,11 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
             (void)hipFuncSetAttribute((const void*)node_head32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        const dim3 grid((unsigned)((a->rows + TR2 - 1) / TR2));
+        const bool per_sample = a->key_end && a->key_L > 0 && a->rows % a->key_L == 0;
+        pf_node_head_args aa = *a;
+        if (!per_sample) aa.key_end = nullptr;
+        const dim3 grid(per_sample ? (unsigned)((a->rows / a->key_L) * ((a->key_L + TR2 - 1) / TR2)) : (unsigned)((a->rows + TR2 - 1) / TR2));
+        a = &aa;
         if (a->single_pass) hipLaunchKernelGGL(node_head32_kernel<true>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(node_head32_kernel<false>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
         PF_CHECK_LAUNCH();

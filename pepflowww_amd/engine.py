@@ -348,6 +348,10 @@ class DenoiseEngine:
         self.et_tiles.copy_(order.to(torch.int32))
         self.et_ntiles.copy_(active.sum().to(torch.int32).reshape(1))
         self.key_end.copy_((m.to(torch.int32) * torch.arange(1, L + 1, device=m.device, dtype=torch.int32)).amax(-1))
+        # host-side hint for the projection's kernel choice (pf_linear_args.active_rows): the one host read per bind_context
+        self.active_rows = int(self.key_end.sum().item())
+        for la in getattr(self, "_proj_args", []):
+            la.active_rows = self.active_rows
         self.zbuf.zero_()
         self.pair_bias.zero_()
         if self.pair_dz is not None:
@@ -356,6 +360,7 @@ class DenoiseEngine:
     def _build_plan(self):
         w, lib = self.w, self.lib
         self._keep = []
+        self._proj_args = []
         plan = []
         B, L, rows = self.B, self.L, self.rows
         lin = self._linear
@@ -380,6 +385,8 @@ class DenoiseEngine:
             la.single_pass = int(self.precision == "f16")
             la.pt_rot, la.pt_trans, la.pt_col0 = rot.data_ptr(), trans.data_ptr(), 3072
             la.pt_qp, la.pt_kp, la.pt_vp = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr()
+            la.key_end, la.key_L, la.active_rows = self.key_end.data_ptr(), L, self.active_rows   # padded batch: row tiles beyond are skipped
+            self._proj_args.append(la)
             if self.att_planes:
                 la.att_qk, la.att_vt, la.att_L = self.att_qk.data_ptr(), self.att_vt.data_ptr(), L
             plan.append(e + (lane,))
@@ -415,6 +422,7 @@ class DenoiseEngine:
             ha.w_in_f16, ha.b_in = w[f"{b}.0.in.w16"].data_ptr(), w[f"{b}.0.in.b"].data_ptr()
             ha.s_ipa, ha.qkv, ha.rows = self.s.data_ptr(), self.qkv.data_ptr(), rows
             ha.single_pass = int(self.precision == "f16")
+            ha.key_end, ha.key_L = self.key_end.data_ptr(), L         # padded batch: row tiles beyond a sample's key end are skipped
             self._keep.append(ha)
             plan.append((lib.pf_node_head_fwd, C.byref(ha), "pf_node_head_fwd"))
             for l in range(2):
@@ -422,6 +430,7 @@ class DenoiseEngine:
                 ta.qkv = (self.qkv if l == 0 else self.qkv2).data_ptr()
                 ta.resid = (self.s if l == 0 else self.v).data_ptr()
                 ta.mask = self.mask.data_ptr()
+                ta.key_end = self.key_end.data_ptr()
                 ta.w_o_f16, ta.b_o = w[f"{b}.{l}.out.w16"].data_ptr(), w[f"{b}.{l}.out.b"].data_ptr()
                 ta.n1_g, ta.n1_b = w[f"{b}.{l}.norm1.w"].data_ptr(), w[f"{b}.{l}.norm1.b"].data_ptr()
                 ta.w_1_f16, ta.b_1 = w[f"{b}.{l}.linear1.w16"].data_ptr(), w[f"{b}.{l}.linear1.b"].data_ptr()
