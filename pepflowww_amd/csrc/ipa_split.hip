@@ -17,6 +17,7 @@
 //        fp32 / f16) that the EdgeTransition kernel producing z emits from its registers (pf_edge_transition_args.dz_out): here
 //        that tensor DOES exist, because writing 64 B per pair once and reading it once is cheaper than reading the 256 B of z
 //        a second time (62.7 -> 26 us per block at B=64, L=128).
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
@@ -879,6 +880,10 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         const size_t fixed = ((size_t)LP * KPS + LP + (size_t)LP * VPS) * sizeof(float), per_wave = (size_t)16 * SLD * sizeof(float);
         int wmax = (int)((160 * 1024 - fixed) / per_wave);
         wmax = wmax > WMAX ? WMAX : wmax;
+        // query tiles that do not divide into 8-wave workgroups (128 < L < 256): workgroups of <= 4 waves -- at L = 144 three 3-wave
+        // workgroups (65 KB of LDS: two per CU) measured 121 us against 149 for 5 + 5 waves (one per CU) and 153 for 8 + 1; with 8
+        // tiles (L = 128) one 8-wave workgroup stays best (105 vs 109 / 137 us for 2 x 4 / 3 x 3)
+        if (tiles > WMAX && tiles % WMAX != 0 && wmax > 4) wmax = 4;
         if (wmax < 1) return PF_E_TOOLARGE;
         const int nrb = (tiles + wmax - 1) / wmax;
         const int wpb = (tiles + nrb - 1) / nrb;
@@ -894,6 +899,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
             int wm = (int)((160 * 1024 - fixed16) / pw16);
             wm = wm > WMAX ? WMAX : wm;
+            if (tiles > WMAX && tiles % WMAX != 0 && wm > 4) wm = 4;          // (as above: 83.5 -> 73.5 us at L = 144)
             if (wm < 1) return PF_E_TOOLARGE;
             const int nrb16 = (tiles + wm - 1) / wm, wpb16 = (tiles + nrb16 - 1) / nrb16;
             const size_t lds16 = fixed16 + wpb16 * pw16;
