@@ -589,6 +589,53 @@ def test_linear_rows_persistent_projection(M):
     G.assert_close(vp2, vp[: M - 64], 1e-6, "tiled vs rows-persistent (points)")
 
 
+def test_projection_skips_row_tiles_beyond_the_key_end():
+    """pf_linear_args.key_end / key_L / active_rows (padded batch, rows = [B][L]): per-sample row tiles that start at or beyond a
+    sample's key end are not written; every row below its key end equals the run without the list (rows-persistent kernel chosen
+    from the active-tile estimate) -- B=64, L=144 with the lengths of the cfg3 workload."""
+    import ctypes as C
+    from pepflowww_amd.engine import split_f16
+    B, L, N, K, C0 = 64, 144, 3968, 128, 3072
+    M = B * L
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    q = torch.randn(M, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True)).reshape(M, 9)
+    T = torch.randn(M, 3, generator=g) * 10
+    ke = torch.randint(48, 146, (B,), generator=g).clamp(max=L).to(torch.int32)
+    ke[3] = 0                                                                # a fully masked sample
+    lib = _capi.load()
+    xs, ws, bs, Rs, Ts, w16 = cu(x), cu(w), cu(b), cu(R), cu(T), split_f16(cu(w))
+
+    def run(key_end):
+        y = torch.full((M, C0), float("nan"), device=G.dev())
+        qp, kp, vp = (torch.full((M, n), float("nan"), device=G.dev()) for n in (192, 192, 288))
+        a = _capi.LinearArgs()
+        a.x, a.ldx, a.w, a.ldw, a.bias = G._p(xs), K, G._p(ws), K, G._p(bs)
+        a.y, a.ldy, a.M, a.N, a.K = G._p(y), C0, M, N, K
+        a.w_f16 = G._p(w16)
+        a.pt_rot, a.pt_trans, a.pt_qp, a.pt_kp, a.pt_vp, a.pt_col0 = G._p(Rs), G._p(Ts), G._p(qp), G._p(kp), G._p(vp), C0
+        if key_end is not None:
+            kd = cu(key_end)
+            a.key_end, a.key_L, a.active_rows = G._p(kd), L, int(key_end.sum())
+        _capi.check(lib.pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
+        G.sync()
+        return y.cpu().view(B, L, C0), vp.cpu().view(B, L, 288)
+
+    y0, v0 = run(None)
+    y1, v1 = run(ke)
+    i = torch.arange(L)[None, :]
+    below = i < ke[:, None]
+    G.assert_close(y1[below], y0[below], 1e-6, "rows below the key end")
+    G.assert_close(v1[below], v0[below], 1e-6, "value points below the key end")
+    tile_start = (i // 32) * 32
+    skipped = tile_start >= ke[:, None]                                      # whole 32-row tiles of a sample beyond its key end
+    assert skipped.any() and torch.isnan(y1[skipped]).all() and torch.isnan(v1[skipped]).all()
+    assert not torch.isnan(y0).any()
+
+
 def test_encode_matches_reference(f2, model):
     b = {k: cu(v) for k, v in _batch(f2).items()}
     R1, x1, ang1, seq1, node, edge = model.encode(b)
