@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace stats of the bench (run ON the GPU box through gpurun); top rows -> gpurun_out/<tag>_<workload>_kernel_stats.csv
 TAG=${1:-v3}; PREC=${2:-fp32}; cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 [ $PREC = fp32 ] || TAG=${TAG}_$PREC
-for W in cfg2 cfg4; do
+for W in cfg2 cfg4 cfg3; do
   if [ $W = cfg2 ]; then K=20; WU=3; else K=10; WU=2; fi
   OUT=gpurun_out/ks_${TAG}_$W; rm -rf $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps $K --warmup $WU --no-graph --no-cpu-baseline --no-secondary --workload $W --precision $PREC > $OUT.log 2>&1
