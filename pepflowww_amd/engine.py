@@ -352,6 +352,8 @@ class DenoiseEngine:
         self.active_rows = int(self.key_end.sum().item())
         for la in getattr(self, "_proj_args", []):
             la.active_rows = self.active_rows
+        for ta in getattr(self, "_tfmr_args", []):
+            ta.key_end = self.key_end.data_ptr() if self.active_rows < B * L else None
         self.zbuf.zero_()
         self.pair_bias.zero_()
         if self.pair_dz is not None:
@@ -361,6 +363,7 @@ class DenoiseEngine:
         w, lib = self.w, self.lib
         self._keep = []
         self._proj_args = []
+        self._tfmr_args = []
         plan = []
         B, L, rows = self.B, self.L, self.rows
         lin = self._linear
@@ -430,7 +433,10 @@ class DenoiseEngine:
                 ta.qkv = (self.qkv if l == 0 else self.qkv2).data_ptr()
                 ta.resid = (self.s if l == 0 else self.v).data_ptr()
                 ta.mask = self.mask.data_ptr()
-                ta.key_end = self.key_end.data_ptr()
+                # (padded batches only: with key_end the kernel gives up the XCD grouping of a sample's query tiles, which costs an
+                #  unpadded batch 1-2 us per launch)
+                ta.key_end = self.key_end.data_ptr() if self.active_rows < rows else None
+                self._tfmr_args.append(ta)
                 ta.w_o_f16, ta.b_o = w[f"{b}.{l}.out.w16"].data_ptr(), w[f"{b}.{l}.out.b"].data_ptr()
                 ta.n1_g, ta.n1_b = w[f"{b}.{l}.norm1.w"].data_ptr(), w[f"{b}.{l}.norm1.b"].data_ptr()
                 ta.w_1_f16, ta.b_1 = w[f"{b}.{l}.linear1.w16"].data_ptr(), w[f"{b}.{l}.linear1.b"].data_ptr()
