@@ -277,7 +277,7 @@ def main():
         "achieved": pairs * IPA_BYTES / ipa_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": pairs * IPA_BYTES / ipa_s / HBM_PEAK, "traffic": t_ipa,
         "traffic_note": f"HBM bytes per launch from {traffic_src}; algorithmic = 256 B/pair (one read of z, SURVEY.md 8(d)) = {pairs * IPA_BYTES} B; "
-                        "since r02t the pair aggregation reads the pair values W_dz z (64 B/pair, 32 in the f16 mode) that the EdgeTransition "
+                        "since round 2 (r02t) the pair aggregation reads the pair values W_dz z (64 B/pair, 32 in the f16 mode) that the EdgeTransition "
                         "kernel emits instead of z itself, so the measured traffic lies BELOW the algorithmic figure",
         "avg_launch_us": ipa_s * 1e6, "share_of_step": share.get("pf_ipa_attn_fwd"),
     }
