@@ -75,6 +75,8 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
     const int kt = (Le + 15) >> 4, ktf = Le >> 4;  // key tiles, full key tiles
     const bool wave_on = i0 < Le;
+    if (rb * rows_per_block >= Le) return;         // padded batch: a workgroup whose query rows all lie beyond the key end (uniform)
+    const int LPe = 16 * kt;                       // keys staged in LDS (<= LP)
     PROFS(0);
 
     // ---- operands of this wave's 16 queries, requested first (they come from the projection kernel's output) ----
@@ -98,15 +100,15 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     if (wave_on) loadk(0, kf);
 
     // ---- key points / key mask of the head -> LDS (all waves) ----
-    for (int idx = tid; idx < LP * 6; idx += blockDim.x) {
+    for (int idx = tid; idx < LPe * 6; idx += blockDim.x) {
         const int j = idx / 6, q = idx - j * 6;
         const float4 v = *reinterpret_cast<const float4*>(a.kp + (rowb + min(j, L - 1)) * 192 + h * 24 + 4 * q);
         *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = v;
     }
-    for (int j = tid; j < LP; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + j] : 0.f;
+    for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + j] : 0.f;
     // value points of the head -> LDS as well: read per key tile they were 12 dword loads per lane and tile in every wave (4-8 cache
     // lines per instruction); with the value loads below they made up 25 of the kernel's 114 us (what-if build without them: 89)
-    for (int idx = tid; idx < LP * 9; idx += blockDim.x) {
+    for (int idx = tid; idx < LPe * 9; idx += blockDim.x) {
         const int j = idx / 9, q = idx - j * 9;
         *reinterpret_cast<float4*>(VP + j * VPS + 4 * q) = *reinterpret_cast<const float4*>(a.vp + (rowb + min(j, L - 1)) * 288 + h * 36 + 4 * q);
     }
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     const int L32 = (LK + 31) & ~31;
     const int kt = LK >> 4;
     const bool wave_on = i0 < LK;
+    if (rb * rows_per_block >= LK) return;         // padded batch: a workgroup whose query rows all lie beyond the key end (uniform)
     const int iq = i0 + r;                         // (< L: L is a multiple of 16)
     PROFS(0);
 
@@ -361,11 +364,11 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     half8 kh[4], kl[4], nh[4], nl[4];
     if (wave_on) loadk(0, kh, kl);
 
-    for (int idx = tid; idx < L * 6; idx += blockDim.x) {
+    for (int idx = tid; idx < LK * 6; idx += blockDim.x) {         // (the keys this sample uses: LK <= L)
         const int j = idx / 6, q = idx - j * 6;
         *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = *reinterpret_cast<const float4*>(a.kp + (rowb + j) * 192 + h * 24 + 4 * q);
     }
-    for (int j = tid; j < L; j += blockDim.x) MJ[j] = a.mask[rowb + j];
+    for (int j = tid; j < LK; j += blockDim.x) MJ[j] = a.mask[rowb + j];
     __syncthreads();
     if (!wave_on) return;
     PROFS(1);
