@@ -673,6 +673,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         __syncthreads();
         ln_tile<TR>(T0, ln2, 1.f, Xb, m0, M, nullptr);
         __syncthreads();
+        PROF(7);
         // ---- s = s_ipa + post_tfmr(v) -> T1 (fp32) + planes Xa                 (ga.py:107) ----
         zero();
         gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
@@ -688,6 +689,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             put_planes(Xa, 16 * rt + r, n, v);
         }
         __syncthreads();
+        PROF(8);
         // ---- StructureModuleTransition: relu(l1) -> Xb, relu(l2) -> Xa, l3 + s -> T0, LN, * mask ----
         zero();
         gemm_split16r<1, 4, SP, RT>(ws, Xa.h, Xa.l, LDP, am, ac, 0, 4);
@@ -731,6 +733,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         __syncthreads();
         ln_tile<TR>(T0, ln3, lnmask_ld * (lnrow < M ? 1.f : 0.f), Xb, m0, M, a.s_out);           // s_new (masked) -> global + planes Xb
         __syncthreads();
+        PROF(9);
         if (do_bb || do_init) {
             zero();
             gemm_split16r<1, 4, SP, RT>(ws, Xb.h, Xb.l, LDP, am, ac, 0, 4);
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
 #pragma unroll
             for (int k = 0; k < 9; ++k) a.rot_out[(size_t)m * 9 + k] = Ro[k];
         }
+        PROF(10);
         // ---- EdgeTransition per-residue terms pre[rows,512] = W_pre n64 + b_pre  (K = 64) ----
         if (a.has_et) {
             f32x4 pm[RT][4], pc[RT][4];
@@ -829,6 +833,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                 __syncthreads();                               // planes Xa / Xc are rewritten by the second head
             }
         }
+        PROF(11);
     }
 }
 
