@@ -108,18 +108,45 @@ def check_final_state(smp, batch, K_total):
     return {"orthogonality_err": orth, "det_err": det}
 
 
+_MODELS = {}
+
+
+def get_model(dev, precision):
+    """One FlowModel per precision mode for the whole process (seeded random-init weights of the reference architecture)."""
+    import pepflowww_amd
+    from pepflowww_amd import synth
+    key = (str(dev), precision)
+    if key not in _MODELS:
+        sd = synth.seeded_state_dict()
+        model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        if precision != "fp32":
+            model.ga_encoder.set_precision(precision)
+        _MODELS[key] = (model, sd)
+    return _MODELS[key]
+
+
+class _Clock:
+    """Wall-clock phases with a device synchronisation on both sides (set-up accounting only, never inside the timed loop)."""
+
+    def __init__(self):
+        self.ms = {}
+        torch.cuda.synchronize()
+        self.t = time.perf_counter()
+
+    def lap(self, name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.ms[name] = round((now - self.t) * 1e3, 3)
+        self.t = now
+
+
 def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_kernels=True):
     """W warm-up + K timed steps of the sampler on this rank's shard; returns (elapsed_s_max_over_ranks, info)."""
-    import pepflowww_amd
     from pepflowww_amd import synth, _capi
-    from pepflowww_amd.sampler import DeviceSampler
     NS = K + W
-    sd = synth.seeded_state_dict()
-    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
-    if precision != "fp32":
-        model.ga_encoder.set_precision(precision)
+    model, sd = get_model(dev, precision)
     first = rank * wl["B"]                                           # contiguous batch shards, global sample ids
     batch, B, L, n_real = make_batch(wl, first)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
@@ -127,15 +154,27 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
     real_pairs = int((batch["res_mask"].sum(-1).to(torch.int64) ** 2).sum())
     info = {"B": B, "L": L, "real_residues": n_real, "real_pairs": real_pairs, "sd": sd, "batch": batch}
     with torch.no_grad():
-        R1, x1, ang1, seq1, node, edge = model.encode(dbatch)
+        # ---- set-up (outside the timed region; reported as "setup") ----
+        ck = _Clock()
+        model.ga_encoder.packed_weights(dev)
+        ck.lap("pack_weights_ms")                                    # once per parameter version (0 when already packed)
         eng = model.ga_encoder.engine(B, L, dev)
+        ck.lap("engine_build_ms")                                    # once per (B, L): workspaces (0 when cached)
+        R1, x1, ang1, seq1, node, edge = model.encode(dbatch, edge_out=eng.edge_buffer())
+        ck.lap("encode_ms")                                          # once per sample() call
         eng.bind_context(node, edge, dbatch["res_mask"])
+        ck.lap("bind_context_ms")                                    # once per call: block-0 pair bias / values, work lists, launch plan
         info["z16"] = bool(getattr(eng, "z16", False))
-        smp = DeviceSampler(eng, NS, (True, True, True), first_sample=first, seed=20240227)
+        smp = eng.sampler(NS)
+        smp.set_seed(20240227, first)
         smp.set_context(R1, x1, ang1, seq1, dbatch["generate_mask"])
         noise = {k: v for k, v in synth.make_noise(B, L, 1, seed=7, first_sample=first).items() if k != "expo"}
-        eng.run()                                                    # eager warm-up (outside capture)
         smp.init_state(noise)
+        ck.lap("sampler_init_ms")                                    # once per call: noise H2D + state init
+        if use_graph and smp.needs_capture():
+            smp.capture()                                            # (runs the plan once eagerly first: kernel attribute set-up)
+        ck.lap("graph_capture_ms")                                   # once per (B, L, num_steps): two hipGraphs (1 and 4 steps)
+        info["setup"] = ck.ms
         smp.run(W, use_graph=use_graph)                              # W untimed warm-up steps
         torch.cuda.synchronize()
         if dist is not None:
@@ -157,6 +196,13 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             all_gather_final_state(smp)
         info["validity"] = check_final_state(smp, batch, NS)
         info["launches_per_step"] = eng.n_launches + 1
+        ck = _Clock()
+        traj = smp.trajectory()                                      # the one D2H of a call: NS steps x (rot, trans, angles, seq, simplex)
+        ck.lap("d2h_ms")
+        info["setup"]["d2h_ms"] = ck.ms["d2h_ms"]
+        info["setup"]["d2h_bytes"] = int(NS * B * L * (37 * 4 + 8))
+        info["setup"]["d2h_steps"] = NS
+        del traj
 
         # ---- per-kernel timing with HIP events on the launch stream (10 eager steps of the plan) ----
         if time_kernels:
@@ -205,7 +251,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the f16@cfg4 / fp32@cfg3 / f16@cfg3 entries of the default line")
+    ap.add_argument("--no-per-call", action="store_true", help="skip the inference.py-style per-call accounting")
+    ap.add_argument("--per-call-steps", type=int, default=200)
     args = ap.parse_args()
+    global PER_CALL_STEPS
+    PER_CALL_STEPS = args.per_call_steps
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched the way the driver may launch it (`python bench.py --gpus N`): become N ranks, one per GPU
@@ -221,17 +272,35 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("PF_BENCH_SHARE_GPU"):              # test hook: several ranks on one GPU (single-GPU dev boxes)
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: one rank per GPU over RCCL needs {world} visible devices, this node shows "
+                         f"{torch.cuda.device_count()} (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}); refusing to share devices silently")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (the host driver's only mode): RCCL needs it
         backend = os.environ.get("PF_BENCH_BACKEND", "nccl")       # "nccl" = RCCL over xGMI on ROCm
+        ndev = torch.cuda.device_count()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)                             # first collective: RCCL builds its communicator (xGMI rings) here
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world, f"RCCL all-reduce over {world} ranks returned {probe.item()}"
+            except Exception as e:                                 # surface RCCL's own message, never fall back to another backend
+                raise SystemExit(f"bench.py: RCCL (torch.distributed 'nccl') could not form a {world}-rank communicator on this node: "
+                                 f"{type(e).__name__}: {e}\n(NCCL_DEBUG=INFO shows the transport RCCL picked)")
         else:
             dist.init_process_group(backend)
+        comm = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "devices_visible": ndev,
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                "collectives_in_timed_region": "barrier only (no data-path collective: samples are independent)",
+                "closing_collective": "one all_gather_into_tensor of the packed final state (38 floats per residue)"}
 
     from pepflowww_amd import _capi
     _capi.load()
@@ -309,6 +378,11 @@ def main():
         out["value_note"] = ("value counts padded residues (B x L_max, the shape the batch has); value_real_residues counts unpadded ones; "
                              "the rooflines count unmasked pairs (masked EdgeTransition tiles and attention keys are skipped)")
 
+    out["setup"] = dict(info["setup"], note="wall ms outside the timed region, each phase between device synchronisations; "
+                        "pack_weights once per parameter version, engine_build once per (B, L), graph_capture once per (B, L, num_steps), "
+                        "encode / bind_context / sampler_init / d2h once per sample() call")
+    if comm is not None:
+        out["rccl"] = comm
     if world == 1 and not args.no_secondary and args.workload != "cfg2":
         e2, i2 = run_sampler(WORKLOADS["cfg2"], K, W, dev, None, 0, 1, use_graph, prec, time_kernels=True)
         k2 = i2["kernel_us"]
@@ -316,6 +390,22 @@ def main():
                             "ms_per_step": e2 / K * 1e3, "steps": K,
                             "hbm_roofline_frac": 16 * 64 * K / e2 * 4096 * 64 / HBM_PEAK,
                             "kernel_us_per_step": {k: round(v["us_per_step"], 1) for k, v in k2.items()}}
+    if world == 1 and not args.no_modes and args.workload == "cfg4" and prec == "fp32":
+        # the other configurations / precision modes BASELINE.json names, each timed the same way (K steps after W warm-up steps)
+        out["modes"] = {}
+        for name, wk, pm in (("f16@cfg4", "cfg4", "f16"), ("fp32@cfg3", "cfg3", "fp32"), ("f16@cfg3", "cfg3", "f16")):
+            em, im = run_sampler(WORKLOADS[wk], K, W, dev, None, 0, 1, use_graph, pm, time_kernels=False)
+            zbm = 2048 if im.get("z16") else 4096
+            ent = {"workload": WORKLOADS[wk]["name"], "precision": pm, "dtype": DTYPE[pm], "ms_per_step": em / K * 1e3,
+                   "value": im["B"] * im["L"] * K / em, "unit": "res*step/s", "steps": K, "residues": im["L"],
+                   "hbm_roofline_frac": zbm * im["real_pairs"] * K / em / HBM_PEAK, "bytes_per_pair_step": zbm,
+                   "final_state_check": im["validity"]}
+            if WORKLOADS[wk].get("variable"):
+                ent["value_real_residues"] = im["real_residues"] * K / em
+                ent["unmasked_pairs"] = im["real_pairs"]
+            out["modes"][name] = ent
+    if world == 1 and not args.no_per_call and args.workload == "cfg4":
+        out["per_call"] = per_call_bench(dev, prec)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(info["sd"], info["batch"], B, L)
     if rank == 0:
@@ -396,26 +486,105 @@ def bench_train(args, wl, dev, dist, rank, world):
         dist.destroy_process_group()
 
 
+PER_CALL_STEPS = 200
+PER_CALL_LENGTHS = (61, 77, 88, 97, 104, 113, 120, 135)     # 8 complexes of different length (pocket + peptide residues)
+
+
+def per_call_bench(dev, precision, num_samples=64):
+    """inference.py:64-99 style use: for each complex, num_samples copies as one batch, model.sample(batch, num_steps) -> list of CPU
+    dicts.  Two passes over the same 8 complexes: `cold` builds every engine / graph it needs (first visit of each padded length),
+    `warm` finds them cached.  overhead = 1 - (time inside the step loop) / (wall time of the call)."""
+    from pepflowww_amd import synth
+    model, _ = get_model(dev, precision)
+    NS = PER_CALL_STEPS
+    res = {}
+    batches = []
+    for i, L0 in enumerate(PER_CALL_LENGTHS):
+        one = synth.make_pocket_batch(1, L0, 8 + i, seed=9000 + i)
+        batches.append({k: (v.expand(num_samples, *v.shape[1:]).contiguous().to(dev) if torch.is_tensor(v) else v) for k, v in one.items()})
+    for name in ("cold", "warm"):
+        calls = []
+        for b in batches:
+            tm = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            traj = model.sample(b, num_steps=NS, seed=1234, timings=tm)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            assert len(traj) == NS and torch.isfinite(traj[-1]["trans"]).all()
+            calls.append({"L": int(b["aa"].shape[1]), "wall_ms": round(wall * 1e3, 2), "loop_ms": round(tm["loop"] * 1e3, 2),
+                          "ms_per_step": round(tm["loop"] / NS * 1e3, 4),
+                          "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items() if k != "loop"}})
+            del traj
+        wall = sum(c["wall_ms"] for c in calls)
+        loop = sum(c["loop_ms"] for c in calls)
+        res[name] = {"wall_ms": round(wall, 1), "loop_ms": round(loop, 1), "overhead_frac": round(1 - loop / wall, 4), "calls": calls}
+    res["note"] = (f"{len(PER_CALL_LENGTHS)} complexes x {num_samples} samples x {NS} steps through FlowModel.sample (CPU trajectory returned); "
+                   "the timings hook synchronises after every phase, so the phases add up to the wall time")
+    res["engines_cached"] = len(model.ga_encoder._engines)
+    return res
+
+
+def _cpu_info():
+    model, cores = "unknown", set()
+    try:
+        phys = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    cores.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
+
+
 def cpu_baseline(sd, batch, B, L):
-    """The CPU oracle (kind 'port': restatement of the reference's PyTorch-CPU path, pinned to the reference by
-    tests/golden) timed on this box's host cores on a bounded sample of the same workload: the first `nb` samples of
-    the batch (samples are independent; the cost per residue-step depends on L, not on B), 2 sampler steps."""
+    """the CPU oracle (kind 'port': restatement of the reference's PyTorch-CPU path, pinned to the reference by
+    tests/golden) on this box's host cores, on a bounded sample of the same workload -- the first samples of the same batch (samples
+    are independent; cost per residue-step depends on L, not on B), 2 sampler steps after 1 warm-up step, MEDIAN of 3 runs, at
+    torch.set_num_threads(physical cores), at 16 threads and at 1 thread.  `value` = the best of them (the strongest baseline)."""
+    import statistics
     from oracle import pepflow_oracle as O
     from pepflowww_amd import synth
-    threads = torch.get_num_threads()
-    nb = min(B, max(1, 2048 // L))                                   # ~2048 residues per step
-    sub = {k: v[:nb] for k, v in batch.items()}
-    noise_steps = 2 if L > 64 else 4
-    noise = synth.make_noise(nb, L, noise_steps, seed=7)
+    cpu_model, phys, logical = _cpu_info()
+    saved = torch.get_num_threads()
+    steps = 2
+    runs = {}
+    t_all = time.perf_counter()
+    plan = [(phys, max(1, 512 // L)), (min(16, phys), max(1, 512 // L)), (1, 1)]
+    seen = set()
     with torch.no_grad():
-        enc = O.encode(sd, sub)
-        O.sample(sd, sub, noise, 1, encoded=enc)                     # warm-up
-        t0 = time.perf_counter()
-        O.sample(sd, sub, noise, noise_steps, encoded=enc)
-        dt = time.perf_counter() - t0
-    return {"value": nb * L * noise_steps / dt, "unit": "res*step/s", "cores": threads, "kind": "port",
-            "sample": f"{noise_steps} sampler steps of the first {nb} samples of the same batch (L={L}; oracle/pepflow_oracle.py, torch CPU fp32)",
-            "seconds": dt}
+        for threads, nb in plan:
+            if threads in seen:
+                continue
+            seen.add(threads)
+            nb = min(nb, B)
+            torch.set_num_threads(threads)
+            sub = {k: v[:nb] for k, v in batch.items()}
+            noise = synth.make_noise(nb, L, steps, seed=7)
+            enc = O.encode(sd, sub)
+            O.sample(sd, sub, noise, 1, encoded=enc)                 # warm-up step
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                O.sample(sd, sub, noise, steps, encoded=enc)
+                ts.append(time.perf_counter() - t0)
+            med = statistics.median(ts)
+            runs[str(threads)] = {"threads": threads, "value": nb * L * steps / med, "samples": nb, "steps": steps,
+                                  "median_s": round(med, 3), "runs_s": [round(t, 3) for t in ts]}
+    torch.set_num_threads(saved)
+    best = max(runs.values(), key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "res*step/s", "cores": best["threads"], "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": phys, "logical_cpus": logical,
+            "one_thread_value": runs["1"]["value"], "physical_cores_value": runs[str(phys)]["value"], "by_threads": runs,
+            "sample": f"first samples of the same batch (L={L}): {steps} sampler steps after 1 warm-up step, median of 3 runs per thread count "
+                      f"({', '.join(r + ' threads: ' + str(v['samples']) + ' samples' for r, v in runs.items())}); "
+                      "oracle/pepflow_oracle.py, torch CPU fp32; value = the fastest thread count",
+            "seconds": round(time.perf_counter() - t_all, 1)}
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 39
+#define PF_ABI_VERSION 40
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -400,6 +400,9 @@ typedef struct {
     const float* expo; uint64_t seed; int64_t first_sample;
     int B, L;
     int sample_bb, sample_ang, sample_seq;
+    /* optional: device uint64[2] = {seed, first_sample} read at run time (overrides the two fields above), so that the
+     * hipGraph captured for one sample() call is replayed by the next call with another seed / shard offset */
+    const uint64_t* seed_dev;
 } pf_sampler_args;
 /* initial state from raw noise (flow_model.py:252-277): rot0/trans0_raw/ang0/simplex0_raw as drawn */
 int pf_sampler_init(const pf_sampler_args* a, const float* rot0, const float* trans0_raw,

@@ -5,6 +5,17 @@
 //   C/D: col = lane&15, row = (lane>>4)*4 + reg.
 #pragma once
 #include <hip/hip_runtime.h>
+
+// CUs of the current device (256 on MI355X); launchers that size "one workgroup per CU" grids or pick a kernel form by whether a
+// grid fits one round of workgroups ask here instead of hard-coding the number.
+static inline int pf_cu_count() {
+    static const int n = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+        return c > 0 ? c : 256;
+    }();
+    return n;
+}
 #include <stdint.h>
 
 #define PF_WAVE 64
@@ -210,8 +221,11 @@ __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 // Range of the split representation: hi = f16(x) needs |x| <= 65504 (the largest finite f16).  Weights are checked when they are
-// packed (engine.split_f16 / pf_split_pack_f16 refuse anything larger); ACTIVATIONS saturate at +-65504 here instead of turning
-// into inf (an fp32 reference would carry on with the large value: beyond 6.5e4 the two differ, and INTEGRATION.md says so).
+// packed (engine.split_f16 / pf_split_pack_f16 refuse anything larger); finite ACTIVATIONS saturate at +-65504 here instead of
+// turning into inf (an fp32 reference would carry on with the large value: beyond 6.5e4 the two differ, and INTEGRATION.md says
+// so).  NaN (and inf) must NOT be swallowed by that clamp -- fmaxf(NaN, -65504) is -65504 under IEEE maxNum, which would turn a
+// diverged activation into a large finite one and hide what the reference shows as a NaN loss (train.py:125): the
+// clamped value gets v * 0 added (0 for finite v, NaN for NaN / inf), so both planes -- and every product with them -- are NaN again.
 // Below ~6e-8 (f16 subnormal range of hi) lo carries the value: relative precision degrades gradually towards 2^-24 absolute.
 constexpr float PF_F16_MAX = 65504.f;
 #ifndef PF_SPLIT_SATURATE
@@ -221,7 +235,8 @@ __device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #if PF_SPLIT_SATURATE
-        const float vc = fminf(fmaxf(v[e], -PF_F16_MAX), PF_F16_MAX);
+        // clamp, then add v * 0 (+-0 for finite v: exact; NaN for NaN / inf -- not folded: no fast-math): both planes propagate NaN
+        const float vc = fminf(fmaxf(v[e], -PF_F16_MAX), PF_F16_MAX) + v[e] * 0.f;
 #else
         const float vc = v[e];
 #endif

@@ -722,11 +722,7 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
     if ((a->tile_list != nullptr) != (a->n_tiles != nullptr)) return PF_E_BADARG;
     if (a->dz_out && (!a->bias_out || !a->wb_frags)) return PF_E_BADARG;        // dz_out rides on the pair-bias tile
     if (a->dz_out_f16 && !(a->dz_out && a->single_pass)) return PF_E_BADARG;
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        return n > 0 ? n : 256;
-    }();
+    const int ncu = pf_cu_count();
     if (a->dump_h1 || a->dump_h2 || a->dump_y) {
         if (!a->dump_h1 || !a->dump_h2 || !a->dump_y || a->single_pass || a->dz_out) return PF_E_BADARG;
         return et3_launch<true, false, 1>(a, stream, ncu);

@@ -16,6 +16,9 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
     __shared__ float red[4][4];
     const int b = blockIdx.x, L = a.L;
     const size_t rowb = (size_t)b * L;
+    // Philox key from device memory when the caller says so (a captured graph is then reusable across sample() calls)
+    const uint64_t seed = a.seed_dev ? a.seed_dev[0] : a.seed;
+    const long long first = a.seed_dev ? (long long)a.seed_dev[1] : (long long)a.first_sample;
     // centre of the generated residues (zero_center_part, flow_model.py:95-106)
     float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
     for (int l = threadIdx.x; l < L; l += 256) {
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) lg[k] = SIMPLEX_K * sx0[row * KCLS + k];
         long long s0 = s1;
-        if (sq) s0 = categorical_dev(lg, a.expo ? a.expo + row * KCLS : nullptr, a.seed, a.first_sample + b, 0, l);
+        if (sq) s0 = categorical_dev(lg, a.expo ? a.expo + row * KCLS : nullptr, seed, first + b, 0, l);
         a.seq_t[row] = s0;
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) {
@@ -83,7 +86,8 @@ __device__ __forceinline__ void sampler_step_body(const pf_sampler_args& a) {
     const int b = row / a.L, l = row - b * a.L;
     const bool gen = a.gen_mask[row] > 0.5f;
     const size_t nrow = (size_t)n;
-    const long long gs = a.first_sample + b;
+    const uint64_t seed = a.seed_dev ? a.seed_dev[0] : a.seed;
+    const long long gs = (a.seed_dev ? (long long)a.seed_dev[1] : (long long)a.first_sample) + b;
 
     // -------- clean prediction --------
     float Rp[9], xp[3], angp[5], sxp[KCLS];
@@ -99,7 +103,7 @@ __device__ __forceinline__ void sampler_step_body(const pf_sampler_args& a) {
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) lg[k] = a.pred_logits[(size_t)row * KCLS + k];
         const float* ex = a.expo ? a.expo + ((size_t)(1 + 2 * s) * nrow + row) * KCLS : nullptr;
-        seqp = categorical_oct(lg, ex, a.seed, gs, 1 + 2 * s, l, sub);
+        seqp = categorical_oct(lg, ex, seed, gs, 1 + 2 * s, l, sub);
     }
 #pragma unroll
     for (int k = 0; k < KCLS; ++k) sxp[k] = simplex_of(seqp, k);
@@ -111,7 +115,7 @@ __device__ __forceinline__ void sampler_step_body(const pf_sampler_args& a) {
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) lg[k] = a.pred_logits[(size_t)row * KCLS + k];
         const float* ex = a.expo ? a.expo + ((size_t)(1 + 2 * s) * nrow + row) * KCLS : nullptr;
-        seq_for_mask = categorical_oct(lg, ex, a.seed, gs, 1 + 2 * s, l, sub);
+        seq_for_mask = categorical_oct(lg, ex, seed, gs, 1 + 2 * s, l, sub);
     }
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
@@ -165,7 +169,7 @@ __device__ __forceinline__ void sampler_step_body(const pf_sampler_args& a) {
     long long seqn_mask = s1;
     if (gen) {
         const float* ex = a.expo ? a.expo + ((size_t)(2 + 2 * s) * nrow + row) * KCLS : nullptr;
-        seqn_mask = categorical_oct(lg, ex, a.seed, gs, 2 + 2 * s, l, sub);
+        seqn_mask = categorical_oct(lg, ex, seed, gs, 2 + 2 * s, l, sub);
         seqn = a.sample_seq ? seqn_mask : s1;
     }
     // (the state is read by all eight lanes above and written only after the last read: wave-synchronous, lane 0 stores)

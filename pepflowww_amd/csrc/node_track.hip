@@ -958,7 +958,7 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
         return PF_E_BADARG;
     const size_t lds = (size_t)2 * 2 * TR * 264 * sizeof(_Float16) + (size_t)TR * LDX * sizeof(float) +
                        (size_t)2 * TR * LDP * sizeof(_Float16);
-    if (a->rows >= 256 * TR2) {                  // a workgroup per CU even at 32 rows: halve the L2 -> CU weight stream
+    if (a->rows >= pf_cu_count() * TR2) {        // a workgroup per CU even at 32 rows: halve the L2 -> CU weight stream
         const size_t lds2 = (size_t)2 * 2 * TR2 * 264 * sizeof(_Float16) + (size_t)TR2 * LDX * sizeof(float) + (size_t)2 * TR2 * LDP * sizeof(_Float16);
         static bool attr_set = false;
         if (!attr_set) {
@@ -1000,9 +1000,14 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
     }
     const int LP = (a->L + 15) / 16 * 16;
     const int LDS_S = LP + 4;
-    // 32 rows per workgroup when the 16-row form would not fit one round of workgroups (one per CU)
+    // 32 rows per workgroup when the 16-row form would not fit one round of workgroups (one per CU).
+    // INVARIANT: this choice depends on the batch size, so a batch shard may run the 16-row form where the whole batch runs the
+    // 32-row form -- both forms (and node_head / node_head32, the tiled / rows-persistent projection) must produce bit-identical
+    // rows: same K order of every dot product, same LayerNorm / softmax reduction trees, a row never sees its tile neighbours.
+    // tests/test_gpu_bigshape.py (B=64 = 512 tiles -> 32-row form, vs two B=32 shards = 256 tiles -> 16-row form, bitwise) and
+    // tests/test_gpu_parity.py::test_node_track_forms_are_bitwise_identical_across_the_tile_threshold hold it.
     const int tiles16 = (a->L + 15) / 16;
-    const int RTn = ((long)a->B * tiles16 > 256 && a->L > 16) ? 2 : 1;
+    const int RTn = ((long)a->B * tiles16 > pf_cu_count() && a->L > 16) ? 2 : 1;
     const int TRn = 16 * RTn;
     const size_t lds = ((size_t)2 * TRn * LDX + TRn * 8 + (size_t)TRn * 4 * LDS_S) * sizeof(float) +
                        (size_t)4 * TRn * LDP * sizeof(_Float16);

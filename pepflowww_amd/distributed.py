@@ -88,14 +88,16 @@ def all_gather_packed(local, sizes, group=None):
     return torch.cat(chunks, 0)
 
 
-def all_gather_final_state(sampler, group=None):
-    """Gather the last trajectory slot of a DeviceSampler from every rank (device tensors, RCCL)."""
+def all_gather_final_state(sampler, group=None, sizes=None):
+    """Gather the last trajectory slot of a DeviceSampler from every rank (device tensors, RCCL): ONE collective.
+    sizes: per-rank sample counts.  Every caller knows them without asking (contiguous shards of a known total: shard_bounds;
+    bench.py: the same per-GPU batch on every rank) -- default = this rank's own count on every rank (weak-scaling replicas)."""
     local = _final_state_of(sampler)
     world = dist.get_world_size(group)
-    sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
-    sizes_t[dist.get_rank(group)] = local.shape[0]
-    dist.all_reduce(sizes_t, group=group)
-    return unpack_state(all_gather_packed(local, [int(s) for s in sizes_t.tolist()], group))
+    if sizes is None:
+        sizes = [local.shape[0]] * world
+    assert len(sizes) == world and sizes[dist.get_rank(group)] == local.shape[0], (sizes, local.shape)
+    return unpack_state(all_gather_packed(local, [int(s) for s in sizes], group))
 
 
 def seeded_noise(lo, hi, L, seed):
@@ -122,13 +124,23 @@ def _final_state_of(smp):
 
 
 @torch.no_grad()
-def sample_sharded(model, batch, num_steps=100, *, noise=None, seed=0, group=None, **kw):
+def sample_sharded(model, batch, num_steps=100, *, noise=None, seed=None, group=None, **kw):
     """FlowModel.sample over a batch sharded across the process group; returns the gathered FINAL state
     (dict of [B_total, L, ...] device tensors) on every rank.
     noise=None: the initial noise is drawn per GLOBAL sample index from `seed` (seeded_noise), so the result does not
-    depend on the world size and equals `model.sample(batch, noise=None, seed=seed)` on one device.  A rank whose shard is
-    empty (B_total < world) skips sampling and contributes zero rows to the all-gather."""
+    depend on the world size and equals `model.sample(batch, noise=None, seed=seed)` on one device.
+    seed=None (default): a FRESH seed per call, like the reference's inference loop which draws new noise every time
+    (flow_model.py:252-277) -- rank 0 draws it from torch's global CPU generator and broadcasts it (8 bytes, set-up, not on the
+    data path), so repeated calls give different samples while all ranks agree; pass an explicit seed for full determinism.
+    A rank whose shard is empty (B_total < world) skips sampling and contributes zero rows to the all-gather."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if seed is None:
+        st = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+        if world > 1:
+            dev = batch["aa"].device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+            st = st.to(dev)
+            dist.broadcast(st, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        seed = int(st.item())
     total, L = batch["aa"].shape[0], batch["aa"].shape[1]
     local, lo, hi = shard_batch(batch, world, rank)
     nz = shard_noise(noise, lo, hi) if noise is not None else seeded_noise(lo, hi, L, seed)

@@ -10,6 +10,7 @@ all arithmetic of the step runs in libpepflow_hip.so.
 """
 import ctypes as C
 import math
+from collections import OrderedDict
 
 import torch
 
@@ -156,6 +157,12 @@ class PackedWeights:
                 t[f"{net}.{i}.w16"] = split_f16(t[f"{net}.{i}.w"])
                 if i == 4:                  # padded so that the kernel's float4 bias load stays inside the buffer
                     t[f"{net}.{i}.b"] = torch.nn.functional.pad(t[f"{net}.{i}.b"], (0, 32 - t[f"{net}.{i}.b"].numel())).contiguous()
+        # what the two output heads return for a zero node state (= every masked residue, ga.py:113,123-124): a constant of the
+        # weights, used by GAEncoder.forward to give masked rows the reference's values instead of stale workspace contents
+        for net in ("seq_net", "angle_net"):
+            h = torch.relu(t[f"{net}.0.b"])
+            h = torch.relu(t[f"{net}.2.w"] @ h + t[f"{net}.2.b"])
+            t[f"{net}.const"] = (t[f"{net}.4.w"] @ h + g(f"{net}.4.bias")).contiguous()
         for b in range(N_BLOCKS):
             p = f"trunk.ipa_{b}."
             t[f"{b}.proj.w"] = torch.cat([g(p + "linear_q.weight"), g(p + "linear_kv.weight"),
@@ -286,7 +293,36 @@ class DenoiseEngine:
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
+        self.plan_version = 0                   # bumped whenever the plan is rebuilt: graphs captured from an older plan are stale
+        self.active_rows = rows
+        self._edge_in = None
+        self._samplers = OrderedDict()
+        self._warm = False                      # the plan has run eagerly once (kernel attribute set-up must not happen under capture)
         self._side = None
+
+    def edge_buffer(self):
+        """Engine-owned fp32 [B,L,L,64] buffer for the pair embedding.  FlowModel.sample has encode() write into it, so that
+        block 0's input pointer -- and with it the launch plan and every captured graph -- survives from one call to the next."""
+        if self._edge_in is None:
+            self._edge_in = torch.zeros(self.B, self.L, self.L, 64, dtype=torch.float32, device=self.device)
+        return self._edge_in
+
+    SAMPLER_CACHE = 2
+
+    def sampler(self, num_steps, flags=(True, True, True)):
+        """DeviceSampler of this engine for (num_steps, flags), cached with its trajectory buffers and captured graphs (the Philox
+        seed and the shard offset are read from device memory, so the same graph serves every call)."""
+        from .sampler import DeviceSampler
+        key = (int(num_steps), tuple(bool(f) for f in flags))
+        smp = self._samplers.get(key)
+        if smp is None:
+            smp = DeviceSampler(self, num_steps, flags)
+            self._samplers[key] = smp
+            while len(self._samplers) > self.SAMPLER_CACHE:
+                self._samplers.popitem(last=False)
+        else:
+            self._samplers.move_to_end(key)
+        return smp
 
     # ---- plan construction -------------------------------------------------------------------
     def _linear(self, x, w, b, y, N, K, relu=False, mask_pre=False, mask_post=False, residual=None, ln=None, w16=None):
@@ -349,15 +385,19 @@ class DenoiseEngine:
         self.et_ntiles.copy_(active.sum().to(torch.int32).reshape(1))
         self.key_end.copy_((m.to(torch.int32) * torch.arange(1, L + 1, device=m.device, dtype=torch.int32)).amax(-1))
         # host-side hint for the projection's kernel choice (pf_linear_args.active_rows): the one host read per bind_context
-        self.active_rows = int(self.key_end.sum().item())
+        ke_sum, m_sum = torch.stack([self.key_end.sum().to(torch.int64), m.sum().to(torch.int64)]).tolist()
+        self.active_rows = int(ke_sum)
         for la in getattr(self, "_proj_args", []):
             la.active_rows = self.active_rows
         for ta in getattr(self, "_tfmr_args", []):
             ta.key_end = self.key_end.data_ptr() if self.active_rows < B * L else None
-        self.zbuf.zero_()
-        self.pair_bias.zero_()
-        if self.pair_dz is not None:
-            self.pair_dz.zero_()
+        # skipped tiles must read as zero (ga.py:118); an unpadded batch skips nothing and overwrites everything
+        self.padded = int(m_sum) < B * L
+        if self.padded:
+            self.zbuf.zero_()
+            self.pair_bias.zero_()
+            if self.pair_dz is not None:
+                self.pair_dz.zero_()
 
     def _build_plan(self):
         w, lib = self.w, self.lib
@@ -495,6 +535,8 @@ class DenoiseEngine:
                 plan.append((None, None, "join", 0))
         # heads (ga.py:123-124): fused into the last block's node_tfmr tail (h_w / h_b above)
         self.plan = plan
+        self.plan_version += 1
+        self._warm = False
 
     # ---- execution ---------------------------------------------------------------------------
     def set_state(self, t, rotmats_t, trans_t, angles_t, seqs_t):
@@ -522,6 +564,7 @@ class DenoiseEngine:
                 rc = fn(*args, st) if isinstance(args, tuple) else fn(args, st)
                 if rc != 0:
                     _capi.check(rc, name)
+            self._warm = True
             return
         main = torch.cuda.current_stream()
         if self._side is None:

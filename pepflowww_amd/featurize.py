@@ -24,8 +24,34 @@ def _linear(lib, x, w, b, y, M, N, K, relu=False, mask=None):
     _capi.check(lib.pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd")
 
 
-def encode(model, batch, save=None):
-    """save: optional dict that receives every intermediate the encoder backward needs (training path)."""
+def _encoder_weights(model):
+    """fp32 / K-padded views of the two embedders' parameters, cached per parameter version (an inference loop that calls
+    encode() once per complex re-packs nothing).  Layout only."""
+    ne, ee = model.node_embedder, model.edge_embedder
+    params = list(ne.parameters()) + list(ee.parameters())
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = getattr(model, "_enc_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    w = dict(
+        aa_table=_f32(ne.aatype_embed.weight), freq_n=_f32(ne.dihed_embed.freq_bands),
+        n0w=F.pad(_f32(ne.mlp[0].weight), (0, 1168 - 1157)).contiguous(), n0b=_f32(ne.mlp[0].bias),
+        n2w=_f32(ne.mlp[2].weight), n2b=_f32(ne.mlp[2].bias), n4w=_f32(ne.mlp[4].weight), n4b=_f32(ne.mlp[4].bias),
+        n6w=_f32(ne.mlp[6].weight), n6b=_f32(ne.mlp[6].bias),
+        edge=[_f32(ee.aa_pair_embed.weight), _f32(ee.relpos_embed.weight), _f32(ee.aapair_to_distcoef.weight),
+              _f32(ee.dihedral_embed.freq_bands),
+              F.pad(_f32(ee.distance_embed[0].weight), (0, 240 - 225)).contiguous(), _f32(ee.distance_embed[0].bias),
+              _f32(ee.distance_embed[2].weight), _f32(ee.distance_embed[2].bias),
+              F.pad(_f32(ee.out_mlp[0].weight), (0, 224 - 218)).contiguous(), _f32(ee.out_mlp[0].bias),
+              _f32(ee.out_mlp[2].weight), _f32(ee.out_mlp[2].bias), _f32(ee.out_mlp[4].weight), _f32(ee.out_mlp[4].bias)])
+    model._enc_cache = (key, w)
+    return w
+
+
+def encode(model, batch, save=None, edge_out=None):
+    """save: optional dict that receives every intermediate the encoder backward needs (training path).
+    edge_out: optional fp32 [B,L,L,64] buffer the pair embedding is written to (FlowModel.sample hands the denoise engine's own
+    input buffer, so that the engine's launch plan / captured graphs keep their pointers from one call to the next)."""
     lib = _capi.load()
     aa = batch["aa"]
     _capi.dptr(aa.contiguous(), torch.int64, "batch['aa']")
@@ -37,6 +63,7 @@ def encode(model, batch, save=None):
     pos = _f32(batch["pos_heavyatom"][:, :, :15])
     mat = _f32(batch["mask_heavyatom"][:, :, :15])
     gen = _f32(batch["generate_mask"])
+    W = _encoder_weights(model) if save is None else None      # (the training path keeps the live parameters' views)
     ne, ee = model.node_embedder, model.edge_embedder
     e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     feat, rot1, trans1, mres, ctx = e(rows, 1168), e(rows, 9), e(rows, 3), e(rows), e(rows)
@@ -44,7 +71,7 @@ def encode(model, batch, save=None):
     na = _capi.NodeFeatArgs()
     na.aa, na.res_nb, na.chain_nb = aa_c.data_ptr(), res_nb.data_ptr(), chain_nb.data_ptr()
     na.pos, na.mask_atoms, na.gen_mask = pos.data_ptr(), mat.data_ptr(), gen.data_ptr()
-    aa_table, freq_n = _f32(ne.aatype_embed.weight), _f32(ne.dihed_embed.freq_bands)
+    aa_table, freq_n = (W["aa_table"], W["freq_n"]) if W else (_f32(ne.aatype_embed.weight), _f32(ne.dihed_embed.freq_bands))
     na.aa_table, na.freq3 = aa_table.data_ptr(), freq_n.data_ptr()
     na.feat, na.rot1, na.trans1, na.mres, na.ctx = feat.data_ptr(), rot1.data_ptr(), trans1.data_ptr(), mres.data_ptr(), ctx.data_ptr()
     na.B, na.L = B, L
@@ -52,17 +79,22 @@ def encode(model, batch, save=None):
     _capi.check(lib.pf_node_features_fwd(C.byref(na), _capi.stream_ptr()), "pf_node_features_fwd")
 
     # node MLP 1157 -> 256 -> 128 -> 128 -> 128 (node.py:20-25), x residue mask (node.py:102)
-    w0 = F.pad(_f32(ne.mlp[0].weight), (0, 1168 - 1157)).contiguous()
     h0, h1, h2, node = e(rows, 256), e(rows, 128), e(rows, 128), e(rows, 128)
-    _linear(lib, feat, w0, _f32(ne.mlp[0].bias), h0, rows, 256, 1168, relu=True)
-    _linear(lib, h0, _f32(ne.mlp[2].weight), _f32(ne.mlp[2].bias), h1, rows, 128, 256, relu=True)
-    _linear(lib, h1, _f32(ne.mlp[4].weight), _f32(ne.mlp[4].bias), h2, rows, 128, 128, relu=True)
-    _linear(lib, h2, _f32(ne.mlp[6].weight), _f32(ne.mlp[6].bias), node, rows, 128, 128, mask=mres)
+    if W:
+        nw = [W["n0w"], W["n0b"], W["n2w"], W["n2b"], W["n4w"], W["n4b"], W["n6w"], W["n6b"]]
+    else:
+        nw = [F.pad(_f32(ne.mlp[0].weight), (0, 1168 - 1157)).contiguous(), _f32(ne.mlp[0].bias), _f32(ne.mlp[2].weight),
+              _f32(ne.mlp[2].bias), _f32(ne.mlp[4].weight), _f32(ne.mlp[4].bias), _f32(ne.mlp[6].weight), _f32(ne.mlp[6].bias)]
+    _linear(lib, feat, nw[0], nw[1], h0, rows, 256, 1168, relu=True)
+    _linear(lib, h0, nw[2], nw[3], h1, rows, 128, 256, relu=True)
+    _linear(lib, h1, nw[4], nw[5], h2, rows, 128, 128, relu=True)
+    _linear(lib, h2, nw[6], nw[7], node, rows, 128, 128, mask=mres)
 
     ea = _capi.EdgeFeatArgs()
     ea.aa, ea.res_nb, ea.chain_nb, ea.pos, ea.mask_atoms = aa_c.data_ptr(), res_nb.data_ptr(), chain_nb.data_ptr(), pos.data_ptr(), mat.data_ptr()
     ea.ctx, ea.mres = ctx.data_ptr(), mres.data_ptr()
-    keep = [_f32(ee.aa_pair_embed.weight), _f32(ee.relpos_embed.weight), _f32(ee.aapair_to_distcoef.weight),
+    keep = W["edge"] if W else [
+            _f32(ee.aa_pair_embed.weight), _f32(ee.relpos_embed.weight), _f32(ee.aapair_to_distcoef.weight),
             _f32(ee.dihedral_embed.freq_bands),
             F.pad(_f32(ee.distance_embed[0].weight), (0, 240 - 225)).contiguous(), _f32(ee.distance_embed[0].bias),
             _f32(ee.distance_embed[2].weight), _f32(ee.distance_embed[2].bias),
@@ -70,7 +102,11 @@ def encode(model, batch, save=None):
             _f32(ee.out_mlp[2].weight), _f32(ee.out_mlp[2].bias), _f32(ee.out_mlp[4].weight), _f32(ee.out_mlp[4].bias)]
     (ea.aapair_table, ea.relpos_table, ea.distcoef, ea.freq3, ea.w_d0, ea.b_d0, ea.w_d2, ea.b_d2,
      ea.w_o0, ea.b_o0, ea.w_o2, ea.b_o2, ea.w_o4, ea.b_o4) = [t.data_ptr() for t in keep]
-    edge = e(B, L, L, 64)
+    if edge_out is not None:
+        assert edge_out.dtype == torch.float32 and edge_out.is_contiguous() and edge_out.numel() == B * L * L * 64
+        edge = edge_out.view(B, L, L, 64)
+    else:
+        edge = e(B, L, L, 64)
     ea.out, ea.B, ea.L = edge.data_ptr(), B, L
     ea.sample_structure, ea.sample_sequence = na.sample_structure, na.sample_sequence
     if save is not None:

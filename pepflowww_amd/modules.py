@@ -12,6 +12,7 @@ Reference classes mirrored (paths relative to /root/reference):
   AngularEncoding      pepflow/modules/common/layers.py:92-113
 """
 import math
+from collections import OrderedDict
 
 import torch
 from torch import nn
@@ -165,10 +166,16 @@ class GAEncoder(nn.Module):
             if b < ipa_conf.num_blocks - 1:
                 self.trunk[f"edge_transition_{b}"] = EdgeTransition(
                     node_embed_size=c, edge_embed_in=ipa_conf.c_z, edge_embed_out=ipa_conf.c_z)
-        self._engine = None
-        self._engine_key = None
+        self._packed = None
+        self._packed_key = None
+        self._engines = OrderedDict()
 
-    # -- engine cache: rebuilt when shape/device change or any parameter was modified in place --
+    # -- caches ------------------------------------------------------------------------------------------------------------
+    # PackedWeights depends on (device, parameter version) only; engines (workspaces + launch plan + captured graphs) on
+    # (B, L, device, precision).  inference.py:64-99 loops over complexes of different length: the packed weights are built once,
+    # and the most recently used ENGINE_CACHE engines stay alive, so a length seen before costs no set-up at all.
+    ENGINE_CACHE = 8
+
     def _param_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
@@ -178,14 +185,38 @@ class GAEncoder(nn.Module):
         assert precision in ("fp32", "f16"), precision
         self._precision = precision
 
+    def packed_weights(self, device):
+        key = (str(device), self._param_version())
+        if self._packed is None or self._packed_key != key:
+            sd = {"ga_encoder." + k: v for k, v in self.state_dict().items()}
+            self._packed = PackedWeights(sd, device)
+            self._packed_key = key
+            self._engines.clear()                # engines hold pointers into the old packed copies
+        return self._packed
+
     def engine(self, B, L, device):
         prec = getattr(self, "_precision", "fp32")
-        key = (B, L, str(device), self._param_version(), prec)
-        if self._engine is None or self._engine_key != key:
-            sd = {"ga_encoder." + k: v for k, v in self.state_dict().items()}
-            self._engine = DenoiseEngine(PackedWeights(sd, device), B, L, device, precision=prec)
-            self._engine_key = key
-        return self._engine
+        w = self.packed_weights(device)
+        key = (B, L, str(device), prec)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = DenoiseEngine(w, B, L, device, precision=prec)
+            self._engines[key] = eng
+            while len(self._engines) > self.ENGINE_CACHE:
+                self._engines.popitem(last=False)
+        else:
+            self._engines.move_to_end(key)
+        return eng
+
+    @property
+    def last_engine(self):
+        """The engine of the most recent call (None before the first one)."""
+        return next(reversed(self._engines.values())) if self._engines else None
+
+    def release_engines(self):
+        """Drop every cached engine (workspaces, graphs) and the packed weight copies."""
+        self._engines.clear()
+        self._packed = self._packed_key = None
 
     def forward(self, t, rotmats_t, trans_t, angles_t, seqs_t, node_embed, edge_embed, generate_mask, res_mask):
         """Same positional signature as the reference (ga.py:87); generate_mask is unused there too."""
@@ -201,8 +232,18 @@ class GAEncoder(nn.Module):
         eng.run()
         rot = eng.rot.view(B, L, 3, 3).clone()
         trans = eng.trans.view(B, L, 3).clone()
-        ang = torch.remainder(eng.ang_raw.view(B, L, 5), 2 * math.pi)     # ga.py:125
-        return rot, trans, ang, eng.logits.view(B, L, 20).clone()
+        ang_raw, logits = eng.ang_raw.view(B, L, 5), eng.logits.view(B, L, 20).clone()
+        if eng.padded:
+            # Row tiles beyond a sample's last unmasked residue are skipped by every kernel (work lists), so the workspaces hold
+            # stale values there.  The reference's values for a masked residue: its frame is never updated (update mask,
+            # ga.py:111-112) and both heads see a zero node state (ga.py:109,123-124) -- copied in here, selection only.
+            m = res_mask.reshape(B, L).to(torch.bool)
+            rot = torch.where(m[..., None, None], rot, rotmats_t.reshape(B, L, 3, 3).to(rot.dtype))
+            trans = torch.where(m[..., None], trans, trans_t.reshape(B, L, 3).to(trans.dtype))
+            logits = torch.where(m[..., None], logits, eng.w["seq_net.const"].expand(B, L, 20))
+            ang_raw = torch.where(m[..., None], ang_raw, eng.w["angle_net.const"].expand(B, L, 5))
+        ang = torch.remainder(ang_raw, 2 * math.pi)                       # ga.py:125
+        return rot, trans, ang, logits
 
 
 class NodeEmbedder(nn.Module):

@@ -1,0 +1,148 @@
+#!/usr/bin/env python
+"""What the sampler produces over the CONFIGURED lengths (BASELINE configs[1]: 100 steps, configs[2]: 500 steps), HIP fp32-parity
+mode and HIP f16 mode against the CPU oracle with the same recorded noise (initial noise + every Exp(1) draw behind the categorical
+samples) -- free-running, i.e. every step continues from the side's own previous state (flow_model.py:286-343).
+
+Per step: max-normalised error of the clean rotation / translation prediction over the generated residues, cumulative number of
+sequence draws that differ; at the end: C-alpha RMSD between the HIP and the oracle final structures, sequence identity.
+
+Test infrastructure (imports oracle/): run on the GPU box,
+    python tests/drift_study.py --out gpurun_out/drift.json            # both cases, ~4 min of host time for the oracle
+tests/test_gpu_drift.py runs the 100-step case in the GPU suite and pins the bounds."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pepflow_oracle as O  # noqa: E402  (checker)
+import pepflowww_amd  # noqa: E402
+from pepflowww_amd import synth  # noqa: E402
+
+
+def _maxnorm(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def compare(traj, ref, gen, res):
+    """traj / ref: lists of per-step dicts (CPU); gen / res: [B,L] bool.  Errors over generated residues (context is pinned)."""
+    N = len(ref)
+    g = gen & res
+    rot, trans, ang, flips_cum, flips = [], [], [], [], 0
+    for i in range(N):
+        rot.append(_maxnorm(traj[i]["rotmats"][g], ref[i]["rotmats"][g]))
+        trans.append(_maxnorm(traj[i]["trans"][g], ref[i]["trans"][g]))
+        d = (traj[i]["angles"][g] - ref[i]["angles"][g]).abs()
+        ang.append(torch.minimum(d, 2 * math.pi - d).max().item())
+        flips += int((traj[i]["seqs"][g] != ref[i]["seqs"][g]).sum())
+        flips_cum.append(flips)
+    dx = traj[-1]["trans"] - ref[-1]["trans"]
+    per_sample = []
+    for b in range(dx.shape[0]):
+        m = g[b]
+        per_sample.append(math.sqrt(float((dx[b][m] ** 2).sum(-1).mean())) if m.any() else 0.0)
+    first_flip = next((i for i, f in enumerate(flips_cum) if f > 0), None)
+    return {
+        "steps": N, "generated_residues": int(g.sum()), "draws": int(g.sum()) * N,
+        "rot_err_step0": rot[0], "trans_err_step0": trans[0],
+        "rot_err_max": max(rot), "trans_err_max": max(trans), "angle_err_max_rad": max(ang),
+        "rot_err_final": rot[-1], "trans_err_final": trans[-1],
+        "rot_err_max_before_first_flip": max(rot[:max(1, first_flip if first_flip is not None else N)]),
+        "trans_err_max_before_first_flip": max(trans[:max(1, first_flip if first_flip is not None else N)]),
+        "first_flip_step": first_flip, "cumulative_flips": flips, "flip_rate": flips / max(1, int(g.sum()) * N),
+        "final_ca_rmsd_A_mean": sum(per_sample) / len(per_sample), "final_ca_rmsd_A_max": max(per_sample),
+        "final_sequence_identity": float((traj[-1]["seqs"][g] == ref[-1]["seqs"][g]).float().mean()),
+        "curve_steps": list(range(0, N, max(1, N // 50))),
+        "rot_err_curve": [rot[i] for i in range(0, N, max(1, N // 50))],
+        "trans_err_curve": [trans[i] for i in range(0, N, max(1, N // 50))],
+        "flips_curve": [flips_cum[i] for i in range(0, N, max(1, N // 50))],
+    }
+
+
+def run_case(model, sd, batch, noise, NS, modes=("fp32", "f16"), threads=None, ref_noise_threads=None):
+    dev = torch.device("cuda:0")
+    if threads:
+        torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = O.sample(sd, batch, noise, NS)
+    t_ref = time.perf_counter() - t0
+    out = {"oracle_seconds": round(t_ref, 1)}
+    if ref_noise_threads:
+        # the CPU path against ITSELF at another thread count (different reduction orders in ATen): the floor any fp32
+        # implementation can be held to over a free run (8e-5 over 50 steps for the reference itself)
+        saved = torch.get_num_threads()
+        torch.set_num_threads(ref_noise_threads)
+        with torch.no_grad():
+            ref2 = O.sample(sd, batch, noise, NS)
+        torch.set_num_threads(saved)
+        out[f"oracle_{ref_noise_threads}_threads_vs_oracle_{saved}_threads"] = compare(ref2, ref, batch["generate_mask"], batch["res_mask"])
+    db = {k: v.to(dev) for k, v in batch.items()}
+    L0 = batch["aa"].shape[1]
+    res, gen = batch["res_mask"], batch["generate_mask"]
+    trajs = {}
+    for mode in modes:
+        model.ga_encoder.set_precision(mode)
+        try:
+            trajs[mode] = model.sample(db, num_steps=NS, noise=noise)
+        finally:
+            model.ga_encoder.set_precision("fp32")
+        out[mode + "_vs_oracle"] = compare(trajs[mode], ref, gen, res)
+    if "fp32" in trajs and "f16" in trajs:
+        out["f16_vs_fp32_hip"] = compare(trajs["f16"], trajs["fp32"], gen, res)
+    out["shape"] = {"B": int(batch["aa"].shape[0]), "L": int(L0), "num_steps": NS}
+    return out
+
+
+def case_cfg2_like(NS=100, B=8, L=64, n_gen=12):
+    batch = synth.make_pocket_batch(B, L, n_gen, seed=114514)
+    noise = synth.make_noise(B, L, NS, seed=31)
+    return batch, noise
+
+
+def case_cfg3_like(NS=500, n=4):
+    sys.path.insert(0, ROOT)
+    import bench
+    wl = bench.WORKLOADS["cfg3"]
+    full, B, L, _ = bench.make_batch(wl, 0)
+    lens = full["res_mask"].sum(1)
+    order = torch.argsort(lens)
+    pick = [int(order[0]), int(order[21]), int(order[42]), int(order[63])][:n]       # shortest ... longest
+    batch = {k: v[pick] for k, v in full.items()}
+    noise = synth.make_noise(len(pick), L, NS, seed=32)
+    return batch, noise
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "drift.json"))
+    ap.add_argument("--steps1", type=int, default=100)
+    ap.add_argument("--steps2", type=int, default=500)
+    ap.add_argument("--threads", type=int, default=32)
+    args = ap.parse_args()
+    sd = synth.seeded_state_dict()
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    model.load_state_dict(sd)
+    model = model.to("cuda:0").eval()
+    res = {"what": __doc__.split("\n\n")[0], "weights": "synthetic seeded N(0, sigma) (pepflowww_amd/synth.py); no trained checkpoint in the image"}
+    b, nz = case_cfg2_like(args.steps1)
+    res["cfg2_like_100_steps"] = run_case(model, sd, b, nz, args.steps1, threads=args.threads, ref_noise_threads=4)
+    print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if "curve" not in kk})
+                      for k, v in res["cfg2_like_100_steps"].items()}, indent=1), flush=True)
+    if args.steps2 > 0:
+        b, nz = case_cfg3_like(args.steps2)
+        res["cfg3_like_500_steps"] = run_case(model, sd, b, nz, args.steps2, threads=args.threads)
+        print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if "curve" not in kk})
+                          for k, v in res["cfg3_like_500_steps"].items()}, indent=1), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -234,3 +234,56 @@ def test_shard_batch_structured_lists_and_square_batches():
     part = D.seeded_noise(2, 4, L, 9)
     for k in nz:
         assert torch.equal(nz[k][2:], part[k]), k
+
+
+# ---- default seed and the closing collective ----
+class _SeedRecorder(_StubModel):
+    def __init__(self):
+        self.seeds = []
+
+    def sample(self, batch, num_steps, noise=None, seed=0, first_sample=0, return_sampler=False, **kw):
+        self.seeds.append(int(seed))
+        return super().sample(batch, num_steps, noise=noise, seed=seed, first_sample=first_sample, return_sampler=return_sampler, **kw)
+
+
+def _fresh_seed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1000 + rank)                     # ranks start from DIFFERENT generator states
+        batch = synth.make_pocket_batch(4, 12, 4, seed=3)
+        m = _SeedRecorder()
+        a = D.sample_sharded(m, batch, num_steps=3)        # seed=None: rank 0 draws, everybody uses it
+        b = D.sample_sharded(m, batch, num_steps=3)
+        # closing collective of the bench path: count what all_gather_final_state issues
+        calls = []
+        real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
+        dist.all_gather_into_tensor = lambda *x, **k: (calls.append("all_gather"), real_ag(*x, **k))[1]
+        dist.all_reduce = lambda *x, **k: (calls.append("all_reduce"), real_ar(*x, **k))[1]
+        try:
+            shard, lo, hi = D.shard_batch(batch, world, rank)
+            nz = D.seeded_noise(lo, hi, 12, 5)
+            out = D.all_gather_final_state(_StubSampler(shard, 3, nz, lo))
+        finally:
+            dist.all_gather_into_tensor, dist.all_reduce = real_ag, real_ar
+        q.put((rank, m.seeds, a["rotmats"].clone(), b["rotmats"].clone(), calls, tuple(out["trans"].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_default_seed_is_fresh_per_call_and_shared_by_the_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fresh_seed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, a0, b0, c0, sh0), (r1, s1, a1, b1, c1, sh1) = res
+    assert s0 == s1 and len(s0) == 2 and s0[0] != s0[1], (s0, s1)        # same seed on both ranks, a new one per call
+    assert torch.equal(a0, a1) and torch.equal(b0, b1) and not torch.equal(a0, b0)
+    assert c0 == ["all_gather"] and c1 == ["all_gather"], (c0, c1)       # ONE collective closes a run
+    assert sh0 == (4, 12, 3) and sh1 == (4, 12, 3)

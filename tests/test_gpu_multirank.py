@@ -31,7 +31,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 m = pepflowww_amd.FlowModel(pepflowww_amd.default_config()); m.load_state_dict(synth.seeded_state_dict()); m = m.to("cuda:0").eval()
-B, L, NS = 5, 32, 3
+B, L, NS = int(os.environ.get("PF_TOTAL", "5")), 32, 3
 batch = {k: v.to("cuda:0") for k, v in synth.make_pocket_batch(B, L, 8, seed=21).items()}
 out = D.sample_sharded(m, batch, num_steps=NS, noise=None, seed=4321)
 if rank == 0:
@@ -53,6 +53,51 @@ def test_sample_sharded_two_ranks_one_gpu(tmp_path):
                         "--master-port", env["MASTER_PORT"], str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARDED_EQUALS_UNSHARDED True" in r.stdout, r.stdout[-2000:]
+
+
+def test_sample_sharded_eight_ranks_ragged_shards(tmp_path):
+    """World size 8 (the node the scaling curve is measured on) with RAGGED shards: 21 samples -> 3,3,3,3,3,2,2,2; every rank's
+    slice, RNG offset and place in the closing all-gather must line up with the unsharded run, bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, PF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", PF_TOTAL="21")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                        "--master-port", env["MASTER_PORT"], str(script)], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "SHARDED_EQUALS_UNSHARDED True" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_eight_ranks_print_one_line():
+    """`python bench.py --gpus 8` (ranks sharing the one GPU of this box, gloo): rank 0 alone prints the JSON line, the aggregate
+    counts all eight shards, and the line says which backend / world size the collectives actually saw."""
+    env = dict(os.environ, PF_BENCH_SHARE_GPU="1", PF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--workload", "cfg2"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
+    assert out["rccl"]["world_size_seen"] == 8 and out["rccl"]["backend"] == "gloo"
+    assert abs(out["value"] - 8 * 16 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out and "modes" not in out and "per_call" not in out
+
+
+def test_bench_refuses_to_fake_a_multi_gpu_rccl_run():
+    """The production backend is RCCL, one rank per GPU.  Asked for 2 GPUs on a node that shows one, bench.py must stop with a
+    message that says so -- not share the device, not fall back to another backend, not print a line."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PF_BENCH_SHARE_GPU", "PF_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode != 0
+    assert "needs 2 visible devices" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_self_spawns_its_ranks():

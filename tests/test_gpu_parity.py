@@ -651,7 +651,7 @@ def test_ga_encoder_step(f2, model):
                            cu(f2["enc_node"]), cu(f2["enc_edge"]), cu(b["generate_mask"].long()), cu(b["res_mask"].long()))
     G.sync()
     R, x, ang, logits = [t.cpu() for t in out]
-    eng = model.ga_encoder._engine
+    eng = model.ga_encoder.last_engine
     valid = b["res_mask"].reshape(-1)
     G.assert_close(eng.s.cpu()[valid], f2["s_blk_5"].reshape(-1, 128)[valid], REL, "node state after block 5")
     em = (b["res_mask"][:, None, :] & b["res_mask"][:, :, None])
