@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 40
+#define PF_ABI_VERSION 41
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -329,9 +329,16 @@ typedef struct {
      * are not touched: the caller keeps them zeroed. */
     float* dz_out;
     int dz_out_f16;                /* f16 mode only (single_pass): dz_out points to [B*L*L,16] f16 */
+    /* optional: the same 256 KiB of weights packed for the 32x32x16 matrix instruction (pepflowww_amd.engine.pack_et_stream32:
+     * 128 entries of [32 features x 16 K] hi | lo fragments in execution order) and the next block's [linear_b; down_z] tile in
+     * that form (pack_bias_frags32, 8 KiB; needed with bias_out).  When w_stream32 is set and no dump_* is requested, the 32x32
+     * kernel runs (csrc/edge_transition_v4.hip: tiles of 16 rows x 16 columns, pf_edge_transition_v4_tile_rows() for the work
+     * list); everything else about the call is unchanged. */
+    const void* w_stream32; const void* wb_frags32;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */
+int pf_edge_transition_v4_tile_rows(void);           /* ... of the 32x32 kernel (16) */
 
 /* ---- encode(): once-per-call context featurisation (FlowModel.encode, flow_model.py:75-93) -------
  * node features: NodeEmbedder.forward up to the MLP input (node.py:35-99): aa embedding, per-aa-type

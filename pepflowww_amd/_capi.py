@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -62,7 +62,8 @@ class EdgeTransitionArgs(C.Structure):
     _fields_ = [("z_in", _fp), ("z_out", _fp), ("pre", _fp), ("w1z_f16", _fp), ("w2_f16", _fp), ("b2", _fp), ("wf_f16", _fp),
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
                 ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp),
-                ("single_pass", _i), ("tile_list", _fp), ("n_tiles", _fp), ("z_in_f16", _i), ("z_out_f16", _i), ("dz_out", _fp), ("dz_out_f16", _i)]
+                ("single_pass", _i), ("tile_list", _fp), ("n_tiles", _fp), ("z_in_f16", _i), ("z_out_f16", _i), ("dz_out", _fp), ("dz_out_f16", _i),
+                ("w_stream32", _fp), ("wb_frags32", _fp)]
 
 
 class SamplerArgs(C.Structure):
@@ -179,6 +180,7 @@ _SIGNATURES = {
     "pf_rigid_update_fwd": ([C.POINTER(RigidUpdateArgs), _fp], _i),
     "pf_edge_transition_fwd": ([C.POINTER(EdgeTransitionArgs), _fp], _i),
     "pf_edge_transition_tile_rows": ([_i], _i),
+    "pf_edge_transition_v4_tile_rows": ([], _i),
     "pf_node_features_fwd": ([C.POINTER(NodeFeatArgs), _fp], _i),
     "pf_edge_features_fwd": ([C.POINTER(EdgeFeatArgs), _fp], _i),
     "pf_sampler_init": ([C.POINTER(SamplerArgs), _fp, _fp, _fp, _fp, _fp], _i),

@@ -129,6 +129,74 @@ def pack_bias_frags(w_b, w_dz=None):
     return torch.cat(out).contiguous()
 
 
+def _frag32(W, mt, kidx):
+    """One stream entry of the 32x32x16 kernel (hi 512 f16 | lo 512 f16, lo = f16(w - hi) unscaled) for the 32-feature tile mt:
+    lane (row = lane & 31, kg = lane >> 5) holds W[32 mt + row][kidx[kg, 0..7]]; rows beyond W are zero."""
+    if W.shape[0] < 32 * (mt + 1):
+        W = torch.nn.functional.pad(W, (0, 0, 0, 32 * (mt + 1) - W.shape[0]))
+    lane = torch.arange(64, device=W.device)
+    rows = 32 * mt + (lane & 31)
+    v = W[rows[:, None], kidx[(lane >> 5)]]                     # [64, 8]
+    check_f16_range(v)
+    hi = v.to(torch.float16)
+    lo = (v - hi.to(torch.float32)).to(torch.float16)
+    return torch.cat([hi.reshape(-1), lo.reshape(-1)])
+
+
+def _k_nat(dev):
+    kg = torch.arange(2, device=dev)[:, None]
+    i8 = torch.arange(8, device=dev)[None, :]
+    return lambda ks: 16 * ks + 8 * kg + i8                      # K-step ks of an input in natural feature order
+
+
+def _k_perm(dev):
+    """K order in which a 32-feature accumulator chunk of v_mfma_f32_32x32x16 becomes the B operand of the next GEMM: a lane
+    (pair n, kg) holds features 8 b + 4 kg + e of the chunk in register 4 b + e; registers 8 s .. 8 s + 7 are K-step s, so
+    slot (8 kg + 4 h + e) <-> feature 32 c + 16 s + 8 h + 4 kg + e."""
+    kg = torch.arange(2, device=dev)[:, None]
+    i8 = torch.arange(8, device=dev)[None, :]
+    return lambda c, s: 32 * c + 16 * s + 8 * (i8 >> 2) + 4 * kg + (i8 & 3)
+
+
+def pack_et_stream32(w1z, w2, wf):
+    """EdgeTransition weights as the 128-entry stream of csrc/edge_transition_v4.hip, in execution order:
+      entries 0..7    Wf[:, :64]   tile mt (2) x K-step ks (4), natural K
+      entries 8..31   W1z          tile mt1 (6) x K-step ks (4), natural K
+      entries 32..43  W2 tile 0    K-steps (c', s) = (0,0),(0,1),(1,0) ... (5,1), permuted K (h1 chunk c', half s)
+      then for c = 0..4: W2 tile c + 1 (12 entries), Wf[:, 64 + 32 c ..] as K-step s (2) x tile mt (2), permuted K (h2 chunk c)
+      entries 124..127 Wf[:, 64 + 160 ..] (chunk 5).
+    Layout/packing only -- no model arithmetic."""
+    w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
+    assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
+    dev = w2.device
+    nat, perm = _k_nat(dev), _k_perm(dev)
+    wfz = wf[:, :64].contiguous()
+    out = []
+    for mt in range(2):
+        out += [_frag32(wfz, mt, nat(ks)) for ks in range(4)]
+    for mt1 in range(6):
+        out += [_frag32(w1z, mt1, nat(ks)) for ks in range(4)]
+    w2_tile = lambda c: [_frag32(w2, c, perm(ks // 2, ks % 2)) for ks in range(12)]
+    wf_chunk = lambda c: [_frag32(wf, mt, perm(c, s)) for s in range(2) for mt in range(2)]
+    out += w2_tile(0)
+    for c in range(5):
+        out += w2_tile(c + 1)
+        out += wf_chunk(c)
+    out += wf_chunk(5)
+    stream = torch.cat(out).contiguous()
+    assert stream.numel() * 2 == 256 * 1024
+    return stream
+
+
+def pack_bias_frags32(w_b, w_dz):
+    """[linear_b (8 rows); down_z (16 rows); 8 zero rows] x K = 64 as 4 entries (K-steps (mt, s) of z' in permuted order) for the
+    32x32 kernel's epilogue (8 KiB).  Layout/packing only."""
+    w = torch.cat([_f32(w_b), _f32(w_dz)], 0)
+    assert w.shape == (24, 64)
+    perm = _k_perm(w.device)
+    return torch.cat([_frag32(w, 0, perm(mt, s)) for mt in range(2) for s in range(2)]).contiguous()
+
+
 class PackedWeights:
     """Kernel-friendly views/copies of the GAEncoder parameters (reference state_dict layout).
 
@@ -216,6 +284,8 @@ class PackedWeights:
                 t[f"{b}.et.w216"], t[f"{b}.et.b2"] = split_f16(g(q + "trunk.2.weight")), g(q + "trunk.2.bias")
                 t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
+                t[f"{b}.et.stream32"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf)
+                t[f"{b}.et.wbfrags32"] = pack_bias_frags32(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
                 t[f"{b}.et.ln.w"], t[f"{b}.et.ln.b"] = g(q + "layer_norm.weight"), g(q + "layer_norm.bias")
@@ -274,7 +344,10 @@ class DenoiseEngine:
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
         # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
-        self.et_rows = int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
+        # EdgeTransition kernel form: the 32x32 kernel (csrc/edge_transition_v4.hip) unless PF_ET_V4=0 (A/B runs against v3)
+        import os
+        self.et_v4 = os.environ.get("PF_ET_V4", "1") != "0"
+        self.et_rows = int(self.lib.pf_edge_transition_v4_tile_rows()) if self.et_v4 else int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
         self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
         self.et_ntiles = e(1, dt=torch.int32)
@@ -523,6 +596,8 @@ class DenoiseEngine:
                 et.wf_f16, et.ln_g, et.ln_b = w[f"{b}.et.wf16"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
                 et.w_stream = w[f"{b}.et.stream"].data_ptr()
                 et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
+                if self.et_v4:
+                    et.w_stream32, et.wb_frags32 = w[f"{b}.et.stream32"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()
                 et.bb = w[f"{b + 1}.linear_b.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")

@@ -129,7 +129,8 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
 def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None,
                     next_dz=None, single_pass=False, dz_f16=False):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
-    persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes).
+    persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes); "v4": the 32x32 kernel
+    (w_stream32 / wb_frags32, csrc/edge_transition_v4.hip).
     next_dz: down_z.weight [16,64] of the next IPA block (with next_bias): also returns dz [B,L,L,16] = W_dz z'."""
     from pepflowww_amd.engine import split_f16, pack_et_stream
     lib = _capi.load()
@@ -141,6 +142,13 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
     a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
     ws = pack_et_stream(w1[:, :64], w2, wf) if persistent else None
     a.w_stream = _p(ws)
+    if persistent == "v4":
+        from pepflowww_amd.engine import pack_et_stream32, pack_bias_frags32
+        ws32 = pack_et_stream32(w1[:, :64], w2, wf)
+        a.w_stream32 = _p(ws32)
+        if next_bias is not None:
+            wbf32 = pack_bias_frags32(next_bias[0], next_dz if next_dz is not None else torch.zeros(16, 64, device=z.device))
+            a.wb_frags32 = _p(wbf32)
     if next_bias is not None:                 # (linear_b.weight [8,64], linear_b.bias [8]) of the next IPA block
         from pepflowww_amd.engine import pack_bias_frags
         wbf = pack_bias_frags(next_bias[0], next_dz)

@@ -335,9 +335,10 @@ def _et_run(sd, pfx, s, z, mask, B, L, persistent=True):
                              cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L, persistent=persistent)
 
 
-@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("persistent", [True, False, "v4"])
 def test_edge_transition(f2, seeded_sd, persistent):
-    """persistent: LDS-ring kernel (edge_transition_v3.hip); else the tiled kernel (edge_transition.hip)."""
+    """persistent: LDS-ring kernel (edge_transition_v3.hip); "v4": the 32x32 kernel (edge_transition_v4.hip); else the tiled kernel
+    (edge_transition.hip)."""
     b = _batch(f2)
     B, L = b["aa"].shape
     out = _et_run(seeded_sd, "ga_encoder.trunk.edge_transition_0.", f2["et0_in_s"], f2["enc_edge"], torch.ones(B, L), B, L, persistent)
@@ -349,8 +350,9 @@ def test_edge_transition(f2, seeded_sd, persistent):
     G.assert_close(out2.view(B, L, L, 64), f2["et0_out"] * em, REL, "EdgeTransition masked")
 
 
-def test_edge_transition_emits_next_pair_bias(f2, seeded_sd):
-    """The persistent kernel also writes sqrt(1/3)(W_b z' + b_b) of the NEXT IPA block from z' in registers."""
+@pytest.mark.parametrize("form", [True, "v4"])
+def test_edge_transition_emits_next_pair_bias(f2, seeded_sd, form):
+    """The persistent kernels also write sqrt(1/3)(W_b z' + b_b) of the NEXT IPA block from z' in registers."""
     b = _batch(f2)
     B, L = b["aa"].shape
     sd, pfx = seeded_sd, "ga_encoder.trunk.edge_transition_0."
@@ -364,15 +366,15 @@ def test_edge_transition_emits_next_pair_bias(f2, seeded_sd):
     wb, bb = sd["ga_encoder.trunk.ipa_1.linear_b.weight"], sd["ga_encoder.trunk.ipa_1.linear_b.bias"]
     out, bias = G.edge_transition(cu(f2["enc_edge"].reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")),
                                   cu(wf), cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
-                                  next_bias=(cu(wb), cu(bb)))
+                                  next_bias=(cu(wb), cu(bb)), persistent=form)
     em = (mask[:, None, :] * mask[:, :, None])[..., None]
     zref = f2["et0_out"] * em
     G.assert_close(out.view(B, L, L, 64), zref, REL, "z'")
     G.assert_close(bias, (math.sqrt(1.0 / 3.0) * F.linear(zref, wb, bb)).permute(0, 3, 1, 2), REL, "next block's pair bias [B,8,L,L]")
 
 
-@pytest.mark.parametrize("persistent", [True, False])
-@pytest.mark.parametrize("B,L", [(3, 7), (2, 45), (1, 3)])
+@pytest.mark.parametrize("persistent", [True, False, "v4"])
+@pytest.mark.parametrize("B,L", [(3, 7), (2, 45), (1, 3), (5, 33)])
 def test_edge_transition_ragged_tail(seeded_sd, persistent, B, L):
     """B*L*L not a multiple of the pair tile (64 / 128), tiles spanning several rows and samples; vs the oracle."""
     g = torch.Generator().manual_seed(9)
@@ -382,11 +384,12 @@ def test_edge_transition_ragged_tail(seeded_sd, persistent, B, L):
     G.assert_close(out.view(B, L, L, 64), ref, REL, "EdgeTransition ragged")
 
 
-def test_edge_transition_tile_list_through_the_c_abi(seeded_sd):
+@pytest.mark.parametrize("form", [True, "v4"])
+def test_edge_transition_tile_list_through_the_c_abi(seeded_sd, form):
     """pf_edge_transition_args.tile_list / n_tiles: listed tiles equal the run without a list, unlisted tiles are not touched;
     a list that covers exactly the tiles with an unmasked pair reproduces the oracle on every unmasked pair."""
     B, L = 2, 40
-    rows = _capi.load().pf_edge_transition_tile_rows(0)
+    rows = _capi.load().pf_edge_transition_v4_tile_rows() if form == "v4" else _capi.load().pf_edge_transition_tile_rows(0)
     nib, njb = (L + rows - 1) // rows, (L + 15) // 16
     g = torch.Generator().manual_seed(31)
     s, z = torch.randn(B, L, 128, generator=g), torch.randn(B, L, L, 64, generator=g)
@@ -394,7 +397,7 @@ def test_edge_transition_tile_list_through_the_c_abi(seeded_sd):
     mask[0, 16:32] = 0
     mask[1, 24:] = 0
     pfx = "ga_encoder.trunk.edge_transition_1."
-    full = _et_run(seeded_sd, pfx, s, z, mask, B, L)
+    full = _et_run(seeded_sd, pfx, s, z, mask, B, L, persistent=form)
     m = mask.bool()
     ra = torch.nn.functional.pad(m, (0, nib * rows - L)).view(B, nib, rows).any(-1)
     ca = torch.nn.functional.pad(m, (0, njb * 16 - L)).view(B, njb, 16).any(-1)
@@ -411,7 +414,7 @@ def test_edge_transition_tile_list_through_the_c_abi(seeded_sd):
     out = torch.full((B * L * L, 64), sentinel, device=G.dev())
     G.edge_transition(cu(z.reshape(-1, 64)), pre, cu(w1), cu(gq("trunk.2.weight")), cu(gq("trunk.2.bias")), cu(wf),
                       cu(gq("layer_norm.weight")), cu(gq("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
-                      tile_list=(cu(lst), cu(torch.tensor([ids.numel()], dtype=torch.int32))), out=out)
+                      tile_list=(cu(lst), cu(torch.tensor([ids.numel()], dtype=torch.int32))), out=out, persistent=form)
     out = out.cpu().view(B, nib * 0 + L, L, 64)
     full = full.cpu().view(B, L, L, 64)
     tile_active = active.view(B, nib, njb)
@@ -464,8 +467,9 @@ def test_ipa_key_end_through_the_c_abi(seeded_sd):
     assert torch.isnan(skipped[beyond]).all() and not torch.isnan(dense[beyond]).any()
 
 
+@pytest.mark.parametrize("form", [True, "v4"])
 @pytest.mark.parametrize("single_pass", [False, True])
-def test_edge_transition_emits_next_pair_values(f2, seeded_sd, single_pass):
+def test_edge_transition_emits_next_pair_values(f2, seeded_sd, single_pass, form):
     """pf_edge_transition_args.dz_out: W_dz z' of the NEXT IPA block (no bias) from z' in registers, next to the pair bias; z' and
     the bias are what they are without it."""
     b = _batch(f2)
@@ -482,7 +486,7 @@ def test_edge_transition_emits_next_pair_values(f2, seeded_sd, single_pass):
     wdz = sd["ga_encoder.trunk.ipa_1.down_z.weight"]
     run = lambda nd: G.edge_transition(cu(f2["enc_edge"].reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")),
                                        cu(wf), cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
-                                       next_bias=(cu(wb), cu(bb)), next_dz=nd, single_pass=single_pass)
+                                       next_bias=(cu(wb), cu(bb)), next_dz=nd, single_pass=single_pass, persistent=form)
     out0, bias0 = run(None)
     out, bias, dz = run(cu(wdz))
     assert torch.equal(out, out0) and torch.equal(bias, bias0)
@@ -496,7 +500,7 @@ def test_edge_transition_emits_next_pair_values(f2, seeded_sd, single_pass):
     if single_pass:                             # f16 storage of the same values (dz_out_f16)
         dz16 = G.edge_transition(cu(f2["enc_edge"].reshape(-1, 64)), pre, cu(w1), cu(g("trunk.2.weight")), cu(g("trunk.2.bias")),
                                  cu(wf), cu(g("layer_norm.weight")), cu(g("layer_norm.bias")), cu(mask.reshape(-1)), B, L,
-                                 next_bias=(cu(wb), cu(bb)), next_dz=cu(wdz), single_pass=True, dz_f16=True)[2]
+                                 next_bias=(cu(wb), cu(bb)), next_dz=cu(wdz), single_pass=True, dz_f16=True, persistent=form)[2]
         assert dz16.dtype == torch.float16 and torch.equal(dz16, dz.to(torch.float16))
 
 
