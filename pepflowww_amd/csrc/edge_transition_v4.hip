@@ -10,6 +10,8 @@
 // at a barrier every ~2.6 k cycles with an exposed LDS round trip behind it and a VALU block in front of it):
 //   * v_mfma_f32_32x32x16_f16: one weight fragment (32 features x 16 K) feeds 32 pairs -- half the LDS fragment bytes and half
 //     the matrix instructions per flop of the 16x16x32 form, 8 issue slots per MFMA for the VALU / LDS work beside it;
+//   * the z tile goes from HBM straight into registers, one tile ahead (its 64 KiB of LDS went to the ring: 32 KiB stages, half
+//     the stage barriers); only the per-residue rows and the masks are staged through LDS;
 //   * a wave owns NT tiles of 32 pairs (2 rows i x 16 columns j each); NW = 8 / NT waves, tile = 16 rows x 16 columns = 256 pairs:
 //     NT = 2 is one 512-register wave per SIMD (every fragment feeds 64 pairs), NT = 1 two 256-register waves per SIMD;
 //   * NO loader waves (their register allocation is the consumers': two of them cost a third of the file): every wave issues its
@@ -24,6 +26,17 @@
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
+#ifdef PF_ET4_PROF
+// dev-only: s_memtime stamps of every wave of one mid-grid workgroup at every stream entry of its second tile (tools/dev/et_bench.py)
+__device__ long long g_prof_et4[8 * 192];
+extern "C" int pf_debug_prof_et4(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_et4), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#define PROF4(i) do { if (it == 1 && blockIdx.x == gridDim.x / 2 && lane == 0) g_prof_et4[wave * 192 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PROF4(i)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,28 +45,24 @@ typedef short short8w __attribute__((ext_vector_type(8)));
 constexpr int TI = 16, TJ = 16;               // tile: 16 rows i x 16 columns j
 constexpr int NENT = 128;                     // stream entries (fragment pairs) per tile
 constexpr int ENT_B = 2048;                   // bytes per entry in the packed stream: hi 1 KiB | lo 1 KiB
-constexpr int STAGE_B = 16384;                // ring stage
+constexpr int STAGE_B = 32768;                // ring stage (the z tile does not pass through LDS: the ring gets its 64 KiB)
 constexpr int NSL = 3;                        // ring slots: stage in use + 2 stages of run-ahead
 constexpr int ADS = 1040, CES = 1040;         // LDS row strides of the a|d and c|e rows (1 KiB + 16: conflict-free float4 reads)
 constexpr int CONST_F = 64 + 64 + 192 + 16;   // LayerNorm gamma | beta | b2 | b_b (+pad)
 
-template <bool SP> constexpr int EPS = SP ? 16 : 8;              // entries per ring stage
-template <bool SP> constexpr int NSTG = NENT / EPS<SP>;          // stages per tile: 16 (fp32 mode), 8 (f16 mode)
+template <bool SP> constexpr int EPS = SP ? 32 : 16;             // entries per ring stage
+template <bool SP> constexpr int NSTG = NENT / EPS<SP>;          // stages per tile: 8 (fp32 mode), 4 (f16 mode)
 template <bool SP> constexpr int ENT_L = SP ? 1024 : 2048;       // bytes per entry in the ring (f16 mode: hi only)
 template <bool SP> constexpr int STG_A = 32 / EPS<SP>;           // stages of part A (everything that reads the tile inputs)
 
 template <bool SP, bool ZI> struct Map {
-    static constexpr int ZROW = ZI ? 2048 : 4096;                // bytes of one row i of the z tile
-    static constexpr int OFF_Z = NSL * STAGE_B;
-    static constexpr int OFF_AD = OFF_Z + TI * ZROW;
+    static constexpr int OFF_AD = NSL * STAGE_B;
     static constexpr int OFF_CE = OFF_AD + TI * ADS;
     static constexpr int OFF_MK = OFF_CE + TJ * CES;             // mask_i[16] | mask_j[16]
     static constexpr int OFF_CS = OFF_MK + 256;
     static constexpr int OFF_WB = OFF_CS + CONST_F * 4;          // 4 entries: [linear_b 8 rows | down_z 16 rows | 0 x 8] x K = 64
     static constexpr int LDS_BYTES = OFF_WB + 4 * ENT_B;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static constexpr int NZP = ZI ? 32 : 64;                     // LDS-DMA pieces of the z tile
-    static constexpr int NPI = NZP + 16 + 16 + 1;                // + a|d rows + c|e rows + masks
 };
 
 // (the base and the LDS address are wave-uniform by construction; readfirstlane pins them to SGPRs where the compiler's
@@ -63,41 +72,32 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
+#ifndef PF_ET4_WHATIF
+#define PF_ET4_WHATIF 0                        // dev what-if builds (tools/dev/et_variants.sh): 1 = no stage barriers, 2 = no LDS-DMA
+#endif
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+    if constexpr ((PF_ET4_WHATIF & 2) != 0) return;
     sbase = uniform_ptr(sbase);
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned lds_addr) {
+    if constexpr ((PF_ET4_WHATIF & 2) != 0) return;
     sbase = uniform_ptr(sbase);
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 #define LDSADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
 
-// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform, small)
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    }
-}
+template <int N> __device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 __device__ __forceinline__ void wg_barrier() {
+    if constexpr ((PF_ET4_WHATIF & 1) != 0) return;
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
+__device__ float g_et4_sink;                   // (dev what-if / slope builds only)
 struct Op { half8 h, l; };                     // one MFMA operand as hi / lo f16 planes (lo unused in the f16 mode)
 
 __device__ __forceinline__ f32x16 mfma32(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -107,6 +107,30 @@ template <bool SP> __device__ __forceinline__ void mac(f32x16& acc, const Op& w,
     acc = mfma32(w.h, x.h, acc);
     if constexpr (!SP) acc = mfma32(w.l, x.h, acc);
 }
+// the same three products spread over two accumulators that alternate from MFMA to MFMA (P = parity of the entry: the pattern
+// A B A | B A B continues across entries); f16 mode: one product, accumulator by entry parity
+template <bool SP, int P> __device__ __forceinline__ void mac_alt(f32x16& a0, f32x16& a1, const Op& w, const Op& x) {
+    f32x16& A = P ? a1 : a0;
+    f32x16& B = P ? a0 : a1;
+    if constexpr (SP) {
+        A = mfma32(w.h, x.h, A);
+    } else {
+        A = mfma32(w.h, x.l, A);
+        B = mfma32(w.h, x.h, B);
+        A = mfma32(w.l, x.h, A);
+    }
+}
+// two weight tiles (two accumulators) against one operand, MFMAs interleaved
+template <bool SP> __device__ __forceinline__ void mac_pair(f32x16& a0, f32x16& a1, const Op& w0, const Op& w1, const Op& x) {
+    if constexpr (!SP) { a0 = mfma32(w0.h, x.l, a0); a1 = mfma32(w1.h, x.l, a1); }
+    a0 = mfma32(w0.h, x.h, a0);
+    a1 = mfma32(w1.h, x.h, a1);
+    if constexpr (!SP) { a0 = mfma32(w0.l, x.h, a0); a1 = mfma32(w1.l, x.h, a1); }
+}
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
 template <bool SP> __device__ __forceinline__ Op ldw(const unsigned char* stage, int idx, int lane) {
     Op f;
     f.h = *reinterpret_cast<const half8*>(stage + idx * ENT_L<SP> + lane * 16);
@@ -115,8 +139,20 @@ template <bool SP> __device__ __forceinline__ Op ldw(const unsigned char* stage,
     return f;
 }
 // eight fp32 values -> operand planes (hi = f16(v), lo = f16(v - hi): exact difference, one v_fma_mix per value)
-template <bool SP, bool RELU> __device__ __forceinline__ Op split8(const float (&v)[8]) {
+#ifndef PF_ET4_XVALU
+#define PF_ET4_XVALU 0                         // dev slope experiment: extra VALU instructions per split8 call
+#endif
+#ifndef PF_ET4_XMFMA
+#define PF_ET4_XMFMA 0                         // dev slope experiment: extra MFMAs per stream entry (dummy accumulator)
+#endif
+template <bool SP, bool RELU> __device__ __forceinline__ Op split8(const float (&v)[8], float m1) {
     Op o;
+    if constexpr (PF_ET4_XVALU > 0) {
+        float t = v[0];
+#pragma unroll
+        for (int x = 0; x < PF_ET4_XVALU; ++x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(t) : "v"(m1));
+        if (t == 12345.678f) g_et4_sink = t;
+    }
     if constexpr (SP) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.h[e] = (_Float16)v[e];
@@ -128,22 +164,41 @@ template <bool SP, bool RELU> __device__ __forceinline__ Op split8(const float (
         }
         o.l = o.h;
     } else {
+        // per pair of values: [v_max_f32 x 2] + v_cvt_pk_f16_f32 (hi pair, RNE) + v_fma_mix{lo,hi}_f16 reading the packed hi halves
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = RELU ? fmaxf(v[e], 0.f) : v[e];
-            const _Float16 h = (_Float16)x;
-            o.h[e] = h;
-            o.l[e] = (_Float16)__builtin_fmaf((float)h, -1.0f, x);
+        for (int e = 0; e < 8; e += 2) {
+            float x0 = v[e], x1 = v[e + 1];
+            if constexpr (RELU) {              // ONE instruction: signed-integer max with 0 on the bit pattern (negative floats, -0.0
+                // included, are negative integers).  fmaxf costs two under IEEE semantics (a canonicalising max in front), and
+                // inline asm would need its own MFMA -> VALU wait states (the compiler pads nothing inside asm).
+                x0 = __int_as_float(max(__float_as_int(x0), 0));
+                x1 = __int_as_float(max(__float_as_int(x1), 0));
+            }
+            const float2v xp = {x0, x1};
+            const half2v hp = __builtin_convertvector(xp, half2v);
+            o.h[e] = hp[0];
+            o.h[e + 1] = hp[1];
+            o.l[e] = (_Float16)__builtin_fmaf((float)hp[0], m1, x0);      // m1 = -1 (opaque): x - hi, exact; one v_fma_mix each
+            o.l[e + 1] = (_Float16)__builtin_fmaf((float)hp[1], m1, x1);
         }
     }
     return o;
 }
 // accumulator registers 8 s .. 8 s + 7 of a 32-feature chunk = K-step s of the next GEMM (K permutation of pack_et_stream32)
-template <bool SP, bool RELU> __device__ __forceinline__ Op split_acc(const f32x16& a, int s) {
+template <bool SP, bool RELU> __device__ __forceinline__ Op split_acc(const f32x16& a, int s, float m1) {
+    if constexpr ((PF_ET4_WHATIF & 4) != 0) {  // no re-split VALU work: a constant operand; the accumulator stays live through one add
+        if (a[8 * s] == 12345.678f) g_et4_sink = a[8 * s + 1];
+        Op o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o.h[e] = (_Float16)0.25f; o.l[e] = (_Float16)0.001f; }
+        return o;
+    }
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = a[8 * s + e];
-    return split8<SP, RELU>(v);
+    return split8<SP, RELU>(v, m1);
 }
 
 struct Tile { int b, i0, j0; };
@@ -159,17 +214,21 @@ template <int I, int N, class F> __device__ __forceinline__ void cfor(F&& f) {
 #define CI(name, ic) constexpr int name = decltype(ic)::value
 
 template <bool SP, int NT, bool ZI, bool ZO, bool DZ>
-__global__ __launch_bounds__(64 * (8 / NT), 1) void edge_transition_v4_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
+__global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_eu(2 / NT, 2 / NT))) void edge_transition_v4_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     static_assert(SP || (!ZI && !ZO), "f16 pair tensor: f16 mode only");
     constexpr int NW = 8 / NT;                 // waves
     constexpr int RW = 2 * NT;                 // rows i per wave
     using M = Map<SP, ZI>;
     constexpr int EPSv = EPS<SP>, NSTGv = NSTG<SP>, SA = STG_A<SP>;
-    constexpr int CW = 16 / NW;                                  // weight pieces per wave and stage
-    constexpr int KMAX = (M::NPI + NW - 1) / NW;                 // input pieces per wave and tile
-    constexpr int WIN = NSTGv - 1 - SA;                          // stages SA .. NSTG-2 carry them
-    constexpr int PPS = (KMAX + WIN - 1) / WIN;                  // ... PPS per stage
-    static_assert(CW + PPS <= 11, "wait_vm range");
+    // LDS-DMA issue is the job of the ND first-dispatched waves: with two waves per SIMD the older one wins the issue arbitration
+    // and reaches every stage barrier several hundred cycles before its partner (phase stamps, tools/dev/et_bench.py), so it has
+    // the slack; the younger waves (the critical path of every stage) issue nothing and wait for nothing but the barrier.
+#ifndef PF_ET4_ALL_LOAD
+    constexpr int ND = NW > 4 ? 4 : NW;
+#else
+    constexpr int ND = NW;
+#endif
+    constexpr int CW = (STAGE_B / 1024) / ND;                    // weight pieces per issuing wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Cs = reinterpret_cast<float*>(smem + M::OFF_CS);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -201,137 +260,196 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) void edge_transition_v4_kernel(pf
             reinterpret_cast<float4*>(smem + M::OFF_WB)[i] = reinterpret_cast<const float4*>(a.wb_frags32)[i];
 
     // ---------------- LDS-DMA issue: every wave carries its share ----------------
+    // Addressing is (uniform SGPR base) + (per-lane 32-bit offset); everything that does not change from piece to piece is formed
+    // once (per kernel / per tile), so that a piece costs a handful of scalar instructions in the consumers' instruction streams.
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w_stream32);
     const unsigned char* zg = reinterpret_cast<const unsigned char*>(a.z_in);
     const unsigned char* pg = reinterpret_cast<const unsigned char*>(a.pre);
     const unsigned l16 = lane * 16;
-    auto issue_w = [&](int stage /* of the tile */, int slot) {
+    constexpr int WSRC_PIECE = SP ? ENT_B : 1024;                // source stride of the pieces of a ring stage (f16 mode: hi halves only)
+    constexpr int NPS = STAGE_B / 1024;                          // LDS-DMA pieces per ring stage
+    constexpr int WSRC_STAGE = NPS * WSRC_PIECE;
+    const unsigned wave_src = (unsigned)(wave & (ND - 1)) * WSRC_PIECE;   // weight piece k of this wave: p = (wave & (ND-1)) + ND k
+    const unsigned wave_lds = lds0 + (wave & (ND - 1)) * 1024;
+    const bool loader = wave < ND;
+    auto issue_w = [&](int stage /* of the tile: compile time */, int slot) __attribute__((always_inline)) {
+        // (an opaque zero per call: otherwise every piece address of every stage is loop-invariant, gets hoisted out of the tile
+        //  loop and is kept -- or spilled -- for the whole kernel: 64 address pairs)
+        unsigned zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        const unsigned char* base = wsrc + stage * WSRC_STAGE + wave_src + zero;
+        const unsigned dst = wave_lds + slot * STAGE_B;
 #pragma unroll
-        for (int k = 0; k < CW; ++k) {
-            const int p = wave + NW * k;                         // piece 0..15 of the stage
-            if constexpr (SP) glds16(wsrc + (size_t)(stage * 16 + p) * ENT_B, l16, lds0 + slot * STAGE_B + p * 1024);
-            else glds16(wsrc + (size_t)stage * STAGE_B + p * 1024, l16, lds0 + slot * STAGE_B + p * 1024);
+        for (int k = 0; k < CW; ++k) glds16(base + ND * k * WSRC_PIECE, l16, dst + ND * k * 1024);
+    };
+    // Tile inputs through LDS: per issuing wave NAW a|d rows, NAW c|e rows and one mask piece (every issuing wave writes the same
+    // 256 bytes: the piece counts -- and with them the immediates of the counted waits -- are compile-time numbers).
+    constexpr int NAW = 16 / ND, TPW = 2 * NAW + 1;
+    struct InAddr { const unsigned char* pb; const float* mb; };
+    auto in_addr = [&](const Tile& t2) __attribute__((always_inline)) {
+        InAddr ia;
+        ia.pb = pg + (size_t)(t2.b * L) * (PF_ET_PRE * 4);
+        ia.mb = a.mask + (size_t)t2.b * L;
+        return ia;
+    };
+    // lane offsets into a pre row: [a 768 B | d 256 B] = bytes 0..767 | 1536..1791, [c 768 B | e 256 B] = 768..1535 | 1792..2047
+    auto issue_in = [&](const InAddr& ia, const Tile& t2, int u /* compile time: piece 0 .. TPW-1 of this wave */) __attribute__((always_inline)) {
+        if (u < NAW) {
+            const int k = wave + ND * u;
+            int i = t2.i0 + k;
+            i = i < L ? i : L - 1;
+            glds16(ia.pb + (unsigned)i * (unsigned)(PF_ET_PRE * 4), l16 < 768 ? l16 : l16 + 768, lds0 + M::OFF_AD + k * ADS);
+        } else if (u < 2 * NAW) {
+            const int k = wave + ND * (u - NAW);
+            int jj = t2.j0 + k;
+            jj = jj < L ? jj : L - 1;
+            glds16(ia.pb + (unsigned)jj * (unsigned)(PF_ET_PRE * 4), l16 < 768 ? l16 + 768 : l16 + 1024, lds0 + M::OFF_CE + k * CES);
+        } else {
+            int row = lane < 16 ? t2.i0 + lane : t2.j0 + (lane & 15);   // lanes 0..15: mask_i, 16..31: mask_j
+            row = row < L ? row : L - 1;                         // (tiles on the edge re-read the last row / column)
+            glds4(ia.mb, (unsigned)row * 4u, lds0 + M::OFF_MK);
         }
     };
-    // z piece: fp32 rows: piece 4 row + m = pairs j = 4 m + (lane >> 4), LDS chunk lane & 15 holds the global chunk (lane & 15) ^ j;
-    // f16 rows (ZI): piece 2 row + m = pairs j = 8 m + (lane >> 3), LDS chunk lane & 7 holds the global chunk (lane & 7) ^ (j >> 1)
-    // (the key j >> 1: pairs j and j + 8 sit 1 KiB apart, on the same banks)
-    auto issue_in = [&](const Tile& tl, int q) {                 // input piece q of tile tl (q wave-uniform)
-        if (q < M::NZP) {
-            const int row = ZI ? (q >> 1) : (q >> 2), m = ZI ? (q & 1) : (q & 3);
-            int i = tl.i0 + row;
-            i = i < L ? i : L - 1;
-            unsigned off;
+    // The z tile: HBM -> registers, one tile ahead.  Lane (pair n = 16 rl + jl, K group g) of the wave's tile t needs features
+    // 16 ks + 8 g .. + 7 of its pair for K-step ks: 32 contiguous bytes (fp32) / 16 (f16) -- the 8 (4) loads of a lane walk its
+    // pair's 256-byte (128) row, so every fetched line is consumed completely by the wave that fetched it.
+    struct ZRaw { float4 f[NT][4][2]; half8 h[NT][4]; };
+    // (ks0 .. ks1: issued a K-step at a time over the first chunks of part B -- all eight loads of all eight waves at once fill the
+    //  vector-memory queue of the CU in front of the LDS-DMA pieces: phase stamps showed every wave stuck ~2 k cycles there)
+    auto load_z = [&](const Tile& t2, ZRaw& zr, int ks0, int ks1) __attribute__((always_inline)) {
+        int jc = t2.j0 + jl;
+        jc = jc < L ? jc : L - 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int ic = t2.i0 + RW * wave + 2 * t + rl;
+            ic = ic < L ? ic : L - 1;
+            const size_t pair = (size_t)(t2.b * L + ic) * L + jc;
             if constexpr (ZI) {
-                const int pp = m * 8 + (lane >> 3);
-                int jr = pp;
-                jr = tl.j0 + jr < L ? jr : L - 1 - tl.j0;
-                off = (unsigned)(jr * 128 + 16 * ((lane & 7) ^ ((pp >> 1) & 7)));
-                glds16(zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 128, off, lds0 + M::OFF_Z + q * 1024);
+                const half8* src = reinterpret_cast<const half8*>(zg + pair * 128) + g;
+#pragma unroll
+                for (int ks = ks0; ks < ks1; ++ks) zr.h[t][ks] = src[2 * ks];
             } else {
-                const int rr = m * 4 + (lane >> 4);
-                int jr = rr;
-                jr = tl.j0 + jr < L ? jr : L - 1 - tl.j0;
-                off = (unsigned)(jr * 256 + 16 * ((lane & 15) ^ rr));
-                glds16(zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 256, off, lds0 + M::OFF_Z + q * 1024);
+                const float4* src = reinterpret_cast<const float4*>(zg + pair * 256) + 2 * g;
+#pragma unroll
+                for (int ks = ks0; ks < ks1; ++ks) { zr.f[t][ks][0] = src[4 * ks]; zr.f[t][ks][1] = src[4 * ks + 1]; }
             }
-        } else if (q < M::NZP + 16) {                            // [a 768 B | d 256 B] of row i0 + k
-            const int k = q - M::NZP;
-            int i = tl.i0 + k;
-            i = i < L ? i : L - 1;
-            const unsigned off = l16 < 768 ? l16 : 1536 + (l16 - 768);
-            glds16(pg + (size_t)(tl.b * L + i) * (PF_ET_PRE * 4), off, lds0 + M::OFF_AD + k * ADS);
-        } else if (q < M::NZP + 32) {                            // [c 768 B | e 256 B] of column j0 + k
-            const int k = q - M::NZP - 16;
-            int j = tl.j0 + k;
-            j = j < L ? j : L - 1;
-            const unsigned off = l16 < 768 ? 768 + l16 : 1792 + (l16 - 768);
-            glds16(pg + (size_t)(tl.b * L + j) * (PF_ET_PRE * 4), off, lds0 + M::OFF_CE + k * CES);
-        } else {                                                 // lanes 0..15: mask_i, 16..31: mask_j (the rest re-read, unused)
-            int row = lane < 16 ? tl.i0 + lane : tl.j0 + (lane & 15);
-            row = row < L ? row : L - 1;
-            glds4(a.mask + (size_t)tl.b * L, (unsigned)row * 4u, lds0 + M::OFF_MK);
         }
     };
+    // pieces of the next tile's inputs issued at the start of stage s (stages SA .. NSTG-2, PPS each)
+    constexpr int WIN = NSTGv - 1 - SA;
+    constexpr int PPS = (TPW + WIN - 1) / WIN;
+    static_assert(CW + PPS <= 15, "counted waits: 4-bit immediates kept small");
 
     int tile = blockIdx.x;
     Tile tl = tile_of(tile);
-    // prologue: the first tile's inputs (all of them, spread over the waves) and ring stages 0 and 1
-    for (int k = 0; k < KMAX; ++k) {
-        const int q = wave + NW * k;
-        if (q < M::NPI) issue_in(tl, q);
+    ZRaw zraw;
+    load_z(tl, zraw, 0, 4);
+    if (loader) {   // prologue: the first tile's inputs and ring stages 0 and 1
+        const InAddr ia = in_addr(tl);
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) issue_in(ia, tl, u);
+        issue_w(0, 0);
+        issue_w(1, 1);
     }
-    issue_w(0, 0);
-    issue_w(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int slot = 0;
     const float* mkb = reinterpret_cast<const float*>(smem + M::OFF_MK);
+    float m1 = -1.0f;                                            // opaque to the optimiser: keeps fma(hi, -1, x) an fma (v_fma_mix)
+    asm volatile("" : "+s"(m1));
 
     for (int it = 0; it < my_tiles; ++it, tile += gridDim.x) {
         tl = tile_of(tile);
         const bool have_next = it + 1 < my_tiles;
         Tile tn = tl;
         if (have_next) tn = tile_of(tile + gridDim.x);
+        const InAddr ian = in_addr(tn);
         const int gs0 = it * NSTGv;
-        int issued = 0;                                          // pieces this wave issued since the last stage barrier
         // stage s of this tile starts: its ring slot is complete and visible; issue the stage two ahead into the slot everybody
         // left at the last barrier, and this stage's slice of the next tile's inputs (part A, their only reader, is over)
-        auto stage_begin = [&](int s) {
-            issued = 0;
+        auto stage_begin = [&](auto is) __attribute__((always_inline)) {
+            CI(s, is);
+            if (!loader) return;
             if (gs0 + s + 2 < total_stages) {
                 int sl2 = slot + 2;
                 sl2 = sl2 >= NSL ? sl2 - NSL : sl2;
                 issue_w((s + 2) % NSTGv, sl2);
-                issued += CW;
             }
-            if (have_next && s >= SA && s < NSTGv - 1) {
+            if constexpr (s >= SA && s < NSTGv - 1) {
+                if (have_next) {
 #pragma unroll
-                for (int u = 0; u < PPS; ++u) {
-                    const int k = (s - SA) * PPS + u;
-                    const int q = wave + NW * k;
-                    if (k < KMAX && q < M::NPI) { issue_in(tn, q); issued += 1; }
+                    for (int u = (s - SA) * PPS; u < (s - SA + 1) * PPS && u < TPW; ++u) issue_in(ian, tn, u);
                 }
             }
         };
-        auto stage_end = [&]() {
-            wait_vm(issued);                                     // everything older than this stage's own issues has landed
+        // leave stage s: everything older than what this wave issued at its start has landed (counted wait: loads complete in
+        // order), then the barrier makes every wave's pieces visible and frees the slot of stage s - 1 ... s for re-use
+        auto stage_end = [&](auto is) __attribute__((always_inline)) {
+            CI(s, is);
+            constexpr int lo = (s - SA) * PPS, hi = (s - SA + 1) * PPS < TPW ? (s - SA + 1) * PPS : TPW;
+            constexpr int NI0 = (s >= SA && s < NSTGv - 1 && hi > lo) ? hi - lo : 0;
+            // + this wave's own z loads (registers, next tile) issued during stage s: those of chunk c go out right before the first
+            // entry 32 + 16 c of the chunk is fetched -- in the tail of the previous stage when that entry opens a stage
+            constexpr int NZL = ZI ? NT : 2 * NT;                // loads per K-step
+            constexpr auto zstage = [](int c) { const int e0 = 32 + 16 * c; return e0 % EPSv == 0 ? e0 / EPSv - 1 : e0 / EPSv; };
+            constexpr int NZ = NZL * ((zstage(0) == s) + (zstage(1) == s) + (zstage(2) == s) + (zstage(3) == s));
+            constexpr int NI = NI0 + NZ;
+            if (loader) {
+                if (have_next) wait_vm_c<CW + NI>();
+                else if (gs0 + s + 2 < total_stages) wait_vm_c<CW>();
+                else wait_vm_c<0>();
+            }
+            PROF4(131 + 3 * s);
             wg_barrier();
+            PROF4(132 + 3 * s);
             slot = slot + 1 == NSL ? 0 : slot + 1;
         };
+        // Stream entry e for the MFMAs: entries are consumed strictly in order, and entry e + 1 is requested from LDS BEFORE the MFMAs
+        // of entry e are issued (two alternating register sets) -- within a ring stage; the first entry of a stage is read right
+        // after its barrier.  (Left to itself hipcc re-uses ONE register quad for every fragment: read, wait, multiply, read, ...)
+        f32x16 xacc;                                             // (slope experiment only)
+        if constexpr (PF_ET4_XMFMA > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
+        }
+#define XMFMA(w, x) do { if constexpr (PF_ET4_XMFMA > 0) { _Pragma("unroll") for (int xx = 0; xx < PF_ET4_XMFMA; ++xx) xacc = mfma32((w).h, (x).h, xacc); } } while (0)
+        Op wq[2];
+        auto getw = [&](auto ie) __attribute__((always_inline)) -> const Op& {
+            CI(e, ie);
+            PROF4(e);
+            if constexpr (e % EPSv == 0) {
+                if constexpr (e != 0) stage_end(std::integral_constant<int, e / EPSv - 1>{});
+                stage_begin(std::integral_constant<int, e / EPSv>{});
+                PROF4(133 + 3 * (e / EPSv));
+                wq[e & 1] = ldw<SP>(smem + slot * STAGE_B, 0, lane);
+            }
+            if constexpr (e + 1 < NENT && (e + 1) % EPSv != 0) wq[(e + 1) & 1] = ldw<SP>(smem + slot * STAGE_B, (e + 1) % EPSv, lane);
+            __builtin_amdgcn_sched_barrier(0);                   // pins the request above the MFMAs that follow in program order
+            return wq[e & 1];
+        };
+#define GETW(e) getw(std::integral_constant<int, (e)>{})
 #define ENTRY(e) (smem + slot * STAGE_B), ((e) % EPSv)
-#define AT_ENTRY(e) do { if constexpr ((e) % EPSv == 0) { if constexpr ((e) != 0) stage_end(); stage_begin((e) / EPSv); } } while (0)
+#define AT_ENTRY(e) do { if constexpr ((e) % EPSv == 0) { if constexpr ((e) != 0) stage_end(std::integral_constant<int, (e) / EPSv - 1>{}); \
+                                                          stage_begin(std::integral_constant<int, (e) / EPSv>{}); } } while (0)
 
         // ---- per-pair bookkeeping of this wave's NT tiles of 32 pairs: rows i0 + RW wave + 2 t + rl, column j0 + jl
-        const int j = tl.j0 + jl;
-        int iv[NT];
-        bool valid[NT];
-        size_t pidx[NT];
-        float mk[NT];
+        float mk[NT];                                            // (read now: the mask buffer is refilled for the next tile in part B)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            iv[t] = tl.i0 + RW * wave + 2 * t + rl;
-            valid[t] = iv[t] < L && j < L;
-            pidx[t] = (size_t)(tl.b * L + iv[t]) * L + j;
-            mk[t] = mkb[RW * wave + 2 * t + rl] * mkb[16 + jl];
-        }
-        // ---- z operands: K-step ks = features 16 ks + 8 g .. + 7 of pair n (natural K order)
+        for (int t = 0; t < NT; ++t) mk[t] = mkb[RW * wave + 2 * t + rl] * mkb[16 + jl];
+        // ---- z operands: K-step ks = features 16 ks + 8 g .. + 7 of pair n (natural K order), from the registers loaded a tile ago
         Op zop[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int row = RW * wave + 2 * t + rl;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if constexpr (ZI) {
-                    zop[t][ks].h = *reinterpret_cast<const half8*>(smem + M::OFF_Z + row * 2048 + jl * 128 + 16 * ((2 * ks + g) ^ ((jl >> 1) & 7)));
-                    zop[t][ks].l = zop[t][ks].h;
+                    zop[t][ks].h = zraw.h[t][ks];
+                    zop[t][ks].l = zraw.h[t][ks];
                 } else {
-                    const unsigned char* zr = smem + M::OFF_Z + row * 4096 + jl * 256;
-                    const float4 q0 = *reinterpret_cast<const float4*>(zr + 16 * ((4 * ks + 2 * g) ^ jl));
-                    const float4 q1 = *reinterpret_cast<const float4*>(zr + 16 * ((4 * ks + 2 * g + 1) ^ jl));
+                    const float4 q0 = zraw.f[t][ks][0], q1 = zraw.f[t][ks][1];
                     const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                    zop[t][ks] = split8<SP, false>(v);
+                    zop[t][ks] = split8<SP, false>(v, m1);
                 }
             }
         }
@@ -349,52 +467,41 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) void edge_transition_v4_kernel(pf
             }
         };
 
+        // (Dependent accumulation is free on this part: a chain of v_mfma_f32_32x32x16_f16 on ONE accumulator issues every 32 cycles,
+        //  tools/dev/mfma_chain_bench.hip -- no second accumulator per GEMM is needed.)
         // ================= part A: final layer's z part, then GEMM1 (stream entries 0..31) =================
         f32x16 m3[2][NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < NT; ++t) seed(m3[mt][t], adr[t], 192 + 32 * mt);     // d_i + e_j (bf folded into e)
-        cfor<0, 8>([&](auto ic) __attribute__((always_inline)) {
-            CI(e, ic);
-            constexpr int mt = e / 4, ks = e % 4;
-            AT_ENTRY(e);
-            const Op w = ldw<SP>(ENTRY(e), lane);
+        cfor<0, 8>([&](auto ie) __attribute__((always_inline)) {                      // entry 2 ks + mt
+            CI(e, ie);
+            const Op& w = GETW(e);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mac<SP>(m3[mt][t], w, zop[t][ks]);
+            for (int t = 0; t < NT; ++t) mac<SP>(m3[e & 1][t], w, zop[t][e >> 1]);
         });
         Op h1[NT][12];
-        f32x16 accp[NT];                                        // GEMM1 tile mt1 - 1: re-split under the MFMAs of tile mt1
-        cfor<0, 7>([&](auto imt) __attribute__((always_inline)) {
+        cfor<0, 6>([&](auto imt) __attribute__((always_inline)) {
             CI(mt1, imt);
             f32x16 acc[NT];
-            if constexpr (mt1 < 6) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) seed(acc[t], adr[t], 32 * mt1);          // a_i + c_j (b1 folded into c)
-                cfor<0, 4>([&](auto iks) __attribute__((always_inline)) {
-                    CI(ks, iks);
-                    constexpr int e = 8 + mt1 * 4 + ks;
-                    AT_ENTRY(e);
-                    const Op w = ldw<SP>(ENTRY(e), lane);
+            for (int t = 0; t < NT; ++t) seed(acc[t], adr[t], 32 * mt1);              // a_i + c_j (b1 folded into c)
+            cfor<0, 4>([&](auto iks) __attribute__((always_inline)) {
+                CI(ks, iks);
+                const Op& w = GETW(8 + mt1 * 4 + ks);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) mac<SP>(acc[t], w, zop[t][ks]);
-                    if constexpr (mt1 > 0 && ks < 2) {
+                for (int t = 0; t < NT; ++t) mac<SP>(acc[t], w, zop[t][ks]);
+            });
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) h1[t][2 * (mt1 - 1) + ks] = split_acc<SP, true>(accp[t], ks);
-                    }
-                });
-#pragma unroll
-                for (int t = 0; t < NT; ++t) accp[t] = acc[t];
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) h1[t][10 + ks] = split_acc<SP, true>(accp[t], ks);
+            for (int t = 0; t < NT; ++t) {
+                h1[t][2 * mt1] = split_acc<SP, true>(acc[t], 0, m1);
+                h1[t][2 * mt1 + 1] = split_acc<SP, true>(acc[t], 1, m1);
             }
         });
 
-        // ================= part B: GEMM2 chunk c + 1 | re-split of chunk c | final layer K-chunk c =================
-        // stream: W2[0] (entries 32..43), then per c: W2[c + 1] (12), Wf[:, 64 + 32 c ..] (4: K-step s x tile mt); last Wf chunk 5
+        // the z operands are dead from here on: their registers take the NEXT tile's z (a K-step per chunk, see load_z)
+        // ================= part B: per 32-feature chunk c: GEMM2 (12 entries) | ReLU + re-split | final layer K-chunk c (4 entries) ====
         auto seed_b2 = [&](f32x16& acc, int c) __attribute__((always_inline)) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -402,52 +509,45 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) void edge_transition_v4_kernel(pf
                 acc[4 * b + 0] = x.x; acc[4 * b + 1] = x.y; acc[4 * b + 2] = x.z; acc[4 * b + 3] = x.w;
             }
         };
-        f32x16 a2p[NT];
-        cfor<0, 7>([&](auto icc) __attribute__((always_inline)) {  // iteration c: GEMM2 of chunk c (c < 6), finish chunk c - 1 (c > 0)
+        cfor<0, 6>([&](auto icc) __attribute__((always_inline)) {
             CI(c, icc);
+            if constexpr (c < 4) { if (have_next) load_z(tn, zraw, c, c + 1); }
             f32x16 a2[NT];
+            constexpr int e0 = 32 + 16 * c;                      // first entry of W2 tile c
+#pragma unroll
+            for (int t = 0; t < NT; ++t) seed_b2(a2[t], c);
+            cfor<0, 12>([&](auto iks) __attribute__((always_inline)) {
+                CI(ks, iks);
+                const Op& w = GETW(e0 + ks);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mac<SP>(a2[t], w, h1[t][ks]);
+            });
             Op h2[NT][2];
-            constexpr int e0 = c == 0 ? 32 : 44 + 16 * (c - 1);  // first entry of W2[c]
-            if constexpr (c < 6) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) seed_b2(a2[t], c);
-                cfor<0, 12>([&](auto iks) __attribute__((always_inline)) {
-                    CI(ks, iks);
-                    constexpr int e = e0 + ks;
-                    AT_ENTRY(e);
-                    const Op w = ldw<SP>(ENTRY(e), lane);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) mac<SP>(a2[t], w, h1[t][ks]);
-                    if constexpr (c > 0 && (ks == 2 || ks == 5)) {   // chunk c - 1: ReLU + re-split, a few MFMAs into this chunk
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) h2[t][ks == 2 ? 0 : 1] = split_acc<SP, true>(a2p[t], ks == 2 ? 0 : 1);
-                    }
-                });
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) h2[t][s] = split_acc<SP, true>(a2p[t], s);
+            for (int t = 0; t < NT; ++t) {
+                h2[t][0] = split_acc<SP, true>(a2[t], 0, m1);
+                h2[t][1] = split_acc<SP, true>(a2[t], 1, m1);
             }
-            if constexpr (c > 0) {
-                constexpr int ef = c < 6 ? e0 + 12 : 124;        // entries of Wf K-chunk c - 1
-                cfor<0, 4>([&](auto iq) __attribute__((always_inline)) {
-                    CI(qq, iq);
-                    constexpr int s = qq / 2, mt = qq % 2;
-                    constexpr int e = ef + qq;
-                    AT_ENTRY(e);
-                    const Op w = ldw<SP>(ENTRY(e), lane);
+            cfor<0, 4>([&](auto iq) __attribute__((always_inline)) {                  // entries e0 + 12 + 2 s + mt
+                CI(q, iq);
+                const Op& w = GETW(e0 + 12 + q);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) mac<SP>(m3[mt][t], w, h2[t][s]);
-                });
-            }
-            if constexpr (c < 6) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) a2p[t] = a2[t];
-            }
+                for (int t = 0; t < NT; ++t) mac<SP>(m3[q & 1][t], w, h2[t][q >> 1]);
+            });
         });
 
+        PROF4(128);
         // ================= epilogue: LayerNorm over the 64 features (32 here, 32 in lane ^ 32), mask, stores =================
+        const int j = tl.j0 + jl;
+        int iv[NT];
+        bool valid[NT];
+        size_t pidx[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            iv[t] = tl.i0 + RW * wave + 2 * t + rl;
+            valid[t] = iv[t] < L && j < L;
+            pidx[t] = (size_t)(tl.b * L + iv[t]) * L + j;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float s = 0.f;
@@ -501,7 +601,7 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) void edge_transition_v4_kernel(pf
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        const Op x = split_acc<SP, false>(o[mt], s2);
+                        const Op x = split_acc<SP, false>(o[mt], s2, m1);
                         Op w;
                         const unsigned char* wb = smem + M::OFF_WB + (2 * mt + s2) * ENT_B;
                         w.h = *reinterpret_cast<const half8*>(wb + lane * 16);
@@ -541,9 +641,14 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) void edge_transition_v4_kernel(pf
                 }
             }
         }
-        stage_end();                                             // leaves the last stage of this tile; the next tile's inputs are in LDS
+        PROF4(129);
+        if constexpr (PF_ET4_XMFMA > 0) { if (xacc[0] == 12345.678f) g_et4_sink = xacc[1]; }
+        stage_end(std::integral_constant<int, NSTGv - 1>{});     // leaves the last stage of this tile; the next tile's inputs are in LDS
+        PROF4(130);
 #undef ENTRY
 #undef AT_ENTRY
+#undef GETW
+#undef XMFMA
     }
 }
 

@@ -160,11 +160,10 @@ def _k_perm(dev):
 
 def pack_et_stream32(w1z, w2, wf):
     """EdgeTransition weights as the 128-entry stream of csrc/edge_transition_v4.hip, in execution order:
-      entries 0..7    Wf[:, :64]   tile mt (2) x K-step ks (4), natural K
+      entries 0..7    Wf[:, :64]   K-step ks (4) x tile mt (2), natural K
       entries 8..31   W1z          tile mt1 (6) x K-step ks (4), natural K
-      entries 32..43  W2 tile 0    K-steps (c', s) = (0,0),(0,1),(1,0) ... (5,1), permuted K (h1 chunk c', half s)
-      then for c = 0..4: W2 tile c + 1 (12 entries), Wf[:, 64 + 32 c ..] as K-step s (2) x tile mt (2), permuted K (h2 chunk c)
-      entries 124..127 Wf[:, 64 + 160 ..] (chunk 5).
+      then for c = 0..5 (16 entries each): W2 tile c: K-steps (c', s) = (0,0),(0,1),(1,0) ... (5,1) in permuted K order (h1 chunk c',
+      half s), followed by Wf[:, 32 c ..] as K-step s (2) x tile mt (2), permuted K (h2 chunk c; y = Wf (h2 + x): all of Wf acts on h2).
     Layout/packing only -- no model arithmetic."""
     w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
     assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
@@ -172,17 +171,13 @@ def pack_et_stream32(w1z, w2, wf):
     nat, perm = _k_nat(dev), _k_perm(dev)
     wfz = wf[:, :64].contiguous()
     out = []
-    for mt in range(2):
-        out += [_frag32(wfz, mt, nat(ks)) for ks in range(4)]
+    for ks in range(4):
+        out += [_frag32(wfz, mt, nat(ks)) for mt in range(2)]
     for mt1 in range(6):
         out += [_frag32(w1z, mt1, nat(ks)) for ks in range(4)]
-    w2_tile = lambda c: [_frag32(w2, c, perm(ks // 2, ks % 2)) for ks in range(12)]
-    wf_chunk = lambda c: [_frag32(wf, mt, perm(c, s)) for s in range(2) for mt in range(2)]
-    out += w2_tile(0)
-    for c in range(5):
-        out += w2_tile(c + 1)
-        out += wf_chunk(c)
-    out += wf_chunk(5)
+    for c in range(6):                                           # (y = Wf (h2 + x): the FULL final layer acts on h2)
+        out += [_frag32(w2, c, perm(ks // 2, ks % 2)) for ks in range(12)]
+        out += [_frag32(wf, mt, perm(c, s)) for s in range(2) for mt in range(2)]
     stream = torch.cat(out).contiguous()
     assert stream.numel() * 2 == 256 * 1024
     return stream
@@ -344,9 +339,10 @@ class DenoiseEngine:
         self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
         # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
-        # EdgeTransition kernel form: the 32x32 kernel (csrc/edge_transition_v4.hip) unless PF_ET_V4=0 (A/B runs against v3)
+        # EdgeTransition kernel form, by measurement at B=64, L=128 (same box, in the step): fp32-parity mode: the 32x32 kernel
+        # (csrc/edge_transition_v4.hip) 379 vs 402 us; f16 mode: the 16x16 kernel (v3) 180 vs 195 us.  PF_ET_V4=0 / 1 forces one (A/B runs).
         import os
-        self.et_v4 = os.environ.get("PF_ET_V4", "1") != "0"
+        self.et_v4 = {"0": False, "1": True}.get(os.environ.get("PF_ET_V4", ""), precision == "fp32")
         self.et_rows = int(self.lib.pf_edge_transition_v4_tile_rows()) if self.et_v4 else int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
         self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
