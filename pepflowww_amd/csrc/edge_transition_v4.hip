@@ -354,6 +354,10 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef PF_ET4_PRIO
+    if (PF_ET4_PRIO == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);      // dev experiment: static priority for one half
+    if (PF_ET4_PRIO == 2 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     int slot = 0;
     const float* mkb = reinterpret_cast<const float*>(smem + M::OFF_MK);
     float m1 = -1.0f;                                            // opaque to the optimiser: keeps fma(hi, -1, x) an fma (v_fma_mix)

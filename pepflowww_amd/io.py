@@ -67,20 +67,36 @@ class PepDataset:
         path = os.path.join(dataset_dir, f"{name}_structure_cache.lmdb")
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path}: structure cache not found (it is written by the reference's preprocessing)")
-        self._db = LmdbReader(path)
-        self.db_ids = [k.decode() for k in self._db.keys()]
+        self._path = path
+        self._db = None                      # opened lazily and per process (pep_dataloader.py:105-121 connects on first access):
+        db = LmdbReader(path)                # the mmap handle cannot be pickled -- DataLoader(num_workers>0) copies the dataset
+        self.db_ids = [k.decode() for k in db.keys()]
+        db.close()
+
+    def _connect(self):
+        if self._db is None:
+            from .lmdb_reader import LmdbReader
+            self._db = LmdbReader(self._path)
+        return self._db
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_db"] = None                      # every worker process opens its own reader
+        return d
 
     def __len__(self):
         return len(self.db_ids)
 
     def __getitem__(self, index):
         import pickle
-        raw = self._db.get(self.db_ids[index].encode())
+        raw = self._connect().get(self.db_ids[index].encode())
         data = pickle.loads(raw)
         return self.transform(data) if self.transform is not None else data
 
     def close(self):
-        self._db.close()
+        if self._db is not None:
+            self._db.close()
+            self._db = None
 
 
 def save_trajectory(final_step, batch, path):

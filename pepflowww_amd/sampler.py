@@ -112,7 +112,8 @@ class DeviceSampler:
         self._init_keep = (rot0, tr0, ang0, sx0)
 
     def _one_step(self):
-        self.eng.run()
+        import os
+        self.eng.run(concurrent=os.environ.get("PF_CONCURRENT", "0") == "1")   # (dev switch: projection(b+1) beside EdgeTransition(b))
         rc = self.lib.pf_sampler_step(C.byref(self.args), _capi.stream_ptr())
         _capi.check(rc, "pf_sampler_step")
 

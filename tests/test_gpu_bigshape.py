@@ -175,8 +175,10 @@ def test_cfg3_variable_length_batch(model, seeded_sd):
     lens = batch["res_mask"].sum(1)
     order = torch.argsort(lens)
     pick = sorted({int(order[0]), int(order[-1])} | {int(order[i]) for i in range(5, 64, 10)})
+    refs = {}
     for b in pick:
         ref = _oracle_chunk(seeded_sd, batch, noise, b, b + 1, NS)
+        refs[b] = ref
         n = int(lens[b])
         sl = [{kk: vv[b:b + 1, :n] for kk, vv in t.items()} for t in traj]
         rf = [{kk: vv[:, :n] for kk, vv in t.items()} for t in ref]
@@ -192,5 +194,13 @@ def test_cfg3_variable_length_batch(model, seeded_sd):
     e_tr = G.rel_err(t16[0]["trans"][ok], traj[0]["trans"][ok])
     flips = sum((t16[i]["seqs"] != traj[i]["seqs"])[ok].sum().item() for i in range(NS))
     print(f"f16 single-pass vs fp32-parity mode, teacher-forced step: rotmats {e_rot:.2e}, trans {e_tr:.2e}; sequence flips over {NS} steps: {flips} of {int(ok.sum()) * NS}")
-    assert e_rot < 2e-2 and e_tr < 2e-2, (e_rot, e_tr)           # tolerance of the reduced-precision mode
-    assert flips <= 0.01 * int(ok.sum()) * NS
+    assert e_rot < 1.2e-2 and e_tr < 3e-3, (e_rot, e_tr)         # ~3x the measured deviation of a teacher-forced step (profiles/r03/drift.json)
+    assert flips <= 0.003 * int(ok.sum()) * NS
+    # ... and against the ORACLE (not only against the fp32 HIP mode) on the same eight samples
+    worst = [0.0, 0.0]
+    for b in pick:
+        n = int(lens[b])
+        worst[0] = max(worst[0], G.rel_err(t16[0]["rotmats"][b, :n], refs[b][0]["rotmats"][0, :n]))
+        worst[1] = max(worst[1], G.rel_err(t16[0]["trans"][b, :n], refs[b][0]["trans"][0, :n]))
+    print(f"f16 mode vs oracle, teacher-forced step, worst of {len(pick)} samples: rotmats {worst[0]:.2e}, trans {worst[1]:.2e}")
+    assert worst[0] < 1.2e-2 and worst[1] < 3e-3, worst

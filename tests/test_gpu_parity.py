@@ -21,6 +21,7 @@ from pepflowww_amd import _capi, synth  # noqa: E402
 import gpu_util as G  # noqa: E402
 
 REL = 1e-4
+F16_LOGIT_TOL = 2e-2          # f16 mode, sequence logits of one step (max-normalised); rotations 1.2e-2, translations 3e-3
 
 
 def load(golden_dir, name):
@@ -831,10 +832,11 @@ def test_masked_tiles_and_keys_are_skipped_exactly(model, seeded_sd, precision):
             out = model.ga_encoder(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t), cu(node), cu(edge), cu(batch["generate_mask"].long()), cu(resm.long()))
             G.sync()
             valid = resm
-            tol = REL if precision == "fp32" else 2e-2
-            G.assert_close(out[0].cpu()[valid], ref[0][valid], tol, f"rotmats[{k}]")
-            G.assert_close(out[1].cpu()[valid], ref[1][valid], tol, f"trans[{k}]")
-            G.assert_close(out[3].cpu()[valid], ref[3][valid], 2 * tol if precision == "fp32" else 5e-2, f"logits[{k}]")
+            # f16 mode: ~3x the measured deviation of one step (profiles/r03/drift.json: rot 3e-3, trans 8e-4)
+            tol_r, tol_x, tol_l = (REL, REL, 2 * REL) if precision == "fp32" else (1.2e-2, 3e-3, F16_LOGIT_TOL)
+            G.assert_close(out[0].cpu()[valid], ref[0][valid], tol_r, f"rotmats[{k}]")
+            G.assert_close(out[1].cpu()[valid], ref[1][valid], tol_x, f"trans[{k}]")
+            G.assert_close(out[3].cpu()[valid], ref[3][valid], tol_l, f"logits[{k}]")
             assert all(torch.isfinite(o).all() for o in out)
     finally:
         model.ga_encoder.set_precision("fp32")
@@ -854,9 +856,9 @@ def test_f16_mode_at_a_length_that_is_not_a_multiple_of_16(model, seeded_sd):
         G.sync()
     finally:
         model.ga_encoder.set_precision("fp32")
-    G.assert_close(out[0].cpu()[resm], ref[0][resm], 2e-2, "rotmats")
-    G.assert_close(out[1].cpu()[resm], ref[1][resm], 2e-2, "trans")
-    G.assert_close(out[3].cpu()[resm], ref[3][resm], 5e-2, "logits")
+    G.assert_close(out[0].cpu()[resm], ref[0][resm], 1.2e-2, "rotmats")
+    G.assert_close(out[1].cpu()[resm], ref[1][resm], 3e-3, "trans")
+    G.assert_close(out[3].cpu()[resm], ref[3][resm], F16_LOGIT_TOL, "logits")
 
 
 def test_encode_ragged_vs_oracle(model, seeded_sd):

@@ -267,13 +267,15 @@ def test_nan_and_inf_activations_propagate_through_split_precision(single_pass):
     assert torch.isnan(y[3]).all(), "the NaN row must come out NaN"
     for r in (9, 12):                                             # inf: NaN (split form: inf * 0 in the lo plane) or +-inf (hi plane only)
         assert (~torch.isfinite(y[r])).all(), f"row {r} must not be finite"
-    fin = [r for r in range(M) if r not in (3, 9, 12)]
-    assert torch.isfinite(y[fin]).all()
-    clean = [r for r in fin if r != 20]
+    clean = [r for r in range(M) if r not in (3, 9, 12, 20)]
+    assert torch.isfinite(y[clean]).all()
     ref = (x[clean].double() @ w.double().T).float()
     G.assert_close(y[clean], ref, 5e-6 if not single_pass else 3e-3, "finite rows")
-    sat = x[20:21].clamp(-65504.0, 65504.0)
-    G.assert_close(y[20:21], (sat.double() @ w.double().T).float(), 1e-5 if not single_pass else 3e-3, "saturated row")
+    if single_pass:                                               # f16 mode: plain f16 conversion -- beyond 65504 the operand is inf
+        assert (~torch.isfinite(y[20])).all()
+    else:                                                         # fp32-parity mode: the hi / lo split saturates finite values
+        sat = x[20:21].clamp(-65504.0, 65504.0)
+        G.assert_close(y[20:21], (sat.double() @ w.double().T).float(), 1e-5, "saturated row")
 
 
 # ------------------------------------------------------------------ kernel forms chosen from the batch size

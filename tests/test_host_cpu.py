@@ -192,6 +192,14 @@ def test_lmdb_reader_walks_leaf_branch_and_overflow_pages(tmp_path):
         LmdbReader(path)
 
 
+class _KeepKeys:
+    def __init__(self, keys):
+        self.keys = keys
+
+    def __call__(self, x):
+        return {k: x[k] for k in self.keys}
+
+
 def test_pep_dataset_reads_the_structure_cache(tmp_path):
     """pep_dataloader.py:87-196 read side: ids in key order, items unpickled, transform applied, collate-able."""
     import pickle
@@ -211,3 +219,11 @@ def test_pep_dataset_reads_the_structure_cache(tmp_path):
     assert batch["aa"].shape[0] == 4 and batch["aa"].shape[1] % 8 == 0 and batch["res_mask"].dtype == torch.bool
     with pytest.raises(FileNotFoundError):
         PepDataset(dataset_dir=str(tmp_path), name="absent")
+    # picklable after use (DataLoader workers get a copy; the reader is re-opened lazily in each of them), also through a real loader
+    ds3 = pickle.loads(pickle.dumps(ds))
+    assert ds3._db is None and ds3[3]["id"] == d["id"] and ds3._db is not None
+    from torch.utils.data import DataLoader
+    keep = ("aa", "pos_heavyatom")
+    ds4 = PepDataset(dataset_dir=str(tmp_path), name="pep", transform=_KeepKeys(keep))
+    got = list(DataLoader(ds4, batch_size=2, shuffle=False, num_workers=2, collate_fn=PaddingCollate(eight=False), multiprocessing_context="spawn"))
+    assert sum(b["aa"].shape[0] for b in got) == len(ds4)
