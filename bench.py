@@ -230,7 +230,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
 def pmc_traffic(workload, precision):
     """HBM bytes per launch of the two big kernels from the PMC passes recorded under profiles/ (rocprofv3 cannot run
     inside this process; tools/pmc_traffic.sh regenerates the file); corrected as MI355X_MICROARCH.md prescribes."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 d = json.load(f)
@@ -324,13 +324,13 @@ def main():
     et_s = ku["pf_edge_transition_fwd"]["avg_launch_us"] * 1e-6
     ipa_s = ku["pf_ipa_attn_fwd"]["avg_launch_us"] * 1e-6
     traffic, traffic_src = pmc_traffic(args.workload, prec)
-    t_et = (traffic.get("edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
+    t_et = (traffic.get("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") or traffic.get("edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
     t_ipa = (traffic.get("ipa_two_kernel_form") or traffic.get("ipa_attn_kernel") or {}).get("hbm_bytes_corrected")
     step_us = sum(v["us_per_step"] for v in ku.values())
     share = {k: round(v["us_per_step"] / step_us, 3) for k, v in sorted(ku.items(), key=lambda kv: -kv[1]["us_per_step"])}
     dominant = next(iter(share))
     rf_et = {
-        "kernel": "edge_transition_v3_kernel (pf_edge_transition_fwd)", "bound": "mfma",
+        "kernel": ("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") + " (pf_edge_transition_fwd)", "bound": "mfma",
         "achieved": pairs * ET_FLOPS_EXEC / et_s / 1e12, "peak": MFMA_F16_PEAK / split / 1e12, "unit": "TFLOP/s",
         "frac": pairs * ET_FLOPS_EXEC * split / et_s / MFMA_F16_PEAK, "traffic": t_et,
         "traffic_note": f"HBM bytes per launch from {traffic_src} (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair = {pairs * ET_BYTES} B "

@@ -87,6 +87,16 @@ __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// four consecutive 1 KiB pieces (source and LDS destination both advance by 1 KiB): ONE m0 set-up, the instruction offset moves both
+// addresses (dev experiment PF_ET4_X4)
+__device__ __forceinline__ void glds16_x4(const void* sbase, unsigned voff, unsigned lds_addr) {
+    if constexpr ((PF_ET4_WHATIF & 2) != 0) return;
+    sbase = uniform_ptr(sbase);
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                 : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
 #define LDSADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
 
 template <int N> __device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
@@ -154,8 +164,15 @@ template <bool SP, bool RELU> __device__ __forceinline__ Op split8(const float (
         if (t == 12345.678f) g_et4_sink = t;
     }
     if constexpr (SP) {
+        typedef float float2s __attribute__((ext_vector_type(2)));
+        typedef _Float16 half2s __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.h[e] = (_Float16)v[e];
+        for (int e = 0; e < 8; e += 2) {       // v_cvt_pk_f16_f32 per pair (element-wise conversions cost a v_cvt each + a v_perm to pack)
+            const float2s xp = {v[e], v[e + 1]};
+            const half2s hp = __builtin_convertvector(xp, half2s);
+            o.h[e] = hp[0];
+            o.h[e + 1] = hp[1];
+        }
         if constexpr (RELU) {                  // ReLU after the rounding, as a packed signed-integer max with 0 (see v3)
             short8w sv = __builtin_bit_cast(short8w, o.h);
             const short8w z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -164,7 +181,7 @@ template <bool SP, bool RELU> __device__ __forceinline__ Op split8(const float (
         }
         o.l = o.h;
     } else {
-        // per pair of values: [v_max_f32 x 2] + v_cvt_pk_f16_f32 (hi pair, RNE) + v_fma_mix{lo,hi}_f16 reading the packed hi halves
+        // per pair of values: [v_max_i32 x 2] + v_cvt_pk_f16_f32 (hi pair, RNE) + v_fma_mix{lo,hi}_f16 reading the packed hi halves
         typedef float float2v __attribute__((ext_vector_type(2)));
         typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -269,8 +286,13 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
     constexpr int WSRC_PIECE = SP ? ENT_B : 1024;                // source stride of the pieces of a ring stage (f16 mode: hi halves only)
     constexpr int NPS = STAGE_B / 1024;                          // LDS-DMA pieces per ring stage
     constexpr int WSRC_STAGE = NPS * WSRC_PIECE;
-    const unsigned wave_src = (unsigned)(wave & (ND - 1)) * WSRC_PIECE;   // weight piece k of this wave: p = (wave & (ND-1)) + ND k
-    const unsigned wave_lds = lds0 + (wave & (ND - 1)) * 1024;
+#ifdef PF_ET4_X4
+    constexpr bool X4 = !SP && (CW % 4 == 0);                    // consecutive pieces per wave, four per m0 set-up (fp32 mode)
+#else
+    constexpr bool X4 = false;
+#endif
+    const unsigned wave_src = (unsigned)(wave & (ND - 1)) * WSRC_PIECE * (X4 ? CW : 1);   // weight piece k of this wave: p = (wave & (ND-1)) + ND k
+    const unsigned wave_lds = lds0 + (wave & (ND - 1)) * 1024 * (X4 ? CW : 1);            // (X4: p = CW (wave & (ND-1)) + k)
     const bool loader = wave < ND;
     auto issue_w = [&](int stage /* of the tile: compile time */, int slot) __attribute__((always_inline)) {
         // (an opaque zero per call: otherwise every piece address of every stage is loop-invariant, gets hoisted out of the tile
@@ -279,8 +301,13 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
         const unsigned char* base = wsrc + stage * WSRC_STAGE + wave_src + zero;
         const unsigned dst = wave_lds + slot * STAGE_B;
+        if constexpr (X4) {
 #pragma unroll
-        for (int k = 0; k < CW; ++k) glds16(base + ND * k * WSRC_PIECE, l16, dst + ND * k * 1024);
+            for (int k = 0; k < CW; k += 4) glds16_x4(base + k * 1024, l16, dst + k * 1024);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CW; ++k) glds16(base + ND * k * WSRC_PIECE, l16, dst + ND * k * 1024);
+        }
     };
     // Tile inputs through LDS: per issuing wave NAW a|d rows, NAW c|e rows and one mask piece (every issuing wave writes the same
     // 256 bytes: the piece counts -- and with them the immediates of the counted waits -- are compile-time numbers).
@@ -424,11 +451,14 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
             PROF4(e);
             if constexpr (e % EPSv == 0) {
                 if constexpr (e != 0) stage_end(std::integral_constant<int, e / EPSv - 1>{});
-                stage_begin(std::integral_constant<int, e / EPSv>{});
-                PROF4(133 + 3 * (e / EPSv));
-                wq[e & 1] = ldw<SP>(smem + slot * STAGE_B, 0, lane);
+                wq[e & 1] = ldw<SP>(smem + slot * STAGE_B, 0, lane);     // the first fragments of the stage are on their way ...
             }
             if constexpr (e + 1 < NENT && (e + 1) % EPSv != 0) wq[(e + 1) & 1] = ldw<SP>(smem + slot * STAGE_B, (e + 1) % EPSv, lane);
+            if constexpr (e % EPSv == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_begin(std::integral_constant<int, e / EPSv>{});    // ... while the issuing waves form their LDS-DMA pieces
+                PROF4(133 + 3 * (e / EPSv));
+            }
             __builtin_amdgcn_sched_barrier(0);                   // pins the request above the MFMAs that follow in program order
             return wq[e & 1];
         };
