@@ -29,12 +29,26 @@ LO_SCALE = 2048.0
 F16_MAX = 65504.0
 
 
+_DEFERRED = None          # inside PackedWeights.__init__: list of (name, 0-dim bool tensor "out of range"), checked once at the end
+
+
+def _range_error(name):
+    return _capi.PepflowHipError(f"{name}: values outside the f16 range (|w| <= {F16_MAX:g}, finite) cannot be carried by the "
+                                 "hi/lo f16 split of the MFMA kernels; rescale the layer or run it through pf_linear_fwd without w_f16")
+
+
 def check_f16_range(w, name="weight"):
     """The hi plane of the split representation is an f16: |w| must not exceed 65504 (and must be finite).  Trained PepFlow
-    weights are O(1); a checkpoint that violates this cannot run in split precision and is refused loudly here."""
-    if w.numel() and not bool(torch.isfinite(w).all() and w.abs().max() <= F16_MAX):
-        raise _capi.PepflowHipError(f"{name}: values outside the f16 range (|w| <= {F16_MAX:g}, finite) cannot be carried by the "
-                                    "hi/lo f16 split of the MFMA kernels; rescale the layer or run it through pf_linear_fwd without w_f16")
+    weights are O(1); a checkpoint that violates this cannot run in split precision and is refused loudly here.
+    (While PackedWeights is being built the verdicts are collected on the device and read back ONCE -- a host round trip per
+    matrix made packing a 0.9 s affair on the GPU.)"""
+    if not w.numel():
+        return
+    bad = ~(torch.isfinite(w).all() & (w.abs().max() <= F16_MAX))
+    if _DEFERRED is not None:
+        _DEFERRED.append((name, bad))
+    elif bool(bad):
+        raise _range_error(name)
 
 
 def split_f16(w):
@@ -70,14 +84,12 @@ def _frag_pair(W, ft, kidx):
     kg = lane >> 4) holds W[16 ft + row][kidx[kg, 0..7]]."""
     lane = torch.arange(64, device=W.device)
     rows = 16 * ft + (lane & 15)
-    v = W[rows[:, None], kidx[(lane >> 4)]]                     # [64, 8]
-    check_f16_range(v)
-    hi = v.to(torch.float16)
-    lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
+    v = W[rows[:, None], kidx[(lane >> 4)]]                     # [64, 8]  (range: checked once per matrix by the callers)
+    hi, lo = _hi_lo(v)
     return torch.cat([hi.reshape(-1), lo.reshape(-1)])
 
 
-def pack_et_stream(w1z, w2, wf):
+def _pack_et_stream_ref(w1z, w2, wf):
     """EdgeTransition weights as the linear 256 KiB fragment stream of csrc/edge_transition_v3.hip:
     128 fragment pairs in the exact order a consumer wave uses them.
       stage 0-1 : W1z feature tiles 0..11 (2 K-steps each, natural K order), then Wf[:, :64] tiles 0..3 (2 K-steps)
@@ -87,6 +99,8 @@ def pack_et_stream(w1z, w2, wf):
     Layout/packing only -- no model arithmetic."""
     w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
     assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
+    for m_, n_ in ((w1z, "trunk.0.weight[:, :64]"), (w2, "trunk.2.weight"), (wf, "final_layer.weight")):
+        check_f16_range(m_, n_)
     dev = w2.device
     kg = torch.arange(4, device=dev)[:, None]
     i8 = torch.arange(8, device=dev)[None, :]
@@ -106,6 +120,62 @@ def pack_et_stream(w1z, w2, wf):
     return stream
 
 
+_STREAM_IDX = {}
+
+
+def _stream_index(which, dev):
+    """Flat gather index [128 entries, 512] into cat(w1z.flatten(), w2.flatten(), wf.flatten()) that reproduces pack_et_stream /
+    pack_et_stream32 entry by entry -- built ONCE per device by running the reference packer on index-valued matrices (values 0 ..
+    65535 are exact in fp32 and f16-representable only up to 2048, so the indices travel in the fp32 `v` path, not through f16)."""
+    key = (which, str(dev))
+    if key not in _STREAM_IDX:
+        n1, n2, n3 = 192 * 64, 192 * 192, 64 * 192
+        a = torch.arange(n1 + n2 + n3, dtype=torch.float32, device=dev)
+        w1z, w2, wf = a[:n1].view(192, 64), a[n1:n1 + n2].view(192, 192), a[n1 + n2:].view(64, 192)
+        global _INDEX_MODE
+        _INDEX_MODE = True
+        try:
+            st = (_pack_et_stream_ref if which == 16 else _pack_et_stream32_ref)(w1z, w2, wf)
+        finally:
+            _INDEX_MODE = False
+        _STREAM_IDX[key] = st.view(128, 2, 512)[:, 0, :].to(torch.int64).contiguous()     # the "hi" halves carry the indices
+    return _STREAM_IDX[key]
+
+
+_INDEX_MODE = False
+
+
+def _hi_lo(v):
+    """[..., n] fp32 -> (hi, lo) f16 with lo = f16(v - hi) UNSCALED (ET_LO_SCALE = 1); in index mode: (v, 0) kept as fp32."""
+    if _INDEX_MODE:
+        return v, torch.zeros_like(v)
+    hi = v.to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
+    return hi, lo
+
+
+def _pack_stream_fast(which, w1z, w2, wf):
+    w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
+    assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
+    for m_, n_ in ((w1z, "trunk.0.weight[:, :64]"), (w2, "trunk.2.weight"), (wf, "final_layer.weight")):
+        check_f16_range(m_, n_)
+    flat = torch.cat([w1z.reshape(-1), w2.reshape(-1), wf.reshape(-1)])
+    v = flat[_stream_index(which, flat.device)]                  # [128, 512]: one gather instead of 128 x (index, split, cat)
+    hi = v.to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
+    return torch.stack([hi, lo], 1).reshape(-1).contiguous()
+
+
+def pack_et_stream(w1z, w2, wf):
+    """The 16x16x32 kernel's stream (layout: _pack_et_stream_ref), packed with one cached gather."""
+    return _pack_stream_fast(16, w1z, w2, wf)
+
+
+def pack_et_stream32(w1z, w2, wf):
+    """The 32x32x16 kernel's stream (layout: _pack_et_stream32_ref), packed with one cached gather."""
+    return _pack_stream_fast(32, w1z, w2, wf)
+
+
 def pack_bias_frags(w_b, w_dz=None):
     """IPA linear_b [8,64] as the 2 fragment pairs (K-steps, permuted K order) the persistent EdgeTransition kernel uses to emit
     the next block's pair bias (4 KiB).  Rows 8..15 of that 16-row tile are zero, or -- with w_dz [16,64] (down_z of the same
@@ -113,6 +183,9 @@ def pack_bias_frags(w_b, w_dz=None):
     hi [32 lanes][8] | lo [32 lanes][8], lane = 8 kg + row.  Layout/packing only."""
     w = _f32(w_b)
     assert w.shape == (8, 64)
+    check_f16_range(w, "linear_b.weight")
+    if w_dz is not None:
+        check_f16_range(_f32(w_dz), "down_z.weight")
     kg = torch.arange(4, device=w.device)[:, None]
     i8 = torch.arange(8, device=w.device)[None, :]
     perm = lambda s: 32 * s + 16 * (i8 >> 2) + 4 * kg + (i8 & 3)
@@ -136,10 +209,8 @@ def _frag32(W, mt, kidx):
         W = torch.nn.functional.pad(W, (0, 0, 0, 32 * (mt + 1) - W.shape[0]))
     lane = torch.arange(64, device=W.device)
     rows = 32 * mt + (lane & 31)
-    v = W[rows[:, None], kidx[(lane >> 5)]]                     # [64, 8]
-    check_f16_range(v)
-    hi = v.to(torch.float16)
-    lo = (v - hi.to(torch.float32)).to(torch.float16)
+    v = W[rows[:, None], kidx[(lane >> 5)]]                     # [64, 8]  (range: checked once per matrix by the callers)
+    hi, lo = _hi_lo(v)
     return torch.cat([hi.reshape(-1), lo.reshape(-1)])
 
 
@@ -158,7 +229,7 @@ def _k_perm(dev):
     return lambda c, s: 32 * c + 16 * s + 8 * (i8 >> 2) + 4 * kg + (i8 & 3)
 
 
-def pack_et_stream32(w1z, w2, wf):
+def _pack_et_stream32_ref(w1z, w2, wf):
     """EdgeTransition weights as the 128-entry stream of csrc/edge_transition_v4.hip, in execution order:
       entries 0..7    Wf[:, :64]   K-step ks (4) x tile mt (2), natural K
       entries 8..31   W1z          tile mt1 (6) x K-step ks (4), natural K
@@ -167,6 +238,8 @@ def pack_et_stream32(w1z, w2, wf):
     Layout/packing only -- no model arithmetic."""
     w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
     assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
+    for m_, n_ in ((w1z, "trunk.0.weight[:, :64]"), (w2, "trunk.2.weight"), (wf, "final_layer.weight")):
+        check_f16_range(m_, n_)
     dev = w2.device
     nat, perm = _k_nat(dev), _k_perm(dev)
     wfz = wf[:, :64].contiguous()
@@ -188,6 +261,7 @@ def pack_bias_frags32(w_b, w_dz):
     32x32 kernel's epilogue (8 KiB).  Layout/packing only."""
     w = torch.cat([_f32(w_b), _f32(w_dz)], 0)
     assert w.shape == (24, 64)
+    check_f16_range(w, "linear_b / down_z")
     perm = _k_perm(w.device)
     return torch.cat([_frag32(w, 0, perm(mt, s)) for mt in range(2) for s in range(2)]).contiguous()
 
@@ -201,6 +275,19 @@ class PackedWeights:
     trunk.0 / final_layer (see pf_edge_transition_fwd)."""
 
     def __init__(self, sd, device):
+        global _DEFERRED
+        _DEFERRED = []
+        try:
+            self._build(sd, device)
+            if _DEFERRED:                                        # ONE host read for every range verdict
+                bad = torch.stack([b.reshape(()) for _, b in _DEFERRED]).tolist()
+                for (name, _), b in zip(_DEFERRED, bad):
+                    if b:
+                        raise _range_error(name)
+        finally:
+            _DEFERRED = None
+
+    def _build(self, sd, device):
         g = lambda k: _f32(sd["ga_encoder." + k]).to(device)
         self.t = {}
         t = self.t
