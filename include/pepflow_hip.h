@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 41
+#define PF_ABI_VERSION 42
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -186,6 +186,10 @@ typedef struct {
      * z (which may then be NULL) */
     const float* dz;
     int dz_f16;                    /* dz is [B,L,L,16] f16 (the f16 mode: pf_edge_transition_args.dz_out_f16) */
+    /* optional (two-kernel form with dz): 1 = the pair aggregation runs INSIDE the score kernel (the probabilities never leave the
+     * workgroup: p_out is not written and may be NULL, no second kernel).  Needs fp32 dz with fp32 operands (proj) or f16 dz with
+     * the f16 operand planes (att_*); other combinations fall back to the two-kernel form (which needs p_out). */
+    int fused_pair;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the

@@ -381,6 +381,9 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef PF_ET4_SKEW                                               // dev experiment: the younger wave of every SIMD starts late
+    if (wave >= NW / 2) { for (int k = 0; k < PF_ET4_SKEW; ++k) __builtin_amdgcn_s_sleep(16); }   // (16 x 64 cycles per step)
+#endif
 #ifdef PF_ET4_PRIO
     if (PF_ET4_PRIO == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);      // dev experiment: static priority for one half
     if (PF_ET4_PRIO == 2 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);

@@ -712,7 +712,7 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     // Measured (rocprofv3, profiles/r02): B=64, L=128: 172 us (scores 112 + pair 60) vs 198 us one-kernel; B=16, L=64: 20.3 + 6 us
     // vs 30.8 us.  The choice depends on L ONLY (not on the batch): the two forms sum in different orders, and a batch shard must
     // reproduce the unsharded run bit for bit (tests/test_gpu_parity.py::test_full_size_shard_equals_unsharded).
-    const bool can_split = a->bias && a->p_out && a->L <= 256;
+    const bool can_split = a->bias && (a->p_out || (a->fused_pair && a->dz)) && a->L <= 256;
     if (a->variant == 2 && !can_split) return PF_E_BADARG;   // two-kernel form demanded but not possible
     if (a->z_f16 && !(can_split && a->variant != 1 && a->L >= 64)) return PF_E_BADARG;   // f16 pair tensor: two-kernel form only
     if (a->dz_f16 && !a->dz) return PF_E_BADARG;

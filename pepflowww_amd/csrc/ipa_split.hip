@@ -46,6 +46,122 @@ constexpr int VPS = 36;                       // ... of a key's 36 value-point c
 
 __device__ __forceinline__ float softplusf2(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// ---- pair aggregation INSIDE the score kernels (pf_ipa_attn_args.fused_pair): o_pair[i][h][c] = b_dz[c] + sum_j P[h][i][j] dz[i][j][c] ----
+// After the softmax a wave has the (unnormalised) probabilities of its 16 queries x all keys in its LDS region; dz[b][i] is one
+// contiguous row of L x 16 values per query.  A wave-load takes 16 keys x 16 channels (lane = key slot ks x channel quad cq: 1 KiB
+// contiguous in fp32, 512 B in f16), every lane multiplies its four channels with P[qi][16 u + ks] (one LDS dword, broadcast over
+// the 4 quads) and keeps 16 queries x 4 channels of partial sums; the 16 key slots are summed at the end by a butterfly that halves
+// the live sums per step (64 -> 32 -> 16 on v_permlane32/16_swap, 16 -> 8 -> 4 on DPP), a lane ends with the four channels 4 cq ..
+// of query qi(lane).  Neither the probability tensor [B,8,L,L] nor a second kernel exists in this form: the dz row of a query is
+// read by the 8 head workgroups of its sample, which run side by side on one XCD (xcd_remap) -- once from HBM, 7 x from L2.
+//   ks = lane bits (0,1,4,5), cq = lane bits (2,3);  NB4 = ceil(key tiles / 4): rows are loaded 4 NB4 tiles at a time, the next
+//   rows of the next D - 1 queries are requested before this query's products (D rotating register sets, compile-time structure).
+template <bool D16> struct DzVec { typedef float4 type; };
+template <> struct DzVec<true> { typedef half4 type; };
+
+template <int NB4, bool D16>
+__device__ __forceinline__ void pair_dz_rows(const void* __restrict__ dzp, size_t rowb, int L, int i0, int Le, int kt,
+                                             const float* __restrict__ Pw, int SLD, int ks, int cq, f32x2 (&acc)[32]) {
+    typedef typename DzVec<D16>::type V4;
+    typedef typename std::conditional<D16, _Float16, float>::type DT;
+    constexpr int NT = 4 * NB4;
+    const DT* base = reinterpret_cast<const DT*>(dzp) + rowb * (size_t)L * 16 + 4 * cq;
+    int koff[NT];                                    // element offset of (tile u, slot ks) inside a row; tiles beyond kt - 1 re-read the last one
+    float on[NT];                                    // ... and count zero
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int uu = min(u, kt - 1);
+        koff[u] = min(16 * uu + ks, L - 1) * 16;
+        on[u] = u < kt ? 1.f : 0.f;
+    }
+    auto load_row = [&](int qi, V4 (&buf)[NT]) {
+        const DT* row = base + (size_t)min(i0 + qi, Le - 1) * L * 16;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) buf[u] = *reinterpret_cast<const V4*>(row + koff[u]);
+    };
+    auto mac_row = [&](int qi, const V4 (&buf)[NT]) {
+        const float* pr = Pw + qi * SLD;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            float pv;
+            if (u <= 4 * (NB4 - 1)) pv = pr[16 * u];             // (tiles 0 .. 4 NB4 - 4 exist for every kt of this NB4)
+            else pv = pr[16 * min(u, kt - 1)] * on[u];            // the last group's tiles 1..3 may lie beyond kt: re-read, count zero
+            const f32x2 p2 = {pv, pv};
+            f32x2 d0, d1;
+            if constexpr (D16) { d0 = (f32x2){(float)buf[u][0], (float)buf[u][1]}; d1 = (f32x2){(float)buf[u][2], (float)buf[u][3]}; }
+            else { d0 = (f32x2){buf[u].x, buf[u].y}; d1 = (f32x2){buf[u].z, buf[u].w}; }
+            acc[2 * qi] = __builtin_elementwise_fma(d0, p2, acc[2 * qi]);
+            acc[2 * qi + 1] = __builtin_elementwise_fma(d1, p2, acc[2 * qi + 1]);
+        }
+    };
+    // D rows in flight (the phase is a latency chain otherwise: with one row ahead it cost as much as the separate kernel it
+    // replaces -- 16 x one memory round trip per wave, all eight waves of the workgroup in this phase at the same time)
+    constexpr int D = NB4 == 1 ? 8 : NB4 == 2 ? 4 : 2;
+    V4 buf[D][NT];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load_row(d, buf[d]);
+#pragma unroll
+    for (int qi = 0; qi < 16; ++qi) {
+        load_row(min(qi + D - 1, 15), buf[(qi + D - 1) % D]);    // (the last trips re-read row 15: unconditional, no branch in the sequence)
+        __builtin_amdgcn_sched_barrier(0);
+        mac_row(qi, buf[qi % D]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the phase: LDS hand-off, rows, butterfly, store.  `inv` = 1 / softmax denominator of query (lane & 15).
+template <bool D16>
+__device__ __forceinline__ void pair_dz_phase(const pf_ipa_attn_args& a, size_t rowb, int h, int i0, int Le, int kt, const float* Pwave,
+                                              int SLD, float inv, int lane) {
+    const int ks = (lane & 3) | ((lane >> 4) << 2), cq = (lane >> 2) & 3;
+    f32x2 acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = (f32x2){0.f, 0.f};
+    const float* Pw = Pwave + ks;
+    const int nb4 = (kt + 3) >> 2;                   // (wave-uniform)
+    if (nb4 <= 1) pair_dz_rows<1, D16>(a.dz, rowb, a.L, i0, Le, kt, Pw, SLD, ks, cq, acc);
+    else if (nb4 == 2) pair_dz_rows<2, D16>(a.dz, rowb, a.L, i0, Le, kt, Pw, SLD, ks, cq, acc);
+    else if (nb4 == 3) pair_dz_rows<3, D16>(a.dz, rowb, a.L, i0, Le, kt, Pw, SLD, ks, cq, acc);
+    else pair_dz_rows<4, D16>(a.dz, rowb, a.L, i0, Le, kt, Pw, SLD, ks, cq, acc);
+    // butterfly over the key slots: lane bit 5 splits on query bit 3, bit 4 on query bit 2, bit 1 on query bit 1, bit 0 on query bit 0
+    float v[64];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { v[2 * k] = acc[k][0]; v[2 * k + 1] = acc[k][1]; }       // v[4 qi + t]
+    float w[32], x[16], y[8], z4[4];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {                               // lanes 0..31 keep v[k], lanes 32..63 keep v[k + 32]
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 32]), false, false);
+        w[k] = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {                               // rows 0, 2 keep w[k], rows 1, 3 keep w[k + 16]
+        auto rr = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[k]), __float_as_uint(w[k + 16]), false, false);
+        x[k] = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+    {
+        const bool hi = lane & 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float send = hi ? x[k] : x[k + 8], keep = hi ? x[k + 8] : x[k];
+            y[k] = keep + lane_xor2(send);
+        }
+    }
+    {
+        const bool hi = lane & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float send = hi ? y[k] : y[k + 4], keep = hi ? y[k + 4] : y[k];
+            z4[k] = keep + lane_xor1(send);
+        }
+    }
+    const int qi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + (lane & 3);
+    const float invq = __shfl(inv, qi);                          // lane qi (row 0) holds query qi's denominator
+    const float4 bd = *reinterpret_cast<const float4*>(a.b_dz + 4 * cq);
+    const int i = min(i0 + qi, Le - 1);                          // (duplicates of row Le - 1 store identical values)
+    *reinterpret_cast<float4*>(a.feats + (rowb + i) * PF_IPA_FEATS + 1408 + h * 16 + 4 * cq) =
+        make_float4(z4[0] * invq + bd.x, z4[1] * invq + bd.y, z4[2] * invq + bd.z, z4[3] * invq + bd.w);
+}
+
 // The wave's score tile S[16 queries][L keys] lives in a wave-private LDS region that every lane only ever reads back where it
 // wrote (lane (r, g): row r, keys 16 t + 4 g .. + 3), i.e. it is register spill space under our control: with the tiles held
 // in registers and the tile loops unrolled, hipcc hoisted every tile's loads and spilled 0.9 - 6.8 KB per lane.
@@ -54,7 +170,7 @@ __device__ __forceinline__ float softplusf2(float x) { return x > 20.f ? x : log
 // the loop.  (First version: conditional prefetches and guarded stores inside the loops -- hipcc emits s_waitcnt vmcnt(0) at
 // every control-flow join, so the "one tile ahead" loads were never in flight: 108 us per launch at B=64, L=128, 28 % of the
 // wave cycles parked on memory, MFMA pipe 29 % busy.)
-template <bool VEC4>                              // L % 4 == 0: bias / probability rows are read / written as float4
+template <bool VEC4, bool FUSE = false>          // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;
@@ -197,7 +313,12 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     sum = sum_xor32(sum_xor16(sum));
     const float inv = 1.f / sum;
     PROFS(3);
-    float* prow = a.p_out + (((size_t)b * H + h) * L + iq) * L;
+    if constexpr (FUSE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the phase reads other lanes' columns of the wave's region
+        __builtin_amdgcn_wave_barrier();
+        pair_dz_phase<false>(a, rowb, h, i0, Le, kt, SW + (size_t)wave * 16 * SLD, SLD, inv, lane);
+    }
+    float* prow = FUSE ? nullptr : a.p_out + (((size_t)b * H + h) * L + iq) * L;
 
     // ---- [o | o_pt] = P [V | V_pts]: A = P (this lane: query r, key 16 t + 4 g + tt in MFMA tt), B = value rows.
     //      V column of (tile n, lane r) = 4 r + n (n < 4), 64 + 4 r + n - 4 (n = 4..7): a load instruction of the 16 lanes of a key
@@ -229,7 +350,8 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         float4 p = *reinterpret_cast<const float4*>(srow + 16 * t);
         p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
         const int jb = 16 * t + 4 * g;
-        if constexpr (VEC4 && !TAIL) {
+        if constexpr (FUSE) {
+        } else if constexpr (VEC4 && !TAIL) {
             *reinterpret_cast<float4*>(prow + jb) = p;            // (duplicate rows store identical values to the same address)
         } else if constexpr (!TAIL) {
             prow[jb] = p.x; prow[jb + 1] = p.y; prow[jb + 2] = p.z; prow[jb + 3] = p.w;
@@ -307,7 +429,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 // Requires L % 16 == 0 (FlowModel.sample pads to that); keys are walked in 32-key steps in the second product (a trailing
 // half step multiplies zero probabilities with whatever the value rows hold there -- the value buffer is zero-initialised
 // and 32 keys longer than its last row).
-template <int MODE>
+template <int MODE, bool FUSE = false>           // FUSE: pair aggregation on a.dz (f16) here, P not stored
 __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int SLD) {
     constexpr bool SPLIT = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -449,7 +571,8 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the second product reads other lanes' columns of row r
     __builtin_amdgcn_wave_barrier();
     PROFS(3);
-    float* prow = a.p_out + (((size_t)b * H + h) * L + iq) * L;
+    if constexpr (FUSE) pair_dz_phase<true>(a, rowb, h, i0, LK, kt, SW + (size_t)wave * 16 * SLD, SLD, inv, lane);
+    float* prow = FUSE ? nullptr : a.p_out + (((size_t)b * H + h) * L + iq) * L;
 
     // ---- [o | o_pt] = P [V | V_pts]: A = P (lane (r = query, g): keys 32 s + 8 g .. + 7), B = transposed value rows
     //      (tile n, lane r) -> value channel 8 r + n for n < 8 (a lane's eight outputs of a query are consecutive floats),
@@ -481,7 +604,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         float4 p1 = *reinterpret_cast<const float4*>(srow + 32 * s32 + 8 * g + 4);
         p0.x *= inv; p0.y *= inv; p0.z *= inv; p0.w *= inv;
         p1.x *= inv; p1.y *= inv; p1.z *= inv; p1.w *= inv;
-        if (32 * s32 + 8 * g < LK) {                             // (false only in a trailing half step)
+        if (!FUSE && 32 * s32 + 8 * g < LK) {                    // (false only in a trailing half step)
             *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g) = p0;
             *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g + 4) = p1;
         }
@@ -876,6 +999,11 @@ __global__ __launch_bounds__(256) void ipa_pair_dz16_kernel(pf_ipa_attn_args a) 
 int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     const int L = a->L;
     int rc = 0;
+    // pair aggregation inside the score kernel (pf_ipa_attn_args.fused_pair): the f16-operand kernels take f16 pair values, the fp32-
+    // operand kernel fp32 ones (what DenoiseEngine pairs up); any other combination runs the two-kernel form and needs p_out
+    const bool planes = a->att_qk && a->att_vt && (a->att_mode == 1 || a->att_mode == 2) && (L & 15) == 0;
+    const bool fuse = a->fused_pair && a->dz && (planes ? a->dz_f16 != 0 : a->dz_f16 == 0);
+    if (!fuse && !a->p_out) return PF_E_BADARG;
     {
         const int LP = (L + 15) & ~15, SLD = LP + 4 < 36 ? 36 : LP + 4;   // (the region later holds the wave's [16][36] o_pt)
         const int tiles = LP >> 4;                               // 16-row query tiles
@@ -895,9 +1023,11 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if (a->att_qk && a->att_vt && (a->att_mode == 1 || a->att_mode == 2) && (L & 15) == 0) {
+        if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
             int wm = (int)((160 * 1024 - fixed16) / pw16);
@@ -910,12 +1040,21 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             if (!attr16) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr16 = true;
             }
-            if (a->att_mode == 1)
-                hipLaunchKernelGGL(ipa_scores16_kernel<1>, dim3((unsigned)(a->B * H * nrb16)), dim3(64 * wpb16), lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+            const dim3 g16((unsigned)(a->B * H * nrb16)), b16(64 * wpb16);
+            if (fuse) {
+                if (a->att_mode == 1) hipLaunchKernelGGL((ipa_scores16_kernel<1, true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+                else hipLaunchKernelGGL((ipa_scores16_kernel<2, true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+            } else if (a->att_mode == 1)
+                hipLaunchKernelGGL(ipa_scores16_kernel<1>, g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
             else
-                hipLaunchKernelGGL(ipa_scores16_kernel<2>, dim3((unsigned)(a->B * H * nrb16)), dim3(64 * wpb16), lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+                hipLaunchKernelGGL(ipa_scores16_kernel<2>, g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+        } else if (fuse) {
+            if ((L & 3) == 0) hipLaunchKernelGGL((ipa_scores_kernel<true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
+            else hipLaunchKernelGGL((ipa_scores_kernel<false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if ((L & 3) == 0)
             hipLaunchKernelGGL(ipa_scores_kernel<true>, dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
         else
@@ -923,6 +1062,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         PF_CHECK_LAUNCH();
     }
     if (rc) return rc;
+    if (fuse) return 0;
     const int ng = (L + 15) / 16;                                // key groups per wave
     const size_t lds = ((size_t)8 * 16 * ng + ZW * 8 * 64 + 4 * 64 * 4) * sizeof(float);
     const long rows = (long)a->B * L;

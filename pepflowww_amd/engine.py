@@ -10,6 +10,7 @@ all arithmetic of the step runs in libpepflow_hip.so.
 """
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -423,12 +424,18 @@ class DenoiseEngine:
         self.pair_dz = e(B, L, L, 16, dt=dzt) if 64 <= L <= 256 else None
         self.pair_dz0 = e(B, L, L, 16, dt=dzt) if 64 <= L <= 256 else None   # ... of block 0 (from edge_embed, in bind_context)
         self._dz0_f32 = e(B, L, L, 16) if (self.z16 and self.pair_dz0 is not None) else None
-        self.attn_p = e(B, 8, L, L)             # attention probabilities: handed from the score kernel to the pair-aggregation kernel
+        # pair aggregation inside the score kernel (pf_ipa_attn_args.fused_pair: the probabilities never leave the workgroup) in the f16
+        # mode only.  A query's pair-value row is then read by the 8 head workgroups of its sample (once from HBM, 7 x from L2): with
+        # f16 values that costs less than the second kernel + the probability round trip (B=64, L=128: step 2.167 -> 2.138 ms, L=64:
+        # 0.528 -> 0.514), with fp32 values (twice the bytes through L2 -> L1) as much as it saves (3.46 vs 3.48 ms; two or four rows
+        # in flight per wave measure the same: bandwidth, not latency).  A rule in (L, precision) alone.  PF_FUSED_PAIR=0 / 1 forces it.
+        self.fused_pair = self.pair_dz is not None and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PAIR", ""), self.z16)
+        # attention probabilities handed from the score kernel to the pair-aggregation kernel (two-kernel form only)
+        self.attn_p = None if self.fused_pair else e(B, 8, L, L)
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
         # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
         # EdgeTransition kernel form, by measurement at B=64, L=128 (same box, in the step): fp32-parity mode: the 32x32 kernel
         # (csrc/edge_transition_v4.hip) 379 vs 402 us; f16 mode: the 16x16 kernel (v3) 180 vs 195 us.  PF_ET_V4=0 / 1 forces one (A/B runs).
-        import os
         self.et_v4 = {"0": False, "1": True}.get(os.environ.get("PF_ET_V4", ""), precision == "fp32")
         self.et_rows = int(self.lib.pf_edge_transition_v4_tile_rows()) if self.et_v4 else int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
@@ -603,7 +610,8 @@ class DenoiseEngine:
             ia.w_dz, ia.b_dz = w[f"{b}.down_z.w"].data_ptr(), w[f"{b}.down_z.b"].data_ptr()
             ia.head_w, ia.feats, ia.B, ia.L = w[f"{b}.head_w"].data_ptr(), self.feats.data_ptr(), B, L
             ia.bias = (self.pair_bias if b > 0 else self.pair_bias0).data_ptr()   # EdgeTransition(b - 1) / bind_context
-            ia.p_out = self.attn_p.data_ptr()
+            ia.p_out = None if self.fused_pair else self.attn_p.data_ptr()
+            ia.fused_pair = int(self.fused_pair)
             ia.key_end = self.key_end.data_ptr()
             ia.z_f16 = int(self.z16)
             if self.pair_dz is not None:

@@ -98,10 +98,10 @@ def rigid_update(quat, rot, trans, upd, mask):
 
 
 def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None,
-              dz=None):
+              dz=None, fused_pair=False):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
     variant=1); head_group: force a head-group split of the one-kernel form; dz: [B,L,L,16] pair values W_dz z (no bias) for the
-    two-kernel form's pair aggregation (z may then be None)."""
+    two-kernel form's pair aggregation (z may then be None); fused_pair: that aggregation inside the score kernel (p_out may be None)."""
     lib = _capi.load()
     rows = B * L
     d = proj.device
@@ -121,6 +121,7 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.key_end = _p(key_end)                  # int32 [B]: 1 + last unmasked residue (two-kernel form skips what lies beyond)
     ia.dz = _p(dz)
     ia.dz_f16 = int(dz is not None and dz.dtype == torch.float16)
+    ia.fused_pair = int(fused_pair)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)

@@ -266,7 +266,7 @@ def test_ipa_forms_agree_on_ragged_shapes(seeded_sd, B, L):
             _ipa_run(seeded_sd, pfx, s, z, R, x, mask, B, L, "split")
 
 
-@pytest.mark.parametrize("B,L", [(2, 32), (3, 48), (1, 144)])
+@pytest.mark.parametrize("B,L", [(2, 32), (3, 48), (1, 144), (2, 128), (1, 208)])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_ipa_on_f16_operand_planes(seeded_sd, B, L, mode):
     """The projection writing the attention operands as f16 planes (pf_linear_args.att_*: q / k rows, values transposed per
@@ -323,6 +323,21 @@ def test_ipa_on_f16_operand_planes(seeded_sd, B, L, mode):
     for name, sl in (("o", slice(0, 1024)), ("o_pt", slice(1024, 1312)), ("norm", slice(1312, 1408)), ("o_pair", slice(1408, 1536))):
         G.assert_close(fg[:, sl], fr[:, sl], tol, f"mode {mode} feats[{name}] vs oracle")
     assert torch.isnan(vp).all()                     # the value points went to the transposed f16 block only
+    if L >= 64:
+        # pair aggregation inside the f16-operand score kernel on f16 pair values (what the f16 mode runs), against the two-kernel
+        # run on the same values (same inputs, other summation order) and the oracle
+        dz16 = cu(F.linear(z, seeded_sd[pfx + "down_z.weight"]).contiguous()).to(torch.float16)
+        ia.z, ia.dz, ia.dz_f16 = None, dz16.data_ptr(), 1
+        two = torch.full((rows, 1536), float("nan"), device=dev)
+        ia.feats = two.data_ptr()
+        _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
+        fused = torch.full((rows, 1536), float("nan"), device=dev)
+        ia.feats, ia.p_out, ia.fused_pair = fused.data_ptr(), None, 1
+        _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
+        G.sync()
+        assert torch.equal(fused.cpu()[valid][:, :1408], two.cpu()[valid][:, :1408])
+        G.assert_close(fused.cpu()[valid][:, 1408:], two.cpu()[valid][:, 1408:], 1e-5, f"mode {mode} fused o_pair vs two-kernel form")
+        G.assert_close(fused.cpu()[valid][:, 1408:], fr[:, 1408:], 3e-3, f"mode {mode} fused o_pair vs oracle")
 
 
 def _et_run(sd, pfx, s, z, mask, B, L, persistent=True):
@@ -548,6 +563,55 @@ def test_ipa_pair_values_through_the_c_abi(seeded_sd):
     with pytest.raises(Exception):
         G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)), gq("linear_b.weight"), gq("linear_b.bias"),
                     gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"), B, L, variant=1, dz=dz)
+
+
+@pytest.mark.parametrize("B,L", [(3, 90), (2, 128), (2, 64), (1, 200), (1, 256), (2, 77)])
+def test_ipa_fused_pair_aggregation(seeded_sd, B, L):
+    """pf_ipa_attn_args.fused_pair: the pair aggregation sum_j P dz inside the score kernel (no probability tensor, no second kernel)
+    against the two-kernel run on the same pair values and against the oracle -- dense, with key ends (ragged L, holes, a nearly
+    empty sample), every number of key-tile groups (1..4), without a probability buffer."""
+    g = torch.Generator().manual_seed(1000 + L)
+    pfx = "ga_encoder.trunk.ipa_3."
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    mask[0, (L * 5) // 9:] = 0
+    if B > 1:
+        mask[1, L - 13:] = 0
+        mask[1, 7] = 0
+    if B > 2:
+        mask[2, :] = 0
+        mask[2, 3:9] = 1
+    kend = (mask.to(torch.int32) * torch.arange(1, L + 1, dtype=torch.int32)).amax(-1)
+    gq = lambda k: cu(seeded_sd[pfx + k])
+    sd = seeded_sd
+    wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    proj = G.linear(cu(s.reshape(B * L, 128)), cu(wproj), cu(bproj))
+    bias = cu((math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"])).reshape(B, L, L, 8).permute(0, 3, 1, 2))
+    dz = cu(F.linear(z, sd[pfx + "down_z.weight"]).contiguous())
+    run = lambda ke, fused: G.ipa_feats(proj, None, cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)),
+                                        gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"),
+                                        B, L, bias=bias, p_out=None if fused else torch.zeros(B, 8, L, L, device=G.dev()), variant=2,
+                                        key_end=ke, dz=dz, fused_pair=fused)[0].cpu()
+    valid = mask.reshape(-1).bool()
+    ref_out, ref_feats = O.ipa(seeded_sd, pfx[:-1], s, z, R, x, mask)
+    for ke in (None, cu(kend)):
+        two, fused = run(ke, False), run(ke, True)
+        assert torch.equal(fused[valid][:, :1408], two[valid][:, :1408])             # everything but o_pair is the same code
+        G.assert_close(fused[valid][:, 1408:], two[valid][:, 1408:], 1e-5, "fused o_pair vs two-kernel form")
+        G.assert_close(fused[valid], ref_feats.reshape(B * L, -1)[valid], REL, "fused vs oracle")
+        again = run(ke, True)
+        assert torch.equal(again[valid], fused[valid])
+    beyond = (torch.arange(L)[None, :] >= kend[:, None]).reshape(-1)
+    assert torch.isnan(fused[beyond]).all()                                          # rows beyond a key end are not written
+    # without pair values there is nothing to fuse: the flag alone does not replace the probability buffer
+    with pytest.raises(Exception):
+        G.ipa_feats(proj, cu(z), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1)), gq("linear_b.weight"), gq("linear_b.bias"),
+                    gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"), B, L, bias=bias, variant=2, fused_pair=True)
 
 
 @pytest.mark.parametrize("M", [8192, 8192 + 256 * 32 - 5])
