@@ -1015,6 +1015,8 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         // workgroups (65 KB of LDS: two per CU) measured 121 us against 149 for 5 + 5 waves (one per CU) and 153 for 8 + 1; with 8
         // tiles (L = 128) one 8-wave workgroup stays best (105 vs 109 / 137 us for 2 x 4 / 3 x 3)
         if (tiles > WMAX && tiles % WMAX != 0 && wmax > 4) wmax = 4;
+        static const int wcap = [] { const char* e = getenv("PF_IPA_WCAP"); return e ? atoi(e) : 0; }();   // (dev: waves per score workgroup)
+        if (wcap > 0 && wmax > wcap) wmax = wcap;
         if (wmax < 1) return PF_E_TOOLARGE;
         const int nrb = (tiles + wmax - 1) / wmax;
         const int wpb = (tiles + nrb - 1) / nrb;
@@ -1033,6 +1035,10 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             int wm = (int)((160 * 1024 - fixed16) / pw16);
             wm = wm > WMAX ? WMAX : wm;
             if (tiles > WMAX && tiles % WMAX != 0 && wm > 4) wm = 4;          // (as above: 83.5 -> 73.5 us at L = 144)
+            // L <= 64: two waves per workgroup (twice the workgroups, each staging the head's key points again): B=16, L=64 in the f16
+            // mode 0.514 -> 0.498 ms per step; the fp32-operand kernel measures the same either way (0.713 / 0.712) and keeps 4
+            if (tiles <= 4 && wm > 2) wm = 2;
+            if (wcap > 0 && wm > wcap) wm = wcap;
             if (wm < 1) return PF_E_TOOLARGE;
             const int nrb16 = (tiles + wm - 1) / wm, wpb16 = (tiles + nrb16 - 1) / nrb16;
             const size_t lds16 = fixed16 + wpb16 * pw16;
