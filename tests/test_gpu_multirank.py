@@ -115,3 +115,46 @@ def test_bench_self_spawns_its_ranks():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["steps"] == 3
     assert abs(out["value"] - 2 * 16 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out and out["final_state_check"]["det_err"] < 1e-3
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PF_ROOT"])
+import pepflowww_amd
+from pepflowww_amd import synth, distributed as D
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)                    # RCCL: the backend the 8-GPU run uses
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+m = pepflowww_amd.FlowModel(pepflowww_amd.default_config()); m.load_state_dict(synth.seeded_state_dict()); m = m.to(dev).eval()
+B, L, NS = 3, 32, 3
+batch = {k: v.to(dev) for k, v in synth.make_pocket_batch(B, L, 8, seed=21).items()}
+out = D.sample_sharded(m, batch, num_steps=NS, noise=None, seed=4321)          # closing collective: device all_gather_into_tensor on RCCL
+assert all(v.is_cuda for v in out.values())
+full = m.sample(batch, num_steps=NS, noise=None, seed=4321)[-1]
+ok = all(torch.equal(out[k].cpu().reshape(full[k].shape), full[k]) for k in ("rotmats", "trans", "angles", "seqs", "seqs_simplex"))
+print("RCCL_GATHER_EQUALS_LOCAL", ok, flush=True)
+# the training path's collective: ONE all-reduce over a flat fp32 bucket the size of the model's gradient (distributed.allreduce_gradients
+# issues exactly this call when the world has more than one rank)
+flat = torch.randn(6_880_000, device=dev)
+ref = flat.clone()
+dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+print("RCCL_ALLREDUCE_OK", bool(torch.equal(flat, ref)), flush=True)
+print("RCCL_VERSION", ".".join(str(v) for v in torch.cuda.nccl.version()), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_backend_single_rank(tmp_path):
+    """The "nccl" (= RCCL) branch itself, which the shared-GPU tests above cannot take: a one-rank RCCL communicator on the one GPU of
+    this box runs the sharded sampler's closing device all-gather and the training path's flat gradient all-reduce -- the same
+    torch.distributed calls, on device tensors, that the 8-GPU run issues."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, PF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RCCL_GATHER_EQUALS_LOCAL True" in r.stdout and "RCCL_ALLREDUCE_OK True" in r.stdout, r.stdout[-2000:]
