@@ -1,23 +1,29 @@
 #!/bin/bash
-# dev-only: kernel-trace of the training bench grouped by (kernel, grid size)  (run ON the GPU box)
+# dev-only: kernel-trace of the training bench (eager, so that every launch is traced), ONE step cut out between two launches of the
+# loss kernel, grouped by kernel name  (run ON the GPU box)
 cd "$(dirname "$0")/../.." && export TMPDIR=/tmp
-OUT=gpurun_out/kgroups; rm -rf $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT.log 2>&1
+OUT=/tmp/kgroups; rm -rf $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python bench.py --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-modes --no-per-call --no-graph "$@" > $OUT.log 2>&1
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", "")))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-n = len(rows)
-rows = rows[int(n * 2 / 3):]          # the last of the three replays
+marks = [i for i, r in enumerate(rows) if "train_losses_kernel" in r[2] or "train_loss" in r[2].lower() and "bwd" not in r[2].lower()]
+if len(marks) < 2:
+    marks = [i for i, r in enumerate(rows) if "loss" in r[2].lower()]
+a, b = marks[-2], marks[-1]
+step = rows[a:b]
+wall = (step[-1][1] - step[0][0]) / 1e6
 tot = collections.Counter(); cnt = collections.Counter()
-for s, e, name, gx, gy, wx in rows:
-    key = (name.replace("(anonymous namespace)::", "")[:48], gx, gy)
+for s, e, name in step:
+    key = re.sub(r"\(anonymous namespace\)::", "", name)
+    key = re.sub(r"^void ", "", key)[:70]
     tot[key] += e - s; cnt[key] += 1
-print(f"one step: {len(rows)} kernels, busy {sum(tot.values())/1e6:.2f} ms")
-for k, t in tot.most_common(45):
-    print(f"{t/1e3:9.0f} us  {cnt[k]:4d} x {t/cnt[k]/1e3:8.1f} us  grid {k[1]:>9s} x {k[2]:>5s}  {k[0]}")
+print(f"one step: {len(step)} kernels, busy {sum(tot.values())/1e6:.2f} ms, wall {wall:.2f} ms")
+for k, t in tot.most_common(60):
+    print(f"{t/1e3:9.0f} us  {cnt[k]:4d} x {t/cnt[k]/1e3:8.1f} us  {k}")
 PY
 rm -rf $OUT
