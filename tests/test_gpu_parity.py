@@ -871,6 +871,45 @@ def _encoder_case(seeded_sd, batch, resm, seed):
     return t, R_t, x_t, ang_t, seq_t, node, edge
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_ga_encoder_on_rescaled_heavy_tailed_weights(seeded_sd, seed, precision):
+    """Weight magnitudes other than the fixtures' N(0, 1/fan_in): every tensor rescaled by its own factor in [0.4, 2.5] and 0.2 % of
+    the dense entries blown up 6-12 x (the heavy tails of trained layers) -- the split-precision planes, their range guard and the
+    f16 staging must hold the same bars against the oracle as on the seeded weights."""
+    g = torch.Generator().manual_seed(4242 + seed)
+    sd = {}
+    for k, v in seeded_sd.items():
+        if k.endswith("freq_bands") or v.dtype != torch.float32:
+            sd[k] = v.clone()
+            continue
+        f = float(torch.exp((torch.rand((), generator=g) * 2 - 1) * math.log(2.5)))
+        is_gain = v.dim() == 1 and not k.endswith("bias") and not k.endswith("head_weights")
+        w = v.clone() if is_gain else v * f                                    # (LayerNorm gains stay near 1: a gain of 2.5 in every norm is not a trained net)
+        if v.dim() == 2 and v.numel() >= 4096:
+            hit = torch.rand(v.shape, generator=g) < 0.002
+            w = torch.where(hit, w * (6 + 6 * torch.rand(v.shape, generator=g)), w)
+        sd[k] = w.contiguous()
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(G.dev()).eval()
+    m.ga_encoder.set_precision(precision)
+    B, L = 2, 64
+    batch = synth.make_pocket_batch(B, L, 9, seed=77 + seed, lengths=[64, 51])
+    resm = batch["res_mask"]
+    t, R_t, x_t, ang_t, seq_t, node, edge = _encoder_case(sd, batch, resm, 900 + seed)
+    ref = O.ga_encoder(sd, t, R_t, x_t, ang_t, seq_t, node, edge, resm.long())
+    out = m.ga_encoder(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t), cu(node), cu(edge), cu(batch["generate_mask"].long()), cu(resm.long()))
+    G.sync()
+    valid = resm
+    rt, tt, lt = (REL, REL, 2 * REL) if precision == "fp32" else (1.2e-2, 3e-3, F16_LOGIT_TOL)
+    G.assert_close(out[0].cpu()[valid], ref[0][valid], rt, "rotmats")
+    G.assert_close(out[1].cpu()[valid], ref[1][valid], tt, "trans")
+    G.assert_close(out[3].cpu()[valid], ref[3][valid], lt, "logits")
+    d = (out[2].cpu()[valid] - ref[2][valid]).abs()
+    assert torch.minimum(d, 2 * math.pi - d).max() < (3e-4 if precision == "fp32" else 3e-2)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16"])
 def test_masked_tiles_and_keys_are_skipped_exactly(model, seeded_sd, precision):
     """Work lists of the padded-batch path (EdgeTransition tile list, IPA key_end): masks with HOLES (a whole 16-residue block
