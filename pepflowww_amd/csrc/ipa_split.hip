@@ -318,6 +318,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         __builtin_amdgcn_wave_barrier();
         pair_dz_phase<false>(a, rowb, h, i0, Le, kt, SW + (size_t)wave * 16 * SLD, SLD, inv, lane);
     }
+    PROFS(7);
     float* prow = FUSE ? nullptr : a.p_out + (((size_t)b * H + h) * L + iq) * L;
 
     // ---- [o | o_pt] = P [V | V_pts]: A = P (this lane: query r, key 16 t + 4 g + tt in MFMA tt), B = value rows.
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     __builtin_amdgcn_wave_barrier();
     PROFS(3);
     if constexpr (FUSE) pair_dz_phase<true>(a, rowb, h, i0, LK, kt, SW + (size_t)wave * 16 * SLD, SLD, inv, lane);
+    PROFS(7);
     float* prow = FUSE ? nullptr : a.p_out + (((size_t)b * H + h) * L + iq) * L;
 
     // ---- [o | o_pt] = P [V | V_pts]: A = P (lane (r = query, g): keys 32 s + 8 g .. + 7), B = transposed value rows
