@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 42
+#define PF_ABI_VERSION 43
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -498,6 +498,10 @@ typedef struct {
     const float* gate;
 } pf_gemm_args;
 int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
+/* the two products of a row-sized Linear backward in ONE launch: dx = dy W (a1) and dW (+)= dy^T x (a2), each described as for
+ * pf_gemm_f32.  Their workgroups share a grid (each product alone fills a fraction of the CUs for a chain of global round trips);
+ * results are those of two pf_gemm_f32 calls bit for bit, and any pair outside the compiled-in layouts runs as exactly that. */
+int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, pf_stream_t stream);
 /* weight gradient of a Linear over all pairs in one pass: C[M,N] (+)= A^T B with A = dy [R,M] (lda), B = x [R,N] (ldb),
  * M <= 192, N <= 256 (multiples of 4), and optionally colsum_a[M] (+)= column sums of A (the bias gradient).  One workgroup owns
  * the whole C for its row range, so A and B are read once (csrc/backward.hip: gemm_tn_wide_kernel; for N <= 192 the product

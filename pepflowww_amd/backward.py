@@ -24,11 +24,12 @@ def _zeros(*shape, device, dtype=torch.float32):
     node was observed to race with following atomics when the training step is replayed as a hipGraph)."""
     return torch.full(shape, 0, dtype=dtype, device=device)
 
+import os
+
 from . import _capi
 
 
-def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None, rowsum=None, gate=None, residual=None):
-    """C = alpha * A B (+ C).  Offsets in elements; batch = (n1, n2, (sA1, sA2), (sB1, sB2), (sC1, sC2)) for sample x head slices."""
+def _gemm_args(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, ldc=None, a_off=0, b_off=0, c_off=0, batch=None, rowsum=None, gate=None, residual=None):
     a = _capi.GemmArgs()
     a.A, a.sam, a.sak = A.data_ptr() + 4 * a_off, sam, sak
     a.B, a.sbk, a.sbn = Bm.data_ptr() + 4 * b_off, sbk, sbn
@@ -43,11 +44,18 @@ def _gemm(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, accumulate=False, alpha=1.0, l
     if batch is not None:
         a.batch1, a.batch2 = batch[0], batch[1]
         (a.bsA1, a.bsA2), (a.bsB1, a.bsB2), (a.bsC1, a.bsC2) = batch[2], batch[3], batch[4]
-    _capi.check(_capi.load().pf_gemm_f32(C.byref(a), _capi.stream_ptr()), "pf_gemm_f32")
+    return a
+
+
+def _gemm(*args, **kw):
+    """C = alpha * A B (+ C).  Offsets in elements; batch = (n1, n2, (sA1, sA2), (sB1, sB2), (sC1, sC2)) for sample x head slices."""
+    _capi.check(_capi.load().pf_gemm_f32(C.byref(_gemm_args(*args, **kw)), _capi.stream_ptr()), "pf_gemm_f32")
+
+
+DUAL_GEMM = os.environ.get("PF_DUAL_GEMM", "1") != "0"      # dx and dW of a row-sized Linear backward in one launch (A/B switch)
 
 
 SPLIT_MIN_ROWS = 8192          # pair-sized products go to the split-precision kernel of the inference path
-import os
 TN_WIDE_MIN_ROWS = int(os.environ.get("PF_TN_WIDE_MIN_ROWS", "8192"))
 
 
@@ -205,19 +213,28 @@ def linear_bwd(x, w, dy, need_dx=True, dW=None, db=None, dx_gate=None, dx_residu
     M, K = x.shape
     N = w.shape[0]
     dx = None
+    dx_args = None
     if need_dx:
         if _split_ok(M, N) and dy.is_contiguous() and K % 4 == 0:
             dx = _linear_split(dy, w, gate=dx_gate, residual=dx_residual, w_transposed=True)   # dx = dy W = dy (W^T)^T
         else:
             dx = torch.empty(M, K, device=x.device)
-            _gemm(dy, N, 1, w, K, 1, dx, M, K, N, gate=dx_gate, residual=dx_residual)      # ReLU backward / skip fused in the epilogue
+            dx_args = _gemm_args(dy, N, 1, w, K, 1, dx, M, K, N, gate=dx_gate, residual=dx_residual)   # ReLU backward / skip fused in the epilogue
     acc = dW is not None
     if dW is None:
         dW, acc = _grad_buffer(N, K, device=x.device)
     accb = db is not None
     if db is None:
         db, accb = _grad_buffer(N, device=x.device)
-    if M >= TN_WIDE_MIN_ROWS and N <= 192 and K <= 192 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous():
+    wide = M >= TN_WIDE_MIN_ROWS and N <= 192 and K <= 192 and N % 4 == 0 and K % 4 == 0 and dW.is_contiguous()
+    if dx_args is not None and DUAL_GEMM and not wide and accb:
+        # row-sized Linear: dx and dW (+ db from the row sums of dy^T) share one launch
+        dw_args = _gemm_args(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=acc, rowsum=db)
+        _capi.check(lib.pf_gemm_f32_dual(C.byref(dx_args), C.byref(dw_args), _capi.stream_ptr()), "pf_gemm_f32_dual")
+        return dx, dW, db
+    if dx_args is not None:
+        _capi.check(lib.pf_gemm_f32(C.byref(dx_args), _capi.stream_ptr()), "pf_gemm_f32")
+    if wide:
         # dW and db in ONE pass over dy and x (csrc/backward.hip: gemm_tn_wide_kernel)
         ws = _tn_workspace(x.device)
         _capi.check(lib.pf_gemm_tn_wide(dy.data_ptr(), N, N, x.data_ptr(), K, K, dW.data_ptr(), K, M, int(acc), db.data_ptr(), int(accb),

@@ -140,31 +140,31 @@ struct Stage {
 // MT = 16-row tiles per wave along M: C tile (32 MT) x 64 per workgroup (MT = 4 for tall problems)
 // D = chunks of K in flight (register stages): the row-sized products of the step (M = B*L ~ 2048) are latency chains of
 // global round trips with one chunk of run-ahead.
+// (the body of one workgroup; bx / by / bz = its tile and split-K / batch coordinates: gemm_f32_kernel passes blockIdx, the dual
+//  kernel below decodes them from a linear block index)
 template <int MT, int D, int MA, int MB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA, int vecB) {
+__device__ __forceinline__ void gemm_f32_body(pf_gemm_args p, int vecA, int vecB, int bx, int by, int bz, float* __restrict__ As, float* __restrict__ Bs) {
     constexpr int TM = 32 * MT;
-    __shared__ __attribute__((aligned(16))) float As[TM * LDT];      // [m][k]
-    __shared__ __attribute__((aligned(16))) float Bs[GT * LDT];      // [n][k]
     int kbeg = 0, kend = p.K;
     if (p.ksplit > 1) {                 // split-K (no batching in this mode): this workgroup owns K range [kbeg, kend), atomicAdd into C
         const int per = ((p.K + p.ksplit - 1) / p.ksplit + GK - 1) / GK * GK;
-        kbeg = blockIdx.z * per;
+        kbeg = bz * per;
         kend = min(p.K, kbeg + per);
         if (kbeg >= kend) return;
     } else {
-        const int z1 = blockIdx.z / (p.batch2 > 0 ? p.batch2 : 1), z2 = blockIdx.z - z1 * (p.batch2 > 0 ? p.batch2 : 1);
+        const int z1 = bz / (p.batch2 > 0 ? p.batch2 : 1), z2 = bz - z1 * (p.batch2 > 0 ? p.batch2 : 1);
         p.A += z1 * p.bsA1 + z2 * p.bsA2;
         p.B += z1 * p.bsB1 + z2 * p.bsB2;
         p.C += z1 * p.bsC1 + z2 * p.bsC2;
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * GT;
+    const int m0 = bx * TM, n0 = by * GT;
     const int wm = (wave >> 1) * 16 * MT, wn = (wave & 1) * 32;
     f32x4 acc[MT][2];
     acc_zero<MT, 2>(acc);
     float rs = 0.f;                                         // row sum of A over this workgroup's K range (rowsum_a: n tile 0 only)
-    const bool do_rs = p.rowsum_a && blockIdx.y == 0 && tid < TM;
+    const bool do_rs = p.rowsum_a && by == 0 && tid < TM;
     Stage<TM, MA> sa;
     Stage<GT, MB> sb;
     sa.init(p.A, p.sam, p.sak, m0, p.M, vecA != 0, kbeg);
@@ -239,6 +239,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA,
                 }
             }
     if (do_rs && m0 + tid < p.M) atomicAdd(p.rowsum_a + m0 + tid, rs);
+}
+
+template <int MT, int D, int MA, int MB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(pf_gemm_args p, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[32 * MT * LDT];      // [m][k]
+    __shared__ __attribute__((aligned(16))) float Bs[GT * LDT];           // [n][k]
+    gemm_f32_body<MT, D, MA, MB>(p, vecA, vecB, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// The two products of a row-sized Linear backward in ONE launch: dx = dy W (k-contiguous A, n-contiguous B) and dW (+)= dy^T x
+// (split-K, both operands row-contiguous).  Each of them alone puts 16 - 128 workgroups on the 256 CUs for a chain of global round
+// trips (8 - 20 us for a few MFLOP); together their workgroups fill the same time.  Blocks [0, n1) belong to the first product.
+struct GemmDualDims { int n1, gx1, gy1, gx2, gy2; };
+template <int MT1, int MT2>
+__global__ __launch_bounds__(256) void gemm_f32_dual_kernel(pf_gemm_args p1, int vA1, int vB1, pf_gemm_args p2, int vA2, int vB2, GemmDualDims d) {
+    constexpr int MTM = MT1 > MT2 ? MT1 : MT2;
+    __shared__ __attribute__((aligned(16))) float As[32 * MTM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[GT * LDT];
+    int b = blockIdx.x;
+    if (b < d.n1) {                                              // (workgroup-uniform)
+        const int bx = b % d.gx1, t = b / d.gx1;
+        gemm_f32_body<MT1, 4, 0, 1>(p1, vA1, vB1, bx, t % d.gy1, t / d.gy1, As, Bs);
+    } else {
+        b -= d.n1;
+        const int bx = b % d.gx2, t = b / d.gx2;
+        gemm_f32_body<MT2, 4, 1, 1>(p2, vA2, vB2, bx, t % d.gy2, t / d.gy2, As, Bs);
+    }
 }
 
 // ---- wide TN product for weight gradients over all pairs:  C[M,N] (+)= A^T B,  A [R,M] (lda), B [R,N] (ldb), M, N <= 192, R = B*L*L.
@@ -1632,16 +1659,22 @@ extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float*
     return 0;
 }
 
-extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
-    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
-    if (a->rowsum_a && (a->batch1 > 0 || a->batch2 > 0)) return PF_E_BADARG;
+namespace {
+// launch configuration of one product (shared by pf_gemm_f32 and pf_gemm_f32_dual)
+struct GemmPlan { pf_gemm_args g; int TM, combo, vA, vB; dim3 grid; bool zero_c; };
+bool gemm_plan(const pf_gemm_args* a, GemmPlan& pl) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return false;
+    if (a->rowsum_a && (a->batch1 > 0 || a->batch2 > 0)) return false;
     const int nb = (a->batch1 > 0 ? a->batch1 : 1) * (a->batch2 > 0 ? a->batch2 : 1);
-    pf_gemm_args g = *a;
+    pf_gemm_args& g = pl.g;
+    g = *a;
     g.ksplit = 1;
+    pl.zero_c = false;
     const bool tall = a->M >= 8192;                       // 128-row C tiles for the pair-sized products
     // row-sized products (M = B*L ~ 2048): 32-row tiles when 64-row ones would leave most CUs without a workgroup
     const bool small = !tall && nb == 1 && (long long)((a->M + 63) / 64) * ((a->N + GT - 1) / GT) < 128 && a->M >= 256;
     const int TM = tall ? 128 : (small ? 32 : 64);
+    pl.TM = TM;
     const long long tiles = (long long)((a->M + TM - 1) / TM) * ((a->N + GT - 1) / GT);
     // long-K, few-tile products (dW = dy^T x over all pairs): split K over workgroups, partial sums by atomicAdd
     // (also the row-sized ones, K = B*L: without the split a 128 x 128 dW runs on 4 workgroups for ~115 us -- a quarter of
@@ -1649,10 +1682,7 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
     if (nb == 1 && !a->bias && !a->relu && !a->residual && !a->gate && a->K >= 512 && tiles < 256) {
         long long want = ((a->K >= 4096 ? 1024 : 512) + tiles - 1) / tiles, kmax = (a->K + 4 * GK - 1) / (4 * GK);
         g.ksplit = (int)(want < kmax ? want : kmax);
-        if (g.ksplit > 1 && !a->accumulate) {
-            if (a->ldc == a->N) zero_fill(a->C, (size_t)a->M * a->N, (hipStream_t)stream);
-            else zero_fill_2d(a->C, a->M, a->N, a->ldc, (hipStream_t)stream);
-        }
+        pl.zero_c = g.ksplit > 1 && !a->accumulate;
     }
     const int gz = g.ksplit > 1 ? g.ksplit : nb;
     // float4 staging needs 16-byte aligned rows / slices of the operand along its unit-stride dimension
@@ -1662,24 +1692,67 @@ extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
         if (s_row == 1) return (s_k % 4 == 0 && n_rows % 4 == 0) ? 1 : 0;
         return 0;
     };
-    const int vA = vec_ok(a->A, a->sam, a->sak, a->M, a->bsA1, a->bsA2), vB = vec_ok(a->B, a->sbn, a->sbk, a->N, a->bsB1, a->bsB2);
-    const dim3 grid((unsigned)((a->M + TM - 1) / TM), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz);
+    pl.vA = vec_ok(a->A, a->sam, a->sak, a->M, a->bsA1, a->bsA2);
+    pl.vB = vec_ok(a->B, a->sbn, a->sbk, a->N, a->bsB1, a->bsB2);
+    pl.grid = dim3((unsigned)((a->M + TM - 1) / TM), (unsigned)((a->N + GT - 1) / GT), (unsigned)gz);
     // operand layouts of the common products compiled in (see Stage): NT forward (0, 0), dx = dy W (0, 1), dW = dy^T x (1, 1)
-    const int mA = vA && a->sak == 1 ? 0 : vA && a->sam == 1 ? 1 : 2, mB = vB && a->sbk == 1 ? 0 : vB && a->sbn == 1 ? 1 : 2;
-    const int combo = (mA == 0 && mB == 0) ? 0 : (mA == 0 && mB == 1) ? 1 : (mA == 1 && mB == 1) ? 2 : mA == 0 ? 4 : 3;
+    const int mA = pl.vA && a->sak == 1 ? 0 : pl.vA && a->sam == 1 ? 1 : 2, mB = pl.vB && a->sbk == 1 ? 0 : pl.vB && a->sbn == 1 ? 1 : 2;
+    pl.combo = (mA == 0 && mB == 0) ? 0 : (mA == 0 && mB == 1) ? 1 : (mA == 1 && mB == 1) ? 2 : mA == 0 ? 4 : 3;
+    return true;
+}
+void gemm_zero_c(const pf_gemm_args* a, hipStream_t st) {
+    if (a->ldc == a->N) zero_fill(a->C, (size_t)a->M * a->N, st);
+    else zero_fill_2d(a->C, a->M, a->N, a->ldc, st);
+}
+}  // namespace
+
+extern "C" int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream) {
+    GemmPlan pl;
+    if (!gemm_plan(a, pl)) return PF_E_BADARG;
     const hipStream_t st = (hipStream_t)stream;
+    if (pl.zero_c) gemm_zero_c(a, st);
+    const pf_gemm_args& g = pl.g;
+    const dim3 grid = pl.grid;
+    const int vA = pl.vA, vB = pl.vB;
 #define PF_GEMM_LAUNCH(MT_, D_) \
-    switch (combo) { \
+    switch (pl.combo) { \
         case 0: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, 0>), grid, dim3(256), 0, st, g, vA, vB); break; \
         case 1: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, 1>), grid, dim3(256), 0, st, g, vA, vB); break; \
         case 2: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 1, 1>), grid, dim3(256), 0, st, g, vA, vB); break; \
         case 4: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, 0, -1>), grid, dim3(256), 0, st, g, vA, vB); break; \
         default: hipLaunchKernelGGL((gemm_f32_kernel<MT_, D_, -1, -1>), grid, dim3(256), 0, st, g, vA, vB); break; \
     }
-    if (tall) { PF_GEMM_LAUNCH(4, 1) }
-    else if (small) { PF_GEMM_LAUNCH(1, 4) }
+    if (pl.TM == 128) { PF_GEMM_LAUNCH(4, 1) }
+    else if (pl.TM == 32) { PF_GEMM_LAUNCH(1, 4) }
     else { PF_GEMM_LAUNCH(2, 4) }
 #undef PF_GEMM_LAUNCH
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
+// dx = dy W and dW (+)= dy^T x of one Linear in one launch (gemm_f32_dual_kernel) when both are row-sized products in the compiled-in
+// layouts; anything else runs as two launches -- same arithmetic either way (a workgroup's work does not depend on which launch
+// carries it).
+extern "C" int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, pf_stream_t stream) {
+    GemmPlan p1, p2;
+    if (!gemm_plan(a1, p1) || !gemm_plan(a2, p2)) return PF_E_BADARG;
+    const hipStream_t st = (hipStream_t)stream;
+    const bool dual_ok = p1.combo == 1 && p2.combo == 2 && p1.TM <= 64 && p2.TM <= 64 && p1.g.ksplit == 1;
+    if (!dual_ok) {
+        int rc = pf_gemm_f32(a1, stream);
+        return rc ? rc : pf_gemm_f32(a2, stream);
+    }
+    if (p2.zero_c) gemm_zero_c(a2, st);
+    GemmDualDims d;
+    d.gx1 = (int)p1.grid.x; d.gy1 = (int)p1.grid.y; d.n1 = (int)(p1.grid.x * p1.grid.y * p1.grid.z);
+    d.gx2 = (int)p2.grid.x; d.gy2 = (int)p2.grid.y;
+    const unsigned nblk = (unsigned)d.n1 + p2.grid.x * p2.grid.y * p2.grid.z;
+#define PF_DUAL(M1_, M2_) hipLaunchKernelGGL((gemm_f32_dual_kernel<M1_, M2_>), dim3(nblk), dim3(256), 0, st, p1.g, p1.vA, p1.vB, p2.g, p2.vA, p2.vB, d)
+    if (p1.TM == 32 && p2.TM == 32) PF_DUAL(1, 1);
+    else if (p1.TM == 32) PF_DUAL(1, 2);
+    else if (p2.TM == 32) PF_DUAL(2, 1);
+    else PF_DUAL(2, 2);
+#undef PF_DUAL
     PF_CHECK_LAUNCH();
     return 0;
 }
