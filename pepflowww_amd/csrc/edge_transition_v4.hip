@@ -73,7 +73,7 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
 #ifndef PF_ET4_WHATIF
-#define PF_ET4_WHATIF 0                        // dev what-if builds (tools/dev/et_variants.sh): 1 = no stage barriers, 2 = no LDS-DMA
+#define PF_ET4_WHATIF 0                        // dev what-if builds (tools/dev/et_variants.sh): 1 = no stage barriers, 2 = no LDS-DMA, 8 = one fragment read per stage
 #endif
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
     if constexpr ((PF_ET4_WHATIF & 2) != 0) return;
@@ -448,22 +448,29 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
             for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
         }
 #define XMFMA(w, x) do { if constexpr (PF_ET4_XMFMA > 0) { _Pragma("unroll") for (int xx = 0; xx < PF_ET4_XMFMA; ++xx) xacc = mfma32((w).h, (x).h, xacc); } } while (0)
-        Op wq[2];
+#ifndef PF_ET4_QD
+#define PF_ET4_QD 2                            // fragment reads in flight per wave: entry e + QD - 1 is requested before entry e is multiplied
+#endif
+        constexpr int QD = PF_ET4_QD;
+        Op wq[QD];
         auto getw = [&](auto ie) __attribute__((always_inline)) -> const Op& {
             CI(e, ie);
             PROF4(e);
-            if constexpr (e % EPSv == 0) {
+            constexpr int es = e % EPSv;                             // position inside the stage
+            if constexpr (es == 0) {
                 if constexpr (e != 0) stage_end(std::integral_constant<int, e / EPSv - 1>{});
-                wq[e & 1] = ldw<SP>(smem + slot * STAGE_B, 0, lane);     // the first fragments of the stage are on their way ...
+                // the first fragments of the stage are on their way ...
+                cfor<0, QD - 1>([&](auto ik) { CI(k, ik); if constexpr (k < EPSv) wq[(e + k) % QD] = ldw<SP>(smem + slot * STAGE_B, k, lane); });
             }
-            if constexpr (e + 1 < NENT && (e + 1) % EPSv != 0) wq[(e + 1) & 1] = ldw<SP>(smem + slot * STAGE_B, (e + 1) % EPSv, lane);
-            if constexpr (e % EPSv == 0) {
+            if constexpr ((PF_ET4_WHATIF & 8) == 0 && es + QD - 1 < EPSv && e + QD - 1 < NENT)       // (what-if 8: no reads but the first of a stage)
+                wq[(e + QD - 1) % QD] = ldw<SP>(smem + slot * STAGE_B, es + QD - 1, lane);
+            if constexpr (es == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage_begin(std::integral_constant<int, e / EPSv>{});    // ... while the issuing waves form their LDS-DMA pieces
                 PROF4(133 + 3 * (e / EPSv));
             }
             __builtin_amdgcn_sched_barrier(0);                   // pins the request above the MFMAs that follow in program order
-            return wq[e & 1];
+            return wq[e % QD];
         };
 #define GETW(e) getw(std::integral_constant<int, (e)>{})
 #define ENTRY(e) (smem + slot * STAGE_B), ((e) % EPSv)
