@@ -244,8 +244,8 @@ def pmc_traffic(workload, precision):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)        # (= the 100-step sampling of BASELINE configs[1]; 0.35 s of timed region)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

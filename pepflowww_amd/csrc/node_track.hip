@@ -768,7 +768,9 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             f32x4 pm[RT][4], pc[RT][4];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc_zero1<4>(pm[rt], pc[rt]);
+            PROF(12);
             gemm_split16r<4, 2, SP, RT>(wp, Xa.h, Xa.l, LDP, pm, pc, 0, 2);
+            PROF(13);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 if (mr[rt] < M) {

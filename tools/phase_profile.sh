@@ -30,7 +30,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     raw = C.CDLL(_capi.LIB_PATH)
     out = (C.c_longlong * 256)()
-    for sym, n in (("pf_debug_prof", 13), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 8), ("pf_debug_prof_et3", 156)):
+    for sym, n in (("pf_debug_prof", 14), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 8), ("pf_debug_prof_et3", 156)):
         getattr(raw, sym)(out, 256 if sym.endswith("et3") else 64)
         v = list(out)
         print(sym, "stamps (cycles rel.):", [x - v[0] for x in v[:n]])
