@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 43
+#define PF_ABI_VERSION 44
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -502,6 +502,21 @@ int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
  * pf_gemm_f32.  Their workgroups share a grid (each product alone fills a fraction of the CUs for a chain of global round trips);
  * results are those of two pf_gemm_f32 calls bit for bit, and any pair outside the compiled-in layouts runs as exactly that. */
 int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, pf_stream_t stream);
+/* ---- the dx chain of the EdgeTransition backward in one kernel (csrc/et_bwd.hip; ipa_pytorch.py:233-248 reversed):
+ *   g_u = g_y Wf;  g_h2 = g_u * [h2 > 0];  g_h1 = (g_h2 W2) * [h1 > 0];  g_x = g_h1 W1 + g_u
+ * g_y [npairs,64] = gradient w.r.t. the pre-LayerNorm output; h1, h2 [npairs,192] = the saved hidden activations
+ * (pf_edge_transition_args.dump_h1 / dump_h2); w*T_f16 = the TRANSPOSED weight matrices as fragment-order f16 hi / lo planes
+ * (pf_split_pack_f16 with transpose = 1: final_layer [64,192] -> [192,64]; trunk.2 and trunk.0 [192,192]).  Outputs [npairs,192]:
+ * g_h2 and g_h1 (already gated: the operands of the weight-gradient products), g_x (for pf_et_concat_bwd).  Same split-precision
+ * arithmetic as three pf_linear_fwd products. */
+typedef struct {
+    const float* g_y; const float* h1; const float* h2;
+    const void* wfT_f16; const void* w2T_f16; const void* w1T_f16;
+    float* g_h2; float* g_h1; float* g_x;
+    long long npairs;
+} pf_et_bwd_args;
+int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream);
+
 /* weight gradient of a Linear over all pairs in one pass: C[M,N] (+)= A^T B with A = dy [R,M] (lda), B = x [R,N] (ldb),
  * M <= 192, N <= 256 (multiples of 4), and optionally colsum_a[M] (+)= column sums of A (the bias gradient).  One workgroup owns
  * the whole C for its row range, so A and B are read once (csrc/backward.hip: gemm_tn_wide_kernel; for N <= 192 the product

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -163,7 +163,13 @@ class NodeTfmrArgs(C.Structure):
                 ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp)]
 
 
+class EtBwdArgs(C.Structure):
+    _fields_ = [("g_y", _fp), ("h1", _fp), ("h2", _fp), ("wfT_f16", _fp), ("w2T_f16", _fp), ("w1T_f16", _fp),
+                ("g_h2", _fp), ("g_h1", _fp), ("g_x", _fp), ("npairs", C.c_longlong)]
+
+
 _SIGNATURES = {
+    "pf_et_bwd_chain": ([C.POINTER(EtBwdArgs), _fp], _i),
     "pf_abi_version": ([], _i),
     "pf_selftest_mfma": ([_fp, _fp, _fp, _i, _fp], _i),
     "pf_selftest_lanes": ([_fp, _fp, _fp], _i),

@@ -581,6 +581,7 @@ class EdgeTransitionBlock:
 
     # forward on the persistent inference kernel (with h1 / h2 / y dumps) instead of three Linears (PF_ET_FUSED_FWD=0: unfused)
     FUSED_FORWARD = os.environ.get("PF_ET_FUSED_FWD", "1") != "0"
+    FUSED_BACKWARD = os.environ.get("PF_ET_FUSED_BWD", "1") != "0"      # the dx chain of the backward as one kernel (A/B switch)
 
     def _forward_fused(self, s, z, n, x, em):
         """z' = mask * LN(Wf(h2 + x) + bf) by pf_edge_transition_fwd's persistent kernel, which also stores h1, h2 and the
@@ -635,11 +636,28 @@ class EdgeTransitionBlock:
         g_y, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"] = layernorm_bwd(sv["y"], W[p + "layer_norm.weight"], g_out, row_scale=sv["em"])
         # final_layer(h2 + x): dW = g_y^T h2 + g_y^T x as two passes accumulating into the same gradient -- cheaper than
         # materialising u = h2 + x ([B L L, 192], one more pair-sized read-read-write) just to contract it once
-        g_u, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y)
-        G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
-        g_h2 = relu_gate(sv["h2"], g_u)                          # g_u also flows through the skip connection h2 + x
-        g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, dx_gate=sv["h1"])
-        g_x, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, dx_residual=g_u)
+        if self.FUSED_BACKWARD:
+            # the dx chain g_y -> g_u -> g_h2 -> g_h1 -> g_x in one kernel (csrc/et_bwd.hip), then the three weight gradients
+            npairs = B * L * L
+            dev = g_out.device
+            g_h2, g_h1, g_x = (torch.empty(npairs, 192, device=dev) for _ in range(3))
+            keep = [_split_pack(W[p + "final_layer.weight"], transpose=True), _split_pack(W[p + "trunk.2.weight"], transpose=True),
+                    _split_pack(W[p + "trunk.0.weight"], transpose=True)]
+            ea = _capi.EtBwdArgs()
+            ea.g_y, ea.h1, ea.h2 = g_y.data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr()
+            ea.wfT_f16, ea.w2T_f16, ea.w1T_f16 = (k.data_ptr() for k in keep)
+            ea.g_h2, ea.g_h1, ea.g_x, ea.npairs = g_h2.data_ptr(), g_h1.data_ptr(), g_x.data_ptr(), npairs
+            _capi.check(lib.pf_et_bwd_chain(C.byref(ea), _capi.stream_ptr()), "pf_et_bwd_chain")
+            _, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y, need_dx=False)
+            G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
+            _, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, need_dx=False)
+            _, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, need_dx=False)
+        else:
+            g_u, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y)
+            G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
+            g_h2 = relu_gate(sv["h2"], g_u)                          # g_u also flows through the skip connection h2 + x
+            g_h1, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, dx_gate=sv["h1"])
+            g_x, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, dx_residual=g_u)
         acc = g_z is not None
         if g_z is None:
             g_z = torch.empty(B * L * L, 64, device=g_out.device)
