@@ -502,6 +502,13 @@ int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
  * pf_gemm_f32.  Their workgroups share a grid (each product alone fills a fraction of the CUs for a chain of global round trips);
  * results are those of two pf_gemm_f32 calls bit for bit, and any pair outside the compiled-in layouts runs as exactly that. */
 int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, pf_stream_t stream);
+/* EdgeTransition operands of the TRAINING forward from the fp32 parameters, two launches (the parameters change every step):
+ * stream_out = the persistent kernel's 256 KiB fragment stream (pf_edge_transition_args.w_stream: [128][hi 512 | lo 512] f16) as a
+ * gather through stream_idx (int32 [128*512] flat indices into trunk.0.weight | trunk.2.weight | final_layer.weight) with
+ * lo = f16((w - hi) * lo_scale); pre_w [512,64], pre_b [512] = weight / bias of the per-residue terms a | c | d | e. */
+int pf_et_pack_train(const float* w1, const float* b1, const float* w2, const float* wf, const float* bf, const int* stream_idx,
+                     void* stream_out, float lo_scale, float* pre_w, float* pre_b, pf_stream_t stream);
+
 /* ---- the dx chain of the EdgeTransition backward in one kernel (csrc/et_bwd.hip; ipa_pytorch.py:233-248 reversed):
  *   g_u = g_y Wf;  g_h2 = g_u * [h2 > 0];  g_h1 = (g_h2 W2) * [h1 > 0];  g_x = g_h1 W1 + g_u
  * g_y [npairs,64] = gradient w.r.t. the pre-LayerNorm output; h1, h2 [npairs,192] = the saved hidden activations

@@ -566,7 +566,7 @@ def _et_stream_index(device):
         for ft in (2 * c, 2 * c + 1):
             out += [frag(OFF2, ft, perm(k)) for k in range(6)]
         out += [frag(OFFF, t, perm(c)) for t in range(4)]
-    idx = torch.stack(out).to(device)
+    idx = torch.stack(out).to(torch.int32).to(device).contiguous()
     assert idx.shape == (128, 512)
     _ET_STREAM_IDX[key] = idx
     return idx
@@ -590,17 +590,16 @@ class EdgeTransitionBlock:
         dev, P = s.device, B * L * L
         w1, w2, wf = W[p + "trunk.0.weight"], W[p + "trunk.2.weight"], W[p + "final_layer.weight"]
         b1, bf = W[p + "trunk.0.bias"], W[p + "final_layer.bias"]
-        # per-residue terms a | c | d | e (include/pepflow_hip.h, pf_edge_transition_args)
-        pre_w = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
-        pre_b = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
-        pre = linear_fwd(n, pre_w, pre_b)
-        # the 256 KiB fragment stream (engine.pack_et_stream) by one gather through a static index + the hi / lo split
-        idx = _et_stream_index(dev)
-        v = torch.cat([w1.reshape(-1), w2.reshape(-1), wf.reshape(-1)])[idx]                    # [128, 512]
-        hi = v.to(torch.float16)
+        # per-residue terms a | c | d | e (include/pepflow_hip.h, pf_edge_transition_args) and the 256 KiB fragment stream
+        # (engine.pack_et_stream: a gather through a static index + the hi / lo split), both by pf_et_pack_train
         from .engine import ET_LO_SCALE
-        lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
-        stream = torch.stack([hi, lo], 1).contiguous()                                          # [128, 2, 512] f16
+        idx = _et_stream_index(dev)
+        pre_w, pre_b = torch.empty(512, 64, device=dev), torch.empty(512, device=dev)
+        stream = torch.empty(128, 2, 512, dtype=torch.float16, device=dev)
+        _capi.check(lib.pf_et_pack_train(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), wf.data_ptr(), bf.data_ptr(), idx.data_ptr(),
+                                         stream.data_ptr(), float(ET_LO_SCALE), pre_w.data_ptr(), pre_b.data_ptr(), _capi.stream_ptr()),
+                    "pf_et_pack_train")
+        pre = linear_fwd(n, pre_w, pre_b)
         out, h1, h2, y = (torch.empty(P, 64, device=dev), torch.empty(P, 192, device=dev), torch.empty(P, 192, device=dev),
                           torch.empty(P, 64, device=dev))
         a = _capi.EdgeTransitionArgs()

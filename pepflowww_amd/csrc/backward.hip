@@ -1756,6 +1756,47 @@ extern "C" int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, 
     PF_CHECK_LAUNCH();
     return 0;
 }
+namespace {
+// EdgeTransition weights of the training forward, repacked every step (the parameters change): the 256 KiB fragment stream of the
+// persistent kernel = a gather through a static index into (trunk.0 | trunk.2 | final_layer) + the hi / lo split, and the [512, 64]
+// weight / [512] bias of the per-residue terms a | c | d | e -- two launches instead of the ~12 torch cat / index / cast launches
+// they took per block.
+__global__ __launch_bounds__(256) void et_pack_stream_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ wf,
+                                                             const int* __restrict__ idx, _Float16* __restrict__ out, float lo_scale) {
+    const int t = blockIdx.x * 256 + threadIdx.x;               // element of the [128 entries][512] gather
+    if (t >= 128 * 512) return;
+    const int i = idx[t];
+    const float v = i < 192 * 192 ? w1[i] : i < 2 * 192 * 192 ? w2[i - 192 * 192] : wf[i - 2 * 192 * 192];
+    const _Float16 hi = (_Float16)v;
+    const int e = t >> 9, k = t & 511;
+    out[(size_t)e * 1024 + k] = hi;
+    out[(size_t)e * 1024 + 512 + k] = (_Float16)((v - (float)hi) * lo_scale);
+}
+__global__ __launch_bounds__(256) void et_pack_pre_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wf,
+                                                          const float* __restrict__ bf, float* __restrict__ pre_w, float* __restrict__ pre_b) {
+    const int t = blockIdx.x * 256 + threadIdx.x;               // element of pre_w [512][64]
+    if (t >= 512 * 64) return;
+    const int row = t >> 6, c = t & 63;
+    float v;
+    if (row < 192) v = w1[row * 192 + 64 + c];                  // a: W1[:, 64:128]
+    else if (row < 384) v = w1[(row - 192) * 192 + 128 + c];    // c: W1[:, 128:192]
+    else if (row < 448) v = wf[(row - 384) * 192 + 64 + c];     // d: Wf[:, 64:128]
+    else v = wf[(row - 448) * 192 + 128 + c];                   // e: Wf[:, 128:192]
+    pre_w[t] = v;
+    if (c == 0) pre_b[row] = row < 192 ? 0.f : row < 384 ? b1[row - 192] : row < 448 ? 0.f : bf[row - 448];
+}
+}  // namespace
+
+extern "C" int pf_et_pack_train(const float* w1, const float* b1, const float* w2, const float* wf, const float* bf, const int* stream_idx,
+                                void* stream_out, float lo_scale, float* pre_w, float* pre_b, pf_stream_t stream) {
+    if (!w1 || !b1 || !w2 || !wf || !bf || !stream_idx || !stream_out || !pre_w || !pre_b) return PF_E_BADARG;
+    hipLaunchKernelGGL(et_pack_stream_kernel, dim3(128 * 512 / 256), dim3(256), 0, (hipStream_t)stream, w1, w2, wf, stream_idx,
+                       reinterpret_cast<_Float16*>(stream_out), lo_scale);
+    hipLaunchKernelGGL(et_pack_pre_kernel, dim3(512 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w1, b1, wf, bf, pre_w, pre_b);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream) {
     if (!x || !out || M <= 0 || N <= 0) return PF_E_BADARG;
     const int chunks = M <= 512 ? 1 : (M + 255) / 256 > 1024 ? 1024 : (M + 255) / 256;
