@@ -1174,6 +1174,94 @@ def test_gemm_three_forms():
 
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 128), (2048, 384, 128), (2000, 128, 1536), (300, 6, 128), (2048, 20, 128)])
+def test_dual_gemm_equals_two_launches(M, N, K):
+    """pf_gemm_f32_dual (dx = dy W and dW += dy^T x + db of a row-sized Linear in ONE grid) against the same two products as two
+    pf_gemm_f32 launches: bit for bit (a workgroup's arithmetic does not depend on the launch that carries it), ragged sizes, with the
+    gate / residual epilogue of dx and the row sums of dW; and against float64."""
+    import ctypes as C
+    from pepflowww_amd import backward as Bk
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, dy = cu(torch.randn(M, K, generator=g)), cu(torch.randn(N, K, generator=g) / math.sqrt(K)), cu(torch.randn(M, N, generator=g))
+    gate, res = cu(torch.randn(M, K, generator=g)), cu(torch.randn(M, K, generator=g))
+    outs = []
+    for dual in (True, False):
+        dx = torch.full((M, K), float("nan"), device=G.dev())
+        dW, db = torch.zeros(N, K, device=G.dev()), torch.zeros(N, device=G.dev())
+        a1 = Bk._gemm_args(dy, N, 1, w, K, 1, dx, M, K, N, gate=gate, residual=res)
+        a2 = Bk._gemm_args(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=True, rowsum=db)
+        if dual:
+            _capi.check(lib.pf_gemm_f32_dual(C.byref(a1), C.byref(a2), _capi.stream_ptr()), "pf_gemm_f32_dual")
+        else:
+            _capi.check(lib.pf_gemm_f32(C.byref(a1), _capi.stream_ptr()), "pf_gemm_f32")
+            _capi.check(lib.pf_gemm_f32(C.byref(a2), _capi.stream_ptr()), "pf_gemm_f32")
+        G.sync()
+        outs.append((dx.cpu(), dW.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])                                       # dx: no atomics -> bit for bit
+    ref_dx = (dy.cpu().double() @ w.cpu().double()) * (gate.cpu() > 0) + res.cpu().double()
+    ref_dW, ref_db = dy.cpu().double().t() @ x.cpu().double(), dy.cpu().double().sum(0)
+    for o in outs:                                                                   # dW / db: split-K atomics, order-dependent in the last bits
+        assert (o[0].double() - ref_dx).abs().max() <= 2e-5 * ref_dx.abs().max()
+        assert (o[1].double() - ref_dW).abs().max() <= 2e-5 * ref_dW.abs().max()
+        assert (o[2].double() - ref_db).abs().max() <= 2e-5 * max(ref_db.abs().max(), 1.0)
+
+
+@pytest.mark.parametrize("npairs", [64 * 37, 64 * 20 + 13])
+def test_edge_transition_backward_chain(npairs):
+    """pf_et_bwd_chain (g_y -> g_u -> gate h2 -> W2^T -> gate h1 -> W1^T + g_u in one kernel) against float64, incl. a ragged last
+    tile; g_h2 / g_h1 are the gated gradients the weight-gradient products read."""
+    import ctypes as C
+    from pepflowww_amd import backward as Bk
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(npairs)
+    wf, w2, w1 = (torch.randn(64, 192, generator=g) / 14, torch.randn(192, 192, generator=g) / 14, torch.randn(192, 192, generator=g) / 14)
+    g_y, h1, h2 = torch.randn(npairs, 64, generator=g), torch.randn(npairs, 192, generator=g), torch.randn(npairs, 192, generator=g)
+    h1, h2 = torch.relu(h1), torch.relu(h2)                                        # saved activations: zeros where the ReLU was off
+    keep = [Bk._split_pack(cu(wf), transpose=True), Bk._split_pack(cu(w2), transpose=True), Bk._split_pack(cu(w1), transpose=True)]
+    dg_y, dh1, dh2 = cu(g_y), cu(h1), cu(h2)
+    o = [torch.full((npairs, 192), float("nan"), device=G.dev()) for _ in range(3)]
+    a = _capi.EtBwdArgs()
+    a.g_y, a.h1, a.h2 = dg_y.data_ptr(), dh1.data_ptr(), dh2.data_ptr()
+    a.wfT_f16, a.w2T_f16, a.w1T_f16 = (k.data_ptr() for k in keep)
+    a.g_h2, a.g_h1, a.g_x, a.npairs = o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), npairs
+    _capi.check(lib.pf_et_bwd_chain(C.byref(a), _capi.stream_ptr()), "pf_et_bwd_chain")
+    G.sync()
+    gu = g_y.double() @ wf.double()
+    r_h2 = gu * (h2 > 0)
+    r_h1 = (r_h2 @ w2.double()) * (h1 > 0)
+    r_x = r_h1 @ w1.double() + gu
+    for got, ref, name in zip(o, (r_h2, r_h1, r_x), ("g_h2", "g_h1", "g_x")):
+        assert torch.isfinite(got).all(), name
+        assert (got.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max(), name
+    with pytest.raises(Exception):
+        a.npairs = 0
+        _capi.check(lib.pf_et_bwd_chain(C.byref(a), _capi.stream_ptr()), "pf_et_bwd_chain")
+
+
+def test_et_pack_train_equals_host_packing():
+    """pf_et_pack_train (the training forward's per-step repacking of the EdgeTransition parameters) produces exactly the fragment
+    stream of engine.pack_et_stream and the per-residue weight / bias the inference engine packs on the host."""
+    from pepflowww_amd import backward as Bk
+    from pepflowww_amd.engine import pack_et_stream, ET_LO_SCALE
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(5)
+    w1, w2, wf = (torch.randn(192, 192, generator=g) / 14, torch.randn(192, 192, generator=g) / 14, torch.randn(64, 192, generator=g) / 14)
+    b1, bf = torch.randn(192, generator=g), torch.randn(64, generator=g)
+    d = [cu(t) for t in (w1, b1, w2, wf, bf)]
+    idx = Bk._et_stream_index(G.dev())
+    stream = torch.zeros(128, 2, 512, dtype=torch.float16, device=G.dev())
+    pre_w, pre_b = torch.full((512, 64), float("nan"), device=G.dev()), torch.full((512,), float("nan"), device=G.dev())
+    _capi.check(lib.pf_et_pack_train(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), idx.data_ptr(),
+                                     stream.data_ptr(), float(ET_LO_SCALE), pre_w.data_ptr(), pre_b.data_ptr(), _capi.stream_ptr()), "pf_et_pack_train")
+    G.sync()
+    host = pack_et_stream(cu(w1[:, :64].contiguous()), cu(w2), cu(wf))
+    assert torch.equal(stream.reshape(-1).cpu(), host.reshape(-1).cpu())
+    ref_w = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0)
+    ref_b = torch.cat([torch.zeros(192), b1, torch.zeros(64), bf], 0)
+    assert torch.equal(pre_w.cpu(), ref_w) and torch.equal(pre_b.cpu(), ref_b)
+
+
 @pytest.mark.parametrize("N,K", [(192, 192), (218, 64), (64, 128), (3744, 128)])
 def test_split_pack_kernel_equals_host_packing(N, K):
     """pf_split_pack_f16 (device-side fragment packing used per step by the training path) produces exactly the planes of
