@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 44
+#define PF_ABI_VERSION 45
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -100,6 +100,11 @@ int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
  * pf_linear_args.w_f16 expects ([2][ceil16(N)/16][K/32][64][8] f16, N zero-padded to 16): the device-side form of
  * engine.split_f16, used per step by the training path (weights change every step).  Layout only. */
 int pf_split_pack_f16(const float* w, int ldw, int N, int K, int transpose, void* out, pf_stream_t stream);
+/* the same for many matrices in ONE launch: desc (DEVICE memory, ndesc entries, ascending `first`) describes each matrix as above
+ * (N rows of the packed matrix, K % 32 == 0) and the index of its first work item (= 8 consecutive k of one output row:
+ * Npad * K / 8 items per matrix); total_items = the sum.  Same planes as pf_split_pack_f16, optional range flag as in *_checked. */
+typedef struct { const float* w; int ldw, N, K, transpose; void* out; int first; int pad_; } pf_pack_desc;
+int pf_split_pack_f16_batch(const pf_pack_desc* desc_dev, int ndesc, int total_items, int* range_flag, pf_stream_t stream);
 /* the same, and *range_flag (device int, zeroed by the caller) is set to 1 if any |w| exceeds the f16 range (65504) or is not
  * finite: the split representation cannot carry such a weight (the packed value saturates); callers treat it as an error */
 int pf_split_pack_f16_checked(const float* w, int ldw, int N, int K, int transpose, void* out, int* range_flag, pf_stream_t stream);
@@ -263,6 +268,12 @@ typedef struct {
     /* optional: query-row tiles that start at or beyond key_end[b] of their sample are skipped -- nothing of theirs is written
      * (s_out, frames, pre, qkv_out, v_out, logits_out, ang_out keep what they held; see pf_linear_args.key_end) */
     const int* key_end;
+    /* optional (training forward; fp32-parity mode, <= 256 row tiles of 16): dump[k] != NULL for k < 5 (last == 0) / k < 10
+     * (last == 1) -> the intermediates the backward needs are also stored, fp32 [B*L,128] each:
+     *   0 att (attention output before out_proj)   1 h = out_proj(att) + x   2 x1 = LN1(h)   3 f = relu(linear1(x1))
+     *   4 h2 = linear2(f) + x1      (the layer output LN2(h2) is v_out for last == 0, dump 5 for last == 1)
+     *   5 tf = LN2(h2)   6 s2 = s_ipa + post_tfmr(tf)   7 t1   8 t2 (StructureModuleTransition hidden)   9 h3 = linear_3(t2) + s2 */
+    float* dump[10];
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -160,7 +160,7 @@ class NodeTfmrArgs(C.Structure):
                 ("b_bb", _fp), ("s_out", _fp), ("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp),
                 ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("has_et", _i),
                 ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i),
-                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp)]
+                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp), ("dump", _fp * 10)]
 
 
 class EtBwdArgs(C.Structure):
@@ -225,6 +225,7 @@ _SIGNATURES = {
     "pf_ipa_bwd_points": ([C.POINTER(IpaBwdArgs), _fp], _i),
     "pf_ipa_headw_bwd": ([_fp, _fp, _fp, _fp], _i),
     "pf_split_pack_f16_checked": ([_fp, _i, _i, _i, _i, _fp, _fp, _fp], _i),
+    "pf_split_pack_f16_batch": ([_fp, _i, _i, _fp, _fp], _i),
     "pf_full_atom_fwd": ([C.POINTER(FullAtomArgs), _fp], _i),
     "pf_backbone_atoms_fwd": ([C.POINTER(BackboneAtomsArgs), _fp], _i),
     "pf_so3_geodesic": ([_fp, _fp, _fp, _fp, _i, _fp], _i),

@@ -151,6 +151,41 @@ def _split_pack(w, transpose=False):
     return out
 
 
+_PACK_BATCH = {}
+
+
+def split_pack_batch(mats):
+    """Fragment-order f16 hi / lo planes of MANY fp32 matrices in one launch (pf_split_pack_f16_batch) -> list of plane tensors.
+    mats: [N, K] tensors, or (tensor [K, N], True) for the planes of the TRANSPOSE.  The descriptor table and the output buffer are
+    built once per set of matrices (keyed by their addresses: the optimizer updates parameters in place) and re-used by every later
+    step -- also by a graph-captured step (no host-to-device copy after the first)."""
+    import numpy as np
+    mats = [(m, False) if torch.is_tensor(m) else (m[0], bool(m[1])) for m in mats]
+    key = tuple((m.data_ptr(), tuple(m.shape), tr) for m, tr in mats)
+    ent = _PACK_BATCH.get(key)
+    if ent is None:
+        dev = mats[0][0].device
+        dims = [((m.shape[1], m.shape[0]) if tr else (m.shape[0], m.shape[1])) for m, tr in mats]        # (N, K) of the packed matrix
+        sizes = [2 * ((N + 15) // 16 * 16) * K for N, K in dims]
+        out = torch.empty(sum(sizes), dtype=torch.float16, device=dev)
+        desc = np.zeros((len(mats), 5), dtype=np.int64)          # pf_pack_desc: {w, (ldw, N), (K, transpose), out, (first, pad)}
+        first, off, views = 0, 0, []
+        for i, ((m, tr), (N, K), sz) in enumerate(zip(mats, dims, sizes)):
+            assert m.is_contiguous() and m.dtype == torch.float32 and K % 32 == 0
+            desc[i] = [m.data_ptr(), m.shape[1] | (N << 32), K | (int(tr) << 32), out.data_ptr() + 2 * off, first]
+            views.append(out[off:off + sz])
+            first += ((N + 15) // 16 * 16) * (K // 8)
+            off += sz
+        ent = (torch.from_numpy(desc).to(dev), first, out, views)
+        if len(_PACK_BATCH) > 8:
+            _PACK_BATCH.clear()
+        _PACK_BATCH[key] = ent
+    desc_dev, total, out, views = ent
+    _capi.check(_capi.load().pf_split_pack_f16_batch(desc_dev.data_ptr(), len(mats), total, _range_flag(mats[0][0].device).data_ptr(),
+                                                     _capi.stream_ptr()), "pf_split_pack_f16_batch")
+    return views
+
+
 def _linear_split(x, w, b=None, relu=False, gate=None, residual=None, w_transposed=False, out=None):
     """y = relu?(x W^T + b) on the split-precision f16 MFMA kernel (csrc/linear.hip, fp32-level accuracy): ~2.3x the rate
     of the fp32-MFMA GEMM on the [B*L*L, 192] products of EdgeTransition.  w: [N, K] fp32, K % 32 == 0, K <= 512."""
@@ -358,8 +393,99 @@ class NodeTrackBlock:
     def p(self, name):
         return self.W[name]
 
+    # forward of the two transformer layers + block tail on the fused inference kernels (pf_node_tfmr_fwd with dumps) instead of
+    # ~25 launches of Linear / LayerNorm / attention / mask (PF_NODE_FUSED_FWD=0: unfused)
+    FUSED_FORWARD = os.environ.get("PF_NODE_FUSED_FWD", "1") != "0"
+    _SCRATCH = {}
+
+    def fused_weight_names(self):
+        """the split-precision operands of _forward_fused, in the reference's parameter names (relative to trunk.)"""
+        b = self.b
+        names = []
+        for l in range(2):
+            q = f"seq_tfmr_{b}.layers.{l}."
+            names += [q + "self_attn.out_proj.weight", q + "linear1.weight", q + "linear2.weight"]
+        t = f"node_transition_{b}."
+        names += [f"seq_tfmr_{b}.layers.1.self_attn.in_proj_weight", f"post_tfmr_{b}.weight", t + "linear_1.weight", t + "linear_2.weight",
+                  t + "linear_3.weight", f"bb_update_{b}.linear.weight"]
+        return names
+
+    def uses_fused_forward(self):
+        return self.FUSED_FORWARD and self.B * ((self.L + 15) // 16) <= 256 and self.L <= 256
+
+    def _forward_fused(self, a0):
+        lib, b, B, L, m = _capi.load(), self.b, self.B, self.L, self.mask
+        rows, dev = B * L, a0.device
+        E = lambda *shape: torch.empty(*shape, device=dev)
+        x = layernorm_fwd(a0, self.p(f"ipa_ln_{b}.weight"), self.p(f"ipa_ln_{b}.bias"))
+        sv = {"a0": a0, "s1": x}
+        q0 = f"seq_tfmr_{b}.layers.0."
+        qkv = linear_fwd(x, self.p(q0 + "self_attn.in_proj_weight"), self.p(q0 + "self_attn.in_proj_bias"))
+        key = (rows, str(dev))
+        if key not in NodeTrackBlock._SCRATCH:           # frames the tail kernel updates on the side (the trainer does its own update)
+            quat = torch.zeros(rows, 4, device=dev)
+            quat[:, 0] = 1.0
+            NodeTrackBlock._SCRATCH[key] = (quat, torch.eye(3, device=dev).reshape(1, 9).repeat(rows, 1).contiguous(), torch.zeros(rows, 3, device=dev),
+                                            E(rows, 4), E(rows, 9), E(rows, 3))
+        fq, fR, fx, oq, oR, ox = NodeTrackBlock._SCRATCH[key]
+        keep = []
+
+        packed = getattr(self, "packed", None)                  # {name: planes}, set by TrunkTrainer (one pack launch per step)
+
+        def sp(name):
+            if packed is not None:
+                return packed[name].data_ptr()
+            keep.append(_split_pack(self.p(name)))
+            return keep[-1].data_ptr()
+        s3 = None
+        for l in range(2):
+            q = f"seq_tfmr_{b}.layers.{l}."
+            ta = _capi.NodeTfmrArgs()
+            ta.qkv, ta.resid, ta.mask = qkv.data_ptr(), x.data_ptr(), m.data_ptr()
+            ta.w_o_f16, ta.b_o = sp(q + "self_attn.out_proj.weight"), self.p(q + "self_attn.out_proj.bias").data_ptr()
+            ta.n1_g, ta.n1_b = self.p(q + "norm1.weight").data_ptr(), self.p(q + "norm1.bias").data_ptr()
+            ta.w_1_f16, ta.b_1 = sp(q + "linear1.weight"), self.p(q + "linear1.bias").data_ptr()
+            ta.w_2_f16, ta.b_2 = sp(q + "linear2.weight"), self.p(q + "linear2.bias").data_ptr()
+            ta.n2_g, ta.n2_b = self.p(q + "norm2.weight").data_ptr(), self.p(q + "norm2.bias").data_ptr()
+            ta.B, ta.L, ta.single_pass = B, L, 0
+            dumps = [E(rows, 128) for _ in range(5 if l == 0 else 10)]
+            for k, d in enumerate(dumps):
+                ta.dump[k] = d.data_ptr()
+            sv[l] = dict(x=x, qkv=qkv, att=dumps[0], h=dumps[1], x1=dumps[2], f=dumps[3], h2=dumps[4])
+            if l == 0:
+                q1 = f"seq_tfmr_{b}.layers.1."
+                ta.last = 0
+                ta.w_in_next_f16, ta.b_in_next = sp(q1 + "self_attn.in_proj_weight"), self.p(q1 + "self_attn.in_proj_bias").data_ptr()
+                qkv1, y0 = E(rows, 384), E(rows, 128)
+                ta.qkv_out, ta.v_out = qkv1.data_ptr(), y0.data_ptr()
+            else:
+                t = f"node_transition_{b}."
+                ta.last = 1
+                s3 = E(rows, 128)
+                ta.s_ipa, ta.s_out = sv["s1"].data_ptr(), s3.data_ptr()
+                ta.w_post_f16, ta.b_post = sp(f"post_tfmr_{b}.weight"), self.p(f"post_tfmr_{b}.bias").data_ptr()
+                ta.w_t1_f16, ta.b_t1 = sp(t + "linear_1.weight"), self.p(t + "linear_1.bias").data_ptr()
+                ta.w_t2_f16, ta.b_t2 = sp(t + "linear_2.weight"), self.p(t + "linear_2.bias").data_ptr()
+                ta.w_t3_f16, ta.b_t3 = sp(t + "linear_3.weight"), self.p(t + "linear_3.bias").data_ptr()
+                ta.nt_g, ta.nt_b = self.p(t + "ln.weight").data_ptr(), self.p(t + "ln.bias").data_ptr()
+                bb8 = torch.nn.functional.pad(self.p(f"bb_update_{b}.linear.bias"), (0, 2)).contiguous()
+                keep.append(bb8)
+                ta.w_bb_f16, ta.b_bb = sp(f"bb_update_{b}.linear.weight"), bb8.data_ptr()
+                ta.quat_in, ta.rot_in, ta.trans_in = fq.data_ptr(), fR.data_ptr(), fx.data_ptr()
+                ta.quat_out, ta.rot_out, ta.trans_out = oq.data_ptr(), oR.data_ptr(), ox.data_ptr()
+                ta.has_et = 0
+            _capi.check(lib.pf_node_tfmr_fwd(C.byref(ta), _capi.stream_ptr()), "pf_node_tfmr_fwd")
+            if l == 0:
+                x, qkv = y0, qkv1
+            else:
+                sv.update(tf=dumps[5], s2=dumps[6], t1=dumps[7], t2=dumps[8], h3=dumps[9])
+        self.saved = sv
+        return s3
+
     def forward(self, a0):
         b, B, L, m = self.b, self.B, self.L, self.mask
+        if self.uses_fused_forward():
+            return self._forward_fused(a0)
         sv = {"a0": a0}
         x = layernorm_fwd(a0, self.p(f"ipa_ln_{b}.weight"), self.p(f"ipa_ln_{b}.bias"))
         sv["s1"] = x
@@ -640,8 +766,12 @@ class EdgeTransitionBlock:
             npairs = B * L * L
             dev = g_out.device
             g_h2, g_h1, g_x = (torch.empty(npairs, 192, device=dev) for _ in range(3))
-            keep = [_split_pack(W[p + "final_layer.weight"], transpose=True), _split_pack(W[p + "trunk.2.weight"], transpose=True),
-                    _split_pack(W[p + "trunk.0.weight"], transpose=True)]
+            packed = getattr(self, "packed", None)                  # (TrunkTrainer: one pack launch per step)
+            if packed is not None and (p + "final_layer.weight^T") in packed:
+                keep = [packed[p + "final_layer.weight^T"], packed[p + "trunk.2.weight^T"], packed[p + "trunk.0.weight^T"]]
+            else:
+                keep = [_split_pack(W[p + "final_layer.weight"], transpose=True), _split_pack(W[p + "trunk.2.weight"], transpose=True),
+                        _split_pack(W[p + "trunk.0.weight"], transpose=True)]
             ea = _capi.EtBwdArgs()
             ea.g_y, ea.h1, ea.h2 = g_y.data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr()
             ea.wfT_f16, ea.w2T_f16, ea.w1T_f16 = (k.data_ptr() for k in keep)
@@ -692,6 +822,20 @@ class TrunkTrainer:
 
     def forward(self, t, rot_t, trans_t, ang_t, seq_t, node_embed, edge_embed):
         lib, B, L, sd, st = _capi.load(), self.B, self.L, self.sd, _capi.stream_ptr()
+        # every split-precision operand the step repacks from the (changed) parameters in ONE launch: the fused node-track forward's
+        # weights and the transposed EdgeTransition matrices of the backward chain kernel
+        names, mats = [], []
+        if self.node[0].uses_fused_forward():
+            names = [n for blk in self.node for n in blk.fused_weight_names()]
+            mats = [self.W[n] for n in names]
+        et_names = [f"edge_transition_{blk.b}.{w}" for blk in self.et for w in ("final_layer.weight", "trunk.2.weight", "trunk.0.weight")]
+        if self.et and self.et[0].FUSED_BACKWARD:
+            names += [n + "^T" for n in et_names]
+            mats += [(self.W[n], True) for n in et_names]
+        if mats:
+            packed = dict(zip(names, split_pack_batch(mats)))
+            for blk in self.node + self.et:
+                blk.packed = packed
         rows, dev = B * L, self.mask.device
         f32 = lambda x, *shape: x.to(torch.float32).reshape(*shape).contiguous()
         feat = _zeros(rows, 640, device=dev)

@@ -671,6 +671,49 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* w, int ldw
 
 }  // namespace
 
+namespace {
+// many matrices in one launch (the training step repacks every split-precision weight after every optimizer step: ~90 launches of
+// 6 us each as separate calls).  desc[i] = {w, ldw, N, K, transpose, out, first} in device memory, `first` = index of the matrix's
+// first work item (8 consecutive k of one output row) in the launch-wide numbering; work item -> matrix by a scan of the table.
+__global__ __launch_bounds__(256) void split_pack_batch_kernel(const pf_pack_desc* __restrict__ desc, int ndesc, int total, int* range_flag) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int i = 0;
+    while (i + 1 < ndesc && desc[i + 1].first <= idx) ++i;
+    const pf_pack_desc d = desc[i];
+    const int it = idx - d.first;
+    const int per_row = d.K / 8, Npad = (d.N + 15) / 16 * 16;
+    const int n = it / per_row, k8 = it - n * per_row;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * k8 + e;
+        v[e] = n < d.N ? (d.transpose ? d.w[(size_t)k * d.ldw + n] : d.w[(size_t)n * d.ldw + k]) : 0.f;
+        if (range_flag && !(fabsf(v[e]) <= PF_F16_MAX)) *range_flag = 1;
+    }
+    half4 h0, l0, h1, l1;
+    const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    const int t = n >> 4, r = n & 15, sidx = k8 >> 2, g = k8 & 3;
+    const size_t o = ((((size_t)t * (d.K / 32) + sidx) * 4 + g) * 16 + r) * 8;
+    const size_t plane = (size_t)Npad * d.K;
+    _Float16* out = reinterpret_cast<_Float16*>(d.out);
+    *reinterpret_cast<half4*>(out + o) = h0;
+    *reinterpret_cast<half4*>(out + o + 4) = h1;
+    *reinterpret_cast<half4*>(out + plane + o) = l0;
+    *reinterpret_cast<half4*>(out + plane + o + 4) = l1;
+}
+}  // namespace
+
+extern "C" int pf_split_pack_f16_batch(const pf_pack_desc* desc_dev, int ndesc, int total_items, int* range_flag, pf_stream_t stream) {
+    if (!desc_dev || ndesc <= 0 || total_items <= 0) return PF_E_BADARG;
+    hipLaunchKernelGGL(split_pack_batch_kernel, dim3((unsigned)((total_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, desc_dev, ndesc,
+                       total_items, range_flag);
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pf_split_pack_f16_checked(const float* w, int ldw, int N, int K, int transpose, void* out, int* range_flag, pf_stream_t stream) {
     if (!w || !out || N <= 0 || K <= 0 || K % 32) return PF_E_BADARG;
     const int Npad = (N + 15) / 16 * 16;

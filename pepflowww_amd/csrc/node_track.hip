@@ -333,7 +333,9 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_h
 // RT: 16-row tiles per workgroup.  RT = 2 when the 16-row form would need more than one round of workgroups (B * ceil(L / 16) >
 // 256 CUs; these kernels are one workgroup per CU): every weight fragment and every K / V operand then feeds two row tiles, and
 // the chain of ~13 dependent stages is walked once per 32 rows instead of twice in a row.
-template <bool LAST, bool SP, int RT>
+// DUMP (training forward, pf_node_tfmr_args.dump): every intermediate the backward needs is also stored, fp32 [rows,128], where it
+// exists in registers anyway -- compile time, so that the inference variants keep their exact instruction streams.
+template <bool LAST, bool SP, int RT, bool DUMP = false>
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfmr_args a, int LP, int LDS_S) {
     constexpr int TR = 16 * RT;             // rows per workgroup (shadows the file-level 16)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -361,6 +363,9 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     int mr[RT];                              // ... of these activation rows (row tile rt, tile row r)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) mr[rt] = m0 + 16 * rt + r;
+    auto dump4 = [&](float* p, int rt, float x, float y, float z, float w) {       // (row mr[rt], columns n .. n + 3)
+        if constexpr (DUMP) { if (mr[rt] < M) *reinterpret_cast<float4*>(p + (size_t)mr[rt] * 128 + n) = make_float4(x, y, z, w); }
+    };
 
     PROF(0);
     // ---- everything small is requested NOW ----
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                 const _Float16 hi = (_Float16)acc[rt][e];
                 Xa.h[(16 * rt + 4 * g + e) * LDP + col] = hi;
                 Xa.l[(16 * rt + 4 * g + e) * LDP + col] = (_Float16)((acc[rt][e] - (float)hi) * PF_LO_SCALE);
+                if constexpr (DUMP) { if (m0 + 16 * rt + 4 * g + e < M) a.dump[0][(size_t)(m0 + 16 * rt + 4 * g + e) * 128 + col] = acc[rt][e]; }   // att
             }
     }
     if (LAST && RT == 2) load_tail_consts();
@@ -596,9 +602,10 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         float v[4];
         joined(rt, bias_o, v);
         *reinterpret_cast<float4*>(T1 + (16 * rt + r) * LDX + n) = make_float4(v[0] + rres.x, v[1] + rres.y, v[2] + rres.z, v[3] + rres.w);
+        dump4(a.dump[1], rt, v[0] + rres.x, v[1] + rres.y, v[2] + rres.z, v[3] + rres.w);                       // h = out_proj(att) + x
     }
     __syncthreads();
-    ln_tile<TR>(T1, ln1, 1.f, Xb, m0, M, nullptr);
+    ln_tile<TR>(T1, ln1, 1.f, Xb, m0, M, DUMP ? a.dump[2] : nullptr);                                            // x1 = LN1(h)
     __syncthreads();
     PROF(5);
     // ---- linear1 + ReLU -> planes Xa ----
@@ -612,6 +619,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
         joined(rt, bias_1, v);
         relu4(v);
         put_planes(Xa, 16 * rt + r, n, v);
+        dump4(a.dump[3], rt, v[0], v[1], v[2], v[3]);                                                            // f = relu(linear1(x1))
     }
     __syncthreads();
     PROF(6);
@@ -626,6 +634,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             float v[4];
             joined(rt, bias_2, v);
             *reinterpret_cast<float4*>(T0 + (16 * rt + r) * LDX + n) = make_float4(v[0] + u.x, v[1] + u.y, v[2] + u.z, v[3] + u.w);
+            dump4(a.dump[4], rt, v[0] + u.x, v[1] + u.y, v[2] + u.z, v[3] + u.w);                                // h2 = linear2(f) + x1
         }
     };
     if constexpr (!LAST) {
@@ -671,7 +680,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             fmask = a.mask[m];
         }
         __syncthreads();
-        ln_tile<TR>(T0, ln2, 1.f, Xb, m0, M, nullptr);
+        ln_tile<TR>(T0, ln2, 1.f, Xb, m0, M, DUMP ? a.dump[5] : nullptr);                                        // tf = LN2(h2)
         __syncthreads();
         PROF(7);
         // ---- s = s_ipa + post_tfmr(v) -> T1 (fp32) + planes Xa                 (ga.py:107) ----
@@ -687,6 +696,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             v[0] += rsipa.x; v[1] += rsipa.y; v[2] += rsipa.z; v[3] += rsipa.w;
             *reinterpret_cast<float4*>(T1 + (16 * rt + r) * LDX + n) = make_float4(v[0], v[1], v[2], v[3]);
             put_planes(Xa, 16 * rt + r, n, v);
+            dump4(a.dump[6], rt, v[0], v[1], v[2], v[3]);                                                        // s2 = s_ipa + post_tfmr(tf)
         }
         __syncthreads();
         PROF(8);
@@ -701,6 +711,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             joined(rt, bias_t1, v);
             relu4(v);
             put_planes(Xb, 16 * rt + r, n, v);
+            dump4(a.dump[7], rt, v[0], v[1], v[2], v[3]);                                                        // t1
         }
         __syncthreads();
         zero();
@@ -713,6 +724,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             joined(rt, bias_t2, v);
             relu4(v);
             put_planes(Xa, 16 * rt + r, n, v);
+            dump4(a.dump[8], rt, v[0], v[1], v[2], v[3]);                                                        // t2
         }
         __syncthreads();
         zero();
@@ -729,6 +741,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
             float v[4];
             joined(rt, bias_t3, v);
             *reinterpret_cast<float4*>(T0 + (16 * rt + r) * LDX + n) = make_float4(v[0] + s0.x, v[1] + s0.y, v[2] + s0.z, v[3] + s0.w);
+            dump4(a.dump[9], rt, v[0] + s0.x, v[1] + s0.y, v[2] + s0.z, v[3] + s0.w);                            // h3 = linear_3(t2) + s2
         }
         __syncthreads();
         ln_tile<TR>(T0, ln3, lnmask_ld * (lnrow < M ? 1.f : 0.f), Xb, m0, M, a.s_out);           // s_new (masked) -> global + planes Xb
@@ -1027,6 +1040,21 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
         }                                                                                                                        \
         hipLaunchKernelGGL((node_tfmr_kernel<LASTV, SPV, RTV>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);      \
         break;
+    if (a->dump[0]) {                                  // training forward: the dump variants exist for the fp32-parity mode, 16-row tiles
+        for (int k = 0; k < (a->last ? 10 : 5); ++k)
+            if (!a->dump[k]) return PF_E_BADARG;
+        if (a->single_pass || RTn != 1) return PF_E_BADARG;
+        static bool dattr[2] = {};
+        if (a->last) {
+            if (!dattr[1]) { (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dattr[1] = true; }
+            hipLaunchKernelGGL((node_tfmr_kernel<true, false, 1, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+        } else {
+            if (!dattr[0]) { (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dattr[0] = true; }
+            hipLaunchKernelGGL((node_tfmr_kernel<false, false, 1, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
+        }
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     switch (variant) {
         PF_NT_CASE(0, false, false, 1) PF_NT_CASE(1, false, true, 1) PF_NT_CASE(2, true, false, 1) PF_NT_CASE(3, true, true, 1)
         PF_NT_CASE(4, false, false, 2) PF_NT_CASE(5, false, true, 2) PF_NT_CASE(6, true, false, 2) PF_NT_CASE(7, true, true, 2)

@@ -1262,6 +1262,50 @@ def test_et_pack_train_equals_host_packing():
     assert torch.equal(pre_w.cpu(), ref_w) and torch.equal(pre_b.cpu(), ref_b)
 
 
+def test_split_pack_batch_equals_single_packs():
+    """pf_split_pack_f16_batch (every repacked weight of a training step in one launch) writes exactly the planes of one
+    pf_split_pack_f16 call per matrix, also for transposed inputs and rows padded to 16; a second call re-uses the cached table."""
+    from pepflowww_amd import backward as Bk
+    g = torch.Generator().manual_seed(9)
+    shapes = [(128, 128), (384, 128), (6, 128), (192, 192), (64, 192), (128, 1536)]
+    mats = [cu(torch.randn(n, k, generator=g) * 0.1) for n, k in shapes]
+    items = [mats[0], mats[1], mats[2], (mats[3], True), (mats[4], True), mats[5]]
+    for _ in range(2):
+        planes = Bk.split_pack_batch(items)
+        G.sync()
+        for it, pl in zip(items, planes):
+            m, tr = (it, False) if torch.is_tensor(it) else it
+            assert torch.equal(pl.cpu(), Bk._split_pack(m, transpose=tr).cpu())
+        mats[0].mul_(1.5)                                                        # parameters change in place between steps
+
+
+def test_node_track_training_forward_fused_equals_unfused(seeded_sd, monkeypatch):
+    """NodeTrackBlock.forward on the fused inference kernels with dumps (pf_node_tfmr_args.dump) against the launch-per-op form:
+    the block output and every saved activation the backward reads (att, h, x1, f, h2 per layer; tf, s2, t1, t2, h3)."""
+    from pepflowww_amd import backward as Bk
+    B, L = 3, 48
+    g = torch.Generator().manual_seed(31)
+    mask = torch.ones(B, L)
+    mask[1, 40:] = 0
+    mask[2, 7] = 0
+    W = {k[len("ga_encoder.trunk."):]: cu(v) for k, v in seeded_sd.items() if k.startswith("ga_encoder.trunk.")}
+    a0 = cu(torch.randn(B * L, 128, generator=g))
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(Bk.NodeTrackBlock, "FUSED_FORWARD", fused)
+        blk = Bk.NodeTrackBlock(W, 2, B, L, cu(mask.reshape(-1)))
+        s3 = blk.forward(a0.clone())
+        G.sync()
+        outs.append((s3.cpu(), {k: (v.cpu() if torch.is_tensor(v) else {kk: vv.cpu() for kk, vv in v.items()}) for k, v in blk.saved.items()}))
+    valid = mask.reshape(-1).bool()
+    G.assert_close(outs[0][0][valid], outs[1][0][valid], 2e-5, "s3")
+    for k in ("tf", "s2", "t1", "t2", "h3"):
+        G.assert_close(outs[0][1][k][valid], outs[1][1][k][valid], 2e-5, k)
+    for l in range(2):
+        for k in ("x", "qkv", "att", "h", "x1", "f", "h2"):
+            G.assert_close(outs[0][1][l][k][valid], outs[1][1][l][k][valid], 2e-5, f"layer {l} {k}")
+
+
 @pytest.mark.parametrize("N,K", [(192, 192), (218, 64), (64, 128), (3744, 128)])
 def test_split_pack_kernel_equals_host_packing(N, K):
     """pf_split_pack_f16 (device-side fragment packing used per step by the training path) produces exactly the planes of
