@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 45
+#define PF_ABI_VERSION 46
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -227,6 +227,8 @@ typedef struct {
     int single_pass;               /* 1 = f16 precision mode: one f16 MFMA per product (hi weight planes only) */
     /* optional: rows = [B][key_L]; row tiles entirely at or beyond their samples' key_end[b] are skipped (see pf_linear_args) */
     const int* key_end; int key_L;
+    /* optional (training forward, fp32-parity mode): a0 = s_in + mask * linear_out(feats), the LayerNorm's input, [rows,128] */
+    float* dump_a0;
 } pf_node_head_args;
 int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream);
 
@@ -268,12 +270,13 @@ typedef struct {
     /* optional: query-row tiles that start at or beyond key_end[b] of their sample are skipped -- nothing of theirs is written
      * (s_out, frames, pre, qkv_out, v_out, logits_out, ang_out keep what they held; see pf_linear_args.key_end) */
     const int* key_end;
-    /* optional (training forward; fp32-parity mode, <= 256 row tiles of 16): dump[k] != NULL for k < 5 (last == 0) / k < 10
+    /* optional (training forward; fp32-parity mode, <= 256 row tiles of 16): dump[k] != NULL for k < 5 (last == 0) / k < 11
      * (last == 1) -> the intermediates the backward needs are also stored, fp32 [B*L,128] each:
      *   0 att (attention output before out_proj)   1 h = out_proj(att) + x   2 x1 = LN1(h)   3 f = relu(linear1(x1))
      *   4 h2 = linear2(f) + x1      (the layer output LN2(h2) is v_out for last == 0, dump 5 for last == 1)
-     *   5 tf = LN2(h2)   6 s2 = s_ipa + post_tfmr(tf)   7 t1   8 t2 (StructureModuleTransition hidden)   9 h3 = linear_3(t2) + s2 */
-    float* dump[10];
+     *   5 tf = LN2(h2)   6 s2 = s_ipa + post_tfmr(tf)   7 t1   8 t2 (StructureModuleTransition hidden)   9 h3 = linear_3(t2) + s2
+     *   10 the backbone update [B*L,8] (6 used: BackboneUpdate output, input of compose_q_update_vec) */
+    float* dump[11];
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 45
+ABI_VERSION = 46
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -147,7 +147,7 @@ class EdgeFeatArgs(C.Structure):
 
 class NodeHeadArgs(C.Structure):
     _fields_ = [("feats", _fp), ("s_in", _fp), ("mask", _fp), ("w_out_f16", _fp), ("b_out", _fp), ("ln_g", _fp),
-                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i), ("single_pass", _i), ("key_end", _fp), ("key_L", _i)]
+                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i), ("single_pass", _i), ("key_end", _fp), ("key_L", _i), ("dump_a0", _fp)]
 
 
 class NodeTfmrArgs(C.Structure):
@@ -160,7 +160,7 @@ class NodeTfmrArgs(C.Structure):
                 ("b_bb", _fp), ("s_out", _fp), ("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp),
                 ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("has_et", _i),
                 ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i),
-                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp), ("dump", _fp * 10)]
+                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp), ("dump", _fp * 11)]
 
 
 class EtBwdArgs(C.Structure):

@@ -407,20 +407,42 @@ class NodeTrackBlock:
             names += [q + "self_attn.out_proj.weight", q + "linear1.weight", q + "linear2.weight"]
         t = f"node_transition_{b}."
         names += [f"seq_tfmr_{b}.layers.1.self_attn.in_proj_weight", f"post_tfmr_{b}.weight", t + "linear_1.weight", t + "linear_2.weight",
-                  t + "linear_3.weight", f"bb_update_{b}.linear.weight"]
+                  t + "linear_3.weight", f"bb_update_{b}.linear.weight", f"ipa_{b}.linear_out.weight",
+                  f"seq_tfmr_{b}.layers.0.self_attn.in_proj_weight"]
         return names
 
     def uses_fused_forward(self):
         return self.FUSED_FORWARD and self.B * ((self.L + 15) // 16) <= 256 and self.L <= 256
 
-    def _forward_fused(self, a0):
+    def forward_from_feats(self, feats, s_in, frames):
+        """The whole node track of a block from the attention features: a0 = s_in + mask * linear_out(feats), LayerNorm, layer-0
+        in_proj by the fused head kernel (pf_node_head_fwd with dump_a0), then _forward_fused; frames = (quat, rot, trans) of the
+        block input -> (s3, (quat, rot, trans) after the backbone update, upd [rows,8])."""
+        lib, b, B, L, m = _capi.load(), self.b, self.B, self.L, self.mask
+        rows, dev = B * L, feats.device
+        a0, s1, qkv = torch.empty(rows, 128, device=dev), torch.empty(rows, 128, device=dev), torch.empty(rows, 384, device=dev)
+        q0 = f"seq_tfmr_{b}.layers.0."
+        packed = self.packed
+        ha = _capi.NodeHeadArgs()
+        ha.feats, ha.s_in, ha.mask = feats.data_ptr(), s_in.data_ptr(), m.data_ptr()
+        ha.w_out_f16, ha.b_out = packed[f"ipa_{b}.linear_out.weight"].data_ptr(), self.p(f"ipa_{b}.linear_out.bias").data_ptr()
+        ha.ln_g, ha.ln_b = self.p(f"ipa_ln_{b}.weight").data_ptr(), self.p(f"ipa_ln_{b}.bias").data_ptr()
+        ha.w_in_f16, ha.b_in = packed[q0 + "self_attn.in_proj_weight"].data_ptr(), self.p(q0 + "self_attn.in_proj_bias").data_ptr()
+        ha.s_ipa, ha.qkv, ha.rows, ha.single_pass, ha.dump_a0 = s1.data_ptr(), qkv.data_ptr(), rows, 0, a0.data_ptr()
+        _capi.check(lib.pf_node_head_fwd(C.byref(ha), _capi.stream_ptr()), "pf_node_head_fwd")
+        return self._forward_fused(a0, head=(s1, qkv), frames=frames)
+
+    def _forward_fused(self, a0, head=None, frames=None):
         lib, b, B, L, m = _capi.load(), self.b, self.B, self.L, self.mask
         rows, dev = B * L, a0.device
         E = lambda *shape: torch.empty(*shape, device=dev)
-        x = layernorm_fwd(a0, self.p(f"ipa_ln_{b}.weight"), self.p(f"ipa_ln_{b}.bias"))
+        if head is None:
+            x = layernorm_fwd(a0, self.p(f"ipa_ln_{b}.weight"), self.p(f"ipa_ln_{b}.bias"))
+            q0 = f"seq_tfmr_{b}.layers.0."
+            qkv = linear_fwd(x, self.p(q0 + "self_attn.in_proj_weight"), self.p(q0 + "self_attn.in_proj_bias"))
+        else:
+            x, qkv = head
         sv = {"a0": a0, "s1": x}
-        q0 = f"seq_tfmr_{b}.layers.0."
-        qkv = linear_fwd(x, self.p(q0 + "self_attn.in_proj_weight"), self.p(q0 + "self_attn.in_proj_bias"))
         key = (rows, str(dev))
         if key not in NodeTrackBlock._SCRATCH:           # frames the tail kernel updates on the side (the trainer does its own update)
             quat = torch.zeros(rows, 4, device=dev)
@@ -428,6 +450,9 @@ class NodeTrackBlock:
             NodeTrackBlock._SCRATCH[key] = (quat, torch.eye(3, device=dev).reshape(1, 9).repeat(rows, 1).contiguous(), torch.zeros(rows, 3, device=dev),
                                             E(rows, 4), E(rows, 9), E(rows, 3))
         fq, fR, fx, oq, oR, ox = NodeTrackBlock._SCRATCH[key]
+        if frames is not None:                                  # the real frames: the tail kernel's backbone update is the block's
+            fq, fR, fx = frames
+            oq, oR, ox = E(rows, 4), E(rows, 9), E(rows, 3)
         keep = []
 
         packed = getattr(self, "packed", None)                  # {name: planes}, set by TrunkTrainer (one pack launch per step)
@@ -449,6 +474,8 @@ class NodeTrackBlock:
             ta.n2_g, ta.n2_b = self.p(q + "norm2.weight").data_ptr(), self.p(q + "norm2.bias").data_ptr()
             ta.B, ta.L, ta.single_pass = B, L, 0
             dumps = [E(rows, 128) for _ in range(5 if l == 0 else 10)]
+            if l == 1:
+                dumps.append(E(rows, 8))                                 # backbone update (6 used)
             for k, d in enumerate(dumps):
                 ta.dump[k] = d.data_ptr()
             sv[l] = dict(x=x, qkv=qkv, att=dumps[0], h=dumps[1], x1=dumps[2], f=dumps[3], h2=dumps[4])
@@ -480,6 +507,8 @@ class NodeTrackBlock:
             else:
                 sv.update(tf=dumps[5], s2=dumps[6], t1=dumps[7], t2=dumps[8], h3=dumps[9])
         self.saved = sv
+        if frames is not None:
+            return s3, (oq, oR, ox), dumps[10]
         return s3
 
     def forward(self, a0):
@@ -554,8 +583,9 @@ class IpaBlock:
         self.w_proj = torch.cat([W[p + n + ".weight"] for n in self.names], 0).contiguous()      # [3744,128]
         self.b_proj = torch.cat([W[p + n + ".bias"] for n in self.names], 0).contiguous()
 
-    def forward(self, s, z, rot, trans):
-        """s [rows,128], z [B*L*L,64], rot [rows,9], trans [rows,3] -> ipa_embed (masked) [rows,128]."""
+    def forward(self, s, z, rot, trans, feats_only=False):
+        """s [rows,128], z [B*L*L,64], rot [rows,9], trans [rows,3] -> ipa_embed (masked) [rows,128]; feats_only: the attention
+        features [rows,1536] instead (linear_out + mask then run inside the fused node-track head, NodeTrackBlock.forward_from_feats)."""
         lib, B, L, W, p = _capi.load(), self.B, self.L, self.W, f"ipa_{self.b}."
         rows = B * L
         dev = s.device
@@ -581,9 +611,10 @@ class IpaBlock:
                                              pbias.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
             ia.bias = pbias.data_ptr()
         _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
-        out = row_mask_(linear_fwd(feats, W[p + "linear_out.weight"], W[p + "linear_out.bias"]), self.mask)
         self.saved = dict(s=s, z=z, rot=rot, trans=trans, proj=proj, qp=qp, kp=kp, vp=vp, feats=feats, P=P)
-        return out
+        if feats_only:
+            return feats
+        return row_mask_(linear_fwd(feats, W[p + "linear_out.weight"], W[p + "linear_out.bias"]), self.mask)
 
     def backward(self, g_out, g_z=None):
         """g_out: gradient w.r.t. the masked IPA output.  g_z: optional buffer to accumulate d/dz into.
@@ -862,15 +893,21 @@ class TrunkTrainer:
         quat = torch.empty(rows, 4, device=dev)
         _capi.check(lib.pf_rot_to_quat(R.data_ptr(), quat.data_ptr(), rows, st), "pf_rot_to_quat")
         for b in range(self.N_BLOCKS):
-            ipa_out = self.ipa[b].forward(s, z, R, x)
-            a0 = add_(ipa_out.clone(), s)
-            s3 = self.node[b].forward(a0)
-            upd = linear_fwd(s3, self.W[f"bb_update_{b}.linear.weight"], self.W[f"bb_update_{b}.linear.bias"])
-            nq, nR, nx = torch.empty(rows, 4, device=dev), torch.empty(rows, 9, device=dev), torch.empty(rows, 3, device=dev)
-            ra = _capi.RigidUpdateArgs()
-            ra.quat_in, ra.rot_in, ra.trans_in, ra.upd, ra.ldu, ra.mask = quat.data_ptr(), R.data_ptr(), x.data_ptr(), upd.data_ptr(), 6, self.mask.data_ptr()
-            ra.quat_out, ra.rot_out, ra.trans_out, ra.n = nq.data_ptr(), nR.data_ptr(), nx.data_ptr(), rows
-            _capi.check(lib.pf_rigid_update_fwd(C.byref(ra), st), "pf_rigid_update_fwd")
+            if self.node[b].uses_fused_forward() and getattr(self.node[b], "packed", None) is not None:
+                # linear_out + mask + residual + LayerNorm + in_proj, both transformer layers, transition, backbone update and the
+                # frame update: three launches of the fused inference kernels (with dumps)
+                feats = self.ipa[b].forward(s, z, R, x, feats_only=True)
+                s3, (nq, nR, nx), upd = self.node[b].forward_from_feats(feats, s, (quat, R, x))
+            else:
+                ipa_out = self.ipa[b].forward(s, z, R, x)
+                a0 = add_(ipa_out.clone(), s)
+                s3 = self.node[b].forward(a0)
+                upd = linear_fwd(s3, self.W[f"bb_update_{b}.linear.weight"], self.W[f"bb_update_{b}.linear.bias"])
+                nq, nR, nx = torch.empty(rows, 4, device=dev), torch.empty(rows, 9, device=dev), torch.empty(rows, 3, device=dev)
+                ra = _capi.RigidUpdateArgs()
+                ra.quat_in, ra.rot_in, ra.trans_in, ra.upd, ra.ldu, ra.mask = quat.data_ptr(), R.data_ptr(), x.data_ptr(), upd.data_ptr(), 6, self.mask.data_ptr()
+                ra.quat_out, ra.rot_out, ra.trans_out, ra.n = nq.data_ptr(), nR.data_ptr(), nx.data_ptr(), rows
+                _capi.check(lib.pf_rigid_update_fwd(C.byref(ra), st), "pf_rigid_update_fwd")
             self.saved["blocks"].append(dict(s3=s3, quat_in=quat, R_in=R, upd=upd))
             quat, R, x = nq, nR, nx
             s = s3

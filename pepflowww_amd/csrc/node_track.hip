@@ -115,7 +115,7 @@ __device__ __forceinline__ void put_planes(Planes p, int r, int n, const float (
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool SP>
+template <bool SP, bool DUMP = false>          // DUMP (training forward): a0 = s + mask * linear_out(feats), the LayerNorm's input, is also stored
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_head_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int CK = 256, LDC = CK + 8;      // feats chunk width (8 K-steps = the weight ring depth), f16 stride
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
         y.z = (join(am[0], ac[0], 2) + bias_out.z) * rmask + rres.z;
         y.w = (join(am[0], ac[0], 3) + bias_out.w) * rmask + rres.w;
         *reinterpret_cast<float4*>(X + r * LDX + n) = y;
+        if constexpr (DUMP) { if (mr < M) *reinterpret_cast<float4*>(a.dump_a0 + (size_t)mr * 128 + n) = y; }
     }
     __syncthreads();
     ln_tile(X, lnp, 1.f, Xa, m0, M, a.s_ipa);
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
                 if (do_bb) {
                     joined(rt, bias_bb, v);
                     if (g < 2) *reinterpret_cast<float4*>(U + (16 * rt + r) * 8 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (DUMP) { if (g < 2 && mr[rt] < M) *reinterpret_cast<float4*>(a.dump[10] + (size_t)mr[rt] * 8 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]); }   // backbone update [rows,8]
                 } else {
                     joined(rt, bias_init, v);
                     put_planes(Xa, 16 * rt + r, (wave - 4) * 16 + 4 * g, v);      // n64 -> planes Xa columns 0..63
@@ -991,6 +993,12 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
         PF_CHECK_LAUNCH();
         return 0;
     }
+    if (a->dump_a0) {                                  // training forward: fp32-parity mode, 16-row tiles
+        if (a->single_pass) return PF_E_BADARG;
+        hipLaunchKernelGGL((node_head_kernel<false, true>), dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     if (a->single_pass) hipLaunchKernelGGL(node_head_kernel<true>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(node_head_kernel<false>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
@@ -1041,7 +1049,7 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
         hipLaunchKernelGGL((node_tfmr_kernel<LASTV, SPV, RTV>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);      \
         break;
     if (a->dump[0]) {                                  // training forward: the dump variants exist for the fp32-parity mode, 16-row tiles
-        for (int k = 0; k < (a->last ? 10 : 5); ++k)
+        for (int k = 0; k < (a->last ? 11 : 5); ++k)
             if (!a->dump[k]) return PF_E_BADARG;
         if (a->single_pass || RTn != 1) return PF_E_BADARG;
         static bool dattr[2] = {};
