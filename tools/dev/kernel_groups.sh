@@ -23,7 +23,7 @@ for s, e, name in step:
     key = re.sub(r"^void ", "", key)[:70]
     tot[key] += e - s; cnt[key] += 1
 print(f"one step: {len(step)} kernels, busy {sum(tot.values())/1e6:.2f} ms, wall {wall:.2f} ms")
-for k, t in tot.most_common(60):
+for k, t in tot.most_common(int(__import__("os").environ.get("KG_TOP", "60"))):
     print(f"{t/1e3:9.0f} us  {cnt[k]:4d} x {t/cnt[k]/1e3:8.1f} us  {k}")
 PY
 rm -rf $OUT
