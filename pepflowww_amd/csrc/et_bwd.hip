@@ -167,7 +167,10 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
 extern "C" int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream) {
     if (!a || !a->g_y || !a->h1 || !a->h2 || !a->wfT_f16 || !a->w2T_f16 || !a->w1T_f16 || !a->g_h2 || !a->g_h1 || !a->g_x || a->npairs <= 0)
         return PF_E_BADARG;
-    constexpr int P = 64;
+#ifndef PF_ETB_P
+#define PF_ETB_P 64                           // pairs per workgroup (64 or 32)
+#endif
+    constexpr int P = PF_ETB_P;
     const long long nblk = (a->npairs + P - 1) / P;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
     const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16);
