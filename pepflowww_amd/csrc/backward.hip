@@ -1737,11 +1737,12 @@ extern "C" int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, 
     GemmPlan p1, p2;
     if (!gemm_plan(a1, p1) || !gemm_plan(a2, p2)) return PF_E_BADARG;
     const hipStream_t st = (hipStream_t)stream;
-    const bool dual_ok = p1.combo == 1 && p2.combo == 2 && p1.TM <= 64 && p2.TM <= 64 && p1.g.ksplit == 1;
+    const bool dual_ok = p1.combo == 1 && p2.combo == 2 && p1.TM <= 64 && p2.TM <= 64;      // (either product may be split-K: bz carries the K range)
     if (!dual_ok) {
         int rc = pf_gemm_f32(a1, stream);
         return rc ? rc : pf_gemm_f32(a2, stream);
     }
+    if (p1.zero_c) gemm_zero_c(a1, st);
     if (p2.zero_c) gemm_zero_c(a2, st);
     GemmDualDims d;
     d.gx1 = (int)p1.grid.x; d.gy1 = (int)p1.grid.y; d.n1 = (int)(p1.grid.x * p1.grid.y * p1.grid.z);

@@ -1174,7 +1174,7 @@ def test_gemm_three_forms():
 
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 128, 128), (2048, 384, 128), (2000, 128, 1536), (300, 6, 128), (2048, 20, 128)])
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 128), (2048, 384, 128), (2000, 128, 1536), (300, 6, 128), (2048, 20, 128), (2048, 3744, 128)])
 def test_dual_gemm_equals_two_launches(M, N, K):
     """pf_gemm_f32_dual (dx = dy W and dW += dy^T x + db of a row-sized Linear in ONE grid) against the same two products as two
     pf_gemm_f32 launches: bit for bit (a workgroup's arithmetic does not depend on the launch that carries it), ragged sizes, with the
@@ -1189,7 +1189,8 @@ def test_dual_gemm_equals_two_launches(M, N, K):
     for dual in (True, False):
         dx = torch.full((M, K), float("nan"), device=G.dev())
         dW, db = torch.zeros(N, K, device=G.dev()), torch.zeros(N, device=G.dev())
-        a1 = Bk._gemm_args(dy, N, 1, w, K, 1, dx, M, K, N, gate=gate, residual=res)
+        epi = dict(gate=gate, residual=res) if N < 512 else {}                      # (a long contraction runs split-K: no epilogue)
+        a1 = Bk._gemm_args(dy, N, 1, w, K, 1, dx, M, K, N, **epi)
         a2 = Bk._gemm_args(dy, 1, N, x, K, 1, dW, N, K, M, accumulate=True, rowsum=db)
         if dual:
             _capi.check(lib.pf_gemm_f32_dual(C.byref(a1), C.byref(a2), _capi.stream_ptr()), "pf_gemm_f32_dual")
@@ -1198,8 +1199,11 @@ def test_dual_gemm_equals_two_launches(M, N, K):
             _capi.check(lib.pf_gemm_f32(C.byref(a2), _capi.stream_ptr()), "pf_gemm_f32")
         G.sync()
         outs.append((dx.cpu(), dW.cpu(), db.cpu()))
-    assert torch.equal(outs[0][0], outs[1][0])                                       # dx: no atomics -> bit for bit
-    ref_dx = (dy.cpu().double() @ w.cpu().double()) * (gate.cpu() > 0) + res.cpu().double()
+    if N < 512:
+        assert torch.equal(outs[0][0], outs[1][0])                                   # dx: no atomics -> bit for bit (N >= 512: split-K)
+    ref_dx = dy.cpu().double() @ w.cpu().double()
+    if N < 512:
+        ref_dx = ref_dx * (gate.cpu() > 0) + res.cpu().double()
     ref_dW, ref_db = dy.cpu().double().t() @ x.cpu().double(), dy.cpu().double().sum(0)
     for o in outs:                                                                   # dW / db: split-K atomics, order-dependent in the last bits
         assert (o[0].double() - ref_dx).abs().max() <= 2e-5 * ref_dx.abs().max()
