@@ -547,6 +547,11 @@ int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream);
 int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, long long R,
                     int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems,
                     pf_stream_t stream);
+/* C[M,N] (+)= A^T (B + B2): the same contraction over all R rows with the B operand given as the SUM of two tensors (same ldb), added
+ * while a chunk is staged -- final_layer's weight gradient g_y^T (h2 + x) in one pass over g_y (M <= 64, N <= 192, R % 32 == 0). */
+int pf_gemm_tn_sum2(const float* A, int lda, int M, const float* B, const float* B2, int ldb, int N, float* C, int ldc, long long R,
+                    int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems,
+                    pf_stream_t stream);   /* colsum_a, workspace: optional, as in pf_gemm_tn_wide */
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
 int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);                                /* dy *= (y > 0) */
 int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream);            /* dst = y > 0 ? src : 0 */

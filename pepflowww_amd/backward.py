@@ -808,8 +808,17 @@ class EdgeTransitionBlock:
             ea.wfT_f16, ea.w2T_f16, ea.w1T_f16 = (k.data_ptr() for k in keep)
             ea.g_h2, ea.g_h1, ea.g_x, ea.npairs = g_h2.data_ptr(), g_h1.data_ptr(), g_x.data_ptr(), npairs
             _capi.check(lib.pf_et_bwd_chain(C.byref(ea), _capi.stream_ptr()), "pf_et_bwd_chain")
-            _, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y, need_dx=False)
-            G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
+            # final_layer(h2 + x): dW = g_y^T (h2 + x) in ONE pass over g_y (pf_gemm_tn_sum2 adds the two operands while it stages them)
+            dWf, wz = _grad_buffer(64, 192, device=dev)
+            dbf, bz = _grad_buffer(64, device=dev)
+            if npairs % 32 == 0:
+                ws = _tn_workspace(dev)
+                _capi.check(lib.pf_gemm_tn_sum2(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["x"].data_ptr(), 192, 192, dWf.data_ptr(), 192,
+                                                npairs, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_sum2")
+                G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
+            else:
+                _, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y, need_dx=False)
+                G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
             _, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, need_dx=False)
             _, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, need_dx=False)
         else:

@@ -408,9 +408,11 @@ __device__ __forceinline__ half8 lds_tr_op(unsigned addr) {
 template <int... I, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
-template <int NTW>
+// MTW = 16-row tiles of C per wave along M (3: M <= 192; 1: M <= 64 -- a third of the accumulators); HASB2: the B operand is the SUM of
+// two tensors (B + B2, same ldb), added while the chunk is staged: dW_f = g_y^T (h2 + x) in one pass over g_y instead of two products.
+template <int NTW, int MTW = 3, bool HASB2 = false>
 __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
-                                                            long long R, long long rows_per_wg, float* colsum_a, float* part) {
+                                                            long long R, long long rows_per_wg, float* colsum_a, float* part, const float* B2 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tn_sm[];
     constexpr int SA = 192 + 8, SB = 32 * NTW + 8;                 // plane row strides in f16 (rows of 32 K values per chunk)
     constexpr int BUF = 2 * WK * (SA + SB);                         // f16 elements of one buffer: [Ah | Al | Bh | Bl]
@@ -418,11 +420,11 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave & 3, wn = wave >> 2;
     const int MT = (M + 15) >> 4, NT = (N + 15) >> 4;
-    const int mt0 = wm * 3, nt0 = wn * NTW;
+    const int mt0 = wm * MTW, nt0 = wn * NTW;
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
-    f32x4 am[3][NTW], ac[3][NTW];
+    f32x4 am[MTW][NTW], ac[MTW][NTW];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) { am[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[i][j] = am[i][j]; }
     // staging map, fixed for the kernel: float4 q of this thread is element (rr, 4 c) of the A chunk (NLA of them) or of the
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
         gb[q] = ok ? rr * ldb + 4 * c : 0;
         lb[q] = ok ? 2 * WK * SA + rr * SB + 4 * c : -1;
     }
-    float4 sa[NLA], sb[NLB];
+    float4 sa[NLA], sb[NLB], sb2[HASB2 ? NLB : 1];
     float4 cs4[NLA];                                                 // column sums of A (the bias gradient) straight from the fp32 staging registers
 #pragma unroll
     for (int q = 0; q < NLA; ++q) cs4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -455,6 +457,11 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
         for (int q = 0; q < NLA; ++q) sa[q] = *reinterpret_cast<const float4*>(Ar + ga[q]);
 #pragma unroll
         for (int q = 0; q < NLB; ++q) sb[q] = *reinterpret_cast<const float4*>(Br + gb[q]);
+        if constexpr (HASB2) {
+            const float* B2r = B2 + (size_t)rb * ldb;
+#pragma unroll
+            for (int q = 0; q < NLB; ++q) sb2[q] = *reinterpret_cast<const float4*>(B2r + gb[q]);
+        }
     };
     auto commit = [&](_Float16* buf) {
 #pragma unroll
@@ -470,7 +477,8 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
 #pragma unroll
         for (int q = 0; q < NLB; ++q)
             if (lb[q] >= 0) {
-                const float v[4] = {sb[q].x, sb[q].y, sb[q].z, sb[q].w};
+                float v[4] = {sb[q].x, sb[q].y, sb[q].z, sb[q].w};
+                if constexpr (HASB2) { v[0] += sb2[q].x; v[1] += sb2[q].y; v[2] += sb2[q].z; v[3] += sb2[q].w; }
                 half4 hi, lo;
                 split4(v, hi, lo);
                 *reinterpret_cast<half4*>(buf + lb[q]) = hi;
@@ -491,8 +499,8 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
     //  B tiles stream through two register sets one tile ahead
     auto multiply = [&](unsigned adA, unsigned adB) {
         constexpr int O = 0;
-        half8 ah[3], al[3], bh[2], bl[2];
-        static_for(std::make_integer_sequence<int, 3>{}, [&](auto ii) {
+        half8 ah[MTW], al[MTW], bh[2], bl[2];
+        static_for(std::make_integer_sequence<int, MTW>{}, [&](auto ii) {
             constexpr int i = decltype(ii)::value;
             ah[i] = lds_tr_op<O + 32 * i, HA>(adA);
             al[i] = lds_tr_op<O + PLA + 32 * i, HA>(adA);
@@ -500,17 +508,17 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
         bh[0] = lds_tr_op<O, HB>(adB);
         bl[0] = lds_tr_op<O + PLB, HB>(adB);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+        for (int i = 0; i < MTW; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
         static_for(std::make_integer_sequence<int, NTW>{}, [&](auto jj) {
             constexpr int j = decltype(jj)::value, c = j & 1, n = c ^ 1;
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[c]), "+v"(bl[c]));
             if constexpr (j + 1 < NTW) { bh[n] = lds_tr_op<O + 32 * (j + 1), HB>(adB); bl[n] = lds_tr_op<O + PLB + 32 * (j + 1), HB>(adB); }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) am[i][j] = mfma_h(ah[i], bh[c], am[i][j]);
+            for (int i = 0; i < MTW; ++i) am[i][j] = mfma_h(ah[i], bh[c], am[i][j]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ac[i][j] = mfma_h(ah[i], bl[c], ac[i][j]);
+            for (int i = 0; i < MTW; ++i) ac[i][j] = mfma_h(ah[i], bl[c], ac[i][j]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ac[i][j] = mfma_h(al[i], bh[c], ac[i][j]);
+            for (int i = 0; i < MTW; ++i) ac[i][j] = mfma_h(al[i], bh[c], ac[i][j]);
         });
     };
     // one barrier per chunk: a wave converts chunk n + 1 into the other buffer right after its MFMAs of chunk n, while slower
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
         if (rb + 2 * WK < r1) fetch(rb + 2 * WK);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             if (mt0 + i >= MT || nt0 + j >= NT) continue;
@@ -1857,6 +1865,39 @@ extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, i
     if (Rm < R) {                                                   // ragged tail: one workgroup, atomically on top
         if (N <= 192) hipLaunchKernelGGL(gemm_tn_wide_kernel<6>, dim3(1), dim3(512), (size_t)2 * WK * WLD * sizeof(float), s, A + (size_t)Rm * lda, lda, M, B + (size_t)Rm * ldb, ldb, N, C, ldc, R - Rm, (long long)WK, colsum_a, (float*)nullptr);
         else hipLaunchKernelGGL(gemm_tn_wide_kernel<8>, dim3(1), dim3(512), (size_t)WK * (WLD + 272) * sizeof(float), s, A + (size_t)Rm * lda, lda, M, B + (size_t)Rm * ldb, ldb, N, C, ldc, R - Rm, (long long)WK, colsum_a, (float*)nullptr);
+        PF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+// dW (+)= A^T (B + B2) over all pairs in ONE pass (A = g_y [R, M <= 64], B, B2 [R, N <= 192]): the final layer's weight gradient
+// g_y^T (h2 + x) without materialising h2 + x and without reading g_y twice.  R a multiple of 32; accumulates atomically into C.
+extern "C" int pf_gemm_tn_sum2(const float* A, int lda, int M, const float* B, const float* B2, int ldb, int N, float* C, int ldc, long long R,
+                               int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems,
+                               pf_stream_t stream) {
+    if (!A || !B || !B2 || !C || M <= 0 || N <= 0 || R <= 0 || M > 64 || N > 192 || R % WK) return PF_E_BADARG;
+    if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)B2) & 15)) return PF_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    long long nwg = (R + 4 * WK - 1) / (4 * WK);
+    if (nwg > 256) nwg = 256;
+    const long long per = ((R + nwg - 1) / nwg + WK - 1) / WK * WK;
+    nwg = (R + per - 1) / per;
+    // as in pf_gemm_tn_wide: per-workgroup partial sums in the workspace + a reduce kernel, or atomics into a zeroed C without one
+    float* part = workspace && workspace_elems >= nwg * ((long long)M * N + M) && nwg > 1 ? workspace : nullptr;
+    if (!part) {
+        if (!accumulate) { if (ldc == N) zero_fill(C, (size_t)M * N, s); else zero_fill_2d(C, M, N, ldc, s); }
+        if (colsum_a && !colsum_accumulate) zero_fill(colsum_a, (size_t)M, s);
+    }
+    hipLaunchKernelGGL((gemm_tn_split_kernel<6, 1, true>), dim3((unsigned)nwg), dim3(512), (size_t)2 * 2 * WK * (200 + 200) * sizeof(_Float16), s, A, lda, M,
+                       B, ldb, N, C, ldc, R, per, colsum_a, part, B2);
+    PF_CHECK_LAUNCH();
+    if (part) {
+        const int S = M * N + (colsum_a ? M : 0);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, s, part, (int)nwg, M, N, C, ldc, accumulate, colsum_a, colsum_accumulate);
         PF_CHECK_LAUNCH();
     }
     return 0;

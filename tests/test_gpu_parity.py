@@ -1918,3 +1918,22 @@ def test_split_precision_range_is_guarded():
     assert torch.isfinite(y).all()
     sat = xs.clamp(-F16_MAX, F16_MAX)
     G.assert_close(y, (sat.double() @ w.double().T).float(), 1e-5, "saturated rows")
+
+
+def test_gemm_tn_sum2():
+    """pf_gemm_tn_sum2: C (+)= A^T (B + B2) with the column sums of A, against float64 (the final layer's weight / bias gradient)."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(12)
+    R, M, N = 32 * 613, 64, 192
+    A, B, B2 = cu(torch.randn(R, M, generator=g)), cu(torch.randn(R, N, generator=g)), cu(torch.randn(R, N, generator=g))
+    C0 = torch.randn(M, N, generator=g)
+    for acc in (0, 1):
+        Cd = cu(C0.clone()) if acc else torch.full((M, N), float("nan"), device=G.dev())
+        cs = torch.full((M,), float("nan"), device=G.dev())
+        ws = torch.empty(256 * (M * N + M), device=G.dev()) if acc else None       # with / without the partial-sum workspace
+        _capi.check(lib.pf_gemm_tn_sum2(A.data_ptr(), M, M, B.data_ptr(), B2.data_ptr(), N, N, Cd.data_ptr(), N, R, acc, cs.data_ptr(), 0,
+                                        ws.data_ptr() if acc else None, ws.numel() if acc else 0, _capi.stream_ptr()), "pf_gemm_tn_sum2")
+        G.sync()
+        ref = A.cpu().double().t() @ (B.cpu().double() + B2.cpu().double()) + (C0.double() if acc else 0)
+        assert (Cd.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+        assert (cs.cpu().double() - A.cpu().double().sum(0)).abs().max() <= 2e-5 * R ** 0.5
