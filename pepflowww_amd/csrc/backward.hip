@@ -909,6 +909,59 @@ __global__ __launch_bounds__(256) void layernorm_bwd64_kernel(pf_layernorm_bwd_a
     }
 }
 
+// N = 128 (the node track's LayerNorms, row-sized inputs): two rows per wave at a time -- 32 lanes x float4 per row -- and all of a
+// wave's rows requested before the first reduction (the one-row-per-wave form above walked its four rows as a chain of load ->
+// four butterflies -> store: 11.5 us for [2048, 128], 36 of them per training step).  Row sums: 16-lane DPP tree + one permlane swap.
+template <int IT>                                                    // IT x 2 rows per wave
+__global__ __launch_bounds__(256) void layernorm_bwd128_kernel(pf_layernorm_bwd_args p) {
+    __shared__ float red[2][4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 31, gr = lane >> 5;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * (2 * IT);
+    auto s32 = [](float v) { return sum_xor16(row16_sum(v)); };
+    const float4 gam = *reinterpret_cast<const float4*>(p.gamma + 4 * sub);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    float4 xs[IT], ds[IT];
+    float rs[IT];
+    bool oks[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const long long row = row0 + 2 * i + gr;
+        oks[i] = row < p.M;
+        const long long rc = oks[i] ? row : p.M - 1;
+        xs[i] = *reinterpret_cast<const float4*>(p.x + (size_t)rc * 128 + 4 * sub);
+        ds[i] = *reinterpret_cast<const float4*>(p.dy + (size_t)rc * 128 + 4 * sub);
+        rs[i] = !oks[i] ? 0.f : p.row_scale ? p.row_scale[rc] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const long long row = row0 + 2 * i + gr;
+        const float4 x = xs[i];
+        float4 d = ds[i];
+        d.x *= rs[i]; d.y *= rs[i]; d.z *= rs[i]; d.w *= rs[i];
+        const float mean = s32((x.x + x.y) + (x.z + x.w)) * (1.f / 128.f);
+        const float4 c = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
+        const float rstd = rsqrtf(s32((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.f / 128.f) + 1e-5f);
+        const float4 xh = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
+        const float4 gv = make_float4(d.x * gam.x, d.y * gam.y, d.z * gam.z, d.w * gam.w);
+        const float sg = s32((gv.x + gv.y) + (gv.z + gv.w)) * (1.f / 128.f);
+        const float sgx = s32((gv.x * xh.x + gv.y * xh.y) + (gv.z * xh.z + gv.w * xh.w)) * (1.f / 128.f);
+        dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
+        db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+        if (oks[i])
+            *reinterpret_cast<float4*>(p.dx + (size_t)row * 128 + 4 * sub) =
+                make_float4(rstd * (gv.x - sg - xh.x * sgx), rstd * (gv.y - sg - xh.y * sgx), rstd * (gv.z - sg - xh.z * sgx), rstd * (gv.w - sg - xh.w * sgx));
+    }
+    if (p.dgamma) {
+        dg.x = sum_xor32(dg.x); dg.y = sum_xor32(dg.y); dg.z = sum_xor32(dg.z); dg.w = sum_xor32(dg.w);       // the wave's two row groups
+        db.x = sum_xor32(db.x); db.y = sum_xor32(db.y); db.z = sum_xor32(db.z); db.w = sum_xor32(db.w);
+        if (gr == 0) { *reinterpret_cast<float4*>(&red[0][wave][4 * sub]) = dg; *reinterpret_cast<float4*>(&red[1][wave][4 * sub]) = db; }
+        __syncthreads();
+        const int n = threadIdx.x & 127, which = threadIdx.x >> 7;
+        const float v = (red[which][0][n] + red[which][1][n]) + (red[which][2][n] + red[which][3][n]);
+        atomicAdd((which ? p.dbeta : p.dgamma) + n, v);
+    }
+}
+
 // dgamma / dbeta += sum over workgroups of their partial column sums: block (x, y) sums slice y of the workgroups for 64 columns
 // (4 thread groups x unrolled loads), then one atomic per column and block (gridDim.y = 32 of them per column)
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* part, int nwg, int N, float* dgamma, float* dbeta) {
@@ -1933,6 +1986,12 @@ extern "C" int pf_layernorm_bwd(const pf_layernorm_bwd_args* a, pf_stream_t stre
         float* part4 = a->dgamma && a->workspace && a->workspace_elems >= (long long)nwg4 * 128 ? a->workspace : nullptr;
         hipLaunchKernelGGL(layernorm_bwd64_kernel, dim3(nwg4), dim3(256), 0, (hipStream_t)stream, *a, qpw, part4);
         if (part4) hipLaunchKernelGGL(ln_reduce_kernel, dim3(2, 32), dim3(256), 0, (hipStream_t)stream, part4, (int)nwg4, 64, a->dgamma, a->dbeta);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a->N == 128 && a->M >= 1024 && a->M < 65536 && !a->dgamma_rows &&
+        (((uintptr_t)a->x | (uintptr_t)a->dy | (uintptr_t)a->dx | (uintptr_t)a->gamma) & 15) == 0) {
+        hipLaunchKernelGGL(layernorm_bwd128_kernel<2>, dim3((unsigned)((a->M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *a);   // 4 rows per wave
         PF_CHECK_LAUNCH();
         return 0;
     }
