@@ -552,6 +552,11 @@ int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, int ldb, int
 int pf_gemm_tn_sum2(const float* A, int lda, int M, const float* B, const float* B2, int ldb, int N, float* C, int ldc, long long R,
                     int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems,
                     pf_stream_t stream);   /* colsum_a, workspace: optional, as in pf_gemm_tn_wide */
+/* the same two contractions with EdgeTransition's concatenated input x = [z_ij | n_i | n_j] [B L L, 192] gathered from z [B L L, 64] and
+ * the per-residue n [B L, 64] while it is staged (x never exists):  C[M,192] (+)= A^T x  (B2 == NULL, M <= 192: trunk.0.weight's
+ * gradient, A = the gated g_h1) or  C[M,192] (+)= A^T (B2 + x)  (M <= 64: final_layer.weight's, A = g_y, B2 = h2); L >= 32. */
+int pf_gemm_tn_cat(const float* A, int lda, int M, const float* B2, const float* z, const float* n, int B, int L, float* C, int ldc,
+                   int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems, pf_stream_t stream);
 int pf_colsum_f32(const float* x, int ld, int M, int N, float* out, int accumulate, pf_stream_t stream);   /* bias grads */
 int pf_relu_bwd(const float* y, float* dy, long long n, pf_stream_t stream);                                /* dy *= (y > 0) */
 int pf_relu_gate(const float* y, const float* src, float* dst, long long n, pf_stream_t stream);            /* dst = y > 0 ? src : 0 */

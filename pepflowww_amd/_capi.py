@@ -170,6 +170,7 @@ class EtBwdArgs(C.Structure):
 
 _SIGNATURES = {
     "pf_et_bwd_chain": ([C.POINTER(EtBwdArgs), _fp], _i),
+    "pf_gemm_tn_cat": ([_fp, _i, _i, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _fp, _i, _fp, C.c_longlong, _fp], _i),
     "pf_gemm_tn_sum2": ([_fp, _i, _i, _fp, _fp, _i, _i, _fp, _i, C.c_longlong, _i, _fp, _i, _fp, C.c_longlong, _fp], _i),
     "pf_et_pack_train": ([_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp], _i),
     "pf_abi_version": ([], _i),

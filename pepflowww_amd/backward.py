@@ -765,16 +765,20 @@ class EdgeTransitionBlock:
         a.mask, a.B, a.L, a.w_stream = self.mask.data_ptr(), B, L, stream.data_ptr()
         a.dump_h1, a.dump_h2, a.dump_y = h1.data_ptr(), h2.data_ptr(), y.data_ptr()
         _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
-        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, y=y)     # (u = h2 + x is not kept: the backward uses h2 and x separately)
+        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, y=y, z=z, n=n)   # (u = h2 + x is not kept: the backward uses h2 and x separately)
         return out
 
     def forward(self, s, z):
         lib, B, L, W, p = _capi.load(), self.B, self.L, self.W, f"edge_transition_{self.b}."
         dev = s.device
         n = linear_fwd(s, W[p + "initial_embed.weight"], W[p + "initial_embed.bias"])
-        x = torch.empty(B * L * L, 192, device=dev)
         em = torch.empty(B * L * L, device=dev)
-        _capi.check(lib.pf_et_concat(z.data_ptr(), n.data_ptr(), self.mask.data_ptr(), x.data_ptr(), em.data_ptr(), B, L, _capi.stream_ptr()), "pf_et_concat")
+        # x = [z_ij | n_i | n_j] is not materialised when nothing reads it as a tensor: the fused forward takes per-residue terms, the
+        # fused backward gathers it while staging (pf_gemm_tn_cat); only the pair mask is computed here then
+        self.virtual_x = self.FUSED_FORWARD and self.FUSED_BACKWARD and L >= 32 and (B * L * L) % 32 == 0
+        x = None if self.virtual_x else torch.empty(B * L * L, 192, device=dev)
+        _capi.check(lib.pf_et_concat(z.data_ptr(), n.data_ptr(), self.mask.data_ptr(), x.data_ptr() if x is not None else None, em.data_ptr(), B, L,
+                                     _capi.stream_ptr()), "pf_et_concat")
         if self.FUSED_FORWARD:
             return self._forward_fused(s, z, n, x, em)
         h1 = linear_fwd(x, W[p + "trunk.0.weight"], W[p + "trunk.0.bias"], relu=True)
@@ -808,11 +812,16 @@ class EdgeTransitionBlock:
             ea.wfT_f16, ea.w2T_f16, ea.w1T_f16 = (k.data_ptr() for k in keep)
             ea.g_h2, ea.g_h1, ea.g_x, ea.npairs = g_h2.data_ptr(), g_h1.data_ptr(), g_x.data_ptr(), npairs
             _capi.check(lib.pf_et_bwd_chain(C.byref(ea), _capi.stream_ptr()), "pf_et_bwd_chain")
-            # final_layer(h2 + x): dW = g_y^T (h2 + x) in ONE pass over g_y (pf_gemm_tn_sum2 adds the two operands while it stages them)
+            # final_layer(h2 + x): dW = g_y^T (h2 + x) in ONE pass over g_y; with the virtual x (pf_gemm_tn_cat) also without reading an x
             dWf, wz = _grad_buffer(64, 192, device=dev)
             dbf, bz = _grad_buffer(64, device=dev)
-            if npairs % 32 == 0:
-                ws = _tn_workspace(dev)
+            ws = _tn_workspace(dev)
+            if sv["x"] is None:
+                _capi.check(lib.pf_gemm_tn_cat(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["z"].data_ptr(), sv["n"].data_ptr(), B, L,
+                                               dWf.data_ptr(), 192, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()),
+                            "pf_gemm_tn_cat")
+                G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
+            elif npairs % 32 == 0:
                 _capi.check(lib.pf_gemm_tn_sum2(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["x"].data_ptr(), 192, 192, dWf.data_ptr(), 192,
                                                 npairs, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_sum2")
                 G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
@@ -820,7 +829,14 @@ class EdgeTransitionBlock:
                 _, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y, need_dx=False)
                 G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
             _, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, need_dx=False)
-            _, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, need_dx=False)
+            if sv["x"] is None:
+                dW1, w1z = _grad_buffer(192, 192, device=dev)
+                db1, b1z = _grad_buffer(192, device=dev)
+                _capi.check(lib.pf_gemm_tn_cat(g_h1.data_ptr(), 192, 192, None, sv["z"].data_ptr(), sv["n"].data_ptr(), B, L, dW1.data_ptr(), 192,
+                                               int(w1z), db1.data_ptr(), int(b1z), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_cat")
+                G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = dW1, db1
+            else:
+                _, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, need_dx=False)
         else:
             g_u, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y)
             G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)

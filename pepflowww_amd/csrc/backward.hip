@@ -410,9 +410,12 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 
 // MTW = 16-row tiles of C per wave along M (3: M <= 192; 1: M <= 64 -- a third of the accumulators); HASB2: the B operand is the SUM of
 // two tensors (B + B2, same ldb), added while the chunk is staged: dW_f = g_y^T (h2 + x) in one pass over g_y instead of two products.
-template <int NTW, int MTW = 3, bool HASB2 = false>
+// CAT: one of the B operands is EdgeTransition's concatenated input x = [z_ij | n_i | n_j] (192 wide), never materialised: its rows are
+// gathered from z [pairs,64] and the per-residue n [B*L,64] while the chunk is staged (1 = B is x, 2 = B2 is x; cat_z / cat_n / cat_L).
+template <int NTW, int MTW = 3, bool HASB2 = false, int CAT = 0>
 __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc,
-                                                            long long R, long long rows_per_wg, float* colsum_a, float* part, const float* B2 = nullptr) {
+                                                            long long R, long long rows_per_wg, float* colsum_a, float* part, const float* B2 = nullptr,
+                                                            const float* cat_z = nullptr, const float* cat_n = nullptr, int cat_L = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tn_sm[];
     constexpr int SA = 192 + 8, SB = 32 * NTW + 8;                 // plane row strides in f16 (rows of 32 K values per chunk)
     constexpr int BUF = 2 * WK * (SA + SB);                         // f16 elements of one buffer: [Ah | Al | Bh | Bl]
@@ -450,17 +453,45 @@ __global__ __launch_bounds__(512) void gemm_tn_split_kernel(const float* A, int 
     float4 cs4[NLA];                                                 // column sums of A (the bias gradient) straight from the fp32 staging registers
 #pragma unroll
     for (int q = 0; q < NLA; ++q) cs4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (CAT) this thread's float4 q of the virtual x chunk: row rr of the chunk, column 4 c of the 192
+    int crr[NLB], ccol[NLB];
+#pragma unroll
+    for (int q = 0; q < NLB; ++q) {
+        const int idx = tid + q * 512, rr = idx / n4, c = idx - rr * n4;
+        crr[q] = rr < WK ? rr : 0;
+        ccol[q] = rr < WK ? 4 * c : 0;
+    }
+    auto cat_fetch = [&](long long rb, float4 (&dst)[NLB]) {
+        const long long LL = (long long)cat_L * cat_L;
+        const int b0 = (int)(rb / LL), rem0 = (int)(rb - (long long)b0 * LL), i0 = rem0 / cat_L, j0 = rem0 - i0 * cat_L;   // (uniform; L >= 32: one wrap at most)
+#pragma unroll
+        for (int q = 0; q < NLB; ++q) {
+            int b = b0, i = i0, j = j0 + crr[q];
+            if (j >= cat_L) { j -= cat_L; ++i; }
+            if (i >= cat_L) { i -= cat_L; ++b; }
+            const int c = ccol[q];
+            const long long srow = c < 64 ? rb + crr[q] : (long long)b * cat_L + (c < 128 ? i : j);
+            const float* src = (c < 64 ? cat_z : cat_n) + srow * 64 + (c & 63);
+            dst[q] = *reinterpret_cast<const float4*>(src);
+        }
+    };
     auto fetch = [&](long long rb) {
         const float* Ar = A + (size_t)rb * lda;
-        const float* Br = B + (size_t)rb * ldb;
 #pragma unroll
         for (int q = 0; q < NLA; ++q) sa[q] = *reinterpret_cast<const float4*>(Ar + ga[q]);
+        if constexpr (CAT == 1) cat_fetch(rb, sb);
+        else {
+            const float* Br = B + (size_t)rb * ldb;
 #pragma unroll
-        for (int q = 0; q < NLB; ++q) sb[q] = *reinterpret_cast<const float4*>(Br + gb[q]);
+            for (int q = 0; q < NLB; ++q) sb[q] = *reinterpret_cast<const float4*>(Br + gb[q]);
+        }
         if constexpr (HASB2) {
-            const float* B2r = B2 + (size_t)rb * ldb;
+            if constexpr (CAT == 2) cat_fetch(rb, sb2);
+            else {
+                const float* B2r = B2 + (size_t)rb * ldb;
 #pragma unroll
-            for (int q = 0; q < NLB; ++q) sb2[q] = *reinterpret_cast<const float4*>(B2r + gb[q]);
+                for (int q = 0; q < NLB; ++q) sb2[q] = *reinterpret_cast<const float4*>(B2r + gb[q]);
+            }
         }
     };
     auto commit = [&](_Float16* buf) {
@@ -1625,7 +1656,21 @@ extern "C" int pf_edge_distcoef_bwd(const float* g_g, const float* gfeat, const 
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void et_emask_kernel(const float* mask, float* emask, int B, int L) {      // m_i m_j per pair
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, np = (long long)B * L * L;
+    if (t >= np) return;
+    const int b = (int)(t / ((long long)L * L)), rem = (int)(t - (long long)b * L * L), i = rem / L, j = rem - i * L;
+    emask[t] = mask[b * L + i] * mask[b * L + j];
+}
+}  // namespace
 extern "C" int pf_et_concat(const float* z, const float* n, const float* mask, float* x, float* emask, int B, int L, pf_stream_t stream) {
+    if (!x && mask && emask && B > 0 && L > 0) {                       // x == NULL: the pair mask alone (x is gathered on the fly, pf_gemm_tn_cat)
+        const long long np = (long long)B * L * L;
+        hipLaunchKernelGGL(et_emask_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, emask, B, L);
+        PF_CHECK_LAUNCH();
+        return 0;
+    }
     if (!z || !n || !mask || !x || B <= 0 || L <= 0) return PF_E_BADARG;
     if ((((uintptr_t)z | (uintptr_t)n | (uintptr_t)x) & 15) != 0) return PF_E_BADARG;
     const long long tot = (long long)B * L * L * 48;                 // float4 per thread
@@ -1947,6 +1992,49 @@ extern "C" int pf_gemm_tn_sum2(const float* A, int lda, int M, const float* B, c
     }
     hipLaunchKernelGGL((gemm_tn_split_kernel<6, 1, true>), dim3((unsigned)nwg), dim3(512), (size_t)2 * 2 * WK * (200 + 200) * sizeof(_Float16), s, A, lda, M,
                        B, ldb, N, C, ldc, R, per, colsum_a, part, B2);
+    PF_CHECK_LAUNCH();
+    if (part) {
+        const int S = M * N + (colsum_a ? M : 0);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, s, part, (int)nwg, M, N, C, ldc, accumulate, colsum_a, colsum_accumulate);
+        PF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+// The two weight gradients of EdgeTransition that contract the concatenated input x = [z_ij | n_i | n_j] [pairs,192], with x gathered
+// from z [pairs,64] and n [B*L,64] while it is staged (x is never written: pf_et_concat + two 768-byte-per-pair reads less per block):
+//   B2 == NULL:  C[M,192] (+)= A^T x            (trunk.0:       A = the gated g_h1, M = 192)
+//   B2 != NULL:  C[M,192] (+)= A^T (B2 + x)     (final_layer:   A = g_y, M = 64, B2 = h2 [pairs,192])
+// + optional column sums of A; R = B L L pairs (a multiple of 32), L >= 32; workspace as in pf_gemm_tn_wide.
+extern "C" int pf_gemm_tn_cat(const float* A, int lda, int M, const float* B2, const float* z, const float* n, int Bn, int L, float* C, int ldc,
+                              int accumulate, float* colsum_a, int colsum_accumulate, float* workspace, long long workspace_elems, pf_stream_t stream) {
+    const long long R = (long long)Bn * L * L;
+    const int N = 192;
+    if (!A || !z || !n || !C || Bn <= 0 || L < 32 || M <= 0 || R % WK) return PF_E_BADARG;
+    if (B2 ? M > 64 : M > 192) return PF_E_BADARG;
+    if ((M & 3) || (lda & 3) || (((uintptr_t)A | (uintptr_t)z | (uintptr_t)n | (uintptr_t)B2) & 15)) return PF_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6, 1, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    long long nwg = (R + 4 * WK - 1) / (4 * WK);
+    if (nwg > 256) nwg = 256;
+    const long long per = ((R + nwg - 1) / nwg + WK - 1) / WK * WK;
+    nwg = (R + per - 1) / per;
+    float* part = workspace && workspace_elems >= nwg * ((long long)M * N + M) && nwg > 1 ? workspace : nullptr;
+    if (!part) {
+        if (!accumulate) { if (ldc == N) zero_fill(C, (size_t)M * N, s); else zero_fill_2d(C, M, N, ldc, s); }
+        if (colsum_a && !colsum_accumulate) zero_fill(colsum_a, (size_t)M, s);
+    }
+    const size_t lds = (size_t)2 * 2 * WK * (200 + 200) * sizeof(_Float16);
+    if (B2)
+        hipLaunchKernelGGL((gemm_tn_split_kernel<6, 1, true, 2>), dim3((unsigned)nwg), dim3(512), lds, s, A, lda, M, B2, N, N, C, ldc, R, per, colsum_a, part,
+                           (const float*)nullptr, z, n, L);
+    else
+        hipLaunchKernelGGL((gemm_tn_split_kernel<6, 3, false, 1>), dim3((unsigned)nwg), dim3(512), lds, s, A, lda, M, (const float*)nullptr, N, N, C, ldc, R, per,
+                           colsum_a, part, (const float*)nullptr, z, n, L);
     PF_CHECK_LAUNCH();
     if (part) {
         const int S = M * N + (colsum_a ? M : 0);

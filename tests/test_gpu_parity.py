@@ -1629,7 +1629,7 @@ def test_edge_transition_block_backward_vs_reference(f4, f5, f6, seeded_sd):
     assert abs(g_z.norm().item() - 0) > 0 and torch.isfinite(g_z).all() and torch.isfinite(g_s).all()
 
 
-@pytest.mark.parametrize("B,L", [(2, 32), (3, 24), (2, 22)])
+@pytest.mark.parametrize("B,L", [(2, 32), (3, 24), (2, 22), (1, 48)])
 def test_fused_edge_transition_training_forward(seeded_sd, B, L):
     """Training forward of EdgeTransition on the persistent inference kernel with h1 / h2 / y dumps == the three stand-alone
     Linears + LayerNorm + mask: output and every saved tensor to fp32 rounding, and the block's backward on either set of
@@ -1648,7 +1648,7 @@ def test_fused_edge_transition_training_forward(seeded_sd, B, L):
         blk = Bk.EdgeTransitionBlock(W, 1, B, L, mask)
         blk.FUSED_FORWARD = fused
         out = blk.forward(s, z)
-        saved = {k: v.clone() for k, v in blk.saved.items()}
+        saved = {k: (v.clone() if v is not None else None) for k, v in blk.saved.items()}   # (x is None where it is gathered on the fly: L >= 32)
         g_s, g_z, G_ = blk.backward(g_out.clone())
         G.sync()
         res[fused] = (out.clone(), saved, g_s.clone(), g_z.clone(), {k: v.clone() for k, v in G_.items()})
@@ -1656,7 +1656,8 @@ def test_fused_edge_transition_training_forward(seeded_sd, B, L):
     o1, sv1, gs1, gz1, G1 = res[True]
     assert (o0 - o1).abs().max().item() <= 2e-5
     for k in ("h1", "h2", "y", "x", "em"):
-        assert (sv0[k] - sv1[k]).abs().max().item() <= 2e-5, k
+        if sv1[k] is not None:
+            assert (sv0[k] - sv1[k]).abs().max().item() <= 2e-5, k
     assert (gs0 - gs1).abs().max() <= 1e-4 * gs0.abs().max() and (gz0 - gz1).abs().max() <= 1e-4 * gz0.abs().max()
     for k in G0:
         assert (G0[k] - G1[k]).abs().max() <= 1e-4 * G0[k].abs().max() + 1e-6, k
@@ -1937,3 +1938,27 @@ def test_gemm_tn_sum2():
         ref = A.cpu().double().t() @ (B.cpu().double() + B2.cpu().double()) + (C0.double() if acc else 0)
         assert (Cd.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
         assert (cs.cpu().double() - A.cpu().double().sum(0)).abs().max() <= 2e-5 * R ** 0.5
+
+
+@pytest.mark.parametrize("B,L", [(2, 48), (1, 96), (3, 32)])
+def test_gemm_tn_cat_gathers_the_concatenated_input(B, L):
+    """pf_gemm_tn_cat: the two EdgeTransition weight gradients that contract x = [z_ij | n_i | n_j] with x gathered from z and the
+    per-residue n while it is staged, against float64 products with the materialised x (sample / row wraps inside a 32-pair chunk)."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(100 * B + L)
+    P = B * L * L
+    z, n = torch.randn(P, 64, generator=g), torch.randn(B * L, 64, generator=g)
+    nb = n.view(B, L, 64)
+    x = torch.cat([z.view(B, L, L, 64), nb[:, :, None, :].expand(B, L, L, 64), nb[:, None, :, :].expand(B, L, L, 64)], -1).reshape(P, 192)
+    ws = torch.empty(256 * (192 * 192 + 192), device=G.dev())
+    for M, with_b2 in ((192, False), (64, True)):
+        A = torch.randn(P, M, generator=g)
+        h2 = torch.randn(P, 192, generator=g)
+        Cd, cs = torch.full((M, 192), float("nan"), device=G.dev()), torch.full((M,), float("nan"), device=G.dev())
+        dA, dz, dn, dh2 = cu(A), cu(z), cu(n), cu(h2)
+        _capi.check(lib.pf_gemm_tn_cat(dA.data_ptr(), M, M, dh2.data_ptr() if with_b2 else None, dz.data_ptr(), dn.data_ptr(), B, L, Cd.data_ptr(), 192,
+                                       0, cs.data_ptr(), 0, ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_cat")
+        G.sync()
+        ref = A.double().t() @ (x.double() + (h2.double() if with_b2 else 0))
+        assert (Cd.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max(), (M, with_b2)
+        assert (cs.cpu().double() - A.double().sum(0)).abs().max() <= 2e-5 * P ** 0.5
