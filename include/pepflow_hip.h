@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 46
+#define PF_ABI_VERSION 47
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -516,6 +516,12 @@ int pf_gemm_f32(const pf_gemm_args* a, pf_stream_t stream);
  * pf_gemm_f32.  Their workgroups share a grid (each product alone fills a fraction of the CUs for a chain of global round trips);
  * results are those of two pf_gemm_f32 calls bit for bit, and any pair outside the compiled-in layouts runs as exactly that. */
 int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, pf_stream_t stream);
+/* n <= PF_GEMM_GROUP_MAX INDEPENDENT products (no output of one is an operand or the output of another), each described as for
+ * pf_gemm_f32, in ONE launch: the batched sample x head products of the IPA backward (ipa_pytorch.py:389-475 reversed: g_q, g_k, g_v
+ * and the three point contractions) are short latency chains whose workgroups overlap in a shared grid.  Results are those of n
+ * pf_gemm_f32 calls bit for bit; products outside the compiled-in layouts / tile size run as exactly that. */
+#define PF_GEMM_GROUP_MAX 6
+int pf_gemm_f32_group(const pf_gemm_args* a, int n, pf_stream_t stream);
 /* EdgeTransition operands of the TRAINING forward from the fp32 parameters, two launches (the parameters change every step):
  * stream_out = the persistent kernel's 256 KiB fragment stream (pf_edge_transition_args.w_stream: [128][hi 512 | lo 512] f16) as a
  * gather through stream_idx (int32 [128*512] flat indices into trunk.0.weight | trunk.2.weight | final_layer.weight) with

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -199,6 +199,7 @@ _SIGNATURES = {
     "pf_train_losses_bwd": ([C.POINTER(TrainArgs), C.POINTER(TrainBwdArgs), _fp], _i),
     "pf_gemm_f32": ([C.POINTER(GemmArgs), _fp], _i),
     "pf_gemm_f32_dual": ([C.POINTER(GemmArgs), C.POINTER(GemmArgs), _fp], _i),
+    "pf_gemm_f32_group": ([C.POINTER(GemmArgs), C.c_int, _fp], _i),
     "pf_colsum_f32": ([_fp, _i, _i, _i, _fp, _i, _fp], _i),
     "pf_gemm_tn_wide": ([_fp, _i, _i, _fp, _i, _i, _fp, _i, C.c_longlong, _i, _fp, _i, _fp, C.c_longlong, _fp], _i),
     "pf_split_pack_f16": ([_fp, _i, _i, _i, _i, _fp, _fp], _i),

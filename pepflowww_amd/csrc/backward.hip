@@ -6,6 +6,7 @@
 //   pf_relu_bwd        dy *= (y > 0)
 //   pf_layernorm_bwd   dx, dgamma, dbeta of nn.LayerNorm (eps 1e-5) over the last dimension
 #include <utility>
+#include <cstring>
 #include "common.h"
 #include "rigid_dev.h"
 #include "../../include/pepflow_hip.h"
@@ -265,6 +266,29 @@ __global__ __launch_bounds__(256) void gemm_f32_dual_kernel(pf_gemm_args p1, int
         b -= d.n1;
         const int bx = b % d.gx2, t = b / d.gx2;
         gemm_f32_body<MT2, 4, 1, 1>(p2, vA2, vB2, bx, t % d.gy2, t / d.gy2, As, Bs);
+    }
+}
+
+// Up to PF_GEMM_GROUP_MAX INDEPENDENT products in one launch (pf_gemm_f32_group): the six products that follow the softmax backward of an
+// IPA block (g_q, g_k, g_v and the three point contractions) are 256 - 512 workgroups of a four-chunk latency chain each (12 - 25 us
+// per launch); in one grid their chains overlap.  end[i] = one past the last linear block index of product i; combo as in GemmPlan.
+struct GemmGroup {
+    pf_gemm_args p[PF_GEMM_GROUP_MAX];
+    int vA[PF_GEMM_GROUP_MAX], vB[PF_GEMM_GROUP_MAX], combo[PF_GEMM_GROUP_MAX], gx[PF_GEMM_GROUP_MAX], gy[PF_GEMM_GROUP_MAX], end[PF_GEMM_GROUP_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroup G) {
+    __shared__ __attribute__((aligned(16))) float As[64 * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[GT * LDT];
+    int b = blockIdx.x, i = 0;
+    while (i + 1 < G.n && b >= G.end[i]) ++i;                    // (workgroup-uniform)
+    if (i > 0) b -= G.end[i - 1];
+    const int gx = G.gx[i], gy = G.gy[i];
+    const int bx = b % gx, t = b / gx;
+    switch (G.combo[i]) {
+        case 0: gemm_f32_body<2, 4, 0, 0>(G.p[i], G.vA[i], G.vB[i], bx, t % gy, t / gy, As, Bs); break;
+        case 1: gemm_f32_body<2, 4, 0, 1>(G.p[i], G.vA[i], G.vB[i], bx, t % gy, t / gy, As, Bs); break;
+        default: gemm_f32_body<2, 4, 1, 1>(G.p[i], G.vA[i], G.vB[i], bx, t % gy, t / gy, As, Bs); break;
     }
 }
 
@@ -1860,6 +1884,41 @@ extern "C" int pf_gemm_f32_dual(const pf_gemm_args* a1, const pf_gemm_args* a2, 
     else if (p2.TM == 32) PF_DUAL(2, 1);
     else PF_DUAL(2, 2);
 #undef PF_DUAL
+    PF_CHECK_LAUNCH();
+    return 0;
+}
+// n independent products in one launch when every one of them is a 64-row-tile product in a compiled-in layout (combos 0, 1, 2 of
+// gemm_plan); anything else runs as n pf_gemm_f32 launches -- same arithmetic either way.
+extern "C" int pf_gemm_f32_group(const pf_gemm_args* a, int n, pf_stream_t stream) {
+    if (!a || n <= 0) return PF_E_BADARG;
+    const hipStream_t st = (hipStream_t)stream;
+    bool ok = n <= PF_GEMM_GROUP_MAX && n > 1;
+    GemmPlan pl[PF_GEMM_GROUP_MAX];
+    if (ok)
+        for (int i = 0; i < n; ++i) {
+            if (!gemm_plan(a + i, pl[i])) return PF_E_BADARG;
+            ok = ok && pl[i].TM == 64 && pl[i].combo <= 2;
+        }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = pf_gemm_f32(a + i, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    GemmGroup G;
+    memset(&G, 0, sizeof(G));
+    G.n = n;
+    long long tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (pl[i].zero_c) gemm_zero_c(a + i, st);
+        G.p[i] = pl[i].g; G.vA[i] = pl[i].vA; G.vB[i] = pl[i].vB; G.combo[i] = pl[i].combo;
+        G.gx[i] = (int)pl[i].grid.x; G.gy[i] = (int)pl[i].grid.y;
+        tot += (long long)pl[i].grid.x * pl[i].grid.y * pl[i].grid.z;
+        if (tot > 0x7fffffffLL) return PF_E_TOOLARGE;
+        G.end[i] = (int)tot;
+    }
+    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3((unsigned)tot), dim3(256), 0, st, G);
     PF_CHECK_LAUNCH();
     return 0;
 }

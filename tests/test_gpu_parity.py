@@ -1211,6 +1211,70 @@ def test_dual_gemm_equals_two_launches(M, N, K):
         assert (o[2].double() - ref_db).abs().max() <= 2e-5 * max(ref_db.abs().max(), 1.0)
 
 
+@pytest.mark.parametrize("Bn,L", [(3, 128), (2, 72)])
+def test_group_gemm_equals_separate_launches(Bn, L):
+    """pf_gemm_f32_group (independent products in ONE grid) on the sample x head products of the IPA backward (g_k, g_v, g_q and the
+    point contractions: transposed and plain operands, N = 128 / 24 / 36, ragged L) against one pf_gemm_f32 launch each: bit for bit
+    (no split-K here), and against float64; a list the group kernel does not cover (a 32-row-tile product) falls back to the same."""
+    import ctypes as C
+    from pepflowww_amd import backward as Bk
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(Bn * 1000 + L)
+    rows, ldp = Bn * L, 3744
+    gA, P = cu(torch.randn(Bn, 8, L, L, generator=g)), cu(torch.rand(Bn, 8, L, L, generator=g))
+    proj, g_feats = cu(torch.randn(rows, ldp, generator=g)), cu(torch.randn(rows, 1536, generator=g))
+    qp, kp, g_opt = cu(torch.randn(rows, 192, generator=g)), cu(torch.randn(rows, 192, generator=g)), cu(torch.randn(rows, 288, generator=g))
+    bAh = (8 * L * L, L * L)
+
+    def problems(o):
+        return [
+            Bk._gemm_args(gA, 1, L, proj, ldp, 1, o["g_proj"], L, 128, L, alpha=0.051, ldc=ldp, c_off=1024, batch=(Bn, 8, bAh, (L * ldp, 128), (L * ldp, 256))),
+            Bk._gemm_args(P, 1, L, g_feats, 1536, 1, o["g_proj"], L, 128, L, ldc=ldp, c_off=1024 + 128, batch=(Bn, 8, bAh, (L * 1536, 128), (L * ldp, 256))),
+            Bk._gemm_args(gA, 1, L, qp, 192, 1, o["g_kp"], L, 24, L, ldc=192, batch=(Bn, 8, bAh, (L * 192, 24), (L * 192, 24))),
+            Bk._gemm_args(P, 1, L, g_opt, 288, 1, o["g_vp"], L, 36, L, ldc=288, batch=(Bn, 8, bAh, (L * 288, 36), (L * 288, 36))),
+            Bk._gemm_args(gA, L, 1, proj, ldp, 1, o["g_proj"], L, 128, L, alpha=0.051, ldc=ldp, b_off=1024, batch=(Bn, 8, bAh, (L * ldp, 256), (L * ldp, 128))),
+            Bk._gemm_args(gA, L, 1, kp, 192, 1, o["g_qp"], L, 24, L, ldc=192, batch=(Bn, 8, bAh, (L * 192, 24), (L * 192, 24))),
+            Bk._gemm_args(g_feats, 1536, 1, proj, 1, ldp, o["gP"], L, L, 128, ldc=L, b_off=1024 + 128, batch=(Bn, 8, (L * 1536, 128), (L * ldp, 256), bAh)),
+        ]
+
+    outs = []
+    for grouped in (True, False):
+        o = dict(g_proj=torch.zeros(rows, ldp, device=G.dev()), g_kp=torch.zeros(rows, 192, device=G.dev()), g_vp=torch.zeros(rows, 288, device=G.dev()),
+                 g_qp=torch.zeros(rows, 192, device=G.dev()), gP=torch.zeros(Bn, 8, L, L, device=G.dev()))
+        pr = problems(o)
+        if grouped:
+            for i in range(0, len(pr), 6):
+                part = pr[i:i + 6]
+                arr = (_capi.GemmArgs * len(part))(*part)
+                _capi.check(lib.pf_gemm_f32_group(arr, len(part), _capi.stream_ptr()), "pf_gemm_f32_group")
+        else:
+            for a in pr:
+                _capi.check(lib.pf_gemm_f32(C.byref(a), _capi.stream_ptr()), "pf_gemm_f32")
+        G.sync()
+        outs.append({k: v.cpu() for k, v in o.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    d = lambda t: t.cpu().double()
+    gk = 0.051 * torch.einsum("bhij,bihc->bjhc", d(gA), d(proj)[:, :1024].view(Bn, L, 8, 128))
+    assert (d(outs[0]["g_proj"])[:, 1024:3072].view(Bn, L, 8, 256)[..., :128] - gk).abs().max() <= 2e-5 * gk.abs().max()
+    gkp = torch.einsum("bhij,bihc->bjhc", d(gA), d(qp).view(Bn, L, 8, 24))
+    assert (d(outs[0]["g_kp"]).view(Bn, L, 8, 24) - gkp).abs().max() <= 2e-5 * gkp.abs().max()
+    gq = 0.051 * torch.einsum("bhij,bjhc->bihc", d(gA), d(proj)[:, 1024:3072].view(Bn, L, 8, 256)[..., :128])
+    assert (d(outs[0]["g_proj"])[:, :1024].view(Bn, L, 8, 128) - gq).abs().max() <= 2e-5 * gq.abs().max()
+    gP = torch.einsum("bihc,bjhc->bhij", d(g_feats)[:, :1024].view(Bn, L, 8, 128), d(proj)[:, 1024:3072].view(Bn, L, 8, 256)[..., 128:])
+    assert (d(outs[0]["gP"]) - gP).abs().max() <= 2e-5 * gP.abs().max()
+    # fallback: a 32-row-tile product in the list -> separate launches, same results
+    x, w = cu(torch.randn(512, 128, generator=g)), cu(torch.randn(64, 128, generator=g))
+    y0, y1 = torch.zeros(512, 64, device=G.dev()), torch.zeros(512, 64, device=G.dev())
+    o2 = dict(g_kp=torch.zeros(rows, 192, device=G.dev()))
+    pr = [Bk._gemm_args(x, 128, 1, w, 1, 128, y0, 512, 64, 128), Bk._gemm_args(gA, 1, L, qp, 192, 1, o2["g_kp"], L, 24, L, ldc=192, batch=(Bn, 8, bAh, (L * 192, 24), (L * 192, 24)))]
+    arr = (_capi.GemmArgs * 2)(*pr)
+    _capi.check(lib.pf_gemm_f32_group(arr, 2, _capi.stream_ptr()), "pf_gemm_f32_group")
+    _capi.check(lib.pf_gemm_f32(C.byref(Bk._gemm_args(x, 128, 1, w, 1, 128, y1, 512, 64, 128)), _capi.stream_ptr()), "pf_gemm_f32")
+    G.sync()
+    assert torch.equal(y0.cpu(), y1.cpu()) and torch.equal(o2["g_kp"].cpu(), outs[0]["g_kp"])
+
+
 @pytest.mark.parametrize("npairs", [64 * 37, 64 * 20 + 13])
 def test_edge_transition_backward_chain(npairs):
     """pf_et_bwd_chain (g_y -> g_u -> gate h2 -> W2^T -> gate h1 -> W1^T + g_u in one kernel) against float64, incl. a ragged last
