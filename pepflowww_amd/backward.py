@@ -133,64 +133,6 @@ def _grad_buffer(*shape, device):
     return torch.empty(*shape, device=device), False
 
 
-SIDE_DW = os.environ.get("PF_SIDE_DW", "1") != "0"     # pair-sized weight-gradient products on a second stream (A/B switch)
-_SIDE_STREAMS = {}
-
-
-class SideLane:
-    """The pair-sized weight-gradient products of a block (EdgeTransition: three passes over [B L L, 192] activations, ~270 us at
-    B=16, L=128; IPA: the two pair projections) are side outputs of the backward: nothing downstream reads them before the optimizer.
-    They run on a second stream, forked after the kernel that produces their operands, while the main stream goes on with the
-    node-track / IPA backward of the block -- chains of row-sized launches that leave most CUs idle.  Captured into the step's
-    hipGraph the fork / join become parallel branches.  Operands allocated on the main stream are held until the join (the caching
-    allocator would otherwise hand their memory to a later main-stream tensor while the side stream still reads it)."""
-    current = None
-
-    def __init__(self, device):
-        self.device = device
-        self.main = torch.cuda.current_stream(device)
-        key = device.index if device.index is not None else torch.cuda.current_device()
-        side = _SIDE_STREAMS.get(key)
-        if side is None or side.cuda_stream == self.main.cuda_stream:
-            side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-        self.side = side
-        self.keep = []
-        self.open = False
-
-    def run(self, fn, keep=()):
-        """fn() issues launches that depend only on what the main stream has been given so far."""
-        if not SIDE_DW:
-            fn()
-            return
-        self.side.wait_stream(self.main)
-        self.keep.extend(keep)
-        self.open = True
-        with torch.cuda.stream(self.side):
-            fn()
-
-    def join(self):
-        if self.open:
-            self.main.wait_stream(self.side)
-            self.open = False
-        self.keep.clear()
-
-    def __enter__(self):
-        SideLane.current = self
-        return self
-
-    def __exit__(self, *exc):
-        self.join()
-        SideLane.current = None
-
-
-def _side_run(fn, keep=()):
-    lane = SideLane.current
-    if lane is None:
-        fn()
-    else:
-        lane.run(fn, keep)
-
-
 _RANGE_FLAGS = {}
 
 
@@ -745,15 +687,13 @@ class IpaBlock:
             _gemm_args(gA, L, 1, sv["kp"], 192, 1, g_qp, L, 24, L, ldc=192, batch=(B, 8, bAh, (L * 192, 24), (L * 192, 24)))])
         _capi.check(lib.pf_ipa_bwd_points(C.byref(a), st), "pf_ipa_bwd_points")
         # parameters of the pair projections: dW_b = g_bias^T z, dW_dz = g_pz^T z (K = pairs)
-        def pair_dw():                                          # side outputs: second stream (SideLane)
-            for nm, gb, n in (("linear_b", g_bias, 8), ("down_z", g_pz, 16)):
-                dW = e(n, 64)
-                db, zeroed = _grad_buffer(n, device=dev)
-                if not zeroed:
-                    db = _zeros(n, device=dev)
-                _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L, rowsum=db)          # db = column sums of gb from the same pass
-                G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
-        _side_run(pair_dw, keep=(g_bias, g_pz))
+        for nm, gb, n in (("linear_b", g_bias, 8), ("down_z", g_pz, 16)):
+            dW = e(n, 64)
+            db, zeroed = _grad_buffer(n, device=dev)
+            if not zeroed:
+                db = _zeros(n, device=dev)
+            _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L, rowsum=db)          # db = column sums of gb from the same pass
+            G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
         gg = e(8)
         _capi.check(lib.pf_colsum_f32(g_gam.data_ptr(), 8, rows, 8, gg.data_ptr(), 0, st), "pf_colsum_f32")
         ghw = e(8)
@@ -893,37 +833,31 @@ class EdgeTransitionBlock:
             ea.wfT_f16, ea.w2T_f16, ea.w1T_f16 = (k.data_ptr() for k in keep)
             ea.g_h2, ea.g_h1, ea.g_x, ea.npairs = g_h2.data_ptr(), g_h1.data_ptr(), g_x.data_ptr(), npairs
             _capi.check(lib.pf_et_bwd_chain(C.byref(ea), _capi.stream_ptr()), "pf_et_bwd_chain")
-            # the three weight gradients: side outputs, on the second stream (SideLane) while the main stream continues with g_x
-            if SideLane.current is not None:
-                SideLane.current.join()                           # (the previous block's products: long finished; frees their operands)
-
-            def dw_products():
-                # final_layer(h2 + x): dW = g_y^T (h2 + x) in ONE pass over g_y; with the virtual x (pf_gemm_tn_cat) also without reading an x
-                dWf, wz = _grad_buffer(64, 192, device=dev)
-                dbf, bz = _grad_buffer(64, device=dev)
-                ws = _tn_workspace(dev)
-                if sv["x"] is None:
-                    _capi.check(lib.pf_gemm_tn_cat(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["z"].data_ptr(), sv["n"].data_ptr(), B, L,
-                                                   dWf.data_ptr(), 192, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()),
-                                "pf_gemm_tn_cat")
-                    G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
-                elif npairs % 32 == 0:
-                    _capi.check(lib.pf_gemm_tn_sum2(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["x"].data_ptr(), 192, 192, dWf.data_ptr(), 192,
-                                                    npairs, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_sum2")
-                    G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
-                else:
-                    _, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y, need_dx=False)
-                    G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
-                _, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, need_dx=False)
-                if sv["x"] is None:
-                    dW1, w1z = _grad_buffer(192, 192, device=dev)
-                    db1, b1z = _grad_buffer(192, device=dev)
-                    _capi.check(lib.pf_gemm_tn_cat(g_h1.data_ptr(), 192, 192, None, sv["z"].data_ptr(), sv["n"].data_ptr(), B, L, dW1.data_ptr(), 192,
-                                                   int(w1z), db1.data_ptr(), int(b1z), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_cat")
-                    G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = dW1, db1
-                else:
-                    _, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, need_dx=False)
-            _side_run(dw_products, keep=(g_y, g_h2, g_h1))
+            # final_layer(h2 + x): dW = g_y^T (h2 + x) in ONE pass over g_y; with the virtual x (pf_gemm_tn_cat) also without reading an x
+            dWf, wz = _grad_buffer(64, 192, device=dev)
+            dbf, bz = _grad_buffer(64, device=dev)
+            ws = _tn_workspace(dev)
+            if sv["x"] is None:
+                _capi.check(lib.pf_gemm_tn_cat(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["z"].data_ptr(), sv["n"].data_ptr(), B, L,
+                                               dWf.data_ptr(), 192, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()),
+                            "pf_gemm_tn_cat")
+                G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
+            elif npairs % 32 == 0:
+                _capi.check(lib.pf_gemm_tn_sum2(g_y.data_ptr(), 64, 64, sv["h2"].data_ptr(), sv["x"].data_ptr(), 192, 192, dWf.data_ptr(), 192,
+                                                npairs, int(wz), dbf.data_ptr(), int(bz), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_sum2")
+                G[p + "final_layer.weight"], G[p + "final_layer.bias"] = dWf, dbf
+            else:
+                _, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y, need_dx=False)
+                G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
+            _, G[p + "trunk.2.weight"], G[p + "trunk.2.bias"] = linear_bwd(sv["h1"], W[p + "trunk.2.weight"], g_h2, need_dx=False)
+            if sv["x"] is None:
+                dW1, w1z = _grad_buffer(192, 192, device=dev)
+                db1, b1z = _grad_buffer(192, device=dev)
+                _capi.check(lib.pf_gemm_tn_cat(g_h1.data_ptr(), 192, 192, None, sv["z"].data_ptr(), sv["n"].data_ptr(), B, L, dW1.data_ptr(), 192,
+                                               int(w1z), db1.data_ptr(), int(b1z), ws.data_ptr(), ws.numel(), _capi.stream_ptr()), "pf_gemm_tn_cat")
+                G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = dW1, db1
+            else:
+                _, G[p + "trunk.0.weight"], G[p + "trunk.0.bias"] = linear_bwd(sv["x"], W[p + "trunk.0.weight"], g_h1, need_dx=False)
         else:
             g_u, dWf, G[p + "final_layer.bias"] = linear_bwd(sv["h2"], W[p + "final_layer.weight"], g_y)
             G[p + "final_layer.weight"] = dw_accumulate(sv["x"], g_y, dWf)
@@ -1035,11 +969,6 @@ class TrunkTrainer:
 
     def backward(self, g_rot, g_trans, g_ang, g_logits):
         lib, B, L, sd, st = _capi.load(), self.B, self.L, self.sd, _capi.stream_ptr()
-        with SideLane(self.mask.device):
-            return self._backward(g_rot, g_trans, g_ang, g_logits)
-
-    def _backward(self, g_rot, g_trans, g_ang, g_logits):
-        lib, B, L, sd, st = _capi.load(), self.B, self.L, self.sd, _capi.stream_ptr()
         rows, dev = B * L, self.mask.device
         G = {}
         s = self.saved["s_final"]
@@ -1093,11 +1022,6 @@ class TrunkTrainer:
 
 # ------------------------------------------------------------------------------------------------- encoder (node.py / edge.py)
 def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
-    with SideLane(g_node.device):
-        return _encoder_backward(model_sd, saved, g_node, g_edge, B, L)
-
-
-def _encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     """Backward of NodeEmbedder / EdgeEmbedder (flow_model.py:75-93) from d/d node_embed [rows,128], d/d edge_embed [pairs,64]
     and the intermediates featurize.encode(..., save=saved) recorded.  model_sd: {full parameter name -> fp32 device tensor}.
     Inputs of the encoder are data, so only parameter gradients are produced."""
@@ -1112,26 +1036,24 @@ def _encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     _capi.check(lib.pf_edge_index(saved["aa"].data_ptr(), saved["res_nb"].data_ptr(), saved["chain_nb"].data_ptr(), saved["ctx"].data_ptr(),
                                   saved["mres"].data_ptr(), saved["sample_structure"], saved["sample_sequence"], aap.data_ptr(), rel.data_ptr(),
                                   same.data_ptr(), sp.data_ptr(), mp.data_ptr(), aa_node.data_ptr(), B, L, st), "pf_edge_index")
+    # ---- node embedder: MLP 1157 -> 256 -> 128 -> 128 -> 128, * mres
     w = lambda k: model_sd[k]
-    # ---- node embedder: MLP 1157 -> 256 -> 128 -> 128 -> 128, * mres -- a chain of row-sized launches, independent of the edge embedder's pair-sized ones: second stream
-    def node_embedder_bwd():
-        g = row_mask_(g_node.clone(), saved["mres"])
-        g2, G["node_embedder.mlp.6.weight"], G["node_embedder.mlp.6.bias"] = linear_bwd(saved["n_h2"], w("node_embedder.mlp.6.weight"), g, dx_gate=saved["n_h2"])
-        g1, G["node_embedder.mlp.4.weight"], G["node_embedder.mlp.4.bias"] = linear_bwd(saved["n_h1"], w("node_embedder.mlp.4.weight"), g2, dx_gate=saved["n_h1"])
-        g0, G["node_embedder.mlp.2.weight"], G["node_embedder.mlp.2.bias"] = linear_bwd(saved["n_h0"], w("node_embedder.mlp.2.weight"), g1, dx_gate=saved["n_h0"])
-        w0 = w("node_embedder.mlp.0.weight")                        # [256,1157]; feat rows are 1168 wide
-        K = w0.shape[1]
-        g_feat = e(rows, 128)
-        _gemm(g0, 256, 1, w0, K, 1, g_feat, rows, 128, 256, ldc=128)              # only the aa-embedding columns are needed
-        dW0 = e(256, K)
-        _gemm(g0, 1, 256, saved["feat"], 1168, 1, dW0, 256, K, rows)
-        db0 = e(256)
-        _capi.check(lib.pf_colsum_f32(g0.data_ptr(), 256, rows, 256, db0.data_ptr(), 0, _capi.stream_ptr()), "pf_colsum_f32")
-        G["node_embedder.mlp.0.weight"], G["node_embedder.mlp.0.bias"] = dW0, db0
-        tg = e(22, 128)
-        _capi.check(lib.pf_embedding_bwd(g_feat.data_ptr(), 128, aa_node.data_ptr(), rows, 22, 128, tg.data_ptr(), _capi.stream_ptr()), "pf_embedding_bwd")
-        G["node_embedder.aatype_embed.weight"] = tg
-    _side_run(node_embedder_bwd, keep=(g_node, aa_node))
+    g = row_mask_(g_node.clone(), saved["mres"])
+    g2, G["node_embedder.mlp.6.weight"], G["node_embedder.mlp.6.bias"] = linear_bwd(saved["n_h2"], w("node_embedder.mlp.6.weight"), g, dx_gate=saved["n_h2"])
+    g1, G["node_embedder.mlp.4.weight"], G["node_embedder.mlp.4.bias"] = linear_bwd(saved["n_h1"], w("node_embedder.mlp.4.weight"), g2, dx_gate=saved["n_h1"])
+    g0, G["node_embedder.mlp.2.weight"], G["node_embedder.mlp.2.bias"] = linear_bwd(saved["n_h0"], w("node_embedder.mlp.2.weight"), g1, dx_gate=saved["n_h0"])
+    w0 = w("node_embedder.mlp.0.weight")                        # [256,1157]; feat rows are 1168 wide
+    K = w0.shape[1]
+    g_feat = e(rows, 128)
+    _gemm(g0, 256, 1, w0, K, 1, g_feat, rows, 128, 256, ldc=128)              # only the aa-embedding columns are needed
+    dW0 = e(256, K)
+    _gemm(g0, 1, 256, saved["feat"], 1168, 1, dW0, 256, K, rows)
+    db0 = e(256)
+    _capi.check(lib.pf_colsum_f32(g0.data_ptr(), 256, rows, 256, db0.data_ptr(), 0, st), "pf_colsum_f32")
+    G["node_embedder.mlp.0.weight"], G["node_embedder.mlp.0.bias"] = dW0, db0
+    tg = e(22, 128)
+    _capi.check(lib.pf_embedding_bwd(g_feat.data_ptr(), 128, aa_node.data_ptr(), rows, 22, 128, tg.data_ptr(), st), "pf_embedding_bwd")
+    G["node_embedder.aatype_embed.weight"] = tg
     # ---- edge embedder
     ge = row_mask_(g_edge.clone(), mp)
     g_o2, G["edge_embedder.out_mlp.4.weight"], G["edge_embedder.out_mlp.4.bias"] = linear_bwd(saved["o2"], w("edge_embedder.out_mlp.4.weight"), ge, dx_gate=saved["o2"])
