@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 47
+#define PF_ABI_VERSION 48
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -394,9 +394,13 @@ typedef struct {
     float* out;                 /* [B,L,L,64] */
     int B, L;
     int sample_structure, sample_sequence;
-    /* optional (training path): intermediates the backward needs, per pair: Gaussian features [225], squared
-     * distances/100 [225], distance_embed.0 output [64], the 224-wide concat tile, out_mlp.0 / .2 outputs [64] */
+    /* optional (training path): intermediates the backward needs, per pair: Gaussian features [225], distance_embed.0 output
+     * [64], the 224-wide concat tile, out_mlp.0 / .2 outputs [64].  dump_d2 is no longer written (ABI 48): pf_edge_distcoef_bwd
+     * takes the squared distances from the features themselves; the field keeps the struct layout. */
     float* dump_g; float* dump_d2; float* dump_h1; float* dump_cat; float* dump_o1; float* dump_o2;
+    /* optional workspace of 484*225 floats: when set, softplus(distcoef) is tabulated there first (one small launch) and the pair
+     * kernel reads the table instead of evaluating log1p(exp(.)) per (pair, atom pair) -- same values */
+    float* softplus_ws;
 } pf_edge_feat_args;
 int pf_edge_features_fwd(const pf_edge_feat_args* a, pf_stream_t stream);
 
@@ -610,7 +614,11 @@ int pf_embedding_bwd_atomic(const float* g, int ldg, const int* idx, const float
                             pf_stream_t stream);
 int pf_slice_relu_mask(const float* src, int lds, int off, const float* ref, int ldr, int off_r, const float* rowscale, float* dst,
                        long long rows, int width, pf_stream_t stream);
-int pf_edge_distcoef_bwd(const float* g_g, const float* gfeat, const float* d2, const int* aap, const float* w, long long pairs,
+/* table_grad [484,225] += d/d aapair_to_distcoef.weight (edge.py:83-89): g_g [pairs, ldg >= 225] = gradient of the Gaussian features,
+ * gfeat [pairs,225] = the features themselves (pf_edge_feat_args.dump_g: g = exp(-softplus(w) d2) * mask), aap [pairs] pair-type rows
+ * (pf_edge_index), w = the coefficient table, ratio_ws = workspace of 484*225 floats.  The squared distance is taken from the feature
+ * itself (-d2 = ln(g) / softplus(w) where g != 0), so the forward does not store it. */
+int pf_edge_distcoef_bwd(const float* g_g, int ldg, const float* gfeat, const int* aap, const float* w, float* ratio_ws, long long pairs,
                          float* table_grad, pf_stream_t stream);
 /* EdgeTransition in unfused (saved-activation) form for the training path: x [B*L*L,192] = [z_ij | n_i | n_j]
  * (ipa_pytorch.py:236-243), emask [B*L*L] = m_i m_j (optional); and the reverse scatter g_z (+)= g_x[:, :64],
@@ -638,6 +646,9 @@ typedef struct {
     float* g_bias; float* g_pz; float* g_z; int accumulate_gz;
     const float* g_qp; const float* g_kp; const float* g_vp; float* g_proj;
     int B, L;
+    /* optional (pf_ipa_bwd_pairs): [pairs,24] = g_bias (8) | g_pz (16) per pair in ONE tensor instead of g_bias / g_pz (which may
+     * then be NULL): the parameter gradients of linear_b and down_z (ipa_pytorch.py:352,355) become one [24,64] product over z */
+    float* g_bp;
 } pf_ipa_bwd_args;
 int pf_ipa_bwd_rows(const pf_ipa_bwd_args* a, pf_stream_t stream);
 /* the same stage from SAVED probabilities (a->P written by pf_ipa_attn_fwd, p_out) and batched GEMMs issued by the host

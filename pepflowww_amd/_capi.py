@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -115,7 +115,7 @@ class IpaBwdArgs(C.Structure):
                 ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp), ("head_w", _fp), ("g_feats", _fp),
                 ("P", _fp), ("gA", _fp), ("g_opt", _fp), ("g_frame_rows", _fp), ("g_gamma_rows", _fp),
                 ("g_bias", _fp), ("g_pz", _fp), ("g_z", _fp), ("accumulate_gz", _i),
-                ("g_qp", _fp), ("g_kp", _fp), ("g_vp", _fp), ("g_proj", _fp), ("B", _i), ("L", _i)]
+                ("g_qp", _fp), ("g_kp", _fp), ("g_vp", _fp), ("g_proj", _fp), ("B", _i), ("L", _i), ("g_bp", _fp)]
 
 
 class FullAtomArgs(C.Structure):
@@ -142,7 +142,8 @@ class EdgeFeatArgs(C.Structure):
                 ("w_d0", _fp), ("b_d0", _fp), ("w_d2", _fp), ("b_d2", _fp), ("w_o0", _fp), ("b_o0", _fp),
                 ("w_o2", _fp), ("b_o2", _fp), ("w_o4", _fp), ("b_o4", _fp), ("out", _fp), ("B", _i), ("L", _i),
                 ("sample_structure", _i), ("sample_sequence", _i),
-                ("dump_g", _fp), ("dump_d2", _fp), ("dump_h1", _fp), ("dump_cat", _fp), ("dump_o1", _fp), ("dump_o2", _fp)]
+                ("dump_g", _fp), ("dump_d2", _fp), ("dump_h1", _fp), ("dump_cat", _fp), ("dump_o1", _fp), ("dump_o2", _fp),
+                ("softplus_ws", _fp)]
 
 
 class NodeHeadArgs(C.Structure):
@@ -217,7 +218,7 @@ _SIGNATURES = {
     "pf_edge_index": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_embedding_bwd_atomic": ([_fp, _i, _fp, _fp, C.c_longlong, _i, _fp, _fp], _i),
     "pf_slice_relu_mask": ([_fp, _i, _i, _fp, _i, _i, _fp, _fp, C.c_longlong, _i, _fp], _i),
-    "pf_edge_distcoef_bwd": ([_fp, _fp, _fp, _fp, _fp, C.c_longlong, _fp, _fp], _i),
+    "pf_edge_distcoef_bwd": ([_fp, _i, _fp, _fp, _fp, _fp, C.c_longlong, _fp, _fp], _i),
     "pf_et_concat": ([_fp, _fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_et_concat_bwd": ([_fp, _fp, _i, _fp, _i, _i, _fp], _i),
     "pf_ipa_bwd_rows": ([C.POINTER(IpaBwdArgs), _fp], _i),

@@ -52,6 +52,8 @@ def _gemm(*args, **kw):
     _capi.check(_capi.load().pf_gemm_f32(C.byref(_gemm_args(*args, **kw)), _capi.stream_ptr()), "pf_gemm_f32")
 
 
+TRAIN_ATTN_TWO_KERNEL = os.environ.get("PF_TRAIN_ATTN2", "0") == "1"   # dev A/B: the two-kernel attention forward below 256 query tiles too
+PAIR_DW_MERGED = os.environ.get("PF_PAIR_DW_MERGED", "1") != "0"   # dW of linear_b and down_z as one [24,64] product (A/B switch)
 GROUP_GEMM = os.environ.get("PF_GROUP_GEMM", "1") != "0"    # independent products of the IPA backward in one launch (A/B switch)
 GEMM_GROUP_MAX = 6
 
@@ -622,7 +624,7 @@ class IpaBlock:
         # pair bias sqrt(1/3)(W_b z + b_b) [B,8,L,L] in its own pass -- which makes pf_ipa_attn_fwd pick its two-kernel form (z is then
         # read once by the attention instead of twice) -- from 256 query tiles up; below that the one-kernel form, which computes the
         # bias itself, measures faster in the training step (B=16, L=128: 16.5 vs 16.9 ms per step)
-        if B * ((L + 15) // 16) >= 256 and 64 <= L <= 256:
+        if (B * ((L + 15) // 16) >= 256 or TRAIN_ATTN_TWO_KERNEL) and 64 <= L <= 256:
             pbias = torch.empty(B, 8, L, L, device=dev)
             _capi.check(lib.pf_pair_bias_fwd(z.data_ptr(), W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(),
                                              pbias.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
@@ -644,7 +646,8 @@ class IpaBlock:
         e = lambda *shape: torch.empty(*shape, device=dev)
         P, gA = sv["P"], e(B, 8, L, L)
         g_opt, g_frame, g_gam = e(rows, 288), e(rows, 12), e(rows, 8)
-        g_bias, g_pz = e(rows * L, 8), e(rows * L, 16)
+        g_bp = e(rows * L, 24) if PAIR_DW_MERGED else None       # g_bias | g_pz per pair
+        g_bias, g_pz = (None, None) if PAIR_DW_MERGED else (e(rows * L, 8), e(rows * L, 16))
         acc_z = g_z is not None
         if g_z is None:
             g_z = e(rows * L, 64)
@@ -656,7 +659,11 @@ class IpaBlock:
         a.w_b, a.b_b, a.w_dz, a.b_dz = W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(), W[p + "down_z.weight"].data_ptr(), W[p + "down_z.bias"].data_ptr()
         a.head_w, a.g_feats = W[p + "head_weights"].data_ptr(), g_feats.data_ptr()
         a.P, a.gA, a.g_opt, a.g_frame_rows, a.g_gamma_rows = P.data_ptr(), gA.data_ptr(), g_opt.data_ptr(), g_frame.data_ptr(), g_gam.data_ptr()
-        a.g_bias, a.g_pz, a.g_z, a.accumulate_gz = g_bias.data_ptr(), g_pz.data_ptr(), g_z.data_ptr(), int(acc_z)
+        if g_bp is not None:
+            a.g_bp = g_bp.data_ptr()
+        else:
+            a.g_bias, a.g_pz = g_bias.data_ptr(), g_pz.data_ptr()
+        a.g_z, a.accumulate_gz = g_z.data_ptr(), int(acc_z)
         a.g_qp, a.g_kp, a.g_vp, a.g_proj, a.B, a.L = g_qp.data_ptr(), g_kp.data_ptr(), g_vp.data_ptr(), g_proj.data_ptr(), B, L
         st = _capi.stream_ptr()
         LL, ldp = L * L, 3744
@@ -687,13 +694,22 @@ class IpaBlock:
             _gemm_args(gA, L, 1, sv["kp"], 192, 1, g_qp, L, 24, L, ldc=192, batch=(B, 8, bAh, (L * 192, 24), (L * 192, 24)))])
         _capi.check(lib.pf_ipa_bwd_points(C.byref(a), st), "pf_ipa_bwd_points")
         # parameters of the pair projections: dW_b = g_bias^T z, dW_dz = g_pz^T z (K = pairs)
-        for nm, gb, n in (("linear_b", g_bias, 8), ("down_z", g_pz, 16)):
-            dW = e(n, 64)
-            db, zeroed = _grad_buffer(n, device=dev)
+        if g_bp is not None:       # both in ONE [24,64] product over z (one pass over the pair tensor instead of two)
+            dW = e(24, 64)
+            db, zeroed = _grad_buffer(24, device=dev)
             if not zeroed:
-                db = _zeros(n, device=dev)
-            _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L, rowsum=db)          # db = column sums of gb from the same pass
-            G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
+                db = _zeros(24, device=dev)
+            _gemm(g_bp, 1, 24, sv["z"], 64, 1, dW, 24, 64, rows * L, rowsum=db)      # db = column sums of g_bp from the same pass
+            G[p + "linear_b.weight"], G[p + "linear_b.bias"] = dW[:8], db[:8]
+            G[p + "down_z.weight"], G[p + "down_z.bias"] = dW[8:], db[8:]
+        else:
+            for nm, gb, n in (("linear_b", g_bias, 8), ("down_z", g_pz, 16)):
+                dW = e(n, 64)
+                db, zeroed = _grad_buffer(n, device=dev)
+                if not zeroed:
+                    db = _zeros(n, device=dev)
+                _gemm(gb, 1, n, sv["z"], 64, 1, dW, n, 64, rows * L, rowsum=db)          # db = column sums of gb from the same pass
+                G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
         gg = e(8)
         _capi.check(lib.pf_colsum_f32(g_gam.data_ptr(), 8, rows, 8, gg.data_ptr(), 0, st), "pf_colsum_f32")
         ghw = e(8)
@@ -1079,9 +1095,18 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     _capi.check(lib.pf_slice_relu_mask(g_cat.data_ptr(), 224, 128, saved["cat"].data_ptr(), 224, 128, sp.data_ptr(), g_fd.data_ptr(), P, 64, st),
                 "pf_slice_relu_mask")
     g_h1, G["edge_embedder.distance_embed.2.weight"], G["edge_embedder.distance_embed.2.bias"] = linear_bwd(saved["h1"], w("edge_embedder.distance_embed.2.weight"), g_fd, dx_gate=saved["h1"])
-    g_g, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], w("edge_embedder.distance_embed.0.weight"), g_h1)
+    wd0 = w("edge_embedder.distance_embed.0.weight")            # [64,225]
+    if _split_ok(P, 64):
+        # d g = g_h1 W on the split-precision kernel into rows of 228 floats (225 is not a multiple of 4: the generic fp32 product
+        # took 212 us at 262144 pairs); the weight / bias gradients from their own product
+        g_g = e(P, 228)
+        _linear_split(g_h1, wd0, w_transposed=True, out=g_g)
+        _, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], wd0, g_h1, need_dx=False)
+    else:
+        g_g, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], wd0, g_h1)
     t_c = _zeros(484, 225, device=dev)
-    _capi.check(lib.pf_edge_distcoef_bwd(g_g.data_ptr(), saved["g"].data_ptr(), saved["d2"].data_ptr(), aap.data_ptr(),
-                                         w("edge_embedder.aapair_to_distcoef.weight").data_ptr(), P, t_c.data_ptr(), st), "pf_edge_distcoef_bwd")
+    _capi.check(lib.pf_edge_distcoef_bwd(g_g.data_ptr(), g_g.shape[1], saved["g"].data_ptr(), aap.data_ptr(),
+                                         w("edge_embedder.aapair_to_distcoef.weight").data_ptr(), e(484, 225).data_ptr(), P, t_c.data_ptr(), st),
+                "pf_edge_distcoef_bwd")
     G["edge_embedder.aapair_to_distcoef.weight"] = t_c
     return G

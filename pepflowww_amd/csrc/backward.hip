@@ -1589,8 +1589,20 @@ __global__ __launch_bounds__(256) void slice_relu_mask_kernel(const float* src, 
 // atomic per (pair, atom pair) (59 M of them at 262144 pairs: 174 us).  Rows outside the block (a chunk that straddles two
 // residues) go to global memory directly.
 constexpr int DC_CHUNK = 128;
-__global__ __launch_bounds__(256) void edge_distcoef_bwd_kernel(const float* g_g, const float* gfeat, const float* d2, const int* aap,
-                                                                const float* w, long long pairs, float* tg) {
+// ratio[row][e] = sigmoid(w) / softplus(w) of the coefficient table (484 x 225 entries; softplus as the forward forms it)
+__global__ __launch_bounds__(256) void distcoef_ratio_kernel(const float* __restrict__ w, float* __restrict__ ratio, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    const float c = x > 20.f ? x : log1pf(expf(x));
+    ratio[i] = 1.f / ((1.f + expf(-x)) * c);
+}
+// The feature is g = exp(-c d2) m with c = softplus(w[row][e]) and an atom-pair mask m in {0, 1}; d g / d w = -d2 g sigmoid(w).  The
+// squared distance is not stored by the forward any more (it was a second [pairs,225] dump, written and read back once per step):
+// where g != 0, -d2 = ln(g) / c, so the contribution is g_g * g ln(g) * sigmoid(w) / softplus(w) -- two streamed operands and a
+// 436 KB table instead of three operands, no expf per element.  (g == 0: masked or underflowed, contributes nothing either way.)
+__global__ __launch_bounds__(256) void edge_distcoef_bwd_kernel(const float* g_g, int ldg, const float* gfeat, const int* aap, const float* ratio,
+                                                                long long pairs, float* tg) {
     __shared__ float T[22 * 225];
     __shared__ int AP[DC_CHUNK];
     const long long p0 = (long long)blockIdx.x * DC_CHUNK;
@@ -1602,9 +1614,11 @@ __global__ __launch_bounds__(256) void edge_distcoef_bwd_kernel(const float* g_g
     const size_t e0 = (size_t)p0 * 225;
     for (int t = threadIdx.x; t < np * 225; t += 256) {
         const int pl = t / 225, e = t - pl * 225;
+        const float gf = gfeat[e0 + t];
+        const float gg = g_g[(size_t)(p0 + pl) * ldg + e];
         const int row = AP[pl];
         const size_t wi = (size_t)row * 225 + e;
-        const float v = g_g[e0 + t] * gfeat[e0 + t] * (-d2[e0 + t]) / (1.f + expf(-w[wi]));
+        const float v = gf > 0.f ? gg * (gf * logf(gf)) * ratio[wi] : 0.f;
         if (v != 0.f) {
             const int slot = row - base;
             if (slot >= 0 && slot < 22) atomicAdd(&T[slot * 225 + e], v);
@@ -1671,11 +1685,12 @@ extern "C" int pf_slice_relu_mask(const float* src, int lds_, int off, const flo
     PF_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int pf_edge_distcoef_bwd(const float* g_g, const float* gfeat, const float* d2, const int* aap, const float* w, long long pairs,
+extern "C" int pf_edge_distcoef_bwd(const float* g_g, int ldg, const float* gfeat, const int* aap, const float* w, float* ratio_ws, long long pairs,
                                     float* table_grad, pf_stream_t stream) {
-    if (!g_g || !gfeat || !d2 || !aap || !w || !table_grad || pairs <= 0) return PF_E_BADARG;
-    hipLaunchKernelGGL(edge_distcoef_bwd_kernel, dim3((unsigned)((pairs + DC_CHUNK - 1) / DC_CHUNK)), dim3(256), 0, (hipStream_t)stream, g_g, gfeat, d2, aap,
-                       w, pairs, table_grad);
+    if (!g_g || !gfeat || !aap || !w || !ratio_ws || !table_grad || pairs <= 0 || ldg < 225) return PF_E_BADARG;
+    hipLaunchKernelGGL(distcoef_ratio_kernel, dim3((484 * 225 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, ratio_ws, 484 * 225);
+    hipLaunchKernelGGL(edge_distcoef_bwd_kernel, dim3((unsigned)((pairs + DC_CHUNK - 1) / DC_CHUNK)), dim3(256), 0, (hipStream_t)stream, g_g, ldg, gfeat,
+                       aap, ratio_ws, pairs, table_grad);
     PF_CHECK_LAUNCH();
     return 0;
 }

@@ -12,6 +12,7 @@
 // rounding noise.  To reproduce the reference's value the cross product and the dot product follow
 // ATen's CPU op sequence exactly: cross_k = fma(a_i, b_j, -(a_j*b_i)), dot = (m0 + m1) + m2
 // (verified bitwise against torch 2.10 CPU).  Compiled with -ffp-contract=off.
+#include <type_traits>
 #include "common.h"
 #include "../../include/pepflow_hip.h"
 
@@ -145,17 +146,21 @@ __global__ __launch_bounds__(256) void node_features_kernel(pf_node_feat_args a)
 // ------------------------------------------------------------------------------------------------
 // edge features + MLPs: 32 flattened pairs per workgroup, 8 threads per pair
 // ------------------------------------------------------------------------------------------------
-constexpr int EP = 32;      // pairs per workgroup: 49 KB of LDS (80 KB with the training dumps) = 3 (2) workgroups per CU; with 64 pairs it was one,
+constexpr int EP = 32;      // pairs per workgroup: 49 KB of LDS = 3 workgroups per CU (the training dumps go out from the same tiles); with 64 pairs it was one,
                             // i.e. one wave per SIMD for a kernel that is a chain of dependent phases (1.15 ms at 262144 pairs)
 constexpr int LDF = 244;     // 240 + 4   (feature tile / concat tile row stride)
 constexpr int LDH = 68;
+
+__global__ __launch_bounds__(256) void softplus_table_kernel(const float* __restrict__ w, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = softplus_t(w[i]);
+}
 
 __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a, long long npairs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ft = smem;                       // [EP][LDF] distance features, later the 224-wide concat tile
     float* H1 = smem + EP * LDF;            // [EP][LDH]
     float* H2 = H1 + EP * LDH;              // [EP][LDH]
-    float* D2 = H2 + EP * LDH;              // [EP][LDF] squared distances (training dumps only: allocated when dump_d2 is set)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int L = a.L;
@@ -178,12 +183,14 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
     const int aap = aa_of(pi) * 22 + aa_of(pj);
     const float spair = a.sample_structure ? a.ctx[pi] * a.ctx[pj] : 1.f;
 
-    // training path: optional dumps of the intermediates the backward needs (whole LDS tiles, cooperative copy)
-    auto dump_tile = [&](float* dst, const float* tile, int ld, int width, int dst_ld) {
+    // training path: optional dumps of the intermediates the backward needs (whole LDS tiles, cooperative copy; the width is a
+    // compile-time number: as a run-time one every element paid a 32-bit division)
+    auto dump_tile = [&](float* dst, const float* tile, int ld, auto width_c) {
+        constexpr int width = decltype(width_c)::value;
         if (!dst) return;
         for (int idx = tid; idx < EP * width; idx += 256) {
             const int row = idx / width, c = idx - row * width;
-            if (p0 + row < npairs) dst[(p0 + row) * dst_ld + c] = tile[row * ld + c];
+            if (p0 + row < npairs) dst[(p0 + row) * width + c] = tile[row * ld + c];
         }
     };
     // ---- phase 1: Gaussian atom-pair distances (edge.py:83-89) ----
@@ -205,7 +212,8 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
 #pragma unroll
         for (int q = 0; q < 15; ++q) stg[sub + 8 * q] = t[q];
         __syncthreads();
-        const float* coef = a.distcoef + (size_t)aap * 225;
+        const bool tab = a.softplus_ws != nullptr;                  // softplus already applied (softplus_table_kernel)
+        const float* coef = (tab ? a.softplus_ws : a.distcoef) + (size_t)aap * 225;
         for (int e0 = sub; e0 < 240; e0 += 48) {
             float cf[6];
 #pragma unroll
@@ -218,17 +226,15 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
                     const int ai = e / A, bj = e - ai * A;
                     const float dx = stg[ai * 3] - stg[45 + bj * 3], dy = stg[ai * 3 + 1] - stg[45 + bj * 3 + 1], dz = stg[ai * 3 + 2] - stg[45 + bj * 3 + 2];
                     const float d = sqrtf((dx * dx + dy * dy) + dz * dz) / 10.f;
-                    const float c = softplus_t(cf[u]);
+                    const float c = tab ? cf[u] : softplus_t(cf[u]);
                     v = expf((-1.f * c) * (d * d)) * (stg[90 + ai] * stg[105 + bj]);
-                    if (a.dump_d2) D2[prow * LDF + e] = d * d;     // through LDS: whole rows go out (4-byte stores 900 B apart otherwise)
                 }
                 Ft[prow * LDF + e] = v;
             }
         }
     }
     __syncthreads();
-    dump_tile(a.dump_g, Ft, LDF, 225, 225);
-    dump_tile(a.dump_d2, D2, LDF, 225, 225);
+    dump_tile(a.dump_g, Ft, LDF, std::integral_constant<int, 225>{});
 
     // ---- GEMM1: distance_embed.0 (225 -> 64) + ReLU ----
     {
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();      // Ft fully consumed, H1 complete
-    dump_tile(a.dump_h1, H1, LDH, 64, 64);
+    dump_tile(a.dump_h1, H1, LDH, std::integral_constant<int, 64>{});
 
     // ---- phase 2: concat tile [aa-pair 64 | relpos 64 | (dist, filled by GEMM2) 64 | dihedral code 26 | 0 x 6] ----
     {
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             }
     }
     __syncthreads();
-    dump_tile(a.dump_cat, Ft, LDF, 224, 224);
+    dump_tile(a.dump_cat, Ft, LDF, std::integral_constant<int, 224>{});
 
     // ---- GEMM3..5: out_mlp (218 -> 64 -> 64 -> 64) ----
     {
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             for (int e = 0; e < 4; ++e) H1[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();
-    dump_tile(a.dump_o1, H1, LDH, 64, 64);
+    dump_tile(a.dump_o1, H1, LDH, std::integral_constant<int, 64>{});
     {
         f32x4 acc[2][1];
         acc_zero<2, 1>(acc);
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(pf_edge_feat_args a,
             for (int e = 0; e < 4; ++e) H2[(mt * 16 + g * 4 + e) * LDH + n] = fmaxf(acc[mt][0][e] + bias, 0.f);
     }
     __syncthreads();
-    dump_tile(a.dump_o2, H2, LDH, 64, 64);
+    dump_tile(a.dump_o2, H2, LDH, std::integral_constant<int, 64>{});
     {
         f32x4 acc[2][1];
         acc_zero<2, 1>(acc);
@@ -364,12 +370,14 @@ extern "C" int pf_edge_features_fwd(const pf_edge_feat_args* a, pf_stream_t stre
     const long long npairs = (long long)a->B * a->L * a->L;
     const long long nblk = (npairs + EP - 1) / EP;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
-    const size_t lds = (size_t)(EP * LDF + 2 * EP * LDH + (a->dump_d2 ? EP * LDF : 0)) * sizeof(float);
+    const size_t lds = (size_t)(EP * LDF + 2 * EP * LDH) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)edge_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    if (a->softplus_ws)
+        hipLaunchKernelGGL(softplus_table_kernel, dim3((484 * 225 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a->distcoef, a->softplus_ws, 484 * 225);
     hipLaunchKernelGGL(edge_features_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *a, npairs);
     PF_CHECK_LAUNCH();
     return 0;

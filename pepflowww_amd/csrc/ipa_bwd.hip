@@ -193,8 +193,16 @@ __global__ __launch_bounds__(256) void ipa_bwd_pairs_kernel(pf_ipa_bwd_args a) {
     __syncthreads();
     const long long nvalid = min((long long)64, npairs - p0);
     // g_bias [pairs,8] and g_pz [pairs,16]: contiguous for the 64 pairs
-    if (tid < 128 && (tid >> 1) < nvalid) *reinterpret_cast<float4*>(a.g_bias + p0 * 8 + 4 * tid) = *reinterpret_cast<const float4*>(GB + 4 * tid);
-    if ((tid >> 2) < nvalid) *reinterpret_cast<float4*>(a.g_pz + p0 * 16 + 4 * tid) = *reinterpret_cast<const float4*>(GZ + 4 * tid);
+    if (a.g_bp) {                  // one [pairs,24] tensor (g_bias | g_pz per pair): 6 float4 per pair, 6144 contiguous bytes per workgroup
+        for (int t = tid; t < 6 * (int)nvalid; t += 256) {
+            const int pl = t / 6, c = t - pl * 6;
+            *reinterpret_cast<float4*>(a.g_bp + p0 * 24 + 4 * t) = c < 2 ? *reinterpret_cast<const float4*>(GB + pl * 8 + 4 * c)
+                                                                         : *reinterpret_cast<const float4*>(GZ + pl * 16 + 4 * (c - 2));
+        }
+    } else {
+        if (tid < 128 && (tid >> 1) < nvalid) *reinterpret_cast<float4*>(a.g_bias + p0 * 8 + 4 * tid) = *reinterpret_cast<const float4*>(GB + 4 * tid);
+        if ((tid >> 2) < nvalid) *reinterpret_cast<float4*>(a.g_pz + p0 * 16 + 4 * tid) = *reinterpret_cast<const float4*>(GZ + 4 * tid);
+    }
     const int c4 = tid & 15;
     float4 wb[8], wz[16];
 #pragma unroll
@@ -458,7 +466,7 @@ extern "C" int pf_ipa_bwd_softmax(const pf_ipa_bwd_args* a, pf_stream_t stream) 
     return 0;
 }
 extern "C" int pf_ipa_bwd_pairs(const pf_ipa_bwd_args* a, pf_stream_t stream) {
-    if (!args_ok(a) || !a->g_bias || !a->g_pz || !a->g_z) return PF_E_BADARG;
+    if (!args_ok(a) || (!a->g_bp && (!a->g_bias || !a->g_pz)) || !a->g_z) return PF_E_BADARG;
     const long long npairs = (long long)a->B * a->L * a->L;
     hipLaunchKernelGGL(ipa_bwd_pairs_kernel, dim3((unsigned)((npairs + 63) / 64)), dim3(256), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();

@@ -8,7 +8,11 @@ import ctypes as C
 import torch
 import torch.nn.functional as F
 
+import os
+
 from . import _capi
+
+SOFTPLUS_TABLE = os.environ.get("PF_SOFTPLUS_TABLE", "1") != "0"    # dev A/B switch
 
 
 def _f32(t):
@@ -109,12 +113,15 @@ def encode(model, batch, save=None, edge_out=None):
         edge = e(B, L, L, 64)
     ea.out, ea.B, ea.L = edge.data_ptr(), B, L
     ea.sample_structure, ea.sample_sequence = na.sample_structure, na.sample_sequence
+    sp_ws = e(484, 225) if SOFTPLUS_TABLE else None           # softplus(distcoef) tabulated once per call instead of per (pair, atom pair)
+    if sp_ws is not None:
+        ea.softplus_ws = sp_ws.data_ptr()
     if save is not None:
         P = B * L * L
-        dumps = dict(g=e(P, 225), d2=e(P, 225), h1=e(P, 64), cat=e(P, 224), o1=e(P, 64), o2=e(P, 64))
-        ea.dump_g, ea.dump_d2, ea.dump_h1 = dumps["g"].data_ptr(), dumps["d2"].data_ptr(), dumps["h1"].data_ptr()
+        # (the squared distances are not kept: pf_edge_distcoef_bwd takes them from the Gaussian features themselves)
+        dumps = dict(g=e(P, 225), h1=e(P, 64), cat=e(P, 224), o1=e(P, 64), o2=e(P, 64))
+        ea.dump_g, ea.dump_h1 = dumps["g"].data_ptr(), dumps["h1"].data_ptr()
         ea.dump_cat, ea.dump_o1, ea.dump_o2 = dumps["cat"].data_ptr(), dumps["o1"].data_ptr(), dumps["o2"].data_ptr()
-        dumps["d2"].fill_(0.0)
         save.update(dumps)
         save.update(feat=feat, n_h0=h0, n_h1=h1, n_h2=h2, mres=mres, ctx=ctx, aa=aa_c, res_nb=res_nb, chain_nb=chain_nb,
                     sample_structure=na.sample_structure, sample_sequence=na.sample_sequence)
