@@ -52,7 +52,7 @@ def _gemm(*args, **kw):
     _capi.check(_capi.load().pf_gemm_f32(C.byref(_gemm_args(*args, **kw)), _capi.stream_ptr()), "pf_gemm_f32")
 
 
-TRAIN_ATTN_TWO_KERNEL = os.environ.get("PF_TRAIN_ATTN2", "0") == "1"   # dev A/B: the two-kernel attention forward below 256 query tiles too
+TRAIN_ATTN_TWO_KERNEL = os.environ.get("PF_TRAIN_ATTN2", "1") != "0"   # the two-kernel attention forward below 256 query tiles too (A/B switch)
 PAIR_DW_MERGED = os.environ.get("PF_PAIR_DW_MERGED", "1") != "0"   # dW of linear_b and down_z as one [24,64] product (A/B switch)
 GROUP_GEMM = os.environ.get("PF_GROUP_GEMM", "1") != "0"    # independent products of the IPA backward in one launch (A/B switch)
 GEMM_GROUP_MAX = 6
@@ -622,8 +622,9 @@ class IpaBlock:
         P = torch.empty(B, 8, L, L, device=dev)                # attention probabilities, saved for the backward
         ia.p_out = P.data_ptr()
         # pair bias sqrt(1/3)(W_b z + b_b) [B,8,L,L] in its own pass -- which makes pf_ipa_attn_fwd pick its two-kernel form (z is then
-        # read once by the attention instead of twice) -- from 256 query tiles up; below that the one-kernel form, which computes the
-        # bias itself, measures faster in the training step (B=16, L=128: 16.5 vs 16.9 ms per step)
+        # read once by the attention instead of twice).  Below 256 query tiles the one-kernel form, which computes the bias itself,
+        # used to measure faster (B=16, L=128: 16.5 vs 16.9 ms per step) -- because the bias pass was a one-thread-per-pair kernel
+        # (106 us per block); with 16 lanes per pair the two-kernel form is 12.42 / 12.44 vs 12.52 / 12.57 ms (same box)
         if (B * ((L + 15) // 16) >= 256 or TRAIN_ATTN_TWO_KERNEL) and 64 <= L <= 256:
             pbias = torch.empty(B, 8, L, L, device=dev)
             _capi.check(lib.pf_pair_bias_fwd(z.data_ptr(), W[p + "linear_b.weight"].data_ptr(), W[p + "linear_b.bias"].data_ptr(),

@@ -1612,17 +1612,31 @@ __global__ __launch_bounds__(256) void edge_distcoef_bwd_kernel(const float* g_g
     __syncthreads();
     const int base = (AP[0] / 22) * 22;
     const size_t e0 = (size_t)p0 * 225;
-    for (int t = threadIdx.x; t < np * 225; t += 256) {
-        const int pl = t / 225, e = t - pl * 225;
-        const float gf = gfeat[e0 + t];
-        const float gg = g_g[(size_t)(p0 + pl) * ldg + e];
-        const int row = AP[pl];
-        const size_t wi = (size_t)row * 225 + e;
-        const float v = gf > 0.f ? gg * (gf * logf(gf)) * ratio[wi] : 0.f;
-        if (v != 0.f) {
-            const int slot = row - base;
-            if (slot >= 0 && slot < 22) atomicAdd(&T[slot * 225 + e], v);
-            else atomicAdd(tg + wi, v);
+    // four elements per thread and round: all twelve loads are requested before the first use (one element at a time every
+    // iteration was a dependent chain of three round trips)
+    const int n = np * 225;
+    for (int t0 = threadIdx.x; t0 < n; t0 += 4 * 256) {
+        float gf[4], gg[4], rt[4];
+        int ee[4], rw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(t0 + 256 * u, n - 1);
+            const int pl = t / 225;
+            ee[u] = t - pl * 225;
+            rw[u] = AP[pl];
+            gf[u] = gfeat[e0 + t];
+            gg[u] = g_g[(size_t)(p0 + pl) * ldg + ee[u]];
+            rt[u] = ratio[(size_t)rw[u] * 225 + ee[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t0 + 256 * u >= n) continue;
+            const float v = gf[u] > 0.f ? gg[u] * (gf[u] * logf(gf[u])) * rt[u] : 0.f;
+            if (v != 0.f) {
+                const int slot = rw[u] - base;
+                if (slot >= 0 && slot < 22) atomicAdd(&T[slot * 225 + ee[u]], v);
+                else atomicAdd(tg + (size_t)rw[u] * 225 + ee[u], v);
+            }
         }
     }
     __syncthreads();

@@ -1211,6 +1211,22 @@ def test_dual_gemm_equals_two_launches(M, N, K):
         assert (o[2].double() - ref_db).abs().max() <= 2e-5 * max(ref_db.abs().max(), 1.0)
 
 
+@pytest.mark.parametrize("B,L", [(2, 37), (3, 64), (1, 16)])
+def test_pair_bias_kernel(B, L):
+    """pf_pair_bias_fwd: sqrt(1/3) (linear_b(z)) as [B,8,L,L] (ipa_pytorch.py:391,404) against float64, pair counts that are not a
+    multiple of the 256-pair workgroup."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(B * 100 + L)
+    z, wb, bb = torch.randn(B, L, L, 64, generator=g), torch.randn(8, 64, generator=g) / 8, torch.randn(8, generator=g)
+    out = torch.full((B, 8, L, L), float("nan"), device=G.dev())
+    dz, dw, db = cu(z), cu(wb), cu(bb)
+    _capi.check(lib.pf_pair_bias_fwd(dz.data_ptr(), dw.data_ptr(), db.data_ptr(), out.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
+    G.sync()
+    ref = math.sqrt(1.0 / 3.0) * (torch.einsum("bijc,hc->bhij", z.double(), wb.double()) + bb.double().view(1, 8, 1, 1))
+    assert torch.isfinite(out).all()
+    assert (out.cpu().double() - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
 @pytest.mark.parametrize("Bn,L", [(3, 128), (2, 72)])
 def test_group_gemm_equals_separate_launches(Bn, L):
     """pf_gemm_f32_group (independent products in ONE grid) on the sample x head products of the IPA backward (g_k, g_v, g_q and the
