@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 48
+#define PF_ABI_VERSION 49
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -353,6 +353,10 @@ typedef struct {
      * kernel runs (csrc/edge_transition_v4.hip: tiles of 16 rows x 16 columns, pf_edge_transition_v4_tile_rows() for the work
      * list); everything else about the call is unchanged. */
     const void* w_stream32; const void* wb_frags32;
+    /* optional (with the dumps): the ReLU gates [h1 > 0] / [h2 > 0] as one bit per (pair, feature), [B*L*L,24] bytes each: byte
+     * 4 t + g of a pair holds the features 32 t + 16 h + 4 g + e at bit 4 h + e (t < 6, g < 4, h < 2, e < 4).  pf_et_bwd_chain
+     * (m1 / m2) gates with them instead of reading the 768-byte activations back. */
+    unsigned char* dump_m1; unsigned char* dump_m2;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */
@@ -545,6 +549,9 @@ typedef struct {
     const void* wfT_f16; const void* w2T_f16; const void* w1T_f16;
     float* g_h2; float* g_h1; float* g_x;
     long long npairs;
+    /* optional: the ReLU gates [h1 > 0], [h2 > 0] as bits, [npairs,24] bytes each (pf_edge_transition_args.dump_m1 / dump_m2); when both
+     * are set the kernel reads them instead of h1 / h2 (which may then be NULL): 48 bytes per pair instead of 1536 */
+    const unsigned char* m1; const unsigned char* m2;
 } pf_et_bwd_args;
 int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream);
 

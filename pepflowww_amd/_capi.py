@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 48
+ABI_VERSION = 49
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -63,7 +63,7 @@ class EdgeTransitionArgs(C.Structure):
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
                 ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp),
                 ("single_pass", _i), ("tile_list", _fp), ("n_tiles", _fp), ("z_in_f16", _i), ("z_out_f16", _i), ("dz_out", _fp), ("dz_out_f16", _i),
-                ("w_stream32", _fp), ("wb_frags32", _fp)]
+                ("w_stream32", _fp), ("wb_frags32", _fp), ("dump_m1", _fp), ("dump_m2", _fp)]
 
 
 class SamplerArgs(C.Structure):
@@ -166,7 +166,7 @@ class NodeTfmrArgs(C.Structure):
 
 class EtBwdArgs(C.Structure):
     _fields_ = [("g_y", _fp), ("h1", _fp), ("h2", _fp), ("wfT_f16", _fp), ("w2T_f16", _fp), ("w1T_f16", _fp),
-                ("g_h2", _fp), ("g_h1", _fp), ("g_x", _fp), ("npairs", C.c_longlong)]
+                ("g_h2", _fp), ("g_h1", _fp), ("g_x", _fp), ("npairs", C.c_longlong), ("m1", _fp), ("m2", _fp)]
 
 
 _SIGNATURES = {

@@ -52,6 +52,7 @@ def _gemm(*args, **kw):
     _capi.check(_capi.load().pf_gemm_f32(C.byref(_gemm_args(*args, **kw)), _capi.stream_ptr()), "pf_gemm_f32")
 
 
+ET_GATE_BITS = os.environ.get("PF_ET_GATE_BITS", "1") != "0"    # EdgeTransition backward: ReLU gates as bits from the forward (A/B switch)
 TRAIN_ATTN_TWO_KERNEL = os.environ.get("PF_TRAIN_ATTN2", "1") != "0"   # the two-kernel attention forward below 256 query tiles too (A/B switch)
 PAIR_DW_MERGED = os.environ.get("PF_PAIR_DW_MERGED", "1") != "0"   # dW of linear_b and down_z as one [24,64] product (A/B switch)
 GROUP_GEMM = os.environ.get("PF_GROUP_GEMM", "1") != "0"    # independent products of the IPA backward in one launch (A/B switch)
@@ -802,8 +803,12 @@ class EdgeTransitionBlock:
         a.b2, a.ln_g, a.ln_b = W[p + "trunk.2.bias"].data_ptr(), W[p + "layer_norm.weight"].data_ptr(), W[p + "layer_norm.bias"].data_ptr()
         a.mask, a.B, a.L, a.w_stream = self.mask.data_ptr(), B, L, stream.data_ptr()
         a.dump_h1, a.dump_h2, a.dump_y = h1.data_ptr(), h2.data_ptr(), y.data_ptr()
+        gm1 = gm2 = None
+        if ET_GATE_BITS and self.FUSED_BACKWARD:      # the ReLU gates as bits for the backward chain kernel (48 instead of 1536 bytes per pair read there)
+            gm1, gm2 = torch.empty(P, 24, dtype=torch.uint8, device=dev), torch.empty(P, 24, dtype=torch.uint8, device=dev)
+            a.dump_m1, a.dump_m2 = gm1.data_ptr(), gm2.data_ptr()
         _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
-        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, y=y, z=z, n=n)   # (u = h2 + x is not kept: the backward uses h2 and x separately)
+        self.saved = dict(s=s, x=x, em=em, h1=h1, h2=h2, y=y, z=z, n=n, gm1=gm1, gm2=gm2)   # (u = h2 + x is not kept: the backward uses h2 and x separately)
         return out
 
     def forward(self, s, z):
@@ -847,6 +852,8 @@ class EdgeTransitionBlock:
                         _split_pack(W[p + "trunk.0.weight"], transpose=True)]
             ea = _capi.EtBwdArgs()
             ea.g_y, ea.h1, ea.h2 = g_y.data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr()
+            if sv.get("gm1") is not None:
+                ea.m1, ea.m2 = sv["gm1"].data_ptr(), sv["gm2"].data_ptr()
             ea.wfT_f16, ea.w2T_f16, ea.w1T_f16 = (k.data_ptr() for k in keep)
             ea.g_h2, ea.g_h1, ea.g_x, ea.npairs = g_h2.data_ptr(), g_h1.data_ptr(), g_x.data_ptr(), npairs
             _capi.check(lib.pf_et_bwd_chain(C.byref(ea), _capi.stream_ptr()), "pf_et_bwd_chain")

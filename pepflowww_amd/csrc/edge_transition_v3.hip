@@ -171,6 +171,11 @@ __device__ __forceinline__ f32x4 add4(const float4& a, const float4& b) { return
 
 struct Tile { int b, i0, j0; };
 
+// the ReLU gates of a lane's eight features (two float4 of one pair) as bits 0..3 | 4..7 (pf_edge_transition_args.dump_m1 / dump_m2)
+__device__ __forceinline__ unsigned char gate_byte(const float4& v0, const float4& v1) {
+    return (unsigned char)((v0.x > 0.f ? 1u : 0u) | (v0.y > 0.f ? 2u : 0u) | (v0.z > 0.f ? 4u : 0u) | (v0.w > 0.f ? 8u : 0u) |
+                           (v1.x > 0.f ? 16u : 0u) | (v1.y > 0.f ? 32u : 0u) | (v1.z > 0.f ? 64u : 0u) | (v1.w > 0.f ? 128u : 0u));
+}
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
 // ZI / ZO (f16 mode only): the pair tensor is read / written as f16 (pf_edge_transition_args.z_in_f16 / z_out_f16)
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                     if (valid[p]) {
                         *reinterpret_cast<float4*>(a.dump_h1 + pidx[p] * 192 + 32 * tp + 4 * g) = v0;
                         *reinterpret_cast<float4*>(a.dump_h1 + pidx[p] * 192 + 32 * tp + 16 + 4 * g) = v1;
+                        if (a.dump_m1) a.dump_m1[pidx[p] * 24 + 4 * tp + g] = gate_byte(v0, v1);
                     }
                 }
                 split8<SP>(v0, v1, h1h[p][tp], h1l[p][tp]);
@@ -561,6 +567,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                     if (valid[p]) {
                         *reinterpret_cast<float4*>(a.dump_h2 + pidx[p] * 192 + 32 * c + 4 * g) = v0;
                         *reinterpret_cast<float4*>(a.dump_h2 + pidx[p] * 192 + 32 * c + 16 + 4 * g) = v1;
+                        if (a.dump_m2) a.dump_m2[pidx[p] * 24 + 4 * c + g] = gate_byte(v0, v1);
                     }
                 }
                 split8<SP>(v0, v1, xh, xl);

@@ -24,7 +24,11 @@ constexpr float LO_INV = PF_LO_INV;
 #ifndef PF_ETB_WGS
 #define PF_ETB_WGS 2                          // workgroups per CU the register budget is set for (2: 4 waves per SIMD, <= 128 VGPRs)
 #endif
-template <int P>
+// BITS: the ReLU gates come as one BIT per (pair, feature) (pf_et_bwd_args.m1 / m2, written by the forward kernel next to its h1 / h2
+// dumps) instead of being read off the saved activations themselves: 2 x 24 bytes per pair instead of 2 x 768; g_u is then not kept in
+// registers across the two long products either but formed a second time inside the last one (K = 64: +14 % matrix work): no scratch
+// (the 128-register form spilled 9 - 23 registers per thread = 75 - 190 MB of extra HBM traffic per launch, PMC WRITE_SIZE).
+template <int P, bool BITS>
 __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et_bwd_args a, long long npairs) {   // (HIP: the second bound is waves per SIMD)
     constexpr int NT = 512;
     constexpr int PT = P / 32;        // 16-pair tiles per wave (two pair halves)
@@ -59,13 +63,35 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
         pok[pt] = pr < npairs;
         prw[pt] = pok[pt] ? pr : npairs - 1;
     }
-    float4 m2[3][PT], m1[3][PT];                        // ReLU masks = the saved activations themselves
+    // ReLU masks: the saved activations themselves, or (BITS) the forward kernel's gate bytes: byte [pair][4 tp + g] holds the features
+    // 32 tp + 16 h + 4 g + e at bit 4 h + e.  This wave's three 16-feature tiles T = 3 wave + wt lie in bytes 4 tpA + g and 4 tpA + 4 + g
+    // (tpA = 3 wave >> 1): nibble 2 (T >> 1 - tpA) + (T & 1) of the two bytes
+    float4 m2[BITS ? 1 : 3][BITS ? 1 : PT], m1[BITS ? 1 : 3][BITS ? 1 : PT];
+    unsigned b2[PT], b1[PT];
+    const int tpA = (wave * 3) >> 1;
+    if constexpr (BITS) {
 #pragma unroll
-    for (int wt = 0; wt < 3; ++wt) {
-        const int n = wave * 48 + wt * 16 + 4 * g;
+        for (int pt = 0; pt < PT; ++pt) {
+            const unsigned char* mb = a.m2 + prw[pt] * 24 + 4 * tpA + g;
+            b2[pt] = (unsigned)mb[0] | ((unsigned)mb[4] << 8);
+        }
+    } else {
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) m2[wt][pt] = *reinterpret_cast<const float4*>(a.h2 + prw[pt] * HID + n);
+        for (int wt = 0; wt < 3; ++wt) {
+            const int n = wave * 48 + wt * 16 + 4 * g;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) m2[wt][pt] = *reinterpret_cast<const float4*>(a.h2 + prw[pt] * HID + n);
+        }
     }
+    auto gate4 = [&](const float4& h, unsigned bits, int T, const float (&v)[4], float (&w)[4]) {
+        if constexpr (BITS) {
+            const unsigned nb = bits >> (8 * ((T >> 1) - tpA) + 4 * (T & 1));       // (wave-uniform shift)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = ((nb >> e) & 1u) ? v[e] : 0.f;
+        } else {
+            w[0] = h.x > 0.f ? v[0] : 0.f; w[1] = h.y > 0.f ? v[1] : 0.f; w[2] = h.z > 0.f ? v[2] : 0.f; w[3] = h.w > 0.f ? v[3] : 0.f;
+        }
+    };
 #pragma unroll
     for (int q = 0; q < ZQ; ++q) {
         const int idx = tid + NT * q;
@@ -92,7 +118,7 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
     };
 
     // ---- product 1: g_u = Wf^T g_y (K = 64), three 16-feature sub-products per wave; g_u stays in registers ----
-    float4 gu[3][PT];
+    float4 gu[BITS ? 1 : 3][BITS ? 1 : PT];               // (BITS: not kept, see product 3)
 #pragma unroll
     for (int wt = 0; wt < 3; ++wt) {
         f32x4 am[1][PT], ac[1][PT];
@@ -104,9 +130,9 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
         for (int pt = 0; pt < PT; ++pt) {
             float v[4];
             joined(am[0][pt], ac[0][pt], v);
-            gu[wt][pt] = make_float4(v[0], v[1], v[2], v[3]);
-            const float4 h = m2[wt][pt];
-            const float w[4] = {h.x > 0.f ? v[0] : 0.f, h.y > 0.f ? v[1] : 0.f, h.z > 0.f ? v[2] : 0.f, h.w > 0.f ? v[3] : 0.f};
+            if constexpr (!BITS) gu[wt][pt] = make_float4(v[0], v[1], v[2], v[3]);
+            float w[4];
+            gate4(m2[BITS ? 0 : wt][BITS ? 0 : pt], b2[pt], wave * 3 + wt, v, w);
             if (pok[pt]) *reinterpret_cast<float4*>(a.g_h2 + prw[pt] * HID + n) = make_float4(w[0], w[1], w[2], w[3]);
             to_planes(wt, pt, w);
         }
@@ -118,7 +144,14 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
     for (int wt = 0; wt < 3; ++wt) {
         const int n = wave * 48 + wt * 16 + 4 * g;
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) m1[wt][pt] = *reinterpret_cast<const float4*>(a.h1 + prw[pt] * HID + n);
+        for (int pt = 0; pt < PT; ++pt) {
+            if constexpr (BITS) {
+                if (wt == 0) {
+                    const unsigned char* mb = a.m1 + prw[pt] * 24 + 4 * tpA + g;
+                    b1[pt] = (unsigned)mb[0] | ((unsigned)mb[4] << 8);
+                }
+            } else m1[wt][pt] = *reinterpret_cast<const float4*>(a.h1 + prw[pt] * HID + n);
+        }
     }
     {
         f32x4 am[3][PT], ac[3][PT];
@@ -133,8 +166,8 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
             for (int pt = 0; pt < PT; ++pt) {
                 float v[4];
                 joined(am[wt][pt], ac[wt][pt], v);
-                const float4 h = m1[wt][pt];
-                const float w[4] = {h.x > 0.f ? v[0] : 0.f, h.y > 0.f ? v[1] : 0.f, h.z > 0.f ? v[2] : 0.f, h.w > 0.f ? v[3] : 0.f};
+                float w[4];
+                gate4(m1[BITS ? 0 : wt][BITS ? 0 : pt], b1[pt], wave * 3 + wt, v, w);
                 if (pok[pt]) *reinterpret_cast<float4*>(a.g_h1 + prw[pt] * HID + n) = make_float4(w[0], w[1], w[2], w[3]);
                 to_planes(wt, pt, w);
             }
@@ -148,6 +181,17 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
         acc_zero<3, PT>(am);
         acc_zero<3, PT>(ac);
         gemm_split<3, PT, true>(a.w1T_f16, HID, HID, wave * 48, HID, Hh + prow0 * LDHh, Hl + prow0 * LDHh, LDHh, am, ac);
+        if constexpr (BITS) {                // g_u = Wf^T g_y once more, on top of the same accumulators (the g_y planes are still in LDS)
+#pragma unroll
+            for (int wt = 0; wt < 3; ++wt) {
+                f32x4 bm[1][PT], bc[1][PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) { bm[0][pt] = am[wt][pt]; bc[0][pt] = ac[wt][pt]; }
+                gemm_split<1, PT, true>(a.wfT_f16, HID, 64, wave * 48 + wt * 16, 64, Zh + prow0 * LDZh, Zl + prow0 * LDZh, LDZh, bm, bc);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) { am[wt][pt] = bm[0][pt]; ac[wt][pt] = bc[0][pt]; }
+            }
+        }
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
             const int n = wave * 48 + wt * 16 + 4 * g;
@@ -155,7 +199,7 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
             for (int pt = 0; pt < PT; ++pt) {
                 float v[4];
                 joined(am[wt][pt], ac[wt][pt], v);
-                const float4 u = gu[wt][pt];
+                const float4 u = BITS ? make_float4(0.f, 0.f, 0.f, 0.f) : gu[BITS ? 0 : wt][BITS ? 0 : pt];
                 if (pok[pt]) *reinterpret_cast<float4*>(a.g_x + prw[pt] * HID + n) = make_float4(v[0] + u.x, v[1] + u.y, v[2] + u.z, v[3] + u.w);
             }
         }
@@ -165,7 +209,9 @@ __global__ __launch_bounds__(512, 2 * PF_ETB_WGS) void et_bwd_chain_kernel(pf_et
 }  // namespace
 
 extern "C" int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream) {
-    if (!a || !a->g_y || !a->h1 || !a->h2 || !a->wfT_f16 || !a->w2T_f16 || !a->w1T_f16 || !a->g_h2 || !a->g_h1 || !a->g_x || a->npairs <= 0)
+    const bool bits = a && a->m1 && a->m2;
+    if (!a || !a->g_y || (!bits && (!a->h1 || !a->h2)) || (!a->m1) != (!a->m2) || !a->wfT_f16 || !a->w2T_f16 || !a->w1T_f16 || !a->g_h2 || !a->g_h1 ||
+        !a->g_x || a->npairs <= 0)
         return PF_E_BADARG;
 #ifndef PF_ETB_P
 #define PF_ETB_P 64                           // pairs per workgroup (64 or 32)
@@ -174,7 +220,8 @@ extern "C" int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream) {
     const long long nblk = (a->npairs + P - 1) / P;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
     const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16);
-    hipLaunchKernelGGL(et_bwd_chain_kernel<P>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, *a, a->npairs);
+    if (bits) hipLaunchKernelGGL((et_bwd_chain_kernel<P, true>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, *a, a->npairs);
+    else hipLaunchKernelGGL((et_bwd_chain_kernel<P, false>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, *a, a->npairs);
     PF_CHECK_LAUNCH();
     return 0;
 }

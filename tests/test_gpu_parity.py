@@ -1291,6 +1291,15 @@ def test_group_gemm_equals_separate_launches(Bn, L):
     assert torch.equal(y0.cpu(), y1.cpu()) and torch.equal(o2["g_kp"].cpu(), outs[0]["g_kp"])
 
 
+def _gate_bytes(h):
+    """[P,192] activations -> [P,24] uint8 of pf_edge_transition_args.dump_m1 / dump_m2: byte 4 t + g holds feature 32 t + 16 hh + 4 g + e
+    at bit 4 hh + e."""
+    P = h.shape[0]
+    bits = (h.reshape(P, 6, 2, 4, 4) > 0).to(torch.int32)                  # [P, t, hh, g, e]
+    wgt = (1 << (4 * torch.arange(2).view(1, 1, 2, 1, 1) + torch.arange(4).view(1, 1, 1, 1, 4))).to(torch.int32)
+    return (bits * wgt).sum(dim=(2, 4)).to(torch.uint8).reshape(P, 24).contiguous()          # [P, t, g] -> [P, 24]
+
+
 @pytest.mark.parametrize("npairs", [64 * 37, 64 * 20 + 13])
 def test_edge_transition_backward_chain(npairs):
     """pf_et_bwd_chain (g_y -> g_u -> gate h2 -> W2^T -> gate h1 -> W1^T + g_u in one kernel) against float64, incl. a ragged last
@@ -1318,6 +1327,18 @@ def test_edge_transition_backward_chain(npairs):
     for got, ref, name in zip(o, (r_h2, r_h1, r_x), ("g_h2", "g_h1", "g_x")):
         assert torch.isfinite(got).all(), name
         assert (got.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max(), name
+    # the ReLU gates as bits (pf_et_bwd_args.m1 / m2, 24 bytes per pair) instead of the activations, h1 / h2 not passed at all: the
+    # gated gradients bit for bit, g_x (whose skip term is then summed inside the matrix accumulators) against float64
+    o2 = [torch.full((npairs, 192), float("nan"), device=G.dev()) for _ in range(3)]
+    gm1, gm2 = cu(_gate_bytes(h1)), cu(_gate_bytes(h2))
+    b = _capi.EtBwdArgs()
+    b.g_y, b.m1, b.m2 = dg_y.data_ptr(), gm1.data_ptr(), gm2.data_ptr()
+    b.wfT_f16, b.w2T_f16, b.w1T_f16 = (k.data_ptr() for k in keep)
+    b.g_h2, b.g_h1, b.g_x, b.npairs = o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(), npairs
+    _capi.check(lib.pf_et_bwd_chain(C.byref(b), _capi.stream_ptr()), "pf_et_bwd_chain")
+    G.sync()
+    assert torch.equal(o[0].cpu(), o2[0].cpu()) and torch.equal(o[1].cpu(), o2[1].cpu())
+    assert torch.isfinite(o2[2]).all() and (o2[2].cpu().double() - r_x).abs().max() <= 2e-5 * r_x.abs().max()
     with pytest.raises(Exception):
         a.npairs = 0
         _capi.check(lib.pf_et_bwd_chain(C.byref(a), _capi.stream_ptr()), "pf_et_bwd_chain")
@@ -1738,6 +1759,8 @@ def test_fused_edge_transition_training_forward(seeded_sd, B, L):
     for k in ("h1", "h2", "y", "x", "em"):
         if sv1[k] is not None:
             assert (sv0[k] - sv1[k]).abs().max().item() <= 2e-5, k
+    if sv1.get("gm1") is not None:         # the gate bits the fused forward stores are exactly [h > 0] of the activations it stores
+        assert torch.equal(sv1["gm1"].cpu(), _gate_bytes(sv1["h1"].cpu())) and torch.equal(sv1["gm2"].cpu(), _gate_bytes(sv1["h2"].cpu()))
     assert (gs0 - gs1).abs().max() <= 1e-4 * gs0.abs().max() and (gz0 - gz1).abs().max() <= 1e-4 * gz0.abs().max()
     for k in G0:
         assert (G0[k] - G1[k]).abs().max() <= 1e-4 * G0[k].abs().max() + 1e-6, k
