@@ -394,6 +394,17 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
     asm volatile("" : "+s"(m1));
 
     for (int it = 0; it < my_tiles; ++it, tile += gridDim.x) {
+        // The lane indices are re-derived per tile from a copy the optimiser cannot see through: every lane-dependent address of the tile
+        // body (per-residue rows, masks, output rows) is then formed next to its use from ONE live register, instead of being hoisted
+        // out of the tile loop as ~14 loop-invariant registers -- which, at the 256-register budget, lived in SCRATCH and were re-loaded
+        // every tile: scratch loads share vmcnt with the z prefetch, so each of their waits drained the prefetch (s_waitcnt vmcnt(0)
+        // right behind the global loads of the next tile's z).
+#ifndef PF_ET4_HOIST                                             // (dev A/B: -DPF_ET4_HOIST = the hoisted / spilled form)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int n = lane_o & 31, g = lane_o >> 5;
+        const int jl = n & 15, rl = n >> 4;
+#endif
         tl = tile_of(tile);
         const bool have_next = it + 1 < my_tiles;
         Tile tn = tl;
