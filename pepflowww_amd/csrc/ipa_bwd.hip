@@ -227,76 +227,78 @@ __global__ __launch_bounds__(256) void ipa_bwd_pairs_kernel(pf_ipa_bwd_args a) {
     }
 }
 
-// one thread per (sample, head, residue) with the residue fastest: the column sums c_hj = sum_i g_a_hij are then coalesced
-// reads, the raw-projection gradients are disjoint per head, and the frame gradients of the 8 heads are added atomically
-// (one thread per residue looping over the heads ran 32 workgroups of one wave each: 330 us)
+// One workgroup per residue row r = (b, j), one thread per (head, point) -- 8 x (8 query + 8 key + 12 value) = 224 of the 256: the raw
+// projections and their gradients are then read / written along the 672 point columns of ONE row (coalesced), the twelve frame-gradient
+// sums of the row are a workgroup reduction (no atomics), and the column sums c_hj = sum_i g_a_hij of the row's eight heads are formed
+// first by all 256 threads (four strided loads each, all in flight).  (One thread per (sample, head, residue) walked its 28 points
+// serially with every lane of a wave in a different row: ~250 uncoalesced 4-byte accesses in a dependent chain, 37 us per launch.)
 __global__ __launch_bounds__(256) void ipa_bwd_points_kernel(pf_ipa_bwd_args a) {
-    const int L = a.L;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (launched with one wave per workgroup: B*H*L threads are few)
-    if (t >= (long long)a.B * H * L) return;
-    const int b = (int)(t / (H * L)), rem = (int)(t - (long long)b * H * L), h = rem / L, j = rem - h * L;
-    const int r = b * L + j;
-    const float* R = a.rot + (size_t)r * 9;
-    float gx[3] = {0.f, 0.f, 0.f}, gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float* gproj = a.g_proj + (size_t)r * a.ldp;
-    const float* praw = a.proj + (size_t)r * a.ldp;
-    auto one_point = [&](const float* gp, const float* raw3, float* graw) {       // gp: global-frame gradient of R raw + x
+    __shared__ float CS[H];
+    __shared__ float FR[4][12];
+    const int L = a.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x, b = r / L, j = r - b * L;
+    {
+        const int h = tid >> 5, l32 = tid & 31;
+        const float* ga = a.gA + (((size_t)b * H + h) * L) * L + j;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = l32;
+        for (; i + 96 < L; i += 128) {
+            s0 += ga[(size_t)i * L]; s1 += ga[(size_t)(i + 32) * L]; s2 += ga[(size_t)(i + 64) * L]; s3 += ga[(size_t)(i + 96) * L];
+        }
+        for (; i < L; i += 32) s0 += ga[(size_t)i * L];
+        const float s = sum_xor16(row16_sum((s0 + s1) + (s2 + s3)));        // over the 32 lanes of this head
+        if (l32 == 0) CS[h] = s;
+    }
+    __syncthreads();
+    float fr[12];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            gx[m] += gp[m];
+    for (int k = 0; k < 12; ++k) fr[k] = 0.f;
+    if (tid < H * 28) {
+        const int h = tid / 28, q = tid - h * 28;
+        const float* R = a.rot + (size_t)r * 9;
+        float* gproj = a.g_proj + (size_t)r * a.ldp;
+        const float* praw = a.proj + (size_t)r * a.ldp;
+        const float gamma = softplusf(a.head_w[h]) * S_PT;
+        float gp[3], raw[3];
+        int col, ms;                                            // the point's x column, stride between x / y / z
+        if (q < PQ) {                                           // query points: g = gamma * (g_a KP)
+            col = 3072 + h * PQ + q; ms = 64;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gR[m * 3 + k] += gp[m] * raw3[k];
+            for (int m = 0; m < 3; ++m) gp[m] = gamma * a.g_qp[(size_t)r * 192 + h * 24 + q * 3 + m];
+        } else if (q < 2 * PQ) {                                // key points: g = gamma * (g_a^T QP - c kp)
+            const int p = q - PQ;
+            col = 3264 + h * (PQ + PV) + p; ms = 160;
+            const float csum = CS[h];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                gp[m] = gamma * (a.g_kp[(size_t)r * 192 + h * 24 + p * 3 + m] - csum * a.kp[(size_t)r * 192 + h * 24 + p * 3 + m]);
+        } else {                                                // value points
+            const int p = q - 2 * PQ;
+            col = 3264 + h * (PQ + PV) + PQ + p; ms = 160;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) gp[m] = a.g_vp[(size_t)r * 288 + h * 36 + p * 3 + m];
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) graw[k] = R[k] * gp[0] + R[3 + k] * gp[1] + R[6 + k] * gp[2];
-    };
-    const float gamma = softplusf(a.head_w[h]) * S_PT;
-    float csum = 0.f;                                       // c_hj = sum_i g_a_hij
-    const float* ga = a.gA + (((size_t)b * H + h) * L) * L + j;
-    {                                                       // eight loads in flight (one at a time this loop was ~2/3 of the kernel: 128 L2 round trips)
-        float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int i = 0;
-        for (; i + 8 <= L; i += 8) {
+        for (int m = 0; m < 3; ++m) raw[m] = praw[col + m * ms];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c8[u] += ga[(size_t)(i + u) * L];
+        for (int m = 0; m < 3; ++m) {                           // gp: global-frame gradient of R raw + x
+            fr[m] = gp[m];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fr[3 + m * 3 + k] = gp[m] * raw[k];
         }
-        for (; i < L; ++i) c8[0] += ga[(size_t)i * L];
-        csum = ((c8[0] + c8[1]) + (c8[2] + c8[3])) + ((c8[4] + c8[5]) + (c8[6] + c8[7]));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gproj[col + k * ms] = R[k] * gp[0] + R[3 + k] * gp[1] + R[6 + k] * gp[2];
     }
-    for (int p = 0; p < PQ; ++p) {
-        // query points: g = gamma * (g_a KP)
-        float gp[3], raw[3], gr[3];
-        const int qi = h * PQ + p;                          // index inside an x/y/z block of linear_q_points (64 wide)
 #pragma unroll
-        for (int m = 0; m < 3; ++m) { gp[m] = gamma * a.g_qp[(size_t)r * 192 + h * 24 + p * 3 + m]; raw[m] = praw[3072 + m * 64 + qi]; }
-        one_point(gp, raw, gr);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) gproj[3072 + m * 64 + qi] = gr[m];
-        // key points: g = gamma * (g_a^T QP - c kp)
-        const int ki = h * (PQ + PV) + p;                   // index inside a block of linear_kv_points (160 wide)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            gp[m] = gamma * (a.g_kp[(size_t)r * 192 + h * 24 + p * 3 + m] - csum * a.kp[(size_t)r * 192 + h * 24 + p * 3 + m]);
-            raw[m] = praw[3264 + m * 160 + ki];
-        }
-        one_point(gp, raw, gr);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) gproj[3264 + m * 160 + ki] = gr[m];
+    for (int k = 0; k < 12; ++k) {
+        const float s = wave_sum(fr[k]);
+        if (lane == 0) FR[wave][k] = s;
     }
-    for (int p = 0; p < PV; ++p) {
-        float gp[3], raw[3], gr[3];
-        const int vi = h * (PQ + PV) + PQ + p;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { gp[m] = a.g_vp[(size_t)r * 288 + h * 36 + p * 3 + m]; raw[m] = praw[3264 + m * 160 + vi]; }
-        one_point(gp, raw, gr);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) gproj[3264 + m * 160 + vi] = gr[m];
+    __syncthreads();
+    if (tid < 12) {
+        float* o = a.g_frame_rows + (size_t)r * 12 + tid;       // accumulated onto the row stage's share
+        *o += (FR[0][tid] + FR[1][tid]) + (FR[2][tid] + FR[3][tid]);
     }
-    float* o = a.g_frame_rows + (size_t)r * 12;             // accumulated onto the row stage's share
-#pragma unroll
-    for (int m = 0; m < 3; ++m) atomicAdd(o + m, gx[m]);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) atomicAdd(o + 3 + k, gR[k]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -474,8 +476,7 @@ extern "C" int pf_ipa_bwd_pairs(const pf_ipa_bwd_args* a, pf_stream_t stream) {
 }
 extern "C" int pf_ipa_bwd_points(const pf_ipa_bwd_args* a, pf_stream_t stream) {
     if (!args_ok(a) || !a->g_qp || !a->g_kp || !a->g_vp || !a->g_proj || !a->g_frame_rows) return PF_E_BADARG;
-    const long long nt = (long long)a->B * H * a->L;
-    hipLaunchKernelGGL(ipa_bwd_points_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(ipa_bwd_points_kernel, dim3((unsigned)(a->B * a->L)), dim3(256), 0, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;
 }
