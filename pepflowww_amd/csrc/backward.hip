@@ -1482,16 +1482,26 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* g, int 
     __shared__ float red[8][32];
     const int chunks = (dim + 31) / 32;
     const int c = blockIdx.x / chunks, d = (blockIdx.x - c * chunks) * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    // the class indices of a block of rows are staged in LDS first: the gradient loads below then depend on nothing that is in flight
+    // (index load -> compare -> gradient load was two dependent round trips per step, 64 steps: 33 us at 2048 rows)
+    constexpr int EB = 4096;
+    __shared__ int cls[EB];
     float acc = 0.f;
-    for (int r0 = rg; r0 < rows; r0 += 32) {
-        long long id[4];
+    for (int rb = 0; rb < rows; rb += EB) {
+        const int nr = min(EB, rows - rb);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nr; k += 256) cls[k] = (int)idx[rb + k];
+        __syncthreads();
+        for (int r0 = rg; r0 < nr; r0 += 64) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int r = r0 + 8 * u; id[u] = r < rows ? idx[r] : -1; }
-        float v[4];
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 8 * u;
+                v[u] = (r < nr && cls[r] == c && d < dim) ? g[(size_t)(rb + r) * ldg + d] : 0.f;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int r = r0 + 8 * u; v[u] = (id[u] == c && d < dim) ? g[(size_t)r * ldg + d] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc += v[u];
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
     }
     red[rg][threadIdx.x & 31] = acc;
     __syncthreads();
@@ -1555,15 +1565,23 @@ __global__ __launch_bounds__(256) void embedding_bwd_lds_kernel(const float* g, 
     for (int k = threadIdx.x; k < nr; k += 256) { const int v = idx[r0 + k]; ID[k] = v; atomicMin(&lo, v); }
     __syncthreads();
     const int base = lo;
-    for (int t = threadIdx.x; t < nr * 64; t += 256) {
-        const int rl = t >> 6, d = t & 63;
-        if (d < dim) {
-            const long long r = r0 + rl;
-            const float v = g[r * ldg + d] * (scale ? scale[r] : 1.f);
-            if (v != 0.f) {
+    // eight rows per thread and round, every load requested before the first atomic (one element at a time was a chain of 32 round trips)
+    const int d = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    for (int rl0 = rq; rl0 < nr; rl0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rl = rl0 + 4 * u;
+            const long long r = r0 + (rl < nr ? rl : nr - 1);
+            v[u] = (rl < nr && d < dim) ? g[r * ldg + d] * (scale ? scale[r] : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rl = rl0 + 4 * u;
+            if (v[u] != 0.f) {
                 const int slot = ID[rl] - base;
-                if (slot < EB_ROWS) atomicAdd(&T[slot * 64 + d], v);
-                else atomicAdd(tg + (size_t)ID[rl] * dim + d, v);
+                if (slot < EB_ROWS) atomicAdd(&T[slot * 64 + d], v[u]);
+                else atomicAdd(tg + (size_t)ID[rl] * dim + d, v[u]);
             }
         }
     }
