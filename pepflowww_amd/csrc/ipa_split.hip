@@ -215,18 +215,55 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     float4 kf[8], kn[8];
     if (wave_on) loadk(0, kf);
 
-    // ---- key points / key mask of the head -> LDS (all waves) ----
-    for (int idx = tid; idx < LPe * 6; idx += blockDim.x) {
-        const int j = idx / 6, q = idx - j * 6;
-        const float4 v = *reinterpret_cast<const float4*>(a.kp + (rowb + min(j, L - 1)) * 192 + h * 24 + 4 * q);
-        *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = v;
-    }
-    for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + j] : 0.f;
-    // value points of the head -> LDS as well: read per key tile they were 12 dword loads per lane and tile in every wave (4-8 cache
-    // lines per instruction); with the value loads below they made up 25 of the kernel's 114 us (what-if build without them: 89)
-    for (int idx = tid; idx < LPe * 9; idx += blockDim.x) {
-        const int j = idx / 9, q = idx - j * 9;
-        *reinterpret_cast<float4*>(VP + j * VPS + 4 * q) = *reinterpret_cast<const float4*>(a.vp + (rowb + min(j, L - 1)) * 288 + h * 36 + 4 * q);
+    // ---- key points / key mask / value points of the head -> LDS (all waves) ----
+    // (value points: read per key tile they were 12 dword loads per lane and tile in every wave (4-8 cache lines per instruction); with
+    //  the value loads below they made up 25 of the kernel's 114 us (what-if build without them: 89))
+    // The first two key-point, the first key-mask and the first three value-point pieces of every thread are REQUESTED TOGETHER and
+    // committed afterwards -- at 512 threads and L = 128 that is all of them.  As plain `load; store to LDS` loops each iteration waited
+    // for its own round trip (s_waitcnt vmcnt(0) in front of every ds_write: 2 + 1 + 3 serialised L2 round trips in the prologue of a
+    // workgroup that lives ~7 us); what is left of the loops covers the remainder (small workgroups, L > 128).
+    {
+        const int nth = blockDim.x;
+        constexpr int KB = 2, VB = 3;
+        float4 k4[KB], v4[VB];
+        float mj0 = 0.f;
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int idx = min(tid + u * nth, LPe * 6 - 1), j = idx / 6, q = idx - j * 6;     // (clamped: loads are unconditional, stores guarded)
+            k4[u] = *reinterpret_cast<const float4*>(a.kp + (rowb + min(j, L - 1)) * 192 + h * 24 + 4 * q);
+        }
+        mj0 = a.mask[rowb + min(tid, L - 1)];
+        mj0 = tid < L ? mj0 : 0.f;
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            const int idx = min(tid + u * nth, LPe * 9 - 1), j = idx / 9, q = idx - j * 9;
+            v4[u] = *reinterpret_cast<const float4*>(a.vp + (rowb + min(j, L - 1)) * 288 + h * 36 + 4 * q);
+        }
+        // (the values pass through an empty asm: otherwise the compiler sinks every load into the guarded block of its store again)
+        asm volatile("" : "+v"(k4[0].x), "+v"(k4[0].y), "+v"(k4[0].z), "+v"(k4[0].w), "+v"(k4[1].x), "+v"(k4[1].y), "+v"(k4[1].z), "+v"(k4[1].w), "+v"(mj0));
+        asm volatile("" : "+v"(v4[0].x), "+v"(v4[0].y), "+v"(v4[0].z), "+v"(v4[0].w), "+v"(v4[1].x), "+v"(v4[1].y), "+v"(v4[1].z), "+v"(v4[1].w),
+                          "+v"(v4[2].x), "+v"(v4[2].y), "+v"(v4[2].z), "+v"(v4[2].w));
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int idx = tid + u * nth, j = idx / 6, q = idx - j * 6;
+            if (idx < LPe * 6) *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = k4[u];
+        }
+        if (tid < LPe) MJ[tid] = mj0;
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            const int idx = tid + u * nth, j = idx / 9, q = idx - j * 9;
+            if (idx < LPe * 9) *reinterpret_cast<float4*>(VP + j * VPS + 4 * q) = v4[u];
+        }
+        for (int idx = tid + KB * nth; idx < LPe * 6; idx += nth) {
+            const int j = idx / 6, q = idx - j * 6;
+            const float4 v = *reinterpret_cast<const float4*>(a.kp + (rowb + min(j, L - 1)) * 192 + h * 24 + 4 * q);
+            *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = v;
+        }
+        for (int j = tid + nth; j < LPe; j += nth) MJ[j] = j < L ? a.mask[rowb + j] : 0.f;
+        for (int idx = tid + VB * nth; idx < LPe * 9; idx += nth) {
+            const int j = idx / 9, q = idx - j * 9;
+            *reinterpret_cast<float4*>(VP + j * VPS + 4 * q) = *reinterpret_cast<const float4*>(a.vp + (rowb + min(j, L - 1)) * 288 + h * 36 + 4 * q);
+        }
     }
     __syncthreads();
     if (!wave_on) return;
