@@ -524,11 +524,35 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     half8 kh[4], kl[4], nh[4], nl[4];
     if (wave_on) loadk(0, kh, kl);
 
-    for (int idx = tid; idx < LK * 6; idx += blockDim.x) {         // (the keys this sample uses: LK <= L)
-        const int j = idx / 6, q = idx - j * 6;
-        *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = *reinterpret_cast<const float4*>(a.kp + (rowb + j) * 192 + h * 24 + 4 * q);
+    // key points / key mask of the head -> LDS (the keys this sample uses: LK <= L).  The first six key-point pieces and the first mask
+    // value of every thread are requested TOGETHER (at 128 threads and L = 128 that is all of them) and committed afterwards; as a
+    // plain `load; store to LDS` loop every iteration waited for its own round trip (see ipa_scores_kernel)
+    {
+        const int nth = blockDim.x;
+        constexpr int KB = 6;
+        float4 k4[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int idx = min(tid + u * nth, max(LK * 6 - 1, 0)), j = idx / 6, q = idx - j * 6;     // (clamped: loads unconditional, stores guarded)
+            k4[u] = *reinterpret_cast<const float4*>(a.kp + (rowb + j) * 192 + h * 24 + 4 * q);
+        }
+        float mj0 = a.mask[rowb + min(tid, max(LK - 1, 0))];
+        asm volatile("" : "+v"(k4[0].x), "+v"(k4[0].y), "+v"(k4[0].z), "+v"(k4[0].w), "+v"(k4[1].x), "+v"(k4[1].y), "+v"(k4[1].z), "+v"(k4[1].w),
+                          "+v"(k4[2].x), "+v"(k4[2].y), "+v"(k4[2].z), "+v"(k4[2].w), "+v"(mj0));
+        asm volatile("" : "+v"(k4[3].x), "+v"(k4[3].y), "+v"(k4[3].z), "+v"(k4[3].w), "+v"(k4[4].x), "+v"(k4[4].y), "+v"(k4[4].z), "+v"(k4[4].w),
+                          "+v"(k4[5].x), "+v"(k4[5].y), "+v"(k4[5].z), "+v"(k4[5].w));
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int idx = tid + u * nth, j = idx / 6, q = idx - j * 6;
+            if (idx < LK * 6) *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = k4[u];
+        }
+        if (tid < LK) MJ[tid] = mj0;
+        for (int idx = tid + KB * nth; idx < LK * 6; idx += nth) {
+            const int j = idx / 6, q = idx - j * 6;
+            *reinterpret_cast<float4*>(KP + j * KPS + 4 * q) = *reinterpret_cast<const float4*>(a.kp + (rowb + j) * 192 + h * 24 + 4 * q);
+        }
+        for (int j = tid + nth; j < LK; j += nth) MJ[j] = a.mask[rowb + j];
     }
-    for (int j = tid; j < LK; j += blockDim.x) MJ[j] = a.mask[rowb + j];
     __syncthreads();
     if (!wave_on) return;
     PROFS(1);
