@@ -1613,7 +1613,12 @@ __global__ __launch_bounds__(256) void distcoef_ratio_kernel(const float* __rest
     if (i >= n) return;
     const float x = w[i];
     const float c = x > 20.f ? x : log1pf(expf(x));
-    ratio[i] = 1.f / ((1.f + expf(-x)) * c);
+    // sigmoid(x) / softplus(x), guarded: for x below ~ -103 expf underflows, c = 0 and 1 / (inf * 0) was NaN -- there g = 1
+    // and the true gradient is ~0; x -> -inf: the ratio tends to 1 (sigmoid ~ softplus ~ e^x), so a vanished softplus writes 0
+    // (the contribution g ln g is exactly 0 at g = 1 anyway) and a non-finite quotient never reaches the table gradient
+    const float sg = 1.f / (1.f + expf(-x));
+    const float rr = c > 0.f ? sg / c : 0.f;
+    ratio[i] = (rr == rr && fabsf(rr) <= 3.0e38f) ? rr : 0.f;
 }
 // The feature is g = exp(-c d2) m with c = softplus(w[row][e]) and an atom-pair mask m in {0, 1}; d g / d w = -d2 g sigmoid(w).  The
 // squared distance is not stored by the forward any more (it was a second [pairs,225] dump, written and read back once per step):

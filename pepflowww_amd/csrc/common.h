@@ -9,12 +9,15 @@
 // CUs of the current device (256 on MI355X); launchers that size "one workgroup per CU" grids or pick a kernel form by whether a
 // grid fits one round of workgroups ask here instead of hard-coding the number.
 static inline int pf_cu_count() {
-    static const int n = [] {
-        int dev = 0, c = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
-        return c > 0 ? c : 256;
-    }();
-    return n;
+    // cached PER DEVICE id (one function-local value per translation unit, taken from whichever device was current at
+    // the first call, mis-sizes persistent grids on a mixed / partitioned node)
+    static int cache[64] = {0};
+    int dev = 0, c = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    if (dev >= 0 && dev < 64) cache[dev] = c;
+    return c;
 }
 #include <stdint.h>
 

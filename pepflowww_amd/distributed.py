@@ -89,15 +89,28 @@ def all_gather_packed(local, sizes, group=None):
 
 
 def all_gather_final_state(sampler, group=None, sizes=None):
-    """Gather the last trajectory slot of a DeviceSampler from every rank (device tensors, RCCL): ONE collective.
-    sizes: per-rank sample counts.  Every caller knows them without asking (contiguous shards of a known total: shard_bounds;
-    bench.py: the same per-GPU batch on every rank) -- default = this rank's own count on every rank (weak-scaling replicas)."""
+    """Gather the last trajectory slot of a DeviceSampler from every rank (device tensors, RCCL): ONE data collective.
+    sizes: per-rank sample counts -- REQUIRED for ragged shards (contiguous shards of a known total: shard_bounds gives them
+    without a collective, as sample_sharded does).  sizes=None means "every rank holds the same number of samples"
+    (bench.py's weak-scaling replicas); that claim is CHECKED with one 2-int MIN/MAX all-reduce (set-up sized, 16 bytes) and a
+    mismatch raises on every rank instead of handing RCCL buffers of different sizes (hang / corrupted rows)."""
     local = _final_state_of(sampler)
     world = dist.get_world_size(group)
     if sizes is None:
-        sizes = [local.shape[0]] * world
-    assert len(sizes) == world and sizes[dist.get_rank(group)] == local.shape[0], (sizes, local.shape)
-    return unpack_state(all_gather_packed(local, [int(s) for s in sizes], group))
+        n = int(local.shape[0])
+        if world > 1:
+            dev = local.device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+            mm = torch.tensor([n, -n], dtype=torch.int64, device=dev)
+            dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+            nmax, nmin = int(mm[0].item()), -int(mm[1].item())
+            if nmax != nmin:
+                raise ValueError(f"all_gather_final_state(sizes=None) needs the same sample count on every rank, got {nmin}..{nmax}: "
+                                 "pass sizes=[shard_bounds(total, world, r) widths] for ragged shards")
+        sizes = [n] * world
+    sizes = [int(s) for s in sizes]
+    if len(sizes) != world or sizes[dist.get_rank(group)] != local.shape[0]:
+        raise ValueError(f"sizes {sizes} do not describe this rank's {local.shape[0]} samples in a world of {world}")
+    return unpack_state(all_gather_packed(local, sizes, group))
 
 
 def seeded_noise(lo, hi, L, seed):

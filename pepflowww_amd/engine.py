@@ -385,9 +385,10 @@ class DenoiseEngine:
     #           (f16 operand planes) and the Linears of the node track run ONE f16 MFMA per product (hi planes only);
     #           accumulation, LayerNorm, softmax, residual streams, geometry and the pair tensor stay fp32.  Measured deviation
     #           from the fp32 mode: tests/test_gpu_bigshape.py, DESIGN.md section 3.8
-    def __init__(self, weights, B, L, device, precision="fp32"):
+    def __init__(self, weights, B, L, device, precision="fp32", owner=None):
         assert precision in ("fp32", "f16"), precision
         self.precision = precision
+        self._owner = owner                     # the GAEncoder whose cache holds this engine (asked to make room on OOM)
         self.lib = _capi.load()
         self.w = weights
         self.B, self.L, self.device = B, L, device
@@ -479,13 +480,33 @@ class DenoiseEngine:
         key = (int(num_steps), tuple(bool(f) for f in flags))
         smp = self._samplers.get(key)
         if smp is None:
-            smp = DeviceSampler(self, num_steps, flags)
+            try:
+                smp = DeviceSampler(self, num_steps, flags)
+            except torch.cuda.OutOfMemoryError:                 # trajectory buffers: drop the other samplers / engines, one retry
+                self._samplers.clear()
+                if self._owner is not None:
+                    self._owner._make_room(self)
+                torch.cuda.empty_cache()
+                smp = DeviceSampler(self, num_steps, flags)
             self._samplers[key] = smp
             while len(self._samplers) > self.SAMPLER_CACHE:
                 self._samplers.popitem(last=False)
         else:
             self._samplers.move_to_end(key)
         return smp
+
+    def nbytes(self):
+        """Device bytes this engine keeps alive: its workspaces and its samplers' trajectory buffers (distinct storages)."""
+        seen, total = set(), 0
+        holders = [self] + list(self._samplers.values())
+        for h in holders:
+            for v in vars(h).values():
+                if torch.is_tensor(v) and v.device.type != "cpu":
+                    st = v.untyped_storage()
+                    if st.data_ptr() not in seen:
+                        seen.add(st.data_ptr())
+                        total += st.nbytes()
+        return total
 
     # ---- plan construction -------------------------------------------------------------------
     def _linear(self, x, w, b, y, N, K, relu=False, mask_pre=False, mask_post=False, residual=None, ln=None, w16=None):

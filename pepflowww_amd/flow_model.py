@@ -90,13 +90,18 @@ class FlowModel(nn.Module):
     # ---- flow_model.py:229-374 ----
     @torch.no_grad()
     def sample(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
-               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None):
+               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False):
         """Reference signature + keyword-only extensions:
         noise        dict(rot0, trans0, ang0, simplex0[, expo]) of pre-drawn noise (parity tests);
         seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator); with noise=None an
                      explicit seed also keys the initial noise per GLOBAL sample index (distributed.seeded_noise);
         first_sample global index of this shard's first sample (world-size independent RNG streams);
         use_graph    replay one captured hipGraph per step (default) or launch eagerly;
+        return_sampler  return the DeviceSampler instead of the CPU trajectory.  It is OWNED BY THE ENGINE: the next sample() call at
+                     the same (B, L, num_steps, flags) overwrites its trajectory buffers, seed and L_out IN PLACE -- read what you
+                     need (distributed._final_state_of / .trajectory()) before calling sample() again, or clone it;
+        pageable     return the trajectory in pageable host memory instead of views of pinned staging buffers (callers that keep
+                     the trajectories of many complexes alive: pinned memory is a bounded resource);
         timings      optional dict: filled with the wall-clock seconds of the call's phases (noise / engine / encode / bind / setup /
                      capture / loop / d2h; each phase is followed by a device synchronisation when this is given -- bench.py's
                      per-call accounting)."""
@@ -149,6 +154,6 @@ class FlowModel(nn.Module):
         smp.L_out = L0
         if return_sampler:
             return smp                                 # (owned by the engine: the next sample() call at this shape reuses it)
-        traj = smp.trajectory()
+        traj = smp.trajectory(pageable=pageable)
         stamp("d2h")
         return traj

@@ -175,6 +175,12 @@ class GAEncoder(nn.Module):
     # (B, L, device, precision).  inference.py:64-99 loops over complexes of different length: the packed weights are built once,
     # and the most recently used ENGINE_CACHE engines stay alive, so a length seen before costs no set-up at all.
     ENGINE_CACHE = 8
+    # ... bounded in BYTES as well: an engine at B=64, L=128 with a 200-step sampler holds ~1-1.5 GB (pair-sized
+    # workspaces, trajectory buffers, two captured graphs).  The cache may keep at most ENGINE_CACHE_FRACTION of the device's
+    # memory (or ENGINE_CACHE_BYTES when set); least recently used engines are dropped first, and an allocation failure while
+    # building an engine / sampler drops every other cached engine and retries once (release_engines() is the manual form).
+    ENGINE_CACHE_FRACTION = 0.25
+    ENGINE_CACHE_BYTES = None
 
     def _param_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -194,19 +200,49 @@ class GAEncoder(nn.Module):
             self._engines.clear()                # engines hold pointers into the old packed copies
         return self._packed
 
+    def _cache_budget(self, device):
+        if self.ENGINE_CACHE_BYTES is not None:
+            return int(self.ENGINE_CACHE_BYTES)
+        try:
+            total = torch.cuda.get_device_properties(device).total_memory
+        except Exception:
+            return 1 << 62
+        return int(total * self.ENGINE_CACHE_FRACTION)
+
+    def cached_bytes(self):
+        """Device bytes held by the cached engines (workspaces + samplers' trajectory buffers)."""
+        return sum(e.nbytes() for e in self._engines.values())
+
+    def _trim(self, device, keep):
+        """Drop least recently used engines (never `keep`) until count and byte bounds hold."""
+        budget = self._cache_budget(device)
+        while len(self._engines) > 1 and (len(self._engines) > self.ENGINE_CACHE or self.cached_bytes() > budget):
+            k0 = next(k for k in self._engines if k != keep)
+            del self._engines[k0]
+
     def engine(self, B, L, device):
         prec = getattr(self, "_precision", "fp32")
         w = self.packed_weights(device)
         key = (B, L, str(device), prec)
         eng = self._engines.get(key)
         if eng is None:
-            eng = DenoiseEngine(w, B, L, device, precision=prec)
+            try:
+                eng = DenoiseEngine(w, B, L, device, precision=prec, owner=self)
+            except torch.cuda.OutOfMemoryError:
+                self._engines.clear()            # every cached engine goes; one retry
+                torch.cuda.empty_cache()
+                eng = DenoiseEngine(w, B, L, device, precision=prec, owner=self)
             self._engines[key] = eng
-            while len(self._engines) > self.ENGINE_CACHE:
-                self._engines.popitem(last=False)
+            self._trim(device, key)
         else:
             self._engines.move_to_end(key)
         return eng
+
+    def _make_room(self, eng):
+        """Called by an engine whose sampler allocation failed: drop every OTHER cached engine."""
+        for k in [k for k, e in self._engines.items() if e is not eng]:
+            del self._engines[k]
+        torch.cuda.empty_cache()
 
     @property
     def last_engine(self):

@@ -160,8 +160,11 @@ class DeviceSampler:
         for _ in range(n):
             self.graph.replay()
 
-    def trajectory(self):
-        """One D2H copy -> list of num_steps dicts of CPU tensors (flow_model.py:313-314,371-374)."""
+    def trajectory(self, pageable=False):
+        """One D2H copy -> list of num_steps dicts of CPU tensors (flow_model.py:313-314,371-374).
+        The tensors are VIEWS of pinned host buffers (PyTorch's caching host allocator recycles them once the views die).  A caller
+        that ACCUMULATES trajectories over many complexes should pass pageable=True (FlowModel.sample(..., pageable=True)): the
+        result is then copied into ordinary pageable memory and the pinned staging blocks return to the allocator at once."""
         B, L, N = self.eng.B, self.eng.L, self.N
         Lo = getattr(self, "L_out", L)                 # FlowModel.sample pads the residue axis to x16 internally: cut back
 
@@ -173,6 +176,8 @@ class DeviceSampler:
             return h
         hosts = [to_host(t) for t in (self.traj_rot, self.traj_trans, self.traj_ang, self.traj_seq, self.traj_simplex)]
         torch.cuda.current_stream().synchronize()
+        if pageable:
+            hosts = [torch.empty(h.shape, dtype=h.dtype).copy_(h) for h in hosts]
         rot = hosts[0].view(N, B, L, 3, 3)[:, :, :Lo]
         trans = hosts[1].view(N, B, L, 3)[:, :, :Lo]
         ang = hosts[2].view(N, B, L, 5)[:, :, :Lo]

@@ -263,10 +263,22 @@ def _fresh_seed_worker(rank, world, port, q):
         try:
             shard, lo, hi = D.shard_batch(batch, world, rank)
             nz = D.seeded_noise(lo, hi, 12, 5)
-            out = D.all_gather_final_state(_StubSampler(shard, 3, nz, lo))
+            sizes = [D.shard_bounds(4, world, r)[1] - D.shard_bounds(4, world, r)[0] for r in range(world)]
+            out = D.all_gather_final_state(_StubSampler(shard, 3, nz, lo), sizes=sizes)      # known sizes: ONE collective
+            n_known = len(calls)
+            D.all_gather_final_state(_StubSampler(shard, 3, nz, lo))                         # sizes=None: + the 16-byte equal-count check
+            calls_none = calls[n_known:]
+            # ragged shards with sizes=None: every rank raises instead of handing the all-gather mismatched buffers
+            rb = synth.make_pocket_batch(3, 12, 4, seed=3)
+            rshard, rlo, rhi = D.shard_batch(rb, world, rank)
+            try:
+                D.all_gather_final_state(_StubSampler(rshard, 3, D.seeded_noise(rlo, rhi, 12, 5), rlo))
+                raised = False
+            except ValueError:
+                raised = True
         finally:
             dist.all_gather_into_tensor, dist.all_reduce = real_ag, real_ar
-        q.put((rank, m.seeds, a["rotmats"].clone(), b["rotmats"].clone(), calls, tuple(out["trans"].shape)))
+        q.put((rank, m.seeds, a["rotmats"].clone(), b["rotmats"].clone(), (calls[:n_known], calls_none, raised), tuple(out["trans"].shape)))
     finally:
         dist.destroy_process_group()
 
@@ -285,5 +297,8 @@ def test_default_seed_is_fresh_per_call_and_shared_by_the_ranks():
     (r0, s0, a0, b0, c0, sh0), (r1, s1, a1, b1, c1, sh1) = res
     assert s0 == s1 and len(s0) == 2 and s0[0] != s0[1], (s0, s1)        # same seed on both ranks, a new one per call
     assert torch.equal(a0, a1) and torch.equal(b0, b1) and not torch.equal(a0, b0)
-    assert c0 == ["all_gather"] and c1 == ["all_gather"], (c0, c1)       # ONE collective closes a run
+    for c in (c0, c1):
+        assert c[0] == ["all_gather"], c                                 # ONE collective closes a run whose shard sizes are known
+        assert c[1] == ["all_reduce", "all_gather"], c                   # sizes=None: the equal-count claim is checked first
+        assert c[2] is True, c                                           # ragged shards + sizes=None raise on every rank
     assert sh0 == (4, 12, 3) and sh1 == (4, 12, 3)

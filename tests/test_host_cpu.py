@@ -64,6 +64,35 @@ def test_no_cpu_fallback():
         model(batch)
 
 
+def test_engine_cache_is_bounded_in_bytes_and_count():
+    """GAEncoder keeps its engines (workspaces, trajectory buffers, graphs) alive across calls; the cache is bounded by
+    COUNT and by BYTES, least recently used first, never dropping the engine just built (host logic: stub engines)."""
+    enc = pepflowww_amd.FlowModel(pepflowww_amd.default_config()).ga_encoder
+
+    class _Eng:
+        def __init__(self, n):
+            self.n = n
+
+        def nbytes(self):
+            return self.n
+    enc.ENGINE_CACHE_BYTES = 1000
+    for i in range(5):
+        enc._engines[i] = _Eng(300)
+        enc._trim("cpu", i)
+        assert i in enc._engines and enc.cached_bytes() <= 1000
+    assert list(enc._engines) == [2, 3, 4]                         # 3 x 300 bytes fit, the oldest went first
+    enc._engines["big"] = _Eng(5000)                               # larger than the whole budget: everything else goes, it stays
+    enc._trim("cpu", "big")
+    assert list(enc._engines) == ["big"]
+    enc.ENGINE_CACHE_BYTES, enc.ENGINE_CACHE = 1 << 40, 2
+    for i in range(4):
+        enc._engines[i] = _Eng(1)
+        enc._trim("cpu", i)
+    assert len(enc._engines) == 2 and 3 in enc._engines
+    enc.release_engines()
+    assert not enc._engines and enc.cached_bytes() == 0
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "pepflowww_amd")
     for fn in os.listdir(pkg):
