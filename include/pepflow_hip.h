@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 49
+#define PF_ABI_VERSION 50
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -195,6 +195,15 @@ typedef struct {
      * workgroup: p_out is not written and may be NULL, no second kernel).  Needs fp32 dz with fp32 operands (proj) or f16 dz with
      * the f16 operand planes (att_*); other combinations fall back to the two-kernel form (which needs p_out). */
     int fused_pair;
+    /* optional (two-kernel form, fp32 operands, L % 4 == 0, every query tile of a sample in one score workgroup: 64 <= L <= 128):
+     * THE PROJECTION RUNS INSIDE THE SCORE KERNEL (ABI 50).  s_in [B*L,128] = the node state; proj_w_f16 = fragment-order hi / lo
+     * planes (engine.split_f16) of the packed projection [3968,128] = [linear_q 1024 | linear_kv 2048 | 64 query points (x,y,z,0) |
+     * 160 key / value points (x,y,z,0)] -- the matrix pf_linear_fwd takes with pt_col0 = 3072 -- and proj_bias [3968] its bias.
+     * Each (sample, head) workgroup forms q, the query / key / value points (global frame, through rot / trans) on chip and
+     * writes only the head's k | v columns of `proj` (which it reads back itself: `proj` is a per-launch SCRATCH then, written
+     * through the const pointer; columns 0..1023 and qp / kp / vp are not touched and may be NULL).  Results are bit-identical
+     * to pf_linear_fwd followed by the plain call (ipa_pytorch.py:347-387 + 389-475 in one launch). */
+    const float* s_in; const void* proj_w_f16; const float* proj_bias;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the

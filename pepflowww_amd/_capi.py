@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -40,7 +40,8 @@ class IpaAttnArgs(C.Structure):
     _fields_ = [("proj", _fp), ("ldp", _i), ("qp", _fp), ("kp", _fp), ("vp", _fp), ("z", _fp), ("rot", _fp),
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
                 ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp),
-                ("variant", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_mode", _i), ("head_group", _i), ("key_end", _fp), ("z_f16", _i), ("dz", _fp), ("dz_f16", _i), ("fused_pair", _i)]
+                ("variant", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_mode", _i), ("head_group", _i), ("key_end", _fp), ("z_f16", _i), ("dz", _fp), ("dz_f16", _i), ("fused_pair", _i),
+                ("s_in", _fp), ("proj_w_f16", _fp), ("proj_bias", _fp)]
 
 
 class InputMixerArgs(C.Structure):

@@ -162,6 +162,157 @@ __device__ __forceinline__ void pair_dz_phase(const pf_ipa_attn_args& a, size_t 
         make_float4(z4[0] * invq + bd.x, z4[1] * invq + bd.y, z4[2] * invq + bd.z, z4[3] * invq + bd.w);
 }
 
+// ---- the IPA projection INSIDE the score kernel (pf_ipa_attn_args.s_in / proj_w_f16 / proj_bias) ----
+// A (sample, head) workgroup forms the head's operands itself: wave w projects ITS OWN 16 residue rows (its queries, which are also 16
+// of the head's keys) through the head's 496 columns of the packed projection [3968,128] (ipa_pytorch.py:347-387: linear_q | linear_kv
+// | linear_q_points | linear_kv_points, points packed (x, y, z, 0) as pf_linear_fwd's pt_* form) -- split-precision MFMA, computed
+// transposed (features x rows) exactly as linear_rows_kernel does, so every value is bit-identical to the stand-alone projection:
+//   q (8 tiles)        stays in registers: the accumulator layout (lane (r = row, g): features 16 t + 4 g + e) IS qf[t];
+//   k | v (16 tiles)   float4 stores into the head's k | v columns of `proj` (the only part of that buffer still used: a per-launch
+//                      scratch that the other waves of this workgroup read back through L2 after the barrier);
+//   q points (2 tiles) R p + t (rigid_utils.py:1124) -> wave-private LDS -> the 24 floats of the lane's row;
+//   k / v points (5)   R p + t -> the workgroup's KP / VP tables in LDS directly.
+// Neither q nor any point ever reaches HBM, and the projection launch (and its [rows,3968] round trip) is gone.
+template <int I, int N, class F> __device__ __forceinline__ void cfor_p(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cfor_p<I + 1, N>(f);
+    }
+}
+constexpr int PJ_TILES = 31;                  // 8 q + 8 k + 8 v + 2 q-point + 5 kv-point tiles of 16 features per head
+constexpr int PJ_NPAD = 3968;
+constexpr int PJ_CT = 3;                      // weight tiles per staged chunk: 3 x (4 K-steps x hi | lo x 1 KiB) = 24 KiB, two buffers
+constexpr int PJ_NCH = (PJ_TILES + PJ_CT - 1) / PJ_CT;
+constexpr int PJ_CHUNK_B = PJ_CT * 8 * 1024;
+constexpr int PJ_STAGE_B = 2 * PJ_CHUNK_B;    // + the waves' query-point regions ([16][24] floats each) behind it
+__device__ __forceinline__ constexpr int pj_tile(int idx, int h) {   // feature tile (of 16) of the packed projection
+    return idx < 8 ? 8 * h + idx : idx < 24 ? 64 + 16 * h + (idx - 8) : idx < 26 ? 192 + 2 * h + (idx - 24) : 208 + 5 * h + (idx - 26);
+}
+// one 1 KiB LDS-DMA piece: (wave-uniform base in SGPRs) + lane * 16 -> LDS at lds_addr + lane * 16 (as in edge_transition_v4.hip)
+__device__ __forceinline__ void pj_glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+    const unsigned long long v = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void pj_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+struct PjW { half8 h[4], l[4]; };
+// Called by EVERY wave of the workgroup (barriers inside).  The head's 248 KiB of weight fragments go L2 -> LDS ONCE per workgroup
+// (LDS-DMA, two 24 KiB buffers, the next chunk in flight under the current chunk's MFMAs) and every wave reads its operands from
+// there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
+// 64 B / clk L1 path and the prologue cost what the projection launch it replaced had cost.
+__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, float* KP,
+                                          float* VP, unsigned char* WS /* 2 x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
+                                          float4 (&qf)[8], float4 (&qp4)[6], int lane, int wave, int nw) {
+    const int r = lane & 15, g = lane >> 4;
+    const unsigned char* whp = reinterpret_cast<const unsigned char*>(a.proj_w_f16);
+    const unsigned char* wlp = whp + (size_t)PJ_NPAD * 128 * 2;
+    const unsigned ws0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)WS;
+    const unsigned l16 = lane * 16;
+    // chunk c -> buffer c & 1: piece (tile tl, K-step ks, plane pl) at ((tl * 4 + ks) * 2 + pl) KiB; pieces wave, wave + nw, ...
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        const int ntl = min(PJ_CT, PJ_TILES - PJ_CT * c);
+        for (int pc = wave; pc < ntl * 8; pc += nw) {
+            const int tl = pc >> 3, ks = (pc >> 1) & 3, pl = pc & 1;
+            const int T16 = pj_tile(PJ_CT * c + tl, h);
+            pj_glds16((pl ? wlp : whp) + (size_t)(T16 * 4 + ks) * 1024, l16, ws0 + (c & 1) * PJ_CHUNK_B + pc * 1024);
+        }
+    };
+    issue(0);
+    // x operand: row iq, K-step ks, slots 8 g .. + 7, as hi / lo planes (split4: the same conversion as the stand-alone kernel)
+    half8 xh[4], xl[4];
+    float R[9], T[3];
+    {
+        const float* xrow = a.s_in + (rowb + iq) * 128 + 8 * g;
+        float4 t[8];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { t[2 * ks] = *reinterpret_cast<const float4*>(xrow + 32 * ks); t[2 * ks + 1] = *reinterpret_cast<const float4*>(xrow + 32 * ks + 4); }
+        const float* Rg = a.rot + (rowb + iq) * 9;
+        const float* Tg = a.trans + (rowb + iq) * 3;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rg[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) T[k] = Tg[k];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float v0[4] = {t[2 * ks].x, t[2 * ks].y, t[2 * ks].z, t[2 * ks].w}, v1[4] = {t[2 * ks + 1].x, t[2 * ks + 1].y, t[2 * ks + 1].z, t[2 * ks + 1].w};
+            half4 h0, l0, h1, l1;
+            split4(v0, h0, l0);
+            split4(v1, h1, l1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xh[ks][e] = h0[e]; xh[ks][4 + e] = h1[e]; xl[ks][e] = l0[e]; xl[ks][4 + e] = l1[e]; }
+        }
+    }
+    float* kvrow = const_cast<float*>(a.proj) + (rowb + iq) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
+    auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
+        const unsigned char* b = WS + (c & 1) * PJ_CHUNK_B + tl * 8192 + lane * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            w.h[ks] = *reinterpret_cast<const half8*>(b + ks * 2048);
+            w.l[ks] = *reinterpret_cast<const half8*>(b + ks * 2048 + 1024);
+        }
+    };
+    cfor_p<0, PJ_NCH>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int c = decltype(ic)::value;
+        // chunk c has landed: this wave's pieces (the k | v stores of the previous chunk's tiles are younger: counted wait -- vector
+        // memory operations complete in order), then everybody's (barrier), which also frees the buffer of chunk c - 1
+        constexpr int NST = c == 0 ? 0 : ((PJ_CT * (c - 1) + 0 >= 8 && PJ_CT * (c - 1) + 0 < 24) + (PJ_CT * (c - 1) + 1 >= 8 && PJ_CT * (c - 1) + 1 < 24) +
+                                          (PJ_CT * (c - 1) + 2 >= 8 && PJ_CT * (c - 1) + 2 < 24));
+        if (wave_on) pj_wait_vm<NST>();
+        else pj_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (c + 1 < PJ_NCH) issue(c + 1);
+        if (wave_on) {
+            PjW wa, wb;
+            ldfrag(c, 0, wa);
+            cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
+                constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
+                if constexpr (idx < PJ_TILES) {
+                    PjW& w = (tl & 1) ? wb : wa;
+                    if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        am = mfma_h(w.h[ks], xh[ks], am);
+                        ac = mfma_h(w.h[ks], xl[ks], ac);
+                        ac = mfma_h(w.l[ks], xh[ks], ac);
+                    }
+                    const int n = 16 * pj_tile(idx, h) + 4 * g;
+                    const float4 b4 = *reinterpret_cast<const float4*>(a.proj_bias + n);
+                    float v[4];
+                    v[0] = (am[0] + ac[0] * PF_LO_INV) + b4.x; v[1] = (am[1] + ac[1] * PF_LO_INV) + b4.y;
+                    v[2] = (am[2] + ac[2] * PF_LO_INV) + b4.z; v[3] = (am[3] + ac[3] * PF_LO_INV) + b4.w;
+                    if constexpr (idx < 8) {
+                        qf[idx] = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if constexpr (idx < 24) {        // k tiles 0..7 | v tiles 0..7 of the head: columns 16 (idx - 8) + 4 g of its 256
+                        *reinterpret_cast<float4*>(kvrow + 16 * (idx - 8)) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {                                // a point (x, y, z, 0) of this row: global frame, as pf_linear_fwd's epilogue forms it
+                        const float ox = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                        const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                        const float oz = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                        if constexpr (idx < 26) {           // query point 4 (idx - 24) + g
+                            float* o = QPW + r * 24 + 3 * (4 * (idx - 24) + g);
+                            o[0] = ox; o[1] = oy; o[2] = oz;
+                        } else {                            // key point pp < 8 | value point pp - 8 of key row jrow
+                            const int pp = 4 * (idx - 26) + g;
+                            float* o = pp < 8 ? KP + jrow * KPS + 3 * pp : VP + jrow * VPS + 3 * (pp - 8);
+                            if (jrow < LPe) { o[0] = ox; o[1] = oy; o[2] = oz; }
+                        }
+                    }
+                }
+            });
+        }
+    });
+    if (wave_on) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private LDS hand-off of the query points
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);
+    }
+}
+
 // The wave's score tile S[16 queries][L keys] lives in a wave-private LDS region that every lane only ever reads back where it
 // wrote (lane (r, g): row r, keys 16 t + 4 g .. + 3), i.e. it is register spill space under our control: with the tiles held
 // in registers and the tile loops unrolled, hipcc hoisted every tile's loads and spilled 0.9 - 6.8 KB per lane.
@@ -170,7 +321,7 @@ __device__ __forceinline__ void pair_dz_phase(const pf_ipa_attn_args& a, size_t 
 // the loop.  (First version: conditional prefetches and guarded stores inside the loops -- hipcc emits s_waitcnt vmcnt(0) at
 // every control-flow join, so the "one tile ahead" loads were never in flight: 108 us per launch at B=64, L=128, 28 % of the
 // wave cycles parked on memory, MFMA pipe 29 % busy.)
-template <bool VEC4, bool FUSE = false>          // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored
+template <bool VEC4, bool FUSE = false, bool PROJ = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_rows16)
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;
@@ -197,13 +348,15 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 
     // ---- operands of this wave's 16 queries, requested first (they come from the projection kernel's output) ----
     const int iq = max(min(i0 + r, Le - 1), 0);    // lanes beyond Le duplicate row Le - 1 exactly
-    const float* qrow = a.proj + (rowb + iq) * a.ldp + h * C + 4 * g;
     float4 qf[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
     float4 qp4[6];
+    if constexpr (!PROJ) {
+        const float* qrow = a.proj + (rowb + iq) * a.ldp + h * C + 4 * g;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(a.qp + (rowb + iq) * 192 + h * 24 + 4 * q);
+        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(a.qp + (rowb + iq) * 192 + h * 24 + 4 * q);
+    }
     const float mi = a.mask[rowb + iq];
     const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
     const float* kbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + 4 * g;
@@ -213,8 +366,20 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
     };
     float4 kf[8], kn[8];
-    if (wave_on) loadk(0, kf);
+    if constexpr (!PROJ) { if (wave_on) loadk(0, kf); }
 
+    if constexpr (PROJ) {
+        // the head's operands are formed here (proj_rows16): k | v rows -> `proj` (scratch), key / value points -> KP / VP, q and the
+        // query points -> registers; only the key mask is staged from memory.  (One 16-row query tile per wave, all of the sample's
+        // rows in this workgroup: the launcher guarantees nrb == 1.)
+        for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + min(j, L - 1)] : 0.f;
+        unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
+        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + wave * 16 * 24;   //  sizes the allocation for staging + query points)
+        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, VP, WS, QPW, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
+        __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
+        if (!wave_on) return;
+        loadk(0, kf);
+    } else {
     // ---- key points / key mask / value points of the head -> LDS (all waves) ----
     // (value points: read per key tile they were 12 dword loads per lane and tile in every wave (4-8 cache lines per instruction); with
     //  the value loads below they made up 25 of the kernel's 114 us (what-if build without them: 89))
@@ -267,6 +432,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     }
     __syncthreads();
     if (!wave_on) return;
+    }
     PROFS(1);
 
     // ---- scores: lane (r = query, g) holds keys 16 t + 4 g + e of its query ----
@@ -1092,7 +1258,23 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if (planes) {
+        // the projection inside the score kernel (s_in): fp32 operands, every query tile of a sample in ONE workgroup, float4 rows
+        const bool pj = a->s_in != nullptr;
+        if (pj && (planes || nrb != 1 || (L & 3) != 0 || !a->proj_w_f16 || !a->proj_bias || !a->proj || a->ldp < OFF_KV + 2 * H * C)) return PF_E_BADARG;
+        if (pj) {
+            static bool attr_pj = false;
+            if (!attr_pj) {
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_pj = true;
+            }
+            // the score regions double as the weight staging buffers + the waves' query-point regions during the prologue
+            const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float);
+            const size_t ldsp = lds > need ? lds : need;
+            if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
+            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+        } else if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
             int wm = (int)((160 * 1024 - fixed16) / pw16);

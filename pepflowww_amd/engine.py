@@ -267,6 +267,24 @@ def pack_bias_frags32(w_b, w_dz):
     return torch.cat([_frag32(w, 0, perm(mt, s)) for mt in range(2) for s in range(2)]).contiguous()
 
 
+def pack_ipa_projection(wfull, bfull):
+    """[linear_q | linear_kv | linear_q_points | linear_kv_points] ([3744,128], [3744]; ipa_pytorch.py:347-387) -> the packed
+    projection of the inference plan: point rows re-ordered to (x, y, z, 0) per point, so that the kernels apply the residue frames
+    to a lane's four consecutive outputs (pf_linear_args.pt_*, pf_ipa_attn_args.proj_w_f16): 3072 scalar features, 64 query points,
+    160 key / value points = [3968,128] as fragment-order f16 planes, and its bias [3968].  Layout only."""
+    device = wfull.device
+    idx = []
+    for pt in range(64):
+        idx += [3072 + m * 64 + pt for m in range(3)] + [-1]
+    for hp in range(160):
+        idx += [3264 + m * 160 + hp for m in range(3)] + [-1]
+    idx_t = torch.tensor(idx, device=device)
+    wz = torch.cat([wfull, torch.zeros(1, 128, device=device)], 0)      # row -1 -> zeros
+    bz = torch.cat([bfull, torch.zeros(1, device=device)], 0)
+    wp = torch.cat([wfull[:3072], wz[idx_t]], 0).contiguous()           # [3968,128]
+    return split_f16(wp), torch.cat([bfull[:3072], bz[idx_t]], 0).contiguous()
+
+
 class PackedWeights:
     """Kernel-friendly views/copies of the GAEncoder parameters (reference state_dict layout).
 
@@ -321,20 +339,7 @@ class PackedWeights:
             t[f"{b}.proj.b"] = torch.cat([g(p + "linear_q.bias"), g(p + "linear_kv.bias"),
                                           g(p + "linear_q_points.bias"), g(p + "linear_kv_points.bias")], 0).contiguous()
             t[f"{b}.proj.w16"] = split_f16(t[f"{b}.proj.w"])
-            # inference plan: point rows re-ordered to (x, y, z, 0) per point so that pf_linear_fwd applies the residue frames
-            # in its epilogue (pf_linear_args.pt_*): 3072 scalar features, 64 query points, 160 key/value points
-            wfull, bfull = t[f"{b}.proj.w"], t[f"{b}.proj.b"]
-            idx = []
-            for pt in range(64):
-                idx += [3072 + m * 64 + pt for m in range(3)] + [-1]
-            for hp in range(160):
-                idx += [3264 + m * 160 + hp for m in range(3)] + [-1]
-            idx_t = torch.tensor(idx, device=device)
-            wz = torch.cat([wfull, torch.zeros(1, 128, device=device)], 0)      # row -1 -> zeros
-            bz = torch.cat([bfull, torch.zeros(1, device=device)], 0)
-            wp = torch.cat([wfull[:3072], wz[idx_t]], 0).contiguous()           # [3968,128]
-            t[f"{b}.projp.w16"] = split_f16(wp)
-            t[f"{b}.projp.b"] = torch.cat([bfull[:3072], bz[idx_t]], 0).contiguous()
+            t[f"{b}.projp.w16"], t[f"{b}.projp.b"] = pack_ipa_projection(t[f"{b}.proj.w"], t[f"{b}.proj.b"])
             for nm in ("linear_b", "down_z", "linear_out"):
                 t[f"{b}.{nm}.w"], t[f"{b}.{nm}.b"] = g(p + nm + ".weight"), g(p + nm + ".bias")
             t[f"{b}.linear_out.w16"] = split_f16(t[f"{b}.linear_out.w"])
@@ -454,6 +459,12 @@ class DenoiseEngine:
             split = self.precision == "fp32"
             self.att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=device)
             self.att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=device)
+        # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_rows16): every (sample, head)
+        # workgroup projects its own rows -- no projection launch, q and the points never reach HBM, `proj` shrinks to a k | v scratch.
+        # Needs the fp32-operand two-kernel form with all query tiles of a sample in one workgroup (64 <= L <= 128, L % 4 == 0): a rule
+        # in (L, precision) alone.  PF_FUSED_PROJ=0 / 1 forces it off / on (same-box A/B runs).
+        can_pj = precision == "fp32" and 64 <= L <= 128 and L % 4 == 0 and not self.att_planes
+        self.fused_proj = can_pj and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PROJ", ""), True)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -618,7 +629,8 @@ class DenoiseEngine:
                 la.att_qk, la.att_vt, la.att_L = self.att_qk.data_ptr(), self.att_vt.data_ptr(), L
             plan.append(e + (lane,))
 
-        emit_proj(0, 0)
+        if not self.fused_proj:
+            emit_proj(0, 0)
         for b in range(N_BLOCKS):
             rot = self.rot_t if b == 0 else self.rot
             trans = self.trans_t if b == 0 else self.trans
@@ -640,6 +652,8 @@ class DenoiseEngine:
                 ia.dz_f16 = int(self.z16)
             if self.att_planes:
                 ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
+            if self.fused_proj:
+                ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.projp.w16"].data_ptr(), w[f"{b}.projp.b"].data_ptr()
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----
@@ -701,7 +715,8 @@ class DenoiseEngine:
                 # EdgeTransition(b) (main lane) and the projection of block b+1 (side lane) are independent: both read
                 # the node state just produced; they are forked onto two HIP streams and joined before IPA(b+1).
                 plan.append((None, None, "fork", 0))
-                emit_proj(b + 1, 1)
+                if not self.fused_proj:
+                    emit_proj(b + 1, 1)
                 et = _capi.EdgeTransitionArgs()
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
                 et.w1z_f16, et.w2_f16, et.b2 = w[f"{b}.et.w1z16"].data_ptr(), w[f"{b}.et.w216"].data_ptr(), w[f"{b}.et.b2"].data_ptr()

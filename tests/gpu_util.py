@@ -97,18 +97,41 @@ def rigid_update(quat, rot, trans, upd, mask):
     return qo, ro, to
 
 
+def ipa_projection(s, w16, bias, rot, trans):
+    """The inference plan's stand-alone projection (pf_linear_fwd on the packed matrix of engine.pack_ipa_projection with the frame
+    transform of the points in its epilogue): proj [rows,3744] (columns 0..3071 written), qp, kp, vp."""
+    lib = _capi.load()
+    rows, d = s.shape[0], s.device
+    proj = torch.full((rows, 3744), float("nan"), device=d)
+    qp, kp, vp = (torch.full((rows, n), float("nan"), device=d) for n in (192, 192, 288))
+    a = _capi.LinearArgs()
+    a.x, a.ldx, a.w, a.ldw, a.w_f16, a.bias = _p(s), 128, None, 128, _p(w16), _p(bias)
+    a.y, a.ldy, a.M, a.N, a.K = _p(proj), 3744, rows, 3968, 128
+    a.pt_rot, a.pt_trans, a.pt_col0, a.pt_qp, a.pt_kp, a.pt_vp = _p(rot), _p(trans), 3072, _p(qp), _p(kp), _p(vp)
+    _capi.check(lib.pf_linear_fwd(C.byref(a), _capi.stream_ptr()), "pf_linear_fwd (packed IPA projection)")
+    sync()
+    return proj, (qp, kp, vp)
+
+
 def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None,
-              dz=None, fused_pair=False):
+              dz=None, fused_pair=False, points=None, fused_proj=None):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
     variant=1); head_group: force a head-group split of the one-kernel form; dz: [B,L,L,16] pair values W_dz z (no bias) for the
     two-kernel form's pair aggregation (z may then be None); fused_pair: that aggregation inside the score kernel (p_out may be None)."""
     lib = _capi.load()
     rows = B * L
     d = proj.device
-    qp, kp, vp = torch.empty(rows, 192, device=d), torch.empty(rows, 192, device=d), torch.empty(rows, 288, device=d)
-    pa = _capi.IpaPointsArgs()
-    pa.proj, pa.ldp, pa.rot, pa.trans, pa.qp, pa.kp, pa.vp, pa.rows = _p(proj), proj.shape[1], _p(rot), _p(trans), _p(qp), _p(kp), _p(vp), rows
-    _capi.check(lib.pf_ipa_points_fwd(C.byref(pa), _capi.stream_ptr()), "pf_ipa_points_fwd")
+    # points: (qp, kp, vp) already in the global frame (ipa_projection); fused_proj: (s [rows,128], w16, bias) -- the projection runs
+    # inside the score kernel (pf_ipa_attn_args.s_in), `proj` is its k | v scratch and no point buffer is read
+    if fused_proj is not None:
+        qp = kp = vp = None
+    elif points is not None:
+        qp, kp, vp = points
+    else:
+        qp, kp, vp = torch.empty(rows, 192, device=d), torch.empty(rows, 192, device=d), torch.empty(rows, 288, device=d)
+        pa = _capi.IpaPointsArgs()
+        pa.proj, pa.ldp, pa.rot, pa.trans, pa.qp, pa.kp, pa.vp, pa.rows = _p(proj), proj.shape[1], _p(rot), _p(trans), _p(qp), _p(kp), _p(vp), rows
+        _capi.check(lib.pf_ipa_points_fwd(C.byref(pa), _capi.stream_ptr()), "pf_ipa_points_fwd")
     feats = torch.full((rows, 1536), float("nan"), device=d)
     ia = _capi.IpaAttnArgs()
     ia.proj, ia.ldp, ia.qp, ia.kp, ia.vp, ia.z = _p(proj), proj.shape[1], _p(qp), _p(kp), _p(vp), _p(z)
@@ -122,6 +145,8 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.dz = _p(dz)
     ia.dz_f16 = int(dz is not None and dz.dtype == torch.float16)
     ia.fused_pair = int(fused_pair)
+    if fused_proj is not None:
+        ia.s_in, ia.proj_w_f16, ia.proj_bias = _p(fused_proj[0]), _p(fused_proj[1]), _p(fused_proj[2])
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)

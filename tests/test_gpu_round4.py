@@ -1,0 +1,130 @@
+"""Round-4 GPU tests: the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, ipa_pytorch.py:347-387 + 389-475 in one
+launch) through the C ABI and in the step, and a longer free run at the full benchmarked shape."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gpu_util as G
+import pepflowww_amd
+from oracle import pepflow_oracle as O
+from pepflowww_amd import _capi, synth
+from pepflowww_amd.engine import pack_ipa_projection
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def cu(t):
+    return t.to(G.dev()).contiguous()
+
+
+@pytest.mark.parametrize("B,L,fused_pair", [(3, 96, False), (2, 128, True), (2, 64, False), (3, 80, True), (1, 128, False)])
+def test_ipa_projection_inside_the_score_kernel(seeded_sd, B, L, fused_pair):
+    """pf_ipa_attn_args.s_in: every (sample, head) workgroup projects its own rows (q / points on chip, k | v through the `proj`
+    scratch).  Bit-identical to pf_linear_fwd (packed projection, frames in the epilogue) followed by the plain call -- dense, with
+    key ends (ragged L, a hole, a nearly empty sample) -- and equal to the oracle's IPA on the unmasked rows."""
+    g = torch.Generator().manual_seed(4000 + L + B)
+    pfx = "ga_encoder.trunk.ipa_4."
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    mask[0, (L * 5) // 9:] = 0
+    if B > 1:
+        mask[1, L - 13:] = 0
+        mask[1, 7] = 0
+    if B > 2:
+        mask[2, :] = 0
+        mask[2, 3:9] = 1
+    kend = (mask.to(torch.int32) * torch.arange(1, L + 1, dtype=torch.int32)).amax(-1)
+    sd = seeded_sd
+    gq = lambda k: cu(sd[pfx + k])
+    wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    w16, bp = pack_ipa_projection(cu(wproj), cu(bproj))
+    sdev, Rd, xd, md = cu(s.reshape(B * L, 128)), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1))
+    bias = cu((math.sqrt(1.0 / 3.0) * F.linear(z, sd[pfx + "linear_b.weight"], sd[pfx + "linear_b.bias"])).reshape(B, L, L, 8).permute(0, 3, 1, 2))
+    dz = cu(F.linear(z, sd[pfx + "down_z.weight"]).contiguous())
+    proj, pts = G.ipa_projection(sdev, w16, bp, Rd, xd)
+
+    def run(ke, inside):
+        scratch = torch.full((B * L, 3744), float("nan"), device=G.dev())
+        return G.ipa_feats(scratch if inside else proj, None, Rd, xd, md, gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"),
+                           gq("down_z.bias"), gq("head_weights"), B, L, bias=bias,
+                           p_out=None if fused_pair else torch.zeros(B, 8, L, L, device=G.dev()), variant=2, key_end=ke, dz=dz,
+                           fused_pair=fused_pair, points=None if inside else pts,
+                           fused_proj=(sdev, w16, bp) if inside else None)[0].cpu()
+    valid = mask.reshape(-1).bool()
+    ref_out, ref_feats = O.ipa(sd, pfx[:-1], s, z, R, x, mask)
+    for ke in (None, cu(kend)):
+        two, one = run(ke, False), run(ke, True)
+        assert torch.equal(one[valid], two[valid]), float((one[valid] - two[valid]).abs().max())
+        G.assert_close(one[valid], ref_feats.reshape(B * L, -1)[valid], REL, "projection inside the score kernel vs oracle")
+        assert torch.equal(run(ke, True)[valid], one[valid])                        # stable from launch to launch
+    beyond = (torch.arange(L)[None, :] >= kend[:, None]).reshape(-1)
+    assert torch.isnan(one[beyond]).all()                                           # rows beyond a key end are not written
+
+
+def test_projection_inside_needs_one_workgroup_per_sample_and_head(seeded_sd):
+    """The form is refused where a sample's query tiles span several score workgroups (L > 128) or L % 4 != 0 (the engine's rule
+    `64 <= L <= 128 and L % 4 == 0` never asks for it there)."""
+    sd, pfx = seeded_sd, "ga_encoder.trunk.ipa_0."
+    for B, L in ((1, 144), (1, 90)):
+        g = torch.Generator().manual_seed(L)
+        s = torch.randn(B * L, 128, generator=g)
+        wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+        bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+        w16, bp = pack_ipa_projection(cu(wproj), cu(bproj))
+        eye = cu(torch.eye(3).reshape(1, 9).repeat(B * L, 1))
+        gq = lambda k: cu(sd[pfx + k])
+        with pytest.raises(Exception):
+            G.ipa_feats(torch.zeros(B * L, 3744, device=G.dev()), None, eye, cu(torch.zeros(B * L, 3)), cu(torch.ones(B * L)),
+                        gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"), B, L,
+                        bias=torch.zeros(B, 8, L, L, device=G.dev()), p_out=torch.zeros(B, 8, L, L, device=G.dev()), variant=2,
+                        dz=torch.zeros(B, L, L, 16, device=G.dev()), fused_proj=(cu(s), w16, bp))
+
+
+@pytest.mark.parametrize("B,L", [(2, 64), (3, 112), (2, 128)])
+def test_step_with_and_without_the_projection_launch_is_bit_identical(seeded_sd, B, L):
+    """DenoiseEngine.fused_proj: one denoise step with the projection inside the score kernels equals the step with the separate
+    projection launches bit for bit (rotations, translations, angles, logits), on a padded batch too -- and has six launches less."""
+    from pepflowww_amd.engine import DenoiseEngine, PackedWeights
+    batch = synth.make_pocket_batch(B, L, 8, seed=3)
+    if B > 2:
+        batch["res_mask"][2, L - 20:] = False
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    model.load_state_dict(seeded_sd, strict=True)
+    model = model.to(G.dev()).eval()
+    bd = {k: (v.to(G.dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        R1, x1, ang1, seq1, node, edge = model.encode(bd)
+    w = model.ga_encoder.packed_weights(G.dev())
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, L, 4, generator=g)
+    Rt = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    xt, at = torch.randn(B, L, 3, generator=g) * 5, torch.rand(B, L, 5, generator=g) * 6
+    st = torch.randint(0, 20, (B, L), generator=g)
+    t = torch.rand(B, 1, generator=g)
+    outs, launches = [], []
+    for flag in ("0", "1"):
+        os.environ["PF_FUSED_PROJ"] = flag
+        try:
+            eng = DenoiseEngine(w, B, L, G.dev())
+        finally:
+            del os.environ["PF_FUSED_PROJ"]
+        assert eng.fused_proj == (flag == "1")
+        eng.bind_context(node, edge, bd["res_mask"])
+        eng.set_state(cu(t), cu(Rt), cu(xt), cu(at), cu(st))
+        eng.run()
+        G.sync()
+        m = bd["res_mask"].reshape(-1).bool().cpu()
+        outs.append([eng.rot.cpu()[m], eng.trans.cpu()[m], eng.ang_raw.cpu()[m], eng.logits.cpu()[m]])
+        launches.append(eng.n_launches)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    assert launches[0] - launches[1] == 6, launches
