@@ -196,6 +196,8 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             all_gather_final_state(smp)
         info["validity"] = check_final_state(smp, batch, NS)
         info["launches_per_step"] = eng.n_launches + 1
+        if wl.get("read_sclk"):
+            info["sclk"] = sclk_under_load(smp, use_graph)
         ck = _Clock()
         traj = smp.trajectory()                                      # the one D2H of a call: NS steps x (rot, trans, angles, seq, simplex)
         ck.lap("d2h_ms")
@@ -230,7 +232,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
 def pmc_traffic(workload, precision):
     """HBM bytes per launch of the two big kernels from the PMC passes recorded under profiles/ (rocprofv3 cannot run
     inside this process; tools/pmc_traffic.sh regenerates the file); corrected as MI355X_MICROARCH.md prescribes."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 d = json.load(f)
@@ -239,6 +241,50 @@ def pmc_traffic(workload, precision):
         except Exception:
             continue
     return {}, None
+
+
+def sclk_under_load(smp, use_graph):
+    """Shader clock while the step loop runs (VERDICT r3 weak 9: the MFMA `frac` is priced against a peak quoted at the guide's clock;
+    the part holds less under sustained matrix load): ~0.3 s of steps are queued, then `rocm-smi --showclocks --json` is read while
+    the device works through them.  None when rocm-smi is unavailable.  Outside the timed region."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        smp.run(96, use_graph=use_graph)                         # asynchronous: the host returns while the device is busy
+        out = subprocess.run([exe, "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        torch.cuda.synchronize()
+        d = json.loads(out[out.index("{"):])
+        card = d.get(f"card{torch.cuda.current_device()}") or next(iter(d.values()))
+        res = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "mhz" in str(v).lower():
+                res["sclk_mhz"] = int("".join(ch for ch in str(v).split("Mhz")[0].split("(")[-1] if ch.isdigit()))
+            elif "mclk" in kl and "mhz" in str(v).lower():
+                res["mclk_mhz"] = int("".join(ch for ch in str(v).split("Mhz")[0].split("(")[-1] if ch.isdigit()))
+        res["note"] = "rocm-smi --showclocks read while 96 queued steps were executing"
+        return res or None
+    except Exception as e:                                       # never fail the bench line over a clock read-out
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def whole_step_traffic(traffic, src, algorithmic_bytes):
+    """Sum of the counted HBM bytes of every kernel of one step (profiles/rNN/pmc_traffic.json: bytes per launch x launches per
+    step, FETCH_SIZE doubled per the guide + WRITE_SIZE) next to the algorithmic 4096 B (2048 in the f16 mode) per pair and step."""
+    per = traffic.get("_per_step") if isinstance(traffic, dict) else None
+    if not per:
+        return None
+    tot = sum(float(v["hbm_bytes_corrected"]) * int(v["launches_per_step"]) for v in per.values())
+    return {"counted_bytes_per_step": tot, "algorithmic_bytes_per_step": algorithmic_bytes, "ratio": tot / algorithmic_bytes if algorithmic_bytes else None,
+            "kernels": {k: {"MB_per_launch": round(float(v["hbm_bytes_corrected"]) / 1e6, 1), "launches_per_step": int(v["launches_per_step"])} for k, v in per.items()},
+            "source": src}
 
 
 def main():
@@ -311,7 +357,7 @@ def main():
         return bench_train(args, wl, dev, dist, rank, world)
     use_graph = not args.no_graph
     prec = args.precision
-    elapsed, info = run_sampler(wl, K, W, dev, dist, rank, world, use_graph, prec)
+    elapsed, info = run_sampler(dict(wl, read_sclk=(rank == 0)), K, W, dev, dist, rank, world, use_graph, prec)
     B, L = info["B"], info["L"]
     pairs = info["real_pairs"]                  # = B * L * L unless the batch is padded (cfg3): rooflines count unmasked pairs only
     split = 3 if prec == "fp32" else 1
@@ -371,6 +417,11 @@ def main():
                          "pair_tensor": "f16" if zb != 4096 else "fp32"},
         "final_state_check": info["validity"],
     }
+    if info.get("sclk") is not None:
+        out["clocks_under_load"] = info["sclk"]
+    wst = whole_step_traffic(traffic, traffic_src, zb * pairs)
+    if wst is not None:
+        out["whole_step_traffic"] = wst
     if wl.get("variable"):
         out["config"]["real_residues_per_gpu"] = info["real_residues"]
         out["value_real_residues"] = world * info["real_residues"] * K / elapsed
@@ -404,6 +455,17 @@ def main():
                 ent["value_real_residues"] = im["real_residues"] * K / em
                 ent["unmasked_pairs"] = im["real_pairs"]
             out["modes"][name] = ent
+        # BASELINE configs[4] (train_ddp.py:117-156 per GPU): one graph-replayed training step, timed the same way (fewer steps: the
+        # step is ~4 x longer and the capture dominates the wall time of this entry)
+        try:
+            kt = max(10, K // 5)
+            tr = run_train(WORKLOADS["cfg5"], kt, 3, dev, None, 0, 1, use_graph)
+            out["modes"]["fp32@cfg5"] = {"workload": WORKLOADS["cfg5"]["name"], "precision": "fp32", "dtype": tr["dtype"], "ms_per_step": tr["ms_per_step"],
+                                         "value": tr["value"], "unit": tr["unit"], "steps": kt, "metric": tr["metric"],
+                                         "mfma_frac_of_split_ceiling": tr["roofline"]["frac"], "launches_per_step": tr["config"].get("launches_per_step")}
+        except Exception as e:                                   # the training entry must never take the inference line down with it
+            out["modes"]["fp32@cfg5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_per_call and args.workload == "cfg4":
         out["per_call"] = per_call_bench(dev, prec)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -415,12 +477,20 @@ def main():
 
 
 def bench_train(args, wl, dev, dist, rank, world):
+    out = run_train(wl, args.steps, args.warmup, dev, dist, rank, world, not args.no_graph)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_train(wl, K, W, dev, dist, rank, world, use_graph):
     """cfg5: one training step = model(batch) -> weighted loss -> backward (HIP backward kernels) -> for N > 1 one flat
-    gradient all-reduce (RCCL)."""
+    gradient all-reduce (RCCL).  Returns the JSON-able result line."""
     import pepflowww_amd
     from pepflowww_amd import synth
     from pepflowww_amd.distributed import allreduce_gradients
-    B, L, K, W = wl["B"], wl["L"], args.steps, args.warmup
+    B, L = wl["B"], wl["L"]
     model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
     model.load_state_dict(synth.seeded_state_dict())
     model = model.to(dev).train()
@@ -431,7 +501,7 @@ def bench_train(args, wl, dev, dist, rank, world):
 
     from pepflowww_amd.train_forward import default_train_noise
     graphed = None
-    if not args.no_graph:
+    if use_graph:
         # the whole step (corrupt, forward, losses, backward) replayed as one hipGraph; gradients land in static tensors
         from pepflowww_amd.train_step import GraphedTrainStep
         graphed = GraphedTrainStep(model, batch, wts, first_sample=first, generator=gen)
@@ -480,10 +550,9 @@ def bench_train(args, wl, dev, dist, rank, world):
                         "note": "fp32-equivalent flops = 3 x forward (SURVEY.md 8(d)); ceiling = dense f16 MFMA peak / 3 (split-precision products), "
                                 "the same ceiling as the inference line; vs the exact-fp32 MFMA peak (157.3 TF) the fraction is "
                                 f"{value / world * TRAIN_FLOPS_PER_RES / MFMA_F32_PEAK:.3f}"}}
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if graphed is not None and hasattr(graphed, "n_launches"):
+        out["config"]["launches_per_step"] = graphed.n_launches
+    return out
 
 
 PER_CALL_STEPS = 200

@@ -267,7 +267,12 @@ def load():
     return lib
 
 
+CALLS = 0          # C-ABI calls checked so far (GraphedTrainStep reports how many one captured step makes)
+
+
 def check(code, what):
+    global CALLS
+    CALLS += 1
     if code != 0:
         raise PepflowHipError(f"{what} failed with code {code} "
                               f"({'bad argument' if code == -1 else 'problem too large' if code == -2 else 'hipError_t'})")

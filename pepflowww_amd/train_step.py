@@ -129,12 +129,14 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        calls0 = _capi.CALLS
         with torch.cuda.graph(self.graph):
             losses, state = _step_forward(model, sd, self.batch, self.noise, 0, first_sample, seed_dev=self.seed)
             grads, self.arena = _step_backward(state, self.weights, return_arena=True)
             self.losses = losses
             self.grads = {n: grads[n].reshape(sd[n].shape) for n in self.names if grads.get(n) is not None}
             del state
+        self.n_launches = _capi.CALLS - calls0            # C-ABI calls of one captured step (a few of them launch two kernels)
         for n, p in model.named_parameters():
             p.grad = self.grads.get(n)
         self.check_weight_range()

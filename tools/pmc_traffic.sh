@@ -7,7 +7,7 @@ for W in cfg2 cfg4; do
     [ $W = cfg2 ] && [ $P = f16 ] && continue
     for C in FETCH_SIZE WRITE_SIZE; do
       OUT=gpurun_out/pt_${W}_${P}_$C; rm -rf $OUT
-      rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --workload $W --precision $P > $OUT.log 2>&1
+      rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --no-modes --no-per-call --workload $W --precision $P > $OUT.log 2>&1
     done
   done
 done
@@ -36,6 +36,26 @@ for W in ("cfg2", "cfg4"):
             f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
             w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
             res[name][key] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_corrected": int((2 * f + w) * 1024), "launches": len(d["FETCH_SIZE"])}
+        # every kernel of OURS in the run, per step: bytes per launch x launches per step (bench.py sums them: whole_step_traffic).
+        # The run holds W + K sampler steps + min(K, 10) instrumented plan runs = 1 + 4 + 4 = 9 passes over the plan.
+        allk = collections.defaultdict(lambda: collections.defaultdict(list))
+        for C in ("FETCH_SIZE", "WRITE_SIZE"):
+            for f in glob.glob(f"gpurun_out/pt_{W}_{P}_{C}/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"]
+                    if "anonymous namespace" in k and row["Counter_Name"] == C and "edge_features" not in k and "node_features" not in k:
+                        short = k.split("::")[-1].split("(")[0].split("<")[0].strip()
+                        allk[short][C].append(float(row["Counter_Value"]))
+        per = {}
+        for short, d in allk.items():
+            n = len(d["FETCH_SIZE"])
+            if n < 9:                       # set-up kernels (bind_context, sampler init): not part of a step
+                continue
+            f = sum(d["FETCH_SIZE"]) / max(1, n)
+            w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
+            lps = n / 9.0 if short != "sampler_step_kernel" else n / 5.0
+            per[short] = {"hbm_bytes_corrected": int((2 * f + w) * 1024), "launches_per_step": int(round(lps))}
+        res[name]["_per_step"] = per
         sk = "ipa_scores_kernel" if "ipa_scores_kernel" in res[name] else "ipa_scores16_kernel"
         pk = next((k for k in ("ipa_pair_dz_kernel", "ipa_pair_dz16_kernel") if k in res[name]), "ipa_pair_kernel")
         if sk in res[name] and pk in res[name]:
