@@ -184,7 +184,10 @@ constexpr int PJ_NPAD = 3968;
 constexpr int PJ_CT = 3;                      // weight tiles per staged chunk: 3 x (4 K-steps x hi | lo x 1 KiB) = 24 KiB, two buffers
 constexpr int PJ_NCH = (PJ_TILES + PJ_CT - 1) / PJ_CT;
 constexpr int PJ_CHUNK_B = PJ_CT * 8 * 1024;
-constexpr int PJ_STAGE_B = 2 * PJ_CHUNK_B;    // + the waves' query-point regions ([16][24] floats each) behind it
+constexpr int PJ_NB = 4;                      // staging buffers: the chunk in use + 3 in flight (one chunk is ~0.3 - 0.6 us of MFMAs, an
+                                              //  LDS-DMA round trip 1 - 2 us: with ONE chunk in flight every chunk waited for its pieces --
+                                              //  the prologue took 11.7 us per workgroup at B=64, L=128 against 6 us of MFMA time)
+constexpr int PJ_STAGE_B = PJ_NB * PJ_CHUNK_B;    // + the waves' query-point regions ([16][24] floats each) behind it
 __device__ __forceinline__ constexpr int pj_tile(int idx, int h) {   // feature tile (of 16) of the packed projection
     return idx < 8 ? 8 * h + idx : idx < 24 ? 64 + 16 * h + (idx - 8) : idx < 26 ? 192 + 2 * h + (idx - 24) : 208 + 5 * h + (idx - 26);
 }
@@ -197,29 +200,53 @@ __device__ __forceinline__ void pj_glds16(const void* sbase, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void pj_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant): everything but the n youngest vector
+// memory operations of this wave has completed (they complete in order)
+__device__ __forceinline__ void pj_wait_vm_dyn(int n) {
+    n = __builtin_amdgcn_readfirstlane(n);
+    switch (n > 40 ? 40 : n) {
+#define PJ_W(k) case k: pj_wait_vm<k>(); break;
+        PJ_W(0) PJ_W(1) PJ_W(2) PJ_W(3) PJ_W(4) PJ_W(5) PJ_W(6) PJ_W(7) PJ_W(8) PJ_W(9) PJ_W(10) PJ_W(11) PJ_W(12) PJ_W(13) PJ_W(14)
+        PJ_W(15) PJ_W(16) PJ_W(17) PJ_W(18) PJ_W(19) PJ_W(20) PJ_W(21) PJ_W(22) PJ_W(23) PJ_W(24) PJ_W(25) PJ_W(26) PJ_W(27) PJ_W(28)
+        PJ_W(29) PJ_W(30) PJ_W(31) PJ_W(32) PJ_W(33) PJ_W(34) PJ_W(35) PJ_W(36) PJ_W(37) PJ_W(38) PJ_W(39) PJ_W(40)
+#undef PJ_W
+    }
+}
+__device__ __forceinline__ constexpr int pj_kv_tiles(int c) {    // k | v tiles (one store instruction each) of chunk c
+    int n = 0;
+    for (int t = 0; t < PJ_CT; ++t) n += (c >= 0 && PJ_CT * c + t >= 8 && PJ_CT * c + t < 24) ? 1 : 0;
+    return n;
+}
 struct PjW { half8 h[4], l[4]; };
 // Called by EVERY wave of the workgroup (barriers inside).  The head's 248 KiB of weight fragments go L2 -> LDS ONCE per workgroup
 // (LDS-DMA, two 24 KiB buffers, the next chunk in flight under the current chunk's MFMAs) and every wave reads its operands from
 // there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
 // 64 B / clk L1 path and the prologue cost what the projection launch it replaced had cost.
 __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, float* KP,
-                                          float* VP, unsigned char* WS /* 2 x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
+                                          float* VP, unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
+                                          float* PB /* [PJ_TILES * 16] the head's bias, staged here */,
                                           float4 (&qf)[8], float4 (&qp4)[6], int lane, int wave, int nw) {
     const int r = lane & 15, g = lane >> 4;
     const unsigned char* whp = reinterpret_cast<const unsigned char*>(a.proj_w_f16);
     const unsigned char* wlp = whp + (size_t)PJ_NPAD * 128 * 2;
     const unsigned ws0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)WS;
     const unsigned l16 = lane * 16;
-    // chunk c -> buffer c & 1: piece (tile tl, K-step ks, plane pl) at ((tl * 4 + ks) * 2 + pl) KiB; pieces wave, wave + nw, ...
+    // chunk c -> buffer c % PJ_NB: piece (tile tl, K-step ks, plane pl) at ((tl * 4 + ks) * 2 + pl) KiB; every wave issues PPW pieces
+    // per chunk (pieces wave, wave + nw, ...; the last ones of a wave may repeat the chunk's last piece: the counted waits below need
+    // the same number of pieces from every wave and every chunk)
+    const int ppw = (PJ_CT * 8 + nw - 1) / nw;
     auto issue = [&](int c) __attribute__((always_inline)) {
-        const int ntl = min(PJ_CT, PJ_TILES - PJ_CT * c);
-        for (int pc = wave; pc < ntl * 8; pc += nw) {
+        const int npc = min(PJ_CT, PJ_TILES - PJ_CT * c) * 8;
+        for (int k = 0; k < ppw; ++k) {
+            const int pc = min(wave + k * nw, npc - 1);
             const int tl = pc >> 3, ks = (pc >> 1) & 3, pl = pc & 1;
             const int T16 = pj_tile(PJ_CT * c + tl, h);
-            pj_glds16((pl ? wlp : whp) + (size_t)(T16 * 4 + ks) * 1024, l16, ws0 + (c & 1) * PJ_CHUNK_B + pc * 1024);
+            pj_glds16((pl ? wlp : whp) + (size_t)(T16 * 4 + ks) * 1024, l16, ws0 + (c % PJ_NB) * PJ_CHUNK_B + pc * 1024);
         }
     };
-    issue(0);
+    // the head's 496 bias values -> LDS (read per tile in the epilogues: from global memory each of them was an exposed L2 round trip
+    // in a wave that has nothing else to issue); visible after the first chunk barrier
+    for (int i = wave * 64 + lane; i < PJ_TILES * 16; i += nw * 64) PB[i] = a.proj_bias[16 * pj_tile(i >> 4, h) + (i & 15)];
     // x operand: row iq, K-step ks, slots 8 g .. + 7, as hi / lo planes (split4: the same conversion as the stand-alone kernel)
     half8 xh[4], xl[4];
     float R[9], T[3];
@@ -244,9 +271,14 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
             for (int e = 0; e < 4; ++e) { xh[ks][e] = h0[e]; xh[ks][4 + e] = h1[e]; xl[ks][e] = l0[e]; xl[ks][4 + e] = l1[e]; }
         }
     }
+    // (the row loads above are OLDER than every LDS-DMA piece: the waits below count what is younger than a chunk's pieces)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < PJ_NB - 1; ++c)
+        if (c < PJ_NCH) issue(c);
     float* kvrow = const_cast<float*>(a.proj) + (rowb + iq) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
     auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
-        const unsigned char* b = WS + (c & 1) * PJ_CHUNK_B + tl * 8192 + lane * 16;
+        const unsigned char* b = WS + (c % PJ_NB) * PJ_CHUNK_B + tl * 8192 + lane * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             w.h[ks] = *reinterpret_cast<const half8*>(b + ks * 2048);
@@ -257,13 +289,16 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         constexpr int c = decltype(ic)::value;
         // chunk c has landed: this wave's pieces (the k | v stores of the previous chunk's tiles are younger: counted wait -- vector
         // memory operations complete in order), then everybody's (barrier), which also frees the buffer of chunk c - 1
-        constexpr int NST = c == 0 ? 0 : ((PJ_CT * (c - 1) + 0 >= 8 && PJ_CT * (c - 1) + 0 < 24) + (PJ_CT * (c - 1) + 1 >= 8 && PJ_CT * (c - 1) + 1 < 24) +
-                                          (PJ_CT * (c - 1) + 2 >= 8 && PJ_CT * (c - 1) + 2 < 24));
-        if (wave_on) pj_wait_vm<NST>();
-        else pj_wait_vm<0>();
+        // younger than the pieces of chunk c: the pieces of the chunks issued after it (up to PJ_NB - 2 of them) and, in a wave with
+        // rows, the k | v stores of the chunks computed since (c - PJ_NB + 1 .. c - 1).  Never MORE than that (an over-count would let
+        // a piece of chunk c be outstanding); uncounted extras (bias loads) only make the wait stricter.
+        constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH) + (PJ_NB > 4 && c + 3 < PJ_NCH);
+        constexpr int NSY = pj_kv_tiles(c - 1) + (PJ_NB > 3 ? pj_kv_tiles(c - 2) : 0) + (PJ_NB > 3 ? pj_kv_tiles(c - 3) : 0);
+        static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");
+        pj_wait_vm_dyn((PJ_NB == 2 ? 0 : NDY * ppw) + (wave_on ? (PJ_NB == 2 ? pj_kv_tiles(c - 1) : NSY) : 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (c + 1 < PJ_NCH) issue(c + 1);
+        if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
         if (wave_on) {
             PjW wa, wb;
             ldfrag(c, 0, wa);
@@ -279,8 +314,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                         ac = mfma_h(w.h[ks], xl[ks], ac);
                         ac = mfma_h(w.l[ks], xh[ks], ac);
                     }
-                    const int n = 16 * pj_tile(idx, h) + 4 * g;
-                    const float4 b4 = *reinterpret_cast<const float4*>(a.proj_bias + n);
+                    const float4 b4 = *reinterpret_cast<const float4*>(PB + 16 * idx + 4 * g);
                     float v[4];
                     v[0] = (am[0] + ac[0] * PF_LO_INV) + b4.x; v[1] = (am[1] + ac[1] * PF_LO_INV) + b4.y;
                     v[2] = (am[2] + ac[2] * PF_LO_INV) + b4.z; v[3] = (am[3] + ac[3] * PF_LO_INV) + b4.w;
@@ -375,7 +409,8 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + min(j, L - 1)] : 0.f;
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
         float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + wave * 16 * 24;   //  sizes the allocation for staging + query points)
-        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, VP, WS, QPW, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
+        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (blockDim.x >> 6) * 16 * 24;
+        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, VP, WS, QPW, PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
         if (!wave_on) return;
         loadk(0, kf);
@@ -1269,7 +1304,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
                 attr_pj = true;
             }
             // the score regions double as the weight staging buffers + the waves' query-point regions during the prologue
-            const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float);
+            const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
             const size_t ldsp = lds > need ? lds : need;
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
             if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
