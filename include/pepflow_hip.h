@@ -317,16 +317,16 @@ typedef struct {
     const float* z_in;             /* [B*L*L,64] */
     float* z_out;                  /* may alias z_in */
     const float* pre;              /* [B*L,512] */
-    const void* w1z_f16;           /* trunk.0.weight[:, :64]  (N=192, K=64)  */
-    const void* w2_f16;            /* trunk.2.weight          (N=192, K=192) */
+    const void* w1z_f16;           /* UNUSED since ABI 50 (operands of the round-1 tiled kernel, removed): leave NULL */
+    const void* w2_f16;            /* UNUSED since ABI 50 */
     const float* b2;               /* trunk.2.bias [192] */
-    const void* wf_f16;            /* final_layer.weight      (N=64,  K=192) */
+    const void* wf_f16;            /* UNUSED since ABI 50 */
     const float* ln_g; const float* ln_b;
     const float* mask;             /* [B*L] */
     int B, L;
-    /* optional: the three matrices as ONE 256 KiB stream of 128 fragment pairs in consumption order
-     * (pepflowww_amd.engine.pack_et_stream).  When set, the persistent LDS-ring kernel is used
-     * (csrc/edge_transition_v3.hip) and w1z_f16 / w2_f16 / wf_f16 may be NULL.  The lo halves of the stream (and of
+    /* REQUIRED (this or w_stream32): trunk.0.weight[:, :64], trunk.2.weight and final_layer.weight as ONE 256 KiB stream of
+     * 128 fragment pairs in consumption order (pepflowww_amd.engine.pack_et_stream) for the persistent LDS-ring kernel
+     * (csrc/edge_transition_v3.hip).  The lo halves of the stream (and of
      * wb_frags) are f16(w - hi) UNSCALED -- this kernel adds all three products into one accumulator -- unlike the
      * w - hi times 2048 of every other split-precision operand (pf_split_pack_f16). */
     const void* w_stream;

@@ -368,8 +368,7 @@ class PackedWeights:
                 t[f"{b}.et.init.w"], t[f"{b}.et.init.b"] = g(q + "initial_embed.weight"), g(q + "initial_embed.bias")
                 w1, b1 = g(q + "trunk.0.weight"), g(q + "trunk.0.bias")
                 wf, bf = g(q + "final_layer.weight"), g(q + "final_layer.bias")
-                t[f"{b}.et.w1z16"], t[f"{b}.et.wf16"] = split_f16(w1[:, :64]), split_f16(wf)
-                t[f"{b}.et.w216"], t[f"{b}.et.b2"] = split_f16(g(q + "trunk.2.weight")), g(q + "trunk.2.bias")
+                t[f"{b}.et.b2"] = g(q + "trunk.2.bias")
                 t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.stream32"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf)
@@ -719,8 +718,7 @@ class DenoiseEngine:
                     emit_proj(b + 1, 1)
                 et = _capi.EdgeTransitionArgs()
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
-                et.w1z_f16, et.w2_f16, et.b2 = w[f"{b}.et.w1z16"].data_ptr(), w[f"{b}.et.w216"].data_ptr(), w[f"{b}.et.b2"].data_ptr()
-                et.wf_f16, et.ln_g, et.ln_b = w[f"{b}.et.wf16"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
+                et.b2, et.ln_g, et.ln_b = w[f"{b}.et.b2"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
                 et.w_stream = w[f"{b}.et.stream"].data_ptr()
                 et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
                 if self.et_v4:

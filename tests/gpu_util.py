@@ -155,16 +155,16 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
 def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None,
                     next_dz=None, single_pass=False, dz_f16=False):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
-    persistent=True: the LDS-ring kernel (w_stream); False: the tiled kernel (w1z/w2/wf planes); "v4": the 32x32 kernel
+    persistent=True: the 16x16x32 LDS-ring kernel (w_stream, csrc/edge_transition_v3.hip); "v4": the 32x32 kernel
     (w_stream32 / wb_frags32, csrc/edge_transition_v4.hip).
     next_dz: down_z.weight [16,64] of the next IPA block (with next_bias): also returns dz [B,L,L,16] = W_dz z'."""
     from pepflowww_amd.engine import split_f16, pack_et_stream
     lib = _capi.load()
     if out is None:
         out = z if inplace else torch.full_like(z, float("nan"))
-    w1s, w2s, wfs = split_f16(w1[:, :64]), split_f16(w2), split_f16(wf)
+    assert persistent, "the tiled (round-1) kernel was removed in round 4: persistent=True (16x16x32 ring kernel) or \"v4\""
     a = _capi.EdgeTransitionArgs()
-    a.z_in, a.z_out, a.pre, a.w1z_f16, a.w2_f16, a.b2, a.wf_f16 = _p(z), _p(out), _p(pre), _p(w1s), _p(w2s), _p(b2), _p(wfs)
+    a.z_in, a.z_out, a.pre, a.b2 = _p(z), _p(out), _p(pre), _p(b2)
     a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
     ws = pack_et_stream(w1[:, :64], w2, wf) if persistent else None
     a.w_stream = _p(ws)
