@@ -535,6 +535,15 @@ def run_train(wl, K, W, dev, dist, rank, world, use_graph):
         elapsed = float(tt.item())
     grads = [p.grad for p in model.parameters() if p.grad is not None] if graphed is None else list(graphed.grads.values())
     assert grads and all(torch.isfinite(g).all() for g in grads), "non-finite gradients in the timed step"
+    grad_sync = None
+    if dist is not None:
+        # after the all-reduce every replica must hold the SAME averaged gradient: compare a float64 checksum across the ranks
+        cs = torch.stack([g.double().sum() for g in grads]).sum().reshape(1)
+        mm = torch.cat([cs, -cs])
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX)                # [max, -min] over the ranks
+        vals = [float(mm[0].item()), -float(mm[1].item())]
+        grad_sync = {"checksum": vals[0], "identical_on_all_ranks": vals[0] == vals[1]}
+        assert grad_sync["identical_on_all_ranks"], f"gradient replicas differ after the all-reduce: max / min checksum {vals}"
     value = world * B * L * K / elapsed
     # the step's matrix products run as 3 x f16 split MFMA (pair-sized) and exact fp32 MFMA (row-sized): the ceiling of the
     # dominant (pair-sized) part is the dense f16 peak / 3, the same ceiling as the inference line
@@ -552,6 +561,8 @@ def run_train(wl, K, W, dev, dist, rank, world, use_graph):
                                 f"{value / world * TRAIN_FLOPS_PER_RES / MFMA_F32_PEAK:.3f}"}}
     if graphed is not None and hasattr(graphed, "n_launches"):
         out["config"]["launches_per_step"] = graphed.n_launches
+    if grad_sync is not None:
+        out["gradient_allreduce"] = grad_sync
     return out
 
 

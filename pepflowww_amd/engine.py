@@ -505,6 +505,24 @@ class DenoiseEngine:
             self._samplers.move_to_end(key)
         return smp
 
+    RANGE_WARN = 0.5 * F16_MAX
+
+    def operand_range(self):
+        """Largest |value| of the activations this engine carries from kernel to kernel (node state, pair tensor, per-residue
+        EdgeTransition terms, attention features) after a step -- ONE small reduction per buffer, one host read.  The split-precision
+        products carry an operand as f16 hi + lo planes: beyond +-65504 a finite activation SATURATES (fp32 mode) or becomes inf (f16
+        mode), which an fp32 reference would not do.  With trained PepFlow weights activations are O(1-100); this is the run-time
+        verdict for checkpoints nobody could try here: FlowModel.sample() calls it once per call and warns
+        above F16_MAX / 2."""
+        bufs = {"node_state": self.s, "pair_tensor": self.zbuf, "et_residue_terms": self.pre, "ipa_features": self.feats,
+                "ipa_projection": self.proj}
+        vals = torch.stack([torch.nan_to_num(b.detach().abs().amax().float(), nan=float("inf")) if b.numel() else torch.zeros((), device=self.device)
+                            for b in bufs.values()]).tolist()
+        rep = dict(zip(bufs, vals))
+        rep["limit"] = F16_MAX
+        rep["ok"] = all(v <= self.RANGE_WARN for v in vals)
+        return rep
+
     def nbytes(self):
         """Device bytes this engine keeps alive: its workspaces and its samplers' trajectory buffers (distinct storages)."""
         seen, total = set(), 0

@@ -90,7 +90,7 @@ class FlowModel(nn.Module):
     # ---- flow_model.py:229-374 ----
     @torch.no_grad()
     def sample(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
-               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False):
+               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False, check_range=True):
         """Reference signature + keyword-only extensions:
         noise        dict(rot0, trans0, ang0, simplex0[, expo]) of pre-drawn noise (parity tests);
         seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator); with noise=None an
@@ -100,6 +100,9 @@ class FlowModel(nn.Module):
         return_sampler  return the DeviceSampler instead of the CPU trajectory.  It is OWNED BY THE ENGINE: the next sample() call at
                      the same (B, L, num_steps, flags) overwrites its trajectory buffers, seed and L_out IN PLACE -- read what you
                      need (distributed._final_state_of / .trajectory()) before calling sample() again, or clone it;
+        check_range  (default on) after the loop, read the largest |activation| the engine carried (engine.operand_range) and warn when
+                     it passes half of the f16 range: the run-time side of the split-precision range contract (weights are refused at
+                     pack time); the report stays in `model.last_range_report`;
         pageable     return the trajectory in pageable host memory instead of views of pinned staging buffers (callers that keep
                      the trajectories of many complexes alive: pinned memory is a bounded resource);
         timings      optional dict: filled with the wall-clock seconds of the call's phases (noise / engine / encode / bind / setup /
@@ -151,6 +154,18 @@ class FlowModel(nn.Module):
             stamp("capture")
         smp.run(num_steps, use_graph=use_graph)
         stamp("loop")
+        if check_range:
+            # run-time range verdict of the split-precision operands (engine.operand_range: five small reductions, one host read
+            # per CALL, not per step): loud, because no trained checkpoint could be tried in this build
+            rep = eng.operand_range()
+            self.last_range_report = rep
+            if not rep["ok"]:
+                import warnings
+                warnings.warn("pepflowww_amd: activations reached " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if k not in ("limit", "ok")) +
+                              f" -- beyond half of the f16 range ({rep['limit']:g}) the hi / lo split of the MFMA operands saturates (fp32 mode) or "
+                              "overflows (f16 mode) where the fp32 reference would not: results may deviate (INTEGRATION.md, numeric range)",
+                              RuntimeWarning, stacklevel=2)
+            stamp("range_check")
         smp.L_out = L0
         if return_sampler:
             return smp                                 # (owned by the engine: the next sample() call at this shape reuses it)

@@ -88,6 +88,25 @@ def test_cfg4_sampler_vs_oracle(model, seeded_sd):
             assert torch.equal(t[-1][k], last[k][lo:hi]), (k, lo)
 
 
+def test_cfg4_twenty_free_steps_vs_oracle(model, seeded_sd):
+    """the longest oracle-compared trajectory at the FULL benchmarked shape was 3 steps.  Here B=64 x L=128 runs
+    21 steps (step 0 teacher-forced + 20 free-running) in the default fp32-parity mode and samples 0, 21, 42 and 63 are compared
+    with the CPU oracle step by step: zero flipped draws, rotations / translations within 3e-4 (max-normalised) at every step."""
+    B, L, NS = 64, 128, 21
+    batch = synth.make_pocket_batch(B, L, 16, seed=114514)
+    noise = synth.make_noise(B, L, NS, seed=11)
+    traj = model.sample({k: cu(v) for k, v in batch.items()}, num_steps=NS, noise=noise, use_graph=True)
+    worst = 0.0
+    for smp in (0, 21, 42, 63):
+        ref = _oracle_chunk(seeded_sd, batch, noise, smp, smp + 1, NS)
+        _compare_traj(traj, ref, smp, smp + 1, NS, f"sample {smp}")
+        for i in range(NS):
+            for k in ("rotmats", "trans"):
+                worst = max(worst, float((traj[i][k][smp:smp + 1] - ref[i][k]).abs().max() / ref[i][k].abs().max()))
+    print(f"cfg4 shape, 20 free steps, 4 samples vs oracle: worst max-normalised deviation {worst:.2e}")
+    assert worst < 3e-4
+
+
 def test_cfg5_training_step_vs_oracle_autograd(seeded_sd):
     """B=16 x L=128 training step (default path: fused EdgeTransition forward, mid-size attention variant): losses and
     the gradient tensor of all 407 parameters against the oracle's autograd."""
