@@ -347,6 +347,137 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     }
 }
 
+// ---- the same inside the f16-operand score kernel (f16 mode): single-pass f16 products, and NOTHING of the projection leaves the
+// chip -- the head's k rows (KL [key][128] f16) and its TRANSPOSED values + value points (VT [164][keys] f16: the layout of
+// pf_linear_args.att_vt) live in LDS next to the key points, the query rows pass through a wave-private scratch.  Values are the ones
+// pf_linear_fwd's f16 path writes to att_qk / att_vt (same products, same rounding): the step is bit-identical to the three-buffer form.
+constexpr int KLS = 128 + 8;                  // f16 row stride of KL (272 B: 16-byte aligned rows, fragment reads spread over the banks)
+constexpr int PJ16_CHUNK_B = PJ_CT * 4 * 1024;                   // hi planes only
+constexpr int PJ16_STAGE_B = PJ_NB * PJ16_CHUNK_B;
+__device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, bool wave_on, float* KP,
+                                            _Float16* KL, _Float16* VT, int VTS, unsigned char* WS /* PJ_NB x PJ16_CHUNK_B */,
+                                            float* QPW /* wave-private, 1536 B: query rows (f16) then query points */, float* PB,
+                                            half8 (&qh)[4], float4 (&qp4)[6], int lane, int wave, int nw) {
+    const int r = lane & 15, g = lane >> 4;
+    const unsigned char* whp = reinterpret_cast<const unsigned char*>(a.proj_w_f16);
+    const unsigned ws0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)WS;
+    const unsigned l16 = lane * 16;
+    const int ppw = (PJ_CT * 4 + nw - 1) / nw;
+    // chunk c -> buffer c % PJ_NB: piece (tile tl, K-step ks) at (tl * 4 + ks) KiB; every wave issues ppw pieces per chunk
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        const int npc = min(PJ_CT, PJ_TILES - PJ_CT * c) * 4;
+        for (int k = 0; k < ppw; ++k) {
+            const int pc = min(wave + k * nw, npc - 1);
+            const int T16 = pj_tile(PJ_CT * c + (pc >> 2), h);
+            pj_glds16(whp + (size_t)(T16 * 4 + (pc & 3)) * 1024, l16, ws0 + (c % PJ_NB) * PJ16_CHUNK_B + pc * 1024);
+        }
+    };
+    for (int i = wave * 64 + lane; i < PJ_TILES * 16; i += nw * 64) PB[i] = a.proj_bias[16 * pj_tile(i >> 4, h) + (i & 15)];
+    half8 xh[4];
+    float R[9], T[3];
+    {
+        const float* xrow = a.s_in + (rowb + iq) * 128 + 8 * g;
+        float4 t[8];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { t[2 * ks] = *reinterpret_cast<const float4*>(xrow + 32 * ks); t[2 * ks + 1] = *reinterpret_cast<const float4*>(xrow + 32 * ks + 4); }
+        const float* Rg = a.rot + (rowb + iq) * 9;
+        const float* Tg = a.trans + (rowb + iq) * 3;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rg[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) T[k] = Tg[k];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                         // plain conversion, as the stand-alone kernel's f16 path
+            xh[ks][0] = (_Float16)t[2 * ks].x; xh[ks][1] = (_Float16)t[2 * ks].y; xh[ks][2] = (_Float16)t[2 * ks].z; xh[ks][3] = (_Float16)t[2 * ks].w;
+            xh[ks][4] = (_Float16)t[2 * ks + 1].x; xh[ks][5] = (_Float16)t[2 * ks + 1].y; xh[ks][6] = (_Float16)t[2 * ks + 1].z; xh[ks][7] = (_Float16)t[2 * ks + 1].w;
+        }
+    }
+    asm volatile("" ::: "memory");                               // (row loads older than every LDS-DMA piece, see proj_head)
+#pragma unroll
+    for (int c = 0; c < PJ_NB - 1; ++c)
+        if (c < PJ_NCH) issue(c);
+    _Float16* QL = reinterpret_cast<_Float16*>(QPW);             // [16 rows][40]: two q tiles (32 channels) of the wave's rows at a time
+    auto ldfrag = [&](int c, int tl, half8 (&w)[4]) __attribute__((always_inline)) {
+        const unsigned char* b = WS + (c % PJ_NB) * PJ16_CHUNK_B + tl * 4096 + lane * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w[ks] = *reinterpret_cast<const half8*>(b + ks * 1024);
+    };
+    cfor_p<0, PJ_NCH>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int c = decltype(ic)::value;
+        constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH);
+        static_assert(PJ_NB == 4, "wait accounting written for 4 staging buffers");
+        pj_wait_vm_dyn(NDY * ppw);                               // (no global stores in this form: only younger pieces are outstanding)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
+        if (wave_on) {
+            half8 wa[4], wb[4];
+            ldfrag(c, 0, wa);
+            cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
+                constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
+                if constexpr (idx < PJ_TILES) {
+                    half8 (&w)[4] = (tl & 1) ? wb : wa;
+                    if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    f32x4 am = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (idx >= 16 && idx < 24) {      // value channels: rows x features (operands swapped) -> lane (r = channel, g): rows 4 g + e
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) am = mfma_h(xh[ks], w[ks], am);
+                        const float bn = PB[16 * idx + r];
+                        half4 hv;
+                        hv[0] = (_Float16)(am[0] + bn); hv[1] = (_Float16)(am[1] + bn); hv[2] = (_Float16)(am[2] + bn); hv[3] = (_Float16)(am[3] + bn);
+                        *reinterpret_cast<half4*>(VT + (16 * (idx - 16) + r) * VTS + (jrow - r) + 4 * g) = hv;     // keys i0 + 4 g .. + 3
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) am = mfma_h(w[ks], xh[ks], am);
+                        const float4 b4 = *reinterpret_cast<const float4*>(PB + 16 * idx + 4 * g);
+                        float v[4];
+                        v[0] = am[0] + b4.x; v[1] = am[1] + b4.y; v[2] = am[2] + b4.z; v[3] = am[3] + b4.w;
+                        if constexpr (idx < 16) {
+                            half4 hv;
+                            hv[0] = (_Float16)v[0]; hv[1] = (_Float16)v[1]; hv[2] = (_Float16)v[2]; hv[3] = (_Float16)v[3];
+                            if constexpr (idx < 8) {            // q channels 16 idx + 4 g ..: through the wave's scratch, two tiles per K-step
+                                *reinterpret_cast<half4*>(QL + r * 40 + 16 * (idx & 1) + 4 * g) = hv;
+                                if constexpr (idx & 1) {
+                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                    __builtin_amdgcn_wave_barrier();
+                                    qh[idx >> 1] = *reinterpret_cast<const half8*>(QL + r * 40 + 8 * g);
+                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            } else {                            // k channels 16 (idx - 8) + 4 g .. of key row jrow
+                                *reinterpret_cast<half4*>(KL + jrow * KLS + 16 * (idx - 8) + 4 * g) = hv;
+                            }
+                        } else {                                // a point (x, y, z, 0) of this row -> global frame
+                            const float ox = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
+                            const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
+                            const float oz = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
+                            if constexpr (idx < 26) {
+                                float* o = QPW + r * 24 + 3 * (4 * (idx - 24) + g);
+                                o[0] = ox; o[1] = oy; o[2] = oz;
+                            } else {
+                                const int pp = 4 * (idx - 26) + g;
+                                if (pp < 8) {
+                                    float* o = KP + jrow * KPS + 3 * pp;
+                                    o[0] = ox; o[1] = oy; o[2] = oz;
+                                } else {                        // value point pp - 8: rows 128 + 3 (pp - 8) + xyz of the transposed block
+                                    _Float16* o = VT + (128 + 3 * (pp - 8)) * VTS + jrow;
+                                    o[0] = (_Float16)ox; o[VTS] = (_Float16)oy; o[2 * VTS] = (_Float16)oz;
+                                }
+                            }
+                        }
+                    }
+                }
+            });
+        }
+    });
+    if (wave_on) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);
+    }
+}
+
 // The wave's score tile S[16 queries][L keys] lives in a wave-private LDS region that every lane only ever reads back where it
 // wrote (lane (r, g): row r, keys 16 t + 4 g .. + 3), i.e. it is register spill space under our control: with the tiles held
 // in registers and the tile loops unrolled, hipcc hoisted every tile's loads and spilled 0.9 - 6.8 KB per lane.
@@ -668,14 +799,21 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 // Requires L % 16 == 0 (FlowModel.sample pads to that); keys are walked in 32-key steps in the second product (a trailing
 // half step multiplies zero probabilities with whatever the value rows hold there -- the value buffer is zero-initialised
 // and 32 keys longer than its last row).
-template <int MODE, bool FUSE = false>           // FUSE: pair aggregation on a.dz (f16) here, P not stored
+template <int MODE, bool FUSE = false, bool PROJ = false>   // FUSE: pair aggregation on a.dz (f16) here, P not stored; PROJ: the head's projection here (proj_head16)
 __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int SLD) {
     constexpr bool SPLIT = MODE == 1;
+    static_assert(!PROJ || MODE == 2, "projection inside the kernel: f16 mode only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;                             // multiple of 16
     float* KP = smem;                              // [L][KPS] key points of this head (global frame)
     float* MJ = KP + L * KPS;                      // [L] key mask
     float* SW = MJ + L;                            // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
+    // PROJ: behind the score regions (which double as the weight staging area of the prologue: the launcher sizes them for both) the
+    // head's k rows and transposed values: KL [L][KLS], VT [PF_ATT_VROWS][VTS] f16
+    const int VTS = ((L + 31) & ~31) + 8;
+    const int sw_floats = PROJ ? max((int)(blockDim.x >> 6) * 16 * SLD, (int)((PJ16_STAGE_B + (blockDim.x >> 6) * 1536 + PJ_TILES * 64) / 4)) : 0;
+    _Float16* KL = reinterpret_cast<_Float16*>(SW + sw_floats);
+    _Float16* VT = KL + L * KLS;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -706,24 +844,46 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         }
     };
     half8 qh[4], ql[4];
-    {
+    float4 qp4[6];
+    if constexpr (!PROJ) {
         const _Float16* qrow = qk + (rowb + (wave_on ? iq : 0)) * RS;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) ldfrag(qrow, h * C, s4, qh[s4], ql[s4]);
-    }
-    float4 qp4[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(a.qp + (rowb + (wave_on ? iq : 0)) * 192 + h * 24 + 4 * q);
+        for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(a.qp + (rowb + (wave_on ? iq : 0)) * 192 + h * 24 + 4 * q);
+    }
     const float mi = a.mask[rowb + (wave_on ? iq : 0)];
     const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
     const int KC0 = (SPLIT ? 1024 : 1024) + h * C;                              // first k channel of the head in the plane row
     auto loadk = [&](int t, half8 (&kh)[4], half8 (&kl)[4]) {
-        const _Float16* krow = qk + (rowb + 16 * t + r) * RS;
+        if constexpr (PROJ) {                      // the head's k rows are in LDS
+            const _Float16* krow = KL + (16 * t + r) * KLS + 8 * g;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) ldfrag(krow, KC0, s4, kh[s4], kl[s4]);
+            for (int s4 = 0; s4 < 4; ++s4) kh[s4] = *reinterpret_cast<const half8*>(krow + 32 * s4);
+        } else {
+            const _Float16* krow = qk + (rowb + 16 * t + r) * RS;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) ldfrag(krow, KC0, s4, kh[s4], kl[s4]);
+        }
     };
     half8 kh[4], kl[4], nh[4], nl[4];
-    if (wave_on) loadk(0, kh, kl);
+    if constexpr (!PROJ) { if (wave_on) loadk(0, kh, kl); }
+
+    if constexpr (PROJ) {
+        for (int j = tid; j < LK; j += blockDim.x) MJ[j] = a.mask[rowb + j];
+        // key columns LK .. L32 - 1 of the transposed values: the trailing half step of the second product multiplies them with zero weights
+        for (int idx = tid; idx < PF_ATT_VROWS * (L32 - LK); idx += blockDim.x) {
+            const int row = idx / (L32 - LK), col = LK + idx - row * (L32 - LK);
+            VT[row * VTS + col] = (_Float16)0.f;
+        }
+        unsigned char* WS = reinterpret_cast<unsigned char*>(SW);
+        float* QPW = reinterpret_cast<float*>(WS + PJ16_STAGE_B) + wave * (1536 / 4);
+        float* PB = reinterpret_cast<float*>(WS + PJ16_STAGE_B) + (blockDim.x >> 6) * (1536 / 4);
+        proj_head16(a, rowb, wave_on ? iq : 0, h, i0 + r, wave_on, KP, KL, VT, VTS, WS, QPW, PB, qh, qp4, lane, wave, (int)(blockDim.x >> 6));
+        __syncthreads();
+        if (!wave_on) return;
+        loadk(0, kh, kl);
+    } else {
 
     // key points / key mask of the head -> LDS (the keys this sample uses: LK <= L).  The first six key-point pieces and the first mask
     // value of every thread are requested TOGETHER (at 128 threads and L = 128 that is all of them) and committed afterwards; as a
@@ -756,6 +916,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     }
     __syncthreads();
     if (!wave_on) return;
+    }
     PROFS(1);
 
     const float scale_qk = 0.051031036307982884f;               // sqrt(1/(3*128)), ipa_pytorch.py:399
@@ -850,7 +1011,9 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     auto loadv = [&](int s32, half8 (&vh)[NTC], half8 (&vl)[NTC]) {
 #pragma unroll
         for (int n = 0; n < NTC; ++n) {
-            if constexpr (SPLIT) {
+            if constexpr (PROJ) {
+                vh[n] = *reinterpret_cast<const half8*>(VT + vrow[n] * VTS + 32 * s32 + 8 * g);
+            } else if constexpr (SPLIT) {
                 const _Float16* p = vt + (size_t)vrow[n] * (2 * L) + (4 * s32 + g) * 16;
                 vh[n] = *reinterpret_cast<const half8*>(p);
                 vl[n] = *reinterpret_cast<const half8*>(p + 8);
@@ -1265,7 +1428,9 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     int rc = 0;
     // pair aggregation inside the score kernel (pf_ipa_attn_args.fused_pair): the f16-operand kernels take f16 pair values, the fp32-
     // operand kernel fp32 ones (what DenoiseEngine pairs up); any other combination runs the two-kernel form and needs p_out
-    const bool planes = a->att_qk && a->att_vt && (a->att_mode == 1 || a->att_mode == 2) && (L & 15) == 0;
+    // f16 operand planes from the projection's epilogue (att_qk / att_vt), or -- att_mode 2 with s_in -- formed inside the kernel
+    const bool pj16 = a->s_in && a->att_mode == 2 && (L & 15) == 0;
+    const bool planes = ((a->att_qk && a->att_vt) || pj16) && (a->att_mode == 1 || a->att_mode == 2) && (L & 15) == 0;
     const bool fuse = a->fused_pair && a->dz && (planes ? a->dz_f16 != 0 : a->dz_f16 == 0);
     if (!fuse && !a->p_out) return PF_E_BADARG;
     {
@@ -1294,7 +1459,24 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             attr_set = true;
         }
         // the projection inside the score kernel (s_in): fp32 operands, every query tile of a sample in ONE workgroup, float4 rows
-        const bool pj = a->s_in != nullptr;
+        const bool pj = a->s_in != nullptr && !pj16;
+        if (pj16) {
+            // every query tile of a sample in ONE workgroup; the score regions double as the staging area; k rows + transposed values behind
+            if (tiles > WMAX || !a->proj_w_f16 || !a->proj_bias || !fuse) return PF_E_BADARG;
+            const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
+            const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float);
+            const size_t swb = (size_t)tiles * 16 * SLD16 * sizeof(float), stg = (size_t)PJ16_STAGE_B + (size_t)tiles * 1536 + (size_t)PJ_TILES * 64;
+            const size_t lds16 = fixed16 + (swb > stg ? swb : stg) + ((size_t)L * KLS + (size_t)PF_ATT_VROWS * (L32 + 8)) * sizeof(_Float16);
+            if (lds16 > 160 * 1024) return PF_E_TOOLARGE;
+            static bool attr_pj16 = false;
+            if (!attr_pj16) {
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_pj16 = true;
+            }
+            hipLaunchKernelGGL((ipa_scores16_kernel<2, true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
+            PF_CHECK_LAUNCH();
+            return 0;
+        }
         if (pj && (planes || nrb != 1 || (L & 3) != 0 || !a->proj_w_f16 || !a->proj_bias || !a->proj || a->ldp < OFF_KV + 2 * H * C)) return PF_E_BADARG;
         if (pj) {
             static bool attr_pj = false;

@@ -454,16 +454,20 @@ class DenoiseEngine:
         # point-distance VALU work, not by the MFMAs; its PV phase has no room for a second fragment set in 256 VGPRs) and the
         # projection 88 vs 77 us (transposed 8-byte stores + hi / lo splits of every output) -- so the fp32 mode keeps fp32 operands.
         self.att_planes = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
-        if self.att_planes:
-            split = self.precision == "fp32"
-            self.att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=device)
-            self.att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=device)
         # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_rows16): every (sample, head)
         # workgroup projects its own rows -- no projection launch, q and the points never reach HBM, `proj` shrinks to a k | v scratch.
         # Needs the fp32-operand two-kernel form with all query tiles of a sample in one workgroup (64 <= L <= 128, L % 4 == 0): a rule
         # in (L, precision) alone.  PF_FUSED_PROJ=0 / 1 forces it off / on (same-box A/B runs).
-        can_pj = precision == "fp32" and 64 <= L <= 128 and L % 4 == 0 and not self.att_planes
+        # f16 mode (L % 16 == 0, pair values fused): the f16-operand score kernel forms k rows and transposed values in LDS -- the
+        # att_qk / att_vt planes are not needed either.
+        can_pj = 64 <= L <= 128 and ((precision == "fp32" and L % 4 == 0 and not self.att_planes) or
+                                     (precision == "f16" and self.att_planes and self.fused_pair))
         self.fused_proj = can_pj and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PROJ", ""), True)
+        self.att_qk = self.att_vt = None
+        if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
+            split = self.precision == "fp32"
+            self.att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=device)
+            self.att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=device)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -642,7 +646,7 @@ class DenoiseEngine:
             la.pt_qp, la.pt_kp, la.pt_vp = self.qp.data_ptr(), self.kp.data_ptr(), self.vp.data_ptr()
             la.key_end, la.key_L, la.active_rows = self.key_end.data_ptr(), L, self.active_rows   # padded batch: row tiles beyond are skipped
             self._proj_args.append(la)
-            if self.att_planes:
+            if self.att_qk is not None:
                 la.att_qk, la.att_vt, la.att_L = self.att_qk.data_ptr(), self.att_vt.data_ptr(), L
             plan.append(e + (lane,))
 
@@ -668,7 +672,9 @@ class DenoiseEngine:
                 ia.dz = (self.pair_dz if b > 0 else self.pair_dz0).data_ptr()     # EdgeTransition(b - 1) / bind_context
                 ia.dz_f16 = int(self.z16)
             if self.att_planes:
-                ia.att_qk, ia.att_vt, ia.att_mode = self.att_qk.data_ptr(), self.att_vt.data_ptr(), (1 if self.precision == "fp32" else 2)
+                ia.att_mode = 1 if self.precision == "fp32" else 2
+                if self.att_qk is not None:
+                    ia.att_qk, ia.att_vt = self.att_qk.data_ptr(), self.att_vt.data_ptr()
             if self.fused_proj:
                 ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.projp.w16"].data_ptr(), w[f"{b}.projp.b"].data_ptr()
             self._keep.append(ia)

@@ -89,10 +89,13 @@ def test_projection_inside_needs_one_workgroup_per_sample_and_head(seeded_sd):
                         dz=torch.zeros(B, L, L, 16, device=G.dev()), fused_proj=(cu(s), w16, bp))
 
 
-@pytest.mark.parametrize("B,L", [(2, 64), (3, 112), (2, 128)])
-def test_step_with_and_without_the_projection_launch_is_bit_identical(seeded_sd, B, L):
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+@pytest.mark.parametrize("B,L", [(2, 64), (3, 112), (2, 128), (2, 80)])
+def test_step_with_and_without_the_projection_launch_is_bit_identical(seeded_sd, B, L, precision):
     """DenoiseEngine.fused_proj: one denoise step with the projection inside the score kernels equals the step with the separate
-    projection launches bit for bit (rotations, translations, angles, logits), on a padded batch too -- and has six launches less."""
+    projection launches bit for bit (rotations, translations, angles, logits), on a padded batch too -- and has six launches less.
+    fp32 mode: k | v through the `proj` scratch (proj_head); f16 mode: k rows and transposed values in LDS, no att_qk / att_vt planes
+    (proj_head16; L = 80 / 112: a trailing half step of 16 keys in the second product)."""
     from pepflowww_amd.engine import DenoiseEngine, PackedWeights
     batch = synth.make_pocket_batch(B, L, 8, seed=3)
     if B > 2:
@@ -114,10 +117,11 @@ def test_step_with_and_without_the_projection_launch_is_bit_identical(seeded_sd,
     for flag in ("0", "1"):
         os.environ["PF_FUSED_PROJ"] = flag
         try:
-            eng = DenoiseEngine(w, B, L, G.dev())
+            eng = DenoiseEngine(w, B, L, G.dev(), precision=precision)
         finally:
             del os.environ["PF_FUSED_PROJ"]
         assert eng.fused_proj == (flag == "1")
+        assert (eng.att_qk is None) == (precision == "fp32" or flag == "1")
         eng.bind_context(node, edge, bd["res_mask"])
         eng.set_state(cu(t), cu(Rt), cu(xt), cu(at), cu(st))
         eng.run()
