@@ -357,7 +357,7 @@ def main():
         return bench_train(args, wl, dev, dist, rank, world)
     use_graph = not args.no_graph
     prec = args.precision
-    elapsed, info = run_sampler(dict(wl, read_sclk=(rank == 0)), K, W, dev, dist, rank, world, use_graph, prec)
+    elapsed, info = run_sampler(dict(wl, read_sclk=(rank == 0 and not os.environ.get("PF_BENCH_NO_SCLK"))), K, W, dev, dist, rank, world, use_graph, prec)
     B, L = info["B"], info["L"]
     pairs = info["real_pairs"]                  # = B * L * L unless the batch is padded (cfg3): rooflines count unmasked pairs only
     split = 3 if prec == "fp32" else 1

@@ -5,7 +5,7 @@ TAG=${1:-v3}; PREC=${2:-fp32}; cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 for W in cfg2 cfg4 cfg3; do
   if [ $W = cfg2 ]; then K=20; WU=3; else K=10; WU=2; fi
   OUT=gpurun_out/ks_${TAG}_$W; rm -rf $OUT
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps $K --warmup $WU --no-graph --no-cpu-baseline --no-secondary --no-modes --no-per-call --workload $W --precision $PREC > $OUT.log 2>&1
+  PF_BENCH_NO_SCLK=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps $K --warmup $WU --no-graph --no-cpu-baseline --no-secondary --no-modes --no-per-call --workload $W --precision $PREC > $OUT.log 2>&1
   f=$(find $OUT -name "*kernel_stats.csv" | head -1)
   (head -1 "$f"; grep "anonymous namespace" "$f" | head -24) | cut -c1-260 > gpurun_out/${TAG}_${W}_kernel_stats.csv
   rm -rf $OUT

@@ -17,7 +17,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-secondary "$@" > $OUT/p$i.log 2>&1
+  PF_BENCH_NO_SCLK=1 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-secondary "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python - "$OUT" "$K" <<'PY'

@@ -7,7 +7,7 @@ for W in cfg2 cfg4; do
     [ $W = cfg2 ] && [ $P = f16 ] && continue
     for C in FETCH_SIZE WRITE_SIZE; do
       OUT=gpurun_out/pt_${W}_${P}_$C; rm -rf $OUT
-      rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --no-modes --no-per-call --workload $W --precision $P > $OUT.log 2>&1
+      PF_BENCH_NO_SCLK=1 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --no-modes --no-per-call --workload $W --precision $P > $OUT.log 2>&1
     done
   done
 done
@@ -43,7 +43,7 @@ for W in ("cfg2", "cfg4"):
             for f in glob.glob(f"gpurun_out/pt_{W}_{P}_{C}/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
                     k = row["Kernel_Name"]
-                    if "anonymous namespace" in k and row["Counter_Name"] == C and "edge_features" not in k and "node_features" not in k:
+                    if "anonymous namespace" in k and "at::" not in k and "rocprim" not in k and row["Counter_Name"] == C and "edge_features" not in k and "node_features" not in k:
                         short = k.split("::")[-1].split("(")[0].split("<")[0].strip()
                         allk[short][C].append(float(row["Counter_Value"]))
         per = {}
