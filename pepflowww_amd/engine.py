@@ -453,7 +453,8 @@ class DenoiseEngine:
         # faster -- measured at B=64, L=128: score kernel 113 k vs 111 k cycles per workgroup (its QK phase is bound by the
         # point-distance VALU work, not by the MFMAs; its PV phase has no room for a second fragment set in 256 VGPRs) and the
         # projection 88 vs 77 us (transposed 8-byte stores + hi / lo splits of every output) -- so the fp32 mode keeps fp32 operands.
-        self.att_planes = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
+        # (PF_ATT_SPLIT=1, dev: the fp32 mode on hi / lo operand planes -- the form measured above)
+        self.att_planes = (precision == "f16" or os.environ.get("PF_ATT_SPLIT") == "1") and (L % 16 == 0) and (64 <= L <= 256)
         # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_rows16): every (sample, head)
         # workgroup projects its own rows -- no projection launch, q and the points never reach HBM, `proj` shrinks to a k | v scratch.
         # Needs the fp32-operand two-kernel form with all query tiles of a sample in one workgroup (64 <= L <= 128, L % 4 == 0): a rule
