@@ -83,10 +83,9 @@ typedef struct {
     int single_pass;                /* split path, 4-wave form only: 1 = f16 precision mode (one f16 MFMA per product, hi planes only) */
     /* split path with pt_* set (IPA projection of the inference plan), optional: write the attention operands as f16 planes
      * instead of fp32 `y` / `pt_vp` (csrc/ipa_split.hip consumes them; L = att_L must be a multiple of 16, M = B L):
-     *   att_qk : per row [q 1024 | k 8 x 128] channels; fp32 mode: 4096 f16 per row, channel octets interleaved (hi8 | lo8);
-     *            f16 mode (single_pass): 2048 f16 per row, hi only
-     *   att_vt : values TRANSPOSED per (sample, head): [B][8][PF_ATT_VROWS = 128 channels + 36 point coordinates][L keys];
-     *            fp32 mode: key octets interleaved (hi8 | lo8), 2 L f16 per row; f16 mode: L f16 per row */
+     * single_pass only since ABI 50 (the hi / lo plane form of the fp32 mode was removed; att_qk without single_pass is refused):
+     *   att_qk : per row [q 1024 | k 8 x 128] channels, 2048 f16 per row
+     *   att_vt : values TRANSPOSED per (sample, head): [B][8][PF_ATT_VROWS = 128 channels + 36 point coordinates][L keys], L f16 per row */
     void* att_qk; void* att_vt; int att_L;
     /* optional (split path): the rows are [B][key_L] residues and key_end[b] (device memory, int32 [B]) = 1 + the last unmasked
      * residue of sample b (the same list as pf_ipa_attn_args.key_end).  A row tile that lies entirely at or beyond its samples'
@@ -177,8 +176,8 @@ typedef struct {
     float* p_out;
     int variant;                   /* 0 = automatic; 1 = force the one-kernel form; 2 = demand the two-kernel form (error if impossible) */
     /* optional (two-kernel form, L % 16 == 0): the q / k / v operands as the f16 planes pf_linear_fwd (att_*) wrote; the score
-     * kernel then runs its products on the f16 matrix instruction (3-MFMA split in the fp32 mode, att_mode = 1; single pass in
-     * the f16 mode, att_mode = 2) and `proj` / `vp` are not read */
+     * kernel then runs its products on the f16 matrix instruction (single pass, att_mode = 2: the f16 mode) and `proj` / `vp` are
+     * not read.  att_mode = 1 (hi / lo planes, 3-MFMA split) existed until ABI 50 as a test-only form and is refused now. */
     const void* att_qk; const void* att_vt; int att_mode;
     int head_group;                /* one-kernel form: 0 = head-group split by size; 2 / 4 / 8 = that variant */
     /* optional (two-kernel form): key_end[b] = 1 + the last unmasked residue of sample b (device memory, int32 [B]).  Keys and

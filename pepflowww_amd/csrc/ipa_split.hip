@@ -792,17 +792,15 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 
 // ---- score kernel on f16 operand planes (pf_ipa_attn_args.att_qk / att_vt, written by the projection's epilogue) ----
 // Same structure and arithmetic as ipa_scores_kernel; the two products run on v_mfma_f32_16x16x32_f16:
-//   MODE 1 (fp32 parity): operands are hi / lo f16 planes, every product = 3 MFMAs (hi hi, hi lo, lo hi), the result
-//           acc_main + acc_corr / 2048 -- 12 MFMAs of 16 cycles per 16-key tile for K Q^T instead of 32 fp32 MFMAs of 32 cycles,
-//           33 per 32 keys for P [V | V_pts] instead of 88; the probabilities are split when they are read back from LDS;
-//   MODE 2 (f16 mode): hi planes only, one MFMA per product.
+// hi planes only, one MFMA per product (the f16 mode; pf_ipa_attn_args.att_mode = 2).  A hi / lo form of the same kernel (att_mode = 1:
+// three MFMAs per product, fp32 parity) existed through round 4 as a test-only mode; its K Q^T phase measured SLOWER than the
+// fp32-MFMA kernel's (43 k vs 36 k cycles per workgroup, profiles/r04/r04g_score_kernel_phases.txt) and it was removed: att_mode = 1
+// is refused.
 // Requires L % 16 == 0 (FlowModel.sample pads to that); keys are walked in 32-key steps in the second product (a trailing
 // half step multiplies zero probabilities with whatever the value rows hold there -- the value buffer is zero-initialised
 // and 32 keys longer than its last row).
-template <int MODE, bool FUSE = false, bool PROJ = false>   // FUSE: pair aggregation on a.dz (f16) here, P not stored; PROJ: the head's projection here (proj_head16)
+template <bool FUSE = false, bool PROJ = false>   // FUSE: pair aggregation on a.dz (f16) here, P not stored; PROJ: the head's projection here (proj_head16)
 __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int SLD) {
-    constexpr bool SPLIT = MODE == 1;
-    static_assert(!PROJ || MODE == 2, "projection inside the kernel: f16 mode only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;                             // multiple of 16
     float* KP = smem;                              // [L][KPS] key points of this head (global frame)
@@ -832,30 +830,23 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     const int iq = i0 + r;                         // (< L: L is a multiple of 16)
     PROFS(0);
 
-    constexpr int RS = SPLIT ? 4096 : 2048;        // f16 per row of the q | k planes
+    constexpr int RS = 2048;                       // f16 per row of the q | k planes
     const _Float16* qk = reinterpret_cast<const _Float16*>(a.att_qk);
     // fragment of channels 32 s + 8 g .. + 7 of (row, first channel c0)
-    auto ldfrag = [&](const _Float16* row, int c0, int s, half8& fh, half8& fl) {
-        if constexpr (SPLIT) {                      // channel octets interleaved (hi8 | lo8): loads are operands as they arrive
-            fh = *reinterpret_cast<const half8*>(row + ((c0 + 32 * s + 8 * g) >> 3) * 16);
-            fl = *reinterpret_cast<const half8*>(row + ((c0 + 32 * s + 8 * g) >> 3) * 16 + 8);
-        } else {
-            fh = *reinterpret_cast<const half8*>(row + c0 + 32 * s + 8 * g);
-        }
-    };
-    half8 qh[4], ql[4];
+    auto ldfrag = [&](const _Float16* row, int c0, int s, half8& fh) { fh = *reinterpret_cast<const half8*>(row + c0 + 32 * s + 8 * g); };
+    half8 qh[4];
     float4 qp4[6];
     if constexpr (!PROJ) {
         const _Float16* qrow = qk + (rowb + (wave_on ? iq : 0)) * RS;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) ldfrag(qrow, h * C, s4, qh[s4], ql[s4]);
+        for (int s4 = 0; s4 < 4; ++s4) ldfrag(qrow, h * C, s4, qh[s4]);
 #pragma unroll
         for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(a.qp + (rowb + (wave_on ? iq : 0)) * 192 + h * 24 + 4 * q);
     }
     const float mi = a.mask[rowb + (wave_on ? iq : 0)];
     const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
-    const int KC0 = (SPLIT ? 1024 : 1024) + h * C;                              // first k channel of the head in the plane row
-    auto loadk = [&](int t, half8 (&kh)[4], half8 (&kl)[4]) {
+    const int KC0 = 1024 + h * C;                                              // first k channel of the head in the plane row
+    auto loadk = [&](int t, half8 (&kh)[4]) {
         if constexpr (PROJ) {                      // the head's k rows are in LDS
             const _Float16* krow = KL + (16 * t + r) * KLS + 8 * g;
 #pragma unroll
@@ -863,11 +854,11 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         } else {
             const _Float16* krow = qk + (rowb + 16 * t + r) * RS;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) ldfrag(krow, KC0, s4, kh[s4], kl[s4]);
+            for (int s4 = 0; s4 < 4; ++s4) ldfrag(krow, KC0, s4, kh[s4]);
         }
     };
-    half8 kh[4], kl[4], nh[4], nl[4];
-    if constexpr (!PROJ) { if (wave_on) loadk(0, kh, kl); }
+    half8 kh[4], nh[4];
+    if constexpr (!PROJ) { if (wave_on) loadk(0, kh); }
 
     if constexpr (PROJ) {
         for (int j = tid; j < LK; j += blockDim.x) MJ[j] = a.mask[rowb + j];
@@ -882,7 +873,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         proj_head16(a, rowb, wave_on ? iq : 0, h, i0 + r, wave_on, KP, KL, VT, VTS, WS, QPW, PB, qh, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();
         if (!wave_on) return;
-        loadk(0, kh, kl);
+        loadk(0, kh);
     } else {
 
     // key points / key mask of the head -> LDS (the keys this sample uses: LK <= L).  The first six key-point pieces and the first mask
@@ -923,19 +914,12 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     const float* brow = a.bias + (((size_t)b * H + h) * L + iq) * L;
     float* srow = SW + (size_t)wave * 16 * SLD + r * SLD;
     float mx = -3.0e38f;
-    auto qk_tile = [&](int t, const half8 (&kh)[4], const half8 (&kl)[4], const float4& bv) {
+    auto qk_tile = [&](int t, const half8 (&kh)[4], const float4& bv) {
         const int jb = 16 * t + 4 * g;
         const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
-        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f}, ac2 = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+        f32x4 am = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {                       // S^T tile: A = key rows, B = query rows
-            am = mfma_h(kh[s4], qh[s4], am);
-            if constexpr (SPLIT) {
-                ac = mfma_h(kh[s4], ql[s4], ac);
-                ac2 = mfma_h(kl[s4], qh[s4], ac2);
-            }
-        }
-        if constexpr (SPLIT) ac += ac2;
+        for (int s4 = 0; s4 < 4; ++s4) am = mfma_h(kh[s4], qh[s4], am);   // S^T tile: A = key rows, B = query rows
         float sv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -950,8 +934,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
                 d2 = __builtin_elementwise_fma(da, da, d2);
                 d2 = __builtin_elementwise_fma(db, db, d2);
             }
-            const float qkv = SPLIT ? am[e] + ac[e] * PF_LO_INV : am[e];
-            float v = qkv * scale_qk + bj[e];
+            float v = am[e] * scale_qk + bj[e];
             v = v + (-0.5f) * (gamma * (d2[0] + d2[1]));
             v = v + 1e5f * (mi * MJ[j] - 1.f);
             sv[e] = v;
@@ -966,18 +949,18 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         float4 bc = *reinterpret_cast<const float4*>(brow + 4 * g), bn;
         int t = 0;
         for (; t + 1 < kt; t += 2) {
-            loadk(t + 1, nh, nl);
+            loadk(t + 1, nh);
             bn = *reinterpret_cast<const float4*>(brow + 16 * (t + 1) + 4 * g);
             __builtin_amdgcn_sched_barrier(0);
-            qk_tile(t, kh, kl, bc);
+            qk_tile(t, kh, bc);
             __builtin_amdgcn_sched_barrier(0);
-            loadk(min(t + 2, kt - 1), kh, kl);
+            loadk(min(t + 2, kt - 1), kh);
             bc = *reinterpret_cast<const float4*>(brow + 16 * min(t + 2, kt - 1) + 4 * g);
             __builtin_amdgcn_sched_barrier(0);
-            qk_tile(t + 1, nh, nl, bn);
+            qk_tile(t + 1, nh, bn);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt & 1) qk_tile(kt - 1, kh, kl, bc);
+        if (kt & 1) qk_tile(kt - 1, kh, bc);
     }
     PROFS(2);
     // ---- softmax over the keys of query r (its keys sit in the 4 lanes r, r+16, r+32, r+48) ----
@@ -1003,30 +986,22 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     //      (tile n, lane r) -> value channel 8 r + n for n < 8 (a lane's eight outputs of a query are consecutive floats),
     //      point coordinate 16 (n - 8) + r for n = 8..10 ----
     constexpr int NTC = 11;
-    constexpr int VRS = SPLIT ? 2 : 1;                           // f16 per key in a value row
-    const _Float16* vt = reinterpret_cast<const _Float16*>(a.att_vt) + ((size_t)b * H + h) * PF_ATT_VROWS * (size_t)(VRS * L);
+    const _Float16* vt = reinterpret_cast<const _Float16*>(a.att_vt) + ((size_t)b * H + h) * PF_ATT_VROWS * (size_t)L;
     int vrow[NTC];
 #pragma unroll
     for (int n = 0; n < NTC; ++n) vrow[n] = n < 8 ? 8 * r + n : min(128 + 16 * (n - 8) + r, PF_ATT_VROWS - 1);
-    auto loadv = [&](int s32, half8 (&vh)[NTC], half8 (&vl)[NTC]) {
+    auto loadv = [&](int s32, half8 (&vh)[NTC]) {
 #pragma unroll
         for (int n = 0; n < NTC; ++n) {
-            if constexpr (PROJ) {
-                vh[n] = *reinterpret_cast<const half8*>(VT + vrow[n] * VTS + 32 * s32 + 8 * g);
-            } else if constexpr (SPLIT) {
-                const _Float16* p = vt + (size_t)vrow[n] * (2 * L) + (4 * s32 + g) * 16;
-                vh[n] = *reinterpret_cast<const half8*>(p);
-                vl[n] = *reinterpret_cast<const half8*>(p + 8);
-            } else {
-                vh[n] = *reinterpret_cast<const half8*>(vt + (size_t)vrow[n] * L + 32 * s32 + 8 * g);
-            }
+            if constexpr (PROJ) vh[n] = *reinterpret_cast<const half8*>(VT + vrow[n] * VTS + 32 * s32 + 8 * g);
+            else vh[n] = *reinterpret_cast<const half8*>(vt + (size_t)vrow[n] * L + 32 * s32 + 8 * g);
         }
     };
-    f32x4 Om[NTC], Oc[NTC];
+    f32x4 Om[NTC];
 #pragma unroll
-    for (int n = 0; n < NTC; ++n) { Om[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; Oc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int n = 0; n < NTC; ++n) Om[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ns = L32 >> 5;
-    auto pv_step = [&](int s32, const half8 (&vh)[NTC], const half8 (&vl)[NTC]) {
+    auto pv_step = [&](int s32, const half8 (&vh)[NTC]) {
         float4 p0 = *reinterpret_cast<const float4*>(srow + 32 * s32 + 8 * g);
         float4 p1 = *reinterpret_cast<const float4*>(srow + 32 * s32 + 8 * g + 4);
         p0.x *= inv; p0.y *= inv; p0.z *= inv; p0.w *= inv;
@@ -1035,51 +1010,27 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
             *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g) = p0;
             *reinterpret_cast<float4*>(prow + 32 * s32 + 8 * g + 4) = p1;
         }
-        half8 ph, pl;
-        {
-            const float v0[4] = {p0.x, p0.y, p0.z, p0.w}, v1[4] = {p1.x, p1.y, p1.z, p1.w};
-            half4 h0, l0, h1, l1;
-            if constexpr (SPLIT) {
-                split4(v0, h0, l0);
-                split4(v1, h1, l1);
-                pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { h0[e] = (_Float16)v0[e]; h1[e] = (_Float16)v1[e]; }
-            }
-            ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+        half8 ph;
+        ph[0] = (_Float16)p0.x; ph[1] = (_Float16)p0.y; ph[2] = (_Float16)p0.z; ph[3] = (_Float16)p0.w;
+        ph[4] = (_Float16)p1.x; ph[5] = (_Float16)p1.y; ph[6] = (_Float16)p1.z; ph[7] = (_Float16)p1.w;
 #pragma unroll
         for (int n = 0; n < NTC; ++n) Om[n] = mfma_h(ph, vh[n], Om[n]);
-        if constexpr (SPLIT) {
-#pragma unroll
-            for (int n = 0; n < NTC; ++n) Oc[n] = mfma_h(ph, vl[n], Oc[n]);
-#pragma unroll
-            for (int n = 0; n < NTC; ++n) Oc[n] = mfma_h(pl, vh[n], Oc[n]);
-        }
     };
-    if constexpr (SPLIT) {
-        // (two fragment sets of 88 registers do not fit: one set, requested a step ahead of the previous step's MFMAs by order)
-        for (int s32 = 0; s32 < ns; ++s32) {
-            half8 vh[NTC], vl[NTC];
-            loadv(s32, vh, vl);
-            pv_step(s32, vh, vl);
-        }
-    } else {
-        half8 va[NTC], vb2[NTC], vdummy[NTC];
-        loadv(0, va, vdummy);
+    {
+        half8 va[NTC], vb2[NTC];
+        loadv(0, va);
         int s32 = 0;
         for (; s32 + 1 < ns; s32 += 2) {
-            loadv(s32 + 1, vb2, vdummy);
+            loadv(s32 + 1, vb2);
             __builtin_amdgcn_sched_barrier(0);
-            pv_step(s32, va, vdummy);
+            pv_step(s32, va);
             __builtin_amdgcn_sched_barrier(0);
-            loadv(min(s32 + 2, ns - 1), va, vdummy);
+            loadv(min(s32 + 2, ns - 1), va);
             __builtin_amdgcn_sched_barrier(0);
-            pv_step(s32 + 1, vb2, vdummy);
+            pv_step(s32 + 1, vb2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ns & 1) pv_step(ns - 1, va, vdummy);
+        if (ns & 1) pv_step(ns - 1, va);
     }
     PROFS(4);
     // D layout: lane (r = column, g), register e -> query 4 g + e
@@ -1091,7 +1042,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         const int ti = 4 * g + e, i = i0 + ti;
         float o[NTC];
 #pragma unroll
-        for (int n = 0; n < NTC; ++n) o[n] = SPLIT ? Om[n][e] + Oc[n][e] * PF_LO_INV : Om[n][e];
+        for (int n = 0; n < NTC; ++n) o[n] = Om[n][e];
         float* f = a.feats + (rowb + i) * PF_IPA_FEATS + h * C + 8 * r;
         *reinterpret_cast<float4*>(f) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(f + 4) = make_float4(o[4], o[5], o[6], o[7]);
@@ -1430,7 +1381,8 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     // operand kernel fp32 ones (what DenoiseEngine pairs up); any other combination runs the two-kernel form and needs p_out
     // f16 operand planes from the projection's epilogue (att_qk / att_vt), or -- att_mode 2 with s_in -- formed inside the kernel
     const bool pj16 = a->s_in && a->att_mode == 2 && (L & 15) == 0;
-    const bool planes = ((a->att_qk && a->att_vt) || pj16) && (a->att_mode == 1 || a->att_mode == 2) && (L & 15) == 0;
+    if (a->att_mode == 1) return PF_E_BADARG;                    // (the hi / lo plane form was removed in round 4)
+    const bool planes = ((a->att_qk && a->att_vt) || pj16) && a->att_mode == 2 && (L & 15) == 0;
     const bool fuse = a->fused_pair && a->dz && (planes ? a->dz_f16 != 0 : a->dz_f16 == 0);
     if (!fuse && !a->p_out) return PF_E_BADARG;
     {
@@ -1470,10 +1422,10 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             if (lds16 > 160 * 1024) return PF_E_TOOLARGE;
             static bool attr_pj16 = false;
             if (!attr_pj16) {
-                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_pj16 = true;
             }
-            hipLaunchKernelGGL((ipa_scores16_kernel<2, true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
+            hipLaunchKernelGGL((ipa_scores16_kernel<true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
             PF_CHECK_LAUNCH();
             return 0;
         }
@@ -1506,20 +1458,13 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const size_t lds16 = fixed16 + wpb16 * pw16;
             static bool attr16 = false;
             if (!attr16) {
-                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr16 = true;
             }
             const dim3 g16((unsigned)(a->B * H * nrb16)), b16(64 * wpb16);
-            if (fuse) {
-                if (a->att_mode == 1) hipLaunchKernelGGL((ipa_scores16_kernel<1, true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
-                else hipLaunchKernelGGL((ipa_scores16_kernel<2, true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
-            } else if (a->att_mode == 1)
-                hipLaunchKernelGGL(ipa_scores16_kernel<1>, g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
-            else
-                hipLaunchKernelGGL(ipa_scores16_kernel<2>, g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+            if (fuse) hipLaunchKernelGGL((ipa_scores16_kernel<true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+            else hipLaunchKernelGGL(ipa_scores16_kernel<false>, g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
         } else if (fuse) {
             if ((L & 3) == 0) hipLaunchKernelGGL((ipa_scores_kernel<true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
             else hipLaunchKernelGGL((ipa_scores_kernel<false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);

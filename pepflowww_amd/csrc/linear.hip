@@ -736,6 +736,7 @@ extern "C" int pf_split_pack_f16(const float* w, int ldw, int N, int K, int tran
 
 extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
     if (!a || !a->x || (!a->w && !a->w_f16) || (!a->y && !a->att_qk) || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
+    if (a->att_qk && !a->single_pass) return PF_E_BADARG;       // (hi / lo operand planes: the form was removed in round 4, see ipa_split.hip)
     if (a->att_qk && (!a->att_vt || !a->w_f16 || !a->pt_rot || a->pt_col0 != 3072 || a->att_L <= 0 || a->att_L % 16 || a->M % a->att_L)) return PF_E_BADARG;
     if (a->K % 16 || a->ldx % 4 || a->ldx < a->K) return PF_E_BADARG;
     if (!a->w_f16 && (a->ldw % 4 || a->ldw < a->K || ((uintptr_t)a->w & 15))) return PF_E_BADARG;
@@ -803,7 +804,6 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         if (Npad > 128 && Npad <= 192 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<6>, dim3(gm, 1), dim3(384), lds, s, *a, Npad);
         else if (Npad > 192 && Npad <= 256 && gm >= 512) hipLaunchKernelGGL(linear_split_kernel<8>, dim3(gm, 1), dim3(512), lds, s, *a, Npad);
         else if (a->att_qk && a->single_pass) hipLaunchKernelGGL((linear_split_kernel<4, true, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
-        else if (a->att_qk) hipLaunchKernelGGL((linear_split_kernel<4, false, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         else if (a->single_pass) hipLaunchKernelGGL((linear_split_kernel<4, true>), dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         else hipLaunchKernelGGL(linear_split_kernel<4>, dim3((a->M + SP_BM - 1) / SP_BM, (Npad + 127) / 128), dim3(256), lds, s, *a, Npad);
         PF_CHECK_LAUNCH();

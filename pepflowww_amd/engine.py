@@ -453,8 +453,8 @@ class DenoiseEngine:
         # faster -- measured at B=64, L=128: score kernel 113 k vs 111 k cycles per workgroup (its QK phase is bound by the
         # point-distance VALU work, not by the MFMAs; its PV phase has no room for a second fragment set in 256 VGPRs) and the
         # projection 88 vs 77 us (transposed 8-byte stores + hi / lo splits of every output) -- so the fp32 mode keeps fp32 operands.
-        # (PF_ATT_SPLIT=1, dev: the fp32 mode on hi / lo operand planes -- the form measured above)
-        self.att_planes = (precision == "f16" or os.environ.get("PF_ATT_SPLIT") == "1") and (L % 16 == 0) and (64 <= L <= 256)
+        # (that hi / lo form left the library in round 4 after its K Q^T phase measured slower than the fp32-MFMA kernel's)
+        self.att_planes = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
         # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_rows16): every (sample, head)
         # workgroup projects its own rows -- no projection launch, q and the points never reach HBM, `proj` shrinks to a k | v scratch.
         # Needs the fp32-operand two-kernel form with all query tiles of a sample in one workgroup (64 <= L <= 128, L % 4 == 0): a rule
@@ -466,9 +466,8 @@ class DenoiseEngine:
         self.fused_proj = can_pj and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PROJ", ""), True)
         self.att_qk = self.att_vt = None
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
-            split = self.precision == "fp32"
-            self.att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=device)
-            self.att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=device)
+            self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
+            self.att_vt = torch.zeros(B * 8 * 164 * L + 64, dtype=torch.float16, device=device)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         self._keep = []
         self.plan = None
@@ -673,7 +672,7 @@ class DenoiseEngine:
                 ia.dz = (self.pair_dz if b > 0 else self.pair_dz0).data_ptr()     # EdgeTransition(b - 1) / bind_context
                 ia.dz_f16 = int(self.z16)
             if self.att_planes:
-                ia.att_mode = 1 if self.precision == "fp32" else 2
+                ia.att_mode = 2
                 if self.att_qk is not None:
                     ia.att_qk, ia.att_vt = self.att_qk.data_ptr(), self.att_vt.data_ptr()
             if self.fused_proj:
