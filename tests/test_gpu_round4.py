@@ -21,7 +21,8 @@ def cu(t):
     return t.to(G.dev()).contiguous()
 
 
-@pytest.mark.parametrize("B,L,fused_pair", [(3, 96, False), (2, 128, True), (2, 64, False), (3, 80, True), (1, 128, False)])
+@pytest.mark.parametrize("B,L,fused_pair", [(3, 96, False), (2, 128, True), (2, 64, False), (3, 80, True), (1, 128, False),
+                                            (2, 100, False), (2, 68, True), (3, 124, False)])      # (L % 16 != 0: a partial last row tile)
 def test_ipa_projection_inside_the_score_kernel(seeded_sd, B, L, fused_pair):
     """pf_ipa_attn_args.s_in: every (sample, head) workgroup projects its own rows (q / points on chip, k | v through the `proj`
     scratch).  Bit-identical to pf_linear_fwd (packed projection, frames in the epilogue) followed by the plain call -- dense, with
