@@ -314,7 +314,8 @@ int pf_rigid_update_fwd(const pf_rigid_update_args* a, pf_stream_t stream);
  * [plane][N/16][K/32][64 lanes][8] -- produced by pepflowww_amd.engine.split_f16 (see csrc/common.h). */
 typedef struct {
     const float* z_in;             /* [B*L*L,64] */
-    float* z_out;                  /* may alias z_in */
+    float* z_out;                  /* may alias z_in; NULL (ABI 50, with bias_out set): z' is not stored -- the last EdgeTransition of a
+                                    * step, whose output only feeds the next attention's pair bias / pair values (ga.py:115-118) */
     const float* pre;              /* [B*L,512] */
     const void* w1z_f16;           /* UNUSED since ABI 50 (operands of the round-1 tiled kernel, removed): leave NULL */
     const void* w2_f16;            /* UNUSED since ABI 50 */

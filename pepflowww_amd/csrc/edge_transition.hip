@@ -16,7 +16,7 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
 int pf_edge_transition_v4_launch(const pf_edge_transition_args* a, hipStream_t stream);   // edge_transition_v4.hip
 
 extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream) {
-    if (!a || !a->z_in || !a->z_out || !a->pre || !a->b2 || !a->ln_g || !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
+    if (!a || !a->z_in || (!a->z_out && !a->bias_out) || !a->pre || !a->b2 || !a->ln_g || !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
         return PF_E_BADARG;
     if (a->w_stream32 && !(a->dump_h1 || a->dump_h2 || a->dump_y)) return pf_edge_transition_v4_launch(a, (hipStream_t)stream);
     if (a->w_stream) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);

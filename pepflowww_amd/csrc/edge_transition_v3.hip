@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 o4[t].z = ((y[4 * t + 2] - mean) * rstd * gm.z + bt.z) * mk[p];
                 o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk[p];
             }
-            if (valid[p]) {
+            if (valid[p] && a.z_out) {                           // (z_out = NULL: the last EdgeTransition of a step, see the v4 kernel)
                 if constexpr (ZO) {
                     _Float16* zo = reinterpret_cast<_Float16*>(a.z_out) + pidx[p] * 64 + 4 * g;
 #pragma unroll
@@ -728,6 +728,7 @@ extern "C" int pf_edge_transition_tile_rows(int single_pass) { return single_pas
 int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t stream) {
     if ((a->tile_list != nullptr) != (a->n_tiles != nullptr)) return PF_E_BADARG;
     if (a->dz_out && (!a->bias_out || !a->wb_frags)) return PF_E_BADARG;        // dz_out rides on the pair-bias tile
+    if (!a->z_out && (!a->bias_out || a->dump_y)) return PF_E_BADARG;           // z' may be dropped only where the pair bias is what is wanted
     if (a->dz_out_f16 && !(a->dz_out && a->single_pass)) return PF_E_BADARG;
     const int ncu = pf_cu_count();
     if (a->dump_h1 || a->dump_h2 || a->dump_y) {

@@ -556,8 +556,8 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[mt][r] *= mk[t];
             }
-            if (valid[t]) {
-#pragma unroll
+            if (valid[t] && a.z_out) {                           // (z_out = NULL: the LAST EdgeTransition of a step -- nobody reads its z',
+#pragma unroll                                                   //  only the pair bias / pair values below: 256 B per pair not written)
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
@@ -655,6 +655,7 @@ int pf_edge_transition_v4_launch(const pf_edge_transition_args* a, hipStream_t s
     if ((a->tile_list != nullptr) != (a->n_tiles != nullptr)) return PF_E_BADARG;
     if (a->bias_out && (!a->wb_frags32 || !a->bb)) return PF_E_BADARG;
     if (a->dz_out && !a->bias_out) return PF_E_BADARG;          // dz_out rides on the pair-bias tile
+    if (!a->z_out && !a->bias_out) return PF_E_BADARG;          // nothing to produce
     if (a->dz_out_f16 && !(a->dz_out && a->single_pass)) return PF_E_BADARG;
     if (a->dump_h1 || a->dump_h2 || a->dump_y) return PF_E_BADARG;                 // the training dumps live in the v3 kernel
     if ((a->z_in_f16 || a->z_out_f16) && !a->single_pass) return PF_E_BADARG;

@@ -741,7 +741,10 @@ class DenoiseEngine:
                 if not self.fused_proj:
                     emit_proj(b + 1, 1)
                 et = _capi.EdgeTransitionArgs()
-                et.z_in, et.z_out, et.pre = z_in.data_ptr(), self.zbuf.data_ptr(), self.pre.data_ptr()
+                # the LAST EdgeTransition's z' is never read: block 5 takes its pair bias and pair values from this launch, and there is
+                # no EdgeTransition after it (ga.py:115-118) -- not stored (256 B per pair; PF_ET_LAST_STORE=1 keeps the store, A/B runs)
+                drop_z = (b == N_BLOCKS - 2 and self.pair_dz is not None and os.environ.get("PF_ET_LAST_STORE") != "1")
+                et.z_in, et.z_out, et.pre = z_in.data_ptr(), (None if drop_z else self.zbuf.data_ptr()), self.pre.data_ptr()
                 et.b2, et.ln_g, et.ln_b = w[f"{b}.et.b2"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
                 et.w_stream = w[f"{b}.et.stream"].data_ptr()
                 et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
