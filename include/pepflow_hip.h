@@ -285,6 +285,10 @@ typedef struct {
      *   5 tf = LN2(h2)   6 s2 = s_ipa + post_tfmr(tf)   7 t1   8 t2 (StructureModuleTransition hidden)   9 h3 = linear_3(t2) + s2
      *   10 the backbone update [B*L,8] (6 used: BackboneUpdate output, input of compose_q_update_vec) */
     float* dump[11];
+    /* optional (last == 1, L % 16 == 0): row_on[(b L + i) / 16] != 0 marks the 16-row groups whose outputs are wanted; a query tile
+     * without a marked group is skipped (nothing of it is written).  The sampler marks the groups that hold a generated residue in
+     * the LAST block of a step: the predictions of context residues are replaced by the context anyway (flow_model.py:291-311). */
+    const int* row_on;
 } pf_node_tfmr_args;
 int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream);
 

@@ -162,7 +162,7 @@ class NodeTfmrArgs(C.Structure):
                 ("b_bb", _fp), ("s_out", _fp), ("quat_in", _fp), ("rot_in", _fp), ("trans_in", _fp),
                 ("quat_out", _fp), ("rot_out", _fp), ("trans_out", _fp), ("has_et", _i),
                 ("w_init_f16", _fp), ("b_init", _fp), ("w_pre_f16", _fp), ("b_pre", _fp), ("pre", _fp), ("B", _i), ("L", _i),
-                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp), ("dump", _fp * 11)]
+                ("h_w", (_fp * 3) * 2), ("h_b", (_fp * 3) * 2), ("logits_out", _fp), ("ang_out", _fp), ("single_pass", _i), ("key_end", _fp), ("dump", _fp * 11), ("row_on", _fp)]
 
 
 class EtBwdArgs(C.Structure):

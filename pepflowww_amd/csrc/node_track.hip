@@ -358,6 +358,16 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_tfmr_kernel(pf_node_tfm
     const size_t rowb = (size_t)b * L;
     // padded batch: a query tile at or beyond the sample's last unmasked residue does nothing (pf_node_tfmr_args.key_end)
     if (a.key_end && i0 >= __builtin_amdgcn_readfirstlane(a.key_end[b])) return;
+    // last block of a sampler step (pf_node_tfmr_args.row_on, one flag per 16 rows, L % 16 == 0): a query tile without a residue whose
+    // prediction anybody reads does nothing -- its rows have already served as keys / values (qkv was written by the previous launch)
+    if constexpr (LAST) {
+        if (a.row_on) {
+            int any = 0;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) any |= a.row_on[((int)rowb + min(i0 + 16 * rt, L - 16)) >> 4];
+            if (!__builtin_amdgcn_readfirstlane(any)) return;
+        }
+    }
     const int m0 = (int)rowb + i0;           // global row of tile row 0
     const int M = (int)rowb + L;             // rows of this sample end here (tile rows beyond are padding)
     const int n = wave * 16 + 4 * g;         // this lane's 4 consecutive output features in the 128-wide stages

@@ -469,6 +469,9 @@ class DenoiseEngine:
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
             self.att_vt = torch.zeros(B * 8 * 164 * L + 64, dtype=torch.float16, device=device)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
+        # 16-row groups whose final predictions are wanted (pf_node_tfmr_args.row_on of the LAST block's tail): all of them for the
+        # stand-alone step; the sampler marks the groups that hold a generated residue (DeviceSampler.set_context)
+        self.row_on = torch.ones(max(1, rows // 16), dtype=torch.int32, device=device) if L % 16 == 0 else None
         self._keep = []
         self.plan = None
         self.plan_version = 0                   # bumped whenever the plan is rebuilt: graphs captured from an older plan are stale
@@ -722,6 +725,8 @@ class DenoiseEngine:
                     ta.quat_in, ta.rot_in, ta.trans_in = self.quat.data_ptr(), rot.data_ptr(), trans.data_ptr()
                     ta.quat_out, ta.rot_out, ta.trans_out = self.quat.data_ptr(), self.rot.data_ptr(), self.trans.data_ptr()
                     ta.has_et = int(b < N_BLOCKS - 1)
+                    if not ta.has_et and self.row_on is not None:
+                        ta.row_on = self.row_on.data_ptr()
                     if not ta.has_et:
                         for ni, net in enumerate(("seq_net", "angle_net")):
                             for li, layer in enumerate((0, 2, 4)):
@@ -766,6 +771,16 @@ class DenoiseEngine:
         self._warm = False
 
     # ---- execution ---------------------------------------------------------------------------
+    def want_rows(self, want=None):
+        """Which residues' final predictions are wanted: None = all (the stand-alone GAEncoder.forward); a [B, L] / [rows] mask = only
+        these (the sampler: generated residues).  Device-side, no synchronisation; graph-safe (the kernel reads the same buffer)."""
+        if self.row_on is None:
+            return
+        if want is None:
+            self.row_on.fill_(1)
+        else:
+            self.row_on.copy_((want.reshape(-1, 16).to(torch.float32).amax(1) > 0).to(torch.int32))
+
     def set_state(self, t, rotmats_t, trans_t, angles_t, seqs_t):
         rows = self.rows
         self.t.copy_(t.reshape(self.B).to(torch.float32))

@@ -83,6 +83,7 @@ class FlowModel(nn.Module):
         tf = TrainForward(eng, (self.sample_structure, self.sample_sequence), first_sample, seed)
         tf.set_context(R1, x1, ang1, seq1, batch["generate_mask"])
         tf.corrupt(default_train_noise(B, L) if noise is None else noise)
+        eng.want_rows(None)                      # (the losses read every unmasked row's prediction)
         eng.run()
         losses = tf.compute_losses()
         return (losses, tf) if return_state else losses

@@ -265,6 +265,7 @@ class GAEncoder(nn.Module):
         eng = self.engine(B, L, node_embed.device)
         eng.bind_context(node_embed, edge_embed, res_mask)
         eng.set_state(t, rotmats_t, trans_t, angles_t, seqs_t)
+        eng.want_rows(None)                      # every row's prediction is returned here (a sampler may have narrowed it on this engine)
         eng.run()
         rot = eng.rot.view(B, L, 3, 3).clone()
         trans = eng.trans.view(B, L, 3).clone()

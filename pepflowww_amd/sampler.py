@@ -95,6 +95,10 @@ class DeviceSampler:
         self.ang1.copy_(ang1.reshape(rows, 5))
         self.seq1.copy_(seq1.reshape(rows))
         self.gen.copy_(gen_mask.reshape(rows).to(torch.float32))
+        # the last block's tail only has to produce the generated residues' predictions (everything else is replaced by the context,
+        # flow_model.py:291-311): its row tiles without one are skipped.  PF_SKIP_CONTEXT_ROWS=0: all rows (A/B runs)
+        import os
+        self.eng.want_rows(self.gen if os.environ.get("PF_SKIP_CONTEXT_ROWS") != "0" else None)
 
     def init_state(self, noise):
         dev, rows = self.eng.device, self.eng.rows
