@@ -3,7 +3,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/pfprof/lib
-for f in selftest linear edge_transition edge_transition_v3 edge_transition_v4 ipa_attn ipa_split node_ops flow_step encode node_track train_fwd backward ipa_bwd full_atom; do
+for f in selftest linear edge_transition edge_transition_v3 edge_transition_v4 ipa_attn ipa_split node_ops flow_step encode node_track train_fwd backward ipa_bwd et_bwd full_atom; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPF_PROFILE $PFX $([ $f = edge_transition_v3 ] && echo -fno-slp-vectorize) $([ $f = edge_transition_v4 ] && echo -fno-slp-vectorize -Wno-inline-asm) -c $R/pepflowww_amd/csrc/$f.hip -o /tmp/pfprof/lib/$f.o &
 done
 wait
@@ -30,7 +30,9 @@ with torch.no_grad():
     torch.cuda.synchronize()
     raw = C.CDLL(_capi.LIB_PATH)
     out = (C.c_longlong * 256)()
-    for sym, n in (("pf_debug_prof", 14), ("pf_debug_prof_et", 10), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 8), ("pf_debug_prof_et3", 156)):
+    for sym, n in (("pf_debug_prof", 14), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 8), ("pf_debug_prof_et3", 156)):
+        if not hasattr(raw, sym):               # (the tiled EdgeTransition kernel and the v4 stamps left the source in round 4)
+            continue
         getattr(raw, sym)(out, 256 if sym.endswith("et3") else 64)
         v = list(out)
         print(sym, "stamps (cycles rel.):", [x - v[0] for x in v[:n]])
