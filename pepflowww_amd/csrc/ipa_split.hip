@@ -486,7 +486,7 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
 // the loop.  (First version: conditional prefetches and guarded stores inside the loops -- hipcc emits s_waitcnt vmcnt(0) at
 // every control-flow join, so the "one tile ahead" loads were never in flight: 108 us per launch at B=64, L=128, 28 % of the
 // wave cycles parked on memory, MFMA pipe 29 % busy.)
-template <bool VEC4, bool FUSE = false, bool PROJ = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_rows16)
+template <bool VEC4, bool FUSE = false, bool PROJ = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     if constexpr (!PROJ) { if (wave_on) loadk(0, kf); }
 
     if constexpr (PROJ) {
-        // the head's operands are formed here (proj_rows16): k | v rows -> `proj` (scratch), key / value points -> KP / VP, q and the
+        // the head's operands are formed here (proj_head): k | v rows -> `proj` (scratch), key / value points -> KP / VP, q and the
         // query points -> registers; only the key mask is staged from memory.  (One 16-row query tile per wave, all of the sample's
         // rows in this workgroup: the launcher guarantees nrb == 1.)
         for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + min(j, L - 1)] : 0.f;

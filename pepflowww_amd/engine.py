@@ -455,7 +455,7 @@ class DenoiseEngine:
         # projection 88 vs 77 us (transposed 8-byte stores + hi / lo splits of every output) -- so the fp32 mode keeps fp32 operands.
         # (that hi / lo form left the library in round 4 after its K Q^T phase measured slower than the fp32-MFMA kernel's)
         self.att_planes = precision == "f16" and (L % 16 == 0) and (64 <= L <= 256)
-        # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_rows16): every (sample, head)
+        # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_head / proj_head16): every (sample, head)
         # workgroup projects its own rows -- no projection launch, q and the points never reach HBM, `proj` shrinks to a k | v scratch.
         # Needs the fp32-operand two-kernel form with all query tiles of a sample in one workgroup (64 <= L <= 128, L % 4 == 0): a rule
         # in (L, precision) alone.  PF_FUSED_PROJ=0 / 1 forces it off / on (same-box A/B runs).

@@ -1,10 +1,12 @@
-# dev: phase stamps (PROFS) of the score kernels at B=64, L=128: fp32 operands (unfused / fused projection) vs hi / lo planes (MODE 1)
+# dev: phase stamps (PROFS) of the fp32 score kernel at B=64, L=128: separate projection vs projection inside.  (The third column of
+# profiles/r04/r04g_score_kernel_phases.txt -- hi / lo operand planes, PF_ATT_SPLIT=1 -- was taken at commit 4ada080, before that
+# form was removed from the library.)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPF_PROFILE -c pepflowww_amd/csrc/ipa_split.hip -o /tmp/ipa_split_prof.o
 objs=$(ls pepflowww_amd/lib/*.o | grep -v ipa_split.o)
 cp pepflowww_amd/lib/libpepflow_hip.so /tmp/orig.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o pepflowww_amd/lib/libpepflow_hip.so $objs /tmp/ipa_split_prof.o
-for cfg in "PF_FUSED_PROJ=0" "PF_FUSED_PROJ=1" "PF_FUSED_PROJ=0 PF_ATT_SPLIT=1"; do
+for cfg in "PF_FUSED_PROJ=0" "PF_FUSED_PROJ=1"; do
 env $cfg python - "$cfg" <<'PY'
 import ctypes as C, torch, sys, os
 sys.path.insert(0, ".")
