@@ -222,11 +222,7 @@ struct PjW { half8 h[4], l[4]; };
 // (LDS-DMA, two 24 KiB buffers, the next chunk in flight under the current chunk's MFMAs) and every wave reads its operands from
 // there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
 // 64 B / clk L1 path and the prologue cost what the projection launch it replaced had cost.
-// role: 0 = this wave projects all 31 tiles of its rows; with HELPER waves (L <= 64: twice as many waves as query tiles, the second half
-// exits after the prologue) 1 = the query wave takes the q and query-point tiles (10), 2 = its helper the k | v and key / value-point
-// tiles (21) of the same rows -- those results go to the scratch / the LDS tables anyway, nothing has to be handed over.
-__device__ __forceinline__ constexpr bool pj_q_tile(int idx) { return idx < 8 || idx == 24 || idx == 25; }
-__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, int role, float* KP,
+__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, float* KP,
                                           float* VP, unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
                                           float* PB /* [PJ_TILES * 16] the head's bias, staged here */,
                                           float4 (&qf)[8], float4 (&qp4)[6], int lane, int wave, int nw) {
@@ -299,20 +295,18 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH) + (PJ_NB > 4 && c + 3 < PJ_NCH);
         constexpr int NSY = pj_kv_tiles(c - 1) + (PJ_NB > 3 ? pj_kv_tiles(c - 2) : 0) + (PJ_NB > 3 ? pj_kv_tiles(c - 3) : 0);
         static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");
-        pj_wait_vm_dyn((PJ_NB == 2 ? 0 : NDY * ppw) + ((wave_on && role != 1) ? (PJ_NB == 2 ? pj_kv_tiles(c - 1) : NSY) : 0));
+        pj_wait_vm_dyn((PJ_NB == 2 ? 0 : NDY * ppw) + (wave_on ? (PJ_NB == 2 ? pj_kv_tiles(c - 1) : NSY) : 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
         if (wave_on) {
             PjW wa, wb;
-            if (role == 0) ldfrag(c, 0, wa);
+            ldfrag(c, 0, wa);
             cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
                 constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
                 if constexpr (idx < PJ_TILES) {
-                  if (role == 0 || (role == 1) == pj_q_tile(idx)) {          // (wave-uniform)
                     PjW& w = (tl & 1) ? wb : wa;
-                    if (role != 0) ldfrag(c, tl, w);                        // (a tile here and there: requested at its use)
-                    else if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
                     f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
@@ -341,12 +335,11 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                             if (jrow < LPe) { o[0] = ox; o[1] = oy; o[2] = oz; }
                         }
                     }
-                  }
                 }
             });
         }
     });
-    if (wave_on && role != 2) {
+    if (wave_on) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private LDS hand-off of the query points
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -509,10 +502,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int h = (lid / nrb) % H;
     const int b = lid / (nrb * H);
     const size_t rowb = (size_t)b * L;
-    // PROJ with helper waves (blockDim = 2 x the query tiles, L <= 64): wave ntq + w helps query wave w through the prologue and exits
-    const int ntq = rows_per_block >> 4;
-    const bool helper = PROJ && wave >= ntq;
-    const int i0 = rb * rows_per_block + (helper ? wave - ntq : wave) * 16;
+    const int i0 = rb * rows_per_block + wave * 16;
     // Le: keys / query rows from here on are masked (pf_ipa_attn_args.key_end; L without it): nothing beyond is read or written
     const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
     const int kt = (Le + 15) >> 4, ktf = Le >> 4;  // key tiles, full key tiles
@@ -549,12 +539,11 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         // rows in this workgroup: the launcher guarantees nrb == 1.)
         for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + min(j, L - 1)] : 0.f;
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
-        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (helper ? 0 : wave) * 16 * 24;   //  sizes the allocation for staging + query points)
-        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + ntq * 16 * 24;
-        const int role = (int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0;
-        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, role, KP, VP, WS, QPW, PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
+        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + wave * 16 * 24;   //  sizes the allocation for staging + query points)
+        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (blockDim.x >> 6) * 16 * 24;
+        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, VP, WS, QPW, PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
-        if (!wave_on || helper) return;
+        if (!wave_on) return;
         loadk(0, kf);
     } else {
     // ---- key points / key mask / value points of the head -> LDS (all waves) ----
@@ -1436,7 +1425,6 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_pj16 = true;
             }
-            // (helper waves for the prologue, as the fp32 form has for L <= 64, measured nothing here: 0.480 vs 0.479 ms at cfg2)
             hipLaunchKernelGGL((ipa_scores16_kernel<true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
             PF_CHECK_LAUNCH();
             return 0;
@@ -1453,12 +1441,8 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
             const size_t ldsp = lds > need ? lds : need;
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
-            // L <= 64: as many helper waves as query waves for the prologue (proj_head roles): cfg2 0.6915 -> 0.6785 ms, same box
-            // (profiles/r04/r04o_helper_waves_ab.txt; PF_PROJ_HELPERS=0 turns them off for A/B runs)
-            static const bool no_helpers = getenv("PF_PROJ_HELPERS") && atoi(getenv("PF_PROJ_HELPERS")) == 0;
-            const int nwv = (wpb <= 4 && !no_helpers) ? 2 * wpb : wpb;
-            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
-            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
