@@ -340,7 +340,11 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         }
     });
     if (wave_on) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private LDS hand-off of the query points
+        // the k | v stores have completed before the caller's barrier: __syncthreads() itself only waits for LDS here (a workgroup-scope
+        // release leaves vmcnt alone on gfx9: stores and the other waves' later loads pass the CU's L1 in order) -- the three stores of
+        // chunk 7 were still allowed in flight by the last counted wait; the explicit wait costs nothing (three chunks later) and the
+        // hand-off through `proj` no longer leans on that ordering rule
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // + wave-private LDS hand-off of the query points
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);

@@ -434,7 +434,9 @@ class DenoiseEngine:
         # f16 values that costs less than the second kernel + the probability round trip (B=64, L=128: step 2.167 -> 2.138 ms, L=64:
         # 0.528 -> 0.514), with fp32 values (twice the bytes through L2 -> L1) as much as it saves (3.46 vs 3.48 ms; two or four rows
         # in flight per wave measure the same: bandwidth, not latency).  A rule in (L, precision) alone.  PF_FUSED_PAIR=0 / 1 forces it.
-        self.fused_pair = self.pair_dz is not None and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PAIR", ""), self.z16)
+        # (round 4: also in the fp32 mode for L <= 64 -- there the separate pair kernel is a 5 us launch of its own and the fused phase
+        #  costs less than that: 0.6974 -> 0.6927 ms at B=16, L=64; at L=128 it stays slower, 3.43 vs 3.47 ms)
+        self.fused_pair = self.pair_dz is not None and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PAIR", ""), self.z16 or L <= 64)
         # attention probabilities handed from the score kernel to the pair-aggregation kernel (two-kernel form only)
         self.attn_p = None if self.fused_pair else e(B, 8, L, L)
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,

@@ -133,3 +133,28 @@ def test_step_with_and_without_the_projection_launch_is_bit_identical(seeded_sd,
     for a, b in zip(*outs):
         assert torch.equal(a, b), float((a - b).abs().max())
     assert launches[0] - launches[1] == 6, launches
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+@pytest.mark.parametrize("B,L,ragged", [(16, 64, False), (16, 64, True), (8, 128, True), (8, 144, True), (8, 96, True)])
+def test_sample_is_stable_from_run_to_run(seeded_sd, precision, B, L, ragged):
+    """Six runs of FlowModel.sample (graph replay and eager, interleaved) on the same noise give the same bits.  The shapes put
+    waves that leave early (rows beyond a sample's key end, padded batches) beside the fused phases of the score kernels
+    (projection inside: 64 <= L <= 128; pair aggregation inside: f16 mode, and fp32 mode at L <= 64) -- a form of the projection
+    prologue with helper waves that returned after their last barrier failed exactly this check."""
+    import random
+    rnd = random.Random(B * 1000 + L)
+    lengths = [rnd.randint(L // 3, L) for _ in range(B)] if ragged else None
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    model.load_state_dict(seeded_sd, strict=True)
+    model = model.to(G.dev()).eval()
+    if precision != "fp32":
+        model.ga_encoder.set_precision(precision)
+    batch = synth.make_pocket_batch(B, L, 8, seed=11, lengths=lengths)
+    noise = synth.make_noise(B, L, 3, seed=3)
+    bd = {k: (v.to(G.dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    runs = [model.sample(bd, num_steps=3, noise=noise, use_graph=ug) for ug in (True, False, False, True, False, True)]
+    for r in runs[1:]:
+        for s in range(3):
+            for k in ("rotmats", "trans", "angles", "seqs_simplex", "seqs"):
+                assert torch.equal(runs[0][s][k], r[s][k]), (s, k)
