@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 50
+#define PF_ABI_VERSION 51
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -198,10 +198,17 @@ typedef struct {
      * THE PROJECTION RUNS INSIDE THE SCORE KERNEL (ABI 50).  s_in [B*L,128] = the node state; proj_w_f16 = fragment-order hi / lo
      * planes (engine.split_f16) of the packed projection [3968,128] = [linear_q 1024 | linear_kv 2048 | 64 query points (x,y,z,0) |
      * 160 key / value points (x,y,z,0)] -- the matrix pf_linear_fwd takes with pt_col0 = 3072 -- and proj_bias [3968] its bias.
-     * Each (sample, head) workgroup forms q, the query / key / value points (global frame, through rot / trans) on chip and
-     * writes only the head's k | v columns of `proj` (which it reads back itself: `proj` is a per-launch SCRATCH then, written
-     * through the const pointer; columns 0..1023 and qp / kp / vp are not touched and may be NULL).  Results are bit-identical
-     * to pf_linear_fwd followed by the plain call (ipa_pytorch.py:347-387 + 389-475 in one launch). */
+     * Each (sample, head) workgroup forms q and the query / key / value points (global frame, through rot / trans) on chip; `proj`
+     * and qp / kp / vp are not touched in this form (proj must still be non-NULL).
+     * fp32 operands (att_mode 0), ABI 51: `att_vt` is REQUIRED as the launch's SCRATCH of B x 8 x 512 x ceil32(L) f16 (1 KiB per key
+     * and head; written through the const pointer): per (sample, head) the values as hi | lo f16 operand fragments of the second
+     * product (transposed, fragment order: 1 KiB per (16-channel tile, 32-key step, plane)) and the k rows as fp32 fragments of the
+     * first (1 KiB per (16-key tile, 16-channel step)) -- every operand load / store of the workgroup is one contiguous KiB.  The
+     * second product runs as three f16 MFMAs per product (P hi V hi + P hi V lo + P lo V hi, ~2^-22 relative: the precision of
+     * every split-precision Linear of this library) instead of fp32 MFMAs.  The buffer must hold FINITE values on entry (zero it
+     * once): key columns at or beyond a sample's key end are not written and meet zero probabilities.
+     * q, k, the points and the first product are bit-identical to pf_linear_fwd followed by the plain call; the outputs agree with
+     * it to ~1e-6 relative (ipa_pytorch.py:347-387 + 389-475 in one launch). */
     const float* s_in; const void* proj_w_f16; const float* proj_bias;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);

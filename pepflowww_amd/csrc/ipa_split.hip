@@ -200,8 +200,8 @@ __device__ __forceinline__ void pj_glds16(const void* sbase, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void pj_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant): everything but the n youngest vector
-// memory operations of this wave has completed (they complete in order)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant): at most n vector memory operations of this
+// wave are outstanding (LOADS complete in order among themselves; a store may complete before an older load, see proj_head)
 __device__ __forceinline__ void pj_wait_vm_dyn(int n) {
     n = __builtin_amdgcn_readfirstlane(n);
     switch (n > 40 ? 40 : n) {
@@ -212,10 +212,21 @@ __device__ __forceinline__ void pj_wait_vm_dyn(int n) {
 #undef PJ_W
     }
 }
-__device__ __forceinline__ constexpr int pj_kv_tiles(int c) {    // k | v tiles (one store instruction each) of chunk c
-    int n = 0;
-    for (int t = 0; t < PJ_CT; ++t) n += (c >= 0 && PJ_CT * c + t >= 8 && PJ_CT * c + t < 24) ? 1 : 0;
-    return n;
+// The head's values as the SECOND product's f16 operands (fp32-parity mode: hi | lo, three MFMAs per product): transposed, in a
+// per-launch scratch (pf_ipa_attn_args.att_vt) in FRAGMENT order -- block (channel tile nt, 32-key step, plane) = 1 KiB = the sixteen
+// bytes of each of the 64 reader lanes, so an operand load is one contiguous KiB (as [128][VTG] planes a load touched sixteen rows, 64
+// bytes of each: twice the cache-line accesses of the fp32 form's value loads, and the phase took as long as that one) --, the value
+// points as [48][VTL] planes in LDS.
+//   row of channel f  = 16 nt + n  where the reader's tile nt, lane n holds column 4 n + nt (nt < 4) / 64 + 4 n + nt - 4 (its two
+//                       float4 output stores per query stay as they were);
+//   position of key j = 32 s + 16 hh + 4 g + e  ->  32 s + 8 g + 4 hh + e: lane (n, g)'s eight operand slots of a 32-key step are
+//                       16 contiguous bytes, and they are the keys whose probabilities lane (r, g) of the score phase holds
+//                       (tiles 2 s and 2 s + 1, keys 4 g .. 4 g + 3) -- the K order of a product is free as long as both sides agree.
+__device__ __forceinline__ constexpr int pj_vt_row(int f) { return f < 64 ? 16 * (f & 3) + (f >> 2) : 64 + 16 * ((f - 64) & 3) + ((f - 64) >> 2); }
+__device__ __forceinline__ int pj_vt_pos(int j) { return (j & ~31) + 8 * ((j >> 2) & 3) + 4 * ((j >> 4) & 1) + (j & 3); }
+__host__ __device__ __forceinline__ constexpr int pj_vtl(int LP) { return ((LP + 31) & ~31) + 8; }          // f16 row stride of the point planes
+__host__ __device__ __forceinline__ constexpr int pj_vp_floats(int LP) {                                    // LDS floats of the value-point region
+    return LP * VPS > 48 * pj_vtl(LP) ? LP * VPS : 48 * pj_vtl(LP);                                          // (fp32 table, or 2 planes x 48 rows f16)
 }
 struct PjW { half8 h[4], l[4]; };
 // Called by EVERY wave of the workgroup (barriers inside).  The head's 248 KiB of weight fragments go L2 -> LDS ONCE per workgroup
@@ -223,7 +234,8 @@ struct PjW { half8 h[4], l[4]; };
 // there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
 // 64 B / clk L1 path and the prologue cost what the projection launch it replaced had cost.
 __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, float* KP,
-                                          float* VP, unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
+                                          _Float16* VPT /* [2][48][VTL] value points, hi | lo */, int VTL, _Float16* VTH /* this head's [8 tiles][VTG / 32 steps][hi | lo][64 lanes][8] */, int VTG,
+                                          unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
                                           float* PB /* [PJ_TILES * 16] the head's bias, staged here */,
                                           float4 (&qf)[8], float4 (&qp4)[6], int lane, int wave, int nw) {
     const int r = lane & 15, g = lane >> 4;
@@ -247,6 +259,9 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     // the head's 496 bias values -> LDS (read per tile in the epilogues: from global memory each of them was an exposed L2 round trip
     // in a wave that has nothing else to issue); visible after the first chunk barrier
     for (int i = wave * 64 + lane; i < PJ_TILES * 16; i += nw * 64) PB[i] = a.proj_bias[16 * pj_tile(i >> 4, h) + (i & 15)];
+    // the value-point planes start as zeros: their rows 36..47 and the keys beyond the last tile meet zero probabilities in the second
+    // product and must be finite (the point tiles write them eight chunk barriers later)
+    for (int i = wave * 64 + lane; i < 24 * VTL; i += nw * 64) reinterpret_cast<float2*>(VPT)[i] = make_float2(0.f, 0.f);   // (2 x 48 x VTL f16)
     // x operand: row iq, K-step ks, slots 8 g .. + 7, as hi / lo planes (split4: the same conversion as the stand-alone kernel)
     half8 xh[4], xl[4];
     float R[9], T[3];
@@ -276,7 +291,9 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
 #pragma unroll
     for (int c = 0; c < PJ_NB - 1; ++c)
         if (c < PJ_NCH) issue(c);
-    float* kvrow = const_cast<float*>(a.proj) + (rowb + iq) * a.ldp + OFF_KV + h * 2 * C + 4 * g;
+    // k rows: fragment order too -- block (key tile = this wave, 16-channel step s) = the 64 lanes' float4 (key r, channels 16 s + 4 g ..)
+    // as the first product's loadk reads them: one contiguous KiB per store / load instruction, behind the head's value blocks
+    float* kfrag = reinterpret_cast<float*>(VTH + (size_t)8 * (VTG >> 5) * 1024) + ((size_t)wave * 8) * 256 + lane * 4;
     auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ_CHUNK_B + tl * 8192 + lane * 16;
 #pragma unroll
@@ -287,15 +304,17 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     };
     cfor_p<0, PJ_NCH>([&](auto ic) __attribute__((always_inline)) {
         constexpr int c = decltype(ic)::value;
-        // chunk c has landed: this wave's pieces (the k | v stores of the previous chunk's tiles are younger: counted wait -- vector
-        // memory operations complete in order), then everybody's (barrier), which also frees the buffer of chunk c - 1
-        // younger than the pieces of chunk c: the pieces of the chunks issued after it (up to PJ_NB - 2 of them) and, in a wave with
-        // rows, the k | v stores of the chunks computed since (c - PJ_NB + 1 .. c - 1).  Never MORE than that (an over-count would let
-        // a piece of chunk c be outstanding); uncounted extras (bias loads) only make the wait stricter.
+        // chunk c has landed: this wave's pieces (counted wait), then everybody's (barrier), which also frees the buffer of chunk c - 1.
+        // The allowance is the PIECES issued after chunk c's (up to PJ_NB - 2 chunks) and nothing else: loads complete in order among
+        // themselves, so "at most that many outstanding" cannot hold while a piece of chunk c is still in flight.  The k | v STORES
+        // issued since are NOT counted: the first build of this loop added them to the allowance ("vector memory operations complete
+        // in order") and was wrong -- a store's vmcnt decrement can overtake an older LDS-DMA piece's, the wait then passes with
+        // chunk c's weights not in LDS yet.  Rare with the scattered 64-byte row stores of that build (one unexplained test failure
+        // in ~10 suite runs), every run once the stores became contiguous KiB blocks (round 4).  Without them in the
+        // allowance the wait also covers the stores of the previous chunks: +1.4 k cycles on the 44 k prologue.
         constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH) + (PJ_NB > 4 && c + 3 < PJ_NCH);
-        constexpr int NSY = pj_kv_tiles(c - 1) + (PJ_NB > 3 ? pj_kv_tiles(c - 2) : 0) + (PJ_NB > 3 ? pj_kv_tiles(c - 3) : 0);
         static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");
-        pj_wait_vm_dyn((PJ_NB == 2 ? 0 : NDY * ppw) + (wave_on ? (PJ_NB == 2 ? pj_kv_tiles(c - 1) : NSY) : 0));
+        pj_wait_vm_dyn(PJ_NB == 2 ? 0 : NDY * ppw);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
@@ -307,21 +326,45 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                 if constexpr (idx < PJ_TILES) {
                     PjW& w = (tl & 1) ? wb : wa;
                     if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    constexpr bool VTILE = idx >= 16 && idx < 24;
                     f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        am = mfma_h(w.h[ks], xh[ks], am);
-                        ac = mfma_h(w.h[ks], xl[ks], ac);
-                        ac = mfma_h(w.l[ks], xh[ks], ac);
+                        if constexpr (VTILE) {              // rows x features: a lane holds four consecutive KEYS of one channel
+                            am = mfma_h(xh[ks], w.h[ks], am);
+                            ac = mfma_h(xl[ks], w.h[ks], ac);
+                            ac = mfma_h(xh[ks], w.l[ks], ac);
+                        } else {
+                            am = mfma_h(w.h[ks], xh[ks], am);
+                            ac = mfma_h(w.h[ks], xl[ks], ac);
+                            ac = mfma_h(w.l[ks], xh[ks], ac);
+                        }
                     }
-                    const float4 b4 = *reinterpret_cast<const float4*>(PB + 16 * idx + 4 * g);
                     float v[4];
-                    v[0] = (am[0] + ac[0] * PF_LO_INV) + b4.x; v[1] = (am[1] + ac[1] * PF_LO_INV) + b4.y;
-                    v[2] = (am[2] + ac[2] * PF_LO_INV) + b4.z; v[3] = (am[3] + ac[3] * PF_LO_INV) + b4.w;
+                    if constexpr (VTILE) {
+                        const float b1 = PB[16 * idx + r];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (am[e] + ac[e] * PF_LO_INV) + b1;
+                    } else {
+                        const float4 b4 = *reinterpret_cast<const float4*>(PB + 16 * idx + 4 * g);
+                        v[0] = (am[0] + ac[0] * PF_LO_INV) + b4.x; v[1] = (am[1] + ac[1] * PF_LO_INV) + b4.y;
+                        v[2] = (am[2] + ac[2] * PF_LO_INV) + b4.z; v[3] = (am[3] + ac[3] * PF_LO_INV) + b4.w;
+                    }
                     if constexpr (idx < 8) {
                         qf[idx] = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if constexpr (idx < 24) {        // k tiles 0..7 | v tiles 0..7 of the head: columns 16 (idx - 8) + 4 g of its 256
-                        *reinterpret_cast<float4*>(kvrow + 16 * (idx - 8)) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if constexpr (idx < 16) {        // k tiles 0..7 of the head: columns 16 (idx - 8) + 4 g of its 256
+                        *reinterpret_cast<float4*>(kfrag + (idx - 8) * 256) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if constexpr (VTILE) {           // channel 16 (idx - 16) + r of keys 16 wave + 4 g + e -> hi | lo plane, 8 bytes each
+                        half4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+                        const int f = 16 * (idx - 16) + r;
+                        // fragment order: block (tile nt, step, plane) = the 64 reader lanes' 16 bytes each; this lane's four keys are
+                        // half (wave & 1) of reader lane (n, g)'s eight slots
+                        const int row = pj_vt_row(f), nst = VTG >> 5;
+                        _Float16* d = VTH + ((size_t)((row >> 4) * nst + (wave >> 1)) * 2 * 64 + 16 * g + (row & 15)) * 8 + 4 * (wave & 1);
+                        *reinterpret_cast<half4*>(d) = hi;
+                        *reinterpret_cast<half4*>(d + 512) = lo;
                     } else {                                // a point (x, y, z, 0) of this row: global frame, as pf_linear_fwd's epilogue forms it
                         const float ox = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + T[0];
                         const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
@@ -331,8 +374,21 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                             o[0] = ox; o[1] = oy; o[2] = oz;
                         } else {                            // key point pp < 8 | value point pp - 8 of key row jrow
                             const int pp = 4 * (idx - 26) + g;
-                            float* o = pp < 8 ? KP + jrow * KPS + 3 * pp : VP + jrow * VPS + 3 * (pp - 8);
-                            if (jrow < LPe) { o[0] = ox; o[1] = oy; o[2] = oz; }
+                            if (jrow < LPe) {
+                                if (pp < 8) {
+                                    float* o = KP + jrow * KPS + 3 * pp;
+                                    o[0] = ox; o[1] = oy; o[2] = oz;
+                                } else {                    // value point pp - 8: rows 3 (pp - 8) .. + 2 of the point planes, column of key jrow
+                                    _Float16* o = VPT + 3 * (pp - 8) * VTL + pj_vt_pos(jrow);
+                                    const float c3[3] = {ox, oy, oz};
+#pragma unroll
+                                    for (int m = 0; m < 3; ++m) {
+                                        const _Float16 hi = (_Float16)c3[m];
+                                        o[m * VTL] = hi;
+                                        o[(48 + m) * VTL] = (_Float16)(c3[m] - (float)hi);
+                                    }
+                                }
+                            }
                         }
                     }
                 }
@@ -496,8 +552,8 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int L = a.L;
     float* KP = smem;                              // [LP][KPS] key points of this head (global frame)
     float* MJ = KP + LP * KPS;                     // [LP] key mask (0 beyond L)
-    float* VP = MJ + LP;                           // [LP][36] value points of this head (global frame)
-    float* SW = VP + LP * VPS;                     // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
+    float* VP = MJ + LP;                           // [LP][36] value points of this head (global frame); PROJ: [2][48][VTL] f16 planes
+    float* SW = VP + (PROJ ? pj_vp_floats(LP) : LP * VPS);   // [waves][16][SLD] scores / probabilities; later [16][36] o_pt of the wave
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -529,10 +585,22 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const float mi = a.mask[rowb + iq];
     const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
     const float* kbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + 4 * g;
+    // PROJ: the k rows come from the launch's scratch in fragment order (proj_head): tile t, step s = one contiguous KiB
+    const char* kfr_u = nullptr;
+    if constexpr (PROJ) {
+        const int VTG = (L + 31) & ~31;
+        kfr_u = reinterpret_cast<const char*>(a.att_vt) + (((size_t)b * H + h) * 512 * VTG + (size_t)8 * (VTG >> 5) * 1024) * sizeof(_Float16);
+    }
     auto loadk = [&](int t, float4 (&kf)[8]) {
-        const float* krow = kbase + (size_t)min(16 * t + r, Le - 1) * a.ldp;
+        if constexpr (PROJ) {
+            const char* kt_u = kfr_u + (size_t)t * 8192;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
+            for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(kt_u + s * 1024 + (unsigned)lane * 16u);
+        } else {
+            const float* krow = kbase + (size_t)min(16 * t + r, Le - 1) * a.ldp;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
+        }
     };
     float4 kf[8], kn[8];
     if constexpr (!PROJ) { if (wave_on) loadk(0, kf); }
@@ -545,7 +613,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
         float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + wave * 16 * 24;   //  sizes the allocation for staging + query points)
         float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (blockDim.x >> 6) * 16 * 24;
-        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, VP, WS, QPW, PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
+        const int VTG = (L + 31) & ~31;                // key stride of the value planes (pf_ipa_attn_args.att_vt as this launch's scratch)
+        _Float16* VTH = reinterpret_cast<_Float16*>(const_cast<void*>(a.att_vt)) + ((size_t)b * H + h) * 512 * VTG;   // values 256 VTG | k rows 256 VTG (as f16 counts)
+        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW, PB, qf, qp4, lane,
+                  wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
         if (!wave_on) return;
         loadk(0, kf);
@@ -700,63 +771,152 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     //      outputs of a query are two float4.  The 36 point coordinates (LDS) use 3 more tiles (column 16 (n - 8) + r).
     //      The normalised probabilities are written out ([B,8,L,L]) on the way ----
     constexpr int NTC = 11;
-    const float* vbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + C + 4 * r;
-    const float* vp0 = VP + r;
-    const float* vp2 = VP + (r < 4 ? 32 + r : 0);
-    auto loadv = [&](int t, float (&vb)[NTC][4]) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int j = min(16 * t + 4 * g + tt, Le - 1);
-            const float* vrow = vbase + (size_t)j * a.ldp;
-            const float4 x = *reinterpret_cast<const float4*>(vrow), y = *reinterpret_cast<const float4*>(vrow + 64);
-            vb[0][tt] = x.x; vb[1][tt] = x.y; vb[2][tt] = x.z; vb[3][tt] = x.w;
-            vb[4][tt] = y.x; vb[5][tt] = y.y; vb[6][tt] = y.z; vb[7][tt] = y.w;
-            vb[8][tt] = vp0[j * VPS]; vb[9][tt] = vp0[j * VPS + 16]; vb[10][tt] = vp2[j * VPS];   // (tile 10: columns 32..35 only)
-        }
-    };
     f32x4 O[NTC];
 #pragma unroll
     for (int n = 0; n < NTC; ++n) O[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float vb[NTC][4], vn[NTC][4];
-    loadv(0, vb);
-    auto pv_tile = [&](int t, const float (&vb)[NTC][4], auto tail) {
-        constexpr bool TAIL = decltype(tail)::value;
-        float4 p = *reinterpret_cast<const float4*>(srow + 16 * t);
-        p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
-        const int jb = 16 * t + 4 * g;
+    if constexpr (PROJ) {
+        // ---- PROJ form: the second product on v_mfma_f32_16x16x32_f16, three MFMAs per product (P hi x V hi + P hi x V lo + P lo x V hi
+        //      into ONE accumulator: lo halves unscaled, gfx950's f16 MFMA honours subnormal operands) -- 33 MFMAs of 16 cycles per 32
+        //      keys instead of 88 fp32 MFMAs of 32 cycles (the fp32 form of this phase was 85 % matrix-pipe time, what-if build
+        //      profiles/r04/r04p_score_whatif.txt).  The value operands are the hi | lo planes proj_head wrote (channels: the launch's
+        //      scratch, read through L2; points: LDS); the probabilities are this lane's own two float4 of tiles 2 s and 2 s + 1,
+        //      normalised and split in registers.  Same output layout as the fp32 form: lane (r = column, g), register e -> query 4 g + e ----
+        const int VTG = (L + 31) & ~31, VTL = pj_vtl(LP);
+        // (wave-uniform base + ONE 32-bit lane offset: sixteen 64-bit lane addresses per step otherwise sit in VGPRs across the loop)
+        const char* vt_u = reinterpret_cast<const char*>(a.att_vt) + ((size_t)b * H + h) * 512 * VTG * sizeof(_Float16);
+        const unsigned vt_lane = (unsigned)lane * 16u;
+        const _Float16* vpt = reinterpret_cast<const _Float16*>(VP) + r * VTL + 8 * g;
+        const int steps = (kt + 1) >> 1;
+        auto loadv16 = [&](int st, half8 (&vh)[8], half8 (&vl)[8]) {
+            const char* su = vt_u + (size_t)st * 2048;                         // block (tile n, step st): hi KiB | lo KiB
+            const size_t tstride = (size_t)(VTG >> 5) * 2048;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                vh[n] = *reinterpret_cast<const half8*>(su + n * tstride + vt_lane);
+                vl[n] = *reinterpret_cast<const half8*>(su + n * tstride + vt_lane + 1024);
+            }
+        };
+        auto pv_step = [&](int st, const half8 (&vh)[8], const half8 (&vl)[8]) {
+            const int t0 = 2 * st, t1 = 2 * st + 1;
+            float4 p0 = *reinterpret_cast<const float4*>(srow + 16 * t0);
+            float4 p1 = *reinterpret_cast<const float4*>(srow + 16 * min(t1, kt - 1));
+            p0.x *= inv; p0.y *= inv; p0.z *= inv; p0.w *= inv;
+            p1.x *= inv; p1.y *= inv; p1.z *= inv; p1.w *= inv;
+            if (t1 >= kt) p1 = make_float4(0.f, 0.f, 0.f, 0.f);          // (wave-uniform: an odd number of key tiles)
+            if constexpr (!FUSE) {                                        // the normalised probabilities, as the fp32 form writes them
+                auto put = [&](int t, const float4& p) {
+                    const int jb = 16 * t + 4 * g;
+                    if (16 * t + 16 <= Le) {
+                        *reinterpret_cast<float4*>(prow + jb) = p;        // (L % 4 == 0 in this form; duplicate rows store identical values)
+                    } else {
+                        if (jb < Le) prow[jb] = p.x;
+                        if (jb + 1 < Le) prow[jb + 1] = p.y;
+                        if (jb + 2 < Le) prow[jb + 2] = p.z;
+                        if (jb + 3 < Le) prow[jb + 3] = p.w;
+                    }
+                };
+                put(t0, p0);
+                if (t1 < kt) put(t1, p1);
+            }
+            const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            half8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)pv[j]; pl[j] = (_Float16)(pv[j] - (float)ph[j]); }
+            half8 qh[3], ql[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {                                 // value points: rows 16 n + r of the LDS planes
+                qh[n] = *reinterpret_cast<const half8*>(vpt + (16 * n) * VTL + 32 * st);
+                ql[n] = *reinterpret_cast<const half8*>(vpt + (48 + 16 * n) * VTL + 32 * st);
+            }
+            // consecutive MFMAs go to different accumulators (eleven independent chains per product)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) O[n] = mfma_h(ph, vh[n], O[n]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) O[8 + n] = mfma_h(ph, qh[n], O[8 + n]);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) O[n] = mfma_h(ph, vl[n], O[n]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) O[8 + n] = mfma_h(ph, ql[n], O[8 + n]);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) O[n] = mfma_h(pl, vh[n], O[n]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) O[8 + n] = mfma_h(pl, qh[n], O[8 + n]);
+        };
         if constexpr (FUSE) {
-        } else if constexpr (VEC4 && !TAIL) {
-            *reinterpret_cast<float4*>(prow + jb) = p;            // (duplicate rows store identical values to the same address)
-        } else if constexpr (!TAIL) {
-            prow[jb] = p.x; prow[jb + 1] = p.y; prow[jb + 2] = p.z; prow[jb + 3] = p.w;
+            // (the form with the pair phase in front runs at L <= 64: two steps; the second operand set buys nothing there)
+            half8 va[8], vc[8];
+            for (int st = 0; st < steps; ++st) {
+                loadv16(st, va, vc);
+                pv_step(st, va, vc);
+            }
         } else {
-            if (jb < Le) prow[jb] = p.x;
-            if (jb + 1 < Le) prow[jb + 1] = p.y;
-            if (jb + 2 < Le) prow[jb + 2] = p.z;
-            if (jb + 3 < Le) prow[jb + 3] = p.w;
+            half8 va[8], vc[8], wa[8], wc[8];
+            loadv16(0, va, vc);
+            int st = 0;
+            for (; st + 1 < steps; st += 2) {
+                loadv16(st + 1, wa, wc);
+                pv_step(st, va, vc);
+                loadv16(min(st + 2, steps - 1), va, vc);                  // unconditional (the last trip re-reads a valid step)
+                pv_step(st + 1, wa, wc);
+            }
+            if (steps & 1) pv_step(steps - 1, va, vc);
         }
-        // consecutive MFMAs go to different accumulators (11 independent chains per key sub-step)
+    } else {
+    const float* vbase = a.proj + rowb * a.ldp + OFF_KV + h * 2 * C + C + 4 * r;
+        const float* vp0 = VP + r;
+        const float* vp2 = VP + (r < 4 ? 32 + r : 0);
+        auto loadv = [&](int t, float (&vb)[NTC][4]) {
 #pragma unroll
-        for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.x, vb[n][0], O[n]);
+            for (int tt = 0; tt < 4; ++tt) {
+                const int j = min(16 * t + 4 * g + tt, Le - 1);
+                const float* vrow = vbase + (size_t)j * a.ldp;
+                const float4 x = *reinterpret_cast<const float4*>(vrow), y = *reinterpret_cast<const float4*>(vrow + 64);
+                vb[0][tt] = x.x; vb[1][tt] = x.y; vb[2][tt] = x.z; vb[3][tt] = x.w;
+                vb[4][tt] = y.x; vb[5][tt] = y.y; vb[6][tt] = y.z; vb[7][tt] = y.w;
+                vb[8][tt] = vp0[j * VPS]; vb[9][tt] = vp0[j * VPS + 16]; vb[10][tt] = vp2[j * VPS];   // (tile 10: columns 32..35 only)
+            }
+        };
+        float vb[NTC][4], vn[NTC][4];
+        loadv(0, vb);
+        auto pv_tile = [&](int t, const float (&vb)[NTC][4], auto tail) {
+            constexpr bool TAIL = decltype(tail)::value;
+            float4 p = *reinterpret_cast<const float4*>(srow + 16 * t);
+            p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
+            const int jb = 16 * t + 4 * g;
+            if constexpr (FUSE) {
+            } else if constexpr (VEC4 && !TAIL) {
+                *reinterpret_cast<float4*>(prow + jb) = p;            // (duplicate rows store identical values to the same address)
+            } else if constexpr (!TAIL) {
+                prow[jb] = p.x; prow[jb + 1] = p.y; prow[jb + 2] = p.z; prow[jb + 3] = p.w;
+            } else {
+                if (jb < Le) prow[jb] = p.x;
+                if (jb + 1 < Le) prow[jb + 1] = p.y;
+                if (jb + 2 < Le) prow[jb + 2] = p.z;
+                if (jb + 3 < Le) prow[jb + 3] = p.w;
+            }
+            // consecutive MFMAs go to different accumulators (11 independent chains per key sub-step)
 #pragma unroll
-        for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.y, vb[n][1], O[n]);
+            for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.x, vb[n][0], O[n]);
 #pragma unroll
-        for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.z, vb[n][2], O[n]);
+            for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.y, vb[n][1], O[n]);
 #pragma unroll
-        for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.w, vb[n][3], O[n]);
-    };
-    for (t = 0; t + 1 < ktf; t += 2) {
-        loadv(t + 1, vn);
-        pv_tile(t, vb, std::false_type{});
-        loadv(min(t + 2, kt - 1), vb);
-        pv_tile(t + 1, vn, std::false_type{});
-    }
-    if (ktf & 1) {
-        loadv(kt - 1, vn);
-        pv_tile(ktf - 1, vb, std::false_type{});
-        if (kt > ktf) pv_tile(ktf, vn, std::true_type{});
-    } else if (kt > ktf) {
-        pv_tile(ktf, vb, std::true_type{});
+            for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.z, vb[n][2], O[n]);
+#pragma unroll
+            for (int n = 0; n < NTC; ++n) O[n] = mfma16(p.w, vb[n][3], O[n]);
+        };
+        for (t = 0; t + 1 < ktf; t += 2) {
+            loadv(t + 1, vn);
+            pv_tile(t, vb, std::false_type{});
+            loadv(min(t + 2, kt - 1), vb);
+            pv_tile(t + 1, vn, std::false_type{});
+        }
+        if (ktf & 1) {
+            loadv(kt - 1, vn);
+            pv_tile(ktf - 1, vb, std::false_type{});
+            if (kt > ktf) pv_tile(ktf, vn, std::true_type{});
+        } else if (kt > ktf) {
+            pv_tile(ktf, vb, std::true_type{});
+        }
     }
     PROFS(4);
     // D layout: lane (r = column, g), register e -> query 4 g + e
@@ -1393,7 +1553,9 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         const int LP = (L + 15) & ~15, SLD = LP + 4 < 36 ? 36 : LP + 4;   // (the region later holds the wave's [16][36] o_pt)
         const int tiles = LP >> 4;                               // 16-row query tiles
         // waves (query tiles) per workgroup: <= 8, and the score regions must fit the 160 KiB LDS next to the key points
-        const size_t fixed = ((size_t)LP * KPS + LP + (size_t)LP * VPS) * sizeof(float), per_wave = (size_t)16 * SLD * sizeof(float);
+        // the projection inside the score kernel (s_in): fp32 operands, every query tile of a sample in ONE workgroup, float4 rows
+        const bool pj = a->s_in != nullptr && !pj16;
+        const size_t fixed = ((size_t)LP * KPS + LP + (size_t)(pj ? pj_vp_floats(LP) : LP * VPS)) * sizeof(float), per_wave = (size_t)16 * SLD * sizeof(float);
         int wmax = (int)((160 * 1024 - fixed) / per_wave);
         wmax = wmax > WMAX ? WMAX : wmax;
         // query tiles that do not divide into 8-wave workgroups (128 < L < 256): workgroups of <= 4 waves -- at L = 144 three 3-wave
@@ -1414,8 +1576,6 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        // the projection inside the score kernel (s_in): fp32 operands, every query tile of a sample in ONE workgroup, float4 rows
-        const bool pj = a->s_in != nullptr && !pj16;
         if (pj16) {
             // every query tile of a sample in ONE workgroup; the score regions double as the staging area; k rows + transposed values behind
             if (tiles > WMAX || !a->proj_w_f16 || !a->proj_bias || !fuse) return PF_E_BADARG;
@@ -1433,7 +1593,8 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             PF_CHECK_LAUNCH();
             return 0;
         }
-        if (pj && (planes || nrb != 1 || (L & 3) != 0 || !a->proj_w_f16 || !a->proj_bias || !a->proj || a->ldp < OFF_KV + 2 * H * C)) return PF_E_BADARG;
+        // (att_vt: this form's scratch for the head's value planes, B x 8 x 2 x 128 x ceil32(L) f16 -- finite on entry, see the header)
+        if (pj && (planes || nrb != 1 || (L & 3) != 0 || !a->proj_w_f16 || !a->proj_bias || !a->proj || !a->att_vt || a->ldp < OFF_KV + 2 * H * C)) return PF_E_BADARG;
         if (pj) {
             static bool attr_pj = false;
             if (!attr_pj) {

@@ -470,6 +470,13 @@ class DenoiseEngine:
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
             self.att_vt = torch.zeros(B * 8 * 164 * L + 64, dtype=torch.float16, device=device)
+        # fp32 mode with the projection inside the score kernel: pf_ipa_attn_args.att_vt as that form's per-launch scratch -- per (sample,
+        # head) the values as hi | lo f16 operand fragments of the second product and the k rows as fp32 fragments of the first (1 KiB per
+        # key and head), written by the prologue and read back by the same workgroup through L2.  Zero-initialised: key columns beyond a
+        # sample's key end are never written and meet zero probabilities -- they must stay finite.
+        self.att_vt32 = None
+        if self.fused_proj and not self.att_planes:
+            self.att_vt32 = torch.zeros(B * 8 * 512 * ((L + 31) // 32 * 32), dtype=torch.float16, device=device)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         # 16-row groups whose final predictions are wanted (pf_node_tfmr_args.row_on of the LAST block's tail): all of them for the
         # stand-alone step; the sampler marks the groups that hold a generated residue (DeviceSampler.set_context)
@@ -682,6 +689,8 @@ class DenoiseEngine:
                     ia.att_qk, ia.att_vt = self.att_qk.data_ptr(), self.att_vt.data_ptr()
             if self.fused_proj:
                 ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.projp.w16"].data_ptr(), w[f"{b}.projp.b"].data_ptr()
+                if self.att_vt32 is not None:
+                    ia.att_vt = self.att_vt32.data_ptr()
             self._keep.append(ia)
             plan.append((lib.pf_ipa_attn_fwd, C.byref(ia), "pf_ipa_attn_fwd"))
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----

@@ -147,6 +147,9 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.fused_pair = int(fused_pair)
     if fused_proj is not None:
         ia.s_in, ia.proj_w_f16, ia.proj_bias = _p(fused_proj[0]), _p(fused_proj[1]), _p(fused_proj[2])
+        # the form's scratch for the head's value planes (hi | lo f16, transposed per (sample, head)): finite on entry
+        vt = torch.zeros(B * 8 * 512 * ((L + 31) // 32 * 32), dtype=torch.float16, device=d)
+        ia.att_vt = _p(vt)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
