@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 51
+#define PF_ABI_VERSION 52
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
@@ -377,6 +377,15 @@ typedef struct {
      * 4 t + g of a pair holds the features 32 t + 16 h + 4 g + e at bit 4 h + e (t < 6, g < 4, h < 2, e < 4).  pf_et_bwd_chain
      * (m1 / m2) gates with them instead of reading the 768-byte activations back. */
     unsigned char* dump_m1; unsigned char* dump_m2;
+    /* optional (32x32 kernel, fp32 pair tensor, L % 16 == 0; ABI 52): z_in / z_out in the kernel's FRAGMENT ORDER instead of
+     * [B,L,L,64] -- the pair tensor between two EdgeTransition launches is read by nobody else (the attention takes bias_out / dz_out),
+     * so the kernel may keep it in the order its lanes hold it: block ((b, 16 x 16 tile, wave w, 32-pair row pair) = 8 KiB) x piece k
+     * (1 KiB) x lane (16 bytes), lane (rl, jl, g) = g * 32 + rl * 16 + jl of pair (i, j) = (16 ib + 2 w + rl, 16 jb + jl), piece k =
+     * 4 mt + q holding channels 32 mt + 8 q + 4 g .. + 3.  Every load / store instruction of the pair tensor is then one contiguous
+     * KiB (as [.., 64] rows an instruction touched 32 rows, 32 bytes of each).  w_stream32 must then have been packed with the
+     * matching K order of the z operand (pepflowww_amd.engine.pack_et_stream32(..., z_frag=True)); pepflowww_amd.engine.z_to_frag /
+     * z_from_frag convert a tensor.  Not with tile_list-skipped layouts other than whole tiles (the list is per tile anyway). */
+    int z_in_frag, z_out_frag;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */

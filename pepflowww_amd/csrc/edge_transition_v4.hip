@@ -291,7 +291,12 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
             int ic = t2.i0 + RW * wave + 2 * t + rl;
             ic = ic < L ? ic : L - 1;
             const size_t pair = (size_t)(t2.b * L + ic) * L + jc;
-            if constexpr (ZI) {
+            if (!ZI && a.z_in_frag) {                           // (uniform) fragment order: piece k = 2 ks + half of block (tile, wave, t)
+                const int tix = (t2.b * nib + t2.i0 / TI) * njb + t2.j0 / TJ;
+                const float4* src = reinterpret_cast<const float4*>(zg + ((size_t)(tix * NW + wave) * NT + t) * 8192) + lane;
+#pragma unroll
+                for (int ks = ks0; ks < ks1; ++ks) { zr.f[t][ks][0] = src[128 * ks]; zr.f[t][ks][1] = src[128 * ks + 64]; }
+            } else if constexpr (ZI) {
                 const half8* src = reinterpret_cast<const half8*>(zg + pair * 128) + g;
 #pragma unroll
                 for (int ks = ks0; ks < ks1; ++ks) zr.h[t][ks] = src[2 * ks];
@@ -566,6 +571,10 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
                             half4 h;
                             h[0] = (_Float16)o[mt][4 * b]; h[1] = (_Float16)o[mt][4 * b + 1]; h[2] = (_Float16)o[mt][4 * b + 2]; h[3] = (_Float16)o[mt][4 * b + 3];
                             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(a.z_out) + pidx[t] * 64 + f0) = h;
+                        } else if (a.z_out_frag) {             // (uniform) piece 4 mt + b of block (tile, wave, t): one contiguous KiB per store
+                            const int tix = (tl.b * nib + tl.i0 / TI) * njb + tl.j0 / TJ;
+                            float* d = a.z_out + ((size_t)(tix * NW + wave) * NT + t) * 2048 + (4 * mt + b) * 256 + lane_o * 4;
+                            *reinterpret_cast<float4*>(d) = make_float4(o[mt][4 * b], o[mt][4 * b + 1], o[mt][4 * b + 2], o[mt][4 * b + 3]);
                         } else {
                             *reinterpret_cast<float4*>(a.z_out + pidx[t] * 64 + f0) = make_float4(o[mt][4 * b], o[mt][4 * b + 1], o[mt][4 * b + 2], o[mt][4 * b + 3]);
                         }
@@ -659,6 +668,7 @@ int pf_edge_transition_v4_launch(const pf_edge_transition_args* a, hipStream_t s
     if (a->dz_out_f16 && !(a->dz_out && a->single_pass)) return PF_E_BADARG;
     if (a->dump_h1 || a->dump_h2 || a->dump_y) return PF_E_BADARG;                 // the training dumps live in the v3 kernel
     if ((a->z_in_f16 || a->z_out_f16) && !a->single_pass) return PF_E_BADARG;
+    if ((a->z_in_frag || a->z_out_frag) && (a->single_pass || (a->L & 15) != 0)) return PF_E_BADARG;   // fragment order: fp32 pair tensor, whole tiles
     const int ncu = pf_cu_count();
     const bool dz = a->dz_out != nullptr;
     if (a->single_pass) {

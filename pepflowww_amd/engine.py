@@ -172,9 +172,46 @@ def pack_et_stream(w1z, w2, wf):
     return _pack_stream_fast(16, w1z, w2, wf)
 
 
-def pack_et_stream32(w1z, w2, wf):
-    """The 32x32x16 kernel's stream (layout: _pack_et_stream32_ref), packed with one cached gather."""
-    return _pack_stream_fast(32, w1z, w2, wf)
+def _z_frag_perm(device):
+    """K order of the z operand when the pair tensor is kept in the 32x32 kernel's fragment order (pf_edge_transition_args.z_in_frag):
+    slot 16 ks + 8 g + j of a K-step holds channel 16 ks + 8 (j >> 2) + 4 g + (j & 3) -- the channels lane (pair, g) itself wrote."""
+    s = torch.arange(64, device=device)
+    ks, g, j = s >> 4, (s >> 3) & 1, s & 7
+    return 16 * ks + 8 * (j >> 2) + 4 * g + (j & 3)
+
+
+def pack_et_stream32(w1z, w2, wf, z_frag=False):
+    """The 32x32x16 kernel's stream (layout: _pack_et_stream32_ref), packed with one cached gather.  z_frag: the z operand's K
+    order of a fragment-ordered pair tensor (columns of W1z and of Wf[:, :64] permuted; layout only)."""
+    nat = _pack_stream_fast(32, w1z, w2, wf)
+    if not z_frag:
+        return nat
+    # entries 0..31 are the products with the z operand (Wf[:, :64] and W1z): their K columns in the fragment order's K order; the
+    # other 96 entries (W2, and ALL of Wf acting on h2) are untouched
+    perm = _z_frag_perm(w1z.device)
+    zp = _pack_stream_fast(32, w1z[:, perm].contiguous(), w2, torch.cat([wf[:, :64][:, perm], wf[:, 64:]], 1).contiguous())
+    return torch.cat([zp[:32 * 1024], nat[32 * 1024:]]).contiguous()
+
+
+def z_to_frag(z, out=None):
+    """[B,L,L,64] (L % 16 == 0) -> the 32x32 EdgeTransition kernel's fragment order (pf_edge_transition_args.z_in_frag): block (b, 16 x 16
+    tile (ib, jb), wave w) of 8 KiB = piece k = 4 mt + q (1 KiB) x lane g * 32 + rl * 16 + jl (16 bytes) = channels 32 mt + 8 q + 4 g ..
+    + 3 of pair (16 ib + 2 w + rl, 16 jb + jl).  A pure permutation (layout only)."""
+    B, L = z.shape[0], z.shape[1]
+    assert L % 16 == 0 and z.shape[2] == L and z.shape[3] == 64
+    v = z.reshape(B, L // 16, 8, 2, L // 16, 16, 2, 4, 2, 4)       # b, ib, w, rl, jb, jl, mt, q, g, e
+    v = v.permute(0, 1, 4, 2, 6, 7, 8, 3, 5, 9)                    # b, ib, jb, w, mt, q, g, rl, jl, e
+    if out is None:
+        return v.contiguous().reshape(B, L, L, 64)
+    out.view(v.shape).copy_(v)
+    return out
+
+
+def z_from_frag(zf):
+    """Inverse of z_to_frag."""
+    B, L = zf.shape[0], zf.shape[1]
+    v = zf.reshape(B, L // 16, L // 16, 8, 2, 4, 2, 2, 16, 4)      # b, ib, jb, w, mt, q, g, rl, jl, e
+    return v.permute(0, 1, 3, 7, 2, 8, 4, 5, 6, 9).contiguous().reshape(B, L, L, 64)
 
 
 def pack_bias_frags(w_b, w_dz=None):
@@ -372,6 +409,7 @@ class PackedWeights:
                 t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.stream32"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf)
+                t[f"{b}.et.stream32f"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf, z_frag=True)
                 t[f"{b}.et.wbfrags32"] = pack_bias_frags32(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
@@ -445,6 +483,13 @@ class DenoiseEngine:
         # (csrc/edge_transition_v4.hip) 379 vs 402 us; f16 mode: the 16x16 kernel (v3) 180 vs 195 us.  PF_ET_V4=0 / 1 forces one (A/B runs).
         self.et_v4 = {"0": False, "1": True}.get(os.environ.get("PF_ET_V4", ""), precision == "fp32")
         self.et_rows = int(self.lib.pf_edge_transition_v4_tile_rows()) if self.et_v4 else int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
+        # the pair tensor between two EdgeTransition launches in the 32x32 kernel's FRAGMENT ORDER (pf_edge_transition_args.z_in_frag /
+        # z_out_frag): nobody else reads it (the attention takes the pair bias / pair values the kernel emits), and every load / store
+        # instruction of it becomes one contiguous KiB (as [.., 64] rows: 32 rows, 32 bytes of each).  The caller's edge embedding is
+        # permuted once per call (bind_context).  fp32 pair tensor, whole 16 x 16 tiles.  PF_ET_ZFRAG=0 / 1 forces it (A/B runs).
+        self.z_frag = (self.et_v4 and not self.z16 and L % 16 == 0 and self.pair_dz is not None and
+                       {"0": False, "1": True}.get(os.environ.get("PF_ET_ZFRAG", ""), True))
+        self.edge_frag = e(B, L, L, 64) if self.z_frag else None
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
         self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
         self.et_ntiles = e(1, dt=torch.int32)
@@ -586,6 +631,8 @@ class DenoiseEngine:
         self.edge_embed = ee
         if self.z16:                            # one conversion per call (the reference re-reads the fp32 tensor in every step)
             self.edge16.copy_(ee.reshape(B, L, L, 64))
+        if self.z_frag:                         # one permutation per call: block 0's EdgeTransition input in fragment order
+            z_to_frag(ee.reshape(B, L, L, 64), out=self.edge_frag)
         _capi.check(self.lib.pf_pair_bias_fwd(ee.data_ptr(), self.w["0.linear_b.w"].data_ptr(), self.w["0.linear_b.b"].data_ptr(),
                                               self.pair_bias0.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
         if self.pair_dz0 is not None:           # block 0's pair values W_dz edge_embed (no bias), once per call like its pair bias
@@ -761,11 +808,15 @@ class DenoiseEngine:
                 # no EdgeTransition after it (ga.py:115-118) -- not stored (256 B per pair; PF_ET_LAST_STORE=1 keeps the store, A/B runs)
                 drop_z = (b == N_BLOCKS - 2 and self.pair_dz is not None and os.environ.get("PF_ET_LAST_STORE") != "1")
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), (None if drop_z else self.zbuf.data_ptr()), self.pre.data_ptr()
+                if self.z_frag:
+                    et.z_in_frag = et.z_out_frag = 1
+                    if b == 0:
+                        et.z_in = self.edge_frag.data_ptr()
                 et.b2, et.ln_g, et.ln_b = w[f"{b}.et.b2"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
                 et.w_stream = w[f"{b}.et.stream"].data_ptr()
                 et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
                 if self.et_v4:
-                    et.w_stream32, et.wb_frags32 = w[f"{b}.et.stream32"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()
+                    et.w_stream32, et.wb_frags32 = w[f"{b}.et.stream32f" if self.z_frag else f"{b}.et.stream32"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()
                 et.bb = w[f"{b + 1}.linear_b.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")

@@ -156,7 +156,7 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
 
 
 def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=False, persistent=True, next_bias=None, tile_list=None, out=None,
-                    next_dz=None, single_pass=False, dz_f16=False):
+                    next_dz=None, single_pass=False, dz_f16=False, z_frag=False):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
     persistent=True: the 16x16x32 LDS-ring kernel (w_stream, csrc/edge_transition_v3.hip); "v4": the 32x32 kernel
     (w_stream32 / wb_frags32, csrc/edge_transition_v4.hip).
@@ -173,8 +173,12 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
     a.w_stream = _p(ws)
     if persistent == "v4":
         from pepflowww_amd.engine import pack_et_stream32, pack_bias_frags32
-        ws32 = pack_et_stream32(w1[:, :64], w2, wf)
+        ws32 = pack_et_stream32(w1[:, :64], w2, wf, z_frag=z_frag)
         a.w_stream32 = _p(ws32)
+        if z_frag:     # pair tensor in the kernel's fragment order on both sides (pf_edge_transition_args.z_in_frag / z_out_frag)
+            from pepflowww_amd.engine import z_to_frag
+            zf = z_to_frag(z.reshape(B, L, L, 64))
+            a.z_in, a.z_in_frag, a.z_out_frag = _p(zf), 1, 1
         if next_bias is not None:
             wbf32 = pack_bias_frags32(next_bias[0], next_dz if next_dz is not None else torch.zeros(16, 64, device=z.device))
             a.wb_frags32 = _p(wbf32)
@@ -191,6 +195,9 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
         a.tile_list, a.n_tiles = _p(tile_list[0]), _p(tile_list[1])
     _capi.check(lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()), "pf_edge_transition_fwd")
     sync()
+    if z_frag:
+        from pepflowww_amd.engine import z_from_frag
+        out = z_from_frag(out.reshape(B, L, L, 64)).reshape(out.shape)
     if next_dz is not None:
         return out, bias, dz
     return (out, bias) if next_bias is not None else out

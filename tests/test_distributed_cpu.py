@@ -11,6 +11,16 @@ from pepflowww_amd import distributed as D
 from pepflowww_amd import synth
 
 
+def _by_value(d):
+    """dict of CPU tensors -> dict of numpy arrays.  Tensors put on an mp.Queue travel as shared-memory handles, and a worker that
+    exits before the parent has read them makes the parent's get() fail (EOFError, seen once in ~10 runs); arrays are pickled by value."""
+    return {k: (v.detach().cpu().numpy().copy() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def _t(x):
+    return torch.from_numpy(x) if x is not None and not torch.is_tensor(x) else x
+
+
 def test_shard_bounds_cover_everything():
     for total in (1, 7, 16, 512):
         for world in (1, 2, 3, 8):
@@ -94,7 +104,7 @@ def _grad_worker(rank, world, port, q):
     for i, p in enumerate(ps[:2]):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
     n = allreduce_gradients(ps, dist)                     # the third parameter has no gradient and is skipped
-    q.put((rank, n, [p.grad.clone() if p.grad is not None else None for p in ps]))
+    q.put((rank, n, [p.grad.numpy().copy() if p.grad is not None else None for p in ps]))      # (by value: see _by_value)
     dist.destroy_process_group()
 
 
@@ -111,6 +121,7 @@ def test_gradient_allreduce_two_ranks():
     for p in procs:
         p.join(60)
     for rank, n, grads in res:
+        grads = [_t(g_) for g_ in grads]
         assert n == 15 + 7
         assert torch.allclose(grads[0], torch.full((3, 5), 1.5)) and torch.allclose(grads[1], torch.full((7,), 3.0))
         assert grads[2] is None
@@ -128,7 +139,7 @@ def _arena_worker(rank, world, port, q):
     b += 2.0 * (rank + 1)
     grads = ar.adopt({"a": a, "b": b, "c": torch.full((2, 2), 10.0 * (rank + 1))})      # "c" was produced outside
     n = allreduce_flat(ar.flat(), dist)
-    q.put((rank, n, {k: v.clone() for k, v in grads.items()}, ar.owns(grads["c"])))
+    q.put((rank, n, _by_value(grads), ar.owns(grads["c"])))
     dist.destroy_process_group()
 
 
@@ -145,6 +156,7 @@ def test_gradient_arena_allreduce_two_ranks():
     for p in procs:
         p.join(60)
     for rank, n, grads, owned in res:
+        grads = {k: _t(v) for k, v in grads.items()}
         assert owned and n == 16 + 8 + 4                  # 15 -> 16, 7 -> 8 (alignment), 4
         assert torch.allclose(grads["a"], torch.full((3, 5), 1.5)) and torch.allclose(grads["b"], torch.full((7,), 3.0))
         assert torch.allclose(grads["c"], torch.full((2, 2), 15.0))
@@ -190,7 +202,7 @@ def _sharded_worker(rank, world, port, total, with_noise, q):
         batch["chain_id"] = [tuple("AB"[(i + l) % 2] for i in range(total)) for l in range(L)]
         noise = {k: v for k, v in synth.make_noise(total, L, 2, seed=5).items() if k != "expo"} if with_noise else None
         out = D.sample_sharded(_StubModel(), batch, num_steps=3, noise=noise, seed=77)
-        q.put((rank, {k: v.clone() for k, v in out.items()}))
+        q.put((rank, _by_value(out)))
     finally:
         dist.destroy_process_group()
 
@@ -214,6 +226,7 @@ def test_sample_sharded_gloo_world2(total, with_noise):
     noise = {k: v for k, v in synth.make_noise(total, L, 2, seed=5).items() if k != "expo"} if with_noise else D.seeded_noise(0, total, L, 77)
     ref = D.unpack_state(D._final_state_of(_StubSampler(batch, 3, noise, 0)))
     for rank, out in res:
+        out = {k: _t(v) for k, v in out.items()}
         for k in ref:
             assert out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]), (rank, k)
     if not with_noise and total > 1:                       # distinct samples draw distinct noise
@@ -278,7 +291,7 @@ def _fresh_seed_worker(rank, world, port, q):
                 raised = True
         finally:
             dist.all_gather_into_tensor, dist.all_reduce = real_ag, real_ar
-        q.put((rank, m.seeds, a["rotmats"].clone(), b["rotmats"].clone(), (calls[:n_known], calls_none, raised), tuple(out["trans"].shape)))
+        q.put((rank, m.seeds, a["rotmats"].numpy().copy(), b["rotmats"].numpy().copy(), (calls[:n_known], calls_none, raised), tuple(out["trans"].shape)))
     finally:
         dist.destroy_process_group()
 
@@ -295,6 +308,7 @@ def test_default_seed_is_fresh_per_call_and_shared_by_the_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     (r0, s0, a0, b0, c0, sh0), (r1, s1, a1, b1, c1, sh1) = res
+    a0, b0, a1, b1 = _t(a0), _t(b0), _t(a1), _t(b1)
     assert s0 == s1 and len(s0) == 2 and s0[0] != s0[1], (s0, s1)        # same seed on both ranks, a new one per call
     assert torch.equal(a0, a1) and torch.equal(b0, b1) and not torch.equal(a0, b0)
     for c in (c0, c1):

@@ -203,3 +203,39 @@ def test_distcoef_backward_with_extreme_coefficients_and_near_zero_distances():
     err = (got - want).abs()
     bound = 1e-4 * want.abs() + 3e-7 * slack + 1e-30
     assert (err <= bound).all(), (float((err / bound).max()), float(err.max()), float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,L,masked", [(2, 64, False), (3, 48, True), (1, 128, False)])
+def test_edge_transition_with_the_pair_tensor_in_fragment_order(seeded_sd, B, L, masked):
+    """pf_edge_transition_args.z_in_frag / z_out_frag (32x32 kernel, ABI 52): the pair tensor on both sides in the order the kernel's
+    lanes hold it (engine.z_to_frag / z_from_frag, weights packed with the matching K order of the z operand).  Same values as the
+    [B,L,L,64] form up to the summation order of the permuted K index (1e-6, max-normalised), the emitted pair bias / pair values
+    likewise, and equal to the oracle's EdgeTransition (ipa_pytorch.py:233-248) to 1e-4; refused for the f16 mode and for L % 16 != 0."""
+    from pepflowww_amd.engine import z_to_frag, z_from_frag
+    g = torch.Generator().manual_seed(900 + L)
+    s, z = torch.randn(B, L, 128, generator=g), torch.randn(B, L, L, 64, generator=g)
+    assert torch.equal(z_from_frag(z_to_frag(z)), z)
+    mask = torch.ones(B, L)
+    if masked:
+        mask[0, L - 11:] = 0
+        mask[1, 5] = 0
+    pfx, nxt = "ga_encoder.trunk.edge_transition_2.", "ga_encoder.trunk.ipa_3."
+    gq = lambda k: seeded_sd[pfx + k]
+    n64 = G.linear(cu(s.reshape(B * L, 128)), cu(gq("initial_embed.weight")), cu(gq("initial_embed.bias")))
+    w1, b1, wf, bf = gq("trunk.0.weight"), gq("trunk.0.bias"), gq("final_layer.weight"), gq("final_layer.bias")
+    pre = G.linear(n64, cu(torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()),
+                   cu(torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0)))
+    nb = (cu(seeded_sd[nxt + "linear_b.weight"]), cu(seeded_sd[nxt + "linear_b.bias"]))
+
+    def run(frag, L_=L, single_pass=False):
+        return G.edge_transition(cu(z.reshape(-1, 64)), pre, cu(w1), cu(gq("trunk.2.weight")), cu(gq("trunk.2.bias")), cu(wf),
+                                 cu(gq("layer_norm.weight")), cu(gq("layer_norm.bias")), cu(mask.reshape(-1)), B, L_, persistent="v4",
+                                 next_bias=nb, next_dz=cu(seeded_sd[nxt + "down_z.weight"]), z_frag=frag, single_pass=single_pass)
+    (o0, b0, d0), (o1, b1_, d1) = run(False), run(True)
+    for a_, b_, what in ((o1, o0, "z'"), (b1_, b0, "pair bias"), (d1, d0, "pair values")):
+        G.assert_close(a_, b_, 1e-6, f"fragment order vs [B,L,L,64]: {what}")
+    em = (mask[:, None, :] * mask[:, :, None])[..., None]                        # edge mask, ga.py:118
+    ref = O.edge_transition(seeded_sd, pfx[:-1], s, z) * em
+    G.assert_close(o1.view(B, L, L, 64), ref, REL, "fragment-ordered EdgeTransition vs oracle")
+    with pytest.raises(Exception):
+        run(True, single_pass=True)

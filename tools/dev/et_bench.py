@@ -30,6 +30,8 @@ if form == "v4":
 a.b2, a.ln_g, a.ln_b, a.mask, a.B, a.L = keep[4].data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(), keep[7].data_ptr(), B, L
 a.bias_out, a.bb, a.dz_out, a.dz_out_f16 = keep[8].data_ptr(), bb.data_ptr(), keep[9].data_ptr(), int(sp)
 a.single_pass, a.z_in_f16, a.z_out_f16 = int(sp), int(sp), int(sp)
+if os.environ.get("PF_ET_FRAG") == "1":      # pair tensor in the kernel's fragment order (timing only here: random data)
+    a.z_in_frag = a.z_out_frag = 1
 rc = lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()); assert rc == 0, rc
 torch.cuda.synchronize()
 gr = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
@@ -40,7 +42,7 @@ gr.replay(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): gr.replay()
 torch.cuda.synchronize()
 us = (time.perf_counter() - t0) / 50 * 1e6
-print(f'{form} {prec} NT={os.environ.get("PF_ET4_NT", "default")} {os.path.basename(sys.argv[3]) if len(sys.argv) > 3 else ""}: {us:.1f} us per launch; finite={bool(torch.isfinite(zout.float()).all())}')
+print(f'{form} {prec} frag={os.environ.get("PF_ET_FRAG", "0")} {os.path.basename(sys.argv[3]) if len(sys.argv) > 3 else ""}: {us:.1f} us per launch; finite={bool(torch.isfinite(zout.float()).all())}')
 
 raw = C.CDLL(_capi.LIB_PATH)
 if hasattr(raw, "pf_debug_prof_et4"):
