@@ -233,7 +233,12 @@ struct PjW { half8 h[4], l[4]; };
 // (LDS-DMA, two 24 KiB buffers, the next chunk in flight under the current chunk's MFMAs) and every wave reads its operands from
 // there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
 // 64 B / clk L1 path and the prologue cost what the projection launch it replaced had cost.
-__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, float* KP,
+// role: 0 = this wave projects all 31 tiles of its rows; with HELPER waves (L <= 64: twice as many waves as query tiles, the second half
+// leaves after the prologue) 1 = the query wave takes the q and query-point tiles (10), 2 = its helper the k | v and key / value-point
+// tiles (21) of the same rows -- those results go to the scratch / the LDS tables anyway, nothing has to be handed over.  tile = the
+// 16-row tile of the sample this wave projects (its own index as a query wave, its partner's as a helper).
+__device__ __forceinline__ constexpr bool pj_q_tile(int idx) { return idx < 8 || idx == 24 || idx == 25; }
+__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, int role, int tile, float* KP,
                                           _Float16* VPT /* [2][48][VTL] value points, hi | lo */, int VTL, _Float16* VTH /* this head's [8 tiles][VTG / 32 steps][hi | lo][64 lanes][8] */, int VTG,
                                           unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
                                           float* PB /* [PJ_TILES * 16] the head's bias, staged here */,
@@ -291,9 +296,9 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
 #pragma unroll
     for (int c = 0; c < PJ_NB - 1; ++c)
         if (c < PJ_NCH) issue(c);
-    // k rows: fragment order too -- block (key tile = this wave, 16-channel step s) = the 64 lanes' float4 (key r, channels 16 s + 4 g ..)
+    // k rows: fragment order too -- block (key tile `tile`, 16-channel step s) = the 64 lanes' float4 (key r, channels 16 s + 4 g ..)
     // as the first product's loadk reads them: one contiguous KiB per store / load instruction, behind the head's value blocks
-    float* kfrag = reinterpret_cast<float*>(VTH + (size_t)8 * (VTG >> 5) * 1024) + ((size_t)wave * 8) * 256 + lane * 4;
+    float* kfrag = reinterpret_cast<float*>(VTH + (size_t)8 * (VTG >> 5) * 1024) + ((size_t)tile * 8) * 256 + lane * 4;
     auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ_CHUNK_B + tl * 8192 + lane * 16;
 #pragma unroll
@@ -320,12 +325,14 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
         if (wave_on) {
             PjW wa, wb;
-            ldfrag(c, 0, wa);
+            if (role == 0) ldfrag(c, 0, wa);
             cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
                 constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
                 if constexpr (idx < PJ_TILES) {
+                  if (role == 0 || (role == 1) == pj_q_tile(idx)) {          // (wave-uniform)
                     PjW& w = (tl & 1) ? wb : wa;
-                    if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    if (role != 0) ldfrag(c, tl, w);                        // (a tile here and there: requested at its use)
+                    else if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
                     constexpr bool VTILE = idx >= 16 && idx < 24;
                     f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -354,15 +361,15 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                         qf[idx] = make_float4(v[0], v[1], v[2], v[3]);
                     } else if constexpr (idx < 16) {        // k tiles 0..7 of the head: columns 16 (idx - 8) + 4 g of its 256
                         *reinterpret_cast<float4*>(kfrag + (idx - 8) * 256) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if constexpr (VTILE) {           // channel 16 (idx - 16) + r of keys 16 wave + 4 g + e -> hi | lo plane, 8 bytes each
+                    } else if constexpr (VTILE) {           // channel 16 (idx - 16) + r of keys 16 tile + 4 g + e -> hi | lo plane, 8 bytes each
                         half4 hi, lo;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
                         const int f = 16 * (idx - 16) + r;
                         // fragment order: block (tile nt, step, plane) = the 64 reader lanes' 16 bytes each; this lane's four keys are
-                        // half (wave & 1) of reader lane (n, g)'s eight slots
+                        // half (tile & 1) of reader lane (n, g)'s eight slots
                         const int row = pj_vt_row(f), nst = VTG >> 5;
-                        _Float16* d = VTH + ((size_t)((row >> 4) * nst + (wave >> 1)) * 2 * 64 + 16 * g + (row & 15)) * 8 + 4 * (wave & 1);
+                        _Float16* d = VTH + ((size_t)((row >> 4) * nst + (tile >> 1)) * 2 * 64 + 16 * g + (row & 15)) * 8 + 4 * (tile & 1);
                         *reinterpret_cast<half4*>(d) = hi;
                         *reinterpret_cast<half4*>(d + 512) = lo;
                     } else {                                // a point (x, y, z, 0) of this row: global frame, as pf_linear_fwd's epilogue forms it
@@ -391,6 +398,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                             }
                         }
                     }
+                  }
                 }
             });
         }
@@ -402,6 +410,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         // hand-off through `proj` no longer leans on that ordering rule
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // + wave-private LDS hand-off of the query points
         __builtin_amdgcn_wave_barrier();
+        if (role == 2) return;                                            // (a helper: no queries of its own)
 #pragma unroll
         for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);
     }
@@ -562,7 +571,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int h = (lid / nrb) % H;
     const int b = lid / (nrb * H);
     const size_t rowb = (size_t)b * L;
-    const int i0 = rb * rows_per_block + wave * 16;
+    // PROJ with helper waves (blockDim = 2 x the query tiles, L <= 64): wave ntq + w helps query wave w through the prologue and leaves
+    const int ntq = rows_per_block >> 4;
+    const bool helper = PROJ && wave >= ntq;
+    const int i0 = rb * rows_per_block + (helper ? wave - ntq : wave) * 16;
     // Le: keys / query rows from here on are masked (pf_ipa_attn_args.key_end; L without it): nothing beyond is read or written
     const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
     const int kt = (Le + 15) >> 4, ktf = Le >> 4;  // key tiles, full key tiles
@@ -611,14 +623,15 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         // rows in this workgroup: the launcher guarantees nrb == 1.)
         for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + min(j, L - 1)] : 0.f;
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
-        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + wave * 16 * 24;   //  sizes the allocation for staging + query points)
-        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (blockDim.x >> 6) * 16 * 24;
+        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (helper ? 0 : wave) * 16 * 24;   //  sizes the allocation for staging + query points)
+        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + ntq * 16 * 24;
+        const int role = (int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0;
         const int VTG = (L + 31) & ~31;                // key stride of the value planes (pf_ipa_attn_args.att_vt as this launch's scratch)
         _Float16* VTH = reinterpret_cast<_Float16*>(const_cast<void*>(a.att_vt)) + ((size_t)b * H + h) * 512 * VTG;   // values 256 VTG | k rows 256 VTG (as f16 counts)
-        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW, PB, qf, qp4, lane,
-                  wave, (int)(blockDim.x >> 6));
+        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
+                  PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
-        if (!wave_on) return;
+        if (!wave_on || helper) return;
         loadk(0, kf);
     } else {
     // ---- key points / key mask / value points of the head -> LDS (all waves) ----
@@ -1606,8 +1619,11 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
             const size_t ldsp = lds > need ? lds : need;
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
-            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
-            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            // L <= 64: as many helper waves as query waves for the prologue (proj_head roles; PF_PROJ_HELPERS=0 turns them off for A/B runs)
+            static const bool no_helpers = getenv("PF_PROJ_HELPERS") && atoi(getenv("PF_PROJ_HELPERS")) == 0;
+            const int nwv = (wpb <= 4 && !no_helpers) ? 2 * wpb : wpb;
+            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
