@@ -19,7 +19,6 @@ extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_strea
     if (!a || !a->z_in || (!a->z_out && !a->bias_out) || !a->pre || !a->b2 || !a->ln_g || !a->ln_b || !a->mask || a->B <= 0 || a->L <= 0)
         return PF_E_BADARG;
     if (a->w_stream32 && !(a->dump_h1 || a->dump_h2 || a->dump_y)) return pf_edge_transition_v4_launch(a, (hipStream_t)stream);
-    if (a->z_in_frag || a->z_out_frag) return PF_E_BADARG;       // the fragment-ordered pair tensor is the 32x32 kernel's
     if (a->w_stream) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);
     return PF_E_BADARG;                                          // a weight stream is required (w1z_f16 / w2_f16 / wf_f16 alone: no kernel)
 }

@@ -298,7 +298,9 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         // (lane & 7) ^ (pp & 7)
         unsigned zoff[4];
         auto prep_z = [&](const Tile& tl) {
-            if constexpr (ZI) {
+            if (ZI && a.z_in_frag) {                              // (uniform) fragment order: a row's 2 KiB are its two DMA pieces as they are
+                zoff[0] = zoff[1] = (unsigned)(lane * 16);
+            } else if constexpr (ZI) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int pp = m * 8 + (lane >> 3);
@@ -321,7 +323,12 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             for (int row = row0; row < row1; ++row) {
                 int i = tl.i0 + row;
                 i = i < L ? i : L - 1;
-                if constexpr (ZI) {
+                if (ZI && a.z_in_frag) {
+                    const int tix = (tl.b * nib + tl.i0 / TI) * njb + tl.j0 / TJ;
+                    const unsigned char* base = zg + ((size_t)tix * TI + row) * 2048;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) GLDS16U(base + m * 1024, zoff[m], OFF_Z + (2 * row + m) * 1024);
+                } else if constexpr (ZI) {
                     const unsigned char* base = zg + ((size_t)(tl.b * L + i) * L + tl.j0) * 128;
 #pragma unroll
                     for (int m = 0; m < 2; ++m) GLDS16U(base, zoff[m], OFF_Z + (2 * row + m) * 1024);
@@ -449,7 +456,10 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         if constexpr (ZI) {       // f16 rows: the 16-byte chunk IS the MFMA operand
-                            zh[p][s] = *reinterpret_cast<const half8*>(smem + OFF_Z + (NP * wave + p) * 2048 + r * 128 + 16 * ((4 * s + g) ^ (r & 7)));
+                            if (a.z_in_frag)      // (uniform) fragment order: piece s of the row, this lane's own 16 bytes
+                                zh[p][s] = *reinterpret_cast<const half8*>(smem + OFF_Z + (NP * wave + p) * 2048 + s * 1024 + lane * 16);
+                            else
+                                zh[p][s] = *reinterpret_cast<const half8*>(smem + OFF_Z + (NP * wave + p) * 2048 + r * 128 + 16 * ((4 * s + g) ^ (r & 7)));
                             zl[p][s] = zh[p][s];
                         } else {
                             const float4 q0 = *reinterpret_cast<const float4*>(zs + p * 4096 + 16 * ((8 * s + 2 * g) ^ r));
@@ -617,7 +627,17 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk[p];
             }
             if (valid[p] && a.z_out) {                           // (z_out = NULL: the last EdgeTransition of a step, see the v4 kernel)
-                if constexpr (ZO) {
+                if (ZO && a.z_out_frag) {                        // (uniform) fragment order: piece s = [o4[2 s] | o4[2 s + 1]] of every lane, one contiguous KiB
+                    const int tix = (tl.b * nib + tl.i0 / TI) * njb + tl.j0 / TJ;
+                    _Float16* zo = reinterpret_cast<_Float16*>(a.z_out) + ((size_t)tix * TI + NP * wave + p) * 1024 + lane * 8;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        half8 h;
+                        h[0] = (_Float16)o4[2 * s2].x; h[1] = (_Float16)o4[2 * s2].y; h[2] = (_Float16)o4[2 * s2].z; h[3] = (_Float16)o4[2 * s2].w;
+                        h[4] = (_Float16)o4[2 * s2 + 1].x; h[5] = (_Float16)o4[2 * s2 + 1].y; h[6] = (_Float16)o4[2 * s2 + 1].z; h[7] = (_Float16)o4[2 * s2 + 1].w;
+                        *reinterpret_cast<half8*>(zo + s2 * 512) = h;
+                    }
+                } else if constexpr (ZO) {
                     _Float16* zo = reinterpret_cast<_Float16*>(a.z_out) + pidx[p] * 64 + 4 * g;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -736,6 +756,9 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
         return et3_launch<true, false, 1>(a, stream, ncu);
     }
     if ((a->z_in_f16 || a->z_out_f16) && !a->single_pass) return PF_E_BADARG;   // f16 pair tensor: f16 mode only
+    // fragment-ordered pair tensor here: the f16 tensor of the f16 mode, whole 16 x 16 tiles (two rows per wave)
+    if ((a->z_in_frag && !a->z_in_f16) || (a->z_out_frag && !a->z_out_f16) || ((a->z_in_frag || a->z_out_frag) && ((a->L & 15) != 0 || PF_ET_SP_NP != 2)))
+        return PF_E_BADARG;
     const bool dz = a->dz_out != nullptr;
     if (a->single_pass) {
         if (a->z_in_f16 && a->z_out_f16)

@@ -167,9 +167,44 @@ def _pack_stream_fast(which, w1z, w2, wf):
     return torch.stack([hi, lo], 1).reshape(-1).contiguous()
 
 
-def pack_et_stream(w1z, w2, wf):
-    """The 16x16x32 kernel's stream (layout: _pack_et_stream_ref), packed with one cached gather."""
-    return _pack_stream_fast(16, w1z, w2, wf)
+def _z_frag_perm16(device):
+    """K order of the z operand of the 16x16x32 kernel with a fragment-ordered f16 pair tensor: slot 32 s + 8 g + j of a K-step holds
+    channel 32 s + 16 (j >> 2) + 4 g + (j & 3) (the order of its register-resident activations)."""
+    c = torch.arange(64, device=device)
+    st, g, j = c >> 5, (c >> 3) & 3, c & 7
+    return 32 * st + 16 * (j >> 2) + 4 * g + (j & 3)
+
+
+def pack_et_stream(w1z, w2, wf, z_frag=False):
+    """The 16x16x32 kernel's stream (layout: _pack_et_stream_ref), packed with one cached gather.  z_frag: the K order of the z
+    operand of a fragment-ordered f16 pair tensor in the first 32 entries (W1z, Wf[:, :64]); layout only."""
+    nat = _pack_stream_fast(16, w1z, w2, wf)
+    if not z_frag:
+        return nat
+    perm = _z_frag_perm16(w1z.device)
+    zp = _pack_stream_fast(16, w1z[:, perm].contiguous(), w2, torch.cat([wf[:, :64][:, perm], wf[:, 64:]], 1).contiguous())
+    return torch.cat([zp[:32 * 1024], nat[32 * 1024:]]).contiguous()
+
+
+def z16_to_frag(z, out=None):
+    """[B,L,L,64] f16 (L % 16 == 0) -> the 16x16x32 EdgeTransition kernel's fragment order (f16 mode, pf_edge_transition_args.z_in_frag):
+    per (16 x 16 tile, row i) 2 KiB = piece s (1 KiB) x lane g * 16 + r (16 bytes) = channels 32 s + 4 g .. + 3 | 32 s + 16 + 4 g .. + 3
+    of pair (i, 16 jb + r).  A pure permutation (layout only)."""
+    B, L = z.shape[0], z.shape[1]
+    assert L % 16 == 0 and z.shape[2] == L and z.shape[3] == 64
+    v = z.reshape(B, L // 16, 16, L // 16, 16, 2, 2, 4, 4)          # b, ib, row, jb, r, s, t2, g, e
+    v = v.permute(0, 1, 3, 2, 5, 7, 4, 6, 8)                        # b, ib, jb, row, s, g, r, t2, e
+    if out is None:
+        return v.contiguous().reshape(B, L, L, 64)
+    out.view(v.shape).copy_(v)
+    return out
+
+
+def z16_from_frag(zf):
+    """Inverse of z16_to_frag."""
+    B, L = zf.shape[0], zf.shape[1]
+    v = zf.reshape(B, L // 16, L // 16, 16, 2, 4, 16, 2, 4)         # b, ib, jb, row, s, g, r, t2, e
+    return v.permute(0, 1, 3, 2, 6, 4, 7, 5, 8).contiguous().reshape(B, L, L, 64)
 
 
 def _z_frag_perm(device):
@@ -407,6 +442,7 @@ class PackedWeights:
                 wf, bf = g(q + "final_layer.weight"), g(q + "final_layer.bias")
                 t[f"{b}.et.b2"] = g(q + "trunk.2.bias")
                 t[f"{b}.et.stream"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf)
+                t[f"{b}.et.streamf"] = pack_et_stream(w1[:, :64], g(q + "trunk.2.weight"), wf, z_frag=True)
                 t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.stream32"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.stream32f"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf, z_frag=True)
@@ -487,9 +523,11 @@ class DenoiseEngine:
         # z_out_frag): nobody else reads it (the attention takes the pair bias / pair values the kernel emits), and every load / store
         # instruction of it becomes one contiguous KiB (as [.., 64] rows: 32 rows, 32 bytes of each).  The caller's edge embedding is
         # permuted once per call (bind_context).  fp32 pair tensor, whole 16 x 16 tiles.  PF_ET_ZFRAG=0 / 1 forces it (A/B runs).
-        self.z_frag = (self.et_v4 and not self.z16 and L % 16 == 0 and self.pair_dz is not None and
-                       {"0": False, "1": True}.get(os.environ.get("PF_ET_ZFRAG", ""), True))
-        self.edge_frag = e(B, L, L, 64) if self.z_frag else None
+        # f16 mode: the same for the f16 pair tensor of the 16x16x32 kernel (a row's two KiB pieces are its LDS-DMA pieces as they are,
+        # the z' store is two contiguous KiB per row instead of four instructions of 8-byte pieces): 208 -> 200 us stand-alone.
+        zf_ok = L % 16 == 0 and self.pair_dz is not None and {"0": False, "1": True}.get(os.environ.get("PF_ET_ZFRAG", ""), True)
+        self.z_frag = zf_ok and ((self.et_v4 and not self.z16) or (self.z16 and not self.et_v4 and self.et_rows == 16))
+        self.edge_frag = e(B, L, L, 64, dt=torch.float16 if self.z16 else torch.float32) if self.z_frag else None
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
         self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
         self.et_ntiles = e(1, dt=torch.int32)
@@ -632,7 +670,10 @@ class DenoiseEngine:
         if self.z16:                            # one conversion per call (the reference re-reads the fp32 tensor in every step)
             self.edge16.copy_(ee.reshape(B, L, L, 64))
         if self.z_frag:                         # one permutation per call: block 0's EdgeTransition input in fragment order
-            z_to_frag(ee.reshape(B, L, L, 64), out=self.edge_frag)
+            if self.z16:
+                z16_to_frag(self.edge16, out=self.edge_frag)
+            else:
+                z_to_frag(ee.reshape(B, L, L, 64), out=self.edge_frag)
         _capi.check(self.lib.pf_pair_bias_fwd(ee.data_ptr(), self.w["0.linear_b.w"].data_ptr(), self.w["0.linear_b.b"].data_ptr(),
                                               self.pair_bias0.data_ptr(), B, L, _capi.stream_ptr()), "pf_pair_bias_fwd")
         if self.pair_dz0 is not None:           # block 0's pair values W_dz edge_embed (no bias), once per call like its pair bias
@@ -813,7 +854,7 @@ class DenoiseEngine:
                     if b == 0:
                         et.z_in = self.edge_frag.data_ptr()
                 et.b2, et.ln_g, et.ln_b = w[f"{b}.et.b2"].data_ptr(), w[f"{b}.et.ln.w"].data_ptr(), w[f"{b}.et.ln.b"].data_ptr()
-                et.w_stream = w[f"{b}.et.stream"].data_ptr()
+                et.w_stream = w[f"{b}.et.streamf" if (self.z_frag and self.z16) else f"{b}.et.stream"].data_ptr()
                 et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
                 if self.et_v4:
                     et.w_stream32, et.wb_frags32 = w[f"{b}.et.stream32f" if self.z_frag else f"{b}.et.stream32"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()

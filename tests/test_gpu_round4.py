@@ -239,3 +239,45 @@ def test_edge_transition_with_the_pair_tensor_in_fragment_order(seeded_sd, B, L,
     G.assert_close(o1.view(B, L, L, 64), ref, REL, "fragment-ordered EdgeTransition vs oracle")
     with pytest.raises(Exception):
         run(True, single_pass=True)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("f16", 4e-3)])
+@pytest.mark.parametrize("B,L", [(2, 64), (3, 112), (2, 128)])
+def test_step_with_the_pair_tensor_in_fragment_order(seeded_sd, B, L, precision, tol):
+    """DenoiseEngine.z_frag: one denoise step with the pair tensor kept in the EdgeTransition kernels' fragment order between the
+    launches (fp32 mode: 32x32 kernel, f16 mode: 16x16x32 kernel with the f16 tensor) against the step with the [B,L,L,64] tensor,
+    on a padded batch too.  fp32 mode: the permuted K index changes the summation order only (1e-5); f16 mode: a differently rounded
+    sum now and then moves a stored f16 value by one unit (4e-3 against the 2e-2 that mode is held to against the oracle)."""
+    from pepflowww_amd.engine import DenoiseEngine
+    batch = synth.make_pocket_batch(B, L, 8, seed=5)
+    if B > 2:
+        batch["res_mask"][2, L - 24:] = False
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    model.load_state_dict(seeded_sd, strict=True)
+    model = model.to(G.dev()).eval()
+    bd = {k: (v.to(G.dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        R1, x1, ang1, seq1, node, edge = model.encode(bd)
+    w = model.ga_encoder.packed_weights(G.dev())
+    g = torch.Generator().manual_seed(6)
+    q = torch.randn(B, L, 4, generator=g)
+    Rt = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    xt, at = torch.randn(B, L, 3, generator=g) * 5, torch.rand(B, L, 5, generator=g) * 6
+    st = torch.randint(0, 20, (B, L), generator=g)
+    t = torch.rand(B, 1, generator=g)
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["PF_ET_ZFRAG"] = flag
+        try:
+            eng = DenoiseEngine(w, B, L, G.dev(), precision=precision)
+        finally:
+            del os.environ["PF_ET_ZFRAG"]
+        assert eng.z_frag == (flag == "1")
+        eng.bind_context(node, edge, bd["res_mask"])
+        eng.set_state(cu(t), cu(Rt), cu(xt), cu(at), cu(st))
+        eng.run()
+        G.sync()
+        m = bd["res_mask"].reshape(-1).bool().cpu()
+        outs.append([eng.rot.cpu()[m], eng.trans.cpu()[m], eng.ang_raw.cpu()[m], eng.logits.cpu()[m]])
+    for a_, b_, what in zip(outs[1], outs[0], ("rotations", "translations", "angles", "logits")):
+        G.assert_close(a_, b_, tol, f"{precision} step, fragment-ordered pair tensor vs [B,L,L,64]: {what}")
