@@ -10,6 +10,10 @@
 //        Every K / V / point row of a (sample, head) is fetched by ONE workgroup (whose waves share it through L1) instead of by
 //        every 16-query tile of the sample: the one-kernel form moved 907 MB per launch at B=64, L=128 (274 MB of K, 281 MB of V
 //        re-reads; rocprof r02a: 198 us), this one 174 MB.
+//        With pf_ipa_attn_args.s_in (64 <= L <= 128) the head's q / k / v / point PROJECTION runs in this kernel's prologue (proj_head);
+//        the two products then read their operands from the launch's scratch (att_vt) in FRAGMENT order -- the k rows as fp32 blocks,
+//        the transposed values as hi | lo f16 blocks: every operand load is one contiguous KiB -- and P.[V | V_pts] runs on split f16
+//        MFMAs (three v_mfma_f32_16x16x32_f16 per product).
 //   ipa_pair_kernel    one wave per query row: zbar[h][c] = sum_j P[h][j] z[i][j][c] streamed at HBM rate (z is read exactly once
 //        per block, 256 B/pair = the algorithmic traffic of the step), then o_pair = W_dz zbar + b_dz (linear in z, so the
 //        [B,L,L,16] pair_z tensor of the reference never exists).
