@@ -202,13 +202,13 @@ typedef struct {
      * and qp / kp / vp are not touched in this form (proj must still be non-NULL).
      * fp32 operands (att_mode 0), ABI 51: `att_vt` is REQUIRED as the launch's SCRATCH of B x 8 x 512 x ceil32(L) f16 (1 KiB per key
      * and head; written through the const pointer): per (sample, head) the values as hi | lo f16 operand fragments of the second
-     * product (transposed, fragment order: 1 KiB per (16-channel tile, 32-key step, plane)) and the k rows as fp32 fragments of the
-     * first (1 KiB per (16-key tile, 16-channel step)) -- every operand load / store of the workgroup is one contiguous KiB.  The
-     * second product runs as three f16 MFMAs per product (P hi V hi + P hi V lo + P lo V hi, ~2^-22 relative: the precision of
-     * every split-precision Linear of this library) instead of fp32 MFMAs.  The buffer must hold FINITE values on entry (zero it
+     * product (transposed, fragment order: 1 KiB per (16-channel tile, 32-key step, plane)) and the k rows as operand fragments of
+     * the first (8 KiB per 16-key tile: hi | lo f16 per 32-channel K-step without fused_pair, fp32 per 16-channel step with it) --
+     * every operand load / store of the workgroup is one contiguous KiB.  The second product -- and without fused_pair the first --
+     * runs as three f16 MFMAs per product (hi hi + hi lo + lo hi, ~2^-22 relative: the precision of every split-precision Linear of
+     * this library) instead of fp32 MFMAs.  The buffer must hold FINITE values on entry (zero it
      * once): key columns at or beyond a sample's key end are not written and meet zero probabilities.
-     * q, k, the points and the first product are bit-identical to pf_linear_fwd followed by the plain call; the outputs agree with
-     * it to ~1e-6 relative (ipa_pytorch.py:347-387 + 389-475 in one launch). */
+     * q, k and the points are bit-identical to pf_linear_fwd followed by the plain call; the outputs agree with it to ~1e-6 relative (ipa_pytorch.py:347-387 + 389-475 in one launch). */
     const float* s_in; const void* proj_w_f16; const float* proj_bias;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);

@@ -295,5 +295,24 @@ def dptr(t, dtype=torch.float32, name="tensor"):
     return t.data_ptr()
 
 
+class capture_guard:
+    """Around a hipGraph capture: the cyclic garbage collector is run once and then held off.  A collection that happens to run
+    DURING capture can finalise device objects of earlier work (a dropped engine's captured graphs, events, pooled blocks); destroying
+    those while a stream is capturing invalidates the capture and aborts the process (seen once in ~15 runs of the GPU suite, inside the
+    training step's capture: "Fatal Python error: Aborted ... Garbage-collecting")."""
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream

@@ -242,6 +242,7 @@ struct PjW { half8 h[4], l[4]; };
 // tiles (21) of the same rows -- those results go to the scratch / the LDS tables anyway, nothing has to be handed over.  tile = the
 // 16-row tile of the sample this wave projects (its own index as a query wave, its partner's as a helper).
 __device__ __forceinline__ constexpr bool pj_q_tile(int idx) { return idx < 8 || idx == 24 || idx == 25; }
+template <bool KS>                           // KS: the k rows as hi | lo f16 operand fragments (first product on split f16 MFMAs); else fp32 fragments
 __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, int role, int tile, float* KP,
                                           _Float16* VPT /* [2][48][VTL] value points, hi | lo */, int VTL, _Float16* VTH /* this head's [8 tiles][VTG / 32 steps][hi | lo][64 lanes][8] */, int VTG,
                                           unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
@@ -300,9 +301,14 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
 #pragma unroll
     for (int c = 0; c < PJ_NB - 1; ++c)
         if (c < PJ_NCH) issue(c);
-    // k rows: fragment order too -- block (key tile `tile`, 16-channel step s) = the 64 lanes' float4 (key r, channels 16 s + 4 g ..)
-    // as the first product's loadk reads them: one contiguous KiB per store / load instruction, behind the head's value blocks
-    float* kfrag = reinterpret_cast<float*>(VTH + (size_t)8 * (VTG >> 5) * 1024) + ((size_t)tile * 8) * 256 + lane * 4;
+    // k rows: fragment order too.  KS (the form without the pair phase): as the hi | lo f16 operands of the first product (three f16
+    // MFMAs per product, like the second one) --
+    // block (key tile `tile`, 32-channel K-step s, plane) = 1 KiB = the 64 lanes' 16 bytes: lane (key r, g) holds channels 32 s + 4 g .. + 3
+    // (from the wave's k tile 2 s) and 32 s + 16 + 4 g .. + 3 (tile 2 s + 1), which is the K order the query operand has for free:
+    // the accumulator registers qf[2 s] | qf[2 s + 1] of lane (query r, g).  Behind the head's value blocks, 8 KiB per key tile.
+    // Without KS (the form with the pair phase in front, L <= 64: no registers to spare, same-box 0.654 vs 0.659 ms at cfg2): fp32
+    // blocks (key tile, 16-channel step) = the 64 lanes' float4, the first product stays on fp32 MFMAs.
+    _Float16* kfrag = VTH + (size_t)8 * (VTG >> 5) * 1024 + (size_t)tile * 4096 + lane * 8;
     auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ_CHUNK_B + tl * 8192 + lane * 16;
 #pragma unroll
@@ -363,8 +369,17 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                     }
                     if constexpr (idx < 8) {
                         qf[idx] = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if constexpr (idx < 16) {        // k tiles 0..7 of the head: columns 16 (idx - 8) + 4 g of its 256
-                        *reinterpret_cast<float4*>(kfrag + (idx - 8) * 256) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if constexpr (idx < 16) {        // k tiles 0..7 of the head -> hi | lo operand fragments of the first product
+                        if constexpr (KS) {
+                            half4 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+                            _Float16* d = kfrag + ((idx - 8) >> 1) * 1024 + ((idx - 8) & 1) * 4;  // K-step (idx - 8) / 2: hi KiB | lo KiB
+                            *reinterpret_cast<half4*>(d) = hi;
+                            *reinterpret_cast<half4*>(d + 512) = lo;
+                        } else {                            // fp32 fragments: block (key tile, 16-channel step idx - 8) = the 64 lanes' float4
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(kfrag - lane * 8) + (idx - 8) * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
                     } else if constexpr (VTILE) {           // channel 16 (idx - 16) + r of keys 16 tile + 4 g + e -> hi | lo plane, 8 bytes each
                         half4 hi, lo;
 #pragma unroll
@@ -562,6 +577,7 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
 template <bool VEC4, bool FUSE = false, bool PROJ = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool KSPLIT = PROJ && !FUSE;         // first product on split f16 MFMAs, k rows as hi | lo fragments (proj_head<true>)
     const int L = a.L;
     float* KP = smem;                              // [LP][KPS] key points of this head (global frame)
     float* MJ = KP + LP * KPS;                     // [LP] key mask (0 beyond L)
@@ -608,7 +624,14 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         kfr_u = reinterpret_cast<const char*>(a.att_vt) + (((size_t)b * H + h) * 512 * VTG + (size_t)8 * (VTG >> 5) * 1024) * sizeof(_Float16);
     }
     auto loadk = [&](int t, float4 (&kf)[8]) {
-        if constexpr (PROJ) {
+        if constexpr (KSPLIT) {                    // kf[s] = hi operand of K-step s, kf[4 + s] = its lo operand (16 bytes each, as bits)
+            const char* kt_u = kfr_u + (size_t)t * 8192;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                kf[s] = *reinterpret_cast<const float4*>(kt_u + s * 2048 + (unsigned)lane * 16u);
+                kf[4 + s] = *reinterpret_cast<const float4*>(kt_u + s * 2048 + 1024 + (unsigned)lane * 16u);
+            }
+        } else if constexpr (PROJ) {               // fp32 fragments: tile t, 16-channel step s = one contiguous KiB
             const char* kt_u = kfr_u + (size_t)t * 8192;
 #pragma unroll
             for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(kt_u + s * 1024 + (unsigned)lane * 16u);
@@ -619,6 +642,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         }
     };
     float4 kf[8], kn[8];
+    half8 qh[4], ql[4];                            // (PROJ: the query rows as hi | lo f16 operands)
     if constexpr (!PROJ) { if (wave_on) loadk(0, kf); }
 
     if constexpr (PROJ) {
@@ -632,11 +656,18 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         const int role = (int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0;
         const int VTG = (L + 31) & ~31;                // key stride of the value planes (pf_ipa_attn_args.att_vt as this launch's scratch)
         _Float16* VTH = reinterpret_cast<_Float16*>(const_cast<void*>(a.att_vt)) + ((size_t)b * H + h) * 512 * VTG;   // values 256 VTG | k rows 256 VTG (as f16 counts)
-        proj_head(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
+        proj_head<KSPLIT>(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
                   PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
         if (!wave_on || helper) return;
         loadk(0, kf);
+        // the query operand of the first product: K-step s = the accumulator registers of q tiles 2 s | 2 s + 1, split in place
+#pragma unroll
+        for (int s = 0; KSPLIT && s < 4; ++s) {
+            const float v[8] = {qf[2 * s].x, qf[2 * s].y, qf[2 * s].z, qf[2 * s].w, qf[2 * s + 1].x, qf[2 * s + 1].y, qf[2 * s + 1].z, qf[2 * s + 1].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qh[s][j] = (_Float16)v[j]; ql[s][j] = (_Float16)(v[j] - (float)qh[s][j]); }
+        }
     } else {
     // ---- key points / key mask / value points of the head -> LDS (all waves) ----
     // (value points: read per key tile they were 12 dword loads per lane and tile in every wave (4-8 cache lines per instruction); with
@@ -712,12 +743,24 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
             for (int e = 0; e < 4; ++e) bj[e] = brow[TAIL ? min(jb + e, L - 1) : jb + e];
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: dependent latency 40 > issue 32 cycles
+        if constexpr (KSPLIT) {
+            // split f16 product (k hi q hi + k hi q lo + k lo q hi; lo halves unscaled, one sum): 12 MFMAs of 16 cycles instead of 32
+            // fp32 ones of 32 -- with the k rows as contiguous fragments this phase had become matrix-pipe time (what-if: - 1.4 % of the step)
 #pragma unroll
-        for (int s = 0; s < 8; s += 2) {
-            acc = mfma16(kf[s].x, qf[s].x, acc);   acc2 = mfma16(kf[s + 1].x, qf[s + 1].x, acc2);
-            acc = mfma16(kf[s].y, qf[s].y, acc);   acc2 = mfma16(kf[s + 1].y, qf[s + 1].y, acc2);
-            acc = mfma16(kf[s].z, qf[s].z, acc);   acc2 = mfma16(kf[s + 1].z, qf[s + 1].z, acc2);
-            acc = mfma16(kf[s].w, qf[s].w, acc);   acc2 = mfma16(kf[s + 1].w, qf[s + 1].w, acc2);
+            for (int s = 0; s < 4; ++s) {
+                const half8 kh = __builtin_bit_cast(half8, kf[s]), kl = __builtin_bit_cast(half8, kf[4 + s]);
+                acc = mfma_h(kh, qh[s], acc);
+                acc2 = mfma_h(kh, ql[s], acc2);
+                acc2 = mfma_h(kl, qh[s], acc2);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; s += 2) {
+                acc = mfma16(kf[s].x, qf[s].x, acc);   acc2 = mfma16(kf[s + 1].x, qf[s + 1].x, acc2);
+                acc = mfma16(kf[s].y, qf[s].y, acc);   acc2 = mfma16(kf[s + 1].y, qf[s + 1].y, acc2);
+                acc = mfma16(kf[s].z, qf[s].z, acc);   acc2 = mfma16(kf[s + 1].z, qf[s + 1].z, acc2);
+                acc = mfma16(kf[s].w, qf[s].w, acc);   acc2 = mfma16(kf[s + 1].w, qf[s + 1].w, acc2);
+            }
         }
         acc += acc2;
         float sv[4];

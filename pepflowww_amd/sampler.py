@@ -127,7 +127,7 @@ class DeviceSampler:
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with _capi.capture_guard(), torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
                 for _ in range(k):
                     self._one_step()

@@ -130,7 +130,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         calls0 = _capi.CALLS
-        with torch.cuda.graph(self.graph):
+        with _capi.capture_guard(), torch.cuda.graph(self.graph):
             losses, state = _step_forward(model, sd, self.batch, self.noise, 0, first_sample, seed_dev=self.seed)
             grads, self.arena = _step_backward(state, self.weights, return_arena=True)
             self.losses = losses
