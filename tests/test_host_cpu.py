@@ -256,3 +256,42 @@ def test_pep_dataset_reads_the_structure_cache(tmp_path):
     ds4 = PepDataset(dataset_dir=str(tmp_path), name="pep", transform=_KeepKeys(keep))
     got = list(DataLoader(ds4, batch_size=2, shuffle=False, num_workers=2, collate_fn=PaddingCollate(eight=False), multiprocessing_context="spawn"))
     assert sum(b["aa"].shape[0] for b in got) == len(ds4)
+
+
+def test_fragment_order_layouts_are_permutations():
+    """Host side of the fragment-ordered pair tensor (pf_edge_transition_args.z_in_frag / z_out_frag): z_to_frag / z16_to_frag are pure
+    permutations with exact inverses and put a pair's channels where the header says (block, piece, lane); the K orders of the z operand
+    are permutations of each K-step's channels; pack_et_stream32 / pack_et_stream with z_frag touch the 32 stream entries that multiply
+    z and nothing else."""
+    import torch
+    from pepflowww_amd.engine import (z_to_frag, z_from_frag, z16_to_frag, z16_from_frag, _z_frag_perm, _z_frag_perm16,
+                                      pack_et_stream32, pack_et_stream)
+    g = torch.Generator().manual_seed(3)
+    B, L = 2, 48
+    z = torch.randn(B, L, L, 64, generator=g)
+    zf = z_to_frag(z)
+    assert torch.equal(z_from_frag(zf), z) and torch.equal(zf.reshape(-1).sort().values, z.reshape(-1).sort().values)
+    # 32x32 kernel: block (b, ib, jb, wave w) of 2048 floats = piece k = 4 mt + q (256 floats) x lane g * 32 + rl * 16 + jl (4 floats)
+    flat = zf.reshape(-1)
+    for (b, i, j, f) in ((0, 0, 0, 0), (1, 17, 35, 45), (0, 47, 16, 63), (1, 30, 47, 8)):
+        ib, w, rl, jb, jl = i // 16, (i % 16) // 2, i % 2, j // 16, j % 16
+        mt, q, gg, e = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
+        blk = ((b * (L // 16) + ib) * (L // 16) + jb) * 8 + w
+        assert flat[blk * 2048 + (4 * mt + q) * 256 + (gg * 32 + rl * 16 + jl) * 4 + e] == z[b, i, j, f]
+    z16 = z.half()
+    zf16 = z16_to_frag(z16)
+    assert torch.equal(z16_from_frag(zf16), z16)
+    flat = zf16.reshape(-1)
+    for (b, i, j, f) in ((0, 0, 0, 0), (1, 17, 35, 45), (0, 47, 16, 63)):
+        ib, row, jb, r = i // 16, i % 16, j // 16, j % 16
+        s, t2, gg, e = f // 32, (f % 32) // 16, (f % 16) // 4, f % 4
+        blk = ((b * (L // 16) + ib) * (L // 16) + jb) * 16 + row
+        assert flat[blk * 1024 + s * 512 + (gg * 16 + r) * 8 + 4 * t2 + e] == z16[b, i, j, f]
+    for perm, step in ((_z_frag_perm(z.device), 16), (_z_frag_perm16(z.device), 32)):
+        assert sorted(perm.tolist()) == list(range(64))
+        assert all(int(p) // step == k // step for k, p in enumerate(perm.tolist()))          # a permutation inside every K-step
+    w1, w2, wf = torch.randn(192, 192, generator=g) * 0.1, torch.randn(192, 192, generator=g) * 0.1, torch.randn(64, 192, generator=g) * 0.1
+    for pack in (pack_et_stream32, pack_et_stream):
+        a, b_ = pack(w1[:, :64], w2, wf), pack(w1[:, :64], w2, wf, z_frag=True)
+        assert a.shape == b_.shape and torch.equal(a[32 * 1024:], b_[32 * 1024:]) and not torch.equal(a[:32 * 1024], b_[:32 * 1024])
+        assert torch.equal(a[:32 * 1024].float().sort().values, b_[:32 * 1024].float().sort().values)   # the same values, reordered
