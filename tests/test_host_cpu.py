@@ -295,3 +295,27 @@ def test_fragment_order_layouts_are_permutations():
         a, b_ = pack(w1[:, :64], w2, wf), pack(w1[:, :64], w2, wf, z_frag=True)
         assert a.shape == b_.shape and torch.equal(a[32 * 1024:], b_[32 * 1024:]) and not torch.equal(a[:32 * 1024], b_[:32 * 1024])
         assert torch.equal(a[:32 * 1024].float().sort().values, b_[:32 * 1024].float().sort().values)   # the same values, reordered
+
+
+def test_capture_guard_holds_the_garbage_collector_off_and_restores_it():
+    """_capi.capture_guard (around every hipGraph capture): collects once, keeps the cyclic collector off inside, restores the caller's
+    setting afterwards -- also when the body raises, and when the collector was already off."""
+    import gc
+    from pepflowww_amd import _capi
+    assert gc.isenabled()
+    with _capi.capture_guard():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with _capi.capture_guard():
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with _capi.capture_guard():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
