@@ -25,8 +25,16 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 52
+#define PF_ABI_VERSION 53
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
+/* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
+ * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
+ * lane row r = c >> 3 (channels), or tile 8 + (c - 128) / 16 as r = (c - 128) % 16 (point coordinates); key j in step j / 32 at
+ * K group (j / 8) % 4, slot j % 8.  PF_ATT_VT_HEAD(L) f16 per (sample, head); PF_ATT_VT_OFF(c, j, L) the offset of an element. */
+#define PF_ATT_VT_NST(L) (((L) + 31) >> 5)
+#define PF_ATT_VT_HEAD(L) ((size_t)11 * PF_ATT_VT_NST(L) * 512)
+#define PF_ATT_VT_OFF(c, j, L) ((((size_t)(((c) < 128 ? ((c) & 7) : 8 + (((c) - 128) >> 4)) * PF_ATT_VT_NST(L) + ((j) >> 5)) * 64 + (((j) >> 3) & 3) * 16 + \
+                                  ((c) < 128 ? ((c) >> 3) : (((c) - 128) & 15))) * 8) + ((j) & 7))
 #define PF_E_BADARG (-1)
 #define PF_E_TOOLARGE (-2)
 
@@ -84,8 +92,11 @@ typedef struct {
     /* split path with pt_* set (IPA projection of the inference plan), optional: write the attention operands as f16 planes
      * instead of fp32 `y` / `pt_vp` (csrc/ipa_split.hip consumes them; L = att_L must be a multiple of 16, M = B L):
      * single_pass only since ABI 50 (the hi / lo plane form of the fp32 mode was removed; att_qk without single_pass is refused):
-     *   att_qk : per row [q 1024 | k 8 x 128] channels, 2048 f16 per row
-     *   att_vt : values TRANSPOSED per (sample, head): [B][8][PF_ATT_VROWS = 128 channels + 36 point coordinates][L keys], L f16 per row */
+     *   att_qk : M x 2048 f16 in all: the q rows [M][1024], then the k rows in the fragment order of the score kernel's first product
+     *            (ABI 53) -- block (sample, head, 16-key tile, 32-channel K-step) = 512 f16 = the eight operand slots of each of the 64
+     *            lanes: key tile row r, channel group kg = (c / 8) % 4 at lane kg * 16 + r, slot c % 8 (natural K order)
+     *   att_vt : values TRANSPOSED per (sample, head), [B][8][PF_ATT_VT_HEAD(L)] f16 in the fragment order described at PF_ATT_VROWS
+     *            (ABI 53; until then [PF_ATT_VROWS][L] rows: an operand load of the score kernel touched sixteen rows, 64 bytes of each) */
     void* att_qk; void* att_vt; int att_L;
     /* optional (split path): the rows are [B][key_L] residues and key_end[b] (device memory, int32 [B]) = 1 + the last unmasked
      * residue of sample b (the same list as pf_ipa_attn_args.key_end).  A row tile that lies entirely at or beyond its samples'

@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     const int iq = i0 + r;                         // (< L: L is a multiple of 16)
     PROFS(0);
 
-    constexpr int RS = 2048;                       // f16 per row of the q | k planes
+    constexpr int RS = 1024;                       // f16 per row of the q plane (the k rows follow as fragments, see loadk)
     const _Float16* qk = reinterpret_cast<const _Float16*>(a.att_qk);
     // fragment of channels 32 s + 8 g .. + 7 of (row, first channel c0)
     auto ldfrag = [&](const _Float16* row, int c0, int s, half8& fh) { fh = *reinterpret_cast<const half8*>(row + c0 + 32 * s + 8 * g); };
@@ -1069,16 +1069,16 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     }
     const float mi = a.mask[rowb + (wave_on ? iq : 0)];
     const float gamma = softplusf2(a.head_w[h]) * 0.09622504486493763f;       // sqrt(1/(3*(8*9/2))), ipa_pytorch.py:412-417
-    const int KC0 = 1024 + h * C;                                              // first k channel of the head in the plane row
     auto loadk = [&](int t, half8 (&kh)[4]) {
         if constexpr (PROJ) {                      // the head's k rows are in LDS
             const _Float16* krow = KL + (16 * t + r) * KLS + 8 * g;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) kh[s4] = *reinterpret_cast<const half8*>(krow + 32 * s4);
         } else {
-            const _Float16* krow = qk + (rowb + 16 * t + r) * RS;
+            // fragment order: block (sample, head, key tile t, K-step s4) = the 64 lanes' 16 bytes -- one contiguous KiB per load
+            const _Float16* kb = qk + (size_t)a.B * L * 1024 + ((((size_t)b * H + h) * (L >> 4) + t) * 4) * 512 + lane * 8;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) ldfrag(krow, KC0, s4, kh[s4]);
+            for (int s4 = 0; s4 < 4; ++s4) kh[s4] = *reinterpret_cast<const half8*>(kb + s4 * 512);
         }
     };
     half8 kh[4], nh[4];
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
     //      (tile n, lane r) -> value channel 8 r + n for n < 8 (a lane's eight outputs of a query are consecutive floats),
     //      point coordinate 16 (n - 8) + r for n = 8..10 ----
     constexpr int NTC = 11;
-    const _Float16* vt = reinterpret_cast<const _Float16*>(a.att_vt) + ((size_t)b * H + h) * PF_ATT_VROWS * (size_t)L;
+    const _Float16* vt = reinterpret_cast<const _Float16*>(a.att_vt) + ((size_t)b * H + h) * PF_ATT_VT_HEAD(L);   // fragment order (pepflow_hip.h)
     int vrow[NTC];
 #pragma unroll
     for (int n = 0; n < NTC; ++n) vrow[n] = n < 8 ? 8 * r + n : min(128 + 16 * (n - 8) + r, PF_ATT_VROWS - 1);
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
 #pragma unroll
         for (int n = 0; n < NTC; ++n) {
             if constexpr (PROJ) vh[n] = *reinterpret_cast<const half8*>(VT + vrow[n] * VTS + 32 * s32 + 8 * g);
-            else vh[n] = *reinterpret_cast<const half8*>(vt + (size_t)vrow[n] * L + 32 * s32 + 8 * g);
+            else vh[n] = *reinterpret_cast<const half8*>(vt + ((size_t)(n * PF_ATT_VT_NST(L) + s32) * 64 + lane) * 8);   // one contiguous KiB per load
         }
     };
     f32x4 Om[NTC];

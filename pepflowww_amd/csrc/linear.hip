@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                 half4 hi, lo;
                 if constexpr (SP) {
                     hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
-                    *reinterpret_cast<half4*>(vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * AL + j) = hi;
+                    *reinterpret_cast<half4*>(vt + ((size_t)bs * 8 + hd) * PF_ATT_VT_HEAD(AL) + PF_ATT_VT_OFF(c, j, AL)) = hi;   // (fragment order: four keys of one slot group)
                 } else {
                     split4(v, hi, lo);
                     _Float16* d = vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * (2 * AL) + (j >> 3) * 16 + (j & 7);
@@ -341,8 +341,10 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                             half4 hi, lo;
                             _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
                             if constexpr (SP) {
-                                _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * AL + j;
-                                d[0] = (_Float16)ox; d[AL] = (_Float16)oy; d[2 * AL] = (_Float16)oz;
+                                _Float16* d = vt + ((size_t)bs * 8 + hh) * PF_ATT_VT_HEAD(AL);
+                                d[PF_ATT_VT_OFF(128 + 3 * pp, j, AL)] = (_Float16)ox;
+                                d[PF_ATT_VT_OFF(129 + 3 * pp, j, AL)] = (_Float16)oy;
+                                d[PF_ATT_VT_OFF(130 + 3 * pp, j, AL)] = (_Float16)oz;
                             } else {
                                 split4(ov, hi, lo);
                                 _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * (2 * AL) + (j >> 3) * 16 + (j & 7);
@@ -360,7 +362,13 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                     half4 hi, lo;
                     if constexpr (SP) {
                         hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
-                        *reinterpret_cast<half4*>(qk + (size_t)m * 2048 + kc) = hi;
+                        if (n < 1024) {                   // q rows [M][1024]
+                            *reinterpret_cast<half4*>(qk + (size_t)m * 1024 + n) = hi;
+                        } else {                          // k rows: fragment order of the score kernel's first product (pepflow_hip.h, att_qk)
+                            const int hd = (n - 1024) >> 8, kch = (n - 1024) & 255, bs = m / AL, j = m - bs * AL;
+                            *reinterpret_cast<half4*>(qk + (size_t)p.M * 1024 + ((((size_t)bs * 8 + hd) * (AL >> 4) + (j >> 4)) * 4 + (kch >> 5)) * 512 +
+                                                      (((kch >> 3) & 3) * 16 + (j & 15)) * 8 + (kch & 7)) = hi;
+                        }
                     } else {                              // channel octets interleaved (hi8 | lo8): the consumer's two 16-byte loads
                         split4(v, hi, lo);                //  per K-step are MFMA operands as they arrive (no re-packing)
                         _Float16* d = qk + (size_t)m * 4096 + (kc >> 3) * 16 + (kc & 7);
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
     // padded batch (key_end, launched with gridDim.x = B ceil(L / BM)): row tiles per SAMPLE; a tile that starts at or beyond the
     // sample's key end does nothing (see node_head32_kernel)
     int m0 = blockIdx.x * BM;
+    const size_t att_k0 = (size_t)p.M * 1024;  // first f16 of the k fragments in att_qk: behind the q rows of ALL rows (p.M is narrowed below)
     if (p.key_end) {
         const int tps = (p.key_L + BM - 1) / BM, b = blockIdx.x / tps, i0 = (blockIdx.x - b * tps) * BM;
         if (i0 >= p.key_end[b]) return;
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                     half4 hi, lo;
                     if constexpr (SP) {
                         hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
-                        *reinterpret_cast<half4*>(vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * AL + j) = hi;
+                        *reinterpret_cast<half4*>(vt + ((size_t)bs * 8 + hd) * PF_ATT_VT_HEAD(AL) + PF_ATT_VT_OFF(c, j, AL)) = hi;   // (fragment order: four keys of one slot group)
                     } else {
                         split4(v, hi, lo);
                         _Float16* d = vt + (((size_t)bs * 8 + hd) * PF_ATT_VROWS + c) * (2 * AL) + (j >> 3) * 16 + (j & 7);
@@ -574,8 +583,10 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                             const int bs = m / AL, j = m - bs * AL;
                             _Float16* vt = reinterpret_cast<_Float16*>(p.att_vt);
                             if constexpr (SP) {
-                                _Float16* d = vt + (((size_t)bs * 8 + hh) * PF_ATT_VROWS + 128 + 3 * pp) * AL + j;
-                                d[0] = (_Float16)ox; d[AL] = (_Float16)oy; d[2 * AL] = (_Float16)oz;
+                                _Float16* d = vt + ((size_t)bs * 8 + hh) * PF_ATT_VT_HEAD(AL);
+                                d[PF_ATT_VT_OFF(128 + 3 * pp, j, AL)] = (_Float16)ox;
+                                d[PF_ATT_VT_OFF(129 + 3 * pp, j, AL)] = (_Float16)oy;
+                                d[PF_ATT_VT_OFF(130 + 3 * pp, j, AL)] = (_Float16)oz;
                             } else {
                                 const float ov[4] = {ox, oy, oz, 0.f};
                                 half4 hi, lo;
@@ -603,7 +614,13 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                     half4 hi, lo;
                     if constexpr (SP) {
                         hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
-                        *reinterpret_cast<half4*>(qk + (size_t)m * 2048 + kc) = hi;
+                        if (n < 1024) {                   // q rows [M][1024]
+                            *reinterpret_cast<half4*>(qk + (size_t)m * 1024 + n) = hi;
+                        } else {                          // k rows: fragment order of the score kernel's first product (pepflow_hip.h, att_qk)
+                            const int hd = (n - 1024) >> 8, kch = (n - 1024) & 255, bs = m / AL, j = m - bs * AL;
+                            *reinterpret_cast<half4*>(qk + att_k0 + ((((size_t)bs * 8 + hd) * (AL >> 4) + (j >> 4)) * 4 + (kch >> 5)) * 512 +
+                                                      (((kch >> 3) & 3) * 16 + (j & 15)) * 8 + (kch & 7)) = hi;
+                        }
                     } else {                              // channel octets interleaved (hi8 | lo8)
                         split4(v, hi, lo);
                         _Float16* d = qk + (size_t)m * 4096 + (kc >> 3) * 16 + (kc & 7);

@@ -552,7 +552,7 @@ class DenoiseEngine:
         self.att_qk = self.att_vt = None
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
-            self.att_vt = torch.zeros(B * 8 * 164 * L + 64, dtype=torch.float16, device=device)
+            self.att_vt = torch.zeros(B * 8 * 11 * ((L + 31) // 32) * 512, dtype=torch.float16, device=device)    # PF_ATT_VT_HEAD(L) per (sample, head)
         # fp32 mode with the projection inside the score kernel: pf_ipa_attn_args.att_vt as that form's per-launch scratch -- per (sample,
         # head) the values as hi | lo f16 operand fragments of the second product and the k rows as fp32 fragments of the first (1 KiB per
         # key and head), written by the prologue and read back by the same workgroup through L2.  Zero-initialised: key columns beyond a

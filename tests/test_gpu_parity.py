@@ -295,7 +295,7 @@ def test_ipa_on_f16_operand_planes(seeded_sd, B, L, mode):
     qp, kp, vp = (torch.full((rows, n), float("nan"), device=dev) for n in (192, 192, 288))
     split = mode == 1
     att_qk = torch.zeros(rows * (4096 if split else 2048), dtype=torch.float16, device=dev)
-    att_vt = torch.zeros(B * 8 * 164 * L * (2 if split else 1) + 64, dtype=torch.float16, device=dev)
+    att_vt = torch.zeros(B * 8 * 11 * ((L + 31) // 32) * 512 * (2 if split else 1), dtype=torch.float16, device=dev)   # PF_ATT_VT_HEAD(L) per (sample, head)
     la = _capi.LinearArgs()
     la.x, la.ldx, la.w, la.ldw = sd_.data_ptr(), 128, W[f"{blk}.proj.w"].data_ptr(), 128
     la.w_f16, la.bias = W[f"{blk}.projp.w16"].data_ptr(), W[f"{blk}.projp.b"].data_ptr()

@@ -281,3 +281,53 @@ def test_step_with_the_pair_tensor_in_fragment_order(seeded_sd, B, L, precision,
         outs.append([eng.rot.cpu()[m], eng.trans.cpu()[m], eng.ang_raw.cpu()[m], eng.logits.cpu()[m]])
     for a_, b_, what in zip(outs[1], outs[0], ("rotations", "translations", "angles", "logits")):
         G.assert_close(a_, b_, tol, f"{precision} step, fragment-ordered pair tensor vs [B,L,L,64]: {what}")
+
+
+@pytest.mark.parametrize("B,L,ragged", [(4, 128, False), (64, 128, False), (57, 144, False), (64, 144, True)])
+def test_attention_planes_in_fragment_order(seeded_sd, B, L, ragged):
+    """pf_linear_args.att_qk / att_vt (f16 mode, ABI 53): the q rows, the k rows and the transposed values of the projection, decoded
+    from the fragment order documented in pepflow_hip.h, equal x W^T + b to f16 resolution -- at row counts that pick each of the
+    projection's kernels (tiled; rows-persistent 64-row form; rows-persistent per-sample form with key ends, whose row bound is
+    narrowed per workgroup: the k fragments must still start behind the q rows of ALL rows)."""
+    import ctypes as C
+    import random
+    from pepflowww_amd.engine import PackedWeights
+    lib, dev = _capi.load(), G.dev()
+    W = PackedWeights(seeded_sd, dev)
+    rows, nst = B * L, (L + 31) // 32
+    g = torch.Generator().manual_seed(B + L)
+    s = cu(torch.randn(rows, 128, generator=g))
+    R, x = cu(torch.eye(3).reshape(1, 9).repeat(rows, 1)), torch.zeros(rows, 3, device=dev)
+    proj = torch.zeros(rows, 3744, device=dev)
+    qp, kp, vp = (torch.zeros(rows, n, device=dev) for n in (192, 192, 288))
+    att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=dev)
+    att_vt = torch.zeros(B * 8 * 11 * nst * 512, dtype=torch.float16, device=dev)
+    la = _capi.LinearArgs()
+    la.x, la.ldx, la.w, la.ldw = s.data_ptr(), 128, W["0.proj.w"].data_ptr(), 128
+    la.w_f16, la.bias = W["0.projp.w16"].data_ptr(), W["0.projp.b"].data_ptr()
+    la.y, la.ldy, la.M, la.N, la.K = proj.data_ptr(), 3744, rows, 3968, 128
+    la.pt_rot, la.pt_trans, la.pt_col0 = R.data_ptr(), x.data_ptr(), 3072
+    la.pt_qp, la.pt_kp, la.pt_vp = qp.data_ptr(), kp.data_ptr(), vp.data_ptr()
+    la.single_pass, la.att_qk, la.att_vt, la.att_L = 1, att_qk.data_ptr(), att_vt.data_ptr(), L
+    valid = torch.ones(B, L, dtype=torch.bool)
+    if ragged:
+        rnd = random.Random(7)
+        ends = [rnd.randint(51, L) for _ in range(B)]
+        ke = cu(torch.tensor(ends, dtype=torch.int32))
+        la.key_end, la.key_L, la.active_rows = ke.data_ptr(), L, int(sum(ends))
+        for b_, e in enumerate(ends):
+            valid[b_, e:] = False                                # (row tiles entirely beyond a key end are skipped: rows < key_end are always written)
+    _capi.check(lib.pf_linear_fwd(C.byref(la), _capi.stream_ptr()), "pf_linear_fwd")
+    G.sync()
+    pfx = "ga_encoder.trunk.ipa_0."
+    wfull = torch.cat([seeded_sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv")], 0)
+    bfull = torch.cat([seeded_sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv")], 0)
+    y = s.cpu() @ wfull.T + bfull                                # [rows, 3072]: q 1024 | (k 128 | v 128) x 8
+    aq, av = att_qk.cpu().float(), att_vt.cpu().float()
+    q = aq[: rows * 1024].view(B, L, 1024)
+    k = aq[rows * 1024:].view(B, 8, L // 16, 4, 4, 16, 8).permute(0, 2, 5, 1, 3, 4, 6).reshape(B, L, 8, 128)   # (b, h, tile, s, kg, r, slot)
+    v = av.view(B, 8, 11, nst, 4, 16, 8)[:, :, :8].permute(0, 3, 4, 6, 1, 5, 2).reshape(B, nst * 32, 8, 128)[:, :L]   # channel 8 r + n
+    yk = y[:, 1024:].view(B, L, 8, 256)
+    for got, want, what in ((q, y[:, :1024].view(B, L, 1024), "q rows"), (k, yk[..., :128], "k fragments"), (v, yk[..., 128:], "value fragments")):
+        err = (got - want).abs()[valid].max().item()
+        assert err < 6e-3, (what, err)
