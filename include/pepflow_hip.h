@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 53
+#define PF_ABI_VERSION 54
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 /* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
  * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
@@ -104,6 +104,11 @@ typedef struct {
      * the same rows; the caller keeps the buffers finite).  active_rows (host side hint, 0 = unknown) = sum of key_end: lets the
      * launcher pick the rows-persistent kernel when the ACTIVE tiles fit whole rounds of workgroups. */
     const int* key_end; int key_L; int active_rows;
+    /* optional (split path with pt_* set, fp32 output, att_L = L a multiple of 16, M = B L; ABI 54): the k columns of the packed IPA
+     * projection (features 1024 + 256 h .. + 127) go to k_frag INSTEAD of y, as fp32 fragments of the score kernel's first product:
+     * block (sample, head, 16-key tile, 16-channel step) = 256 floats = the float4 of each of the 64 lanes (key r, channels 4 g ..);
+     * M x 1024 floats in all.  pf_ipa_attn_args.k_frag takes the same buffer. */
+    float* k_frag;
 } pf_linear_args;
 int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream);
 /* W [N,K] fp32 (ldw) -- or W^T when `transpose` (then w is [K,N], ldw >= N) -- to the fragment-order f16 hi/lo planes
@@ -221,6 +226,10 @@ typedef struct {
      * once): key columns at or beyond a sample's key end are not written and meet zero probabilities.
      * q, k and the points are bit-identical to pf_linear_fwd followed by the plain call; the outputs agree with it to ~1e-6 relative (ipa_pytorch.py:347-387 + 389-475 in one launch). */
     const float* s_in; const void* proj_w_f16; const float* proj_bias;
+    /* optional (two-kernel form, fp32 operands without s_in, L % 16 == 0; ABI 54): the k rows as fp32 fragments written by pf_linear_fwd
+     * (pf_linear_args.k_frag): the first product reads them instead of the k columns of `proj` -- one contiguous KiB per load instead of
+     * sixteen rows x 64 bytes.  Same values, same arithmetic: results are bit-identical to the call without it. */
+    const float* k_frag;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the

@@ -731,7 +731,7 @@ extern "C" int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream) {
     if (a->dz_f16 && !a->dz) return PF_E_BADARG;
     if (a->dz && !(can_split && a->variant != 1 && a->L >= 64)) return PF_E_BADARG;      // pair values: two-kernel form only
     if (can_split && (a->variant == 2 || (a->variant == 0 && a->L >= 64))) return pf_ipa_split_launch(a, s);
-    if (a->s_in) return PF_E_BADARG;                         // the projection inside the score kernel: two-kernel form only
+    if (a->s_in || a->k_frag) return PF_E_BADARG;            // the projection inside the score kernel / k fragments: two-kernel form only
     // (HG = 4 at large sizes was measured slower -- 8.24 vs 7.88 ms/step at B=64, L=128: the second z pass costs
     //  more than the extra occupancy buys.)
     const int force_hg = a->head_group;                      // 0 = by size; 2 / 4 / 8 = that head-group variant (tests)

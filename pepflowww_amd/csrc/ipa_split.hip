@@ -635,6 +635,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
             const char* kt_u = kfr_u + (size_t)t * 8192;
 #pragma unroll
             for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(kt_u + s * 1024 + (unsigned)lane * 16u);
+        } else if (a.k_frag) {                      // (uniform) fp32 fragments written by the projection launch (pf_linear_args.k_frag): tile t,
+            const float* kt_f = a.k_frag + ((((size_t)b * H + h) * (L >> 4) + t) * 8) * 256 + lane * 4;   //  16-channel step s = one contiguous KiB
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(kt_f + s * 256);
         } else {
             const float* krow = kbase + (size_t)min(16 * t + r, Le - 1) * a.ldp;
 #pragma unroll
@@ -1654,6 +1658,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             return 0;
         }
         // (att_vt: this form's scratch for the head's value planes, B x 8 x 2 x 128 x ceil32(L) f16 -- finite on entry, see the header)
+        if (a->k_frag && (a->s_in || planes || (L & 15) != 0)) return PF_E_BADARG;   // k fragments: the fp32 form with the projection launch
         if (pj && (planes || nrb != 1 || (L & 3) != 0 || !a->proj_w_f16 || !a->proj_bias || !a->proj || !a->att_vt || a->ldp < OFF_KV + 2 * H * C)) return PF_E_BADARG;
         if (pj) {
             static bool attr_pj = false;

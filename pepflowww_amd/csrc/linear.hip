@@ -377,6 +377,12 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
                     }
                     continue;
                 }
+                if (p.k_frag && n >= 1024 && n < 3072 && ((n - 1024) & 255) < 128) {     // k columns -> fp32 fragments (pepflow_hip.h, k_frag)
+                    const int hd = (n - 1024) >> 8, kch = (n - 1024) & 255, KL_ = p.att_L, bs = m / KL_, j = m - bs * KL_;
+                    *reinterpret_cast<float4*>(p.k_frag + ((((size_t)bs * 8 + hd) * (KL_ >> 4) + (j >> 4)) * 8 + (kch >> 4)) * 256 +
+                                               (((kch >> 2) & 3) * 16 + (j & 15)) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
                 float* dst = p.y + (size_t)m * p.ldy + n;
                 if (vec_ok && n + 3 < p.N) {             // one 16-byte store per lane (the store tail is issue-bound)
                     if (p.gate) {
@@ -629,6 +635,12 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int 
                     }
                     continue;
                 }
+                if (p.k_frag && n >= 1024 && n < 3072 && ((n - 1024) & 255) < 128) {     // k columns -> fp32 fragments (pepflow_hip.h, k_frag)
+                    const int hd = (n - 1024) >> 8, kch = (n - 1024) & 255, KL_ = p.att_L, bs = m / KL_, j = m - bs * KL_;
+                    *reinterpret_cast<float4*>(p.k_frag + ((((size_t)bs * 8 + hd) * (KL_ >> 4) + (j >> 4)) * 8 + (kch >> 4)) * 256 +
+                                               (((kch >> 2) & 3) * 16 + (j & 15)) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
                 float* dst = p.y + (size_t)m * p.ldy + n;
                 if (vec_ok && n + 3 < p.N) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else {
@@ -754,6 +766,7 @@ extern "C" int pf_split_pack_f16(const float* w, int ldw, int N, int K, int tran
 extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
     if (!a || !a->x || (!a->w && !a->w_f16) || (!a->y && !a->att_qk) || a->M <= 0 || a->N <= 0 || a->K <= 0) return PF_E_BADARG;
     if (a->att_qk && !a->single_pass) return PF_E_BADARG;       // (hi / lo operand planes: the form was removed in round 4, see ipa_split.hip)
+    if (a->k_frag && (a->att_qk || !a->pt_rot || a->pt_col0 != 3072 || a->att_L <= 0 || a->att_L % 16 || a->M % a->att_L || !a->w_f16)) return PF_E_BADARG;
     if (a->att_qk && (!a->att_vt || !a->w_f16 || !a->pt_rot || a->pt_col0 != 3072 || a->att_L <= 0 || a->att_L % 16 || a->M % a->att_L)) return PF_E_BADARG;
     if (a->K % 16 || a->ldx % 4 || a->ldx < a->K) return PF_E_BADARG;
     if (!a->w_f16 && (a->ldw % 4 || a->ldw < a->K || ((uintptr_t)a->w & 15))) return PF_E_BADARG;

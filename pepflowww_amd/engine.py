@@ -560,6 +560,13 @@ class DenoiseEngine:
         self.att_vt32 = None
         if self.fused_proj and not self.att_planes:
             self.att_vt32 = torch.zeros(B * 8 * 512 * ((L + 31) // 32 * 32), dtype=torch.float16, device=device)
+        # fp32 mode with the projection LAUNCH (L > 128 or L % 4 != 0 ...) and the two-kernel attention: the k columns of the projection go
+        # to a scratch in the fragment order of the score kernel's first product instead of `proj` (pf_linear_args.k_frag /
+        # pf_ipa_attn_args.k_frag: one contiguous KiB per load instead of sixteen rows x 64 bytes).  PF_K_FRAG=0 / 1 forces it (A/B runs).
+        self.k_frag = None
+        if (not self.fused_proj and precision == "fp32" and L % 16 == 0 and self.pair_dz is not None and
+                {"0": False, "1": True}.get(os.environ.get("PF_K_FRAG", ""), True)):
+            self.k_frag = e(rows, 1024)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         # 16-row groups whose final predictions are wanted (pf_node_tfmr_args.row_on of the LAST block's tail): all of them for the
         # stand-alone step; the sampler marks the groups that hold a generated residue (DeviceSampler.set_context)
@@ -748,6 +755,8 @@ class DenoiseEngine:
             self._proj_args.append(la)
             if self.att_qk is not None:
                 la.att_qk, la.att_vt, la.att_L = self.att_qk.data_ptr(), self.att_vt.data_ptr(), L
+            if self.k_frag is not None:
+                la.k_frag, la.att_L = self.k_frag.data_ptr(), L
             plan.append(e + (lane,))
 
         if not self.fused_proj:
@@ -775,6 +784,8 @@ class DenoiseEngine:
                 ia.att_mode = 2
                 if self.att_qk is not None:
                     ia.att_qk, ia.att_vt = self.att_qk.data_ptr(), self.att_vt.data_ptr()
+            if self.k_frag is not None:
+                ia.k_frag = self.k_frag.data_ptr()
             if self.fused_proj:
                 ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.projp.w16"].data_ptr(), w[f"{b}.projp.b"].data_ptr()
                 if self.att_vt32 is not None:

@@ -331,3 +331,45 @@ def test_attention_planes_in_fragment_order(seeded_sd, B, L, ragged):
     for got, want, what in ((q, y[:, :1024].view(B, L, 1024), "q rows"), (k, yk[..., :128], "k fragments"), (v, yk[..., 128:], "value fragments")):
         err = (got - want).abs()[valid].max().item()
         assert err < 6e-3, (what, err)
+
+
+@pytest.mark.parametrize("B,L,ragged", [(3, 144, True), (64, 144, True), (2, 256, False), (57, 144, False)])
+def test_step_with_the_k_rows_as_fragments_is_bit_identical(seeded_sd, B, L, ragged):
+    """DenoiseEngine.k_frag (fp32 mode with the projection launch, pf_linear_args.k_frag / pf_ipa_attn_args.k_frag, ABI 54): the k
+    columns of the projection go to a scratch in the fragment order of the score kernel's first product instead of `proj`.  Same
+    values, same arithmetic: one denoise step equals the step without it bit for bit -- at row counts that pick each of the
+    projection's kernels, dense and with key ends."""
+    import random
+    from pepflowww_amd.engine import DenoiseEngine
+    rnd = random.Random(B + L)
+    lengths = [rnd.randint(51, L) for _ in range(B)] if ragged else None
+    batch = synth.make_pocket_batch(B, L, 8, seed=9, lengths=lengths)
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    model.load_state_dict(seeded_sd, strict=True)
+    model = model.to(G.dev()).eval()
+    bd = {k: (v.to(G.dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        R1, x1, ang1, seq1, node, edge = model.encode(bd)
+    w = model.ga_encoder.packed_weights(G.dev())
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(B, L, 4, generator=g)
+    Rt = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    xt, at = torch.randn(B, L, 3, generator=g) * 5, torch.rand(B, L, 5, generator=g) * 6
+    st = torch.randint(0, 20, (B, L), generator=g)
+    t = torch.rand(B, 1, generator=g)
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["PF_K_FRAG"] = flag
+        try:
+            eng = DenoiseEngine(w, B, L, G.dev(), precision="fp32")
+        finally:
+            del os.environ["PF_K_FRAG"]
+        assert (eng.k_frag is not None) == (flag == "1") and not eng.fused_proj
+        eng.bind_context(node, edge, bd["res_mask"])
+        eng.set_state(cu(t), cu(Rt), cu(xt), cu(at), cu(st))
+        eng.run()
+        G.sync()
+        m = bd["res_mask"].reshape(-1).bool().cpu()
+        outs.append([eng.rot.cpu()[m], eng.trans.cpu()[m], eng.ang_raw.cpu()[m], eng.logits.cpu()[m]])
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_), float((a_ - b_).abs().max())
