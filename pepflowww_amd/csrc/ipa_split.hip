@@ -574,7 +574,10 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
 // the loop.  (First version: conditional prefetches and guarded stores inside the loops -- hipcc emits s_waitcnt vmcnt(0) at
 // every control-flow join, so the "one tile ahead" loads were never in flight: 108 us per launch at B=64, L=128, 28 % of the
 // wave cycles parked on memory, MFMA pipe 29 % busy.)
-template <bool VEC4, bool FUSE = false, bool PROJ = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
+// KFRAG (without PROJ): the k rows come from pf_ipa_attn_args.k_frag (fp32 fragments written by the projection launch) -- a COMPILE-TIME
+// variant: as a run-time test inside loadk the branch cost the loop its load pipelining (113 -> 166 us at B=64, L=144, and 136 with the
+// fragments: hipcc drains vmcnt at every control-flow join -- the lesson of round 2 once more).
+template <bool VEC4, bool FUSE = false, bool PROJ = false, bool KFRAG = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool KSPLIT = PROJ && !FUSE;         // first product on split f16 MFMAs, k rows as hi | lo fragments (proj_head<true>)
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
             const char* kt_u = kfr_u + (size_t)t * 8192;
 #pragma unroll
             for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(kt_u + s * 1024 + (unsigned)lane * 16u);
-        } else if (a.k_frag) {                      // (uniform) fp32 fragments written by the projection launch (pf_linear_args.k_frag): tile t,
+        } else if constexpr (KFRAG) {               // fp32 fragments written by the projection launch (pf_linear_args.k_frag): tile t,
             const float* kt_f = a.k_frag + ((((size_t)b * H + h) * (L >> 4) + t) * 8) * 256 + lane * 4;   //  16-channel step s = one contiguous KiB
 #pragma unroll
             for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const float4*>(kt_f + s * 256);
@@ -1638,6 +1641,8 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
         if (pj16) {
@@ -1698,6 +1703,9 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const dim3 g16((unsigned)(a->B * H * nrb16)), b16(64 * wpb16);
             if (fuse) hipLaunchKernelGGL((ipa_scores16_kernel<true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
             else hipLaunchKernelGGL(ipa_scores16_kernel<false>, g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);
+        } else if (a->k_frag) {                     // (L % 16 == 0 checked above)
+            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
+            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if (fuse) {
             if ((L & 3) == 0) hipLaunchKernelGGL((ipa_scores_kernel<true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
             else hipLaunchKernelGGL((ipa_scores_kernel<false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * wpb), lds, s, *a, nrb, 16 * wpb, LP, SLD);
