@@ -179,7 +179,7 @@ __device__ __forceinline__ unsigned char gate_byte(const float4& v0, const float
 // DUMP: the training forward also needs h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2) [pairs,192] and the pre-LayerNorm y [pairs,64]
 // (saved for the backward): stored from the accumulator registers where they are formed, natural feature order.
 // ZI / ZO (f16 mode only): the pair tensor is read / written as f16 (pf_edge_transition_args.z_in_f16 / z_out_f16)
-template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false, bool DZ = false>   // DZ: also emit dz_out
+template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false, bool DZ = false, bool ZF = false>   // DZ: also emit dz_out; ZF: the f16 pair tensor on both sides in fragment order (compile-time: see the v4 kernel)
 __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     static_assert(SP || (!ZI && !ZO), "f16 pair tensor: f16 mode only");
     using M = Map<SP, NP, ZI>;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
         // (lane & 7) ^ (pp & 7)
         unsigned zoff[4];
         auto prep_z = [&](const Tile& tl) {
-            if (ZI && a.z_in_frag) {                              // (uniform) fragment order: a row's 2 KiB are its two DMA pieces as they are
+            if constexpr (ZI && ZF) {                             // fragment order: a row's 2 KiB are its two DMA pieces as they are
                 zoff[0] = zoff[1] = (unsigned)(lane * 16);
             } else if constexpr (ZI) {
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
             for (int row = row0; row < row1; ++row) {
                 int i = tl.i0 + row;
                 i = i < L ? i : L - 1;
-                if (ZI && a.z_in_frag) {
+                if constexpr (ZI && ZF) {
                     const int tix = (tl.b * nib + tl.i0 / TI) * njb + tl.j0 / TJ;
                     const unsigned char* base = zg + ((size_t)tix * TI + row) * 2048;
 #pragma unroll
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         if constexpr (ZI) {       // f16 rows: the 16-byte chunk IS the MFMA operand
-                            if (a.z_in_frag)      // (uniform) fragment order: piece s of the row, this lane's own 16 bytes
+                            if constexpr (ZF)     // fragment order: piece s of the row, this lane's own 16 bytes
                                 zh[p][s] = *reinterpret_cast<const half8*>(smem + OFF_Z + (NP * wave + p) * 2048 + s * 1024 + lane * 16);
                             else
                                 zh[p][s] = *reinterpret_cast<const half8*>(smem + OFF_Z + (NP * wave + p) * 2048 + r * 128 + 16 * ((4 * s + g) ^ (r & 7)));
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
                 o4[t].w = ((y[4 * t + 3] - mean) * rstd * gm.w + bt.w) * mk[p];
             }
             if (valid[p] && a.z_out) {                           // (z_out = NULL: the last EdgeTransition of a step, see the v4 kernel)
-                if (ZO && a.z_out_frag) {                        // (uniform) fragment order: piece s = [o4[2 s] | o4[2 s + 1]] of every lane, one contiguous KiB
+                if constexpr (ZO && ZF) {                        // fragment order: piece s = [o4[2 s] | o4[2 s + 1]] of every lane, one contiguous KiB
                     const int tix = (tl.b * nib + tl.i0 / TI) * njb + tl.j0 / TJ;
                     _Float16* zo = reinterpret_cast<_Float16*>(a.z_out) + ((size_t)tix * TI + NP * wave + p) * 1024 + lane * 8;
 #pragma unroll
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64 * (NCW + 2), 1) void edge_transition_v3_kernel(p
 }  // namespace
 
 // launcher used by pf_edge_transition_fwd (edge_transition.hip) when args.w_stream is set
-template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false, bool DZ = false>
+template <bool DUMP, bool SP, int NP, bool ZI = false, bool ZO = false, bool DZ = false, bool ZF = false>
 static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
     using M = Map<SP, NP, ZI>;
     const int nib = (a->L + M::TI - 1) / M::TI, njb = (a->L + TJ - 1) / TJ;
@@ -734,11 +734,11 @@ static int et3_launch(const pf_edge_transition_args* a, hipStream_t stream, int 
     const int grid = (int)(nt < ncu ? nt : ncu);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO, DZ>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO, DZ, ZF>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
         attr_set = true;
     }
-    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO, DZ>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    hipLaunchKernelGGL((edge_transition_v3_kernel<DUMP, SP, NP, ZI, ZO, DZ, ZF>), dim3((unsigned)grid), dim3(64 * (NCW + 2)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -761,6 +761,10 @@ int pf_edge_transition_v3_launch(const pf_edge_transition_args* a, hipStream_t s
         return PF_E_BADARG;
     const bool dz = a->dz_out != nullptr;
     if (a->single_pass) {
+        if ((a->z_in_frag != 0) != (a->z_out_frag != 0) && a->z_out) return PF_E_BADARG;           // fragment order: on BOTH sides (one kernel variant)
+        if (a->z_in_f16 && a->z_out_f16 && a->z_in_frag)
+            return dz ? et3_launch<false, true, PF_ET_SP_NP, true, true, true, true>(a, stream, ncu) : et3_launch<false, true, PF_ET_SP_NP, true, true, false, true>(a, stream, ncu);
+        if (a->z_in_frag || a->z_out_frag) return PF_E_BADARG;                                      // (f16 in AND out only)
         if (a->z_in_f16 && a->z_out_f16)
             return dz ? et3_launch<false, true, PF_ET_SP_NP, true, true, true>(a, stream, ncu) : et3_launch<false, true, PF_ET_SP_NP, true, true>(a, stream, ncu);
         if (a->z_out_f16)

@@ -184,7 +184,9 @@ template <int I, int N, class F> __device__ __forceinline__ void cfor(F&& f) {
 }
 #define CI(name, ic) constexpr int name = decltype(ic)::value
 
-template <bool SP, int NT, bool ZI, bool ZO, bool DZ>
+// ZF: the fp32 pair tensor on both sides in the kernel's fragment order (pf_edge_transition_args.z_in_frag / z_out_frag) -- a compile-time
+// variant: tested at run time the two uniform branches cost the kernel ~1 % in BOTH settings (true A/B against the build before them)
+template <bool SP, int NT, bool ZI, bool ZO, bool DZ, bool ZF = false>
 __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_eu(2 / NT, 2 / NT))) void edge_transition_v4_kernel(pf_edge_transition_args a, int ntiles, int nib, int njb) {
     static_assert(SP || (!ZI && !ZO), "f16 pair tensor: f16 mode only");
     constexpr int NW = 8 / NT;                 // waves
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
             int ic = t2.i0 + RW * wave + 2 * t + rl;
             ic = ic < L ? ic : L - 1;
             const size_t pair = (size_t)(t2.b * L + ic) * L + jc;
-            if (!ZI && a.z_in_frag) {                           // (uniform) fragment order: piece k = 2 ks + half of block (tile, wave, t)
+            if constexpr (!ZI && ZF) {                          // fragment order: piece k = 2 ks + half of block (tile, wave, t)
                 const int tix = (t2.b * nib + t2.i0 / TI) * njb + t2.j0 / TJ;
                 const float4* src = reinterpret_cast<const float4*>(zg + ((size_t)(tix * NW + wave) * NT + t) * 8192) + lane;
 #pragma unroll
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
                             half4 h;
                             h[0] = (_Float16)o[mt][4 * b]; h[1] = (_Float16)o[mt][4 * b + 1]; h[2] = (_Float16)o[mt][4 * b + 2]; h[3] = (_Float16)o[mt][4 * b + 3];
                             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(a.z_out) + pidx[t] * 64 + f0) = h;
-                        } else if (a.z_out_frag) {             // (uniform) piece 4 mt + b of block (tile, wave, t): one contiguous KiB per store
+                        } else if constexpr (ZF) {             // piece 4 mt + b of block (tile, wave, t): one contiguous KiB per store
                             const int tix = (tl.b * nib + tl.i0 / TI) * njb + tl.j0 / TJ;
                             float* d = a.z_out + ((size_t)(tix * NW + wave) * NT + t) * 2048 + (4 * mt + b) * 256 + lane_o * 4;
                             *reinterpret_cast<float4*>(d) = make_float4(o[mt][4 * b], o[mt][4 * b + 1], o[mt][4 * b + 2], o[mt][4 * b + 3]);
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(64 * (8 / NT), 1) __attribute__((amdgpu_waves_per_e
     }
 }
 
-template <bool SP, int NT, bool ZI, bool ZO, bool DZ>
+template <bool SP, int NT, bool ZI, bool ZO, bool DZ, bool ZF = false>
 int et4_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
     using M = Map<SP, ZI>;
     const int nib = (a->L + TI - 1) / TI, njb = (a->L + TJ - 1) / TJ;
@@ -646,11 +648,11 @@ int et4_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
     const int grid = (int)(nt < ncu ? nt : ncu);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v4_kernel<SP, NT, ZI, ZO, DZ>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v4_kernel<SP, NT, ZI, ZO, DZ, ZF>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
         attr_set = true;
     }
-    hipLaunchKernelGGL((edge_transition_v4_kernel<SP, NT, ZI, ZO, DZ>), dim3((unsigned)grid), dim3(64 * (8 / NT)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
+    hipLaunchKernelGGL((edge_transition_v4_kernel<SP, NT, ZI, ZO, DZ, ZF>), dim3((unsigned)grid), dim3(64 * (8 / NT)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
     PF_CHECK_LAUNCH();
     return 0;
 }
@@ -669,6 +671,7 @@ int pf_edge_transition_v4_launch(const pf_edge_transition_args* a, hipStream_t s
     if (a->dump_h1 || a->dump_h2 || a->dump_y) return PF_E_BADARG;                 // the training dumps live in the v3 kernel
     if ((a->z_in_f16 || a->z_out_f16) && !a->single_pass) return PF_E_BADARG;
     if ((a->z_in_frag || a->z_out_frag) && (a->single_pass || (a->L & 15) != 0)) return PF_E_BADARG;   // fragment order: fp32 pair tensor, whole tiles
+    if ((a->z_in_frag != 0) != (a->z_out_frag != 0) && a->z_out) return PF_E_BADARG;                  // ... on BOTH sides (one kernel variant)
     const int ncu = pf_cu_count();
     const bool dz = a->dz_out != nullptr;
     if (a->single_pass) {
@@ -681,5 +684,6 @@ int pf_edge_transition_v4_launch(const pf_edge_transition_args* a, hipStream_t s
     }
     // (a two-tile form -- NT = 2: four 512-register waves, every fragment feeding 64 pairs -- measured 646 / 360 us against 421 / 214:
     //  above 256 registers hipcc shuttles values between the VGPR and AGPR halves of the file; its instantiations are not built)
+    if (a->z_in_frag) return dz ? et4_launch<false, 1, false, false, true, true>(a, stream, ncu) : et4_launch<false, 1, false, false, false, true>(a, stream, ncu);
     return dz ? et4_launch<false, 1, false, false, true>(a, stream, ncu) : et4_launch<false, 1, false, false, false>(a, stream, ncu);
 }
