@@ -146,8 +146,9 @@ def test_step_with_and_without_the_projection_launch(seeded_sd, B, L, precision)
 def test_sample_is_stable_from_run_to_run(seeded_sd, precision, B, L, ragged):
     """Six runs of FlowModel.sample (graph replay and eager, interleaved) on the same noise give the same bits.  The shapes put
     waves that leave early (rows beyond a sample's key end, padded batches) beside the fused phases of the score kernels
-    (projection inside: 64 <= L <= 128; pair aggregation inside: f16 mode, and fp32 mode at L <= 64) -- a form of the projection
-    prologue with helper waves that returned after their last barrier failed exactly this check."""
+    (projection inside: 64 <= L <= 128; pair aggregation inside: f16 mode, and fp32 mode at L <= 64).  Two ordering bugs of the
+    projection prologue failed exactly this check: staging waits that counted stores, and a bare s_barrier in front of
+    which a wave's own LDS writes had not been waited for."""
     import random
     rnd = random.Random(B * 1000 + L)
     lengths = [rnd.randint(L // 3, L) for _ in range(B)] if ragged else None
