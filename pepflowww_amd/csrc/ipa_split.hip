@@ -237,8 +237,13 @@ struct PjW { half8 h[4], l[4]; };
 // (LDS-DMA, two 24 KiB buffers, the next chunk in flight under the current chunk's MFMAs) and every wave reads its operands from
 // there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
 // 64 B / clk L1 path and the prologue cost what the projection launch it replaced had cost.
+// role: 0 = this wave projects all 31 tiles of its rows; with HELPER waves (L <= 64: twice as many waves as query tiles, the second half
+// leaves after the prologue) 1 = the query wave takes the q and query-point tiles (10), 2 = its helper the k | v and key / value-point
+// tiles (21) of the same rows -- those results go to the scratch / the LDS tables anyway, nothing has to be handed over.  tile = the
+// 16-row tile of the sample this wave projects (its own index as a query wave, its partner's as a helper).
+__device__ __forceinline__ constexpr bool pj_q_tile(int idx) { return idx < 8 || idx == 24 || idx == 25; }
 template <bool KS>                           // KS: the k rows as hi | lo f16 operand fragments (first product on split f16 MFMAs); else fp32 fragments
-__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, int tile, float* KP,
+__device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, int role, int tile, float* KP,
                                           _Float16* VPT /* [2][48][VTL] value points, hi | lo */, int VTL, _Float16* VTH /* this head's [8 tiles][VTG / 32 steps][hi | lo][64 lanes][8] */, int VTG,
                                           unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
                                           float* PB /* [PJ_TILES * 16] the head's bias, staged here */,
@@ -326,21 +331,21 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");
         pj_wait_vm_dyn(PJ_NB == 2 ? 0 : NDY * ppw);
         // (the bare s_barrier does not wait for this wave's own LDS writes, unlike __syncthreads(): the bias staging and the zero fill of
-        //  the point planes above must have LANDED before anybody passes the first barrier -- without this wait a wave could read a bias
-        //  another wave had not finished writing; masked for a while by the waits hipcc put at the helper-role branches, found when they went)
+        //  the point planes above must have LANDED before anybody passes the first barrier)
         if constexpr (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
         if (wave_on) {
             PjW wa, wb;
-            ldfrag(c, 0, wa);
+            if (role == 0) ldfrag(c, 0, wa);
             cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
                 constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
                 if constexpr (idx < PJ_TILES) {
-                  {
+                  if (role == 0 || (role == 1) == pj_q_tile(idx)) {          // (wave-uniform)
                     PjW& w = (tl & 1) ? wb : wa;
-                    if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    if (role != 0) ldfrag(c, tl, w);                        // (a tile here and there: requested at its use)
+                    else if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
                     constexpr bool VTILE = idx >= 16 && idx < 24;
                     f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -427,6 +432,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         // hand-off through `proj` no longer leans on that ordering rule
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // + wave-private LDS hand-off of the query points
         __builtin_amdgcn_wave_barrier();
+        if (role == 2) return;                                            // (a helper: no queries of its own)
 #pragma unroll
         for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);
     }
@@ -592,7 +598,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const int h = (lid / nrb) % H;
     const int b = lid / (nrb * H);
     const size_t rowb = (size_t)b * L;
-    const int i0 = rb * rows_per_block + wave * 16;
+    // PROJ with helper waves (blockDim = 2 x the query tiles, L <= 64): wave ntq + w helps query wave w through the prologue and leaves
+    const int ntq = rows_per_block >> 4;
+    const bool helper = PROJ && wave >= ntq;
+    const int i0 = rb * rows_per_block + (helper ? wave - ntq : wave) * 16;
     // Le: keys / query rows from here on are masked (pf_ipa_attn_args.key_end; L without it): nothing beyond is read or written
     const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
     const int kt = (Le + 15) >> 4, ktf = Le >> 4;  // key tiles, full key tiles
@@ -653,14 +662,15 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         // rows in this workgroup: the launcher guarantees nrb == 1.)
         for (int j = tid; j < LPe; j += blockDim.x) MJ[j] = j < L ? a.mask[rowb + min(j, L - 1)] : 0.f;
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
-        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + wave * 16 * 24;   //  sizes the allocation for staging + query points)
-        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (blockDim.x >> 6) * 16 * 24;
+        float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (helper ? 0 : wave) * 16 * 24;   //  sizes the allocation for staging + query points)
+        float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + ntq * 16 * 24;
+        const int role = (int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0;
         const int VTG = (L + 31) & ~31;                // key stride of the value planes (pf_ipa_attn_args.att_vt as this launch's scratch)
         _Float16* VTH = reinterpret_cast<_Float16*>(const_cast<void*>(a.att_vt)) + ((size_t)b * H + h) * 512 * VTG;   // values 256 VTG | k rows 256 VTG (as f16 counts)
-        proj_head<KSPLIT>(a, rowb, iq, h, i0 + r, LPe, wave_on, wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
+        proj_head<KSPLIT>(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
                   PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
-        if (!wave_on) return;
+        if (!wave_on || helper) return;
         loadk(0, kf);
         // the query operand of the first product: K-step s = the accumulator registers of q tiles 2 s | 2 s + 1, split in place
 #pragma unroll
@@ -1670,11 +1680,11 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
             const size_t ldsp = lds > need ? lds : need;
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
-            // (four more waves per workgroup at L <= 64 that took the k | v / point tiles of the prologue measured SLOWER against a build
-            //  without the run-time tests they need: 0.647 vs 0.643 ms at cfg2 -- removed)
-            const dim3 gridp((unsigned)(a->B * H * nrb));
-            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), gridp, dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
-            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), gridp, dim3(64 * wpb), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            // L <= 64: as many helper waves as query waves for the prologue (proj_head roles; PF_PROJ_HELPERS=0 turns them off for A/B runs)
+            static const bool no_helpers = getenv("PF_PROJ_HELPERS") && atoi(getenv("PF_PROJ_HELPERS")) == 0;
+            const int nwv = (wpb <= 4 && !no_helpers) ? 2 * wpb : wpb;
+            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);
