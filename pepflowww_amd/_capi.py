@@ -297,13 +297,14 @@ def dptr(t, dtype=torch.float32, name="tensor"):
 
 
 class capture_guard:
-    """Around a hipGraph capture: the cyclic garbage collector is run once and then held off.  A collection that happens to run
-    DURING capture can finalise device objects of earlier work (a dropped engine's captured graphs, events, pooled blocks); destroying
+    """Around a hipGraph capture: the cyclic garbage collector is held off (NOT run).  A collection that happens to run DURING
+    capture can finalise device objects of earlier work (a dropped engine's captured graphs, events, pooled blocks); destroying
     those while a stream is capturing invalidates the capture and aborts the process (seen once in ~15 runs of the GPU suite, inside the
-    training step's capture: "Fatal Python error: Aborted ... Garbage-collecting")."""
+    training step's capture: "Fatal Python error: Aborted ... Garbage-collecting").  Holding the collector off is all that needs:
+    round 4 also ran a full gc.collect() on entry, which cost 40 - 70 ms per capture once a process held a few engines -- 85 - 135 ms
+    of every FlowModel.sample() call that captured (BENCH_r04 per_call: 19 - 23 % overhead)."""
     def __enter__(self):
         import gc
-        gc.collect()
         self._was = gc.isenabled()
         gc.disable()
         return self

@@ -201,7 +201,11 @@ __device__ __forceinline__ void pj_glds16(const void* sbase, unsigned voff, unsi
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
+    // s_nop 4: FIVE wait states between the v_readfirstlane that forms the base (it depends on the wave index: a VALU write of the SGPR
+    // pair) and the vector memory instruction reading it (CDNA3/4 ISA, "manually inserted wait states"; hipcc's hazard recognizer inserts
+    // them for its own instructions and cannot see into an asm statement; edge_transition_v4.hip's bases are SALU results and only need
+    // the M0 wait state).  Rounds 3 - 4 had `s_nop 0` here: a spec violation, though no failure could be tied to it.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void pj_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant): at most n vector memory operations of this

@@ -174,7 +174,7 @@ class GAEncoder(nn.Module):
     # PackedWeights depends on (device, parameter version) only; engines (workspaces + launch plan + captured graphs) on
     # (B, L, device, precision).  inference.py:64-99 loops over complexes of different length: the packed weights are built once,
     # and the most recently used ENGINE_CACHE engines stay alive, so a length seen before costs no set-up at all.
-    ENGINE_CACHE = 8
+    ENGINE_CACHE = 32         # (count bound; the byte bound below is the one that matters on a 288 GB part)
     # ... bounded in BYTES as well: an engine at B=64, L=128 with a 200-step sampler holds ~1-1.5 GB (pair-sized
     # workspaces, trajectory buffers, two captured graphs).  The cache may keep at most ENGINE_CACHE_FRACTION of the device's
     # memory (or ENGINE_CACHE_BYTES when set); least recently used engines are dropped first, and an allocation failure while

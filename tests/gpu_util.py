@@ -1,5 +1,6 @@
 """Thin test-side wrappers that call the C-ABI entry points on torch device tensors."""
 import ctypes as C
+import os
 
 import torch
 
@@ -114,7 +115,7 @@ def ipa_projection(s, w16, bias, rot, trans):
 
 
 def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None,
-              dz=None, fused_pair=False, points=None, fused_proj=None):
+              dz=None, fused_pair=False, points=None, fused_proj=None, debug_pts=None):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
     variant=1); head_group: force a head-group split of the one-kernel form; dz: [B,L,L,16] pair values W_dz z (no bias) for the
     two-kernel form's pair aggregation (z may then be None); fused_pair: that aggregation inside the score kernel (p_out may be None)."""
@@ -125,6 +126,8 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     # inside the score kernel (pf_ipa_attn_args.s_in), `proj` is its k | v scratch and no point buffer is read
     if fused_proj is not None:
         qp = kp = vp = None
+        if debug_pts is not None:          # (dev builds with -DPJ_DBG_QP: the query points as read back / as written)
+            qp, kp = debug_pts
     elif points is not None:
         qp, kp, vp = points
     else:
@@ -149,6 +152,8 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
         ia.s_in, ia.proj_w_f16, ia.proj_bias = _p(fused_proj[0]), _p(fused_proj[1]), _p(fused_proj[2])
         # the form's scratch for the head's value planes (hi | lo f16, transposed per (sample, head)): finite on entry
         vt = torch.zeros(B * 8 * 512 * ((L + 31) // 32 * 32), dtype=torch.float16, device=d)
+        if os.environ.get("PF_TEST_POISON_VT"):     # (dev: a fragment read before it was written shows as NaN; L % 32 == 0 only)
+            vt.fill_(float("nan"))
         ia.att_vt = _p(vt)
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()

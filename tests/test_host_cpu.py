@@ -298,7 +298,7 @@ def test_fragment_order_layouts_are_permutations():
 
 
 def test_capture_guard_holds_the_garbage_collector_off_and_restores_it():
-    """_capi.capture_guard (around every hipGraph capture): collects once, keeps the cyclic collector off inside, restores the caller's
+    """_capi.capture_guard (around every hipGraph capture): keeps the cyclic collector off inside (without running it), restores the caller's
     setting afterwards -- also when the body raises, and when the collector was already off."""
     import gc
     from pepflowww_amd import _capi
