@@ -229,18 +229,34 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
     return elapsed, info
 
 
+def kernel_src_sha():
+    """Hash of the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): what the PMC passes record and the bench line compares --
+    `git rev-parse` is not available on the GPU box (the snapshot ships without .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pepflowww_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pepflowww_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def pmc_traffic(workload, precision):
     """HBM bytes per launch of the two big kernels from the PMC passes recorded under profiles/ (rocprofv3 cannot run
-    inside this process; tools/pmc_traffic.sh regenerates the file); corrected as MI355X_MICROARCH.md prescribes."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    inside this process; tools/pmc_traffic.sh regenerates the file); corrected as MI355X_MICROARCH.md prescribes.
+    Returns (per-kernel dict, source string, stale): stale = the file was recorded for other kernel sources than the ones timed here."""
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 d = json.load(f)
             key = workload if precision == "fp32" else f"{workload}_{precision}"
-            return d[key], f"profiles/{rnd}/pmc_traffic.json ({d.get('_commit', 'commit not recorded')})"
+            stale = d.get("_src_sha") != kernel_src_sha()
+            return d[key], f"profiles/{rnd}/pmc_traffic.json (commit {d.get('_commit', 'not recorded')}, kernel sources {d.get('_src_sha', 'not recorded')})", stale
         except Exception:
             continue
-    return {}, None
+    return {}, None, None
 
 
 def sclk_under_load(smp, use_graph):
@@ -369,7 +385,7 @@ def main():
     ku = info["kernel_us"]
     et_s = ku["pf_edge_transition_fwd"]["avg_launch_us"] * 1e-6
     ipa_s = ku["pf_ipa_attn_fwd"]["avg_launch_us"] * 1e-6
-    traffic, traffic_src = pmc_traffic(args.workload, prec)
+    traffic, traffic_src, traffic_stale = pmc_traffic(args.workload, prec)
     t_et = (traffic.get("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") or traffic.get("edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
     t_ipa = (traffic.get("ipa_two_kernel_form") or traffic.get("ipa_attn_kernel") or {}).get("hbm_bytes_corrected")
     step_us = sum(v["us_per_step"] for v in ku.values())
@@ -430,6 +446,18 @@ def main():
     wst = whole_step_traffic(traffic, traffic_src, zb * pairs)
     if wst is not None:
         out["whole_step_traffic"] = wst
+    # The driver's record keeps `roofline` and `cpu_baseline` whole and only the NAMES of the other keys: the BASELINE headline
+    # fraction (whole-step HBM roofline), the counted / algorithmic traffic ratio, the clock the box held and whether the counted
+    # traffic belongs to the kernel sources that were timed ride inside `roofline` as well.
+    for rf in (out["roofline"], out["roofline_other"]):
+        rf["hbm_frac"] = out["hbm_roofline"]["frac"]
+        rf["hbm_frac_note"] = f"whole step: {zb} algorithmic B per pair and step x pairs / ms_per_step / 8 TB/s (BASELINE.json metric)"
+        rf["whole_step_traffic_ratio"] = wst["ratio"] if wst is not None else None
+        rf["sclk_mhz"] = (info.get("sclk") or {}).get("sclk_mhz")
+        rf["kernel_src_sha"] = kernel_src_sha()
+        rf["traffic_stale"] = traffic_stale
+        if traffic_stale:
+            rf["traffic_note"] = "STALE (recorded for other kernel sources than the ones timed here; tools/pmc_traffic.sh regenerates it) -- " + rf["traffic_note"]
     if wl.get("variable"):
         out["config"]["real_residues_per_gpu"] = info["real_residues"]
         out["value_real_residues"] = world * info["real_residues"] * K / elapsed

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 54
+#define PF_ABI_VERSION 55
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 /* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
  * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
@@ -232,6 +232,10 @@ typedef struct {
     const float* k_frag;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
+/* 1 when pf_ipa_attn_fwd would run the projection-inside form (s_in) at this length (fp32 operands: f16_mode = 0; f16 operand
+ * planes formed in LDS, att_mode 2: f16_mode = 1), 0 when it would refuse it (more than one score workgroup per (sample, head),
+ * L % 4 / L % 16, LDS beyond 160 KiB): asked once per launch plan (ABI 55). */
+int pf_ipa_proj_inside_ok(int L, int f16_mode);
 /* the `bias` operand above for a pair tensor that EdgeTransition did not produce (block 0: edge_embed is constant over the
  * sampler steps -> computed once per sample() call): bias [B,8,L,L] = sqrt(1/3)(linear_b(z)), ipa_pytorch.py:393-404 */
 int pf_pair_bias_fwd(const float* z, const float* w_b, const float* b_b, float* bias, int B, int L, pf_stream_t stream);

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PF_LIB_PATH: another build of the same library -- same-box A/B runs of kernel variants, tools/dev)
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 54
+ABI_VERSION = 55
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -185,6 +185,7 @@ _SIGNATURES = {
     "pf_input_mixer_fwd": ([C.POINTER(InputMixerArgs), _fp], _i),
     "pf_ipa_points_fwd": ([C.POINTER(IpaPointsArgs), _fp], _i),
     "pf_ipa_attn_fwd": ([C.POINTER(IpaAttnArgs), _fp], _i),
+    "pf_ipa_proj_inside_ok": ([_i, _i], _i),
     "pf_pair_bias_fwd": ([_fp, _fp, _fp, _fp, _i, _i, _fp], _i),
     "pf_seq_attn_fwd": ([C.POINTER(SeqAttnArgs), _fp], _i),
     "pf_node_head_fwd": ([C.POINTER(NodeHeadArgs), _fp], _i),

@@ -24,7 +24,6 @@ def _zeros(*shape, device, dtype=torch.float32):
     node was observed to race with following atomics when the training step is replayed as a hipGraph)."""
     return torch.full(shape, 0, dtype=dtype, device=device)
 
-import os
 
 from . import _capi
 
@@ -52,10 +51,10 @@ def _gemm(*args, **kw):
     _capi.check(_capi.load().pf_gemm_f32(C.byref(_gemm_args(*args, **kw)), _capi.stream_ptr()), "pf_gemm_f32")
 
 
-ET_GATE_BITS = os.environ.get("PF_ET_GATE_BITS", "1") != "0"    # EdgeTransition backward: ReLU gates as bits from the forward (A/B switch)
-TRAIN_ATTN_TWO_KERNEL = os.environ.get("PF_TRAIN_ATTN2", "1") != "0"   # the two-kernel attention forward below 256 query tiles too (A/B switch)
-PAIR_DW_MERGED = os.environ.get("PF_PAIR_DW_MERGED", "1") != "0"   # dW of linear_b and down_z as one [24,64] product (A/B switch)
-GROUP_GEMM = os.environ.get("PF_GROUP_GEMM", "1") != "0"    # independent products of the IPA backward in one launch (A/B switch)
+ET_GATE_BITS = True    # EdgeTransition backward: ReLU gates as bits from the forward (A/B switch)
+TRAIN_ATTN_TWO_KERNEL = True   # the two-kernel attention forward below 256 query tiles too (A/B switch)
+PAIR_DW_MERGED = True   # dW of linear_b and down_z as one [24,64] product (A/B switch)
+GROUP_GEMM = True    # independent products of the IPA backward in one launch (A/B switch)
 GEMM_GROUP_MAX = 6
 
 
@@ -72,11 +71,11 @@ def _gemm_group(arg_list):
         _capi.check(lib.pf_gemm_f32_group(arr, len(part), _capi.stream_ptr()), "pf_gemm_f32_group")
 
 
-DUAL_GEMM = os.environ.get("PF_DUAL_GEMM", "1") != "0"      # dx and dW of a row-sized Linear backward in one launch (A/B switch)
+DUAL_GEMM = True      # dx and dW of a row-sized Linear backward in one launch (A/B switch)
 
 
 SPLIT_MIN_ROWS = 8192          # pair-sized products go to the split-precision kernel of the inference path
-TN_WIDE_MIN_ROWS = int(os.environ.get("PF_TN_WIDE_MIN_ROWS", "8192"))
+TN_WIDE_MIN_ROWS = 8192
 
 
 class GradArena:
@@ -415,7 +414,7 @@ class NodeTrackBlock:
 
     # forward of the two transformer layers + block tail on the fused inference kernels (pf_node_tfmr_fwd with dumps) instead of
     # ~25 launches of Linear / LayerNorm / attention / mask (PF_NODE_FUSED_FWD=0: unfused)
-    FUSED_FORWARD = os.environ.get("PF_NODE_FUSED_FWD", "1") != "0"
+    FUSED_FORWARD = True
     _SCRATCH = {}
 
     def fused_weight_names(self):
@@ -776,8 +775,8 @@ class EdgeTransitionBlock:
         self.W, self.b, self.B, self.L, self.mask = W, b, B, L, mask
 
     # forward on the persistent inference kernel (with h1 / h2 / y dumps) instead of three Linears (PF_ET_FUSED_FWD=0: unfused)
-    FUSED_FORWARD = os.environ.get("PF_ET_FUSED_FWD", "1") != "0"
-    FUSED_BACKWARD = os.environ.get("PF_ET_FUSED_BWD", "1") != "0"      # the dx chain of the backward as one kernel (A/B switch)
+    FUSED_FORWARD = True
+    FUSED_BACKWARD = True      # the dx chain of the backward as one kernel (A/B switch)
 
     def _forward_fused(self, s, z, n, x, em):
         """z' = mask * LN(Wf(h2 + x) + bf) by pf_edge_transition_fwd's persistent kernel, which also stores h1, h2 and the

@@ -1803,23 +1803,22 @@ extern "C" int pf_seq_attn_bwd(const float* qkv, const float* mask, const float*
     if (!qkv || !mask || !g_out || !g_qkv || !stats || B <= 0 || L <= 0) return PF_E_BADARG;
     if (L <= SQ_L) {
         const size_t lds = ((size_t)4 * SQ_L * SQ_LDQ + SQ_L * SQ_LDX + SQ_L) * sizeof(float);
-        static bool attr_m = false;
-        if (!attr_m) { (void)hipFuncSetAttribute((const void*)seq_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
+        static PfOncePerDevice attr_m;
+        if (attr_m.first()) { (void)hipFuncSetAttribute((const void*)seq_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         hipLaunchKernelGGL(seq_attn_bwd_mfma_kernel, dim3((unsigned)(B * 4)), dim3(512), lds, (hipStream_t)stream, qkv, mask, g_out, g_qkv, B, L);
         PF_CHECK_LAUNCH();
         return 0;
     }
     if (L <= 256) {
         const size_t lds = ((size_t)4 * L * (AD + 1) + L) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PfOncePerDevice attr_set;
+        if (attr_set.first()) {
             (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)seq_attn_bwd_lds_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
         }
         // row chunks of 256 / TPR rows (every thread of a workgroup has a row): TPR = 8 (4 features per thread) while that
         // still leaves the chip short of workgroups, else fewer threads per row
@@ -2031,12 +2030,11 @@ extern "C" int pf_gemm_tn_wide(const float* A, int lda, int M, const float* B, i
     hipStream_t s = (hipStream_t)stream;
     constexpr long long cap = 256;                  // workgroups of the whole-C kernels: one per CU
     constexpr int use_split = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     // the split-precision kernels take whole 32-row chunks; a ragged tail (< 32 rows) goes through the fp32 kernel
     const bool split = use_split && R >= WK;
@@ -2086,10 +2084,9 @@ extern "C" int pf_gemm_tn_sum2(const float* A, int lda, int M, const float* B, c
     if (!A || !B || !B2 || !C || M <= 0 || N <= 0 || R <= 0 || M > 64 || N > 192 || R % WK) return PF_E_BADARG;
     if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)B2) & 15)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     long long nwg = (R + 4 * WK - 1) / (4 * WK);
     if (nwg > 256) nwg = 256;
@@ -2124,11 +2121,10 @@ extern "C" int pf_gemm_tn_cat(const float* A, int lda, int M, const float* B2, c
     if (B2 ? M > 64 : M > 192) return PF_E_BADARG;
     if ((M & 3) || (lda & 3) || (((uintptr_t)A | (uintptr_t)z | (uintptr_t)n | (uintptr_t)B2) & 15)) return PF_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6, 1, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<6, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     long long nwg = (R + 4 * WK - 1) / (4 * WK);
     if (nwg > 256) nwg = 256;

@@ -514,3 +514,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 #define PF_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: the launchers' "done once" flags are kept per device
+// (a process that drives a second GPU launched its > 64 KiB-LDS kernels there without the raised limit).
+struct PfOncePerDevice {
+    bool done[32] = {};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 31;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};

@@ -646,11 +646,10 @@ int et4_launch(const pf_edge_transition_args* a, hipStream_t stream, int ncu) {
     const long long nt = (long long)a->B * nib * njb;
     if (nt > 0x7fffffffLL || (long long)a->B * a->L > 0x7fffffffLL) return PF_E_TOOLARGE;
     const int grid = (int)(nt < ncu ? nt : ncu);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(edge_transition_v4_kernel<SP, NT, ZI, ZO, DZ, ZF>), hipFuncAttributeMaxDynamicSharedMemorySize, M::LDS_BYTES) != hipSuccess)
             return PF_E_BADARG;
-        attr_set = true;
     }
     hipLaunchKernelGGL((edge_transition_v4_kernel<SP, NT, ZI, ZO, DZ, ZF>), dim3((unsigned)grid), dim3(64 * (8 / NT)), M::LDS_BYTES, stream, *a, (int)nt, nib, njb);
     PF_CHECK_LAUNCH();

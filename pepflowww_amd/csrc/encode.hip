@@ -371,10 +371,9 @@ extern "C" int pf_edge_features_fwd(const pf_edge_feat_args* a, pf_stream_t stre
     const long long nblk = (npairs + EP - 1) / EP;
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
     const size_t lds = (size_t)(EP * LDF + 2 * EP * LDH) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)edge_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     if (a->softplus_ws)
         hipLaunchKernelGGL(softplus_table_kernel, dim3((484 * 225 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a->distcoef, a->softplus_ws, 484 * 225);

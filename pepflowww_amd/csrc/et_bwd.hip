@@ -221,11 +221,10 @@ extern "C" int pf_et_bwd_chain(const pf_et_bwd_args* a, pf_stream_t stream) {
     if (nblk > 0x7fffffffLL) return PF_E_TOOLARGE;
     const size_t lds = (size_t)(2 * P * LDHh + 2 * P * LDZh) * sizeof(_Float16);
     // > 64 KiB of dynamic LDS: the limit is raised explicitly, once per kernel variant, like every other kernel above 64 KiB here
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[bits]) {
+    static PfOncePerDevice attr_set[2];
+    if (attr_set[bits].first()) {
         const void* fn = bits ? reinterpret_cast<const void*>(et_bwd_chain_kernel<P, true>) : reinterpret_cast<const void*>(et_bwd_chain_kernel<P, false>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_E_BADARG;
-        attr_set[bits] = true;
     }
     if (bits) hipLaunchKernelGGL((et_bwd_chain_kernel<P, true>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, *a, a->npairs);
     else hipLaunchKernelGGL((et_bwd_chain_kernel<P, false>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, *a, a->npairs);

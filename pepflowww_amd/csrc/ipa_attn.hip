@@ -641,10 +641,9 @@ int launch_attn(const pf_ipa_attn_args& a, hipStream_t s) {
     const int LDS_S = LP + 4;
     const size_t lds = ((size_t)TI * HG * LDS_S + TI * HG * 24 + TI * HG * 36 + NW * HG * 64 * (HG < 4 ? 4 : 1)) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)ipa_attn_kernel<HG, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const int tiles = (a.L + TI - 1) / TI;
     hipLaunchKernelGGL((ipa_attn_kernel<HG, NW>), dim3((unsigned)(a.B * tiles * (H / HG))), dim3(64 * NW), lds, s, a, LP, LDS_S);

@@ -438,10 +438,9 @@ extern "C" int pf_ipa_bwd_rows(const pf_ipa_bwd_args* a, pf_stream_t stream) {
     const int LP = (a->L + 3) / 4 * 4;
     const size_t lds = ((size_t)3 * H * LP + (size_t)LP * 16 + 288 * 2 + 8) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)ipa_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(ipa_bwd_rows_kernel, dim3((unsigned)(a->B * a->L)), dim3(256), lds, (hipStream_t)stream, *a, LP);
     PF_CHECK_LAUNCH();

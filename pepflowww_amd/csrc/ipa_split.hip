@@ -1613,6 +1613,34 @@ __global__ __launch_bounds__(256) void ipa_pair_dz16_kernel(pf_ipa_attn_args a) 
 }  // namespace
 
 // two-kernel IPA (called by pf_ipa_attn_fwd, ipa_attn.hip): requires a->bias and a->p_out, L <= 256
+// Would pf_ipa_split_launch accept the projection-inside form (pf_ipa_attn_args.s_in) at this length?  The engine asks at PLAN time
+// (the form was chosen from (L, precision) alone and a refusal surfaced as PF_E_BADARG / PF_E_TOOLARGE on every step); the
+// conditions are the launcher's own (same LDS arithmetic, same wave cap) -- keep the two in step.
+extern "C" int pf_ipa_proj_inside_ok(int L, int f16_mode) {
+    if (L < 1) return 0;
+    const int LP = (L + 15) & ~15, SLD = LP + 4 < 36 ? 36 : LP + 4, tiles = LP >> 4;
+    if (f16_mode) {
+        if ((L & 15) != 0 || tiles > WMAX) return 0;
+        const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
+        const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float);
+        const size_t swb = (size_t)tiles * 16 * SLD16 * sizeof(float), stg = (size_t)PJ16_STAGE_B + (size_t)tiles * 1536 + (size_t)PJ_TILES * 64;
+        const size_t lds16 = fixed16 + (swb > stg ? swb : stg) + ((size_t)L * KLS + (size_t)PF_ATT_VROWS * (L32 + 8)) * sizeof(_Float16);
+        return lds16 <= 160 * 1024;
+    }
+    if ((L & 3) != 0) return 0;
+    const size_t fixed = ((size_t)LP * KPS + LP + (size_t)pj_vp_floats(LP)) * sizeof(float), per_wave = (size_t)16 * SLD * sizeof(float);
+    if (fixed + per_wave > 160 * 1024) return 0;
+    int wmax = (int)((160 * 1024 - fixed) / per_wave);
+    wmax = wmax > WMAX ? WMAX : wmax;
+    if (tiles > WMAX && tiles % WMAX != 0 && wmax > 4) wmax = 4;
+    if (wmax < 1) return 0;
+    const int nrb = (tiles + wmax - 1) / wmax, wpb = (tiles + nrb - 1) / nrb;
+    if (nrb != 1) return 0;
+    const size_t lds = fixed + wpb * per_wave;
+    const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
+    return (lds > need ? lds : need) <= 160 * 1024;
+}
+
 int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     const int L = a->L;
     int rc = 0;
@@ -1637,21 +1665,18 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         // workgroups (65 KB of LDS: two per CU) measured 121 us against 149 for 5 + 5 waves (one per CU) and 153 for 8 + 1; with 8
         // tiles (L = 128) one 8-wave workgroup stays best (105 vs 109 / 137 us for 2 x 4 / 3 x 3)
         if (tiles > WMAX && tiles % WMAX != 0 && wmax > 4) wmax = 4;
-        static const int wcap = [] { const char* e = getenv("PF_IPA_WCAP"); return e ? atoi(e) : 0; }();   // (dev: waves per score workgroup)
-        if (wcap > 0 && wmax > wcap) wmax = wcap;
         if (wmax < 1) return PF_E_TOOLARGE;
         const int nrb = (tiles + wmax - 1) / wmax;
         const int wpb = (tiles + nrb - 1) / nrb;
         const size_t lds = fixed + wpb * per_wave;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PfOncePerDevice attr_set;
+        if (attr_set.first()) {
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
         }
         if (pj16) {
             // every query tile of a sample in ONE workgroup; the score regions double as the staging area; k rows + transposed values behind
@@ -1661,10 +1686,9 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             const size_t swb = (size_t)tiles * 16 * SLD16 * sizeof(float), stg = (size_t)PJ16_STAGE_B + (size_t)tiles * 1536 + (size_t)PJ_TILES * 64;
             const size_t lds16 = fixed16 + (swb > stg ? swb : stg) + ((size_t)L * KLS + (size_t)PF_ATT_VROWS * (L32 + 8)) * sizeof(_Float16);
             if (lds16 > 160 * 1024) return PF_E_TOOLARGE;
-            static bool attr_pj16 = false;
-            if (!attr_pj16) {
+            static PfOncePerDevice attr_pj16;
+            if (attr_pj16.first()) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_pj16 = true;
             }
             hipLaunchKernelGGL((ipa_scores16_kernel<true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
             PF_CHECK_LAUNCH();
@@ -1674,19 +1698,17 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         if (a->k_frag && (a->s_in || planes || (L & 15) != 0)) return PF_E_BADARG;   // k fragments: the fp32 form with the projection launch
         if (pj && (planes || nrb != 1 || (L & 3) != 0 || !a->proj_w_f16 || !a->proj_bias || !a->proj || !a->att_vt || a->ldp < OFF_KV + 2 * H * C)) return PF_E_BADARG;
         if (pj) {
-            static bool attr_pj = false;
-            if (!attr_pj) {
+            static PfOncePerDevice attr_pj;
+            if (attr_pj.first()) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_pj = true;
             }
             // the score regions double as the weight staging buffers + the waves' query-point regions during the prologue
             const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
             const size_t ldsp = lds > need ? lds : need;
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
-            // L <= 64: as many helper waves as query waves for the prologue (proj_head roles; PF_PROJ_HELPERS=0 turns them off for A/B runs)
-            static const bool no_helpers = getenv("PF_PROJ_HELPERS") && atoi(getenv("PF_PROJ_HELPERS")) == 0;
-            const int nwv = (wpb <= 4 && !no_helpers) ? 2 * wpb : wpb;
+            // L <= 64: as many helper waves as query waves for the prologue (proj_head roles)
+            const int nwv = wpb <= 4 ? 2 * wpb : wpb;
             if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
             else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if (planes) {
@@ -1698,15 +1720,13 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             // L <= 64: two waves per workgroup (twice the workgroups, each staging the head's key points again): B=16, L=64 in the f16
             // mode 0.514 -> 0.498 ms per step; the fp32-operand kernel measures the same either way (0.713 / 0.712) and keeps 4
             if (tiles <= 4 && wm > 2) wm = 2;
-            if (wcap > 0 && wm > wcap) wm = wcap;
             if (wm < 1) return PF_E_TOOLARGE;
             const int nrb16 = (tiles + wm - 1) / wm, wpb16 = (tiles + nrb16 - 1) / nrb16;
             const size_t lds16 = fixed16 + wpb16 * pw16;
-            static bool attr16 = false;
-            if (!attr16) {
+            static PfOncePerDevice attr16;
+            if (attr16.first()) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr16 = true;
             }
             const dim3 g16((unsigned)(a->B * H * nrb16)), b16(64 * wpb16);
             if (fuse) hipLaunchKernelGGL((ipa_scores16_kernel<true>), g16, b16, lds16, s, *a, nrb16, 16 * wpb16, SLD16);

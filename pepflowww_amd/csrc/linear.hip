@@ -778,15 +778,14 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         if (a->K % 32 || a->ln_gamma || a->K > 512) return PF_E_BADARG;   // x tile [64][K] must fit LDS
         const int Npad = (a->N + 15) / 16 * 16;
         const size_t lds = (size_t)2 * SP_BM * (a->K + 8) * sizeof(_Float16);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PfOncePerDevice attr_set;
+        if (attr_set.first()) {
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)linear_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
         }
         // the IPA projection of large batches: rows-persistent form (one workgroup = 32 rows x all features)
         // ... when its workgroups fill whole rounds of the 256 CUs (>= 90 %): one workgroup is ~1/256 of the launch, so 288 of them
@@ -812,8 +811,7 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
             !a->residual && !a->gate &&
             (!a->att_qk || (a->single_pass && a->pt_rot && a->att_vt && a->att_L > 0 && a->att_L % 16 == 0))) {   // (planes: f16 mode only -- 256 VGPRs + spills in split form)
             // 64-row form (two workgroups per 64 rows, half of the features each) when it also fits
-            static const int rows64 = [] { const char* e = getenv("PF_WR_ROWS64"); return e ? atoi(e) : 1; }();
-            if (rows64 && Npad % 32 == 0 && fit64) {
+            if (Npad % 32 == 0 && fit64) {
                 const dim3 grid64((unsigned)grid_tiles(64), 2);
                 if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
                 else if (a->single_pass) hipLaunchKernelGGL((linear_rows_kernel<true, false, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);

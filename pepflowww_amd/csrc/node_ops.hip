@@ -251,18 +251,17 @@ extern "C" int pf_seq_attn_fwd(const pf_seq_attn_args* a, pf_stream_t stream) {
     if (!a || !a->qkv || !a->mask || !a->out || a->B <= 0 || a->L <= 0) return PF_E_BADARG;
     if (a->L <= SM_L) {
         const size_t ldm = ((size_t)3 * SM_L * SA_LD + SM_L * SM_LDX + SM_L) * sizeof(float);
-        static bool attr_m = false;
-        if (!attr_m) { (void)hipFuncSetAttribute((const void*)seq_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
+        static PfOncePerDevice attr_m;
+        if (attr_m.first()) { (void)hipFuncSetAttribute((const void*)seq_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         hipLaunchKernelGGL(seq_attn_mfma_kernel, dim3((unsigned)(a->B * 4)), dim3(512), ldm, (hipStream_t)stream, *a);
         PF_CHECK_LAUNCH();
         return 0;
     }
     const size_t lds = ((size_t)a->L * (2 * SA_LD + 1)) * sizeof(float);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PfOncePerDevice attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)seq_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(seq_attn_kernel, dim3((unsigned)(a->B * 4)), dim3(256), lds, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();

@@ -987,11 +987,10 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
                        (size_t)2 * TR * LDP * sizeof(_Float16);
     if (a->rows >= pf_cu_count() * TR2) {        // a workgroup per CU even at 32 rows: halve the L2 -> CU weight stream
         const size_t lds2 = (size_t)2 * 2 * TR2 * 264 * sizeof(_Float16) + (size_t)TR2 * LDX * sizeof(float) + (size_t)2 * TR2 * LDP * sizeof(_Float16);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PfOncePerDevice attr_set;
+        if (attr_set.first()) {
             (void)hipFuncSetAttribute((const void*)node_head32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)node_head32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
         }
         const bool per_sample = a->key_end && a->key_L > 0 && a->rows % a->key_L == 0;
         pf_node_head_args aa = *a;
@@ -1048,13 +1047,12 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
     const int tiles = (a->L + TRn - 1) / TRn;
     const dim3 grid((unsigned)(a->B * tiles));
     const int variant = (RTn == 2 ? 4 : 0) + (a->last ? 2 : 0) + (a->single_pass ? 1 : 0);
-    static bool attr_set[8] = {};
+    static PfOncePerDevice attr_set[8];
 #define PF_NT_CASE(V, LASTV, SPV, RTV)                                                                                           \
     case V:                                                                                                                      \
-        if (!attr_set[V]) {                                                                                                      \
+        if (attr_set[V].first()) {                                                                                                      \
             (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<LASTV, SPV, RTV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                               \
-            attr_set[V] = true;                                                                                                  \
         }                                                                                                                        \
         hipLaunchKernelGGL((node_tfmr_kernel<LASTV, SPV, RTV>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);      \
         break;
@@ -1062,12 +1060,12 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
         for (int k = 0; k < (a->last ? 11 : 5); ++k)
             if (!a->dump[k]) return PF_E_BADARG;
         if (a->single_pass || RTn != 1) return PF_E_BADARG;
-        static bool dattr[2] = {};
+        static PfOncePerDevice dattr[2];
         if (a->last) {
-            if (!dattr[1]) { (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dattr[1] = true; }
+            if (dattr[1].first()) { (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
             hipLaunchKernelGGL((node_tfmr_kernel<true, false, 1, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
         } else {
-            if (!dattr[0]) { (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dattr[0] = true; }
+            if (dattr[0].first()) { (void)hipFuncSetAttribute((const void*)node_tfmr_kernel<false, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
             hipLaunchKernelGGL((node_tfmr_kernel<false, false, 1, true>), grid, dim3(NTHR), lds, (hipStream_t)stream, *a, LP, LDS_S);
         }
         PF_CHECK_LAUNCH();

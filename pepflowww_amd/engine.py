@@ -10,7 +10,6 @@ all arithmetic of the step runs in libpepflow_hip.so.
 """
 import ctypes as C
 import math
-import os
 from collections import OrderedDict
 
 import torch
@@ -463,9 +462,16 @@ class DenoiseEngine:
     #           (f16 operand planes) and the Linears of the node track run ONE f16 MFMA per product (hi planes only);
     #           accumulation, LayerNorm, softmax, residual streams, geometry and the pair tensor stay fp32.  Measured deviation
     #           from the fp32 mode: tests/test_gpu_bigshape.py, DESIGN.md section 3.8
-    def __init__(self, weights, B, L, device, precision="fp32", owner=None):
+    # plan choices a caller may force (tests and same-box A/B runs of tools/dev; the defaults are rules in (L, precision) alone):
+    #   fused_proj, fused_pair, et_v4, et_zfrag, k_frag: True / False;  et_last_store: keep the last EdgeTransition's z' store
+    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store")
+
+    def __init__(self, weights, B, L, device, precision="fp32", owner=None, options=None):
         assert precision in ("fp32", "f16"), precision
         self.precision = precision
+        opt = dict(options or {})
+        assert set(opt) <= set(self.OPTIONS), sorted(set(opt) - set(self.OPTIONS))
+        self.options = opt
         self._owner = owner                     # the GAEncoder whose cache holds this engine (asked to make room on OOM)
         self.lib = _capi.load()
         self.w = weights
@@ -507,25 +513,25 @@ class DenoiseEngine:
         # mode only.  A query's pair-value row is then read by the 8 head workgroups of its sample (once from HBM, 7 x from L2): with
         # f16 values that costs less than the second kernel + the probability round trip (B=64, L=128: step 2.167 -> 2.138 ms, L=64:
         # 0.528 -> 0.514), with fp32 values (twice the bytes through L2 -> L1) as much as it saves (3.46 vs 3.48 ms; two or four rows
-        # in flight per wave measure the same: bandwidth, not latency).  A rule in (L, precision) alone.  PF_FUSED_PAIR=0 / 1 forces it.
+        # in flight per wave measure the same: bandwidth, not latency).  A rule in (L, precision) alone.  options={'fused_pair': ...} forces it.
         # (round 4: also in the fp32 mode for L <= 64 -- there the separate pair kernel is a 5 us launch of its own and the fused phase
         #  costs less than that: 0.6974 -> 0.6927 ms at B=16, L=64; at L=128 it stays slower, 3.43 vs 3.47 ms)
-        self.fused_pair = self.pair_dz is not None and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PAIR", ""), self.z16 or L <= 64)
+        self.fused_pair = self.pair_dz is not None and opt.get("fused_pair", self.z16 or L <= 64)
         # attention probabilities handed from the score kernel to the pair-aggregation kernel (two-kernel form only)
         self.attn_p = None if self.fused_pair else e(B, 8, L, L)
         # EdgeTransition work list (pf_edge_transition_args.tile_list): tiles of the persistent kernel that hold an unmasked pair,
         # refreshed from the mask by bind_context (device-side, no synchronisation); padded batches skip the rest
         # EdgeTransition kernel form, by measurement at B=64, L=128 (same box, in the step): fp32-parity mode: the 32x32 kernel
-        # (csrc/edge_transition_v4.hip) 379 vs 402 us; f16 mode: the 16x16 kernel (v3) 180 vs 195 us.  PF_ET_V4=0 / 1 forces one (A/B runs).
-        self.et_v4 = {"0": False, "1": True}.get(os.environ.get("PF_ET_V4", ""), precision == "fp32")
+        # (csrc/edge_transition_v4.hip) 379 vs 402 us; f16 mode: the 16x16 kernel (v3) 180 vs 195 us.  options={'et_v4': ...} forces one (A/B runs).
+        self.et_v4 = opt.get("et_v4", precision == "fp32")
         self.et_rows = int(self.lib.pf_edge_transition_v4_tile_rows()) if self.et_v4 else int(self.lib.pf_edge_transition_tile_rows(int(precision == "f16")))
         # the pair tensor between two EdgeTransition launches in the 32x32 kernel's FRAGMENT ORDER (pf_edge_transition_args.z_in_frag /
         # z_out_frag): nobody else reads it (the attention takes the pair bias / pair values the kernel emits), and every load / store
         # instruction of it becomes one contiguous KiB (as [.., 64] rows: 32 rows, 32 bytes of each).  The caller's edge embedding is
-        # permuted once per call (bind_context).  fp32 pair tensor, whole 16 x 16 tiles.  PF_ET_ZFRAG=0 / 1 forces it (A/B runs).
+        # permuted once per call (bind_context).  fp32 pair tensor, whole 16 x 16 tiles.  options={'et_zfrag': ...} forces it (A/B runs).
         # f16 mode: the same for the f16 pair tensor of the 16x16x32 kernel (a row's two KiB pieces are its LDS-DMA pieces as they are,
         # the z' store is two contiguous KiB per row instead of four instructions of 8-byte pieces): 208 -> 200 us stand-alone.
-        zf_ok = L % 16 == 0 and self.pair_dz is not None and {"0": False, "1": True}.get(os.environ.get("PF_ET_ZFRAG", ""), True)
+        zf_ok = L % 16 == 0 and self.pair_dz is not None and opt.get("et_zfrag", True)
         self.z_frag = zf_ok and ((self.et_v4 and not self.z16) or (self.z16 and not self.et_v4 and self.et_rows == 16))
         self.edge_frag = e(B, L, L, 64, dt=torch.float16 if self.z16 else torch.float32) if self.z_frag else None
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
@@ -543,12 +549,14 @@ class DenoiseEngine:
         # the IPA projection inside the score kernel (pf_ipa_attn_args.s_in, csrc/ipa_split.hip: proj_head / proj_head16): every (sample, head)
         # workgroup projects its own rows -- no projection launch, q and the points never reach HBM, `proj` shrinks to a k | v scratch.
         # Needs the fp32-operand two-kernel form with all query tiles of a sample in one workgroup (64 <= L <= 128, L % 4 == 0): a rule
-        # in (L, precision) alone.  PF_FUSED_PROJ=0 / 1 forces it off / on (same-box A/B runs).
+        # in (L, precision) alone.  options={'fused_proj': False} forces it off (same-box A/B runs).
         # f16 mode (L % 16 == 0, pair values fused): the f16-operand score kernel forms k rows and transposed values in LDS -- the
         # att_qk / att_vt planes are not needed either.
         can_pj = 64 <= L <= 128 and ((precision == "fp32" and L % 4 == 0 and not self.att_planes) or
                                      (precision == "f16" and self.att_planes and self.fused_pair))
-        self.fused_proj = can_pj and {"0": False, "1": True}.get(os.environ.get("PF_FUSED_PROJ", ""), True)
+        # ... and the library is asked whether it would launch that form here (its LDS arithmetic and wave cap decide: ADVICE r4)
+        can_pj = bool(can_pj and self.lib.pf_ipa_proj_inside_ok(L, int(precision == "f16")))
+        self.fused_proj = can_pj and opt.get("fused_proj", True)
         self.att_qk = self.att_vt = None
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
@@ -562,10 +570,10 @@ class DenoiseEngine:
             self.att_vt32 = torch.zeros(B * 8 * 512 * ((L + 31) // 32 * 32), dtype=torch.float16, device=device)
         # fp32 mode with the projection LAUNCH (L > 128 or L % 4 != 0 ...) and the two-kernel attention: the k columns of the projection go
         # to a scratch in the fragment order of the score kernel's first product instead of `proj` (pf_linear_args.k_frag /
-        # pf_ipa_attn_args.k_frag: one contiguous KiB per load instead of sixteen rows x 64 bytes).  PF_K_FRAG=0 / 1 forces it (A/B runs).
+        # pf_ipa_attn_args.k_frag: one contiguous KiB per load instead of sixteen rows x 64 bytes).  options={'k_frag': ...} forces it (A/B runs).
         self.k_frag = None
         if (not self.fused_proj and precision == "fp32" and L % 16 == 0 and self.pair_dz is not None and
-                {"0": False, "1": True}.get(os.environ.get("PF_K_FRAG", ""), True)):
+                opt.get("k_frag", True)):
             self.k_frag = e(rows, 1024)
         self.logits, self.ang_raw = e(rows, 20), e(rows, 5)
         # 16-row groups whose final predictions are wanted (pf_node_tfmr_args.row_on of the LAST block's tail): all of them for the
@@ -665,6 +673,7 @@ class DenoiseEngine:
     def bind_context(self, node_embed, edge_embed, res_mask):
         """Per-call context: node_embed / mask are copied (small); edge_embed is used zero-copy."""
         B, L = self.B, self.L
+        self.want_rows(None)                    # a sampler's narrowing (DeviceSampler.set_context) does not outlive its call (ADVICE r4)
         self.node_embed.copy_(node_embed.reshape(B * L, 128))
         self.mask.copy_(res_mask.reshape(B * L).to(torch.float32))
         self._refresh_work_lists(res_mask.reshape(B, L))
@@ -857,8 +866,8 @@ class DenoiseEngine:
                     emit_proj(b + 1, 1)
                 et = _capi.EdgeTransitionArgs()
                 # the LAST EdgeTransition's z' is never read: block 5 takes its pair bias and pair values from this launch, and there is
-                # no EdgeTransition after it (ga.py:115-118) -- not stored (256 B per pair; PF_ET_LAST_STORE=1 keeps the store, A/B runs)
-                drop_z = (b == N_BLOCKS - 2 and self.pair_dz is not None and os.environ.get("PF_ET_LAST_STORE") != "1")
+                # no EdgeTransition after it (ga.py:115-118) -- not stored (256 B per pair; options={'et_last_store': True} keeps the store, A/B runs)
+                drop_z = (b == N_BLOCKS - 2 and self.pair_dz is not None and not self.options.get("et_last_store", False))
                 et.z_in, et.z_out, et.pre = z_in.data_ptr(), (None if drop_z else self.zbuf.data_ptr()), self.pre.data_ptr()
                 if self.z_frag:
                     et.z_in_frag = et.z_out_frag = 1

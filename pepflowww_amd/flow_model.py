@@ -40,6 +40,8 @@ def _pad_residues(batch, noise, L0, L):
 
 
 class FlowModel(nn.Module):
+    GC_UNDER_LOOP = True      # sample(): run the cyclic garbage collector while the device works through the step loop (see there)
+
     def __init__(self, cfg):
         super().__init__()
         self._model_cfg = cfg.encoder
@@ -154,6 +156,15 @@ class FlowModel(nn.Module):
             smp.capture()
             stamp("capture")
         smp.run(num_steps, use_graph=use_graph)
+        # The step loop is enqueued (graph replays) and the host now only waits for the device: the one place where a full pass of
+        # the cyclic garbage collector costs nothing.  A call returns ~2 000 tensor / dict objects (the reference's list-of-dicts
+        # trajectory), so a loop over complexes triggers full collections anyway -- 15 - 90 ms each, in whatever host phase they hit
+        # (BENCH r05: three of eight warm calls, 180 of 295 ms of all overhead); collecting here, under >= ~40 ms of device work,
+        # takes them out of the call's critical path.  Only when the collector is enabled at all.
+        if self.GC_UNDER_LOOP and B * L * num_steps >= 100_000:
+            import gc
+            if gc.isenabled():
+                gc.collect()
         stamp("loop")
         if check_range:
             # run-time range verdict of the split-precision operands (engine.operand_range: five small reductions, one host read

@@ -96,9 +96,8 @@ class DeviceSampler:
         self.seq1.copy_(seq1.reshape(rows))
         self.gen.copy_(gen_mask.reshape(rows).to(torch.float32))
         # the last block's tail only has to produce the generated residues' predictions (everything else is replaced by the context,
-        # flow_model.py:291-311): its row tiles without one are skipped.  PF_SKIP_CONTEXT_ROWS=0: all rows (A/B runs)
-        import os
-        self.eng.want_rows(self.gen if os.environ.get("PF_SKIP_CONTEXT_ROWS") != "0" else None)
+        # flow_model.py:291-311): its row tiles without one are skipped.  (DeviceSampler.SKIP_CONTEXT_ROWS = False: all rows, A/B runs)
+        self.eng.want_rows(self.gen if self.SKIP_CONTEXT_ROWS else None)
 
     def init_state(self, noise):
         dev, rows = self.eng.device, self.eng.rows
@@ -116,11 +115,12 @@ class DeviceSampler:
         self._init_keep = (rot0, tr0, ang0, sx0)
 
     def _one_step(self):
-        import os
-        self.eng.run(concurrent=os.environ.get("PF_CONCURRENT", "0") == "1")   # (dev switch: projection(b+1) beside EdgeTransition(b))
+        self.eng.run(concurrent=self.CONCURRENT)
         rc = self.lib.pf_sampler_step(C.byref(self.args), _capi.stream_ptr())
         _capi.check(rc, "pf_sampler_step")
 
+    SKIP_CONTEXT_ROWS = True  # the last block's tail only produces the generated residues' predictions (set_context)
+    CONCURRENT = False        # projection(b + 1) on a side stream beside EdgeTransition(b): measured slower (DenoiseEngine.run)
     GRAPH_STEPS = 4          # steps per replayed graph: the host-side relaunch gap (~8 us) is paid once per replay
 
     def _capture(self, k):

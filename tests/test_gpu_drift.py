@@ -46,6 +46,13 @@ def test_f16_mode_over_100_free_steps(drift):
     # (round 4: per-sample statistics instead of "before the first flipped draw" -- a free run has a second kind of branch point, the
     #  torus geodesic at opposite angles (drift_study.compare), which an f16-sized difference in a prediction can trip in a single
     #  sample long before any draw flips: the typical sample stays within the old bound, no sample leaves the after-a-flip range)
+    # (round 5, ADVICE r4: the per-sample error before the sample's first detected branch event is REPORTED by drift_study.compare but
+    #  cannot be bounded at 3e-2 -- one sample leaves it at step 3 through the conditioning of the SO(3) geodesic near a half turn, with
+    #  no flipped draw and no torsion turn-around (tools/dev/r05_drift_diag.py).  What pins the f16 DATA PATH against a silent
+    #  regression is bit-level: tests/test_gpu_round4.py::test_step_with_and_without_the_projection_launch[f16] (projection inside the
+    #  score kernel == the three-buffer form, bit for bit), ::test_attention_planes_in_fragment_order and
+    #  ::test_edge_transition_with_the_pair_tensor_in_fragment_order (fragment order == row order, bit for bit), and
+    #  tests/test_gpu_fresh_process.py (run-to-run, f16 mode included).  This test is the statistical view on top of those.)
     assert r["rot_err_sample_median"] < 3e-2 and r["trans_err_sample_median"] < 1e-2, (r["rot_err_sample_median"], r["trans_err_sample_median"])
     assert sum(x > 3e-2 for x in r["rot_err_sample_max"]) <= len(r["rot_err_sample_max"]) // 4, r["rot_err_sample_max"]
     assert r["rot_err_max"] < 0.5, r["rot_err_max"]

@@ -119,11 +119,7 @@ def test_step_with_and_without_the_projection_launch(seeded_sd, B, L, precision)
     t = torch.rand(B, 1, generator=g)
     outs, launches = [], []
     for flag in ("0", "1"):
-        os.environ["PF_FUSED_PROJ"] = flag
-        try:
-            eng = DenoiseEngine(w, B, L, G.dev(), precision=precision)
-        finally:
-            del os.environ["PF_FUSED_PROJ"]
+        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"fused_proj": flag == "1"})
         assert eng.fused_proj == (flag == "1")
         assert (eng.att_qk is None) == (precision == "fp32" or flag == "1")
         eng.bind_context(node, edge, bd["res_mask"])
@@ -269,11 +265,7 @@ def test_step_with_the_pair_tensor_in_fragment_order(seeded_sd, B, L, precision,
     t = torch.rand(B, 1, generator=g)
     outs = []
     for flag in ("0", "1"):
-        os.environ["PF_ET_ZFRAG"] = flag
-        try:
-            eng = DenoiseEngine(w, B, L, G.dev(), precision=precision)
-        finally:
-            del os.environ["PF_ET_ZFRAG"]
+        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"et_zfrag": flag == "1"})
         assert eng.z_frag == (flag == "1")
         eng.bind_context(node, edge, bd["res_mask"])
         eng.set_state(cu(t), cu(Rt), cu(xt), cu(at), cu(st))
@@ -361,11 +353,7 @@ def test_step_with_the_k_rows_as_fragments_is_bit_identical(seeded_sd, B, L, rag
     t = torch.rand(B, 1, generator=g)
     outs = []
     for flag in ("0", "1"):
-        os.environ["PF_K_FRAG"] = flag
-        try:
-            eng = DenoiseEngine(w, B, L, G.dev(), precision="fp32")
-        finally:
-            del os.environ["PF_K_FRAG"]
+        eng = DenoiseEngine(w, B, L, G.dev(), precision="fp32", options={"k_frag": flag == "1"})
         assert (eng.k_frag is not None) == (flag == "1") and not eng.fused_proj
         eng.bind_context(node, edge, bd["res_mask"])
         eng.set_state(cu(t), cu(Rt), cu(xt), cu(at), cu(st))
