@@ -3,7 +3,7 @@
 //   x = [z_ij, n_i, n_j];  h1 = relu(W1 x + b1);  h2 = relu(W2 h1 + b2);
 //   y = Wf (h2 + x) + bf;  z' = LayerNorm(y) * m_i m_j
 //
-// Two persistent kernels implement it: edge_transition_v4.hip (v_mfma_f32_32x32x16_f16, no loader waves: the
+// Two persistent kernels implement it (NOTES.md 3.2): edge_transition_v4.hip (v_mfma_f32_32x32x16_f16, no loader waves: the
 // fp32-parity mode of the inference step) and edge_transition_v3.hip (16x16x32 with loader waves: the f16 mode and the training
 // forward with its activation dumps).  Both take the weights as ONE fragment stream in consumption order (engine.pack_et_stream*)
 // and the per-residue parts of W1 x / Wf x as pre[B*L,512] (produced by the node-track tail).  The round-1 tiled kernel that used

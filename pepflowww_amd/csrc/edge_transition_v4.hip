@@ -6,7 +6,7 @@
 // Same arithmetic and the same ideas as edge_transition_v3.hip (persistent workgroup per CU, weights as one linear fragment
 // stream through an LDS ring by LDS-DMA, activations register-resident from GEMM to GEMM through a K permutation, per-residue
 // terms as accumulator seeds, LayerNorm / mask / next block's pair bias + pair values in the epilogue) on a different machine
-// mapping, chosen from what bounded v3 (2 KiB of LDS fragment reads per 3 MFMAs of 16 pairs, ten waves meeting
+// mapping, chosen from what bounded v3 (NOTES.md 3.2: 2 KiB of LDS fragment reads per 3 MFMAs of 16 pairs, ten waves meeting
 // at a barrier every ~2.6 k cycles with an exposed LDS round trip behind it and a VALU block in front of it):
 //   * v_mfma_f32_32x32x16_f16: one weight fragment (32 features x 16 K) feeds 32 pairs -- half the LDS fragment bytes and half
 //     the matrix instructions per flop of the 16x16x32 form, 8 issue slots per MFMA for the VALU / LDS work beside it;

@@ -11,7 +11,7 @@
 // diagonal (i == j) that triple product is exactly zero in real arithmetic, so its sign is pure
 // rounding noise.  To reproduce the reference's value the cross product and the dot product follow
 // ATen's CPU op sequence exactly: cross_k = fma(a_i, b_j, -(a_j*b_i)), dot = (m0 + m1) + m2
-// (verified bitwise against torch 2.10 CPU).  Compiled with -ffp-contract=off.
+// (verified bitwise against torch 2.10 CPU, see NOTES.md 3.6).  Compiled with -ffp-contract=off.
 #include <type_traits>
 #include "common.h"
 #include "../../include/pepflow_hip.h"

@@ -166,7 +166,7 @@ __device__ __forceinline__ void pair_dz_phase(const pf_ipa_attn_args& a, size_t 
         make_float4(z4[0] * invq + bd.x, z4[1] * invq + bd.y, z4[2] * invq + bd.z, z4[3] * invq + bd.w);
 }
 
-// ---- the IPA projection INSIDE the score kernel (pf_ipa_attn_args.s_in / proj_w_f16 / proj_bias) ----
+// ---- the IPA projection INSIDE the score kernel (pf_ipa_attn_args.s_in / proj_w_f16 / proj_bias; DESIGN.md 3.2, NOTES.md 3.3) ----
 // A (sample, head) workgroup forms the head's operands itself: wave w projects ITS OWN 16 residue rows (its queries, which are also 16
 // of the head's keys) through the head's 496 columns of the packed projection [3968,128] (ipa_pytorch.py:347-387: linear_q | linear_kv
 // | linear_q_points | linear_kv_points, points packed (x, y, z, 0) as pf_linear_fwd's pt_* form) -- split-precision MFMA, computed
@@ -204,7 +204,7 @@ __device__ __forceinline__ void pj_glds16(const void* sbase, unsigned voff, unsi
     // s_nop 4: FIVE wait states between the v_readfirstlane that forms the base (it depends on the wave index: a VALU write of the SGPR
     // pair) and the vector memory instruction reading it (CDNA3/4 ISA, "manually inserted wait states"; hipcc's hazard recognizer inserts
     // them for its own instructions and cannot see into an asm statement; edge_transition_v4.hip's bases are SALU results and only need
-    // the M0 wait state).  Rounds 3 - 4 had `s_nop 0` here: a spec violation, though no failure could be tied to it (DESIGN.md 3.3).
+    // the M0 wait state).  Rounds 3 - 4 had `s_nop 0` here: a spec violation, though no failure could be tied to it (DESIGN.md 3.2).
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void pj_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         // issued since are NOT counted: the first build of this loop added them to the allowance ("vector memory operations complete
         // in order") and was wrong -- a store's vmcnt decrement can overtake an older LDS-DMA piece's, the wait then passes with
         // chunk c's weights not in LDS yet.  Rare with the scattered 64-byte row stores of that build (one unexplained test failure
-        // in ~10 suite runs), every run once the stores became contiguous KiB blocks (round 4).  Without them in the
+        // in ~10 suite runs), every run once the stores became contiguous KiB blocks (round 4, NOTES.md 3.3).  Without them in the
         // allowance the wait also covers the stores of the previous chunks: +1.4 k cycles on the 44 k prologue.
         constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH) + (PJ_NB > 4 && c + 3 < PJ_NCH);
         static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");

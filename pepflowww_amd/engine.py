@@ -461,7 +461,7 @@ class DenoiseEngine:
     #   "f16" : BASELINE configs[2] mode -- EdgeTransition (85 % of the step's flops), the IPA projection, the attention products
     #           (f16 operand planes) and the Linears of the node track run ONE f16 MFMA per product (hi planes only);
     #           accumulation, LayerNorm, softmax, residual streams, geometry and the pair tensor stay fp32.  Measured deviation
-    #           from the fp32 mode: tests/test_gpu_bigshape.py, DESIGN.md section 3.8
+    #           from the fp32 mode: tests/test_gpu_bigshape.py, NOTES.md section 3.8
     # plan choices a caller may force (tests and same-box A/B runs of tools/dev; the defaults are rules in (L, precision) alone):
     #   fused_proj, fused_pair, et_v4, et_zfrag, k_frag: True / False;  et_last_store: keep the last EdgeTransition's z' store
     OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store")

@@ -3,7 +3,7 @@
 Round 4 shipped the projection prologue of the fp32 score kernel in the one form that never failed these checks (run-time "role"
 branches in its tile loop) next to a straight-line form that mismatched in 1 of 5 ... 10 of 10 fresh processes.  Round 5 pinned the
 straight-line form's failures down to single workgroups in which ONE wave's projection is off -- most often one dword of the
-LDS hand-off of its query points -- without finding the mechanism (profiles/r05/README.md, DESIGN.md 3.3: what was excluded).  In-process
+LDS hand-off of its query points -- without finding the mechanism (profiles/r05/README.md, DESIGN.md 3.2: what was excluded).  In-process
 repetition of a whole sample() never showed it (`test_sample_is_stable_from_run_to_run` passed on the failing build); these two do.
 """
 import os
@@ -36,7 +36,7 @@ def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd):
     """The projection-inside score kernel (fp32 mode) at B x L = 64 x 128, launched 1500 times on the same inputs (the rows rewritten
     by a copy kernel before every launch, as in the step): every output bit-equal to the first launch's.  tools/dev/r05_ipa_repeat.py is
     the diagnostic form (it locates a difference: which workgroup, which wave, which operand); a build of the prologue WITHOUT the
-    run-time role branches failed this in 0.3 - 1.5 % of the launches (DESIGN.md 3.3, profiles/r05/README.md)."""
+    run-time role branches failed this in 0.3 - 1.5 % of the launches (DESIGN.md 3.2, profiles/r05/README.md)."""
     import math
     import torch
     import torch.nn.functional as F

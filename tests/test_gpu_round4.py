@@ -143,9 +143,9 @@ def test_sample_is_stable_from_run_to_run(seeded_sd, precision, B, L, ragged):
     """Six runs of FlowModel.sample (graph replay and eager, interleaved) on the same noise give the same bits.  The shapes put
     waves that leave early (rows beyond a sample's key end, padded batches) beside the fused phases of the score kernels
     (projection inside: 64 <= L <= 128; pair aggregation inside: f16 mode, and fp32 mode at L <= 64).  Two ordering bugs of the
-    projection prologue failed exactly this check: staging waits that counted stores, and a bare s_barrier in front of
+    projection prologue failed exactly this check (NOTES.md 3.3): staging waits that counted stores, and a bare s_barrier in front of
     which a wave's own LDS writes had not been waited for.  (A third dependence shows only in the bitwise shard check of fresh
-    processes at B = 64 x 128, tools/dev/r04_det3.py, on a build without the helper-role branches: DESIGN.md 3.3 / 7.)"""
+    processes at B = 64 x 128, tools/shard_check.py, on a build without the helper-role branches: DESIGN.md 3.2, tests/test_gpu_fresh_process.py.)"""
     import random
     rnd = random.Random(B * 1000 + L)
     lengths = [rnd.randint(L // 3, L) for _ in range(B)] if ragged else None

@@ -2,7 +2,7 @@
 
 Every kernel of the denoise step is deterministic and batch-invariant by construction (no atomics on the inference path, one workgroup
 owns a (sample, head) / a pair tile), so the two runs must agree bit for bit.  A hardware-level ordering or hazard bug shows up here as
-single samples that differ in a few processes out of many (DESIGN.md 3.3: the straight-line build of the projection prologue).
+single samples that differ in a few processes out of many (DESIGN.md 3.2: the straight-line build of the projection prologue).
 tests/test_gpu_fresh_process.py runs this script in a loop of fresh subprocesses.
 
   python tools/shard_check.py [B L steps reps precision]      -> prints "mismatches N", exit code 1 if N > 0
