@@ -287,6 +287,56 @@ __global__ __launch_bounds__(512) void probe_war(const char* hot, unsigned* earl
     if (bad) { atomicOr(&early[2], bad); atomicOr(&early[3], 1u << g); }
 }
 
+// mode 6: the staging PROTOCOL of the projection prologue in isolation: 8 waves, 4 LDS buffers of 24 KiB, 11 chunks of 24 one-KiB pieces
+// (3 per wave and chunk), chunks c + 1 .. c + 2 in flight while chunk c is consumed, counted `s_waitcnt vmcnt(6 / 3 / 0)` + a bare
+// s_barrier per chunk, chunk c + 3 requested right behind barrier c into the buffer chunk c - 1 just left.  Every piece of the source
+// holds its own index in every dword, so each wave can check every dword of every chunk it is about to consume; waves are skewed by
+// `s_sleep (wave * skew)` inside the "compute".  Mismatches = the protocol (or the hardware under it) lets a wave read a buffer that
+// does not hold its chunk.
+__global__ __launch_bounds__(512) void probe_ring(const unsigned* src /* [11][24][256] dwords, value = chunk * 24 + piece */, unsigned* early, unsigned* total, int skew) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned ws0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned voff = lane * 16;
+    constexpr int NCH = 11, NB = 4, CHB = 24576;
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        for (int k = 0; k < 3; ++k) {
+            const int pc = wave + 8 * k;
+            const unsigned long long v = (unsigned long long)(src + ((size_t)c * 24 + pc) * 256);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+            const unsigned la = __builtin_amdgcn_readfirstlane(ws0 + (c % NB) * CHB + pc * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(la) : "memory", "m0");
+        }
+    };
+    unsigned bad = 0;
+    asm volatile("" ::: "memory");
+    issue(0); issue(1); issue(2);
+    for (int c = 0; c < NCH; ++c) {
+        const int ndy = (c + 1 < NCH) + (c + 2 < NCH);
+        if (ndy == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ndy == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + NB - 1 < NCH) issue(c + NB - 1);
+        const unsigned* buf = reinterpret_cast<const unsigned*>(lds + (c % NB) * CHB);
+        for (int pc = 0; pc < 24; ++pc) {
+            const uint4 v = *reinterpret_cast<const uint4*>(buf + pc * 256 + lane * 4);
+            const unsigned want = (unsigned)(c * 24 + pc);
+            if (v.x != want || v.y != want || v.z != want || v.w != want) bad |= 1u << (c < 31 ? c : 31);
+            if (skew && pc == 11) __builtin_amdgcn_s_sleep(1);
+        }
+        for (int k = 0; k < wave * skew; ++k) __builtin_amdgcn_s_sleep(2);
+    }
+    const unsigned long long bm = __ballot(bad != 0);
+    if (lane == 0) {
+        if (bm) atomicAdd(&early[0], 1u);
+        atomicAdd(total, 1u);
+    }
+    if (bad) { atomicOr(&early[2], bad); atomicOr(&early[3], 1u << wave); }
+}
+
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 6;
     const size_t cold_bytes = (size_t)2 << 30, flush_bytes = (size_t)1 << 30;
@@ -342,6 +392,29 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(h, early, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&t, total, 4, hipMemcpyDeviceToHost));
         printf("mode 5  ds_write2_b32 data registers reloaded by the next ds_read_b128, %2d LDS-DMA pieces landing: waves with a corrupted store: %u of %u (x 200 rounds each); which dword: mask 0x%x, which 16-lane group: mask 0x%x\n",
                ndma, h[0], t, h[2], h[3]);
+    }
+    {
+        unsigned* ring;
+        CK(hipMalloc(&ring, 11 * 24 * 1024));
+        std::vector<unsigned> h(11 * 24 * 256);
+        for (int i = 0; i < 11 * 24; ++i) for (int j = 0; j < 256; ++j) h[(size_t)i * 256 + j] = (unsigned)i;
+        CK(hipMemcpy(ring, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        CK(hipFuncSetAttribute((const void*)probe_ring, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576));
+        for (int skew = 0; skew <= 4; skew += 2) {
+            unsigned te = 0, tt = 0, m2 = 0, m3 = 0;
+            for (int r = 0; r < 40; ++r) {
+                if ((r & 7) == 0) sweep_kernel<<<2048, 256>>>((const float4*)flush, flush_bytes / 16, sink);   // cold source now and then
+                CK(hipMemset(early, 0, 16)); CK(hipMemset(total, 0, 4));
+                probe_ring<<<2048, 512, 4 * 24576>>>(ring, early, total, skew);
+                CK(hipGetLastError());
+                CK(hipDeviceSynchronize());
+                unsigned hh[4], t;
+                CK(hipMemcpy(hh, early, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&t, total, 4, hipMemcpyDeviceToHost));
+                te += hh[0]; tt += t; m2 |= hh[2]; m3 |= hh[3];
+            }
+            printf("mode 6  staging ring of the projection prologue (4 buffers, counted waits, bare barriers), wave skew %d: waves that read a wrong dword: %u of %u; chunks: mask 0x%x, waves: mask 0x%x\n",
+                   skew, te, tt, m2, m3);
+        }
     }
     return 0;
 }
