@@ -337,6 +337,96 @@ __global__ __launch_bounds__(512) void probe_ring(const unsigned* src /* [11][24
     if (bad) { atomicOr(&early[2], bad); atomicOr(&early[3], 1u << wave); }
 }
 
+// mode 7: WAR between an MFMA's A operand and a DS load issued right behind it into the SAME registers -- what hipcc emits for the
+// straight-line projection prologue (`v_mfma ... v[50:53] ...` immediately followed by `ds_read_b128 v[50:53]`: the fragments of the
+// next K-step).  Eight waves per workgroup (two per SIMD, both streaming MFMAs, so an MFMA may wait for the matrix pipe).  A = 1.0,
+// B = 1.0 -> every element of D must be 32; the reload brings 2.0 (64 if the MFMA saw it).  PRE = independent MFMAs issued right in
+// front of the critical one (how far the pipe is backed up).
+template <int PRE, int DEPTH>
+__global__ __launch_bounds__(512) void probe_mfma_war(unsigned* early, unsigned* total, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    _Float16* l16p = reinterpret_cast<_Float16*>(lds) + wave * 2048;
+    for (int k = lane; k < 1024; k += 64) { l16p[k] = (_Float16)1.0f; l16p[1024 + k] = (_Float16)2.0f; }
+    __syncthreads();
+    const unsigned a1 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + wave * 4096 + lane * 16;
+    const unsigned a2 = a1 + 2048;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        float d0, d1, d2, d3;
+        asm volatile(
+            "v_mov_b32 v60, 0x3c003c00\n v_mov_b32 v61, 0x3c003c00\n v_mov_b32 v62, 0x3c003c00\n v_mov_b32 v63, 0x3c003c00\n"    // B = 1.0 x 8
+            "ds_read_b128 v[50:53], %[a1]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            ".rept %[pre]\n"
+            "v_mfma_f32_16x16x32_f16 v[70:73], v[60:63], v[60:63], 0\n"
+            "v_mfma_f32_16x16x32_f16 v[74:77], v[60:63], v[60:63], 0\n"
+            ".endr\n"
+            // the kernel's sequence: a DEPENDENT chain (the third product waits for the second one's result as SrcC) whose A operand is
+            // reloaded right behind it:  D = 1 x 1 (32) + [v50:53] x 1 (32) = 64; 96 if the reloaded 2.0 was seen
+            "ds_read_b128 v[46:49], %[a1]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_mfma_f32_16x16x32_f16 v[66:69], v[46:49], v[60:63], 0\n"
+            "v_mfma_f32_16x16x32_f16 v[46:49], v[46:49], v[60:63], 0\n"
+            "v_mfma_f32_16x16x32_f16 v[54:57], v[50:53], v[60:63], v[46:49]\n"
+            // ... and DEPTH more products on the SAME accumulator, all reading A = v[50:53]: a chain of dependent MFMAs executes one
+            // after the other (each waits for its SrcC), so the last ones read their operands long after they were issued
+            ".rept %[depth]\n"
+            "v_mfma_f32_16x16x32_f16 v[54:57], v[50:53], v[60:63], v[54:57]\n"
+            ".endr\n"
+            "ds_read_b128 v[50:53], %[a2]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+            "v_mov_b32 %[d0], v54\n v_mov_b32 %[d1], v55\n v_mov_b32 %[d2], v56\n v_mov_b32 %[d3], v57\n"
+            : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
+            : [a1] "v"(a1), [a2] "v"(a2), [pre] "n"(PRE), [depth] "n"(DEPTH)
+            : "memory", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v60", "v61", "v62", "v63", "v66", "v67", "v68", "v69",
+              "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77");
+        const float want = 64.f + 32.f * DEPTH;
+        if (d0 != want || d1 != want || d2 != want || d3 != want) bad |= 1u;
+    }
+    const unsigned long long bm = __ballot(bad != 0);
+    if (lane == 0) {
+        if (bm) atomicAdd(&early[0], 1u);
+        atomicAdd(total, 1u);
+    }
+    if (bad) atomicOr(&early[3], 1u << wave);
+}
+
+// mode 8: an MFMA whose DESTINATION overlaps its A operand (hipcc allocates `v_mfma_f32_16x16x32_f16 v[46:49], v[46:49], b, c` freely:
+// no early-clobber on the 4-register forms).  A = 1.0, B = 1.0, C = 0 -> 32 everywhere; then a second product with D = A again and
+// C = the first result -> 64.  Eight waves per workgroup stream the same sequence (matrix pipe shared by two waves per SIMD).
+__global__ __launch_bounds__(512) void probe_mfma_overlap(unsigned* early, unsigned* total, int iters) {
+    const int lane = threadIdx.x & 63;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        float d0, d1, d2, d3, e0, e1, e2, e3;
+        asm volatile(
+            "v_mov_b32 v60, 0x3c003c00\n v_mov_b32 v61, 0x3c003c00\n v_mov_b32 v62, 0x3c003c00\n v_mov_b32 v63, 0x3c003c00\n"
+            "v_mov_b32 v50, 0x3c003c00\n v_mov_b32 v51, 0x3c003c00\n v_mov_b32 v52, 0x3c003c00\n v_mov_b32 v53, 0x3c003c00\n"
+            "v_mov_b32 v46, 0x3c003c00\n v_mov_b32 v47, 0x3c003c00\n v_mov_b32 v48, 0x3c003c00\n v_mov_b32 v49, 0x3c003c00\n"
+            "s_nop 4\n"
+            "v_mfma_f32_16x16x32_f16 v[70:73], v[60:63], v[60:63], 0\n"
+            "v_mfma_f32_16x16x32_f16 v[74:77], v[60:63], v[60:63], 0\n"
+            "v_mfma_f32_16x16x32_f16 v[50:53], v[50:53], v[60:63], 0\n"            // D = A
+            "v_mfma_f32_16x16x32_f16 v[46:49], v[46:49], v[60:63], v[50:53]\n"      // D = A, C = previous result
+            "s_nop 15\n s_nop 15\n s_nop 15\n"
+            "v_mov_b32 %[d0], v50\n v_mov_b32 %[d1], v51\n v_mov_b32 %[d2], v52\n v_mov_b32 %[d3], v53\n"
+            "v_mov_b32 %[e0], v46\n v_mov_b32 %[e1], v47\n v_mov_b32 %[e2], v48\n v_mov_b32 %[e3], v49\n"
+            : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3)
+            :
+            : "memory", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v60", "v61", "v62", "v63", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77");
+        if (d0 != 32.f || d1 != 32.f || d2 != 32.f || d3 != 32.f) bad |= 1u;
+        if (e0 != 64.f || e1 != 64.f || e2 != 64.f || e3 != 64.f) bad |= 2u;
+    }
+    const unsigned long long bm = __ballot(bad != 0);
+    if (lane == 0) {
+        if (bm) atomicAdd(&early[0], 1u);
+        atomicAdd(total, 1u);
+    }
+    if (bad) atomicOr(&early[2], bad);
+}
+
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 6;
     const size_t cold_bytes = (size_t)2 << 30, flush_bytes = (size_t)1 << 30;
@@ -415,6 +505,30 @@ int main(int argc, char** argv) {
             printf("mode 6  staging ring of the projection prologue (4 buffers, counted waits, bare barriers), wave skew %d: waves that read a wrong dword: %u of %u; chunks: mask 0x%x, waves: mask 0x%x\n",
                    skew, te, tt, m2, m3);
         }
+    }
+    {
+        for (int cfg = 0; cfg < 4; ++cfg) {
+            CK(hipMemset(early, 0, 16)); CK(hipMemset(total, 0, 4));
+            if (cfg == 0) probe_mfma_war<0, 0><<<1024, 512, 32768>>>(early, total, 2000);
+            else if (cfg == 1) probe_mfma_war<0, 4><<<1024, 512, 32768>>>(early, total, 2000);
+            else if (cfg == 2) probe_mfma_war<0, 10><<<1024, 512, 32768>>>(early, total, 2000);
+            else probe_mfma_war<0, 22><<<1024, 512, 32768>>>(early, total, 2000);
+            CK(hipGetLastError());
+            CK(hipDeviceSynchronize());
+            unsigned hh[4], t;
+            CK(hipMemcpy(hh, early, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&t, total, 4, hipMemcpyDeviceToHost));
+            printf("mode 7  MFMA A operand reloaded by a ds_read_b128 issued right behind a chain of %d dependent MFMAs that all read it: waves with a wrong product: %u of %u (x 2000 rounds each); waves: mask 0x%x\n",
+                   cfg == 0 ? 1 : cfg == 1 ? 5 : cfg == 2 ? 11 : 23, hh[0], t, hh[3]);
+        }
+    }
+    {
+        CK(hipMemset(early, 0, 16)); CK(hipMemset(total, 0, 4));
+        probe_mfma_overlap<<<1024, 512>>>(early, total, 4000);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        unsigned hh[4], t;
+        CK(hipMemcpy(hh, early, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&t, total, 4, hipMemcpyDeviceToHost));
+        printf("mode 8  v_mfma_f32_16x16x32_f16 with vDst = SrcA (and a dependent one with SrcC = that result): waves with a wrong product: %u of %u (x 4000 rounds each); which: mask 0x%x\n", hh[0], t, hh[2]);
     }
     return 0;
 }
