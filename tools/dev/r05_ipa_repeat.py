@@ -62,8 +62,10 @@ for it in range(N):
     f, p = run()
     if torch.equal(f, f0) and torch.equal(p, p0):
         continue
+    if os.environ.get("NANEQ") and torch.equal(f.nan_to_num(12345.0), f0.nan_to_num(12345.0)) and torch.equal(p, p0):
+        continue                  # (reduced kernels leave feature columns unwritten: NaN-filled on both sides)
     nn_ = torch.isnan(f).any(1)
-    if nn_.any():
+    if nn_.any() and not os.environ.get("NANEQ"):
         rws_ = torch.nonzero(nn_).flatten()
         print(f"it {it}: NaN in feats: samples {sorted(set((rws_ // L).tolist()))} rows {len(rws_)} heads(o) {sorted(set((torch.nonzero(torch.isnan(f[:, :1024]).any(0)).flatten() // 128).tolist()))}", flush=True)
     nbad += 1
