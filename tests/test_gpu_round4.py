@@ -363,3 +363,36 @@ def test_step_with_the_k_rows_as_fragments_is_bit_identical(seeded_sd, B, L, rag
         outs.append([eng.rot.cpu()[m], eng.trans.cpu()[m], eng.ang_raw.cpu()[m], eng.logits.cpu()[m]])
     for a_, b_ in zip(*outs):
         assert torch.equal(a_, b_), float((a_ - b_).abs().max())
+
+
+def test_plan_time_query_agrees_with_the_attention_launcher(seeded_sd):
+    """pf_ipa_proj_inside_ok (ABI 55): what the engine asks at plan time is what pf_ipa_attn_fwd does -- where the query says
+    yes the projection-inside form launches, where it says no the same call is refused (PF_E_BADARG / PF_E_TOOLARGE raise), fp32
+    operands, lengths around every edge of the rule (multiples of 4 and 16, 64 ... 176)."""
+    from pepflowww_amd import _capi
+    lib = _capi.load()
+    sd, pfx = seeded_sd, "ga_encoder.trunk.ipa_1."
+    names = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")
+    w16, bp = pack_ipa_projection(cu(torch.cat([sd[pfx + n + ".weight"] for n in names], 0)), cu(torch.cat([sd[pfx + n + ".bias"] for n in names], 0)))
+    gq = lambda k: cu(sd[pfx + k])  # noqa: E731
+    seen = set()
+    for L in (62, 64, 68, 96, 100, 126, 128, 132, 144, 160, 176):
+        ok = bool(lib.pf_ipa_proj_inside_ok(L, 0))
+        seen.add(ok)
+        B = 1
+        g = torch.Generator().manual_seed(L)
+        s = cu(torch.randn(B * L, 128, generator=g))
+        eye = cu(torch.eye(3).reshape(1, 9).repeat(B * L, 1))
+        args = dict(bias=torch.zeros(B, 8, L, L, device=G.dev()), p_out=torch.zeros(B, 8, L, L, device=G.dev()), variant=2,
+                    dz=torch.zeros(B, L, L, 16, device=G.dev()), fused_proj=(s, w16, bp))
+        call = lambda: G.ipa_feats(torch.zeros(B * L, 3744, device=G.dev()), None, eye, cu(torch.zeros(B * L, 3)), cu(torch.ones(B * L)),  # noqa: E731
+                                   gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"), B, L, **args)
+        if ok:
+            f = call()[0]
+            assert torch.isfinite(f).all(), L
+        else:
+            with pytest.raises(Exception):
+                call()
+    assert seen == {True, False}
+    # f16 operand planes formed in LDS: multiples of 16 up to eight tiles
+    assert lib.pf_ipa_proj_inside_ok(128, 1) == 1 and lib.pf_ipa_proj_inside_ok(120, 1) == 0 and lib.pf_ipa_proj_inside_ok(144, 1) == 0

@@ -319,3 +319,41 @@ def test_capture_guard_holds_the_garbage_collector_off_and_restores_it():
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_engine_options_are_validated_and_noise_is_shard_invariant():
+    """DenoiseEngine(options=...) replaces the environment switches of rounds 3 - 4: unknown keys are refused before anything is
+    allocated; seeded_noise (two draws per sample since round 5) is a pure function of (seed, global sample index)."""
+    import inspect
+    from pepflowww_amd import distributed as D
+    from pepflowww_amd.engine import DenoiseEngine
+    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store"}
+    assert "options" in inspect.signature(DenoiseEngine.__init__).parameters
+    with pytest.raises(AssertionError):
+        DenoiseEngine(None, 1, 16, torch.device("cpu"), options={"no_such_switch": True})
+    full, part = D.seeded_noise(0, 6, 20, 11), D.seeded_noise(2, 5, 20, 11)
+    for k in full:
+        assert torch.equal(full[k][2:5], part[k]), k
+    R = full["rot0"]
+    assert float((R @ R.transpose(-1, -2) - torch.eye(3)).abs().max()) < 1e-5 and float(torch.linalg.det(R).min()) > 0.999
+    assert 0.0 <= float(full["ang0"].min()) and float(full["ang0"].max()) < 6.2832
+    assert not torch.equal(D.seeded_noise(0, 2, 20, 12)["trans0"], full["trans0"][:2])
+
+
+def test_counted_traffic_is_flagged_when_recorded_for_other_kernel_sources(tmp_path, monkeypatch):
+    """bench.py: `roofline.traffic` comes from profiles/rNN/pmc_traffic.json; the file records the hash of the kernel sources it was
+    collected for and the bench line says `traffic_stale` when that is not the hash of the sources being timed."""
+    import json
+    import bench
+    sha = bench.kernel_src_sha()
+    assert len(sha) == 12 and sha == bench.kernel_src_sha()
+    t, src, stale = bench.pmc_traffic("cfg4", "fp32")
+    assert src is None or isinstance(stale, bool)
+    root = tmp_path / "profiles" / "r05"
+    root.mkdir(parents=True)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (root / "pmc_traffic.json").write_text(json.dumps({"_commit": "x", "_src_sha": "0" * 12, "cfg4": {"k": {"hbm_bytes_corrected": 1}}}))
+    monkeypatch.setattr(bench, "kernel_src_sha", lambda: "0" * 12)
+    assert bench.pmc_traffic("cfg4", "fp32")[2] is False
+    monkeypatch.setattr(bench, "kernel_src_sha", lambda: "1" * 12)
+    assert bench.pmc_traffic("cfg4", "fp32")[2] is True
