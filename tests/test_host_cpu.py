@@ -357,3 +357,75 @@ def test_counted_traffic_is_flagged_when_recorded_for_other_kernel_sources(tmp_p
     assert bench.pmc_traffic("cfg4", "fp32")[2] is False
     monkeypatch.setattr(bench, "kernel_src_sha", lambda: "1" * 12)
     assert bench.pmc_traffic("cfg4", "fp32")[2] is True
+
+
+def test_torsion_angles_match_the_reference(golden_dir):
+    """preprocess.get_torsion_angle vs golden F11 = the reference's models_con/torsion.py:48-65 on full-atom coordinates of every
+    residue type (incl. UNK): psi and chi1-4 in [0, 2 pi) to 1e-5 rad (circular), the mask of defined angles exactly."""
+    import math
+    import numpy as np
+    from pepflowww_amd import preprocess as P
+    f = np.load(os.path.join(golden_dir, "f11_torsion.npz"))
+    pos, aa = torch.from_numpy(f["pos"]), torch.from_numpy(f["aa"])
+    for b in range(pos.shape[0]):
+        tors, mask = P.get_torsion_angle(pos[b], aa[b])
+        assert torch.equal(mask, torch.from_numpy(f["mask"][b]))
+        d = (tors - torch.from_numpy(f["torsion"][b])).abs()
+        d = torch.minimum(d, 2 * math.pi - d)
+        assert float(d.max()) < 1e-5, float(d.max())
+        assert float(tors.min()) >= 0.0 and float(tors.max()) < 2 * math.pi + 1e-6
+        assert not tors[~mask].any()
+
+
+def test_pdb_reader_and_preprocess_structure(golden_dir, tmp_path):
+    """preprocess.parse_pdb / preprocess_structure (parsers.py:68-160, pep_dataloader.py:41-84) on files written by io.write_pdb from
+    the full-atom golden F7 (all residue types): residue types, heavy atoms (to the 1e-3 A of the PDB columns) and their mask come back;
+    UNK residues and residues without a backbone are dropped; chains are ordered by identifier; res_nb restarts per chain and jumps
+    over a chain break; the sample is centred on the peptide's C-alpha centroid with the receptor first and its chain_nb + 1."""
+    import numpy as np
+    from pepflowww_amd import io as IO
+    from pepflowww_amd import preprocess as P
+    f = np.load(os.path.join(golden_dir, "f7_full_atom.npz"))
+    pos14, aa, mask14 = torch.from_numpy(f["pos14"]), torch.from_numpy(f["aa"]), torch.from_numpy(f["mask"])
+    L = aa.shape[1]
+
+    def structure(b, n, chain, first_resseq, shift=0.0):
+        pos = torch.zeros(n, 15, 3)
+        pos[:, :14] = pos14[b, :n] + shift
+        m = torch.zeros(n, 15, dtype=torch.bool)
+        m[:, :14] = mask14[b, :n, :14]
+        return dict(aa=aa[b, :n].clone(), pos_heavyatom=pos, mask_heavyatom=m, chain_nb=torch.zeros(n, dtype=torch.int64),
+                    chain_id=[chain] * n, resseq=torch.arange(first_resseq, first_resseq + n), icode=[" "] * n)
+    pep = structure(0, 12, "P", 1)
+    rec = structure(1, L, "A", 5)
+    rec["resseq"][10:] += 7                                   # a numbering gap (the F7 residues are scattered: every C-alpha pair is > 4 A apart)
+    rec["pos_heavyatom"][4] += (rec["pos_heavyatom"][3, 1] + torch.tensor([3.8, 0.0, 0.0]) - rec["pos_heavyatom"][4, 1])   # ... but 3 -> 4 is a bonded pair
+    d = tmp_path / "cplx"
+    d.mkdir()
+    IO.write_pdb(pep, str(d / "peptide.pdb"))
+    IO.write_pdb(rec, str(d / "pocket.pdb"))
+    got, seq_map = P.parse_pdb(str(d / "pocket.pdb"))
+    keep = (rec["aa"] < 20)                                    # UNK is dropped (parsers.py:104-106)
+    assert torch.equal(got["aa"], rec["aa"][keep]) and got["chain_id"] == ["A"] * int(keep.sum())
+    assert torch.equal(got["mask_heavyatom"], rec["mask_heavyatom"][keep])
+    assert float((got["pos_heavyatom"] - rec["pos_heavyatom"][keep] * rec["mask_heavyatom"][keep][..., None]).abs().max()) < 2e-3
+    assert torch.equal(got["resseq"], rec["resseq"][keep]) and len(seq_map) == int(keep.sum())
+    rn = got["res_nb"].tolist()
+    assert rn[0] == 1 and all(b_ > a_ for a_, b_ in zip(rn, rn[1:]))
+    jumps = [b_ - a_ for a_, b_ in zip(rn, rn[1:])]
+    rs = got["resseq"].tolist()
+    ca = got["pos_heavyatom"][:, 1]
+    want = [1 if float((ca[i + 1] - ca[i]).norm()) <= 4.0 else max(2, rs[i + 1] - rs[i]) for i in range(len(rs) - 1)]
+    assert jumps == want and 1 in jumps and 8 in jumps and 2 in jumps   # (bonded pair +1; break: the resseq difference, at least 2)
+    sample = P.preprocess_structure({"id": "x", "pdb_path": str(d)})
+    n_rec, n_pep = int(keep.sum()), 12 - int((pep["aa"] >= 20).sum())
+    assert sample["aa"].shape[0] == n_rec + n_pep and sample["generate_mask"].tolist() == [False] * n_rec + [True] * n_pep
+    assert sample["chain_nb"][:n_rec].unique().tolist() == [1] and sample["chain_nb"][n_rec:].unique().tolist() == [0]
+    ca = sample["pos_heavyatom"][n_rec:, 1]
+    assert float(ca.mean(0).abs().max()) < 2e-3               # centred on the peptide's C-alpha centroid
+    t2, m2 = P.get_torsion_angle(sample["pos_heavyatom"], sample["aa"])
+    assert torch.equal(sample["torsion_angle_mask"], m2) and torch.allclose(sample["torsion_angle"], t2)
+    # a peptide of two residues is refused (logged, None), like pep_dataloader.py:55-56
+    IO.write_pdb(structure(0, 2, "P", 1), str(d / "peptide.pdb"))
+    assert P.preprocess_structure({"id": "x", "pdb_path": str(d)}) is None
+    assert P.residue_type("MSE") == P.residue_type("MET") and P.residue_type("HOH") is None and P.residue_type("UNK") == 20
