@@ -427,6 +427,78 @@ __global__ __launch_bounds__(512) void probe_mfma_overlap(unsigned* early, unsig
     if (bad) atomicOr(&early[2], bad);
 }
 
+// mode 9: mode 6 (the staging ring) with the prologue's CONSUMER: every wave multiplies every staged fragment pair (hi | lo KiB of a
+// K-step) into two accumulators with v_mfma_f32_16x16x32_f16 against an all-ones operand, loading each K-step's fragments just in
+// time (the register pair is reloaded right behind the MFMAs that read it: what hipcc makes of the straight-line prologue), and
+// stores a result to a wave-private LDS row after every tile (the point tiles' epilogue).  Every element of piece n holds the f16
+// value 1 + n / 512, so both sums are exact and known: am = 32 sum_ks v(hi), ac = 32 sum_ks (v(hi) + v(lo)).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void probe_ring_mfma(const _Float16* src /* [11][24][512] halfs */, unsigned* early, unsigned* total, int skew) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned ws0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned voff = lane * 16;
+    constexpr int NCH = 11, NB = 4, CHB = 24576;
+    float* priv = reinterpret_cast<float*>(lds + NB * CHB) + wave * 64 * 4;
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        for (int k = 0; k < 3; ++k) {
+            const int pc = wave + 8 * k;
+            const unsigned long long v = (unsigned long long)(src + ((size_t)c * 24 + pc) * 512);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+            const unsigned la = __builtin_amdgcn_readfirstlane(ws0 + (c % NB) * CHB + pc * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(la) : "memory", "m0");
+        }
+    };
+    h8 ones;
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+    unsigned bad = 0;
+    asm volatile("" ::: "memory");
+    issue(0); issue(1); issue(2);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ndy = (c + 1 < NCH) + (c + 2 < NCH);
+        if (ndy == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ndy == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + NB - 1 < NCH) issue(c + NB - 1);
+        const char* buf = lds + (c % NB) * CHB + lane * 16;
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl) {
+            f4v am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
+            float want_m = 0.f, want_c = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h8 wh = *reinterpret_cast<const h8*>(buf + tl * 8192 + ks * 2048);
+                const h8 wl = *reinterpret_cast<const h8*>(buf + tl * 8192 + ks * 2048 + 1024);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ones, am, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ones, ac, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ones, ac, 0, 0, 0);
+                const float vh = 1.f + (float)(c * 24 + tl * 8 + ks * 2) / 512.f, vl = 1.f + (float)(c * 24 + tl * 8 + ks * 2 + 1) / 512.f;
+                want_m += 32.f * vh;
+                want_c += 32.f * (vh + vl);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (am[e] != want_m) bad |= 1u;
+                if (ac[e] != want_c) bad |= 2u;
+            }
+            priv[lane * 4 + (tl & 3)] = am[0] + ac[1];                    // an LDS store behind every tile
+            if (skew) __builtin_amdgcn_s_sleep(1);
+        }
+        for (int k = 0; k < wave * skew; ++k) __builtin_amdgcn_s_sleep(2);
+    }
+    const unsigned long long bm = __ballot(bad != 0);
+    if (lane == 0) {
+        if (bm) atomicAdd(&early[0], 1u);
+        atomicAdd(total, 1u);
+    }
+    if (bad) { atomicOr(&early[2], bad); atomicOr(&early[3], 1u << wave); }
+}
+
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 6;
     const size_t cold_bytes = (size_t)2 << 30, flush_bytes = (size_t)1 << 30;
@@ -529,6 +601,29 @@ int main(int argc, char** argv) {
         unsigned hh[4], t;
         CK(hipMemcpy(hh, early, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&t, total, 4, hipMemcpyDeviceToHost));
         printf("mode 8  v_mfma_f32_16x16x32_f16 with vDst = SrcA (and a dependent one with SrcC = that result): waves with a wrong product: %u of %u (x 4000 rounds each); which: mask 0x%x\n", hh[0], t, hh[2]);
+    }
+    {
+        _Float16* ringh;
+        CK(hipMalloc(&ringh, 11 * 24 * 1024));
+        std::vector<_Float16> hh(11 * 24 * 512);
+        for (int n = 0; n < 11 * 24; ++n) for (int j = 0; j < 512; ++j) hh[(size_t)n * 512 + j] = (_Float16)(1.0f + (float)n / 512.0f);
+        CK(hipMemcpy(ringh, hh.data(), hh.size() * 2, hipMemcpyHostToDevice));
+        CK(hipFuncSetAttribute((const void*)probe_ring_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576 + 8192));
+        for (int skew = 0; skew <= 4; skew += 2) {
+            unsigned te = 0, tt = 0, m2 = 0, m3 = 0;
+            for (int r = 0; r < 40; ++r) {
+                if ((r & 7) == 0) sweep_kernel<<<2048, 256>>>((const float4*)flush, flush_bytes / 16, sink);
+                CK(hipMemset(early, 0, 16)); CK(hipMemset(total, 0, 4));
+                probe_ring_mfma<<<2048, 512, 4 * 24576 + 8192>>>(ringh, early, total, skew);
+                CK(hipGetLastError());
+                CK(hipDeviceSynchronize());
+                unsigned h4[4], t;
+                CK(hipMemcpy(h4, early, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&t, total, 4, hipMemcpyDeviceToHost));
+                te += h4[0]; tt += t; m2 |= h4[2]; m3 |= h4[3];
+            }
+            printf("mode 9  staging ring + just-in-time fragment loads into MFMAs + an LDS store per tile, wave skew %d: waves with a wrong sum: %u of %u; which sum: mask 0x%x, waves: mask 0x%x\n",
+                   skew, te, tt, m2, m3);
+        }
     }
     return 0;
 }
