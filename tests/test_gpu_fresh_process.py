@@ -32,6 +32,15 @@ def test_shard_check_in_fresh_processes(precision):
     assert not bad, f"{len(bad)} of {n} fresh processes mismatched: {bad[:2]}"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_shard_check_of_the_helper_wave_form_in_fresh_processes(precision):
+    """B x L = 16 x 64: the prologue with HELPER waves (L <= 64, `proj_head` roles 1 / 2) and the score kernel with the pair phase in
+    front -- the other instantiations tools/kernel_isa_pin.py pins (profiles/r05/r05_campaign.txt: 0 of 20 processes each)."""
+    n = int(os.environ.get("PF_FRESH_PROCS_SMALL", 4))
+    bad = _run([16, 64, 3, 2, precision], n)
+    assert not bad, f"{len(bad)} of {n} fresh processes mismatched: {bad[:2]}"
+
+
 def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd):
     """The projection-inside score kernel (fp32 mode) at B x L = 64 x 128, launched 1500 times on the same inputs (the rows rewritten
     by a copy kernel before every launch, as in the step): every output bit-equal to the first launch's.  tools/dev/r05_ipa_repeat.py is

@@ -429,3 +429,25 @@ def test_pdb_reader_and_preprocess_structure(golden_dir, tmp_path):
     IO.write_pdb(structure(0, 2, "P", 1), str(d / "peptide.pdb"))
     assert P.preprocess_structure({"id": "x", "pdb_path": str(d)}) is None
     assert P.residue_type("MSE") == P.residue_type("MET") and P.residue_type("HOH") is None and P.residue_type("UNK") == 20
+
+
+def test_prologue_kernels_are_the_validated_machine_code():
+    """The projection prologue's ordering dependence is not root-caused: what is validated is one machine-code form
+    of the three kernels that run it (0 of 240 fresh processes, profiles/r05/r05_campaign.txt).  A compiler bump or an edit anywhere
+    in ipa_split.hip that changes their instruction streams must not pass silently: the disassembly of the BUILT library is compared
+    with the committed pin; after a deliberate change re-run the GPU validation, then `python tools/kernel_isa_pin.py --update`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_isa_pin", os.path.join(ROOT, "tools", "kernel_isa_pin.py"))
+    pin_tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin_tool)
+    if not pin_tool.tools_present():
+        pytest.skip("llvm-objcopy / clang-offload-bundler / llvm-objdump not in this image")
+    pin = json.load(open(pin_tool.PIN))
+    got = pin_tool.kernel_hashes(pin_tool.LIB)
+    assert set(got) == set(pin_tool.PINNED) == set(pin["kernels"]), (sorted(got), sorted(pin["kernels"]))
+    for k in pin_tool.PINNED:
+        assert got[k]["lds_dma"] > 0 and got[k]["mfma"] > 0
+        assert got[k]["sha1"] == pin["kernels"][k]["sha1"], (
+            f"{k}: the built library's instruction stream ({got[k]['instructions']} instructions, {got[k]['sha1'][:12]}) is not the validated "
+            f"one ({pin['kernels'][k]['instructions']}, {pin['kernels'][k]['sha1'][:12]}; pinned with {pin['hipcc']}): re-run "
+            "tools/dev/r05_campaign.sh + tests/test_gpu_fresh_process.py on the GPU box, then tools/kernel_isa_pin.py --update")
