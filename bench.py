@@ -109,6 +109,7 @@ def check_final_state(smp, batch, K_total):
 
 
 _MODELS = {}
+USE_BUCKETS = True        # ragged workloads (cfg3) run through the length buckets, as FlowModel.sample() does by default (--no-buckets: one engine)
 
 
 def get_model(dev, precision):
@@ -158,19 +159,33 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
         ck = _Clock()
         model.ga_encoder.packed_weights(dev)
         ck.lap("pack_weights_ms")                                    # once per parameter version (0 when already packed)
-        eng = model.ga_encoder.engine(B, L, dev)
-        ck.lap("engine_build_ms")                                    # once per (B, L): workspaces (0 when cached)
-        R1, x1, ang1, seq1, node, edge = model.encode(dbatch, edge_out=eng.edge_buffer())
-        ck.lap("encode_ms")                                          # once per sample() call
-        eng.bind_context(node, edge, dbatch["res_mask"])
-        ck.lap("bind_context_ms")                                    # once per call: block-0 pair bias / values, work lists, launch plan
-        info["z16"] = bool(getattr(eng, "z16", False))
-        smp = eng.sampler(NS)
-        smp.set_seed(20240227, first)
-        smp.set_context(R1, x1, ang1, seq1, dbatch["generate_mask"])
         noise = {k: v for k, v in synth.make_noise(B, L, 1, seed=7, first_sample=first).items() if k != "expo"}
-        smp.init_state(noise)
-        ck.lap("sampler_init_ms")                                    # once per call: noise H2D + state init
+        plan = None
+        if wl.get("variable") and USE_BUCKETS:
+            # ragged batch: FlowModel.sample()'s default path = length buckets on concurrent streams (pepflowww_amd/buckets.py)
+            from pepflowww_amd import buckets as bk
+            plan = bk.plan_length_buckets(bk.sample_lengths(batch["res_mask"]))
+            plan = plan if len(plan) > 1 else None
+        if plan is not None:
+            smp = bk.BucketedSampler(model, plan, B, L, NS, (True, True, True))
+            smp.bind(dbatch, noise, L, 20240227, first)
+            ck.lap("buckets_bind_ms")                                # per bucket: engine (cached), encode, bind_context, sampler init
+            engines = list(smp.engines)
+            info["buckets"] = [{"samples": len(idx), "padded_length": Lk} for idx, Lk in plan]
+        else:
+            eng = model.ga_encoder.engine(B, L, dev)
+            ck.lap("engine_build_ms")                                # once per (B, L): workspaces (0 when cached)
+            R1, x1, ang1, seq1, node, edge = model.encode(dbatch, edge_out=eng.edge_buffer())
+            ck.lap("encode_ms")                                      # once per sample() call
+            eng.bind_context(node, edge, dbatch["res_mask"])
+            ck.lap("bind_context_ms")                                # once per call: block-0 pair bias / values, work lists, launch plan
+            smp = eng.sampler(NS)
+            smp.set_seed(20240227, first)
+            smp.set_context(R1, x1, ang1, seq1, dbatch["generate_mask"])
+            smp.init_state(noise)
+            ck.lap("sampler_init_ms")                                # once per call: noise H2D + state init
+            engines = [eng]
+        info["z16"] = bool(getattr(engines[0], "z16", False))
         if use_graph and smp.needs_capture():
             smp.capture()                                            # (runs the plan once eagerly first: kernel attribute set-up)
         ck.lap("graph_capture_ms")                                   # once per (B, L, num_steps): two hipGraphs (1 and 4 steps)
@@ -195,7 +210,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             from pepflowww_amd.distributed import all_gather_final_state
             all_gather_final_state(smp)
         info["validity"] = check_final_state(smp, batch, NS)
-        info["launches_per_step"] = eng.n_launches + 1
+        info["launches_per_step"] = sum(e.n_launches + 1 for e in engines)
         if wl.get("read_sclk"):
             info["sclk"] = sclk_under_load(smp, use_graph)
         ck = _Clock()
@@ -211,7 +226,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             evs = {}
             st = _capi.stream_ptr()
             for _ in range(min(K, 10)):
-                for entry in eng.plan:
+                for entry in [en for e in engines for en in e.plan]:
                     fn, a, name = entry[0], entry[1], entry[2]
                     if fn is None:
                         continue
@@ -223,8 +238,9 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
                     assert rc == 0, name
             torch.cuda.synchronize()
             n_it = min(K, 10)
-            info["kernel_us"] = {k: {"avg_launch_us": sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e3,
-                                     "launches_per_step": len(v) // n_it,
+            nb = len(engines)        # (length buckets: a "launch" below = one launch per bucket, i.e. one pass over ALL the batch's pairs / rows)
+            info["kernel_us"] = {k: {"avg_launch_us": sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e3 * nb,
+                                     "launches_per_step": len(v) // n_it // nb,
                                      "us_per_step": sum(a.elapsed_time(b) for a, b in v) / n_it * 1e3} for k, v in evs.items()}
     return elapsed, info
 
@@ -314,11 +330,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the f16@cfg4 / fp32@cfg3 / f16@cfg3 entries of the default line")
+    ap.add_argument("--no-buckets", action="store_true", help="ragged workloads (cfg3): one engine at the longest sample's padded length instead of length buckets")
     ap.add_argument("--no-per-call", action="store_true", help="skip the inference.py-style per-call accounting")
     ap.add_argument("--per-call-steps", type=int, default=200)
     args = ap.parse_args()
-    global PER_CALL_STEPS
+    global PER_CALL_STEPS, USE_BUCKETS
     PER_CALL_STEPS = args.per_call_steps
+    USE_BUCKETS = not args.no_buckets
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched the way the driver may launch it (`python bench.py --gpus N`): become N ranks, one per GPU
@@ -458,6 +476,11 @@ def main():
         rf["traffic_stale"] = traffic_stale
         if traffic_stale:
             rf["traffic_note"] = "STALE (recorded for other kernel sources than the ones timed here; tools/pmc_traffic.sh regenerates it) -- " + rf["traffic_note"]
+    if info.get("buckets"):
+        out["config"]["length_buckets"] = info["buckets"]
+        out["config"]["length_buckets_note"] = ("samples split by padded length at the fused attention kernel's limit (128); one engine, launch plan and "
+                                                "hipGraph per bucket, replayed concurrently on separate HIP streams; per-kernel times are the sum over the "
+                                                "buckets' launches (timed one after the other)")
     if wl.get("variable"):
         out["config"]["real_residues_per_gpu"] = info["real_residues"]
         out["value_real_residues"] = world * info["real_residues"] * K / elapsed
@@ -487,6 +510,8 @@ def main():
                    "value": im["B"] * im["L"] * K / em, "unit": "res*step/s", "steps": K, "residues": im["L"],
                    "hbm_roofline_frac": zbm * im["real_pairs"] * K / em / HBM_PEAK, "bytes_per_pair_step": zbm,
                    "final_state_check": im["validity"]}
+            if im.get("buckets"):
+                ent["length_buckets"] = im["buckets"]
             if WORKLOADS[wk].get("variable"):
                 ent["value_real_residues"] = im["real_residues"] * K / em
                 ent["unmasked_pairs"] = im["real_pairs"]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 55
+#define PF_ABI_VERSION 56
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 /* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
  * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
@@ -489,6 +489,10 @@ typedef struct {
     /* optional: device uint64[2] = {seed, first_sample} read at run time (overrides the two fields above), so that the
      * hipGraph captured for one sample() call is replayed by the next call with another seed / shard offset */
     const uint64_t* seed_dev;
+    /* optional (ABI 56): device int64 [B] = the GLOBAL index of each local sample (overrides first_sample + b).  A batch that was
+     * re-ordered on the way in -- the length buckets of a ragged batch (pepflowww_amd/buckets.py) -- then draws exactly the streams
+     * of the unpermuted run: the Philox key is (seed, sample_ids[b], draw, residue, class). */
+    const int64_t* sample_ids;
 } pf_sampler_args;
 /* initial state from raw noise (flow_model.py:252-277): rot0/trans0_raw/ang0/simplex0_raw as drawn */
 int pf_sampler_init(const pf_sampler_args* a, const float* rot0, const float* trans0_raw,

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PF_LIB_PATH: another build of the same library -- same-box A/B runs of kernel variants, tools/dev)
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 55
+ABI_VERSION = 56
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -77,7 +77,7 @@ class SamplerArgs(C.Structure):
                 ("traj_rot", _fp), ("traj_trans", _fp), ("traj_ang", _fp), ("traj_seq", _fp), ("traj_simplex", _fp),
                 ("ts", _fp), ("num_steps", _i), ("step", _fp), ("t_out", _fp),
                 ("expo", _fp), ("seed", C.c_uint64), ("first_sample", C.c_int64),
-                ("B", _i), ("L", _i), ("sample_bb", _i), ("sample_ang", _i), ("sample_seq", _i), ("seed_dev", _fp)]
+                ("B", _i), ("L", _i), ("sample_bb", _i), ("sample_ang", _i), ("sample_seq", _i), ("seed_dev", _fp), ("sample_ids", _fp)]
 
 
 class TrainArgs(C.Structure):

@@ -1,0 +1,244 @@
+"""Length buckets for ragged batches (BASELINE configs[2]: pocket 45-120 + peptide 3-25 residues, pep_dataloader.py:53-54).
+
+The reference pads every sample of a batch to the longest one (PaddingCollate) and its IPA is length-agnostic
+(ipa_pytorch.py:316-484).  Here the attention's fastest form -- projection, scores and aggregation of one (sample, head) in ONE
+workgroup (csrc/ipa_split.hip) -- exists for padded lengths <= 128 only, and ONE sample beyond that puts the whole batch on the
+three-launch form.  Samples never interact (no cross-sample op in encode / ga_encoder / the flow updates: what the multi-GPU
+batch sharding already rests on), so a ragged batch is split BY LENGTH into sub-batches that each get their own engine (own padded
+length, own launch plan, own captured graphs) and run CONCURRENTLY on separate HIP streams: the few long samples no longer decide
+the kernels of the many short ones, and their small launches fill the gaps of the big bucket's instead of running alone.
+
+Results: every sample sees the same inputs, noise and Philox streams (pf_sampler_args.sample_ids keys the in-kernel draws by the
+sample's index in the CALLER's batch) as in the unbucketed run; the values agree to the precision two kernel forms of the same
+arithmetic agree (~1e-6), padded rows carry the context values of a padded residue exactly as before.
+
+Host side only: index plumbing, stream fork / join, one device-side scatter of the trajectories before the D2H copy."""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import _capi
+
+FUSED_MAX_L = 128        # longest padded length of the projection-inside score kernel (pf_ipa_proj_inside_ok)
+
+
+def sample_lengths(res_mask):
+    """1 + index of the last unmasked residue per sample (0 for a fully masked one): what the kernels' key-end lists use."""
+    m = res_mask.to(torch.bool)
+    L = m.shape[1]
+    idx = torch.arange(1, L + 1, device=m.device).expand_as(m)
+    return torch.where(m, idx, torch.zeros_like(idx)).amax(dim=1).tolist()
+
+
+def plan_length_buckets(lengths, edges=(FUSED_MAX_L,), quantum=16):
+    """Partition sample indices by padded length.  `edges`: ascending upper bounds of the buckets' padded lengths (the last bucket is
+    open).  Returns [(indices, L_k)] with L_k = the bucket's own padded length (multiple of `quantum`, >= quantum), buckets in
+    ascending L_k, indices ascending inside a bucket; empty buckets are dropped.  One bucket = "do not split"."""
+    pad = [max(quantum, (int(n) + quantum - 1) // quantum * quantum) for n in lengths]
+    edges = sorted(int(e) for e in edges)
+    groups = [[] for _ in range(len(edges) + 1)]
+    for i, p in enumerate(pad):
+        k = 0
+        while k < len(edges) and p > edges[k]:
+            k += 1
+        groups[k].append(i)
+    return [(g, max(pad[i] for i in g)) for g in groups if g]
+
+
+def _take(v, idx_dev, B, L0, Lk, pad_value=0):
+    """Rows `idx` of a [B, L0, ...] tensor, residue axis cut or padded to Lk."""
+    import torch.nn.functional as F
+    v = v.index_select(0, idx_dev.to(v.device))
+    if v.dim() >= 2 and v.shape[1] == L0 and L0 != Lk:
+        if Lk < L0:
+            v = v[:, :Lk]
+        else:
+            v = F.pad(v, [0, 0] * (v.dim() - 2) + [0, Lk - L0], value=pad_value)
+    return v.contiguous()
+
+
+def sub_batch(batch, idx, L0, Lk):
+    """The samples `idx` of a PaddingCollate-style batch at padded length Lk (pad values as PaddingCollate: zeros, aa -> 21)."""
+    B = batch["aa"].shape[0]
+    it = torch.as_tensor(idx, dtype=torch.int64)
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B:
+            out[k] = _take(v, it, B, L0, Lk, pad_value=21 if k == "aa" else 0)
+        elif isinstance(v, (list, tuple)) and len(v) == B:
+            out[k] = [v[i] for i in idx]
+        else:
+            out[k] = v
+    return out
+
+
+def sub_noise(noise, idx, L0, Lk):
+    """Pre-drawn noise of the samples `idx`, residue axis cut / padded to Lk (identity frames, unit exponentials on the padding: never
+    used, only finite)."""
+    it = torch.as_tensor(idx, dtype=torch.int64)
+    out = {}
+    for k, v in noise.items():
+        if v is None:
+            out[k] = None
+            continue
+        if k == "expo":                                  # [2N, B, L0, 20]
+            w = v.index_select(1, it.to(v.device))
+            if Lk < L0:
+                w = w[:, :, :Lk]
+            elif Lk > L0:
+                w = torch.nn.functional.pad(w, (0, 0, 0, Lk - L0), value=1.0)
+            out[k] = w.contiguous()
+        elif k == "rot0":
+            w = v.index_select(0, it.to(v.device))
+            if Lk < L0:
+                w = w[:, :Lk]
+            elif Lk > L0:
+                eye = torch.eye(3, dtype=w.dtype, device=w.device).expand(w.shape[0], Lk - L0, 3, 3)
+                w = torch.cat([w, eye], 1)
+            out[k] = w.contiguous()
+        else:
+            out[k] = _take(v, it, v.shape[0], L0, Lk)
+    return out
+
+
+class BucketedSampler:
+    """The DeviceSamplers of a ragged batch's length buckets behind the interface of one (run / trajectory / traj_* / N / L_out /
+    eng.B / eng.L): FlowModel.sample(), distributed._final_state_of() and bench.py use it like a DeviceSampler."""
+
+    def __init__(self, model, plan, B, L, num_steps, flags):
+        self.model, self.plan, self.N = model, plan, int(num_steps)
+        self.flags = tuple(bool(f) for f in flags)
+        self.samplers, self.engines = [], []
+        self.eng = SimpleNamespace(B=B, L=L, rows=B * L, buckets=self.engines)      # (merged shape: what _final_state_of / bench read)
+        self.L_out = L
+        self._merged = None
+        self._streams = None
+        self._pad_rows = None
+
+    # ---- set-up of one call ----------------------------------------------------------------------------------------------
+    def bind(self, batch, noise, L0, seed, first_sample, stamp=lambda name: None):
+        """batch / noise: the caller's ([B, L0, ...], not padded).  Builds (or fetches from the encoder's cache) one engine + sampler
+        per bucket, encodes each sub-batch into its engine's pair buffer and initialises the sampler states."""
+        model, dev = self.model, batch["aa"].device
+        self.samplers.clear()
+        self.engines.clear()
+        self._merged = None
+        self._idx_dev = []
+        for idx, Lk in self.plan:
+            sb = sub_batch(batch, idx, L0, Lk)
+            nz = sub_noise(noise, idx, L0, Lk)
+            eng = model.ga_encoder.engine(len(idx), Lk, dev)
+            stamp("engine")
+            R1, x1, ang1, seq1, node, edge = model.encode(sb, edge_out=eng.edge_buffer())
+            stamp("encode")
+            eng.bind_context(node, edge, sb["res_mask"])
+            stamp("bind")
+            smp = eng.sampler(self.N, self.flags)
+            smp.set_seed(seed, first_sample)
+            ids = torch.as_tensor(idx, dtype=torch.int64) + int(first_sample)
+            smp.set_sample_ids(ids)
+            smp.set_context(R1, x1, ang1, seq1, sb["generate_mask"])
+            smp.init_state(nz)
+            smp.L_out = Lk
+            self.samplers.append(smp)
+            self.engines.append(eng)
+            self._idx_dev.append(torch.as_tensor(idx, dtype=torch.int64, device=dev))
+            stamp("setup")
+        self._pad_rows = self._padded_residue(batch)
+        stamp("setup")
+
+    def _padded_residue(self, batch):
+        """Context values of ONE padded residue (what rows beyond a bucket's padded length hold in the unbucketed run): frames from
+        encode() of a PaddingCollate-padded residue, angles 0, residue type 21, simplex of a non-class."""
+        dev = batch["aa"].device
+        dummy = {}
+        B = batch["aa"].shape[0]
+        for k, v in batch.items():
+            if torch.is_tensor(v) and v.dim() >= 2 and v.shape[0] == B:
+                z = torch.zeros((1, 16) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+                if k == "aa":
+                    z.fill_(21)
+                dummy[k] = z
+            else:
+                dummy[k] = v
+        R1, x1, ang1, seq1, _, _ = self.model.encode(dummy)
+        return {"rot": R1[0, 0].reshape(9).clone(), "trans": x1[0, 0].reshape(3).clone(),
+                "ang": torch.zeros(5, device=dev), "seq": torch.full((), 21, dtype=torch.int64, device=dev),
+                "simplex": torch.full((20,), -float(self.model.k), device=dev)}
+
+    # ---- the step loop ---------------------------------------------------------------------------------------------------
+    def needs_capture(self):
+        return any(s.needs_capture() for s in self.samplers)
+
+    def capture(self):
+        for s in self.samplers:
+            if s.needs_capture():
+                s.capture()
+
+    def run(self, n_steps=None, use_graph=True):
+        """Every bucket's loop on its own stream: forked from the current stream, joined back into it."""
+        n = self.N if n_steps is None else n_steps
+        self._merged = None
+        if use_graph:
+            self.capture()
+        cur = torch.cuda.current_stream()
+        if self._streams is None or len(self._streams) < len(self.samplers):
+            self._streams = [torch.cuda.Stream() for _ in self.samplers]
+        for smp, st in zip(self.samplers, self._streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                smp.run(n, use_graph=use_graph)
+        for st in self._streams[:len(self.samplers)]:
+            cur.wait_stream(st)
+
+    def operand_range(self):
+        reps = [e.operand_range() for e in self.engines]
+        out = {k: max(r[k] for r in reps) for k in reps[0] if k not in ("limit", "ok")}
+        out["limit"] = reps[0]["limit"]
+        out["ok"] = all(r["ok"] for r in reps)
+        return out
+
+    # ---- results ---------------------------------------------------------------------------------------------------------
+    def _merge(self):
+        """Scatter the buckets' trajectory buffers into [N, B, L, .] device buffers in the caller's sample order (index plumbing)."""
+        if self._merged is not None:
+            return self._merged
+        B, L, N = self.eng.B, self.eng.L, self.N
+        dev = self._idx_dev[0].device
+        p = self._pad_rows
+        m = {"traj_rot": p["rot"].expand(N, B, L, 9).contiguous(), "traj_trans": p["trans"].expand(N, B, L, 3).contiguous(),
+             "traj_ang": p["ang"].expand(N, B, L, 5).contiguous(), "traj_simplex": p["simplex"].expand(N, B, L, 20).contiguous(),
+             "traj_seq": p["seq"].expand(N, B, L).contiguous(),
+             "rot1": p["rot"].expand(B, L, 9).contiguous(), "trans1": p["trans"].expand(B, L, 3).contiguous(),
+             "ang1": p["ang"].expand(B, L, 5).contiguous(), "seq1": p["seq"].expand(B, L).contiguous()}
+        for smp, idx in zip(self.samplers, self._idx_dev):
+            Bk, Lk = smp.eng.B, smp.eng.L
+            Lc = min(Lk, L)
+            for name, w in (("traj_rot", 9), ("traj_trans", 3), ("traj_ang", 5), ("traj_simplex", 20)):
+                m[name][:, idx, :Lc] = getattr(smp, name).view(N, Bk, Lk, w)[:, :, :Lc]
+            m["traj_seq"][:, idx, :Lc] = smp.traj_seq.view(N, Bk, Lk)[:, :, :Lc]
+            for name, w in (("rot1", 9), ("trans1", 3), ("ang1", 5)):
+                m[name][idx, :Lc] = getattr(smp, name).view(Bk, Lk, w)[:, :Lc]
+            m["seq1"][idx, :Lc] = smp.seq1.view(Bk, Lk)[:, :Lc]
+        rows = B * L
+        self._merged = {"traj_rot": m["traj_rot"].view(N, rows, 9), "traj_trans": m["traj_trans"].view(N, rows, 3),
+                        "traj_ang": m["traj_ang"].view(N, rows, 5), "traj_simplex": m["traj_simplex"].view(N, rows, 20),
+                        "traj_seq": m["traj_seq"].view(N, rows), "rot1": m["rot1"].view(rows, 9), "trans1": m["trans1"].view(rows, 3),
+                        "ang1": m["ang1"].view(rows, 5), "seq1": m["seq1"].view(rows)}
+        return self._merged
+
+    traj_rot = property(lambda self: self._merge()["traj_rot"])
+    traj_trans = property(lambda self: self._merge()["traj_trans"])
+    traj_ang = property(lambda self: self._merge()["traj_ang"])
+    traj_simplex = property(lambda self: self._merge()["traj_simplex"])
+    traj_seq = property(lambda self: self._merge()["traj_seq"])
+    rot1 = property(lambda self: self._merge()["rot1"])
+    trans1 = property(lambda self: self._merge()["trans1"])
+    ang1 = property(lambda self: self._merge()["ang1"])
+    seq1 = property(lambda self: self._merge()["seq1"])
+
+    def trajectory(self, pageable=False):
+        """Same format as DeviceSampler.trajectory: list of N dicts of CPU tensors [B, L_out, ...] in the caller's sample order."""
+        from .sampler import DeviceSampler
+        return DeviceSampler.trajectory(self, pageable=pageable)

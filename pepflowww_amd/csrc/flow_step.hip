@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
     const size_t rowb = (size_t)b * L;
     // Philox key from device memory when the caller says so (a captured graph is then reusable across sample() calls)
     const uint64_t seed = a.seed_dev ? a.seed_dev[0] : a.seed;
-    const long long first = a.seed_dev ? (long long)a.seed_dev[1] : (long long)a.first_sample;
+    const long long gs0 = a.sample_ids ? (long long)a.sample_ids[b] : (a.seed_dev ? (long long)a.seed_dev[1] : (long long)a.first_sample) + b;
     // centre of the generated residues (zero_center_part, flow_model.py:95-106)
     float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
     for (int l = threadIdx.x; l < L; l += 256) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void sampler_init_kernel(pf_sampler_args a, co
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) lg[k] = SIMPLEX_K * sx0[row * KCLS + k];
         long long s0 = s1;
-        if (sq) s0 = categorical_dev(lg, a.expo ? a.expo + row * KCLS : nullptr, seed, first + b, 0, l);
+        if (sq) s0 = categorical_dev(lg, a.expo ? a.expo + row * KCLS : nullptr, seed, gs0, 0, l);
         a.seq_t[row] = s0;
 #pragma unroll
         for (int k = 0; k < KCLS; ++k) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void sampler_step_body(const pf_sampler_args& a) {
     const bool gen = a.gen_mask[row] > 0.5f;
     const size_t nrow = (size_t)n;
     const uint64_t seed = a.seed_dev ? a.seed_dev[0] : a.seed;
-    const long long gs = (a.seed_dev ? (long long)a.seed_dev[1] : (long long)a.first_sample) + b;
+    const long long gs = a.sample_ids ? (long long)a.sample_ids[b] : (a.seed_dev ? (long long)a.seed_dev[1] : (long long)a.first_sample) + b;
 
     // -------- clean prediction --------
     float Rp[9], xp[3], angp[5], sxp[KCLS];

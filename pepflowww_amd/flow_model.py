@@ -93,7 +93,8 @@ class FlowModel(nn.Module):
     # ---- flow_model.py:229-374 ----
     @torch.no_grad()
     def sample(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
-               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False, check_range=True):
+               noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False, check_range=True,
+               buckets="auto"):
         """Reference signature + keyword-only extensions:
         noise        dict(rot0, trans0, ang0, simplex0[, expo]) of pre-drawn noise (parity tests);
         seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator); with noise=None an
@@ -108,6 +109,11 @@ class FlowModel(nn.Module):
                      pack time); the report stays in `model.last_range_report`;
         pageable     return the trajectory in pageable host memory instead of views of pinned staging buffers (callers that keep
                      the trajectories of many complexes alive: pinned memory is a bounded resource);
+        buckets      "auto" (default): a RAGGED batch whose padded sample lengths lie on both sides of the fused attention kernel's limit
+                     (128) is split by length into sub-batches that run concurrently on their own engines (pepflowww_amd/buckets.py;
+                     BASELINE configs[2]); False: one engine at the batch's padded length, whatever the samples' lengths; a tuple of
+                     padded-length bounds: those bucket edges.  Samples are independent, so the values agree with the unsplit run
+                     to kernel-form precision (~1e-6) and the in-kernel draws are keyed by the caller's sample index either way;
         timings      optional dict: filled with the wall-clock seconds of the call's phases (noise / engine / encode / bind / setup /
                      capture / loop / d2h; each phase is followed by a device synchronisation when this is given -- bench.py's
                      per-call accounting)."""
@@ -123,12 +129,20 @@ class FlowModel(nn.Module):
                 _t[0] = now
         dev = batch["aa"].device
         B, L0 = batch["aa"].shape
+        self.last_buckets = None                       # [(samples, padded length)] of the call when it was split by length
         if noise is None:
             if seed is None:
                 noise = default_noise(B, L0)          # torch's global CPU generator, like the reference (flow_model.py:252-277)
             else:                                      # explicit seed: per-global-sample streams (shard == slice of the full run)
                 from .distributed import seeded_noise
                 noise = seeded_noise(first_sample, first_sample + B, L0, seed)
+        if buckets is not None and buckets is not False and "res_mask" in batch and L0 > 16:
+            from . import buckets as _bk
+            edges = (_bk.FUSED_MAX_L,) if buckets == "auto" or buckets is True else tuple(buckets)
+            plan = _bk.plan_length_buckets(_bk.sample_lengths(batch["res_mask"]), edges)
+            if len(plan) > 1:
+                return self._sample_bucketed(plan, batch, num_steps, (sample_bb, sample_ang, sample_seq), noise, seed, first_sample,
+                                             use_graph, return_sampler, timings, pageable, check_range, stamp)
         # Residue axis padded to a multiple of 16 internally (what PaddingCollate does to a shorter sample of a batch: pad values,
         # res_mask False -- padded residues are inert, tests/test_gpu_parity.py ragged cases): every kernel then runs its
         # full-tile path (16-row / 16-key tiles, float4 rows of the [B,8,L,L] buffers).  In-kernel random draws are keyed by
@@ -181,6 +195,44 @@ class FlowModel(nn.Module):
         smp.L_out = L0
         if return_sampler:
             return smp                                 # (owned by the engine: the next sample() call at this shape reuses it)
+        traj = smp.trajectory(pageable=pageable)
+        stamp("d2h")
+        return traj
+
+    def _sample_bucketed(self, plan, batch, num_steps, flags, noise, seed, first_sample, use_graph, return_sampler, timings, pageable,
+                         check_range, stamp):
+        """sample() of a ragged batch through its length buckets (pepflowww_amd/buckets.py): same inputs, noise, Philox streams and
+        output format as the unsplit path."""
+        from .buckets import BucketedSampler
+        stamp("noise")
+        B, L0 = batch["aa"].shape
+        L = (L0 + 15) // 16 * 16
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        smp = BucketedSampler(self, plan, B, L, num_steps, flags)
+        smp.bind(batch, noise, L0, seed, first_sample, stamp)
+        if use_graph and timings is not None and smp.needs_capture():
+            smp.capture()
+            stamp("capture")
+        smp.run(num_steps, use_graph=use_graph)
+        if self.GC_UNDER_LOOP and B * L * num_steps >= 100_000:
+            import gc
+            if gc.isenabled():
+                gc.collect()
+        stamp("loop")
+        if check_range:
+            rep = smp.operand_range()
+            self.last_range_report = rep
+            if not rep["ok"]:
+                import warnings
+                warnings.warn("pepflowww_amd: activations reached " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if k not in ("limit", "ok")) +
+                              f" -- beyond half of the f16 range ({rep['limit']:g}) the split-precision operands saturate / overflow "
+                              "(INTEGRATION.md, numeric range)", RuntimeWarning, stacklevel=3)
+            stamp("range_check")
+        smp.L_out = L0
+        self.last_buckets = [(len(idx), Lk) for idx, Lk in plan]
+        if return_sampler:
+            return smp
         traj = smp.trajectory(pageable=pageable)
         stamp("d2h")
         return traj

@@ -69,6 +69,10 @@ class DeviceSampler:
         # Philox key in device memory (pf_sampler_args.seed_dev): a captured graph then serves every later call
         self.seed_dev = e(2, dt=torch.int64)
         a.seed_dev = self.seed_dev.data_ptr()
+        # ... and the GLOBAL index of every local sample (pf_sampler_args.sample_ids, ABI 56): first_sample + b for a contiguous
+        # shard (set_seed), the caller's own indices for a length bucket of a ragged batch (set_sample_ids, buckets.py)
+        self.sample_ids = e(B, dt=torch.int64)
+        a.sample_ids = self.sample_ids.data_ptr()
         self.args = a
         self.graph = None
         self.graph_k = None
@@ -81,6 +85,14 @@ class DeviceSampler:
         s = s - 2 ** 64 if s >= 2 ** 63 else s                          # uint64 bit pattern in an int64 tensor
         self.args.seed, self.args.first_sample = int(seed) & (2 ** 64 - 1), int(first_sample)
         self.seed_dev.copy_(torch.tensor([s, int(first_sample)], dtype=torch.int64))
+        self.sample_ids.copy_(torch.arange(self.eng.B, dtype=torch.int64) + int(first_sample))
+
+    def set_sample_ids(self, ids):
+        """Global sample index of every local sample (int64 [B]) when they are not first_sample + b: keys the in-kernel Philox
+        draws, so a re-ordered sub-batch draws what its samples draw in the caller's order."""
+        ids = torch.as_tensor(ids, dtype=torch.int64).reshape(-1)
+        assert ids.numel() == self.eng.B, (ids.numel(), self.eng.B)
+        self.sample_ids.copy_(ids)
 
     def _launch_key(self):
         """Everything a captured graph has baked in besides device pointers that never move: the plan (pointer of block 0's pair

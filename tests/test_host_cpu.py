@@ -451,3 +451,41 @@ def test_prologue_kernels_are_the_validated_machine_code():
             f"{k}: the built library's instruction stream ({got[k]['instructions']} instructions, {got[k]['sha1'][:12]}) is not the validated "
             f"one ({pin['kernels'][k]['instructions']}, {pin['kernels'][k]['sha1'][:12]}; pinned with {pin['hipcc']}): re-run "
             "tools/dev/r05_campaign.sh + tests/test_gpu_fresh_process.py on the GPU box, then tools/kernel_isa_pin.py --update")
+
+
+def test_length_bucket_plan_and_sub_batches():
+    """Host logic of pepflowww_amd/buckets.py (no GPU): the plan partitions the samples by padded length at the given edges, buckets
+    carry their own padded length, a batch on one side of the limit stays whole; sub-batches / sub-noise are PaddingCollate-style
+    cuts of the caller's tensors (pad values, identity frames, unit exponentials)."""
+    import sys
+    from pepflowww_amd import buckets as bk
+    sys.path.insert(0, ROOT)
+    import bench
+    lens, _ = bench.variable_lengths(64)
+    plan = bk.plan_length_buckets(lens)
+    assert [(len(i), L) for i, L in plan] == [(61, 128), (3, 144)]
+    assert sorted(i for idx, _ in plan for i in idx) == list(range(64))
+    for idx, Lk in plan:
+        assert idx == sorted(idx) and Lk % 16 == 0 and all(lens[i] <= Lk for i in idx)
+    assert all(lens[i] > 128 for i in plan[1][0])
+    assert len(bk.plan_length_buckets([50, 128, 99])) == 1 and len(bk.plan_length_buckets([130, 144, 129])) == 1
+    assert bk.plan_length_buckets([0, 3, 200], edges=(64, 128)) == [([0, 1], 16), ([2], 208)]
+    assert [(len(i), L) for i, L in bk.plan_length_buckets([61, 137, 100, 128, 70, 130, 96, 133], edges=(96, 128))] == [(3, 96), (2, 128), (3, 144)]
+    m = torch.zeros(3, 20, dtype=torch.bool)
+    m[0, :5] = True
+    m[1, 3] = True
+    assert bk.sample_lengths(m) == [5, 4, 0]
+    B, L0 = 4, 21
+    batch = {"aa": torch.arange(B * L0).reshape(B, L0) % 20, "pos_heavyatom": torch.randn(B, L0, 15, 3),
+             "res_mask": torch.ones(B, L0, dtype=torch.bool), "id": ["a", "b", "c", "d"], "scalar": 3}
+    sb = bk.sub_batch(batch, [3, 1], L0, 16)
+    assert sb["aa"].shape == (2, 16) and torch.equal(sb["aa"], batch["aa"][[3, 1], :16]) and sb["id"] == ["d", "b"] and sb["scalar"] == 3
+    sb = bk.sub_batch(batch, [0, 2], L0, 32)
+    assert sb["aa"].shape == (2, 32) and (sb["aa"][:, L0:] == 21).all() and not sb["res_mask"][:, L0:].any()
+    assert torch.equal(sb["pos_heavyatom"][:, :L0], batch["pos_heavyatom"][[0, 2]]) and (sb["pos_heavyatom"][:, L0:] == 0).all()
+    noise = {"rot0": torch.randn(B, L0, 3, 3), "trans0": torch.randn(B, L0, 3), "expo": torch.rand(6, B, L0, 20), "ang0": None}
+    nz = bk.sub_noise(noise, [2], L0, 32)
+    assert nz["ang0"] is None and nz["expo"].shape == (6, 1, 32, 20) and (nz["expo"][:, :, L0:] == 1).all()
+    assert torch.equal(nz["rot0"][0, L0:], torch.eye(3).expand(32 - L0, 3, 3)) and torch.equal(nz["trans0"][0, :L0], noise["trans0"][2])
+    nz = bk.sub_noise(noise, [1, 0], L0, 16)
+    assert torch.equal(nz["expo"], noise["expo"][:, [1, 0], :16]) and torch.equal(nz["rot0"], noise["rot0"][[1, 0], :16])
