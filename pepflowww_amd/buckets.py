@@ -125,10 +125,13 @@ class BucketedSampler:
         self.engines.clear()
         self._merged = None
         self._idx_dev = []
+        shapes = {}
         for idx, Lk in self.plan:
             sb = sub_batch(batch, idx, L0, Lk)
             nz = sub_noise(noise, idx, L0, Lk)
-            eng = model.ga_encoder.engine(len(idx), Lk, dev)
+            slot = shapes.get((len(idx), Lk), 0)            # two sub-batches of one shape: two engines (they run at the same time)
+            shapes[(len(idx), Lk)] = slot + 1
+            eng = model.ga_encoder.engine(len(idx), Lk, dev, slot=slot)
             stamp("engine")
             R1, x1, ang1, seq1, node, edge = model.encode(sb, edge_out=eng.edge_buffer())
             stamp("encode")

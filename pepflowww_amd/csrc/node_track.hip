@@ -985,7 +985,9 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
         return PF_E_BADARG;
     const size_t lds = (size_t)2 * 2 * TR * 264 * sizeof(_Float16) + (size_t)TR * LDX * sizeof(float) +
                        (size_t)2 * TR * LDP * sizeof(_Float16);
-    if (a->rows >= pf_cu_count() * TR2) {        // a workgroup per CU even at 32 rows: halve the L2 -> CU weight stream
+    if (a->rows >= pf_cu_count() * TR2 && !a->dump_a0) {   // a workgroup per CU even at 32 rows: halve the L2 -> CU weight stream
+        // (!dump_a0: the training forward's dump lives in the 16-row kernel only -- until round 5 a training batch of >= 8192 rows
+        //  took this branch and its LayerNorm input was never stored)
         const size_t lds2 = (size_t)2 * 2 * TR2 * 264 * sizeof(_Float16) + (size_t)TR2 * LDX * sizeof(float) + (size_t)2 * TR2 * LDP * sizeof(_Float16);
         static PfOncePerDevice attr_set;
         if (attr_set.first()) {
@@ -1039,10 +1041,17 @@ extern "C" int pf_node_tfmr_fwd(const pf_node_tfmr_args* a, pf_stream_t stream) 
     // tests/test_gpu_bigshape.py (B=64 = 512 tiles -> 32-row form, vs two B=32 shards = 256 tiles -> 16-row form, bitwise) and
     // tests/test_gpu_parity.py::test_node_track_forms_are_bitwise_identical_across_the_tile_threshold hold it.
     const int tiles16 = (a->L + 15) / 16;
-    const int RTn = ((long)a->B * tiles16 > pf_cu_count() && a->L > 16) ? 2 : 1;
+    auto lds_of = [&](int rt) {
+        const int tr = 16 * rt;
+        return ((size_t)2 * tr * LDX + tr * 8 + (size_t)tr * 4 * LDS_S) * sizeof(float) + (size_t)4 * tr * LDP * sizeof(_Float16);
+    };
+    // (the 32-row form's score rows pass the 160 KiB of LDS beyond L = 176: the 16-row form takes over there -- bit-identical rows by
+    //  the invariant above; until round 5 such a call, e.g. B = 64 x L = 192, was refused as too large)
+    // (the training forward's dump variants exist as 16-row tiles only: a training batch beyond 256 row tiles, e.g. B = 32 x L = 144,
+    //  takes them too instead of being refused)
+    const int RTn = ((long)a->B * tiles16 > pf_cu_count() && a->L > 16 && !a->dump[0] && lds_of(2) <= (size_t)160 * 1024) ? 2 : 1;
     const int TRn = 16 * RTn;
-    const size_t lds = ((size_t)2 * TRn * LDX + TRn * 8 + (size_t)TRn * 4 * LDS_S) * sizeof(float) +
-                       (size_t)4 * TRn * LDP * sizeof(_Float16);
+    const size_t lds = lds_of(RTn);
     if (lds > 160 * 1024) return PF_E_TOOLARGE;
     const int tiles = (a->L + TRn - 1) / TRn;
     const dim3 grid((unsigned)(a->B * tiles));

@@ -220,10 +220,11 @@ class GAEncoder(nn.Module):
             k0 = next(k for k in self._engines if k != keep)
             del self._engines[k0]
 
-    def engine(self, B, L, device):
+    def engine(self, B, L, device, slot=0):
+        """slot: distinguishes engines of the same shape that must be alive at the same time (sub-batches running concurrently)."""
         prec = getattr(self, "_precision", "fp32")
         w = self.packed_weights(device)
-        key = (B, L, str(device), prec)
+        key = (B, L, str(device), prec) if not slot else (B, L, str(device), prec, slot)
         eng = self._engines.get(key)
         if eng is None:
             try:

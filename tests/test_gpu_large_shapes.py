@@ -1,0 +1,106 @@
+"""Shapes BEYOND the benchmarked ones (the reference is length- and batch-agnostic: ipa_pytorch.py:316-484, flow_model.py:111-227).
+
+Round 5 found three shape-dependent dispatch bugs by sweeping B=64 over the lengths of real pockets (tools/dev/r05_len_sweep.py):
+  * pf_node_tfmr_fwd refused B x L beyond 256 row tiles with L > 176 (the 32-row form's LDS need; e.g. 64 x 192) as "too large";
+  * the training forward at more than 256 row tiles (e.g. the reference's default batch 32 at L = 144) was refused: its dump variants
+    are 16-row kernels and the launcher had already chosen 32 rows;
+  * pf_node_head_fwd at >= 8192 rows took the 32-row kernel, which has no dump: a training step of B=64 x 128 would have trained
+    with a LayerNorm input that was never stored -- silently.
+The checks: inference against the CPU oracle on one sample of the big batch; training through a size-independent property -- every
+loss is a per-sample quantity averaged over the batch (flow_model.py:125-218), so losses and parameter gradients of a batch equal
+the mean over its two halves.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(__file__))
+from oracle import pepflow_oracle as O  # noqa: E402  (checker only)
+import pepflowww_amd  # noqa: E402
+from pepflowww_amd import synth  # noqa: E402
+import gpu_util as G  # noqa: E402
+
+
+def _model(seeded_sd, train=False):
+    m = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.to(G.dev())
+    return m.train() if train else m.eval()
+
+
+@pytest.mark.parametrize("B,L", [(64, 192), (24, 192), (40, 208), (6, 400)])
+def test_sampler_at_shapes_beyond_the_benchmarks(seeded_sd, B, L):
+    """Two free steps at (B, L) where the row-tile count passes one workgroup per CU and / or L passes the 32-row node kernels' LDS
+    limit: runs, and the last sample matches the oracle (sequences identical, frames 1e-4)."""
+    m = _model(seeded_sd)
+    NS = 2
+    batch = synth.make_pocket_batch(B, L, 14, seed=77)
+    noise = synth.make_noise(B, L, NS, seed=8)
+    traj = m.sample({k: v.to(G.dev()) for k, v in batch.items()}, num_steps=NS, noise=noise)
+    b = B - 1
+    sub = {k: v[b:b + 1] for k, v in batch.items()}
+    nz = {k: (v[:, b:b + 1] if k == "expo" else v[b:b + 1]).contiguous() for k, v in noise.items()}
+    with torch.no_grad():
+        ref = O.sample(seeded_sd, sub, nz, NS)
+    for i in range(NS):
+        assert torch.equal(traj[i]["seqs"][b], ref[i]["seqs"][0]), (B, L, i)
+    G.assert_close(traj[0]["rotmats"][b], ref[0]["rotmats"][0], 1e-4, f"{B}x{L} rotmats")
+    G.assert_close(traj[0]["trans"][b], ref[0]["trans"][0], 1e-4, f"{B}x{L} trans")
+    m.ga_encoder.release_engines()
+
+
+def _train_noise(B, L, seed):
+    nz = synth.make_noise(B, L, 1, seed=seed)
+    return {"t": torch.rand(B, 1, generator=torch.Generator().manual_seed(seed)) * 0.8 + 0.1, "trans0": nz["trans0"], "rot0": nz["rot0"],
+            "ang0": nz["ang0"], "simplex0": nz["simplex0"], "expo": nz["expo"][:2].clone()}
+
+
+def _step(m, batch, noise):
+    m.zero_grad(set_to_none=True)
+    ld = m({k: v.to(G.dev()) for k, v in batch.items()}, noise=noise)
+    sum(O.LOSS_WEIGHTS[k] * v for k, v in ld.items()).backward()
+    G.sync()
+    return {k: v.item() for k, v in ld.items()}, {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("B,L", [(32, 144), (64, 128)])
+def test_training_step_of_a_big_batch_is_the_mean_of_its_halves(seeded_sd, golden_dir, B, L):
+    """(32, 144): 288 row tiles -- the training forward's 16-row dump kernels past one workgroup per CU; (64, 128): 8192 rows -- the
+    node-head dump.  Tolerance per parameter = 1.5e-3 + 3 x the fp32 noise level the reference itself shows on that parameter (golden
+    F6 'param_fp32_noise'): the two sides differ only in the order of their sums over the batch."""
+    m = _model(seeded_sd, train=True)
+    batch = synth.make_pocket_batch(B, L, 16, seed=4242)
+    noise = _train_noise(B, L, 6)
+    l_full, g_full = _step(m, batch, noise)
+    h = B // 2
+    parts = []
+    for lo, hi in ((0, h), (h, B)):
+        sb = {k: v[lo:hi] for k, v in batch.items()}
+        nz = {k: (v[:, lo:hi] if k == "expo" else v[lo:hi]).contiguous() for k, v in noise.items()}
+        parts.append(_step(m, sb, nz))
+    for k in l_full:
+        mean = 0.5 * (parts[0][0][k] + parts[1][0][k])
+        assert abs(l_full[k] - mean) <= 2e-5 * max(abs(mean), 1e-3), (k, l_full[k], mean)
+    names = json.load(open(os.path.join(golden_dir, "f6_param_names.json")))
+    lvl = dict(zip(names, np.load(os.path.join(golden_dir, "f6_trunk_grads.npz"))["param_fp32_noise"].tolist()))
+    assert len(g_full) >= 400, len(g_full)
+    bad, worst = [], (0.0, None)
+    for n, g in g_full.items():
+        ref = 0.5 * (parts[0][1][n] + parts[1][1][n])
+        if n.endswith("linear_b.bias"):                      # analytically zero (softmax shift invariance): rounding noise on both sides
+            assert g.abs().max() < 2e-5 and ref.abs().max() < 2e-5, n
+            continue
+        tol = 1.5e-3 + 3 * float(lvl.get(n, 0.0))
+        err = ((g - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+        if err / tol > worst[0]:
+            worst = (err / tol, n, err)
+        if not torch.isfinite(g).all() or err > tol:
+            bad.append((n, err, tol))
+    print(f"{B}x{L}: {len(g_full)} gradients, worst err/tol", worst)
+    assert not bad, (len(bad), bad[:8])
