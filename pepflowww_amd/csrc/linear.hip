@@ -424,6 +424,7 @@ __global__ __launch_bounds__(64 * NWV) void linear_split_kernel(pf_linear_args p
 // bound by the L2 -> CU weight stream (256 workgroups x 2 MiB per launch at 32 rows); with 64 rows every fragment feeds four row
 // tiles and that stream is halved, at the same number of workgroups.
 constexpr int WR_BM = 32, WR_K = 128, WR_LDK = WR_K + 8;
+// (48-row form: 16-feature weight tiles in the fp32 mode -- 235 VGPRs, no scratch; 32-feature tiles spill 36 registers there)
 template <bool SP, bool ATT = false, int NRT = 2, int NWT = 2>   // ATT: attention operand planes (pf_linear_args.att_*), as in linear_split_kernel
 __global__ __launch_bounds__(512) void linear_rows_kernel(pf_linear_args p, int Npad) {
     constexpr int BM = 16 * NRT, TW = 16 * NWT;                // rows per workgroup, features per weight tile
@@ -806,7 +807,11 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
         pf_linear_args ar = *a;                                     // (key_end only in the per-sample form)
         if (!per_sample) ar.key_end = nullptr;
         const bool fit32 = fits(WR_BM, 1), fit64 = fits(64, 2);
-        const bool rows_fit = fit32 || fit64;
+        // 48-row form (round 5): row counts a little beyond one 32-row workgroup per CU -- B = 64 x L = 144 .. 192, the padded lengths
+        // of real pockets, 9216 .. 12288 rows -- ran the tiled kernel (103 us at 9216 rows against 50 for the rows kernel at 8192): the
+        // same kernel with three 16-row tiles per workgroup covers them in ONE round of <= 256 workgroups
+        const bool fit48 = !fit32 && !fit64 && fits(48, 1);
+        const bool rows_fit = fit32 || fit64 || fit48;
         if (rows_fit && a->K == WR_K && Npad % 32 == 0 && Npad >= 1024 && a->M >= 256 * WR_BM && !a->relu && !a->row_mask &&
             !a->residual && !a->gate &&
             (!a->att_qk || (a->single_pass && a->pt_rot && a->att_vt && a->att_L > 0 && a->att_L % 16 == 0))) {   // (planes: f16 mode only -- 256 VGPRs + spills in split form)
@@ -816,6 +821,14 @@ extern "C" int pf_linear_fwd(const pf_linear_args* a, pf_stream_t stream) {
                 if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
                 else if (a->single_pass) hipLaunchKernelGGL((linear_rows_kernel<true, false, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
                 else hipLaunchKernelGGL((linear_rows_kernel<false, false, 4, 1>), grid64, dim3(512), 0, s, ar, Npad);
+                PF_CHECK_LAUNCH();
+                return 0;
+            }
+            if (fit48) {
+                const dim3 grid48((unsigned)grid_tiles(48));
+                if (a->att_qk) hipLaunchKernelGGL((linear_rows_kernel<true, true, 3, 2>), grid48, dim3(512), 0, s, ar, Npad);
+                else if (a->single_pass) hipLaunchKernelGGL((linear_rows_kernel<true, false, 3, 2>), grid48, dim3(512), 0, s, ar, Npad);
+                else hipLaunchKernelGGL((linear_rows_kernel<false, false, 3, 1>), grid48, dim3(512), 0, s, ar, Npad);
                 PF_CHECK_LAUNCH();
                 return 0;
             }
