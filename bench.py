@@ -660,6 +660,24 @@ def per_call_bench(dev, precision, num_samples=64):
         wall = sum(c["wall_ms"] for c in calls)
         loop = sum(c["loop_ms"] for c in calls)
         res[name] = {"wall_ms": round(wall, 1), "loop_ms": round(loop, 1), "overhead_frac": round(1 - loop / wall, 4), "calls": calls}
+    # ... and one RAGGED batch (the cfg3 workload: 64 pockets of different length in one call): FlowModel.sample() splits it into length
+    # buckets (pepflowww_amd/buckets.py) -- two engines, two encodes, one device-side scatter of the trajectories before the D2H copy
+    rb, _, _, _ = make_batch(WORKLOADS["cfg3"], 0)
+    rb = {k: v.to(dev) for k, v in rb.items()}
+    rag = {}
+    for name in ("cold", "warm"):
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        traj = model.sample(rb, num_steps=NS, seed=1234, timings=tm)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        assert len(traj) == NS and torch.isfinite(traj[-1]["trans"]).all()
+        rag[name] = {"wall_ms": round(wall * 1e3, 2), "loop_ms": round(tm["loop"] * 1e3, 2), "ms_per_step": round(tm["loop"] / NS * 1e3, 4),
+                     "overhead_frac": round(1 - tm["loop"] / wall, 4), "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items() if k != "loop"}}
+        del traj
+    rag["length_buckets"] = model.last_buckets
+    res["ragged_cfg3"] = rag
     res["note"] = (f"{len(PER_CALL_LENGTHS)} complexes x {num_samples} samples x {NS} steps through FlowModel.sample (CPU trajectory returned); "
                    "the timings hook synchronises after every phase, so the phases add up to the wall time")
     res["engines_cached"] = len(model.ga_encoder._engines)
