@@ -13,12 +13,9 @@ sample's index in the CALLER's batch) as in the unbucketed run; the values agree
 arithmetic agree (~1e-6), padded rows carry the context values of a padded residue exactly as before.
 
 Host side only: index plumbing, stream fork / join, one device-side scatter of the trajectories before the D2H copy."""
-import math
 from types import SimpleNamespace
 
 import torch
-
-from . import _capi
 
 FUSED_MAX_L = 128        # longest padded length of the projection-inside score kernel (pf_ipa_proj_inside_ok)
 
@@ -160,6 +157,9 @@ class BucketedSampler:
         """Context values of ONE padded residue (what rows beyond a bucket's padded length hold in the unbucketed run): frames from
         encode() of a PaddingCollate-padded residue, angles 0, residue type 21, simplex of a non-class."""
         dev = batch["aa"].device
+        cache = self.model.__dict__.setdefault("_pad_row_cache", {})          # (frames of a padded residue depend on no weight)
+        if dev in cache:
+            return cache[dev]
         dummy = {}
         B = batch["aa"].shape[0]
         for k, v in batch.items():
@@ -171,9 +171,10 @@ class BucketedSampler:
             else:
                 dummy[k] = v
         R1, x1, ang1, seq1, _, _ = self.model.encode(dummy)
-        return {"rot": R1[0, 0].reshape(9).clone(), "trans": x1[0, 0].reshape(3).clone(),
-                "ang": torch.zeros(5, device=dev), "seq": torch.full((), 21, dtype=torch.int64, device=dev),
-                "simplex": torch.full((20,), -float(self.model.k), device=dev)}
+        cache[dev] = {"rot": R1[0, 0].reshape(9).clone(), "trans": x1[0, 0].reshape(3).clone(),
+                      "ang": torch.zeros(5, device=dev), "seq": torch.full((), 21, dtype=torch.int64, device=dev),
+                      "simplex": torch.full((20,), -float(self.model.k), device=dev)}
+        return cache[dev]
 
     # ---- the step loop ---------------------------------------------------------------------------------------------------
     def needs_capture(self):
