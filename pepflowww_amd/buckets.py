@@ -216,12 +216,22 @@ class BucketedSampler:
         cur = torch.cuda.current_stream()
         key = cur.device.index if cur.device.index is not None else torch.cuda.current_device()
         cache = _STREAMS.setdefault(key, {})
+        work = [s.eng.B * s.eng.L * s.eng.L for s in self.samplers]
+        big = max(range(n), key=lambda b: work[b])
+        rest = [b for b in range(n) if b != big]
+
+        def by_role(big_stream, other_streams):      # the arbitration is a property of the streams: keep them by ROLE, not by bucket index
+            out = [None] * n
+            out[big] = big_stream
+            for b, st in zip(rest, other_streams):
+                out[b] = st
+            return out
         if n in cache:
-            return cache[n]
+            return by_role(*cache[n])
         cands = [torch.cuda.Stream() for _ in range(n + 3)]
         if not self.CALIBRATE or n < 2:
-            cache[n] = cands[:n]
-            return cache[n]
+            cache[n] = (cands[0], cands[1:n])
+            return by_role(*cache[n])
         k = max(1, min(4, self.N))
 
         def timed(assign):                    # assign: {bucket: stream}; the other buckets sit this one out
@@ -235,9 +245,6 @@ class BucketedSampler:
                 cur.wait_stream(st)
             torch.cuda.synchronize()
             return time.perf_counter() - t0
-        work = [s.eng.B * s.eng.L * s.eng.L for s in self.samplers]
-        big = max(range(n), key=lambda b: work[b])
-        rest = [b for b in range(n) if b != big]
         timed({b: cands[0] for b in [big]})                                   # (first use: lazy set-up)
         alone = [min(timed({b: cands[0]}) for _ in range(2)) for b in range(n)]
         serial, best = sum(alone), None
@@ -249,17 +256,17 @@ class BucketedSampler:
                 t = timed(assign)
                 if best is None or t < best[0]:
                     best = (t, assign)
-                if t < alone[big] + 0.35 * (serial - alone[big]):             # the small buckets' time mostly hidden: take it
+                if t < alone[big] + 0.6 * (serial - alone[big]):              # clearly below "one after the other": take it
                     break
             else:
                 continue
             break
-        cache[n] = [best[1][b] for b in range(n)]
+        cache[n] = (best[1][big], [best[1][b] for b in rest])
         self.calibration = {"steps": k, "alone_ms": [round(a / k * 1e3, 3) for a in alone], "chosen_ms": round(best[0] / k * 1e3, 3)}
         for smp, nz in zip(self.samplers, self._nz):                          # the probe steps moved the states: start over
             smp.init_state(nz)
         torch.cuda.synchronize()
-        return cache[n]
+        return by_role(*cache[n])
 
     def operand_range(self):
         reps = [e.operand_range() for e in self.engines]
