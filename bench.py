@@ -526,7 +526,8 @@ def main():
                                          "mfma_frac_of_split_ceiling": tr["roofline"]["frac"], "launches_per_step": tr["config"].get("launches_per_step")}
         except Exception as e:                                   # the training entry must never take the inference line down with it
             out["modes"]["fp32@cfg5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        torch.cuda.empty_cache()
+        if not os.environ.get("PF_BENCH_KEEP_CACHE"):
+            torch.cuda.empty_cache()
     if world == 1 and not args.no_per_call and args.workload == "cfg4":
         out["per_call"] = per_call_bench(dev, prec)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -43,26 +43,39 @@ def plan_length_buckets(lengths, edges=(FUSED_MAX_L,), quantum=16):
     return [(g, max(pad[i] for i in g)) for g in groups if g]
 
 
-def _take(v, idx_dev, B, L0, Lk, pad_value=0):
-    """Rows `idx` of a [B, L0, ...] tensor, residue axis cut or padded to Lk."""
-    import torch.nn.functional as F
-    v = v.index_select(0, idx_dev.to(v.device))
-    if v.dim() >= 2 and v.shape[1] == L0 and L0 != Lk:
-        if Lk < L0:
-            v = v[:, :Lk]
-        else:
-            v = F.pad(v, [0, 0] * (v.dim() - 2) + [0, Lk - L0], value=pad_value)
-    return v.contiguous()
+def _rows(v, idx, axis=0):
+    """v[idx] along `axis`: device tensors by one GPU gather, host tensors through numpy (torch's CPU ops fork an OpenMP team beyond 32 k
+    elements, which was measured at 20 - 200 ms in a process with a large idle thread pool: sampler.quat_to_rot_host)."""
+    if v.is_cuda:
+        return v.index_select(axis, torch.as_tensor(idx, dtype=torch.int64, device=v.device))
+    import numpy as np
+    return torch.from_numpy(np.ascontiguousarray(np.take(v.numpy(), np.asarray(idx, dtype=np.int64), axis=axis)))
+
+
+def _fit(v, L0, Lk, axis=1, value=0):
+    """Residue axis cut or padded from L0 to Lk."""
+    from .flow_model import _pad_axis1
+    if Lk == L0:
+        return v
+    if Lk < L0:
+        return v.narrow(axis, 0, Lk).contiguous()
+    if axis == 1:
+        return _pad_axis1(v, Lk - L0, value)
+    lead = tuple(v.shape[:axis - 1])                     # ([2N, B, L0, 20]: fold the leading axis, pad, unfold)
+    w = _pad_axis1(v.reshape((-1,) + tuple(v.shape[axis:])), Lk - L0, value)
+    return w.reshape(lead + tuple(v.shape[axis - 1:axis]) + (Lk,) + tuple(v.shape[axis + 1:]))
 
 
 def sub_batch(batch, idx, L0, Lk):
     """The samples `idx` of a PaddingCollate-style batch at padded length Lk (pad values as PaddingCollate: zeros, aa -> 21)."""
     B = batch["aa"].shape[0]
-    it = torch.as_tensor(idx, dtype=torch.int64)
     out = {}
     for k, v in batch.items():
         if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B:
-            out[k] = _take(v, it, B, L0, Lk, pad_value=21 if k == "aa" else 0)
+            w = _rows(v, idx)
+            if w.dim() >= 2 and w.shape[1] == L0:
+                w = _fit(w, L0, Lk, 1, 21 if k == "aa" else 0)
+            out[k] = w.contiguous()
         elif isinstance(v, (list, tuple)) and len(v) == B:
             out[k] = [v[i] for i in idx]
         else:
@@ -73,29 +86,26 @@ def sub_batch(batch, idx, L0, Lk):
 def sub_noise(noise, idx, L0, Lk):
     """Pre-drawn noise of the samples `idx`, residue axis cut / padded to Lk (identity frames, unit exponentials on the padding: never
     used, only finite)."""
-    it = torch.as_tensor(idx, dtype=torch.int64)
     out = {}
     for k, v in noise.items():
         if v is None:
             out[k] = None
-            continue
-        if k == "expo":                                  # [2N, B, L0, 20]
-            w = v.index_select(1, it.to(v.device))
+        elif k == "expo":                                  # [2N, B, L0, 20]
+            w = _rows(v, idx, axis=1)
             if Lk < L0:
-                w = w[:, :, :Lk]
+                w = w[:, :, :Lk].contiguous()
             elif Lk > L0:
-                w = torch.nn.functional.pad(w, (0, 0, 0, Lk - L0), value=1.0)
-            out[k] = w.contiguous()
+                w = _fit(w, L0, Lk, 2, 1.0)
+            out[k] = w
         elif k == "rot0":
-            w = v.index_select(0, it.to(v.device))
-            if Lk < L0:
-                w = w[:, :Lk]
-            elif Lk > L0:
-                eye = torch.eye(3, dtype=w.dtype, device=w.device).expand(w.shape[0], Lk - L0, 3, 3)
-                w = torch.cat([w, eye], 1)
-            out[k] = w.contiguous()
+            w = _fit(_rows(v, idx), L0, Lk, 1, 0)
+            if Lk > L0:
+                w[:, L0:, 0, 0] = 1
+                w[:, L0:, 1, 1] = 1
+                w[:, L0:, 2, 2] = 1
+            out[k] = w
         else:
-            out[k] = _take(v, it, v.shape[0], L0, Lk)
+            out[k] = _fit(_rows(v, idx), L0, Lk, 1, 0)
     return out
 
 

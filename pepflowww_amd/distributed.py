@@ -128,13 +128,12 @@ def seeded_noise(lo, hi, L, seed):
         g = torch.Generator().manual_seed((int(seed) * 1000003 + i) % (2 ** 63 - 1))
         nrm[k].normal_(generator=g)
         uni[k].uniform_(generator=g)
-    q = nrm[..., :4]
-    q = q / q.norm(dim=-1, keepdim=True)
-    a, b, c, d = q.unbind(-1)
-    rot = torch.stack([a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c),
-                       2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b),
-                       2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d], -1).reshape(max(n, 0), L, 3, 3)
-    return {"rot0": rot, "trans0": nrm[..., 4:7].contiguous(), "ang0": uni * (2 * math.pi), "simplex0": nrm[..., 7:].contiguous()}
+    # (the algebra and the slicing in numpy: single-threaded by construction -- see sampler.quat_to_rot_host)
+    import numpy as np
+    from .sampler import quat_to_rot_host
+    a = nrm.numpy()
+    return {"rot0": quat_to_rot_host(a[..., :4]), "trans0": torch.from_numpy(np.ascontiguousarray(a[..., 4:7])),
+            "ang0": torch.from_numpy(uni.numpy() * np.float32(2 * math.pi)), "simplex0": torch.from_numpy(np.ascontiguousarray(a[..., 7:]))}
 
 
 def _final_state_of(smp):

@@ -14,15 +14,27 @@ MAX_NUM_HEAVYATOMS = 15     # pepflow/modules/protein/constants.py:91
 _PAD_AA = 21                # constants.PAD_RESIDUE_INDEX (pepflow/utils/data.py:9-13)
 
 
+def _pad_axis1(v, n, value=0):
+    """[B, L0, ...] -> [B, L0 + n, ...] with `value` appended along the residue axis.  Host tensors go through numpy (torch's CPU ops fork
+    an OpenMP team beyond 32 k elements: 20 - 200 ms stalls were measured on a 150 KB pad, see sampler.quat_to_rot_host), device tensors
+    through one GPU kernel."""
+    if v.is_cuda:
+        import torch.nn.functional as F
+        return F.pad(v, [0, 0] * (v.dim() - 2) + [0, n], value=value)
+    import numpy as np
+    a = v.numpy()
+    out = np.full((a.shape[0], a.shape[1] + n) + a.shape[2:], value, dtype=a.dtype)
+    out[:, :a.shape[1]] = a
+    return torch.from_numpy(out)
+
+
 def _pad_residues(batch, noise, L0, L):
     """Pad every per-residue tensor of the batch ([B, L0, ...]) and of the pre-drawn noise to L residues the way PaddingCollate
     pads (zeros; aa -> 21; masks False).  Index plumbing only."""
-    import torch.nn.functional as F
     out = {}
     for k, v in batch.items():
         if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == L0:
-            pad = [0, 0] * (v.dim() - 2) + [0, L - L0]
-            out[k] = F.pad(v, pad, value=_PAD_AA if k == "aa" else 0)
+            out[k] = _pad_axis1(v, L - L0, _PAD_AA if k == "aa" else 0)
         else:
             out[k] = v
     nz = {}
@@ -30,17 +42,21 @@ def _pad_residues(batch, noise, L0, L):
         if v is None:
             nz[k] = None
         elif k == "expo":                                # [2N, B, L0, 20]; padded draws are never used (1.0 keeps p / E finite)
-            nz[k] = F.pad(v, (0, 0, 0, L - L0), value=1.0)
+            nz[k] = _pad_axis1(v.reshape((-1, L0) + tuple(v.shape[3:])), L - L0, 1.0).reshape(tuple(v.shape[:2]) + (L,) + tuple(v.shape[3:]))
         elif k == "rot0":                                # [B, L0, 3, 3]: identity frames on the padding
-            eye = torch.eye(3, dtype=v.dtype, device=v.device).expand(v.shape[0], L - L0, 3, 3)
-            nz[k] = torch.cat([v, eye], 1)
+            w = _pad_axis1(v, L - L0, 0)
+            w[:, L0:, 0, 0] = 1
+            w[:, L0:, 1, 1] = 1
+            w[:, L0:, 2, 2] = 1
+            nz[k] = w
         else:
-            nz[k] = F.pad(v, [0, 0] * (v.dim() - 2) + [0, L - L0])
+            nz[k] = _pad_axis1(v, L - L0, 0)
     return out, nz
 
 
 class FlowModel(nn.Module):
     GC_UNDER_LOOP = True      # sample(): run the cyclic garbage collector while the device works through the step loop (see there)
+    GC_MIN_PAIR_STEPS = 40_000_000   # ... when the loop is long enough to hide a full pass (~3 ns of device time per pair and step: >= 120 ms)
 
     def __init__(self, cfg):
         super().__init__()
@@ -92,7 +108,24 @@ class FlowModel(nn.Module):
 
     # ---- flow_model.py:229-374 ----
     @torch.no_grad()
-    def sample(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
+    def sample(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, **kw):
+        """FlowModel.sample of the reference (flow_model.py:229-374); keyword-only extensions: see _sample_impl.
+        The cyclic garbage collector is HELD OFF for the host phases of the call (and released again before returning): an automatic
+        full collection costs 60 - 180 ms in a process that holds a few engines, and it used to land in whatever phase allocated the
+        object that tripped it -- five of eight first-visit calls of the per-call benchmark (profiles/r05/README.md, gc trace).  The
+        one collection a call does need runs where it is free: while the device works through the step loop (GC_UNDER_LOOP)."""
+        import gc
+        was = gc.isenabled()
+        if was:
+            gc.disable()
+        self._gc_was_enabled = was
+        try:
+            return self._sample_impl(batch, num_steps, sample_bb, sample_ang, sample_seq, **kw)
+        finally:
+            if was:
+                gc.enable()
+
+    def _sample_impl(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
                noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False, check_range=True,
                buckets="auto"):
         """Reference signature + keyword-only extensions:
@@ -175,9 +208,9 @@ class FlowModel(nn.Module):
         # trajectory), so a loop over complexes triggers full collections anyway -- 15 - 90 ms each, in whatever host phase they hit
         # (BENCH r05: three of eight warm calls, 180 of 295 ms of all overhead); collecting here, under >= ~40 ms of device work,
         # takes them out of the call's critical path.  Only when the collector is enabled at all.
-        if self.GC_UNDER_LOOP and B * L * num_steps >= 100_000:
+        if self.GC_UNDER_LOOP and B * L * L * num_steps >= self.GC_MIN_PAIR_STEPS:
             import gc
-            if gc.isenabled():
+            if getattr(self, "_gc_was_enabled", gc.isenabled()):
                 gc.collect()
         stamp("loop")
         if check_range:
@@ -215,9 +248,9 @@ class FlowModel(nn.Module):
             smp.capture()
             stamp("capture")
         smp.run(num_steps, use_graph=use_graph)
-        if self.GC_UNDER_LOOP and B * L * num_steps >= 100_000:
+        if self.GC_UNDER_LOOP and B * L * L * num_steps >= self.GC_MIN_PAIR_STEPS:
             import gc
-            if gc.isenabled():
+            if getattr(self, "_gc_was_enabled", gc.isenabled()):
                 gc.collect()
         stamp("loop")
         if check_range:

@@ -12,23 +12,34 @@ rebuilds `t` on the host every step (288).  Here the whole loop lives on the GPU
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _capi
+
+
+def quat_to_rot_host(q):
+    """Unit quaternions [..., 4] -> rotation matrices [..., 3, 3] on the host, in NUMPY: torch's CPU ops fork an OpenMP team for any
+    tensor beyond 32 k elements, and in a process whose (often > 100) pool threads were used elsewhere that fork was measured at 20 - 200 ms
+    for a 150 KB tensor (profiles/r05/README.md, per-call stalls) -- numpy's elementwise loops stay on the calling thread."""
+    import numpy as np
+    q = q.numpy() if torch.is_tensor(q) else q
+    q = q / np.sqrt((q * q).sum(-1, keepdims=True))
+    a, b, c, d = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    rot = np.stack([a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c),
+                    2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b),
+                    2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d], -1).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(rot.reshape(q.shape[:-1] + (3, 3))))
 
 
 def default_noise(B, L, generator=None):
     """Initial noise drawn on the host like the reference's uniform_so3 (pepflow/modules/so3/dist.py:40-45,
     Haar via normalised Gaussian quaternions) + randn / rand (flow_model.py:255,264,269)."""
     g = generator
-    q = torch.randn(B, L, 4, generator=g)
-    q = q / q.norm(dim=-1, keepdim=True)
-    a, b, c, d = q.unbind(-1)
-    rot = torch.stack([a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c),
-                       2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b),
-                       2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d], -1).reshape(B, L, 3, 3)
-    return {"rot0": rot, "trans0": torch.randn(B, L, 3, generator=g),
-            "ang0": torch.rand(B, L, 5, generator=g) * (2 * math.pi),
+    q = torch.randn(B, L, 4, generator=g)                 # (draw order as before: rotations, translations, angles, simplex)
+    trans0 = torch.randn(B, L, 3, generator=g)
+    ang = torch.rand(B, L, 5, generator=g)
+    return {"rot0": quat_to_rot_host(q), "trans0": trans0, "ang0": torch.from_numpy(ang.numpy() * np.float32(2 * math.pi)),
             "simplex0": torch.randn(B, L, 20, generator=g)}
 
 
