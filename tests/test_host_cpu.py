@@ -489,3 +489,35 @@ def test_length_bucket_plan_and_sub_batches():
     assert torch.equal(nz["rot0"][0, L0:], torch.eye(3).expand(32 - L0, 3, 3)) and torch.equal(nz["trans0"][0, :L0], noise["trans0"][2])
     nz = bk.sub_noise(noise, [1, 0], L0, 16)
     assert torch.equal(nz["expo"], noise["expo"][:, [1, 0], :16]) and torch.equal(nz["rot0"], noise["rot0"][[1, 0], :16])
+
+
+def test_host_plumbing_in_numpy_equals_the_torch_formulation():
+    """sample()'s host-side index plumbing runs in numpy (a torch CPU op beyond 32 k elements forks an OpenMP team: 20 - 200 ms stalls
+    per call were measured on the GPU boxes' hosts): bit-identical to the torch ops it replaced -- seeded streams must not move."""
+    import math
+    import torch.nn.functional as F
+    from pepflowww_amd import flow_model as fm, distributed as D, sampler as S
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(7, 50, 4, generator=g)
+    qn = q / q.norm(dim=-1, keepdim=True)
+    a, b, c, d = qn.unbind(-1)
+    ref = torch.stack([a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c), 2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b),
+                       2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d], -1).reshape(7, 50, 3, 3)
+    assert torch.equal(S.quat_to_rot_host(q), ref)
+    B, L0, L = 3, 21, 32
+    noise = {"rot0": torch.randn(B, L0, 3, 3), "trans0": torch.randn(B, L0, 3), "ang0": torch.rand(B, L0, 5), "simplex0": torch.randn(B, L0, 20),
+             "expo": torch.rand(6, B, L0, 20), "none": None}
+    batch = {"aa": torch.randint(0, 20, (B, L0)), "pos_heavyatom": torch.randn(B, L0, 15, 3), "res_mask": torch.ones(B, L0, dtype=torch.bool), "id": ["a", "b", "c"]}
+    ob, nz = fm._pad_residues(batch, noise, L0, L)
+    assert torch.equal(nz["expo"], F.pad(noise["expo"], (0, 0, 0, L - L0), value=1.0)) and nz["none"] is None
+    assert torch.equal(nz["rot0"], torch.cat([noise["rot0"], torch.eye(3).expand(B, L - L0, 3, 3)], 1))
+    for k in ("trans0", "ang0", "simplex0"):
+        assert torch.equal(nz[k], F.pad(noise[k], [0, 0] * (noise[k].dim() - 2) + [0, L - L0]))
+    assert torch.equal(ob["aa"], F.pad(batch["aa"], [0, L - L0], value=21)) and not ob["res_mask"][:, L0:].any() and ob["id"] == batch["id"]
+    assert torch.equal(ob["pos_heavyatom"], F.pad(batch["pos_heavyatom"], [0, 0, 0, 0, 0, L - L0]))
+    torch.manual_seed(5)
+    x = S.default_noise(4, 30)
+    torch.manual_seed(5)
+    q = torch.randn(4, 30, 4); t0 = torch.randn(4, 30, 3); an = torch.rand(4, 30, 5) * (2 * math.pi); sx = torch.randn(4, 30, 20)
+    assert torch.equal(x["trans0"], t0) and torch.equal(x["ang0"], an) and torch.equal(x["simplex0"], sx)     # (draw order unchanged)
+    assert torch.equal(x["rot0"], S.quat_to_rot_host(q))
