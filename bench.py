@@ -334,6 +334,9 @@ def main():
     ap.add_argument("--no-per-call", action="store_true", help="skip the inference.py-style per-call accounting")
     ap.add_argument("--per-call-steps", type=int, default=200)
     args = ap.parse_args()
+    if os.environ.get("PF_BENCH_O_PREMUL") == "0":              # same-box A/B of the folded value projection (DenoiseEngine.O_PREMUL)
+        from pepflowww_amd.engine import DenoiseEngine
+        DenoiseEngine.O_PREMUL = False
     global PER_CALL_STEPS, USE_BUCKETS
     PER_CALL_STEPS = args.per_call_steps
     USE_BUCKETS = not args.no_buckets

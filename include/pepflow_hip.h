@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 56
+#define PF_ABI_VERSION 57
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 /* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
  * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
@@ -268,6 +268,13 @@ typedef struct {
     const int* key_end; int key_L;
     /* optional (training forward, fp32-parity mode): a0 = s_in + mask * linear_out(feats), the LayerNorm's input, [rows,128] */
     float* dump_a0;
+    /* optional (ABI 57): 1 = the first 1024 columns of feats hold, per head h, that head's CONTRIBUTION to linear_out's output
+     * (feats[:, 128 h + n] = sum_j P_h (W_out[:, 128 h : 128 h + 128] v_j)[n]: the value projection was multiplied by linear_out's
+     * o-block when the weights were packed -- linear_out is linear and the softmax rows sum to one, ipa_pytorch.py:456,475-476).
+     * The kernel then ADDS the eight head blocks (fixed order: ((h0 + h2) + h4) + h6, ((h1 + h3) + h5) + h7, the two sums) instead
+     * of contracting them, and w_out_f16 is the [128, 512] matrix of the remaining columns (o_pt | o_pt_norm | o_pair): a third of
+     * the weight stream and of the matrix work of this kernel.  Not with dump_a0. */
+    int o_premul;
 } pf_node_head_args;
 int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream);
 

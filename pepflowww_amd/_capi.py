@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PF_LIB_PATH: another build of the same library -- same-box A/B runs of kernel variants, tools/dev)
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 56
+ABI_VERSION = 57
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -151,7 +151,7 @@ class EdgeFeatArgs(C.Structure):
 
 class NodeHeadArgs(C.Structure):
     _fields_ = [("feats", _fp), ("s_in", _fp), ("mask", _fp), ("w_out_f16", _fp), ("b_out", _fp), ("ln_g", _fp),
-                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i), ("single_pass", _i), ("key_end", _fp), ("key_L", _i), ("dump_a0", _fp)]
+                ("ln_b", _fp), ("w_in_f16", _fp), ("b_in", _fp), ("s_ipa", _fp), ("qkv", _fp), ("rows", _i), ("single_pass", _i), ("key_end", _fp), ("key_L", _i), ("dump_a0", _fp), ("o_premul", _i)]
 
 
 class NodeTfmrArgs(C.Structure):

@@ -115,7 +115,9 @@ __device__ __forceinline__ void put_planes(Planes p, int r, int n, const float (
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool SP, bool DUMP = false>          // DUMP (training forward): a0 = s + mask * linear_out(feats), the LayerNorm's input, is also stored
+// PM (pf_node_head_args.o_premul): the eight head blocks of feats are ADDED (they already went through linear_out's o-block, folded
+// into the value projection), only columns 1024 .. 1535 are contracted -- with the [128, 512] matrix w_out_f16 then holds.
+template <bool SP, bool DUMP = false, bool PM = false>   // DUMP (training forward): a0 = s + mask * linear_out(feats), the LayerNorm's input, is also stored
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_head_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int CK = 256, LDC = CK + 8;      // feats chunk width (8 K-steps = the weight ring depth), f16 stride
@@ -128,8 +130,9 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
     if (pf_rows_all_masked(a.key_end, a.key_L, m0, TR, M)) return;         // padded batch: nothing of this row tile is consumed
     const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
 
+    constexpr int C0 = PM ? 4 : 0;             // first contracted chunk (PM: the o-block's four chunks are summed, not contracted)
     WSplit<1, 8, SP> ws;
-    ws.init(a.w_out_f16, 128, PF_IPA_FEATS, wave * 16);
+    ws.init(a.w_out_f16, 128, PF_IPA_FEATS - C0 * 256, wave * 16);
     ws.prefetch();
     // small per-lane operands
     LnParams lnp;
@@ -166,14 +169,23 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
             *reinterpret_cast<half4*>(bl + srow * LDC + hlf * 128 + 4 * sc4) = lo;
         }
     };
-    commit(0);
+    if constexpr (PM) {
+        // head sums of this thread's (row, 4 features): chunk c, half hlf = head 2 c + hlf.  The order is part of the contract
+        // (node_head32 adds the same way: even heads in sequence, odd heads in sequence, then the two) -- both forms stay bit-identical.
+        auto add4 = [](const float4& p, const float4& q) { return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w); };
+        float4 ev = sel4(sok, st[0][0]), od = sel4(sok, st[0][1]);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) { ev = add4(ev, sel4(sok, st[c][0])); od = add4(od, sel4(sok, st[c][1])); }
+        *reinterpret_cast<float4*>(X + srow * LDX + 4 * sc4) = add4(ev, od);
+    }
+    commit(C0);
     __syncthreads();
     f32x4 am[1], ac[1];
     acc_zero1<1>(am, ac);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = C0; c < NCH; ++c) {
         const _Float16* bh = Ch + (c & 1) * 2 * TR * LDC;
-        gemm_split16(ws, bh, bh + TR * LDC, LDC, am, ac, c * 8, 8);
+        gemm_split16(ws, bh, bh + TR * LDC, LDC, am, ac, (c - C0) * 8, 8);
         if (c + 1 < NCH) commit(c + 1);
         __syncthreads();
     }
@@ -183,11 +195,14 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
     {
         const float rmask = rmask_ld * (mr < M ? 1.f : 0.f);
         const float4 rres = sel4(mr < M, rres_ld);
+        float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PM) hs = *reinterpret_cast<const float4*>(X + r * LDX + n);      // (written before the chunk loop's barriers; this thread overwrites it below)
+        auto lin = [&](int e, float h) { const float j = join(am[0], ac[0], e); if constexpr (PM) return j + h; else return j; };
         float4 y;
-        y.x = (join(am[0], ac[0], 0) + bias_out.x) * rmask + rres.x;
-        y.y = (join(am[0], ac[0], 1) + bias_out.y) * rmask + rres.y;
-        y.z = (join(am[0], ac[0], 2) + bias_out.z) * rmask + rres.z;
-        y.w = (join(am[0], ac[0], 3) + bias_out.w) * rmask + rres.w;
+        y.x = (lin(0, hs.x) + bias_out.x) * rmask + rres.x;
+        y.y = (lin(1, hs.y) + bias_out.y) * rmask + rres.y;
+        y.z = (lin(2, hs.z) + bias_out.z) * rmask + rres.z;
+        y.w = (lin(3, hs.w) + bias_out.w) * rmask + rres.w;
         *reinterpret_cast<float4*>(X + r * LDX + n) = y;
         if constexpr (DUMP) { if (mr < M) *reinterpret_cast<float4*>(a.dump_a0 + (size_t)mr * 128 + n) = y; }
     }
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head_kernel(pf_node_hea
 // fragment feeds two row tiles.  The feats tile is staged chunk by chunk (one chunk of loads in flight under the MFMAs of the
 // previous one) instead of being requested whole at entry (96 VGPRs at 32 rows).
 constexpr int TR2 = 32;
-template <bool SP>
+template <bool SP, bool PM = false>
 __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_head_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int CK = 256, LDC = CK + 8;      // feats chunk width (8 K-steps = the weight ring depth), f16 stride
@@ -235,8 +250,9 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_h
     }
     const int n = wave * 16 + 4 * g;           // this lane's 4 consecutive output features in 128-wide stages
 
+    constexpr int C0 = PM ? 4 : 0;             // first contracted chunk (see node_head_kernel)
     WSplit<1, 8, SP> ws;
-    ws.init(a.w_out_f16, 128, PF_IPA_FEATS, wave * 16);
+    ws.init(a.w_out_f16, 128, PF_IPA_FEATS - C0 * 256, wave * 16);
     ws.prefetch();
     LnParams lnp;
     ln_load(lnp, a.ln_g, a.ln_b);
@@ -280,16 +296,40 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_h
     };
     fetch(0, st[0]);
     fetch(1, st[1]);
-    commit(0, st[0]);
+    if constexpr (PM) {
+        // chunk c of this thread = head 2 c + (c4 >> 5), features 4 (c4 & 31) .. + 3 of row idx >> 6: the thread adds its heads of the four
+        // o-block chunks in sequence (even heads in lanes c4 < 32, odd heads in lanes c4 >= 32 -- lane pairs 32 apart), then the pair
+        // adds across: ((h0 + h2) + h4) + h6 + ((h1 + h3) + h5) + h7, the order node_head_kernel uses.  Chunks 4 and 5 end up in st[0] / st[1].
+        auto add4 = [](const float4& p, const float4& q) { return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w); };
+        float4 hsum[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + u * NTHR, row = idx >> 6;
+                const float4 v = sel4(m0 + row < M, st[c & 1][u]);
+                hsum[u] = c == 0 ? v : add4(hsum[u], v);
+            }
+            fetch(c + 2, st[c & 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + u * NTHR, row = idx >> 6, c4 = idx & 63;
+            float4 o;
+            o.x = __shfl_xor(hsum[u].x, 32); o.y = __shfl_xor(hsum[u].y, 32); o.z = __shfl_xor(hsum[u].z, 32); o.w = __shfl_xor(hsum[u].w, 32);
+            if (c4 < 32) *reinterpret_cast<float4*>(X + row * LDX + 4 * c4) = add4(hsum[u], o);       // (even-head sum + odd-head sum)
+        }
+    }
+    commit(C0, st[C0 & 1]);
     __syncthreads();
     f32x4 am[2][1], ac[2][1];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) acc_zero1<1>(am[rt], ac[rt]);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (c + 2 < NCH) fetch(c + 2, st[c & 1]);             // (its buffer was committed one iteration ago)
+    for (int c = C0; c < NCH; ++c) {
+        if (!PM && c + 2 < NCH) fetch(c + 2, st[c & 1]);      // (its buffer was committed one iteration ago; PM: chunks 4 and 5 are already in flight)
         const _Float16* bh = Ch + (c & 1) * 2 * TR2 * LDC;
-        gemm_split16r<1, 8, SP, 2>(ws, bh, bh + TR2 * LDC, LDC, am, ac, c * 8, 8);
+        gemm_split16r<1, 8, SP, 2>(ws, bh, bh + TR2 * LDC, LDC, am, ac, (c - C0) * 8, 8);
         if (c + 1 < NCH) commit(c + 1, st[(c + 1) & 1]);
         __syncthreads();
     }
@@ -301,11 +341,14 @@ __global__ __launch_bounds__(NTHR, PF_NT_MINW) void node_head32_kernel(pf_node_h
         const int mr = m0 + rt * 16 + r;
         const float rmask = rmask_ld[rt] * (mr < M ? 1.f : 0.f);
         const float4 rres = sel4(mr < M, rres_ld[rt]);
+        float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PM) hs = *reinterpret_cast<const float4*>(X + (rt * 16 + r) * LDX + n);
+        auto lin = [&](int e, float h) { const float j = join(am[rt][0], ac[rt][0], e); if constexpr (PM) return j + h; else return j; };
         float4 y;
-        y.x = (join(am[rt][0], ac[rt][0], 0) + bias_out.x) * rmask + rres.x;
-        y.y = (join(am[rt][0], ac[rt][0], 1) + bias_out.y) * rmask + rres.y;
-        y.z = (join(am[rt][0], ac[rt][0], 2) + bias_out.z) * rmask + rres.z;
-        y.w = (join(am[rt][0], ac[rt][0], 3) + bias_out.w) * rmask + rres.w;
+        y.x = (lin(0, hs.x) + bias_out.x) * rmask + rres.x;
+        y.y = (lin(1, hs.y) + bias_out.y) * rmask + rres.y;
+        y.z = (lin(2, hs.z) + bias_out.z) * rmask + rres.z;
+        y.w = (lin(3, hs.w) + bias_out.w) * rmask + rres.w;
         *reinterpret_cast<float4*>(X + (rt * 16 + r) * LDX + n) = y;
     }
     __syncthreads();
@@ -993,24 +1036,32 @@ extern "C" int pf_node_head_fwd(const pf_node_head_args* a, pf_stream_t stream) 
         if (attr_set.first()) {
             (void)hipFuncSetAttribute((const void*)node_head32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)node_head32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)node_head32_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)node_head32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         const bool per_sample = a->key_end && a->key_L > 0 && a->rows % a->key_L == 0;
         pf_node_head_args aa = *a;
         if (!per_sample) aa.key_end = nullptr;
         const dim3 grid(per_sample ? (unsigned)((a->rows / a->key_L) * ((a->key_L + TR2 - 1) / TR2)) : (unsigned)((a->rows + TR2 - 1) / TR2));
         a = &aa;
-        if (a->single_pass) hipLaunchKernelGGL(node_head32_kernel<true>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
+        if (a->o_premul) {
+            if (a->single_pass) hipLaunchKernelGGL((node_head32_kernel<true, true>), grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
+            else hipLaunchKernelGGL((node_head32_kernel<false, true>), grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
+        } else if (a->single_pass) hipLaunchKernelGGL(node_head32_kernel<true>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(node_head32_kernel<false>, grid, dim3(NTHR), lds2, (hipStream_t)stream, *a);
         PF_CHECK_LAUNCH();
         return 0;
     }
     if (a->dump_a0) {                                  // training forward: fp32-parity mode, 16-row tiles
-        if (a->single_pass) return PF_E_BADARG;
+        if (a->single_pass || a->o_premul) return PF_E_BADARG;
         hipLaunchKernelGGL((node_head_kernel<false, true>), dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
         PF_CHECK_LAUNCH();
         return 0;
     }
-    if (a->single_pass) hipLaunchKernelGGL(node_head_kernel<true>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    if (a->o_premul) {
+        if (a->single_pass) hipLaunchKernelGGL((node_head_kernel<true, false, true>), dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL((node_head_kernel<false, false, true>), dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
+    } else if (a->single_pass) hipLaunchKernelGGL(node_head_kernel<true>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(node_head_kernel<false>, dim3((unsigned)((a->rows + TR - 1) / TR)), dim3(NTHR), lds, (hipStream_t)stream, *a);
     PF_CHECK_LAUNCH();
     return 0;

@@ -338,6 +338,23 @@ def pack_bias_frags32(w_b, w_dz):
     return torch.cat([_frag32(w, 0, perm(mt, s)) for mt in range(2) for s in range(2)]).contiguous()
 
 
+def fold_linear_out_into_values(wproj, bproj, w_out):
+    """The packed IPA projection with linear_out's o-block folded into the value rows (weights only, float64 on the way).
+    ipa_pytorch.py:456,475-476: s = linear_out([o | o_pt | o_pt_norm | o_pair]) with o_h = sum_j P_h[i, j] v_h[j].  linear_out is
+    linear and a softmax row sums to one, so W_out[:, 128 h : 128 h + 128] o_h = sum_j P_h[i, j] (W_out,h v_h[j]): the value rows of
+    linear_kv become W_out,h W_v,h (bias W_out,h b_v,h), the attention kernels -- which never look inside a value -- produce head
+    h's CONTRIBUTION to linear_out's output in the columns where o_h was, and pf_node_head_fwd (o_premul) adds eight blocks instead
+    of contracting 1024 columns: two thirds of that kernel's weight stream and matrix work.  wproj [3744,128] = [q 1024 | per head
+    k 128, v 128 | points], w_out [128,1536]."""
+    w, b = wproj.double().clone(), bproj.double().clone()
+    for h in range(8):
+        r0 = 1024 + h * 256 + 128
+        wo = w_out[:, h * 128:(h + 1) * 128].double()
+        w[r0:r0 + 128] = wo @ wproj[r0:r0 + 128].double()
+        b[r0:r0 + 128] = wo @ bproj[r0:r0 + 128].double()
+    return w.to(torch.float32).contiguous(), b.to(torch.float32).contiguous()
+
+
 def pack_ipa_projection(wfull, bfull):
     """[linear_q | linear_kv | linear_q_points | linear_kv_points] ([3744,128], [3744]; ipa_pytorch.py:347-387) -> the packed
     projection of the inference plan: point rows re-ordered to (x, y, z, 0) per point, so that the kernels apply the residue frames
@@ -414,6 +431,10 @@ class PackedWeights:
             for nm in ("linear_b", "down_z", "linear_out"):
                 t[f"{b}.{nm}.w"], t[f"{b}.{nm}.b"] = g(p + nm + ".weight"), g(p + nm + ".bias")
             t[f"{b}.linear_out.w16"] = split_f16(t[f"{b}.linear_out.w"])
+            # ... and the same block with linear_out's o-block folded into the value projection (DenoiseEngine option o_premul)
+            t[f"{b}.projm.w"], t[f"{b}.projm.b"] = fold_linear_out_into_values(t[f"{b}.proj.w"], t[f"{b}.proj.b"], t[f"{b}.linear_out.w"])
+            t[f"{b}.projpm.w16"], t[f"{b}.projpm.b"] = pack_ipa_projection(t[f"{b}.projm.w"], t[f"{b}.projm.b"])
+            t[f"{b}.linear_out.w16m"] = split_f16(t[f"{b}.linear_out.w"][:, 1024:].contiguous())
             t[f"{b}.head_w"] = g(p + "head_weights")
             t[f"{b}.ipa_ln.w"], t[f"{b}.ipa_ln.b"] = g(f"trunk.ipa_ln_{b}.weight"), g(f"trunk.ipa_ln_{b}.bias")
             for l in range(2):
@@ -464,7 +485,9 @@ class DenoiseEngine:
     #           from the fp32 mode: tests/test_gpu_bigshape.py, NOTES.md section 3.8
     # plan choices a caller may force (tests and same-box A/B runs of tools/dev; the defaults are rules in (L, precision) alone):
     #   fused_proj, fused_pair, et_v4, et_zfrag, k_frag: True / False;  et_last_store: keep the last EdgeTransition's z' store
-    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store")
+    #   o_premul: linear_out's o-block folded into the value projection (fold_linear_out_into_values; default on)
+    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul")
+    O_PREMUL = True           # default of the o_premul option (class attribute: same-box A/B runs of bench.py flip it)
 
     def __init__(self, weights, B, L, device, precision="fp32", owner=None, options=None):
         assert precision in ("fp32", "f16"), precision
@@ -557,6 +580,7 @@ class DenoiseEngine:
         # ... and the library is asked whether it would launch that form here (its LDS arithmetic and wave cap decide: ADVICE r4)
         can_pj = bool(can_pj and self.lib.pf_ipa_proj_inside_ok(L, int(precision == "f16")))
         self.fused_proj = can_pj and opt.get("fused_proj", True)
+        self.o_premul = bool(opt.get("o_premul", self.O_PREMUL))
         self.att_qk = self.att_vt = None
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
@@ -755,7 +779,8 @@ class DenoiseEngine:
             rot = self.rot_t if b == 0 else self.rot
             trans = self.trans_t if b == 0 else self.trans
             # projection with the frame transform of the points fused into its epilogue (no pf_ipa_points_fwd launch)
-            e = lin(self.s, w[f"{b}.proj.w"], w[f"{b}.projp.b"], self.proj, 3968, 128, w16=w[f"{b}.projp.w16"])
+            pk = "projpm" if self.o_premul else "projp"
+            e = lin(self.s, w[f"{b}.projm.w" if self.o_premul else f"{b}.proj.w"], w[f"{b}.{pk}.b"], self.proj, 3968, 128, w16=w[f"{b}.{pk}.w16"])
             la = self._keep[-1]
             la.single_pass = int(self.precision == "f16")
             la.pt_rot, la.pt_trans, la.pt_col0 = rot.data_ptr(), trans.data_ptr(), 3072
@@ -796,7 +821,8 @@ class DenoiseEngine:
             if self.k_frag is not None:
                 ia.k_frag = self.k_frag.data_ptr()
             if self.fused_proj:
-                ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.projp.w16"].data_ptr(), w[f"{b}.projp.b"].data_ptr()
+                pk = "projpm" if self.o_premul else "projp"
+                ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.{pk}.w16"].data_ptr(), w[f"{b}.{pk}.b"].data_ptr()
                 if self.att_vt32 is not None:
                     ia.att_vt = self.att_vt32.data_ptr()
             self._keep.append(ia)
@@ -804,7 +830,8 @@ class DenoiseEngine:
             # ---- fused node track: 3 launches (csrc/node_track.hip) ----
             ha = _capi.NodeHeadArgs()
             ha.feats, ha.s_in, ha.mask = self.feats.data_ptr(), self.s.data_ptr(), self.mask.data_ptr()
-            ha.w_out_f16, ha.b_out = w[f"{b}.linear_out.w16"].data_ptr(), w[f"{b}.linear_out.b"].data_ptr()
+            ha.w_out_f16, ha.b_out = w[f"{b}.linear_out.w16m" if self.o_premul else f"{b}.linear_out.w16"].data_ptr(), w[f"{b}.linear_out.b"].data_ptr()
+            ha.o_premul = int(self.o_premul)
             ha.ln_g, ha.ln_b = w[f"{b}.ipa_ln.w"].data_ptr(), w[f"{b}.ipa_ln.b"].data_ptr()
             ha.w_in_f16, ha.b_in = w[f"{b}.0.in.w16"].data_ptr(), w[f"{b}.0.in.b"].data_ptr()
             ha.s_ipa, ha.qkv, ha.rows = self.s.data_ptr(), self.qkv.data_ptr(), rows

@@ -327,7 +327,7 @@ def test_engine_options_are_validated_and_noise_is_shard_invariant():
     import inspect
     from pepflowww_amd import distributed as D
     from pepflowww_amd.engine import DenoiseEngine
-    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store"}
+    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul"}
     assert "options" in inspect.signature(DenoiseEngine.__init__).parameters
     with pytest.raises(AssertionError):
         DenoiseEngine(None, 1, 16, torch.device("cpu"), options={"no_such_switch": True})
@@ -521,3 +521,28 @@ def test_host_plumbing_in_numpy_equals_the_torch_formulation():
     q = torch.randn(4, 30, 4); t0 = torch.randn(4, 30, 3); an = torch.rand(4, 30, 5) * (2 * math.pi); sx = torch.randn(4, 30, 20)
     assert torch.equal(x["trans0"], t0) and torch.equal(x["ang0"], an) and torch.equal(x["simplex0"], sx)     # (draw order unchanged)
     assert torch.equal(x["rot0"], S.quat_to_rot_host(q))
+
+
+def test_linear_out_folded_into_the_value_projection_is_the_same_map():
+    """engine.fold_linear_out_into_values (DenoiseEngine option o_premul): for ANY attention weights P whose rows sum to one,
+    linear_out([o | rest]) == sum_h P_h (W_out,h v_h) + W_out[:, 1024:] rest + b -- checked in float64 on random weights (the kernels
+    never look inside a value, so this identity is all the change rests on)."""
+    from pepflowww_amd.engine import fold_linear_out_into_values
+    g = torch.Generator().manual_seed(4)
+    wproj, bproj = torch.randn(3744, 128, generator=g) / 11, torch.randn(3744, generator=g)
+    w_out, b_out = torch.randn(128, 1536, generator=g) / 39, torch.randn(128, generator=g)
+    wm, bm = fold_linear_out_into_values(wproj, bproj, w_out)
+    keep = torch.ones(3744, dtype=torch.bool)
+    for h in range(8):
+        keep[1024 + h * 256 + 128:1024 + h * 256 + 256] = False
+    assert torch.equal(wm[keep], wproj[keep]) and torch.equal(bm[keep], bproj[keep])       # q, k and the points are untouched
+    L = 9
+    s = torch.randn(L, 128, generator=g).double()
+    P = torch.softmax(torch.randn(8, L, L, generator=g).double(), -1)
+    rest = torch.randn(L, 512, generator=g).double()
+    proj, projm = s @ wproj.double().T + bproj.double(), s @ wm.double().T + bm.double()
+    o = torch.cat([P[h] @ proj[:, 1024 + h * 256 + 128:1024 + h * 256 + 256] for h in range(8)], -1)        # [L, 1024] (head-major)
+    ref = torch.cat([o, rest], -1) @ w_out.double().T + b_out.double()
+    om = sum(P[h] @ projm[:, 1024 + h * 256 + 128:1024 + h * 256 + 256] for h in range(8))                 # head blocks ADDED
+    got = om + rest @ w_out.double()[:, 1024:].T + b_out.double()
+    assert (got - ref).abs().max() < 1e-5 * ref.abs().max()
