@@ -337,6 +337,9 @@ def main():
     if os.environ.get("PF_BENCH_O_PREMUL") == "0":              # same-box A/B of the folded value projection (DenoiseEngine.O_PREMUL)
         from pepflowww_amd.engine import DenoiseEngine
         DenoiseEngine.O_PREMUL = False
+    if os.environ.get("PF_BENCH_K_FOLD") == "0":                # same-box A/B of the keys-are-the-state form (DenoiseEngine.K_FOLD)
+        from pepflowww_amd.engine import DenoiseEngine
+        DenoiseEngine.K_FOLD = False
     global PER_CALL_STEPS, USE_BUCKETS
     PER_CALL_STEPS = args.per_call_steps
     USE_BUCKETS = not args.no_buckets

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 57
+#define PF_ABI_VERSION 58
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 /* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
  * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
@@ -230,6 +230,11 @@ typedef struct {
      * (pf_linear_args.k_frag): the first product reads them instead of the k columns of `proj` -- one contiguous KiB per load instead of
      * sixteen rows x 64 bytes.  Same values, same arithmetic: results are bit-identical to the call without it. */
     const float* k_frag;
+    /* optional (with s_in; ABI 58): 1 = THE KEYS ARE THE NODE STATE.  q_h . k_h = s_i^T (W_q,h^T W_k,h) s_j + terms constant along a softmax
+     * row (ipa_pytorch.py:389-404,427-432), so when proj_w_f16 / proj_bias hold the query rows as W_k,h^T (W_q,h s + b_q,h)
+     * (engine.fold_keys_into_queries: weights only) the k operand of the first product is the row of s_in itself: the kernel writes its
+     * fragments from s_in and passes over the eight k tiles of the packed projection (whose rows are then never multiplied). */
+    int k_from_s;
 } pf_ipa_attn_args;
 int pf_ipa_attn_fwd(const pf_ipa_attn_args* a, pf_stream_t stream);
 /* 1 when pf_ipa_attn_fwd would run the projection-inside form (s_in) at this length (fp32 operands: f16_mode = 0; f16 operand

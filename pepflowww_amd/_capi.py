@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PF_LIB_PATH: another build of the same library -- same-box A/B runs of kernel variants, tools/dev)
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 57
+ABI_VERSION = 58
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -43,7 +43,7 @@ class IpaAttnArgs(C.Structure):
                 ("trans", _fp), ("mask", _fp), ("w_b", _fp), ("b_b", _fp), ("w_dz", _fp), ("b_dz", _fp),
                 ("head_w", _fp), ("feats", _fp), ("B", _i), ("L", _i), ("bias", _fp), ("p_out", _fp),
                 ("variant", _i), ("att_qk", _fp), ("att_vt", _fp), ("att_mode", _i), ("head_group", _i), ("key_end", _fp), ("z_f16", _i), ("dz", _fp), ("dz_f16", _i), ("fused_pair", _i),
-                ("s_in", _fp), ("proj_w_f16", _fp), ("proj_bias", _fp), ("k_frag", _fp)]
+                ("s_in", _fp), ("proj_w_f16", _fp), ("proj_bias", _fp), ("k_frag", _fp), ("k_from_s", _i)]
 
 
 class InputMixerArgs(C.Structure):

@@ -237,6 +237,15 @@ __host__ __device__ __forceinline__ constexpr int pj_vp_floats(int LP) {        
     return LP * VPS > 48 * pj_vtl(LP) ? LP * VPS : 48 * pj_vtl(LP);                                          // (fp32 table, or 2 planes x 48 rows f16)
 }
 struct PjW { half8 h[4], l[4]; };
+// KF (pf_ipa_attn_args.k_from_s, ABI 58): THE KEYS ARE THE NODE STATE.  q_h . k_h = s_i^T (W_q,h^T W_k,h) s_j + terms that are constant along
+// a softmax row, so with the query rows packed as W_k,h^T (W_q,h s + b_q,h) (engine.fold_keys_into_queries: weights only) the k
+// operand of the first product is the row of s itself -- every wave writes its 16 rows as operand fragments before the tile loop and
+// the eight k tiles leave the weight stream altogether: 23 tiles in 8 chunks instead of 31 in 11 (a first build only passed over their
+// MFMAs and fragment reads and let their LDS-DMA pieces flow: no gain at all -- the prologue is bound by its staging pipeline, one
+// chunk per L2 -> LDS round trip, not by what the waves do with a chunk; profiles/r05/README.md).
+template <bool KF> __device__ __forceinline__ constexpr int pj_ntiles() { return KF ? PJ_TILES - 8 : PJ_TILES; }                 // tiles that are staged and computed
+template <bool KF> __device__ __forceinline__ constexpr int pj_nch() { return (pj_ntiles<KF>() + PJ_CT - 1) / PJ_CT; }
+template <bool KF> __device__ __forceinline__ constexpr int pj_orig(int j) { return KF && j >= 8 ? j + 8 : j; }                   // j-th staged tile -> its index among the 31
 // Called by EVERY wave of the workgroup (barriers inside).  The head's 248 KiB of weight fragments go L2 -> LDS ONCE per workgroup
 // (LDS-DMA, two 24 KiB buffers, the next chunk in flight under the current chunk's MFMAs) and every wave reads its operands from
 // there -- with each wave streaming the fragments itself (first build) the eight waves pulled 2 MiB per workgroup through the CU's
@@ -246,7 +255,7 @@ struct PjW { half8 h[4], l[4]; };
 // tiles (21) of the same rows -- those results go to the scratch / the LDS tables anyway, nothing has to be handed over.  tile = the
 // 16-row tile of the sample this wave projects (its own index as a query wave, its partner's as a helper).
 __device__ __forceinline__ constexpr bool pj_q_tile(int idx) { return idx < 8 || idx == 24 || idx == 25; }
-template <bool KS>                           // KS: the k rows as hi | lo f16 operand fragments (first product on split f16 MFMAs); else fp32 fragments
+template <bool KS, bool KF = false>         // KS: the k rows as hi | lo f16 operand fragments (first product on split f16 MFMAs); else fp32 fragments; KF: see pj_live
 __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, int LPe, bool wave_on, int role, int tile, float* KP,
                                           _Float16* VPT /* [2][48][VTL] value points, hi | lo */, int VTL, _Float16* VTH /* this head's [8 tiles][VTG / 32 steps][hi | lo][64 lanes][8] */, int VTG,
                                           unsigned char* WS /* PJ_NB x PJ_CHUNK_B */, float* QPW /* wave-private [16][24] */,
@@ -261,12 +270,13 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     // per chunk (pieces wave, wave + nw, ...; the last ones of a wave may repeat the chunk's last piece: the counted waits below need
     // the same number of pieces from every wave and every chunk)
     const int ppw = (PJ_CT * 8 + nw - 1) / nw;
+    constexpr int NT = pj_ntiles<KF>(), NCH = pj_nch<KF>();
     auto issue = [&](int c) __attribute__((always_inline)) {
-        const int npc = min(PJ_CT, PJ_TILES - PJ_CT * c) * 8;
+        const int npc = min(PJ_CT, NT - PJ_CT * c) * 8;
         for (int k = 0; k < ppw; ++k) {
             const int pc = min(wave + k * nw, npc - 1);
             const int tl = pc >> 3, ks = (pc >> 1) & 3, pl = pc & 1;
-            const int T16 = pj_tile(PJ_CT * c + tl, h);
+            const int T16 = pj_tile(pj_orig<KF>(PJ_CT * c + tl), h);
             pj_glds16((pl ? wlp : whp) + (size_t)(T16 * 4 + ks) * 1024, l16, ws0 + (c % PJ_NB) * PJ_CHUNK_B + pc * 1024);
         }
     };
@@ -300,11 +310,42 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
             for (int e = 0; e < 4; ++e) { xh[ks][e] = h0[e]; xh[ks][4 + e] = h1[e]; xl[ks][e] = l0[e]; xl[ks][4 + e] = l1[e]; }
         }
     }
+    if constexpr (KF) {
+        _Float16* kfrag = VTH + (size_t)8 * (VTG >> 5) * 1024 + (size_t)tile * 4096 + lane * 8;  // (layout: below; formed here for this form only --
+                                                                                                 //  the other form keeps its instruction stream)
+        // the k fragments of this wave's 16 rows straight from the node state, in the slot order the tiles below would have produced:
+        // lane (key r, g) holds channels 16 t + 4 g .. + 3 of "tile" t.  Loads and stores OLDER than every LDS-DMA piece (as the row
+        // loads above): an outstanding store only makes a counted wait below wait longer.
+        if (wave_on && role != 1) {
+            const float* krow = a.s_in + (rowb + iq) * 128 + 4 * g;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {                     // (two batches of four: 16 registers in flight, not 32)
+                float4 kt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kt[u] = *reinterpret_cast<const float4*>(krow + 16 * (4 * hb + u));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t8 = 4 * hb + u;
+                    const float v[4] = {kt[u].x, kt[u].y, kt[u].z, kt[u].w};
+                    if constexpr (KS) {
+                        half4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+                        _Float16* d = kfrag + (t8 >> 1) * 1024 + (t8 & 1) * 4;
+                        *reinterpret_cast<half4*>(d) = hi;
+                        *reinterpret_cast<half4*>(d + 512) = lo;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(kfrag - lane * 8) + t8 * 256 + lane * 4) = kt[u];
+                    }
+                }
+            }
+        }
+    }
     // (the row loads above are OLDER than every LDS-DMA piece: the waits below count what is younger than a chunk's pieces)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < PJ_NB - 1; ++c)
-        if (c < PJ_NCH) issue(c);
+        if (c < NCH) issue(c);
     // k rows: fragment order too.  KS (the form without the pair phase): as the hi | lo f16 operands of the first product (three f16
     // MFMAs per product, like the second one) --
     // block (key tile `tile`, 32-channel K-step s, plane) = 1 KiB = the 64 lanes' 16 bytes: lane (key r, g) holds channels 32 s + 4 g .. + 3
@@ -321,7 +362,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
             w.l[ks] = *reinterpret_cast<const half8*>(b + ks * 2048 + 1024);
         }
     };
-    cfor_p<0, PJ_NCH>([&](auto ic) __attribute__((always_inline)) {
+    cfor_p<0, NCH>([&](auto ic) __attribute__((always_inline)) {
         constexpr int c = decltype(ic)::value;
         // chunk c has landed: this wave's pieces (counted wait), then everybody's (barrier), which also frees the buffer of chunk c - 1.
         // The allowance is the PIECES issued after chunk c's (up to PJ_NB - 2 chunks) and nothing else: loads complete in order among
@@ -331,7 +372,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         // chunk c's weights not in LDS yet.  Rare with the scattered 64-byte row stores of that build (one unexplained test failure
         // in ~10 suite runs), every run once the stores became contiguous KiB blocks (round 4, NOTES.md 3.3).  Without them in the
         // allowance the wait also covers the stores of the previous chunks: +1.4 k cycles on the 44 k prologue.
-        constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH) + (PJ_NB > 4 && c + 3 < PJ_NCH);
+        constexpr int NDY = (c + 1 < NCH) + (PJ_NB > 3 && c + 2 < NCH) + (PJ_NB > 4 && c + 3 < NCH);
         static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");
         pj_wait_vm_dyn(PJ_NB == 2 ? 0 : NDY * ppw);
         // (the bare s_barrier does not wait for this wave's own LDS writes, unlike __syncthreads(): the bias staging and the zero fill of
@@ -339,17 +380,17 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         if constexpr (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
+        if constexpr (c + PJ_NB - 1 < NCH) issue(c + PJ_NB - 1);
         if (wave_on) {
             PjW wa, wb;
             if (role == 0) ldfrag(c, 0, wa);
             cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
-                constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
-                if constexpr (idx < PJ_TILES) {
+                constexpr int tl = decltype(it)::value, jt = PJ_CT * c + tl, idx = pj_orig<KF>(jt);   // idx: the tile's index among the 31 (what it computes)
+                if constexpr (jt < NT) {
                   if (role == 0 || (role == 1) == pj_q_tile(idx)) {          // (wave-uniform)
                     PjW& w = (tl & 1) ? wb : wa;
                     if (role != 0) ldfrag(c, tl, w);                        // (a tile here and there: requested at its use)
-                    else if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    else if constexpr (tl + 1 < PJ_CT && jt + 1 < NT) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
                     constexpr bool VTILE = idx >= 16 && idx < 24;
                     f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -449,6 +490,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
 constexpr int KLS = 128 + 8;                  // f16 row stride of KL (272 B: 16-byte aligned rows, fragment reads spread over the banks)
 constexpr int PJ16_CHUNK_B = PJ_CT * 4 * 1024;                   // hi planes only
 constexpr int PJ16_STAGE_B = PJ_NB * PJ16_CHUNK_B;
+template <bool KF = false>                   // KF: the keys are the node state (pj_live): KL rows = f16(s), the k tiles are passed over
 __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t rowb, int iq, int h, int jrow, bool wave_on, float* KP,
                                             _Float16* KL, _Float16* VT, int VTS, unsigned char* WS /* PJ_NB x PJ16_CHUNK_B */,
                                             float* QPW /* wave-private, 1536 B: query rows (f16) then query points */, float* PB,
@@ -459,11 +501,12 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
     const unsigned l16 = lane * 16;
     const int ppw = (PJ_CT * 4 + nw - 1) / nw;
     // chunk c -> buffer c % PJ_NB: piece (tile tl, K-step ks) at (tl * 4 + ks) KiB; every wave issues ppw pieces per chunk
+    constexpr int NT = pj_ntiles<KF>(), NCH = pj_nch<KF>();
     auto issue = [&](int c) __attribute__((always_inline)) {
-        const int npc = min(PJ_CT, PJ_TILES - PJ_CT * c) * 4;
+        const int npc = min(PJ_CT, NT - PJ_CT * c) * 4;
         for (int k = 0; k < ppw; ++k) {
             const int pc = min(wave + k * nw, npc - 1);
-            const int T16 = pj_tile(PJ_CT * c + (pc >> 2), h);
+            const int T16 = pj_tile(pj_orig<KF>(PJ_CT * c + (pc >> 2)), h);
             pj_glds16(whp + (size_t)(T16 * 4 + (pc & 3)) * 1024, l16, ws0 + (c % PJ_NB) * PJ16_CHUNK_B + pc * 1024);
         }
     };
@@ -487,33 +530,41 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
             xh[ks][4] = (_Float16)t[2 * ks + 1].x; xh[ks][5] = (_Float16)t[2 * ks + 1].y; xh[ks][6] = (_Float16)t[2 * ks + 1].z; xh[ks][7] = (_Float16)t[2 * ks + 1].w;
         }
     }
+    if constexpr (KF) {
+        // key row jrow of KL = this lane's eight f16 channels per K-step, as they are (LDS stores: landed before the first chunk
+        // barrier through the lgkmcnt(0) in front of it, read by other waves only after the prologue)
+        if (wave_on) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<half8*>(KL + jrow * KLS + 32 * ks + 8 * g) = xh[ks];
+        }
+    }
     asm volatile("" ::: "memory");                               // (row loads older than every LDS-DMA piece, see proj_head)
 #pragma unroll
     for (int c = 0; c < PJ_NB - 1; ++c)
-        if (c < PJ_NCH) issue(c);
+        if (c < NCH) issue(c);
     _Float16* QL = reinterpret_cast<_Float16*>(QPW);             // [16 rows][40]: two q tiles (32 channels) of the wave's rows at a time
     auto ldfrag = [&](int c, int tl, half8 (&w)[4]) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ16_CHUNK_B + tl * 4096 + lane * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) w[ks] = *reinterpret_cast<const half8*>(b + ks * 1024);
     };
-    cfor_p<0, PJ_NCH>([&](auto ic) __attribute__((always_inline)) {
+    cfor_p<0, NCH>([&](auto ic) __attribute__((always_inline)) {
         constexpr int c = decltype(ic)::value;
-        constexpr int NDY = (c + 1 < PJ_NCH) + (PJ_NB > 3 && c + 2 < PJ_NCH);
+        constexpr int NDY = (c + 1 < NCH) + (PJ_NB > 3 && c + 2 < NCH);
         static_assert(PJ_NB == 4, "wait accounting written for 4 staging buffers");
         pj_wait_vm_dyn(NDY * ppw);                               // (no global stores in this form: only younger pieces are outstanding)
         if constexpr (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's bias staging has landed, see proj_head)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (c + PJ_NB - 1 < PJ_NCH) issue(c + PJ_NB - 1);
+        if constexpr (c + PJ_NB - 1 < NCH) issue(c + PJ_NB - 1);
         if (wave_on) {
             half8 wa[4], wb[4];
             ldfrag(c, 0, wa);
             cfor_p<0, PJ_CT>([&](auto it) __attribute__((always_inline)) {
-                constexpr int tl = decltype(it)::value, idx = PJ_CT * c + tl;
-                if constexpr (idx < PJ_TILES) {
+                constexpr int tl = decltype(it)::value, jt = PJ_CT * c + tl, idx = pj_orig<KF>(jt);
+                if constexpr (jt < NT) {
                     half8 (&w)[4] = (tl & 1) ? wb : wa;
-                    if constexpr (tl + 1 < PJ_CT && idx + 1 < PJ_TILES) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
+                    if constexpr (tl + 1 < PJ_CT && jt + 1 < NT) ldfrag(c, tl + 1, (tl & 1) ? wa : wb);
                     f32x4 am = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (idx >= 16 && idx < 24) {      // value channels: rows x features (operands swapped) -> lane (r = channel, g): rows 4 g + e
 #pragma unroll
@@ -585,7 +636,7 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
 // KFRAG (without PROJ): the k rows come from pf_ipa_attn_args.k_frag (fp32 fragments written by the projection launch) -- a COMPILE-TIME
 // variant: as a run-time test inside loadk the branch cost the loop its load pipelining (113 -> 166 us at B=64, L=144, and 136 with the
 // fragments: hipcc drains vmcnt at every control-flow join -- the lesson of round 2 once more).
-template <bool VEC4, bool FUSE = false, bool PROJ = false, bool KFRAG = false>   // L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
+template <bool VEC4, bool FUSE = false, bool PROJ = false, bool KFRAG = false, bool KF = false>   // (KF: with PROJ, the keys are the node state: pj_live)  L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool KSPLIT = PROJ && !FUSE;         // first product on split f16 MFMAs, k rows as hi | lo fragments (proj_head<true>)
@@ -671,7 +722,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         const int role = (int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0;
         const int VTG = (L + 31) & ~31;                // key stride of the value planes (pf_ipa_attn_args.att_vt as this launch's scratch)
         _Float16* VTH = reinterpret_cast<_Float16*>(const_cast<void*>(a.att_vt)) + ((size_t)b * H + h) * 512 * VTG;   // values 256 VTG | k rows 256 VTG (as f16 counts)
-        proj_head<KSPLIT>(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
+        proj_head<KSPLIT, KF>(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
                   PB, qf, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();                               // (global k | v stores + LDS tables: visible to every wave of the workgroup)
         if (!wave_on || helper) return;
@@ -1038,7 +1089,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
 // Requires L % 16 == 0 (FlowModel.sample pads to that); keys are walked in 32-key steps in the second product (a trailing
 // half step multiplies zero probabilities with whatever the value rows hold there -- the value buffer is zero-initialised
 // and 32 keys longer than its last row).
-template <bool FUSE = false, bool PROJ = false>   // FUSE: pair aggregation on a.dz (f16) here, P not stored; PROJ: the head's projection here (proj_head16)
+template <bool FUSE = false, bool PROJ = false, bool KF = false>   // FUSE: pair aggregation on a.dz (f16) here, P not stored; PROJ: the head's projection here (proj_head16); KF: keys = node state
 __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;                             // multiple of 16
@@ -1109,7 +1160,7 @@ __global__ __launch_bounds__(512) void ipa_scores16_kernel(pf_ipa_attn_args a, i
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);
         float* QPW = reinterpret_cast<float*>(WS + PJ16_STAGE_B) + wave * (1536 / 4);
         float* PB = reinterpret_cast<float*>(WS + PJ16_STAGE_B) + (blockDim.x >> 6) * (1536 / 4);
-        proj_head16(a, rowb, wave_on ? iq : 0, h, i0 + r, wave_on, KP, KL, VT, VTS, WS, QPW, PB, qh, qp4, lane, wave, (int)(blockDim.x >> 6));
+        proj_head16<KF>(a, rowb, wave_on ? iq : 0, h, i0 + r, wave_on, KP, KL, VT, VTS, WS, QPW, PB, qh, qp4, lane, wave, (int)(blockDim.x >> 6));
         __syncthreads();
         if (!wave_on) return;
         loadk(0, kh);
@@ -1648,6 +1699,7 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
     // operand kernel fp32 ones (what DenoiseEngine pairs up); any other combination runs the two-kernel form and needs p_out
     // f16 operand planes from the projection's epilogue (att_qk / att_vt), or -- att_mode 2 with s_in -- formed inside the kernel
     const bool pj16 = a->s_in && a->att_mode == 2 && (L & 15) == 0;
+    if (a->k_from_s && !a->s_in) return PF_E_BADARG;            // (the keys-are-the-state form exists inside the projecting score kernels only)
     if (a->att_mode == 1) return PF_E_BADARG;                    // (the hi / lo plane form was removed in round 4)
     const bool planes = ((a->att_qk && a->att_vt) || pj16) && a->att_mode == 2 && (L & 15) == 0;
     const bool fuse = a->fused_pair && a->dz && (planes ? a->dz_f16 != 0 : a->dz_f16 == 0);
@@ -1689,8 +1741,10 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             static PfOncePerDevice attr_pj16;
             if (attr_pj16.first()) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores16_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
-            hipLaunchKernelGGL((ipa_scores16_kernel<true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
+            if (a->k_from_s) hipLaunchKernelGGL((ipa_scores16_kernel<true, true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
+            else hipLaunchKernelGGL((ipa_scores16_kernel<true, true>), dim3((unsigned)(a->B * H)), dim3(64 * tiles), lds16, s, *a, 1, 16 * tiles, SLD16);
             PF_CHECK_LAUNCH();
             return 0;
         }
@@ -1702,6 +1756,8 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             if (attr_pj.first()) {
                 (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
             // the score regions double as the weight staging buffers + the waves' query-point regions during the prologue
             const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
@@ -1709,7 +1765,10 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
             // L <= 64: as many helper waves as query waves for the prologue (proj_head roles)
             const int nwv = wpb <= 4 ? 2 * wpb : wpb;
-            if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            if (a->k_from_s) {
+                if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+                else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+            } else if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
             else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
         } else if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;

@@ -355,6 +355,21 @@ def fold_linear_out_into_values(wproj, bproj, w_out):
     return w.to(torch.float32).contiguous(), b.to(torch.float32).contiguous()
 
 
+def fold_keys_into_queries(wproj, bproj):
+    """The packed IPA projection with the key projection folded into the query rows (weights only, float64 on the way).
+    ipa_pytorch.py:389-404,427-432: a_ij ~ softmax_j(sqrt(1/(3C)) q_i . k_j + ...), q = W_q s + b_q, k = W_k s + b_k.
+    q_i . k_j = (W_k^T (W_q s_i + b_q)) . s_j + (W_q s_i + b_q) . b_k, and the second term is constant along j -- it leaves the softmax
+    unchanged.  So with query rows W_k,h^T W_q,h (bias W_k,h^T b_q,h; c_hidden = c_s = 128: same shape) the KEYS are the node state
+    itself: the score kernels that project in their prologue (pf_ipa_attn_args.k_from_s) write the k operand from s and never
+    multiply the k rows of this matrix (left as they are).  wproj [3744,128] = [q: 8 heads x 128 | per head k 128, v 128 | points]."""
+    w, b = wproj.double().clone(), bproj.double().clone()
+    for h in range(8):
+        wk = wproj[1024 + h * 256:1024 + h * 256 + 128].double()           # [c_hidden, c_s]
+        w[h * 128:(h + 1) * 128] = wk.T @ wproj[h * 128:(h + 1) * 128].double()
+        b[h * 128:(h + 1) * 128] = wk.T @ bproj[h * 128:(h + 1) * 128].double()
+    return w.to(torch.float32).contiguous(), b.to(torch.float32).contiguous()
+
+
 def pack_ipa_projection(wfull, bfull):
     """[linear_q | linear_kv | linear_q_points | linear_kv_points] ([3744,128], [3744]; ipa_pytorch.py:347-387) -> the packed
     projection of the inference plan: point rows re-ordered to (x, y, z, 0) per point, so that the kernels apply the residue frames
@@ -435,6 +450,11 @@ class PackedWeights:
             t[f"{b}.projm.w"], t[f"{b}.projm.b"] = fold_linear_out_into_values(t[f"{b}.proj.w"], t[f"{b}.proj.b"], t[f"{b}.linear_out.w"])
             t[f"{b}.projpm.w16"], t[f"{b}.projpm.b"] = pack_ipa_projection(t[f"{b}.projm.w"], t[f"{b}.projm.b"])
             t[f"{b}.linear_out.w16m"] = split_f16(t[f"{b}.linear_out.w"][:, 1024:].contiguous())
+            # ... and, on top of it, the key projection folded into the query rows (option k_fold: the projecting score kernels only)
+            wk_, bk_ = fold_keys_into_queries(t[f"{b}.projm.w"], t[f"{b}.projm.b"])
+            t[f"{b}.projpmk.w16"], t[f"{b}.projpmk.b"] = pack_ipa_projection(wk_, bk_)
+            wk_, bk_ = fold_keys_into_queries(t[f"{b}.proj.w"], t[f"{b}.proj.b"])
+            t[f"{b}.projpk.w16"], t[f"{b}.projpk.b"] = pack_ipa_projection(wk_, bk_)
             t[f"{b}.head_w"] = g(p + "head_weights")
             t[f"{b}.ipa_ln.w"], t[f"{b}.ipa_ln.b"] = g(f"trunk.ipa_ln_{b}.weight"), g(f"trunk.ipa_ln_{b}.bias")
             for l in range(2):
@@ -486,7 +506,9 @@ class DenoiseEngine:
     # plan choices a caller may force (tests and same-box A/B runs of tools/dev; the defaults are rules in (L, precision) alone):
     #   fused_proj, fused_pair, et_v4, et_zfrag, k_frag: True / False;  et_last_store: keep the last EdgeTransition's z' store
     #   o_premul: linear_out's o-block folded into the value projection (fold_linear_out_into_values; default on)
-    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul")
+    #   k_fold: the key projection folded into the query rows, keys = the node state (fold_keys_into_queries; with fused_proj only; default on)
+    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul", "k_fold")
+    K_FOLD = True             # default of the k_fold option
     O_PREMUL = True           # default of the o_premul option (class attribute: same-box A/B runs of bench.py flip it)
 
     def __init__(self, weights, B, L, device, precision="fp32", owner=None, options=None):
@@ -581,6 +603,7 @@ class DenoiseEngine:
         can_pj = bool(can_pj and self.lib.pf_ipa_proj_inside_ok(L, int(precision == "f16")))
         self.fused_proj = can_pj and opt.get("fused_proj", True)
         self.o_premul = bool(opt.get("o_premul", self.O_PREMUL))
+        self.k_fold = bool(self.fused_proj and opt.get("k_fold", self.K_FOLD))
         self.att_qk = self.att_vt = None
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)
@@ -821,8 +844,9 @@ class DenoiseEngine:
             if self.k_frag is not None:
                 ia.k_frag = self.k_frag.data_ptr()
             if self.fused_proj:
-                pk = "projpm" if self.o_premul else "projp"
+                pk = ("projpm" if self.o_premul else "projp") + ("k" if self.k_fold else "")
                 ia.s_in, ia.proj_w_f16, ia.proj_bias = self.s.data_ptr(), w[f"{b}.{pk}.w16"].data_ptr(), w[f"{b}.{pk}.b"].data_ptr()
+                ia.k_from_s = int(self.k_fold)
                 if self.att_vt32 is not None:
                     ia.att_vt = self.att_vt32.data_ptr()
             self._keep.append(ia)

@@ -115,7 +115,7 @@ def ipa_projection(s, w16, bias, rot, trans):
 
 
 def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None,
-              dz=None, fused_pair=False, points=None, fused_proj=None, debug_pts=None):
+              dz=None, fused_pair=False, points=None, fused_proj=None, debug_pts=None, k_from_s=False):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
     variant=1); head_group: force a head-group split of the one-kernel form; dz: [B,L,L,16] pair values W_dz z (no bias) for the
     two-kernel form's pair aggregation (z may then be None); fused_pair: that aggregation inside the score kernel (p_out may be None)."""
@@ -150,6 +150,7 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
     ia.fused_pair = int(fused_pair)
     if fused_proj is not None:
         ia.s_in, ia.proj_w_f16, ia.proj_bias = _p(fused_proj[0]), _p(fused_proj[1]), _p(fused_proj[2])
+        ia.k_from_s = int(k_from_s)              # (fused_proj[1:] then hold engine.fold_keys_into_queries weights)
         # the form's scratch for the head's value planes (hi | lo f16, transposed per (sample, head)): finite on entry
         vt = torch.zeros(B * 8 * 512 * ((L + 31) // 32 * 32), dtype=torch.float16, device=d)
         if os.environ.get("PF_TEST_POISON_VT"):     # (dev: a fragment read before it was written shows as NaN; L % 32 == 0 only)

@@ -41,8 +41,10 @@ def test_shard_check_of_the_helper_wave_form_in_fresh_processes(precision):
     assert not bad, f"{len(bad)} of {n} fresh processes mismatched: {bad[:2]}"
 
 
-def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd):
-    """The projection-inside score kernel (fp32 mode) at B x L = 64 x 128, launched 1500 times on the same inputs (the rows rewritten
+@pytest.mark.parametrize("k_from_s", [True, False])
+def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd, k_from_s):
+    """(k_from_s: the form the engine runs since ABI 58 -- keys from the node state, the k tiles passed over -- and the form before it.)
+    The projection-inside score kernel (fp32 mode) at B x L = 64 x 128, launched 1500 times on the same inputs (the rows rewritten
     by a copy kernel before every launch, as in the step): every output bit-equal to the first launch's.  tools/dev/r05_ipa_repeat.py is
     the diagnostic form (it locates a difference: which workgroup, which wave, which operand); a build of the prologue WITHOUT the
     run-time role branches failed this in 0.3 - 1.5 % of the launches (profiles/r05/README.md)."""
@@ -63,7 +65,11 @@ def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd):
     x = torch.randn(B, L, 3, generator=g) * 8
     gq = lambda k: cu(sd[pfx + k])  # noqa: E731
     names = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")
-    w16, bp = pack_ipa_projection(cu(torch.cat([sd[pfx + n + ".weight"] for n in names], 0)), cu(torch.cat([sd[pfx + n + ".bias"] for n in names], 0)))
+    wcat, bcat = cu(torch.cat([sd[pfx + n + ".weight"] for n in names], 0)), cu(torch.cat([sd[pfx + n + ".bias"] for n in names], 0))
+    if k_from_s:
+        from pepflowww_amd.engine import fold_keys_into_queries
+        wcat, bcat = fold_keys_into_queries(wcat, bcat)
+    w16, bp = pack_ipa_projection(wcat, bcat)
     s_master, Rd, xd, md = cu(s.reshape(B * L, 128)), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), torch.ones(B * L, device=G.dev())
     sdev = s_master.clone()
     zd = cu(z)
@@ -76,7 +82,7 @@ def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd):
         p = torch.zeros(B, 8, L, L, device=G.dev())
         f = G.ipa_feats(torch.full((B * L, 3744), float("nan"), device=G.dev()), None, Rd, xd, md, gq("linear_b.weight"), gq("linear_b.bias"),
                         gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"), B, L, bias=bias, p_out=p, variant=2, dz=dz,
-                        fused_proj=(sdev, w16, bp))[0]
+                        fused_proj=(sdev, w16, bp), k_from_s=k_from_s)[0]
         return f, p
     first = [run() for _ in range(3)]
     assert all(torch.equal(first[0][0], t[0]) and torch.equal(first[0][1], t[1]) for t in first[1:]), "the first three launches differ"

@@ -87,13 +87,53 @@ def test_step_with_the_folded_value_projection_equals_the_plain_step(seeded_sd, 
     seq_t = torch.randint(0, 20, (B, L), generator=g)
     outs = {}
     for pm in (True, False):
-        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"o_premul": pm})
-        assert eng.o_premul == pm
+        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"o_premul": pm, "k_fold": False})
+        assert eng.o_premul == pm and not eng.k_fold
         eng.bind_context(cu(enc[4]), cu(enc[5]), cu(batch["res_mask"]))
         eng.set_state(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t))
         eng.run()
         G.sync()
         outs[pm] = [eng.rot.clone(), eng.trans.clone(), eng.ang_raw.clone(), eng.logits.clone()]
+    ok = batch["res_mask"].reshape(-1)
+    tol = 3e-5 if precision == "fp32" else 2e-2
+    for name, a, b in zip(("rot", "trans", "ang_raw", "logits"), outs[True], outs[False]):
+        assert torch.isfinite(a[cu(ok)]).all(), name
+        assert G.rel_err(a[cu(ok)], b[cu(ok)]) < tol, (name, G.rel_err(a[cu(ok)], b[cu(ok)]))
+    if precision == "fp32":
+        with torch.no_grad():
+            ref = O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, enc[4], enc[5], batch["res_mask"].long())
+        G.assert_close(outs[True][0].cpu()[ok], ref[0].reshape(-1, 9)[ok], 1e-4, "rot vs oracle")
+        G.assert_close(outs[True][1].cpu()[ok], ref[1].reshape(-1, 3)[ok], 1e-4, "trans vs oracle")
+
+
+@pytest.mark.parametrize("B,L,lengths", [(4, 64, None), (3, 128, [128, 77, 100]), (2, 96, None), (5, 80, [80, 33, 80, 61, 70])])
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_step_with_the_keys_taken_from_the_node_state(seeded_sd, B, L, lengths, precision):
+    """DenoiseEngine option k_fold (pf_ipa_attn_args.k_from_s, ABI 58): q . k = (W_k^T (W_q s_i + b_q)) . s_j + a term constant along the
+    softmax row, so the projecting score kernels take the KEYS from the node state and pass over the eight k tiles of their weight stream.
+    One step with the fold on (default) and off: all three kernels (fp32 two-kernel form at 128 / 96 / 80, the form with the pair phase and
+    helper waves at 64, the f16 kernel), a ragged batch -- outputs agree to rounding, the default matches the oracle."""
+    from pepflowww_amd.engine import PackedWeights
+    sd = {k: cu(v) for k, v in seeded_sd.items()}
+    w = PackedWeights(sd, G.dev())
+    batch = synth.make_pocket_batch(B, L, 8, seed=37, lengths=lengths)
+    g = torch.Generator().manual_seed(3)
+    enc = O.encode(seeded_sd, batch)
+    t = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    q = torch.randn(B, L, 4, generator=g)
+    R_t = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x_t = enc[1] + torch.randn(B, L, 3, generator=g)
+    ang_t = torch.rand(B, L, 5, generator=g) * 2 * math.pi
+    seq_t = torch.randint(0, 20, (B, L), generator=g)
+    outs = {}
+    for kf in (True, False):
+        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"k_fold": kf})
+        assert eng.fused_proj and eng.k_fold == kf
+        eng.bind_context(cu(enc[4]), cu(enc[5]), cu(batch["res_mask"]))
+        eng.set_state(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t))
+        eng.run()
+        G.sync()
+        outs[kf] = [eng.rot.clone(), eng.trans.clone(), eng.ang_raw.clone(), eng.logits.clone()]
     ok = batch["res_mask"].reshape(-1)
     tol = 3e-5 if precision == "fp32" else 2e-2
     for name, a, b in zip(("rot", "trans", "ang_raw", "logits"), outs[True], outs[False]):

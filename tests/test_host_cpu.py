@@ -327,7 +327,7 @@ def test_engine_options_are_validated_and_noise_is_shard_invariant():
     import inspect
     from pepflowww_amd import distributed as D
     from pepflowww_amd.engine import DenoiseEngine
-    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul"}
+    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul", "k_fold"}
     assert "options" in inspect.signature(DenoiseEngine.__init__).parameters
     with pytest.raises(AssertionError):
         DenoiseEngine(None, 1, 16, torch.device("cpu"), options={"no_such_switch": True})
@@ -546,3 +546,22 @@ def test_linear_out_folded_into_the_value_projection_is_the_same_map():
     om = sum(P[h] @ projm[:, 1024 + h * 256 + 128:1024 + h * 256 + 256] for h in range(8))                 # head blocks ADDED
     got = om + rest @ w_out.double()[:, 1024:].T + b_out.double()
     assert (got - ref).abs().max() < 1e-5 * ref.abs().max()
+
+
+def test_keys_folded_into_the_queries_leave_the_softmax_unchanged():
+    """engine.fold_keys_into_queries (DenoiseEngine option k_fold): softmax_j(q_i . k_j + m_ij) == softmax_j(q'_i . s_j + m_ij) with
+    q' = W_k^T (W_q s + b_q) -- the dropped term (W_q s_i + b_q) . b_k is constant along j.  Float64, random weights, per head."""
+    from pepflowww_amd.engine import fold_keys_into_queries
+    g = torch.Generator().manual_seed(8)
+    wproj, bproj = torch.randn(3744, 128, generator=g) / 11, torch.randn(3744, generator=g)
+    wk, bk = fold_keys_into_queries(wproj, bproj)
+    assert torch.equal(wk[1024:], wproj[1024:]) and torch.equal(bk[1024:], bproj[1024:])     # only the query rows change
+    L = 11
+    s = torch.randn(L, 128, generator=g).double()
+    m = torch.randn(8, L, L, generator=g).double()                       # whatever else enters the scores (pair bias, point term, mask)
+    proj, projk = s @ wproj.double().T + bproj.double(), s @ wk.double().T + bk.double()
+    for h in range(8):
+        q, k = proj[:, h * 128:(h + 1) * 128], proj[:, 1024 + h * 256:1024 + h * 256 + 128]
+        ref = torch.softmax(0.05 * q @ k.T + m[h], -1)
+        got = torch.softmax(0.05 * projk[:, h * 128:(h + 1) * 128] @ s.T + m[h], -1)
+        assert (got - ref).abs().max() < 1e-6

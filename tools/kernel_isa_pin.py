@@ -27,7 +27,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 # the instantiations that run a projection prologue: fp32 mode without / with the pair phase, f16 mode
-PINNED = ("ipa_scores_kernelILb1ELb0ELb1ELb0EE", "ipa_scores_kernelILb1ELb1ELb1ELb0EE", "ipa_scores16_kernelILb1ELb1EE")
+# (template parameters: ipa_scores_kernel<VEC4, FUSE, PROJ, KFRAG, KF>, ipa_scores16_kernel<FUSE, PROJ, KF>; KF = keys from the node state, ABI 58)
+PINNED = ("ipa_scores_kernelILb1ELb0ELb1ELb0ELb0EE", "ipa_scores_kernelILb1ELb1ELb1ELb0ELb0EE", "ipa_scores16_kernelILb1ELb1ELb0EE",
+          "ipa_scores_kernelILb1ELb0ELb1ELb0ELb1EE", "ipa_scores_kernelILb1ELb1ELb1ELb0ELb1EE", "ipa_scores16_kernelILb1ELb1ELb1EE")
 
 
 def tools_present():
@@ -91,7 +93,9 @@ def main():
     got = kernel_hashes()
     if "--update" in sys.argv:
         pin = {"hipcc": hipcc_version(),
-               "validated_by": "profiles/r05/r05_campaign.txt (0 of 240 fresh processes), tests/test_gpu_fresh_process.py",
+               "validated_by": "KF = false (the three kernels of profiles/r05/r05_campaign.txt, 0 of 240 fresh processes): instruction streams identical to the "
+                               "validated ones up to three kernel-argument offsets (pf_ipa_attn_args grew by 8 bytes, ABI 58); KF = true (keys from the node "
+                               "state, 23 tiles in 8 chunks): profiles/r05/r05_campaign_kf.txt (0 of 144 fresh processes), tests/test_gpu_fresh_process.py",
                "kernels": got}
         with open(PIN, "w") as f:
             json.dump(pin, f, indent=1, sort_keys=True)
