@@ -354,6 +354,12 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     // Without KS (the form with the pair phase in front, L <= 64: no registers to spare, same-box 0.654 vs 0.659 ms at cfg2): fp32
     // blocks (key tile, 16-channel step) = the 64 lanes' float4, the first product stays on fp32 MFMAs.
     _Float16* kfrag = VTH + (size_t)8 * (VTG >> 5) * 1024 + (size_t)tile * 4096 + lane * 8;
+    // this lane's query point of each of the two query-point tiles (global frame): point 4 t + g of row r.  They STAY IN REGISTERS and
+    // reach the lanes of their row through cross-lane reads behind the loop -- until round 5 they went through a wave-private LDS region
+    // (ds_write2_b32 here, ds_read_b128 there), and that hand-off is where every failure of the run-to-run checks was located: ONE dword
+    // (the y of the last point, written by the last 16 lanes) read back as the slot's previous content, in 0.03 - 0.3 % of the launches
+    // on boxes that hold 2.4 GHz, never on the ones that hold 1.8 GHz (profiles/r05/README.md).  No LDS memory, no hand-off.
+    float qpr[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ_CHUNK_B + tl * 8192 + lane * 16;
 #pragma unroll
@@ -444,8 +450,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                         const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
                         const float oz = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
                         if constexpr (idx < 26) {           // query point 4 (idx - 24) + g
-                            float* o = QPW + r * 24 + 3 * (4 * (idx - 24) + g);
-                            o[0] = ox; o[1] = oy; o[2] = oz;
+                            qpr[idx - 24][0] = ox; qpr[idx - 24][1] = oy; qpr[idx - 24][2] = oz;
                         } else {                            // key point pp < 8 | value point pp - 8 of key row jrow
                             const int pp = 4 * (idx - 26) + g;
                             if (jrow < LPe) {
@@ -475,11 +480,20 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         // release leaves vmcnt alone on gfx9: stores and the other waves' later loads pass the CU's L1 in order) -- the three stores of
         // chunk 7 were still allowed in flight by the last counted wait; the explicit wait costs nothing (three chunks later) and the
         // hand-off through `proj` no longer leans on that ordering rule
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // + wave-private LDS hand-off of the query points
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (role == 2) return;                                            // (a helper: no queries of its own)
+        // row r's eight query points: point 4 t + gs sits in lane r + 16 gs (registers qpr[t]) -- 24 cross-lane reads, once per launch
+        float qv[24];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int gs = 0; gs < 4; ++gs)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) qv[3 * (4 * t2 + gs) + cc] = __shfl(qpr[t2][cc], r + 16 * gs, 64);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) qp4[q] = make_float4(qv[4 * q], qv[4 * q + 1], qv[4 * q + 2], qv[4 * q + 3]);
+        (void)QPW;
     }
 }
 
@@ -543,6 +557,7 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
     for (int c = 0; c < PJ_NB - 1; ++c)
         if (c < NCH) issue(c);
     _Float16* QL = reinterpret_cast<_Float16*>(QPW);             // [16 rows][40]: two q tiles (32 channels) of the wave's rows at a time
+    float qpr[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};        // this lane's query point of the two query-point tiles: registers + cross-lane reads, as in proj_head
     auto ldfrag = [&](int c, int tl, half8 (&w)[4]) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ16_CHUNK_B + tl * 4096 + lane * 16;
 #pragma unroll
@@ -599,8 +614,7 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
                             const float oy = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + T[1];
                             const float oz = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + T[2];
                             if constexpr (idx < 26) {
-                                float* o = QPW + r * 24 + 3 * (4 * (idx - 24) + g);
-                                o[0] = ox; o[1] = oy; o[2] = oz;
+                                qpr[idx - 24][0] = ox; qpr[idx - 24][1] = oy; qpr[idx - 24][2] = oz;
                             } else {
                                 const int pp = 4 * (idx - 26) + g;
                                 if (pp < 8) {
@@ -620,8 +634,15 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
     if (wave_on) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        float qv[24];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) qp4[q] = *reinterpret_cast<const float4*>(QPW + r * 24 + 4 * q);
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int gs = 0; gs < 4; ++gs)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) qv[3 * (4 * t2 + gs) + cc] = __shfl(qpr[t2][cc], r + 16 * gs, 64);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) qp4[q] = make_float4(qv[4 * q], qv[4 * q + 1], qv[4 * q + 2], qv[4 * q + 3]);
     }
 }
 

@@ -43,7 +43,12 @@ def test_shard_check_of_the_helper_wave_form_in_fresh_processes(precision):
 
 @pytest.mark.parametrize("k_from_s", [True, False])
 def test_fused_score_kernel_is_bitwise_stable_over_many_launches(seeded_sd, k_from_s):
-    """(k_from_s: the form the engine runs since ABI 58 -- keys from the node state, the k tiles passed over -- and the form before it.)
+    """(k_from_s = True: the form the engine runs since ABI 58 -- keys from the node state, 23 weight tiles; False: the form before it.)
+    History of this test: with the query points handed from the projecting lanes to the lanes of their row through a wave-private LDS
+    region, the k_from_s = 0 form had passed 30 000 launches and 340 fresh processes on boxes that held 1.8 GHz -- and failed THIS test in
+    0.03 - 0.3 % of the launches on boxes that hold 2.4 GHz (one dword of one wave's hand-off, the signature of the straight-line build);
+    same box, same minute, alternating libraries: 7 and 43 of 20 000 with the LDS hand-off, 0 and 0 of 20 000 with the points kept in
+    registers and read across lanes (profiles/r05/r05_handoff_ab.txt) -- what both forms do now.
     The projection-inside score kernel (fp32 mode) at B x L = 64 x 128, launched 1500 times on the same inputs (the rows rewritten
     by a copy kernel before every launch, as in the step): every output bit-equal to the first launch's.  tools/dev/r05_ipa_repeat.py is
     the diagnostic form (it locates a difference: which workgroup, which wave, which operand); a build of the prologue WITHOUT the

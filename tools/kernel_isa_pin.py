@@ -93,9 +93,9 @@ def main():
     got = kernel_hashes()
     if "--update" in sys.argv:
         pin = {"hipcc": hipcc_version(),
-               "validated_by": "KF = false (the three kernels of profiles/r05/r05_campaign.txt, 0 of 240 fresh processes): instruction streams identical to the "
-                               "validated ones up to three kernel-argument offsets (pf_ipa_attn_args grew by 8 bytes, ABI 58); KF = true (keys from the node "
-                               "state, 23 tiles in 8 chunks): profiles/r05/r05_campaign_kf.txt (0 of 144 fresh processes), tests/test_gpu_fresh_process.py",
+               "validated_by": "profiles/r05/r05_campaign_regs.txt (0 of 144 fresh processes, six shapes x two modes), tests/test_gpu_fresh_process.py, "
+                               "profiles/r05/r05_handoff_ab.txt (0 of 80 000 launches of the fp32 forms with the query points handed over in registers; 7 and 43 of 20 000 "
+                               "with the LDS hand-off on the same box); the f16 forms are the ones of profiles/r05/r05_campaign.txt / r05_campaign_kf.txt",
                "kernels": got}
         with open(PIN, "w") as f:
             json.dump(pin, f, indent=1, sort_keys=True)
