@@ -602,8 +602,11 @@ class DenoiseEngine:
         # ... and the library is asked whether it would launch that form here (its LDS arithmetic and wave cap decide: ADVICE r4)
         can_pj = bool(can_pj and self.lib.pf_ipa_proj_inside_ok(L, int(precision == "f16")))
         self.fused_proj = can_pj and opt.get("fused_proj", True)
-        self.o_premul = bool(opt.get("o_premul", self.O_PREMUL))
-        self.k_fold = bool(self.fused_proj and opt.get("k_fold", self.K_FOLD))
+        # (both weight folds default to the fp32-parity mode only: there they leave the error against the oracle where it was, 3 - 8e-6; in
+        #  the f16 mode the folded matrices are rounded to f16 ONCE as a product and on heavy-tailed weights the step's worst rotation error
+        #  went from 8.5e-3 to 1.1e-2 (o_premul) / 1.4e-2 (k_fold) for 0.5 % / 1.4 % of its time: tools/dev/r05_f16_fold_err.py)
+        self.o_premul = bool(opt.get("o_premul", self.O_PREMUL and precision == "fp32"))
+        self.k_fold = bool(self.fused_proj and opt.get("k_fold", self.K_FOLD and precision == "fp32"))
         self.att_qk = self.att_vt = None
         if self.att_planes and not self.fused_proj:              # (planes through HBM only where the projection is its own launch)
             self.att_qk = torch.zeros(rows * 2048, dtype=torch.float16, device=device)

@@ -127,8 +127,8 @@ def test_step_with_the_keys_taken_from_the_node_state(seeded_sd, B, L, lengths, 
     seq_t = torch.randint(0, 20, (B, L), generator=g)
     outs = {}
     for kf in (True, False):
-        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"k_fold": kf})
-        assert eng.fused_proj and eng.k_fold == kf
+        eng = DenoiseEngine(w, B, L, G.dev(), precision=precision, options={"k_fold": kf, "o_premul": True})
+        assert eng.fused_proj and eng.k_fold == kf and eng.o_premul
         eng.bind_context(cu(enc[4]), cu(enc[5]), cu(batch["res_mask"]))
         eng.set_state(cu(t), cu(R_t), cu(x_t), cu(ang_t), cu(seq_t))
         eng.run()
@@ -144,3 +144,15 @@ def test_step_with_the_keys_taken_from_the_node_state(seeded_sd, B, L, lengths, 
             ref = O.ga_encoder(seeded_sd, t, R_t, x_t, ang_t, seq_t, enc[4], enc[5], batch["res_mask"].long())
         G.assert_close(outs[True][0].cpu()[ok], ref[0].reshape(-1, 9)[ok], 1e-4, "rot vs oracle")
         G.assert_close(outs[True][1].cpu()[ok], ref[1].reshape(-1, 3)[ok], 1e-4, "trans vs oracle")
+
+
+def test_weight_folds_default_to_the_fp32_mode(seeded_sd):
+    """Both folds are on by default in the fp32-parity mode and off in the f16 mode (one f16 rounding of a PRODUCT matrix costs that mode
+    accuracy on heavy-tailed weights: tools/dev/r05_f16_fold_err.py); the options force either."""
+    from pepflowww_amd.engine import PackedWeights
+    w = PackedWeights({k: cu(v) for k, v in seeded_sd.items()}, G.dev())
+    e32, e16 = DenoiseEngine(w, 2, 64, G.dev(), precision="fp32"), DenoiseEngine(w, 2, 64, G.dev(), precision="f16")
+    assert e32.o_premul and e32.k_fold and not e16.o_premul and not e16.k_fold
+    e = DenoiseEngine(w, 2, 64, G.dev(), precision="f16", options={"o_premul": True, "k_fold": True})
+    assert e.o_premul and e.k_fold
+    assert not DenoiseEngine(w, 2, 144, G.dev(), precision="fp32").k_fold            # (no projecting score kernel beyond 128: nothing to fold into)

@@ -93,9 +93,9 @@ def main():
     got = kernel_hashes()
     if "--update" in sys.argv:
         pin = {"hipcc": hipcc_version(),
-               "validated_by": "profiles/r05/r05_campaign_regs.txt (0 of 144 fresh processes, six shapes x two modes), tests/test_gpu_fresh_process.py, "
-                               "profiles/r05/r05_handoff_ab.txt (0 of 80 000 launches of the fp32 forms with the query points handed over in registers; 7 and 43 of 20 000 "
-                               "with the LDS hand-off on the same box); the f16 forms are the ones of profiles/r05/r05_campaign.txt / r05_campaign_kf.txt",
+               "validated_by": "query points handed over in registers in all six kernels: profiles/r05/r05_campaign_regs2.txt (0 of 144 fresh processes, six shapes x "
+                               "two modes; r05_campaign_regs.txt: the same for the fp32 forms one commit earlier), tests/test_gpu_fresh_process.py, "
+                               "profiles/r05/r05_handoff_ab.txt (fp32 forms: 0 of 80 000 launches; 7 and 43 of 20 000 with the LDS hand-off on the same box)",
                "kernels": got}
         with open(PIN, "w") as f:
             json.dump(pin, f, indent=1, sort_keys=True)
