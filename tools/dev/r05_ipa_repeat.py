@@ -19,6 +19,10 @@ mask = torch.ones(B, L)
 gq = lambda k: cu(sd[pfx + k])
 wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
 bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+KF = int(os.environ.get("KF", 0))          # 1: the keys-from-the-node-state form (folded query rows, pf_ipa_attn_args.k_from_s)
+if KF:
+    from pepflowww_amd.engine import fold_keys_into_queries
+    wproj, bproj = fold_keys_into_queries(wproj, bproj)
 w16, bp = pack_ipa_projection(cu(wproj), cu(bproj))
 pfxB = "ga_encoder.trunk.ipa_4."
 wprojB = torch.cat([sd[pfxB + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
@@ -42,7 +46,7 @@ def run(other=False):
     global dbg
     dbg = (torch.zeros(B * L, 192, device=G.dev()), torch.zeros(B * L, 192, device=G.dev())) if os.environ.get("DBG_QP") else None
     f = G.ipa_feats(scratch, None, Rd, xd, md, gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"),
-                    B, L, bias=bias, p_out=p, variant=2, key_end=None, dz=dz, fused_pair=False, points=None, fused_proj=(sdev, w16, bp), debug_pts=dbg)[0]
+                    B, L, bias=bias, p_out=p, variant=2, key_end=None, dz=dz, fused_pair=False, points=None, fused_proj=(sdev, w16, bp), debug_pts=dbg, k_from_s=bool(KF))[0]
     return f, p
 f0, p0 = run()
 qpl = (s.double() @ sd[pfx + "linear_q_points.weight"].double().T + sd[pfx + "linear_q_points.bias"].double())       # [B, L, 192] = x | y | z blocks of 64
