@@ -246,13 +246,13 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
 
 
 def kernel_src_sha():
-    """Hash of the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): what the PMC passes record and the bench line compares --
+    """Hash of the kernel sources and their build recipe (csrc/*.hip, csrc/*.h, include/*.h, build.py): what the PMC passes record and the bench line compares --
     `git rev-parse` is not available on the GPU box (the snapshot ships without .git)."""
     import glob
     import hashlib
     h = hashlib.sha1()
     for f in sorted(glob.glob(os.path.join(ROOT, "pepflowww_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pepflowww_amd", "csrc", "*.h")) +
-                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+                    glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(ROOT, "pepflowww_amd", "build.py")]):   # (build.py: the compiler flags)
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

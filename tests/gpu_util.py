@@ -115,7 +115,7 @@ def ipa_projection(s, w16, bias, rot, trans):
 
 
 def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bias=None, p_out=None, variant=0, head_group=0, key_end=None,
-              dz=None, fused_pair=False, points=None, fused_proj=None, debug_pts=None, k_from_s=False):
+              dz=None, fused_pair=False, points=None, fused_proj=None, debug_pts=None, k_from_s=False, keep=None):
     """bias: [B,8,L,L] head-major (or None: computed in-kernel); p_out: [B,8,L,L] buffer (with bias -> two-kernel form unless
     variant=1); head_group: force a head-group split of the one-kernel form; dz: [B,L,L,16] pair values W_dz z (no bias) for the
     two-kernel form's pair aggregation (z may then be None); fused_pair: that aggregation inside the score kernel (p_out may be None)."""
@@ -156,6 +156,8 @@ def ipa_feats(proj, z, rot, trans, mask, w_b, b_b, w_dz, b_dz, head_w, B, L, bia
         if os.environ.get("PF_TEST_POISON_VT"):     # (dev: a fragment read before it was written shows as NaN; L % 32 == 0 only)
             vt.fill_(float("nan"))
         ia.att_vt = _p(vt)
+        if keep is not None:                        # (dev: the scratch handed back for a look at the fragments)
+            keep["vt"] = vt
     _capi.check(lib.pf_ipa_attn_fwd(C.byref(ia), _capi.stream_ptr()), "pf_ipa_attn_fwd")
     sync()
     return feats, (qp, kp, vp)
