@@ -207,6 +207,14 @@ __device__ __forceinline__ void pj_glds16(const void* sbase, unsigned voff, unsi
     // the M0 wait state).  Rounds 3 - 4 had `s_nop 0` here: a spec violation, though no failure could be tied to it.
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(lds_addr) : "memory", "m0");
 }
+// hi | lo split with the hi plane DEFINED by the packed registers the MFMA reads.  hipcc may select f16(x) twice -- inside the packed
+// conversion that builds the operand vector (v_cvt_pk_f16_f32 of the fp32 value) and again for the scalar that feeds lo, and when x
+// is a product or a sum it folds that second one into v_fma_mixlo_f16, which rounds ONCE from the exact result.  At an fp32 value
+// that lies exactly between two f16 numbers the two selections differ by one f16 ulp and hi + lo is off by that ulp: with
+// -fno-slp-vectorize the fused form did exactly that to a probability of 0.0625 - 2^-16 (one query row of 8192, 1e-4 against the
+// oracle; the packed build had happened to extract lo's operand from the packed registers).  The empty asm makes the vector opaque:
+// what lo is computed from is what the MFMA multiplies.  No instruction.
+template <class V> __device__ __forceinline__ void pf_pin(V& v) { asm("" : "+v"(v)); }
 template <int N> __device__ __forceinline__ void pj_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant): at most n vector memory operations of this
 // wave are outstanding (LOADS complete in order among themselves; a store may complete before an older load, see proj_head)
@@ -330,7 +338,10 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                     if constexpr (KS) {
                         half4 hi, lo;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+                        for (int e = 0; e < 4; ++e) hi[e] = (_Float16)v[e];
+                        pf_pin(hi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(v[e] - (float)hi[e]);
                         _Float16* d = kfrag + (t8 >> 1) * 1024 + (t8 & 1) * 4;
                         *reinterpret_cast<half4*>(d) = hi;
                         *reinterpret_cast<half4*>(d + 512) = lo;
@@ -427,7 +438,10 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                         if constexpr (KS) {
                             half4 hi, lo;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+                            for (int e = 0; e < 4; ++e) hi[e] = (_Float16)v[e];
+                            pf_pin(hi);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(v[e] - (float)hi[e]);
                             _Float16* d = kfrag + ((idx - 8) >> 1) * 1024 + ((idx - 8) & 1) * 4;  // K-step (idx - 8) / 2: hi KiB | lo KiB
                             *reinterpret_cast<half4*>(d) = hi;
                             *reinterpret_cast<half4*>(d + 512) = lo;
@@ -437,7 +451,10 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                     } else if constexpr (VTILE) {           // channel 16 (idx - 16) + r of keys 16 tile + 4 g + e -> hi | lo plane, 8 bytes each
                         half4 hi, lo;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+                        for (int e = 0; e < 4; ++e) hi[e] = (_Float16)v[e];
+                        pf_pin(hi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(v[e] - (float)hi[e]);
                         const int f = 16 * (idx - 16) + r;
                         // fragment order: block (tile nt, step, plane) = the 64 reader lanes' 16 bytes each; this lane's four keys are
                         // half (tile & 1) of reader lane (n, g)'s eight slots
@@ -753,7 +770,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         for (int s = 0; KSPLIT && s < 4; ++s) {
             const float v[8] = {qf[2 * s].x, qf[2 * s].y, qf[2 * s].z, qf[2 * s].w, qf[2 * s + 1].x, qf[2 * s + 1].y, qf[2 * s + 1].z, qf[2 * s + 1].w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { qh[s][j] = (_Float16)v[j]; ql[s][j] = (_Float16)(v[j] - (float)qh[s][j]); }
+            for (int j = 0; j < 8; ++j) qh[s][j] = (_Float16)v[j];
+            pf_pin(qh[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ql[s][j] = (_Float16)(v[j] - (float)qh[s][j]);
         }
     } else {
     // ---- key points / key mask / value points of the head -> LDS (all waves) ----
@@ -968,7 +988,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
             const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
             half8 ph, pl;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)pv[j]; pl[j] = (_Float16)(pv[j] - (float)ph[j]); }
+            for (int j = 0; j < 8; ++j) ph[j] = (_Float16)pv[j];
+            pf_pin(ph);                                                   // (lo from the hi the MFMA reads: pf_pin)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pl[j] = (_Float16)(pv[j] - (float)ph[j]);
             half8 qh[3], ql[3];
 #pragma unroll
             for (int n = 0; n < 3; ++n) {                                 // value points: rows 16 n + r of the LDS planes

@@ -47,10 +47,42 @@ def run(other=False):
     global dbg
     dbg = (torch.zeros(B * L, 192, device=G.dev()), torch.zeros(B * L, 192, device=G.dev())) if os.environ.get("DBG_QP") or os.environ.get("DBG_KP") else None
     f = G.ipa_feats(scratch, None, Rd, xd, md, gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"), gq("head_weights"),
-                    B, L, bias=bias, p_out=p, variant=2, key_end=None, dz=dz, fused_pair=False, points=None, fused_proj=(sdev, w16, bp), debug_pts=dbg, k_from_s=bool(KF), keep=KEEP)[0]
+                    B, L, bias=bias, p_out=p, variant=2, key_end=None, dz=dz, fused_pair=bool(int(os.environ.get("FUSED", 0))), points=None, fused_proj=(sdev, w16, bp), debug_pts=dbg, k_from_s=bool(KF), keep=KEEP)[0]
     return f, p
 f0, p0 = run()
 vt0 = KEEP["vt"].clone()
+if os.environ.get("SAVE_TAG"):        # dev: the first launch's outputs kept for a comparison between two builds of the library
+    os.makedirs("gpurun_out/bd", exist_ok=True)
+    tg = os.environ["SAVE_TAG"]
+    torch.save((f0.cpu(), p0.cpu()), f"gpurun_out/bd/{tg}_kf{KF}.pt")
+    for fn_ in sorted(os.listdir("gpurun_out/bd")):
+        if fn_.endswith(f"_kf{KF}.pt") and not fn_.startswith(tg + "_"):
+            f1, p1 = torch.load(f"gpurun_out/bd/{fn_}")
+            nf = (f0.cpu() != f1) & ~(torch.isnan(f0.cpu()) & torch.isnan(f1)); npp = (p0.cpu() != p1)
+            print(f"{tg} vs {fn_}: feats differ in {int(nf.sum())} values / {int(nf.any(1).sum())} rows; P differs in {int(npp.sum())} values / {int(npp.any(-1).sum())} (b,h,row) rows")
+            idx = torch.nonzero(npp.any(-1))
+            for b_, h_, i_ in idx[:6].tolist():
+                a_, c_ = p0.cpu()[b_, h_, i_], p1[b_, h_, i_]
+                j_ = int((a_ - c_).abs().argmax())
+                msk = (a_ != c_)
+                print(f"   P row (b {b_}, h {h_}, i {i_}): {int(msk.sum())} keys differ; max|dP| {float((a_ - c_).abs().max()):.3e} at key {j_} (P {float(a_[j_]):.6e} vs {float(c_[j_]):.6e}); row max P {float(a_.max()):.4f}; sum {float(a_.sum()):.7f} vs {float(c_.sum()):.7f}; ratio now/other at differing keys: min {float((a_[msk] / c_[msk]).min()):.7f} max {float((a_[msk] / c_[msk]).max()):.7f}")
+            with torch.no_grad():
+                ref_f = O.ipa(sd, pfx[:-1], s, z, R, x, mask)[1].reshape(B * L, -1)
+            for r_ in torch.nonzero(nf.any(1)).flatten().tolist()[:4]:
+                cs = torch.nonzero(nf[r_]).flatten()
+                sc = float(ref_f[r_].abs().max())
+                print(f"   row {r_} (b {r_ // L}, i {r_ % L}): {len(cs)} columns {cs[0].item()}..{cs[-1].item()}; error vs the oracle on them / max|row|: this build {float((f0.cpu()[r_, cs] - ref_f[r_, cs]).abs().max()) / sc:.3e}, the other {float((f1[r_, cs] - ref_f[r_, cs]).abs().max()) / sc:.3e}; on the row's other columns: {float((f0.cpu()[r_] - ref_f[r_]).abs().max()) / sc:.3e}")
+                print("      this  ", [round(v, 6) for v in f0.cpu()[r_, cs[:6]].tolist()], "\n      other ", [round(v, 6) for v in f1[r_, cs[:6]].tolist()], "\n      oracle", [round(v, 6) for v in ref_f[r_, cs[:6]].tolist()])
+            if os.environ.get("PROW"):
+                b_, h_, i_ = [int(v) for v in os.environ["PROW"].split(",")]
+                pr = p0.cpu()[b_, h_, i_]
+                top = torch.topk(pr, 6)
+                print(f"   P row (b {b_}, h {h_}, i {i_}): top {[(int(k_), float(v_)) for v_, k_ in zip(top.values, top.indices)]}  sum {float(pr.sum()):.7f}  min {float(pr.min()):.3e}")
+                ph_ = pr.half().float(); pl_ = (pr - ph_)
+                print(f"      as f16 hi: {[float(v) for v in ph_[top.indices]]}  lo: {[float(v) for v in pl_[top.indices]]}  lo as f16: {[float(v) for v in pl_.half().float()[top.indices]]}")
+            rows_f = torch.nonzero(nf.any(1)).flatten()
+            prow = set((b_ * L + i_) for b_, h_, i_ in idx.tolist())
+            print(f"   feats rows differing without a differing P row: {len([r_ for r_ in rows_f.tolist() if r_ not in prow])} of {len(rows_f)}")
 qpl = (s.double() @ sd[pfx + "linear_q_points.weight"].double().T + sd[pfx + "linear_q_points.bias"].double())       # [B, L, 192] = x | y | z blocks of 64
 qpl = torch.stack(qpl.chunk(3, -1), -1)                                      # [B, L, 64, 3] local, point index = h * 8 + p
 qp_ref = (torch.einsum("blij,blpj->blpi", R.double(), qpl) + x.double()[:, :, None, :]).reshape(B * L, 192).float()
