@@ -93,9 +93,11 @@ def main():
     got = kernel_hashes()
     if "--update" in sys.argv:
         pin = {"hipcc": hipcc_version(),
-               "validated_by": "query points handed over in registers in all six kernels: profiles/r05/r05_campaign_regs2.txt (0 of 144 fresh processes, six shapes x "
-                               "two modes; r05_campaign_regs.txt: the same for the fp32 forms one commit earlier), tests/test_gpu_fresh_process.py, "
-                               "profiles/r05/r05_handoff_ab.txt (fp32 forms: 0 of 80 000 launches; 7 and 43 of 20 000 with the LDS hand-off on the same box)",
+               "validated_by": "library built with -fno-slp-vectorize (no compiler-formed packed fp32 instruction: profiles/r05/r05_pkmul_bisect.txt), hi | lo "
+                               "splits through pf_pin, query points handed over in registers: 0 of 20 000 launches in each of three kernel forms "
+                               "(keys from the state / projected, fused form), bit-identical to the packed build launch by launch "
+                               "(tools/dev/r05_launch_trace.py), GPU suite profiles/r05/r05fin9_gputest.log, fresh-process campaign "
+                               "profiles/r05/r05_campaign_noslp.txt, tests/test_gpu_fresh_process.py",
                "kernels": got}
         with open(PIN, "w") as f:
             json.dump(pin, f, indent=1, sort_keys=True)
