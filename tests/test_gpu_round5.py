@@ -156,3 +156,45 @@ def test_weight_folds_default_to_the_fp32_mode(seeded_sd):
     e = DenoiseEngine(w, 2, 64, G.dev(), precision="f16", options={"o_premul": True, "k_fold": True})
     assert e.o_premul and e.k_fold
     assert not DenoiseEngine(w, 2, 144, G.dev(), precision="fp32").k_fold            # (no projecting score kernel beyond 128: nothing to fold into)
+
+
+@pytest.mark.parametrize("k_from_s", [True, False])
+def test_fused_score_kernel_row_by_row_at_an_exact_f16_tie(seeded_sd, k_from_s):
+    """A hi | lo split must take lo from the hi the MFMA reads (ipa_split.hip pf_pin).  These inputs (tools/dev/r05_ipa_repeat.py:
+    seed 7, B x L = 16 x 64, block ipa_2, fused form) contain a normalised probability of 0.0625 - 2^-16 -- an fp32 value exactly
+    between two f16 numbers -- in query row 3 of sample 12, head 0.  A build in which hipcc selected f16(p * inv) twice
+    (v_cvt_pk_f16_f32 of the fp32 product for the operand, v_fma_mixlo_f16 for lo's scalar: double vs single rounding) was off by
+    one f16 ulp there: that row 1.05e-4 from the oracle, every other row ~1e-6 -- inside the 1e-4 whole-tensor bar, so only a
+    ROW-WISE bound catches it.  Every row within 1e-5 of the oracle (normalised by the row's largest feature)."""
+    import torch.nn.functional as F
+    from pepflowww_amd.engine import pack_ipa_projection, fold_keys_into_queries
+    B, L = 16, 64
+    sd = seeded_sd
+    g = torch.Generator().manual_seed(7)
+    pfx = "ga_encoder.trunk.ipa_2."
+    s = torch.randn(B, L, 128, generator=g)
+    z = torch.randn(B, L, L, 64, generator=g)
+    q = torch.randn(B, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    x = torch.randn(B, L, 3, generator=g) * 8
+    mask = torch.ones(B, L)
+    gq = lambda k: cu(sd[pfx + k])
+    wproj = torch.cat([sd[pfx + n + ".weight"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    bproj = torch.cat([sd[pfx + n + ".bias"] for n in ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")], 0)
+    if k_from_s:
+        wproj, bproj = fold_keys_into_queries(wproj, bproj)
+    w16, bp = pack_ipa_projection(cu(wproj), cu(bproj))
+    sdev, Rd, xd, md = cu(s.reshape(B * L, 128)), cu(R.reshape(B * L, 9)), cu(x.reshape(B * L, 3)), cu(mask.reshape(-1))
+    zd = cu(z)
+    bias = (math.sqrt(1.0 / 3.0) * F.linear(zd, gq("linear_b.weight"), gq("linear_b.bias"))).reshape(B, L, L, 8).permute(0, 3, 1, 2).contiguous()
+    dz = F.linear(zd, gq("down_z.weight")).contiguous()
+    scratch = torch.full((B * L, 3744), float("nan"), device=G.dev())
+    feats = G.ipa_feats(scratch, None, Rd, xd, md, gq("linear_b.weight"), gq("linear_b.bias"), gq("down_z.weight"), gq("down_z.bias"),
+                        gq("head_weights"), B, L, bias=bias, p_out=None, variant=2, key_end=None, dz=dz, fused_pair=True, points=None,
+                        fused_proj=(sdev, w16, bp), k_from_s=k_from_s)[0].cpu()
+    with torch.no_grad():
+        ref = O.ipa(sd, pfx[:-1], s, z, R, x, mask)[1].reshape(B * L, -1)
+    err = (feats - ref).abs().amax(1) / ref.abs().amax(1)
+    worst = int(err.argmax())
+    print(f"k_from_s={k_from_s}: worst row {worst} (sample {worst // L}, query {worst % L}): {float(err[worst]):.3e}; the tie row 771: {float(err[771]):.3e}")
+    assert torch.isfinite(feats).all() and float(err.max()) < 1e-5, (worst, float(err.max()))

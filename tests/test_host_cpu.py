@@ -432,10 +432,11 @@ def test_pdb_reader_and_preprocess_structure(golden_dir, tmp_path):
 
 
 def test_prologue_kernels_are_the_validated_machine_code():
-    """The projection prologue's ordering dependence is not root-caused: what is validated is one machine-code form
-    of the three kernels that run it (0 of 240 fresh processes, profiles/r05/r05_campaign.txt).  A compiler bump or an edit anywhere
-    in ipa_split.hip that changes their instruction streams must not pass silently: the disassembly of the BUILT library is compared
-    with the committed pin; after a deliberate change re-run the GPU validation, then `python tools/kernel_isa_pin.py --update`."""
+    """The machine code of the six kernels that run a projection prologue is pinned: their failures were traced to a compiler-formed
+    packed multiply (test below), but the validation (bitwise repeat tests, fresh-process campaign,
+    profiles/r05/r05_campaign_noslp.txt) is of ONE instruction stream per kernel.  A compiler bump or an edit anywhere in
+    ipa_split.hip that changes them must not pass silently: the disassembly of the BUILT library is compared with the committed
+    pin; after a deliberate change re-run the GPU validation, then `python tools/kernel_isa_pin.py --update`."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("kernel_isa_pin", os.path.join(ROOT, "tools", "kernel_isa_pin.py"))
     pin_tool = importlib.util.module_from_spec(spec)
@@ -451,6 +452,45 @@ def test_prologue_kernels_are_the_validated_machine_code():
             f"{k}: the built library's instruction stream ({got[k]['instructions']} instructions, {got[k]['sha1'][:12]}) is not the validated "
             f"one ({pin['kernels'][k]['instructions']}, {pin['kernels'][k]['sha1'][:12]}; pinned with {pin['hipcc']}): re-run "
             "tools/dev/r05_campaign.sh + tests/test_gpu_fresh_process.py on the GPU box, then tools/kernel_isa_pin.py --update")
+
+
+def test_library_holds_no_compiler_formed_packed_fp32_with_op_sel():
+    """Round 5 traced every run-to-run failure of the projecting score kernels to ONE instruction hipcc's SLP vectoriser had formed
+    from scalar code -- v_pk_mul_f32 vD, vA, vB op_sel:[0,1] op_sel_hi:[1,0], whose low-half product came out as 0 in lanes 48..63
+    of 2.4 % of the waves (profiles/r05/r05_pkmul_bisect.txt).  The library is built with -fno-slp-vectorize (build.py); what is
+    left are the hand-written v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 of the score and pair phases, none with crossed halves.
+    The BUILT library is disassembled: no packed fp32 instruction with an op_sel modifier may be in it, and the flag must be in the
+    recipe."""
+    import importlib.util
+    import re
+    import subprocess
+    import tempfile
+    from pepflowww_amd import build as B
+    assert "-fno-slp-vectorize" in B.FLAGS and "-ffp-contract=off" in B.FLAGS
+    spec = importlib.util.spec_from_file_location("kernel_isa_pin", os.path.join(ROOT, "tools", "kernel_isa_pin.py"))
+    pin_tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin_tool)
+    if not pin_tool.tools_present() or not os.path.exists(pin_tool.LIB):
+        pytest.skip("llvm-objcopy / clang-offload-bundler / llvm-objdump or the built library not here")
+    bad, packed, kernels = [], 0, 0
+    with tempfile.TemporaryDirectory() as wd:
+        for co in pin_tool.device_code_objects(pin_tool.LIB, wd):
+            txt = subprocess.run([os.path.join(pin_tool.LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--no-leading-addr", co],
+                                 capture_output=True, text=True, check=True).stdout
+            cur = None
+            for line in txt.split("\n"):
+                m = re.match(r"^[0-9a-f]* ?<(.+)>:$", line.strip())
+                if m:
+                    cur, kernels = m.group(1), kernels + 1
+                    continue
+                t = line.split()
+                if t and t[0].startswith("v_pk_") and t[0].endswith("_f32"):
+                    packed += 1
+                    if "op_sel:" in line:
+                        bad.append((cur, " ".join(t[:8])))
+    assert kernels > 100, kernels
+    assert not bad, (len(bad), bad[:5])
+    print(f"{kernels} kernels, {packed} packed fp32 instructions, none with op_sel")
 
 
 def test_length_bucket_plan_and_sub_batches():
