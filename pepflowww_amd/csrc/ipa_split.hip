@@ -367,9 +367,11 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     _Float16* kfrag = VTH + (size_t)8 * (VTG >> 5) * 1024 + (size_t)tile * 4096 + lane * 8;
     // this lane's query point of each of the two query-point tiles (global frame): point 4 t + g of row r.  They STAY IN REGISTERS and
     // reach the lanes of their row through cross-lane reads behind the loop -- until round 5 they went through a wave-private LDS region
-    // (ds_write2_b32 here, ds_read_b128 there), and that hand-off is where every failure of the run-to-run checks was located: ONE dword
-    // (the y of the last point, written by the last 16 lanes) read back as the slot's previous content, in 0.03 - 0.3 % of the launches
-    // on boxes that hold 2.4 GHz, never on the ones that hold 1.8 GHz (profiles/r05/README.md).  No LDS memory, no hand-off.
+    // (ds_write2_b32 here, ds_read_b128 there).  That hand-off was blamed for the run-to-run failures (ONE dword, the y of the last
+    // point, written by the last 16 lanes, in 0.03 - 0.3 % of the launches on 2.4 GHz boxes) and replaced; the end of the round
+    // showed that the value was wrong BEFORE it was stored: the low half of a compiler-formed v_pk_mul_f32 ... op_sel:[0,1]
+    // op_sel_hi:[1,0] in the rotation below (build.py: -fno-slp-vectorize; profiles/r05/r05_pkmul_bisect.txt).  The register form
+    // stays: no LDS memory, nothing to hand over.
     float qpr[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto ldfrag = [&](int c, int tl, PjW& w) __attribute__((always_inline)) {
         const unsigned char* b = WS + (c % PJ_NB) * PJ_CHUNK_B + tl * 8192 + lane * 16;
