@@ -493,6 +493,64 @@ def test_library_holds_no_compiler_formed_packed_fp32_with_op_sel():
     print(f"{kernels} kernels, {packed} packed fp32 instructions, none with op_sel")
 
 
+def test_lds_dma_bases_are_never_fresh_valu_results():
+    """`global_load_lds` reads its SGPR base (and M0) -- an SGPR written by a VALU instruction (v_readfirstlane_b32) needs five
+    wait states before a vector-memory instruction may read it, and the compiler pads nothing inside the inline asm of the LDS-DMA
+    helpers (ipa_split.hip carries `s_nop 4` for that reason; the EdgeTransition helpers say their bases are SALU results).  That
+    claim is checked against the disassembly of the BUILT library: in every kernel, no v_readfirstlane_b32 within the five
+    instructions in front of a global_load_lds may write an SGPR that instruction reads (its base pair, or the source of the s_mov
+    to M0 in between) -- unless at least five wait states of s_nop lie between them."""
+    import importlib.util
+    import re
+    import subprocess
+    import tempfile
+    spec = importlib.util.spec_from_file_location("kernel_isa_pin", os.path.join(ROOT, "tools", "kernel_isa_pin.py"))
+    pin_tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin_tool)
+    if not pin_tool.tools_present() or not os.path.exists(pin_tool.LIB):
+        pytest.skip("llvm-objcopy / clang-offload-bundler / llvm-objdump or the built library not here")
+
+    def sregs(tok):
+        m = re.match(r"s\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"s(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    bad, dma = [], 0
+    with tempfile.TemporaryDirectory() as wd:
+        for co in pin_tool.device_code_objects(pin_tool.LIB, wd):
+            txt = subprocess.run([os.path.join(pin_tool.LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--no-leading-addr", co],
+                                 capture_output=True, text=True, check=True).stdout
+            cur, win = None, []
+            for line in txt.split("\n"):
+                m = re.match(r"^[0-9a-f]* ?<(.+)>:$", line.strip())
+                if m:
+                    cur, win = m.group(1), []
+                    continue
+                t = [x.rstrip(",") for x in line.split("//")[0].split()]
+                if not t:
+                    continue
+                if t[0].startswith("global_load_lds") or (t[0].startswith("buffer_load") and "lds" in t):
+                    dma += 1
+                    need = set()
+                    for tok in t[1:]:
+                        need |= sregs(tok)
+                    states = 0
+                    for prev in reversed(win[-8:]):
+                        if prev[0] == "s_mov_b32" and prev[1] == "m0":
+                            need |= sregs(prev[2])
+                        if prev[0] == "v_readfirstlane_b32" and sregs(prev[1]) & need and states < 5:
+                            bad.append((cur, " ".join(prev), " ".join(t), states))
+                        states += int(prev[1]) + 1 if prev[0] == "s_nop" else 1
+                        if states >= 5:
+                            break
+                win.append(t)
+    assert dma > 500, dma
+    assert not bad, (len(bad), bad[:5])
+    print(f"{dma} LDS-DMA instructions, none reads an SGPR inside the wait states of the v_readfirstlane that wrote it")
+
+
 def test_length_bucket_plan_and_sub_batches():
     """Host logic of pepflowww_amd/buckets.py (no GPU): the plan partitions the samples by padded length at the given edges, buckets
     carry their own padded length, a batch on one side of the limit stays whole; sub-batches / sub-noise are PaddingCollate-style
