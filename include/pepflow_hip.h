@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 58
+#define PF_ABI_VERSION 59
 #define PF_ATT_VROWS 164             /* rows of a head's transposed value block: 128 channels + 12 points x 3 */
 /* att_vt (f16 mode, ABI 53): a head's transposed values [PF_ATT_VROWS rows][keys] in the FRAGMENT ORDER of the score kernel's second
  * product -- block (tile n, 32-key step) = 512 f16 = the eight operand slots of each of its 64 lanes: row c sits in tile n = c & 7 as
@@ -422,6 +422,12 @@ typedef struct {
      * matching K order of the z operand (pepflowww_amd.engine.pack_et_stream32(..., z_frag=True)); pepflowww_amd.engine.z_to_frag /
      * z_from_frag convert a tensor.  Not with tile_list-skipped layouts other than whole tiles (the list is per tile anyway). */
     int z_in_frag, z_out_frag;
+    /* optional (ABI 59; fp32-parity mode with z_in_frag / z_out_frag and bias_out, 32 <= L <= 4096): the same 256 KiB of weights in the
+     * execution order of the hand-scheduled kernel (csrc/edge_transition_v5.hip: one 512-register wave per SIMD, every fragment
+     * feeding 64 pairs, GEMM2 K-outer) -- pepflowww_amd.engine.pack_et_stream64(..., z_frag=True).  When set and the call has that
+     * form, that kernel runs; any other form of call falls through to w_stream32 / w_stream as before.  Same inputs, outputs and
+     * work-list semantics; results differ from the 32x32 kernel's only by the summation order inside the fp32 accumulators. */
+    const void* w_stream64;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);
 int pf_edge_transition_tile_rows(int single_pass);   /* rows i per tile of the persistent kernel (8; 16 in the f16 mode) */

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PF_LIB_PATH: another build of the same library -- same-box A/B runs of kernel variants, tools/dev)
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "lib", "libpepflow_hip.so")
-ABI_VERSION = 58
+ABI_VERSION = 59
 
 _fp = C.c_void_p
 _i = C.c_int
@@ -66,7 +66,7 @@ class EdgeTransitionArgs(C.Structure):
                 ("ln_g", _fp), ("ln_b", _fp), ("mask", _fp), ("B", _i), ("L", _i), ("w_stream", _fp),
                 ("bias_out", _fp), ("wb_frags", _fp), ("bb", _fp), ("dump_h1", _fp), ("dump_h2", _fp), ("dump_y", _fp),
                 ("single_pass", _i), ("tile_list", _fp), ("n_tiles", _fp), ("z_in_f16", _i), ("z_out_f16", _i), ("dz_out", _fp), ("dz_out_f16", _i),
-                ("w_stream32", _fp), ("wb_frags32", _fp), ("dump_m1", _fp), ("dump_m2", _fp), ("z_in_frag", _i), ("z_out_frag", _i)]
+                ("w_stream32", _fp), ("wb_frags32", _fp), ("dump_m1", _fp), ("dump_m2", _fp), ("z_in_frag", _i), ("z_out_frag", _i), ("w_stream64", _fp)]
 
 
 class SamplerArgs(C.Structure):

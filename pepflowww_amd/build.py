@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpepflow_hip.so")
-SOURCES = ["selftest.hip", "linear.hip", "edge_transition.hip", "edge_transition_v3.hip", "edge_transition_v4.hip", "ipa_attn.hip", "ipa_split.hip", "node_ops.hip", "flow_step.hip", "encode.hip", "node_track.hip", "train_fwd.hip", "backward.hip", "ipa_bwd.hip", "et_bwd.hip", "full_atom.hip"]
+SOURCES = ["selftest.hip", "linear.hip", "edge_transition.hip", "edge_transition_v3.hip", "edge_transition_v4.hip", "edge_transition_v5.hip", "ipa_attn.hip", "ipa_split.hip", "node_ops.hip", "flow_step.hip", "encode.hip", "node_track.hip", "train_fwd.hip", "backward.hip", "ipa_bwd.hip", "et_bwd.hip", "full_atom.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize, every file: hipcc's SLP vectoriser pairs independent scalar fp32 operations into packed ones (v_pk_mul_f32 /
 # v_pk_add_f32, with op_sel where the halves cross).  Round 5 traced EVERY run-to-run failure of the projecting score kernels to one such
@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # does (the hand-written v_pk_fma_f32 / v_pk_add_f32 of the score and pair phases, no op_sel, stay).  Cost: within run-to-run noise on
 # cfg2 - cfg4, +1.8 % at cfg5 (same box).  It was already set for the EdgeTransition kernels, there for speed.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize"]
-EXTRA_FLAGS = {"edge_transition_v4.hip": ["-Wno-inline-asm"]}
+EXTRA_FLAGS = {"edge_transition_v4.hip": ["-Wno-inline-asm"], "edge_transition_v5.hip": ["-Wno-inline-asm"]}
 
 
 def _stale(target, deps):
@@ -31,7 +31,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]
     hdrs += [os.path.join(HERE, "..", "include", "pepflow_hip.h"), __file__]
     objs = []
     procs = []

@@ -1,0 +1,901 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled EdgeTransition instruction stream ("v5", csrc/edge_transition_v5.hip).
+
+Why a generator: the fp32-parity EdgeTransition (ipa_pytorch.py:233-248 + ga.py:118) is 792 `v_mfma_f32_32x32x16_f16` per wave and 16 x 16
+tile; what bounded the compiler-scheduled kernel (edge_transition_v4.hip, NOTES 3.2) was not the matrix pipe but the serial non-matrix
+work of its in-order waves and the 2 KiB of LDS fragment reads per three MFMAs.  The form that cuts both -- ONE wave per SIMD with
+512 registers, every weight fragment feeding 64 pairs, accumulators in AGPRs -- is out of hipcc's reach (it shuttles values between the
+two halves of the register file: 848 us).  So the whole kernel body is written as ONE assembly block with hand-assigned registers,
+and this script is the hand: it lays the 128 stream entries out as a fixed MFMA sequence and places every other instruction (fragment
+reads, the hi | lo re-splits, accumulator seeds, LDS-DMA pieces, stage barriers, the next tile's prefetch) into the issue slots
+between two MFMAs with an earliest-deadline list scheduler, then computes every `s_waitcnt` from the issue order.
+
+Geometry: workgroup = 4 waves (one per SIMD), persistent over 16 x 16 tiles; wave w owns rows 4w .. 4w+3 as two 32-pair groups t
+(rows 4w + 2t + rl, rl = (lane >> 4) & 1, column jl = lane & 15, K group g = lane >> 5).
+Loop order (differs from v4): GEMM2 runs K-OUTER -- h1 is produced one 32-feature chunk at a time and consumed at once by all six
+output tiles of GEMM2, whose 6 x 2 accumulators (192 registers) live in AGPRs together with the final layer's (64): 256 AGPRs.  VGPRs
+hold only what VALU instructions touch.
+Stream order (pepflowww_amd.engine.pack_et_stream64 packs the weights in it):
+  E0-3 W1z tile 0 | E4-7 W1z tile 1 | E8-19 W2[:, K-chunk 0] | for c = 2..5: W1z tile c (4), W2[:, K-chunk c-1] (12) |
+  E84-91 Wf[:, :64] (K-step x tile) | E92-103 W2[:, K-chunk 5] | E104-127 Wf on h2: chunk c (6) x K-step (2) x tile (2).
+
+  python pepflowww_amd/csrc/gen_et5.py            # rewrites csrc/edge_transition_v5_body.inc
+  python pepflowww_amd/csrc/gen_et5.py --check    # exit 1 when the committed file differs from what the script generates
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "edge_transition_v5_body.inc")
+
+# ------------------------------------------------------------------ LDS map (bytes)
+STAGE_B = 32768
+NSLOT = 3
+RING = 0
+ROWS_AD = RING + NSLOT * STAGE_B          # 16 rows i: [a 768 B | d 256 B], stride 1040
+ROWS_CE = ROWS_AD + 16 * 1040             # 16 columns j: [c 768 B | e 256 B]
+MASK = ROWS_CE + 16 * 1040                # mask_i (lanes 0..15 of a 256-byte piece) | mask_j (second piece)
+CS = MASK + 512                           # ln_g 64 | ln_b 64 | b2 192 | b_b 8 (+ pad) floats
+WB = CS + 336 * 4                         # 4 entries of the [linear_b; down_z] tile (hi 1 KiB | lo 1 KiB)
+LDS_BYTES = WB + 8192
+assert LDS_BYTES <= 160 * 1024 and CS % 16 == 0 and WB % 16 == 0
+
+# ------------------------------------------------------------------ kernarg layout (struct Et5Args, edge_transition_v5.hip)
+KA = dict(w_stream=0, z_in=8, z_out=16, pre=24, mask=32, ln_g=40, ln_b=48, b2=56, bb=64, wb_frags=72, bias_out=80, dz_out=88,
+          tile_list=96, n_tiles=104, dbg=112, L=120, NB=124, per=128, magic_per=132, magic_nb=136, ntiles=140, nwg=144)
+
+# ------------------------------------------------------------------ registers
+def vr(lo, n=1):
+    return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
+
+
+def ar(lo, n=1):
+    return f"a{lo}" if n == 1 else f"a[{lo}:{lo + n - 1}]"
+
+
+def sr(lo, n=1):
+    return f"s{lo}" if n == 1 else f"s[{lo}:{lo + n - 1}]"
+
+
+Z0 = 0                                     # Z[0..71]: operands at Z[8k .. 8k+7] (hi 4 | lo 4), raw fp32 at Z[8 + 8k ..]
+ACC1 = 72                                  # [buf 2][t 2][16]
+H1 = 136                                   # [buf 2][t 2][s 2][hi 4 | lo 4]
+WREG = 200                                 # [3][hi 4 | lo 4]
+V_L16, V_WADDR = 224, 225
+V_ZOFF = 226                               # 4: l16 + w * 16384 + j * 4096
+V_DMA = 230                                # 2: l16 + w * 8192 (+ 4096)
+V_ROWAD, V_ROWCE, V_RL4 = 232, 233, 234              # V_RL4: LDS address of mask_i of this lane's row of group 0
+V_ADADDR = 235                             # 2 (t)
+V_CEADDR, V_CSADDR = 237, 238
+V_BIASOFF = 239                            # 2 (t)
+V_DZOFF = 241                              # 2 (t)
+V_MK = 243                                 # 2 (t)
+V_TMP = 245
+TQ = 246                                   # 8: two temporary quads
+LAST_V = 253                               # v254, v255 are left to the compiler (the kernel's inputs arrive there)
+
+
+def acc1(buf, t):
+    return ACC1 + 32 * buf + 16 * t
+
+
+def h1(buf, t, s):
+    return H1 + 32 * buf + 16 * t + 8 * s
+
+
+def h2(buf, t, s):                          # three buffers in the tail: ACC1[0], ACC1[1], H1[0]
+    base = (ACC1, ACC1 + 32, H1)[buf]
+    return base + 16 * t + 8 * s
+
+
+def zk(t, ks):
+    return 2 * ks + t                        # conversion order of the z octets: K-step major (octet k is written over the raw input of octet k - 1)
+
+
+def zop(t, ks):
+    return Z0 + 8 * zk(t, ks)
+
+
+def a2(mt, t):
+    return 32 * mt + 16 * t
+
+
+def m3(mt, t):
+    return 192 + 32 * mt + 16 * t
+
+
+S = dict(KA=16, WG=18, NWG=19, w_stream=20, z_in=22, z_out=24, pre=26, mask=28, ln_g=30, ln_b=32, b2=34, bb=36, wb_frags=38,
+         bias_out=40, dz_out=42, tile_list=44, n_tiles=46, dbg=48, L=50, NB=51, per=52, magic_per=53, magic_nb=54, ntiles=55,
+         wave=56, nwork=57, tile=58, ntile=59, b=60, i0=61, j0=62, nb=63, ni0=64, nj0=65, slot_rd=66, slot_wr=67, wp=68, woff=70,
+         m1=71, zin_next=72, zout=74, bias=76, hs=78, zmask=79, dz=80, t0=82, t1=83, t2=84, t3=85, t4=86, t5=87, w8192=88, w4=89,
+         ex=90, rowad=92, rowce=94, cid=96, nid=97)            # s[16:97] are this kernel's
+
+
+def sg(name, n=1):
+    return sr(S[name], n)
+
+
+# ------------------------------------------------------------------ instruction records
+class Ins:
+    __slots__ = ("text", "kind", "lds_tag", "vm_tag", "need_lds", "need_vm", "counted", "w")
+
+    def __init__(self, text, kind="valu", lds_tag=None, vm_tag=None, need_lds=(), need_vm=(), counted=True, w=1.0):
+        self.text, self.kind, self.lds_tag, self.vm_tag = text, kind, lds_tag, vm_tag
+        self.need_lds, self.need_vm, self.counted, self.w = tuple(need_lds), tuple(need_vm), counted, w
+
+
+def valu(text, need_lds=(), need_vm=()):
+    return Ins(text, "valu", need_lds=need_lds, need_vm=need_vm)
+
+
+def salu(text):
+    return Ins(text, "salu", w=0.5)
+
+
+def lds(text, tag, need_lds=(), need_vm=()):
+    return Ins(text, "lds", lds_tag=tag, need_lds=need_lds, need_vm=need_vm)
+
+
+def vmem(text, tag=None, counted=True, need_lds=(), need_vm=()):
+    return Ins(text, "vmem", vm_tag=tag or "_", counted=counted, need_lds=need_lds, need_vm=need_vm)
+
+
+def raw(text):
+    return Ins(text, "raw", w=0.0)
+
+
+# ------------------------------------------------------------------ the stream entries
+def entries():
+    ent = []
+    g1 = lambda c: [dict(kind="G1", c=c, ks=ks) for ks in range(4)]
+    g2 = lambda c: [dict(kind="G2", c=c, mt=mt, s=s) for mt in range(6) for s in range(2)]
+    ent += g1(0) + g1(1) + g2(0)
+    for c in range(2, 6):
+        ent += g1(c) + g2(c - 1)
+    ent += [dict(kind="WFZ", ks=ks, mt=mt) for ks in range(4) for mt in range(2)]
+    ent += g2(5)
+    ent += [dict(kind="G3", c=c, s=s, mt=mt) for c in range(6) for s in range(2) for mt in range(2)]
+    assert len(ent) == 128
+    return ent
+
+
+ENT = entries()
+
+
+def first_entry(pred):
+    return next(e for e, d in enumerate(ENT) if pred(d))
+
+
+def last_entry(pred):
+    return max(e for e, d in enumerate(ENT) if pred(d))
+
+
+def mi(e, j=0):
+    return 6 * e + j                        # index of MFMA j of entry e
+
+
+# ------------------------------------------------------------------ building blocks
+def split8(src, dst, relu, need_lds=(), need_vm=()):
+    """8 fp32 values in v[src .. src+7] -> operand planes hi v[dst .. dst+3] | lo v[dst+4 .. dst+7] (lo = f16(x - hi), exact difference).
+    relu: signed-integer max with 0 on the bit pattern first (in place)."""
+    out = []
+    if relu:
+        for k in range(8):
+            out.append(valu(f"v_max_i32 {vr(src + k)}, 0, {vr(src + k)}", need_lds if k == 0 else (), need_vm if k == 0 else ()))
+        need_lds = need_vm = ()
+    for k in range(4):
+        out.append(valu(f"v_cvt_pk_f16_f32 {vr(dst + k)}, {vr(src + 2 * k)}, {vr(src + 2 * k + 1)}", need_lds if k == 0 else (), need_vm if k == 0 else ()))
+    for k in range(4):
+        out.append(valu(f"v_fma_mixlo_f16 {vr(dst + 4 + k)}, {vr(dst + k)}, {sg('m1')}, {vr(src + 2 * k)} op_sel_hi:[1,0,0]"))
+    for k in range(4):
+        out.append(valu(f"v_fma_mixhi_f16 {vr(dst + 4 + k)}, {vr(dst + k)}, {sg('m1')}, {vr(src + 2 * k + 1)} op_sel:[1,0,0] op_sel_hi:[1,0,0]"))
+    return out
+
+
+def zsplit(t, ks, need_vm=()):
+    k = zk(t, ks)
+    return split8(Z0 + 8 + 8 * k, Z0 + 8 * k, False, need_vm=need_vm)
+
+
+def seeds(c):
+    """GEMM1's accumulators of chunk c start from a_i + c_j (b1 folded into c): a rows straight into the accumulator registers,
+    c through the two temporary quads (shared by both groups: same column)."""
+    buf = c & 1
+    out = []
+    for t in range(2):
+        for b in range(4):
+            out.append(lds(f"ds_read_b128 {vr(acc1(buf, t) + 4 * b, 4)}, {vr(V_ADADDR + t)} offset:{(32 * c + 8 * b) * 4}", f"sa{c}{t}{b}"))
+    rd = lambda b: lds(f"ds_read_b128 {vr(TQ + 4 * (b & 1), 4)}, {vr(V_CEADDR)} offset:{(32 * c + 8 * b) * 4}", f"sc{c}{b}")
+    out += [rd(0), rd(1)]
+    for b in range(4):
+        q = TQ + 4 * (b & 1)
+        for t in range(2):
+            for k in range(4):
+                r = acc1(buf, t) + 4 * b + k
+                out.append(valu(f"v_add_f32 {vr(r)}, {vr(r)}, {vr(q + k)}", need_lds=(f"sc{c}{b}", f"sa{c}{t}{b}") if k == 0 else ()))
+        if b + 2 < 4:
+            out.append(rd(b + 2))               # (behind the adds that read this quad: in-order issue)
+    return out
+
+
+def split_acc1(c):
+    buf = c & 1
+    out = []
+    for t in range(2):
+        for s in range(2):
+            out += split8(acc1(buf, t) + 8 * s, h1(buf, t, s), True)
+    return out
+
+
+class Sched:
+    """MFMA sequence + chains of filler instructions.  A filler has an earliest gap (`after`: gap g = the slot behind MFMA g, -1 = in
+    front of the first) and a deadline (`before`: it must sit in front of MFMA `before`); the items of one chain keep their order."""
+
+    def __init__(self, cap=4.0):
+        self.mf, self.chains, self.cap, self.prio = [], {}, cap, {}
+
+    def mfma(self, ins):
+        self.mf.append(ins)
+        return len(self.mf) - 1
+
+    def fill(self, chain, items, after=-1, before=None, prio=1):
+        if isinstance(items, Ins):
+            items = [items]
+        ch = self.chains.setdefault(chain, [])
+        self.prio.setdefault(chain, prio)
+        for it in items:
+            ch.append([it, after, before if before is not None else 10 ** 9])
+
+    def run(self):
+        n = len(self.mf)
+        for ch in self.chains.values():      # effective deadlines: an item must not starve the items behind it
+            dl = 10 ** 9
+            for rec in reversed(ch):
+                dl = min(dl, rec[2])
+                rec[2] = dl
+        heads = {k: 0 for k in self.chains}
+        out, stats = [], []
+        for g in range(-1, n):
+            if g >= 0:
+                out.append(self.mf[g])
+            load = 0.0
+            while True:
+                best = None
+                for name, ch in self.chains.items():
+                    i = heads[name]
+                    if i >= len(ch):
+                        continue
+                    it, after, before = ch[i]
+                    if after > g:
+                        continue
+                    key = (before, self.prio[name], name)
+                    if best is None or key < best[0]:
+                        best = (key, name, it, before)
+                if best is None:
+                    break
+                _, name, it, before = best
+                if before <= g:
+                    raise RuntimeError(f"chain {name}: deadline {before} missed at gap {g}: {it.text}")
+                forced = before <= g + 1
+                if not forced and load + it.w > self.cap:
+                    break
+                out.append(it)
+                load += it.w
+                heads[name] += 1
+            stats.append(load)
+        for name, ch in self.chains.items():
+            assert heads[name] == len(ch), (name, heads[name], len(ch))
+        return out, stats
+
+
+# ------------------------------------------------------------------ LDS-DMA issue
+def dma_stage(st):
+    """This wave's 8 pieces (contiguous 8 KiB) of tile-relative ring stage st into the slot s_slot_wr."""
+    out = [salu(f"s_add_i32 {sg('woff')}, {sg('woff')}, 0x{STAGE_B:x}"),
+           salu(f"s_and_b32 {sg('woff')}, {sg('woff')}, 0x3ffff"),
+           salu(f"s_add_u32 {sg('wp')}, {sg('w_stream')}, {sg('woff')}"),
+           salu(f"s_addc_u32 {sr(S['wp'] + 1)}, {sr(S['w_stream'] + 1)}, 0"),
+           salu(f"s_add_i32 m0, {sg('slot_wr')}, {sg('w8192')}"),
+           salu("s_nop 0")]
+    for k in range(4):
+        out.append(vmem(f"global_load_lds_dwordx4 {vr(V_DMA)}, {sg('wp', 2)} offset:{k * 1024}", f"stg{st}"))
+    out += [salu("s_add_i32 m0, m0, 0x1000"), salu("s_nop 0")]
+    for k in range(4):
+        out.append(vmem(f"global_load_lds_dwordx4 {vr(V_DMA + 1)}, {sg('wp', 2)} offset:{k * 1024}", f"stg{st}"))
+    return out
+
+
+def dma_rows():
+    """This wave's share of the NEXT tile's per-residue rows (rows 4w .. 4w+3 of a|d and of c|e) and both mask pieces."""
+    out = []
+    for which, base, voff in (("rowad", ROWS_AD, V_ROWAD), ("rowce", ROWS_CE, V_ROWCE)):
+        # s_t0:t1 = source of this wave's first row; LDS address = base + (4 w + u) * 1040
+        out += [salu(f"s_mul_i32 {sg('t2')}, {sg('w4')}, 1040"),
+                salu(f"s_add_i32 {sg('t2')}, {sg('t2')}, 0x{base:x}"),
+                salu(f"s_lshl_b32 {sg('t3')}, {sg('w4')}, 11"),
+                salu(f"s_add_u32 {sg('t0')}, {sg(which)}, {sg('t3')}"),
+                salu(f"s_addc_u32 {sg('t1')}, {sr(S[which] + 1)}, 0")]
+        for u in range(4):
+            out += [salu(f"s_mov_b32 m0, {sg('t2')}"), salu("s_nop 0"),
+                    vmem(f"global_load_lds_dwordx4 {vr(voff)}, {sg('t0', 2)}", "rows")]
+            if u < 3:
+                out += [salu(f"s_add_i32 {sg('t2')}, {sg('t2')}, 1040"),
+                        salu(f"s_add_u32 {sg('t0')}, {sg('t0')}, 0x800"),
+                        salu(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0")]
+    # masks: piece A = mask[nb L + ni0 + (lane & 15)] -> MASK, piece B = mask[nb L + nj0 + (lane & 15)] -> MASK + 256 (every wave: same bytes)
+    out += [valu(f"v_bfe_u32 {vr(V_TMP)}, {vr(V_L16)}, 4, 4"),
+            valu(f"v_lshlrev_b32 {vr(V_TMP)}, 2, {vr(V_TMP)}"),
+            salu(f"s_mul_i32 {sg('t2')}, {sg('nb')}, {sg('L')}"),
+            salu(f"s_add_i32 {sg('t3')}, {sg('t2')}, {sg('ni0')}"),
+            salu(f"s_lshl_b32 {sg('t3')}, {sg('t3')}, 2"),
+            salu(f"s_add_u32 {sg('t0')}, {sg('mask')}, {sg('t3')}"),
+            salu(f"s_addc_u32 {sg('t1')}, {sr(S['mask'] + 1)}, 0"),
+            salu(f"s_mov_b32 m0, 0x{MASK:x}"), salu("s_nop 0"),
+            vmem(f"global_load_lds_dword {vr(V_TMP)}, {sg('t0', 2)}", "rows"),
+            salu(f"s_add_i32 {sg('t3')}, {sg('t2')}, {sg('nj0')}"),
+            salu(f"s_lshl_b32 {sg('t3')}, {sg('t3')}, 2"),
+            salu(f"s_add_u32 {sg('t0')}, {sg('mask')}, {sg('t3')}"),
+            salu(f"s_addc_u32 {sg('t1')}, {sr(S['mask'] + 1)}, 0"),
+            salu(f"s_mov_b32 m0, 0x{MASK + 256:x}"), salu("s_nop 0"),
+            vmem(f"global_load_lds_dword {vr(V_TMP)}, {sg('t0', 2)}", "rows")]
+    return out
+
+
+def z_loads():
+    zl = []
+    for t in range(2):
+        for k in range(8):
+            p = 8 * t + k                      # 1 KiB piece p of the wave's 16 KiB: offset p * 1024 = j * 4096 + imm
+            zl.append(vmem(f"global_load_dwordx4 {vr(Z0 + 8 + 8 * zk(t, k // 2) + 4 * (k & 1), 4)}, {vr(V_ZOFF + p // 4)}, {sg('zin_next', 2)} offset:{(p % 4) * 1024}", "zraw"))
+    return zl
+
+
+# ------------------------------------------------------------------ the tile body
+def mfma_text(dst, a, b, acc_is_agpr):
+    d = ar(dst, 16) if acc_is_agpr else vr(dst, 16)
+    return f"v_mfma_f32_32x32x16_f16 {d}, {vr(a, 4)}, {vr(b, 4)}, {d}"
+
+
+def tile_head():
+    """In front of the first MFMA (exposed): the masks of this lane's pairs, the z operands of K-step 0, GEMM1's first seeds."""
+    it = [valu(f"v_bfe_u32 {vr(V_TMP)}, {vr(V_L16)}, 4, 4"),
+          valu(f"v_lshlrev_b32 {vr(V_TMP)}, 2, {vr(V_TMP)}"),
+          valu(f"v_add_u32 {vr(V_TMP)}, 0x{MASK + 256:x}, {vr(V_TMP)}"),
+          lds(f"ds_read_b32 {vr(TQ)}, {vr(V_TMP)}", "mkj"),
+          lds(f"ds_read_b32 {vr(TQ + 1)}, {vr(V_RL4)}", "mki0"),
+          lds(f"ds_read_b32 {vr(TQ + 2)}, {vr(V_RL4)} offset:8", "mki1")]
+    it += zsplit(0, 0, need_vm=("zraw",)) + zsplit(1, 0)
+    it += [valu(f"v_mul_f32 {vr(V_MK)}, {vr(TQ)}, {vr(TQ + 1)}", need_lds=("mkj", "mki0")),
+           valu(f"v_mul_f32 {vr(V_MK + 1)}, {vr(TQ)}, {vr(TQ + 2)}", need_lds=("mki1",)),
+           valu(f"v_cmp_neq_f32 {sg('ex', 2)}, 1.0, {vr(V_MK)}"),
+           valu(f"v_cmp_neq_f32 vcc, 1.0, {vr(V_MK + 1)}"),
+           raw("s_nop 1"),
+           raw(f"s_or_b64 {sg('ex', 2)}, {sg('ex', 2)}, vcc"),
+           raw(f"s_cmp_lg_u64 {sg('ex', 2)}, 0"),
+           raw(f"s_cselect_b32 {sg('zmask')}, 1, 0")]
+    it += seeds(0)
+    return it
+
+
+def build_stream():
+    sc = Sched()
+    # ---- MFMAs, entry by entry: per entry t0 / t1 alternating over the three products w.h x.l, w.h x.h, w.l x.h
+    for e, d in enumerate(ENT):
+        w = WREG + 8 * (e % 3)
+        for j in range(6):
+            t, prod = j & 1, j >> 1
+            if d["kind"] == "G1":
+                acc, ag, x = acc1(d["c"] & 1, t), False, zop(t, d["ks"])
+            elif d["kind"] == "G2":
+                acc, ag, x = a2(d["mt"], t), True, h1(d["c"] & 1, t, d["s"])
+            elif d["kind"] == "WFZ":
+                acc, ag, x = m3(d["mt"], t), True, zop(t, d["ks"])
+            else:
+                acc, ag, x = m3(d["mt"], t), True, h2(d["c"] % 3, t, d["s"])
+            a = w + (4 if prod == 2 else 0)
+            b = x + (4 if prod == 0 else 0)
+            need = (f"W{e}h",) if j == 0 else ((f"W{e}l",) if j == 4 else ())
+            sc.mfma(Ins(mfma_text(acc, a, b, ag), "mfma", need_lds=need, w=0.0))
+
+    # ---- chain HEAD: forced in front of MFMA 0
+    sc.fill("HEAD", tile_head(), after=-1, before=0, prio=1)
+
+    # ---- chain W: fragment reads (up to 2 entries ahead, three register sets) and the stage barriers, in stream order
+    def wreads(e):
+        w = WREG + 8 * (e % 3)
+        es = e % 16
+        return [lds(f"ds_read_b128 {vr(w, 4)}, {vr(V_WADDR)} offset:{es * 2048}", f"W{e}h"),
+                lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(V_WADDR)} offset:{es * 2048 + 1024}", f"W{e}l")]
+
+    for e in range(128):
+        sc.fill("W", wreads(e), after=mi(e - 3, 5) if e >= 3 else -1, before=mi(e), prio=0)
+        if e % 16 == 15:
+            # B(st), in the gap in front of the LAST entry of stage st (its fragments are requested just above): every wave has confirmed
+            # its own pieces of stage st + 1 and holds everything it will read of stage st in registers; behind the barrier stage st + 1
+            # is complete for everybody and the slot of stage st takes stage st + 3
+            st = e // 16
+            g = mi(e) - 1
+            blk = [Ins("", "wait_vm", need_vm=(f"stg{(st + 1) % 8}",), w=0.0),
+                   Ins("s_waitcnt lgkmcnt(0)", "wait_lds_all", w=0.0),
+                   Ins("s_barrier", "raw", w=0.0),
+                   salu(f"s_mov_b32 {sg('slot_wr')}, {sg('slot_rd')}"),
+                   salu(f"s_add_i32 {sg('slot_rd')}, {sg('slot_rd')}, 0x{STAGE_B:x}"),
+                   salu(f"s_cmp_eq_u32 {sg('slot_rd')}, 0x{NSLOT * STAGE_B:x}"),
+                   salu(f"s_cselect_b32 {sg('slot_rd')}, 0, {sg('slot_rd')}"),
+                   valu(f"v_add_u32 {vr(V_WADDR)}, {sg('slot_rd')}, {vr(V_L16)}")]
+            sc.fill("W", blk, after=g, before=g + 1, prio=0)
+            d_items = dma_stage((st + 3) % 8)
+            if st == 4:
+                d_items = d_items + dma_rows()     # every wave is past the last reader of the rows (seeds of chunk 5, the m3 seeds)
+            sc.fill("D", d_items, after=g, before=g + 1 + 36)
+
+    # ---- chain ZS: the z operands of K-steps 1..3 (K-step 0 is converted in the head)
+    for ks in range(1, 4):
+        for t in range(2):                     # (octet order: zk(t, ks) ascending)
+            sc.fill("ZS", zsplit(t, ks), after=-1, before=mi(first_entry(lambda d: d["kind"] == "G1" and d["ks"] == ks)))
+
+    # ---- chain A2S: GEMM2's accumulators start from b2 (LDS -> AGPR, no VALU)
+    for mt in range(6):
+        first = first_entry(lambda d: d["kind"] == "G2" and d["mt"] == mt)
+        for t in range(2):
+            for b in range(4):
+                sc.fill("A2S", lds(f"ds_read_b128 {ar(a2(mt, t) + 4 * b, 4)}, {vr(V_CSADDR)} offset:{(128 + 32 * mt + 8 * b) * 4}", f"a2s{mt}{t}{b}"),
+                        after=-1, before=mi(first))
+            m = sc.mf[mi(first, t)]
+            m.need_lds = m.need_lds + tuple(f"a2s{mt}{t}{b}" for b in range(4))
+
+    # ---- chain ACT: seeds of GEMM1's accumulators, re-splits, the drain of GEMM2's accumulators (one chain: they share registers)
+    g1_last = lambda c: mi(last_entry(lambda d: d["kind"] == "G1" and d["c"] == c), 5)
+    g1_first = lambda c: mi(first_entry(lambda d: d["kind"] == "G1" and d["c"] == c))
+    g2_first = lambda c: mi(first_entry(lambda d: d["kind"] == "G2" and d["c"] == c))
+    g3_first = lambda c: mi(first_entry(lambda d: d["kind"] == "G3" and d["c"] == c))
+    g3_last = lambda c: mi(last_entry(lambda d: d["kind"] == "G3" and d["c"] == c), 5)
+    wfz_first = mi(first_entry(lambda d: d["kind"] == "WFZ"))
+    wfz_last = mi(last_entry(lambda d: d["kind"] == "WFZ"), 5)
+    sc.fill("ACT", seeds(1), after=-1, before=g1_first(1))
+    for c in range(6):
+        sc.fill("ACT", split_acc1(c), after=g1_last(c) + 2, before=g2_first(c))
+        if c + 2 < 6:
+            sc.fill("ACT", seeds(c + 2), after=g1_last(c) + 2, before=g1_first(c + 2))
+    # drain: a2[c'] -> ReLU -> h2 chunk c' (three buffers); temporaries: the two quads of TQ as one octet, and Z[0..7]
+    unit = 0
+    for c in range(6):
+        ready = mi(last_entry(lambda d: d["kind"] == "G2" and d["c"] == 5 and d["mt"] == c), 5) + 2
+        after = max(ready, wfz_last + 1, g3_last(c - 3) + 1 if c >= 3 else -1)
+        for t in range(2):
+            for s in range(2):
+                tmp = (TQ, Z0)[unit & 1]
+                unit += 1
+                items = [valu(f"v_accvgpr_read_b32 {vr(tmp + k)}, {ar(a2(c, t) + 8 * s + k)}") for k in range(8)]
+                items += split8(tmp, h2(c % 3, t, s), True)
+                sc.fill("ACT", items, after=after, before=g3_first(c))
+
+    # ---- chain M3: the final layer's accumulators start from d_i + e_j (bf folded into e); temporaries Z[64..71]
+    for mt in range(2):
+        for t in range(2):
+            for b in range(4):
+                qa, qb = Z0 + 64, Z0 + 68
+                tg = f"m3{mt}{t}{b}"
+                items = [lds(f"ds_read_b128 {vr(qa, 4)}, {vr(V_ADADDR + t)} offset:{768 + (32 * mt + 8 * b) * 4}", tg + "d"),
+                         lds(f"ds_read_b128 {vr(qb, 4)}, {vr(V_CEADDR)} offset:{768 + (32 * mt + 8 * b) * 4}", tg + "e")]
+                for k in range(4):
+                    items.append(valu(f"v_add_f32 {vr(qa + k)}, {vr(qa + k)}, {vr(qb + k)}", need_lds=(tg + "d", tg + "e") if k == 0 else ()))
+                for k in range(4):
+                    items.append(valu(f"v_accvgpr_write_b32 {ar(m3(mt, t) + 4 * b + k)}, {vr(qa + k)}"))
+                sc.fill("M3", items, after=mi(3, 5), before=mi(64), prio=2)      # (behind the last z conversion: Z[64..71] is its raw input)
+
+    # ---- chain VM: the next tile's z behind the last MFMA that reads this tile's
+    sc.fill("VM", z_loads(), after=wfz_last + 1, before=wfz_last + 1 + 72, prio=2)
+    return sc
+
+
+# ------------------------------------------------------------------ straight-line parts (plain text: waits written by hand)
+def kernel_setup():
+    L = []
+    a = L.append
+    a("; ---- inputs: %0 = kernarg segment, %1 = workgroup id, %2 = thread id")
+    a(f"s_mov_b64 {sg('KA', 2)}, %0")
+    a(f"s_mov_b32 {sg('WG')}, %1")
+    a(f"v_mov_b32 {vr(V_TMP)}, %2")
+    a(f"s_load_dwordx16 {sr(S['w_stream'], 16)}, {sg('KA', 2)}, 0x0")
+    a(f"s_load_dwordx8 {sr(S['bb'], 8)}, {sg('KA', 2)}, 0x40")
+    a(f"s_load_dwordx8 {sr(S['tile_list'], 8)}, {sg('KA', 2)}, 0x60")
+    a(f"s_load_dwordx4 {sr(S['per'], 4)}, {sg('KA', 2)}, 0x80")
+    a(f"s_load_dword {sg('NWG')}, {sg('KA', 2)}, 0x90")
+    a("s_waitcnt lgkmcnt(0)")
+    # nwork = n_tiles ? min(*n_tiles, ntiles) : ntiles
+    a(f"s_mov_b32 {sg('nwork')}, {sg('ntiles')}")
+    a(f"s_cmp_eq_u64 {sg('n_tiles', 2)}, 0")
+    a("s_cbranch_scc1 .Lv5_nolist%=")
+    a(f"s_load_dword {sg('t0')}, {sg('n_tiles', 2)}, 0x0")
+    a("s_waitcnt lgkmcnt(0)")
+    a(f"s_min_i32 {sg('nwork')}, {sg('t0')}, {sg('ntiles')}")
+    a(".Lv5_nolist%=:")
+    a(f"s_cmp_ge_i32 {sg('WG')}, {sg('nwork')}")
+    a("s_cbranch_scc1 .Lv5_end%=")
+    # lane-level constants (TQ .. TQ+7 are scratch here)
+    a(f"v_lshrrev_b32 {vr(TQ)}, 6, {vr(V_TMP)}")
+    a("s_nop 0")
+    a(f"v_readfirstlane_b32 {sg('wave')}, {vr(TQ)}")
+    a(f"v_and_b32 {vr(V_TMP)}, 63, {vr(V_TMP)}")                             # lane
+    a(f"v_lshlrev_b32 {vr(V_L16)}, 4, {vr(V_TMP)}")
+    a(f"s_mov_b32 {sg('m1')}, 0xbf800000")
+    a("s_nop 2")
+    a(f"s_lshl_b32 {sg('w8192')}, {sg('wave')}, 13")
+    a(f"s_lshl_b32 {sg('w4')}, {sg('wave')}, 2")
+    a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, 14")
+    a(f"v_add_u32 {vr(V_ZOFF)}, {sg('t0')}, {vr(V_L16)}")
+    for j in range(1, 4):
+        a(f"v_add_u32 {vr(V_ZOFF + j)}, 0x{4096 * j:x}, {vr(V_ZOFF)}")
+    a(f"v_add_u32 {vr(V_DMA)}, {sg('w8192')}, {vr(V_L16)}")
+    a(f"v_add_u32 {vr(V_DMA + 1)}, 0x1000, {vr(V_DMA)}")
+    # row-piece source offsets: a|d = bytes 0..767 | 1536..1791 of a pre row, c|e = 768..1535 | 1792..2047
+    a(f"v_add_u32 {vr(TQ + 1)}, 0x300, {vr(V_L16)}")
+    a(f"v_add_u32 {vr(TQ + 2)}, 0x400, {vr(V_L16)}")
+    a(f"v_cmp_gt_u32 vcc, 0x300, {vr(V_L16)}")
+    a("s_nop 1")
+    a(f"v_cndmask_b32 {vr(V_ROWAD)}, {vr(TQ + 1)}, {vr(V_L16)}, vcc")
+    a(f"v_cndmask_b32 {vr(V_ROWCE)}, {vr(TQ + 2)}, {vr(TQ + 1)}, vcc")
+    # jl = lane & 15, rl = (lane >> 4) & 1, g = lane >> 5
+    a(f"v_and_b32 {vr(TQ)}, 15, {vr(V_TMP)}")                                # jl
+    a(f"v_bfe_u32 {vr(TQ + 1)}, {vr(V_TMP)}, 4, 1")                          # rl
+    a(f"v_lshrrev_b32 {vr(TQ + 2)}, 5, {vr(V_TMP)}")                         # g
+    a(f"v_lshlrev_b32 {vr(TQ + 3)}, 4, {vr(TQ + 2)}")                        # 16 g
+    a(f"v_mov_b32 {vr(TQ + 7)}, 0x{1040:x}")
+    for t in range(2):                                                       # a|d row address: ROWS_AD + (4 w + 2 t + rl) * 1040 + 16 g
+        a(f"s_add_i32 {sg('t0')}, {sg('w4')}, {2 * t}")
+        a(f"v_add_u32 {vr(TQ + 4)}, {sg('t0')}, {vr(TQ + 1)}")
+        a(f"v_mul_u32_u24 {vr(TQ + 4)}, {vr(TQ + 4)}, {vr(TQ + 7)}")
+        a(f"v_add_u32 {vr(TQ + 4)}, {vr(TQ + 4)}, {vr(TQ + 3)}")
+        a(f"v_add_u32 {vr(V_ADADDR + t)}, 0x{ROWS_AD:x}, {vr(TQ + 4)}")
+    a(f"v_mul_u32_u24 {vr(TQ + 4)}, {vr(TQ)}, {vr(TQ + 7)}")
+    a(f"v_add_u32 {vr(TQ + 4)}, {vr(TQ + 4)}, {vr(TQ + 3)}")
+    a(f"v_add_u32 {vr(V_CEADDR)}, 0x{ROWS_CE:x}, {vr(TQ + 4)}")
+    a(f"v_add_u32 {vr(V_CSADDR)}, 0x{CS:x}, {vr(TQ + 3)}")
+    # mask_i of group 0's row: MASK + (4 w + rl) * 4  (group 1: + 8)
+    a(f"v_add_u32 {vr(TQ + 4)}, {sg('w4')}, {vr(TQ + 1)}")
+    a(f"v_lshlrev_b32 {vr(TQ + 4)}, 2, {vr(TQ + 4)}")
+    a(f"v_add_u32 {vr(V_RL4)}, 0x{MASK:x}, {vr(TQ + 4)}")
+    # output offsets (constant over the tiles): bias [B,8,L,L]: ((4 g L + row) L + jl) * 4; dz [B,L,L,16]: (row L + jl) * 64 + 16 g
+    a(f"v_lshlrev_b32 {vr(TQ + 5)}, 2, {vr(TQ + 2)}")                        # 4 g
+    a(f"v_mul_lo_u32 {vr(TQ + 5)}, {vr(TQ + 5)}, {sg('L')}")                 # 4 g L
+    for t in range(2):
+        a(f"s_add_i32 {sg('t0')}, {sg('w4')}, {2 * t}")
+        a(f"v_add_u32 {vr(TQ + 4)}, {sg('t0')}, {vr(TQ + 1)}")               # row
+        a(f"v_add_u32 {vr(TQ + 6)}, {vr(TQ + 5)}, {vr(TQ + 4)}")
+        a(f"v_mul_lo_u32 {vr(TQ + 6)}, {vr(TQ + 6)}, {sg('L')}")
+        a(f"v_add_lshl_u32 {vr(V_BIASOFF + t)}, {vr(TQ + 6)}, {vr(TQ)}, 2")
+        a(f"v_mul_lo_u32 {vr(TQ + 6)}, {vr(TQ + 4)}, {sg('L')}")
+        a(f"v_add_lshl_u32 {vr(TQ + 6)}, {vr(TQ + 6)}, {vr(TQ)}, 6")
+        a(f"v_add_u32 {vr(V_DZOFF + t)}, {vr(TQ + 6)}, {vr(TQ + 3)}")
+    a(f"s_mul_i32 {sg('hs')}, {sg('L')}, {sg('L')}")
+    a(f"s_lshl_b32 {sg('hs')}, {sg('hs')}, 2")
+    # constants into LDS: wave 0: ln_g, ln_b; waves 0..2: b2; wave 3 lanes 0..7: b_b
+    a(f"v_lshlrev_b32 {vr(TQ + 4)}, 2, {vr(V_TMP)}")                         # lane * 4
+    a(f"v_add_u32 {vr(TQ + 3)}, 0x{CS:x}, {vr(TQ + 4)}")                     # CS + lane * 4
+    a(f"s_cmp_lg_u32 {sg('wave')}, 0")
+    a("s_cbranch_scc1 .Lv5_c1%=")
+    a(f"global_load_dword {vr(TQ + 5)}, {vr(TQ + 4)}, {sg('ln_g', 2)}")
+    a(f"global_load_dword {vr(TQ + 6)}, {vr(TQ + 4)}, {sg('ln_b', 2)}")
+    a("s_waitcnt vmcnt(0)")
+    a(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 5)}")
+    a(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 6)} offset:256")
+    a(".Lv5_c1%=:")
+    a(f"s_cmp_eq_u32 {sg('wave')}, 3")
+    a("s_cbranch_scc1 .Lv5_c2%=")
+    a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, 8")
+    a(f"v_add_u32 {vr(TQ + 7)}, {sg('t0')}, {vr(TQ + 4)}")                   # (64 wave + lane) * 4
+    a(f"global_load_dword {vr(TQ + 5)}, {vr(TQ + 7)}, {sg('b2', 2)}")
+    a("s_waitcnt vmcnt(0)")
+    a(f"v_add_u32 {vr(TQ + 2)}, {sg('t0')}, {vr(TQ + 3)}")
+    a(f"ds_write_b32 {vr(TQ + 2)}, {vr(TQ + 5)} offset:512")
+    a("s_branch .Lv5_c3%=")
+    a(".Lv5_c2%=:")
+    a(f"s_mov_b64 {sg('ex', 2)}, exec")
+    a("s_mov_b64 exec, 0xff")
+    a(f"global_load_dword {vr(TQ + 5)}, {vr(TQ + 4)}, {sg('bb', 2)}")
+    a("s_waitcnt vmcnt(0)")
+    a(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 5)} offset:1280")
+    a(f"s_mov_b64 exec, {sg('ex', 2)}")
+    a(".Lv5_c3%=:")
+    # the [linear_b; down_z] tile: 8 KiB, two pieces per wave
+    a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, 11")
+    a(f"s_add_i32 m0, {sg('t0')}, 0x{WB:x}")
+    a(f"v_add_u32 {vr(TQ + 7)}, {sg('t0')}, {vr(V_L16)}")
+    a("s_nop 0")
+    a(f"global_load_lds_dwordx4 {vr(TQ + 7)}, {sg('wb_frags', 2)}")
+    a(f"global_load_lds_dwordx4 {vr(TQ + 7)}, {sg('wb_frags', 2)} offset:1024")
+    return L
+
+
+def decode_tile(idx, tid, b, i0, j0, lab):
+    """SALU: index `idx` of the work (through the work list when there is one) -> tile id `tid`, sample b, first row i0, first column j0."""
+    L = []
+    a = L.append
+    a(f"s_mov_b32 {sg(tid)}, {sg(idx)}")
+    a(f"s_cmp_eq_u64 {sg('tile_list', 2)}, 0")
+    a(f"s_cbranch_scc1 .Lv5_{lab}%=")
+    a(f"s_lshl_b32 {sg('t4')}, {sg(idx)}, 2")
+    a(f"s_load_dword {sg(tid)}, {sg('tile_list', 2)}, {sg('t4')}")
+    a("s_waitcnt lgkmcnt(0)")
+    a(f".Lv5_{lab}%=:")
+    a(f"s_mul_hi_u32 {sg(b)}, {sg(tid)}, {sg('magic_per')}")
+    a(f"s_mul_i32 {sg('t4')}, {sg(b)}, {sg('per')}")
+    a(f"s_sub_i32 {sg('t4')}, {sg(tid)}, {sg('t4')}")                        # rem
+    a(f"s_mul_hi_u32 {sg(i0)}, {sg('t4')}, {sg('magic_nb')}")                # ib
+    a(f"s_mul_i32 {sg(j0)}, {sg(i0)}, {sg('NB')}")
+    a(f"s_sub_i32 {sg(j0)}, {sg('t4')}, {sg(j0)}")                           # jb
+    a(f"s_lshl_b32 {sg(i0)}, {sg(i0)}, 4")
+    a(f"s_lshl_b32 {sg(j0)}, {sg(j0)}, 4")
+    return L
+
+
+def next_tile_addresses():
+    """From (nid, nb, ni0, nj0): the z block and the row bases of the NEXT tile (what the stream's prefetches read)."""
+    L = []
+    a = L.append
+    a(f"s_lshr_b32 {sg('t1')}, {sg('nid')}, 16")
+    a(f"s_lshl_b32 {sg('t0')}, {sg('nid')}, 16")
+    a(f"s_add_u32 {sg('zin_next')}, {sg('z_in')}, {sg('t0')}")
+    a(f"s_addc_u32 {sr(S['zin_next'] + 1)}, {sr(S['z_in'] + 1)}, {sg('t1')}")
+    a(f"s_mul_i32 {sg('t2')}, {sg('nb')}, {sg('L')}")
+    for which, x0 in (("rowad", "ni0"), ("rowce", "nj0")):
+        a(f"s_add_i32 {sg('t3')}, {sg('t2')}, {sg(x0)}")
+        a(f"s_lshr_b32 {sg('t1')}, {sg('t3')}, 21")
+        a(f"s_lshl_b32 {sg('t0')}, {sg('t3')}, 11")
+        a(f"s_add_u32 {sg(which)}, {sg('pre')}, {sg('t0')}")
+        a(f"s_addc_u32 {sr(S[which] + 1)}, {sr(S['pre'] + 1)}, {sg('t1')}")
+    return L
+
+
+def cur_tile_addresses():
+    """Output bases of the CURRENT tile from (cid, b, i0, j0)."""
+    L = []
+    a = L.append
+    a(f"s_lshr_b32 {sg('t1')}, {sg('cid')}, 16")
+    a(f"s_lshl_b32 {sg('t0')}, {sg('cid')}, 16")
+    a(f"s_add_u32 {sg('zout')}, {sg('z_out')}, {sg('t0')}")
+    a(f"s_addc_u32 {sr(S['zout'] + 1)}, {sr(S['z_out'] + 1)}, {sg('t1')}")
+    # bias: (b 8 L L + i0 L + j0) * 4 bytes  (hs = L L 4)
+    a(f"s_lshl_b32 {sg('t2')}, {sg('b')}, 3")
+    a(f"s_mul_hi_u32 {sg('t1')}, {sg('t2')}, {sg('hs')}")
+    a(f"s_mul_i32 {sg('t0')}, {sg('t2')}, {sg('hs')}")
+    a(f"s_mul_i32 {sg('t3')}, {sg('i0')}, {sg('L')}")
+    a(f"s_add_i32 {sg('t3')}, {sg('t3')}, {sg('j0')}")
+    a(f"s_lshl_b32 {sg('t3')}, {sg('t3')}, 2")
+    a(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('t3')}")
+    a(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0")
+    a(f"s_add_u32 {sg('bias')}, {sg('bias_out')}, {sg('t0')}")
+    a(f"s_addc_u32 {sr(S['bias'] + 1)}, {sr(S['bias_out'] + 1)}, {sg('t1')}")
+    # dz: ((b L + i0) L + j0) * 64 bytes
+    a(f"s_mul_i32 {sg('t2')}, {sg('b')}, {sg('L')}")
+    a(f"s_add_i32 {sg('t2')}, {sg('t2')}, {sg('i0')}")
+    a(f"s_mul_hi_u32 {sg('t1')}, {sg('t2')}, {sg('L')}")
+    a(f"s_mul_i32 {sg('t0')}, {sg('t2')}, {sg('L')}")
+    a(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('j0')}")
+    a(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0")
+    a(f"s_lshl_b64 {sg('t0', 2)}, {sg('t0', 2)}, 6")
+    a(f"s_add_u32 {sg('dz')}, {sg('dz_out')}, {sg('t0')}")
+    a(f"s_addc_u32 {sr(S['dz'] + 1)}, {sr(S['dz_out'] + 1)}, {sg('t1')}")
+    return L
+
+
+def prologue_loads():
+    """First tile: its rows / masks / z (the 'next tile' machinery pointed at it) and ring stages 0, 1, 2; everything waited for."""
+    L = [it.text for it in dma_rows()]
+    L += [it.text for it in z_loads()]
+    L.append(f"s_mov_b32 {sg('woff')}, 0x{(8 - 1) * STAGE_B:x}")                # dma_stage pre-increments (and wraps): first issue = offset 0
+    for st in range(3):
+        L.append(f"s_mov_b32 {sg('slot_wr')}, 0x{st * STAGE_B:x}")
+        L += [it.text for it in dma_stage(st)]
+    L.append(f"s_mov_b32 {sg('slot_rd')}, 0")
+    L.append(f"v_mov_b32 {vr(V_WADDR)}, {vr(V_L16)}")
+    L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    L.append("s_barrier")
+    return L
+
+
+def epilogue():
+    """LayerNorm over the 64 features of a pair (32 in this lane, 32 in lane ^ 32), edge mask, z' store, the next block's pair bias and
+    pair values from z' in registers (ipa_pytorch.py:391,440).  Straight-line per 32-pair group."""
+    L = []
+    Y = H1                                    # 32 registers: y, then y - mean, then z'
+    X = H1 + 32                               # 32 registers: z' as operand planes, 4 K-steps x (hi 4 | lo 4)
+    BM = ACC1                                 # 16: the [linear_b; down_z] tile
+    G = ACC1 + 32                             # 32: gamma | beta quads
+    a = L.append
+    for t in range(2):
+        for mt in range(2):
+            for r in range(16):
+                a(valu(f"v_accvgpr_read_b32 {vr(Y + 16 * mt + r)}, {ar(m3(mt, t) + r)}"))
+        s1, s2 = V_TMP, TQ
+        a(valu(f"v_add_f32 {vr(s1)}, {vr(Y)}, {vr(Y + 1)}"))
+        for r in range(2, 32):
+            a(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(Y + r)}"))
+        a(valu(f"v_mov_b32 {vr(s2)}, {vr(s1)}"))
+        a(raw("s_nop 1"))
+        a(valu(f"v_permlane32_swap_b32 {vr(s1)}, {vr(s2)}"))
+        a(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(s2)}"))
+        a(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))                 # mean
+        a(valu(f"v_sub_f32 {vr(Y)}, {vr(Y)}, {vr(s1)}"))
+        a(valu(f"v_mul_f32 {vr(s2)}, {vr(Y)}, {vr(Y)}"))
+        for r in range(1, 32):
+            a(valu(f"v_sub_f32 {vr(Y + r)}, {vr(Y + r)}, {vr(s1)}"))
+            a(valu(f"v_fmac_f32 {vr(s2)}, {vr(Y + r)}, {vr(Y + r)}"))
+        a(valu(f"v_mov_b32 {vr(s1)}, {vr(s2)}"))
+        a(raw("s_nop 1"))
+        a(valu(f"v_permlane32_swap_b32 {vr(s2)}, {vr(s1)}"))
+        a(valu(f"v_add_f32 {vr(s1)}, {vr(s2)}, {vr(s1)}"))
+        a(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))
+        a(valu(f"v_add_f32 {vr(s1)}, 0x3727c5ac, {vr(s1)}"))                 # + 1e-5
+        a(valu(f"v_rsq_f32 {vr(s1)}, {vr(s1)}"))
+        a(raw("s_nop 0"))
+        # z' = (y - mean) * rstd * gamma + beta; gamma / beta of this lane's features 32 mt + 8 b + 4 g + e, 16 features at a time
+        for mt in range(2):
+            for b in range(4):
+                a(lds(f"ds_read_b128 {vr(G + 8 * b, 4)}, {vr(V_CSADDR)} offset:{(32 * mt + 8 * b) * 4}", f"gm{t}{mt}{b}"))
+                a(lds(f"ds_read_b128 {vr(G + 8 * b + 4, 4)}, {vr(V_CSADDR)} offset:{(64 + 32 * mt + 8 * b) * 4}", f"bt{t}{mt}{b}"))
+            for b in range(4):
+                for k in range(4):
+                    r = Y + 16 * mt + 4 * b + k
+                    a(valu(f"v_mul_f32 {vr(r)}, {vr(r)}, {vr(s1)}"))
+                    a(valu(f"v_fma_f32 {vr(r)}, {vr(r)}, {vr(G + 8 * b + k)}, {vr(G + 8 * b + 4 + k)}", need_lds=(f"gm{t}{mt}{b}", f"bt{t}{mt}{b}") if k == 0 else ()))
+        # edge mask (ga.py:118): skipped for a wave whose 64 pairs are all unmasked (x * 1 is x)
+        a(raw(f"s_cmp_eq_u32 {sg('zmask')}, 0"))
+        a(raw(f"s_cbranch_scc1 .Lv5_nomask{t}%="))
+        for r in range(32):
+            a(valu(f"v_mul_f32 {vr(Y + r)}, {vr(Y + r)}, {vr(V_MK + t)}"))
+        a(raw(f".Lv5_nomask{t}%=:"))
+        # z' in fragment order: piece 4 mt + b of block (tile, 2 w + t): byte (8 t + p) * 1024 of the wave's 16 KiB = j * 4096 + imm
+        a(raw(f"s_cmp_eq_u64 {sg('z_out', 2)}, 0"))
+        a(raw(f"s_cbranch_scc1 .Lv5_nozout{t}%="))
+        for mt in range(2):
+            for b in range(4):
+                p = 8 * t + 4 * mt + b
+                a(vmem(f"global_store_dwordx4 {vr(V_ZOFF + p // 4)}, {vr(Y + 16 * mt + 4 * b, 4)}, {sg('zout', 2)} offset:{(p % 4) * 1024}", counted=False))
+        a(raw(f".Lv5_nozout{t}%=:"))
+        # operand planes of z' (no ReLU): K-step (mt, s2) = registers 16 mt + 8 s2 .. + 7
+        for mt in range(2):
+            for s2 in range(2):
+                L.extend(split8(Y + 16 * mt + 8 * s2, X + 8 * (2 * mt + s2), False))
+        # [linear_b; down_z] tile: 4 entries x 3 products, accumulator from 0
+        a(valu(f"v_add_u32 {vr(TQ + 1)}, 0x{WB:x}, {vr(V_L16)}"))
+        wbuf = lambda q: WREG + 8 * q if q < 3 else G + 8      # four fragment pairs in flight: the stream's three sets + a gamma / beta octet
+        for q in range(4):
+            w = wbuf(q)
+            a(lds(f"ds_read_b128 {vr(w, 4)}, {vr(TQ + 1)} offset:{q * 2048}", f"wb{t}{q}h"))
+            a(lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(TQ + 1)} offset:{q * 2048 + 1024}", f"wb{t}{q}l"))
+        for q in range(4):
+            w = wbuf(q)
+            x = X + 8 * q
+            c0 = "0" if q == 0 else vr(BM, 16)
+            a(Ins(f"v_mfma_f32_32x32x16_f16 {vr(BM, 16)}, {vr(w, 4)}, {vr(x + 4, 4)}, {c0}", "mfma", need_lds=(f"wb{t}{q}h",)))
+            a(Ins(f"v_mfma_f32_32x32x16_f16 {vr(BM, 16)}, {vr(w, 4)}, {vr(x, 4)}, {vr(BM, 16)}", "mfma"))
+            a(Ins(f"v_mfma_f32_32x32x16_f16 {vr(BM, 16)}, {vr(w + 4, 4)}, {vr(x, 4)}, {vr(BM, 16)}", "mfma", need_lds=(f"wb{t}{q}l",)))
+        a(lds(f"ds_read_b128 {vr(G, 4)}, {vr(V_CSADDR)} offset:{320 * 4}", f"bb{t}"))
+        a(raw("s_nop 7"))
+        a(raw("s_nop 7"))
+        for k in range(4):
+            a(valu(f"v_add_f32 {vr(BM + k)}, {vr(BM + k)}, {vr(G + k)}", need_lds=(f"bb{t}",) if k == 0 else ()))
+            a(valu(f"v_mul_f32 {vr(BM + k)}, 0x3f13cd3a, {vr(BM + k)}"))     # sqrt(1/3), ipa_pytorch.py:404
+        # pair bias [B,8,L,L]: heads 4 g + e, e = 0..3, one plane (hs bytes) apart
+        a(raw(f"s_mov_b64 {sg('t0', 2)}, {sg('bias', 2)}"))
+        for k in range(4):
+            a(vmem(f"global_store_dword {vr(V_BIASOFF + t)}, {vr(BM + k)}, {sg('t0', 2)}"))
+            if k < 3:
+                a(raw(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('hs')}"))
+                a(raw(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0"))
+        a(raw(f"s_cmp_eq_u64 {sg('dz_out', 2)}, 0"))
+        a(raw(f"s_cbranch_scc1 .Lv5_nodz{t}%="))
+        a(vmem(f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 4, 4)}, {sg('dz', 2)}", counted=False))
+        a(vmem(f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 8, 4)}, {sg('dz', 2)} offset:32", counted=False))
+        a(raw(f".Lv5_nodz{t}%=:"))
+    return L
+
+
+# ------------------------------------------------------------------ s_waitcnt from the issue order
+def finalize(body):
+    """Two passes over the loop body (the second sees what the first left in flight); returns the text of the second pass.  LDS
+    operations and vector memory operations complete in issue order (AMDGPUUsage, memory model GFX6-GFX9: completion is reported
+    to a wavefront in execution order), so "operation k has completed" = at most (number of operations issued behind k) outstanding.
+    Conditional stores (counted = False) are left out of that number: the wait is then stricter than needed when they were issued."""
+    lds_seq, vm_seq = 0, 0
+    lds_tag, vm_tag = {}, {}
+    lds_done, vm_done = -1, -1
+    out = []
+    for rep in range(2):
+        out = []
+        for it in body:
+            if it.kind == "wait_lds_all":
+                lds_done = lds_seq - 1
+                out.append("s_waitcnt lgkmcnt(0)")
+                continue
+            nl = max([lds_tag[t] for t in it.need_lds if t in lds_tag], default=-1)
+            nv = max([vm_tag[t] for t in it.need_vm if t in vm_tag], default=-1)
+            parts = []
+            if nv > vm_done:
+                n = min(vm_seq - 1 - nv, 63)
+                assert n >= 0
+                parts.append(f"vmcnt({n})")
+                vm_done = vm_seq - 1 - n
+            if nl > lds_done:
+                n = min(lds_seq - 1 - nl, 15)
+                assert n >= 0
+                parts.append(f"lgkmcnt({n})")
+                lds_done = lds_seq - 1 - n
+            if parts:
+                out.append("s_waitcnt " + " ".join(parts))
+            if it.kind == "wait_vm":
+                continue
+            if it.text:
+                out.append(it.text)
+            if it.kind == "lds":
+                assert rep == 1 or it.lds_tag not in lds_tag, it.lds_tag
+                lds_tag[it.lds_tag] = lds_seq
+                lds_seq += 1
+            elif it.kind == "vmem" and it.counted:
+                vm_tag[it.vm_tag] = vm_seq
+                vm_seq += 1
+    return out
+
+
+def generate(stats_out=None):
+    sc = build_stream()
+    stream, stats = sc.run()
+    if stats_out is not None:
+        stats_out.extend(stats)
+    body = stream + epilogue()
+    lines = []
+    lines += kernel_setup()
+    lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")
+    lines.append(f"s_mov_b32 {sg('ntile')}, {sg('WG')}")
+    lines += decode_tile("ntile", "nid", "nb", "ni0", "nj0", "dec0")
+    lines += next_tile_addresses()
+    lines += prologue_loads()
+    lines.append(".Lv5_loop%=:")
+    lines.append("; ---- the prefetched tile becomes the current one; pick, decode and address the next")
+    for d, s_ in (("cid", "nid"), ("b", "nb"), ("i0", "ni0"), ("j0", "nj0")):
+        lines.append(f"s_mov_b32 {sg(d)}, {sg(s_)}")
+    lines += cur_tile_addresses()
+    lines.append(f"s_add_i32 {sg('ntile')}, {sg('tile')}, {sg('NWG')}")
+    lines.append(f"s_cmp_lt_i32 {sg('ntile')}, {sg('nwork')}")
+    lines.append(f"s_cselect_b32 {sg('ntile')}, {sg('ntile')}, {sg('tile')}")      # no next tile: prefetch this one again (valid addresses)
+    lines += decode_tile("ntile", "nid", "nb", "ni0", "nj0", "dec1")
+    lines += next_tile_addresses()
+    lines.append("; ---- tile body: head, 768 MFMAs with everything else in their issue slots, epilogue")
+    lines += finalize(body)
+    lines.append(f"s_add_i32 {sg('tile')}, {sg('tile')}, {sg('NWG')}")
+    lines.append(f"s_cmp_lt_i32 {sg('tile')}, {sg('nwork')}")
+    lines.append("s_cbranch_scc1 .Lv5_loop%=")
+    lines.append(".Lv5_end%=:")
+    lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    txt = ["// GENERATED by gen_et5.py -- do not edit; `python pepflowww_amd/csrc/gen_et5.py` rewrites it, tests/test_host_cpu.py checks it is current.",
+           f"// LDS bytes: {LDS_BYTES}"]
+    for ln in lines:
+        txt.append('"' + ln.replace("\\", "\\\\").replace('"', '\\"') + '\\n\\t"')
+    return "\n".join(txt) + "\n"
+
+
+def main():
+    if "--stats" in sys.argv:
+        st = []
+        generate(st)
+        import collections
+        print("fillers per gap (weighted):", dict(sorted(collections.Counter(round(x) for x in st).items())))
+        return 0
+    text = generate()
+    if "--check" in sys.argv:
+        cur = open(OUT).read() if os.path.exists(OUT) else ""
+        if cur != text:
+            print("edge_transition_v5_body.inc is stale: run python pepflowww_amd/csrc/gen_et5.py")
+            return 1
+        print("edge_transition_v5_body.inc is up to date")
+        return 0
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("wrote", OUT, len(text.splitlines()), "lines")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

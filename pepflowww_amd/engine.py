@@ -227,6 +227,60 @@ def pack_et_stream32(w1z, w2, wf, z_frag=False):
     return torch.cat([zp[:32 * 1024], nat[32 * 1024:]]).contiguous()
 
 
+def _pack_et_stream64_ref(w1z_p, w2, wf, wfz_p):
+    """EdgeTransition weights as the 128-entry stream of csrc/edge_transition_v5.hip (gen_et5.py `entries()`), in execution order --
+    GEMM2 K-outer: h1 chunk c (32 features, two K-steps) meets all six 32-feature tiles of W2 as soon as it exists:
+      E0-3 W1z tile 0 | E4-7 W1z tile 1 | E8-19 W2[:, K-chunk 0] as (tile mt, half s) | for c = 2..5: W1z tile c (4), W2[:, K-chunk c-1] (12) |
+      E84-91 Wf[:, :64] as (K-step ks, tile mt) | E92-103 W2[:, K-chunk 5] | E104-127 Wf on h2: (chunk c, half s, tile mt).
+    w1z_p / wfz_p: the z-multiplying matrices with their columns in the fragment-ordered pair tensor's K order (_z_frag_perm).
+    Layout/packing only -- no model arithmetic."""
+    dev = w2.device
+    nat, perm = _k_nat(dev), _k_perm(dev)
+    g1 = lambda c: [_frag32(w1z_p, c, nat(ks)) for ks in range(4)]
+    g2 = lambda c: [_frag32(w2, mt, perm(c, s)) for mt in range(6) for s in range(2)]
+    out = g1(0) + g1(1) + g2(0)
+    for c in range(2, 6):
+        out += g1(c) + g2(c - 1)
+    out += [_frag32(wfz_p, mt, nat(ks)) for ks in range(4) for mt in range(2)]
+    out += g2(5)
+    out += [_frag32(wf, mt, perm(c, s)) for c in range(6) for s in range(2) for mt in range(2)]
+    stream = torch.cat(out).contiguous()
+    assert stream.numel() * 2 == 256 * 1024
+    return stream
+
+
+def pack_et_stream64(w1z, w2, wf):
+    """The hand-scheduled kernel's stream (pf_edge_transition_args.w_stream64; layout: _pack_et_stream64_ref), packed with one cached
+    gather.  Always for a fragment-ordered pair tensor (the only form that kernel takes)."""
+    w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
+    assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
+    for m_, n_ in ((w1z, "trunk.0.weight[:, :64]"), (w2, "trunk.2.weight"), (wf, "final_layer.weight")):
+        check_f16_range(m_, n_)
+    dev = w2.device
+    perm = _z_frag_perm(dev)
+    mats = [w1z[:, perm].contiguous(), w2, wf, wf[:, :64][:, perm].contiguous()]
+    key = (64, str(dev))
+    if key not in _STREAM_IDX:
+        sizes = [m.numel() for m in mats]
+        a = torch.arange(sum(sizes), dtype=torch.float32, device=dev)
+        parts, o = [], 0
+        for m, n in zip(mats, sizes):
+            parts.append(a[o:o + n].view(m.shape))
+            o += n
+        global _INDEX_MODE
+        _INDEX_MODE = True
+        try:
+            st = _pack_et_stream64_ref(*parts)
+        finally:
+            _INDEX_MODE = False
+        _STREAM_IDX[key] = st.view(128, 2, 512)[:, 0, :].to(torch.int64).contiguous()
+    flat = torch.cat([m.reshape(-1) for m in mats])
+    v = flat[_STREAM_IDX[key]]
+    hi = v.to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * ET_LO_SCALE).to(torch.float16)
+    return torch.stack([hi, lo], 1).reshape(-1).contiguous()
+
+
 def z_to_frag(z, out=None):
     """[B,L,L,64] (L % 16 == 0) -> the 32x32 EdgeTransition kernel's fragment order (pf_edge_transition_args.z_in_frag): block (b, 16 x 16
     tile (ib, jb), wave w) of 8 KiB = piece k = 4 mt + q (1 KiB) x lane g * 32 + rl * 16 + jl (16 bytes) = channels 32 mt + 8 q + 4 g ..
@@ -486,6 +540,7 @@ class PackedWeights:
                 t[f"{b}.et.wbfrags"] = pack_bias_frags(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.stream32"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.stream32f"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf, z_frag=True)
+                t[f"{b}.et.stream64f"] = pack_et_stream64(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.wbfrags32"] = pack_bias_frags32(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
@@ -507,7 +562,7 @@ class DenoiseEngine:
     #   fused_proj, fused_pair, et_v4, et_zfrag, k_frag: True / False;  et_last_store: keep the last EdgeTransition's z' store
     #   o_premul: linear_out's o-block folded into the value projection (fold_linear_out_into_values; default on)
     #   k_fold: the key projection folded into the query rows, keys = the node state (fold_keys_into_queries; with fused_proj only; default on)
-    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul", "k_fold")
+    OPTIONS = ("fused_proj", "fused_pair", "et_v4", "et_v5", "et_zfrag", "k_frag", "et_last_store", "o_premul", "k_fold")
     K_FOLD = True             # default of the k_fold option
     O_PREMUL = True           # default of the o_premul option (class attribute: same-box A/B runs of bench.py flip it)
 
@@ -579,6 +634,10 @@ class DenoiseEngine:
         zf_ok = L % 16 == 0 and self.pair_dz is not None and opt.get("et_zfrag", True)
         self.z_frag = zf_ok and ((self.et_v4 and not self.z16) or (self.z16 and not self.et_v4 and self.et_rows == 16))
         self.edge_frag = e(B, L, L, 64, dt=torch.float16 if self.z16 else torch.float32) if self.z_frag else None
+        # round 6: the hand-scheduled EdgeTransition stream (csrc/edge_transition_v5.hip, pf_edge_transition_args.w_stream64): one
+        # 512-register wave per SIMD, every weight fragment feeding 64 pairs.  Takes the calls of the fp32-parity step with the pair
+        # tensor in fragment order; options={'et_v5': False} keeps the 32x32 kernel (A/B runs).
+        self.et_v5 = bool(self.et_v4 and self.z_frag and not self.z16 and 32 <= L <= 4096 and opt.get("et_v5", True))
         self.et_nib, self.et_njb = (L + self.et_rows - 1) // self.et_rows, (L + 15) // 16
         self.et_tiles = e(B * self.et_nib * self.et_njb, dt=torch.int32)
         self.et_ntiles = e(1, dt=torch.int32)
@@ -932,6 +991,8 @@ class DenoiseEngine:
                 et.bias_out, et.wb_frags = self.pair_bias.data_ptr(), w[f"{b}.et.wbfrags"].data_ptr()
                 if self.et_v4:
                     et.w_stream32, et.wb_frags32 = w[f"{b}.et.stream32f" if self.z_frag else f"{b}.et.stream32"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()
+                if self.et_v5:
+                    et.w_stream64 = w[f"{b}.et.stream64f"].data_ptr()
                 et.bb = w[f"{b + 1}.linear_b.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")
