@@ -17,7 +17,7 @@ output tiles of GEMM2, whose 6 x 2 accumulators (192 registers) live in AGPRs to
 hold only what VALU instructions touch.
 Stream order (pepflowww_amd.engine.pack_et_stream64 packs the weights in it):
   E0-3 W1z tile 0 | E4-7 W1z tile 1 | E8-19 W2[:, K-chunk 0] | for c = 2..5: W1z tile c (4), W2[:, K-chunk c-1] (12) |
-  E84-91 Wf[:, :64] (K-step x tile) | E92-103 W2[:, K-chunk 5] | E104-127 Wf on h2: chunk c (6) x K-step (2) x tile (2).
+  E84-95 W2[:, K-chunk 5] | E96-103 Wf[:, :64] (K-step x tile) | E104-127 Wf on h2: chunk c (6) x K-step (2) x tile (2).
 
   python pepflowww_amd/csrc/gen_et5.py            # rewrites csrc/edge_transition_v5_body.inc
   python pepflowww_amd/csrc/gen_et5.py --check    # exit 1 when the committed file differs from what the script generates
@@ -83,8 +83,8 @@ def h1(buf, t, s):
     return H1 + 32 * buf + 16 * t + 8 * s
 
 
-def h2(buf, t, s):                          # three buffers in the tail: ACC1[0], ACC1[1], H1[0]
-    base = (ACC1, ACC1 + 32, H1)[buf]
+def h2(buf, t, s):                          # four buffers in the tail: ACC1[0], ACC1[1], H1[0], H1[1]
+    base = (ACC1, ACC1 + 32, H1, H1 + 32)[buf]
     return base + 16 * t + 8 * s
 
 
@@ -148,12 +148,12 @@ def raw(text):
 def entries():
     ent = []
     g1 = lambda c: [dict(kind="G1", c=c, ks=ks) for ks in range(4)]
-    g2 = lambda c: [dict(kind="G2", c=c, mt=mt, s=s) for mt in range(6) for s in range(2)]
+    g2 = lambda c: [dict(kind="G2", c=c, mt=mt, s=s) for s in range(2) for mt in range(6)] if c < 5 else [dict(kind="G2", c=c, mt=mt, s=s) for mt in range(6) for s in range(2)]
     ent += g1(0) + g1(1) + g2(0)
     for c in range(2, 6):
         ent += g1(c) + g2(c - 1)
-    ent += [dict(kind="WFZ", ks=ks, mt=mt) for ks in range(4) for mt in range(2)]
     ent += g2(5)
+    ent += [dict(kind="WFZ", ks=ks, mt=mt) for ks in range(4) for mt in range(2)]
     ent += [dict(kind="G3", c=c, s=s, mt=mt) for c in range(6) for s in range(2) for mt in range(2)]
     assert len(ent) == 128
     return ent
@@ -175,10 +175,33 @@ def mi(e, j=0):
 
 
 # ------------------------------------------------------------------ building blocks
+MIX = os.environ.get("GEN_ET5_MIX", "0") == "1"      # lo halves by v_fma_mix{lo,hi}_f16 (3.2 - 4.8 cycles each beside MFMAs, tools/dev/filler_bench.py) instead of plain VALU
+
+
 def split8(src, dst, relu, need_lds=(), need_vm=()):
     """8 fp32 values in v[src .. src+7] -> operand planes hi v[dst .. dst+3] | lo v[dst+4 .. dst+7] (lo = f16(x - hi), exact difference).
-    relu: signed-integer max with 0 on the bit pattern first (in place)."""
+    relu: signed-integer max with 0 on the bit pattern first (in place).  The source registers are destroyed.
+    lo without v_fma_mix: hi back to fp32 (v_cvt_f32_f16, the high half through SDWA), x - hi in fp32 (exact: the difference has at
+    most 13 significant bits), one v_cvt_pk_f16_f32 per pair -- the same bits as the single-rounded fma, six plain VALU per pair."""
     out = []
+    if not MIX:
+        if relu:
+            for k in range(8):
+                out.append(valu(f"v_max_i32 {vr(src + k)}, 0, {vr(src + k)}", need_lds if k == 0 else (), need_vm if k == 0 else ()))
+            need_lds = need_vm = ()
+        for k in range(4):
+            out.append(valu(f"v_cvt_pk_f16_f32 {vr(dst + k)}, {vr(src + 2 * k)}, {vr(src + 2 * k + 1)}", need_lds if k == 0 else (), need_vm if k == 0 else ()))
+        for k in range(4):
+            out.append(valu(f"v_cvt_f32_f16 {vr(dst + 4 + k)}, {vr(dst + k)}"))
+        for k in range(4):
+            out.append(valu(f"v_sub_f32 {vr(src + 2 * k)}, {vr(src + 2 * k)}, {vr(dst + 4 + k)}"))
+        for k in range(4):
+            out.append(valu(f"v_cvt_f32_f16_sdwa {vr(dst + 4 + k)}, {vr(dst + k)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"))
+        for k in range(4):
+            out.append(valu(f"v_sub_f32 {vr(src + 2 * k + 1)}, {vr(src + 2 * k + 1)}, {vr(dst + 4 + k)}"))
+        for k in range(4):
+            out.append(valu(f"v_cvt_pk_f16_f32 {vr(dst + 4 + k)}, {vr(src + 2 * k)}, {vr(src + 2 * k + 1)}"))
+        return out
     if relu:
         for k in range(8):
             out.append(valu(f"v_max_i32 {vr(src + k)}, 0, {vr(src + k)}", need_lds if k == 0 else (), need_vm if k == 0 else ()))
@@ -218,12 +241,11 @@ def seeds(c):
     return out
 
 
-def split_acc1(c):
+def split_acc1(c, s):
     buf = c & 1
     out = []
     for t in range(2):
-        for s in range(2):
-            out += split8(acc1(buf, t) + 8 * s, h1(buf, t, s), True)
+        out += split8(acc1(buf, t) + 8 * s, h1(buf, t, s), True)
     return out
 
 
@@ -231,8 +253,8 @@ class Sched:
     """MFMA sequence + chains of filler instructions.  A filler has an earliest gap (`after`: gap g = the slot behind MFMA g, -1 = in
     front of the first) and a deadline (`before`: it must sit in front of MFMA `before`); the items of one chain keep their order."""
 
-    def __init__(self, cap=4.0):
-        self.mf, self.chains, self.cap, self.prio = [], {}, cap, {}
+    def __init__(self, cap=float(os.environ.get("GEN_ET5_CAP", "4.0")), lds_cap=int(os.environ.get("GEN_ET5_LDSCAP", "2"))):
+        self.mf, self.chains, self.cap, self.prio, self.lds_cap, self.cap_fn = [], {}, cap, {}, lds_cap, None
 
     def mfma(self, ins):
         self.mf.append(ins)
@@ -258,9 +280,9 @@ class Sched:
         for g in range(-1, n):
             if g >= 0:
                 out.append(self.mf[g])
-            load = 0.0
+            load, nlds = 0.0, 0
             while True:
-                best = None
+                cands = []
                 for name, ch in self.chains.items():
                     i = heads[name]
                     if i >= len(ch):
@@ -268,19 +290,28 @@ class Sched:
                     it, after, before = ch[i]
                     if after > g:
                         continue
-                    key = (before, self.prio[name], name)
-                    if best is None or key < best[0]:
-                        best = (key, name, it, before)
-                if best is None:
+                    cands.append(((before, self.prio[name], name), name, it, before))
+                cands.sort(key=lambda c: c[0])
+                pick = None
+                for key, name, it, before in cands:
+                    if before <= g:
+                        raise RuntimeError(f"chain {name}: deadline {before} missed at gap {g}: {it.text}")
+                    forced = before <= g + 1
+                    if forced:
+                        pick = (name, it)
+                        break
+                    if load + it.w > (self.cap_fn(g) if self.cap_fn else self.cap):
+                        continue
+                    if it.kind == "lds" and nlds >= self.lds_cap:      # (a ds_read_b128 is 16 cycles of the CU's LDS pipe: 2 per MFMA hide, 4 do not)
+                        continue
+                    pick = (name, it)
                     break
-                _, name, it, before = best
-                if before <= g:
-                    raise RuntimeError(f"chain {name}: deadline {before} missed at gap {g}: {it.text}")
-                forced = before <= g + 1
-                if not forced and load + it.w > self.cap:
+                if pick is None:
                     break
+                name, it = pick
                 out.append(it)
                 load += it.w
+                nlds += it.kind == "lds"
                 heads[name] += 1
             stats.append(load)
         for name, ch in self.chains.items():
@@ -364,7 +395,10 @@ def tile_head():
           lds(f"ds_read_b32 {vr(TQ)}, {vr(V_TMP)}", "mkj"),
           lds(f"ds_read_b32 {vr(TQ + 1)}, {vr(V_RL4)}", "mki0"),
           lds(f"ds_read_b32 {vr(TQ + 2)}, {vr(V_RL4)} offset:8", "mki1")]
+    global MIX
+    keep, MIX = MIX, True                      # exposed code: the form with fewer instructions
     it += zsplit(0, 0, need_vm=("zraw",)) + zsplit(1, 0)
+    MIX = keep
     it += [valu(f"v_mul_f32 {vr(V_MK)}, {vr(TQ)}, {vr(TQ + 1)}", need_lds=("mkj", "mki0")),
            valu(f"v_mul_f32 {vr(V_MK + 1)}, {vr(TQ)}, {vr(TQ + 2)}", need_lds=("mki1",)),
            valu(f"v_cmp_neq_f32 {sg('ex', 2)}, 1.0, {vr(V_MK)}"),
@@ -377,8 +411,18 @@ def tile_head():
     return it
 
 
+PROF = False                                # --prof: s_memtime stamps at phase boundaries (dev builds only, edge_transition_v5_body_prof.inc)
+N_STAMP = 12
+
+
+def stamp(k):
+    return [raw(f"s_memtime {sr(98, 2)}"), Ins("s_waitcnt lgkmcnt(0)", "wait_lds_all", w=0.0), raw(f"s_mov_b32 {sr(4 + k)}, s98")]
+
+
 def build_stream():
     sc = Sched()
+    tail_cap = float(os.environ.get("GEN_ET5_TAILCAP", "5.0"))
+    sc.cap_fn = lambda g: tail_cap if (g >= mi(84) or g < mi(8)) else sc.cap      # the drain phase and the first two chunks carry more than 4 per MFMA
     # ---- MFMAs, entry by entry: per entry t0 / t1 alternating over the three products w.h x.l, w.h x.h, w.l x.h
     for e, d in enumerate(ENT):
         w = WREG + 8 * (e % 3)
@@ -391,7 +435,7 @@ def build_stream():
             elif d["kind"] == "WFZ":
                 acc, ag, x = m3(d["mt"], t), True, zop(t, d["ks"])
             else:
-                acc, ag, x = m3(d["mt"], t), True, h2(d["c"] % 3, t, d["s"])
+                acc, ag, x = m3(d["mt"], t), True, h2(d["c"] % 4, t, d["s"])
             a = w + (4 if prod == 2 else 0)
             b = x + (4 if prod == 0 else 0)
             need = (f"W{e}h",) if j == 0 else ((f"W{e}l",) if j == 4 else ())
@@ -430,9 +474,12 @@ def build_stream():
             sc.fill("D", d_items, after=g, before=g + 1 + 36)
 
     # ---- chain ZS: the z operands of K-steps 1..3 (K-step 0 is converted in the head)
+    global MIX
+    keep, MIX = MIX, os.environ.get("GEN_ET5_ZMIX", "1") == "1"   # 24 instead of 48 instructions per K-step: they have the six gaps of ONE entry
     for ks in range(1, 4):
         for t in range(2):                     # (octet order: zk(t, ks) ascending)
             sc.fill("ZS", zsplit(t, ks), after=-1, before=mi(first_entry(lambda d: d["kind"] == "G1" and d["ks"] == ks)))
+    MIX = keep
 
     # ---- chain A2S: GEMM2's accumulators start from b2 (LDS -> AGPR, no VALU)
     for mt in range(6):
@@ -454,20 +501,21 @@ def build_stream():
     wfz_last = mi(last_entry(lambda d: d["kind"] == "WFZ"), 5)
     sc.fill("ACT", seeds(1), after=-1, before=g1_first(1))
     for c in range(6):
-        sc.fill("ACT", split_acc1(c), after=g1_last(c) + 2, before=g2_first(c))
+        for s_ in range(2):                    # (GEMM2 of chunks 0..4 runs half-major: the second half of h1 is needed six entries later)
+            sc.fill("ACT", split_acc1(c, s_), after=g1_last(c) + 2, before=mi(first_entry(lambda d: d["kind"] == "G2" and d["c"] == c and d["s"] == s_)))
         if c + 2 < 6:
             sc.fill("ACT", seeds(c + 2), after=g1_last(c) + 2, before=g1_first(c + 2))
-    # drain: a2[c'] -> ReLU -> h2 chunk c' (three buffers); temporaries: the two quads of TQ as one octet, and Z[0..7]
-    unit = 0
+    # drain: a2[c'] -> ReLU -> h2 chunk c' (three buffers); temporaries: the two quads of TQ as one octet (in-order issue: the next
+    # unit's reads follow the last instruction that reads this unit's)
     for c in range(6):
         ready = mi(last_entry(lambda d: d["kind"] == "G2" and d["c"] == 5 and d["mt"] == c), 5) + 2
-        after = max(ready, wfz_last + 1, g3_last(c - 3) + 1 if c >= 3 else -1)
+        g2_last5 = mi(last_entry(lambda d: d["kind"] == "G2" and d["c"] == 5), 5)
+        after = max(ready, g2_last5 + 1 if c == 3 else -1, g3_last(c - 4) + 1 if c >= 4 else -1)      # (buffer 3 = h1 chunk 5's registers)
         for t in range(2):
             for s in range(2):
-                tmp = (TQ, Z0)[unit & 1]
-                unit += 1
+                tmp = TQ
                 items = [valu(f"v_accvgpr_read_b32 {vr(tmp + k)}, {ar(a2(c, t) + 8 * s + k)}") for k in range(8)]
-                items += split8(tmp, h2(c % 3, t, s), True)
+                items += split8(tmp, h2(c % 4, t, s), True)
                 sc.fill("ACT", items, after=after, before=g3_first(c))
 
     # ---- chain M3: the final layer's accumulators start from d_i + e_j (bf folded into e); temporaries Z[64..71]
@@ -482,10 +530,17 @@ def build_stream():
                     items.append(valu(f"v_add_f32 {vr(qa + k)}, {vr(qa + k)}, {vr(qb + k)}", need_lds=(tg + "d", tg + "e") if k == 0 else ()))
                 for k in range(4):
                     items.append(valu(f"v_accvgpr_write_b32 {ar(m3(mt, t) + 4 * b + k)}, {vr(qa + k)}"))
-                sc.fill("M3", items, after=mi(3, 5), before=mi(64), prio=2)      # (behind the last z conversion: Z[64..71] is its raw input)
+                sc.fill("M3", items, after=mi(7, 5), before=mi(72), prio=2)      # (behind the last z conversion: Z[64..71] is its raw input; in front of B(4): the rows are refilled behind it)
 
     # ---- chain VM: the next tile's z behind the last MFMA that reads this tile's
     sc.fill("VM", z_loads(), after=wfz_last + 1, before=wfz_last + 1 + 72, prio=2)
+    if PROF:                                   # stamps: 1 = first MFMA, 2 = G2(0), 3 = in front of B(3), 4 = behind it, 5 = WfZ, 6 = G2(5), 7 = G3
+        sc.fill("HEAD", stamp(1), after=-1, before=0)
+        for k, g in ((2, g2_first(0)), (5, wfz_first), (6, g2_first(5)), (7, g3_first(0))):
+            sc.fill(f"P{k}", stamp(k), after=g - 1, before=g, prio=0)
+        gb3 = mi(16 * 3 + 15) - 1
+        sc.fill("P3", stamp(3), after=gb3 - 1, before=gb3, prio=0)
+        sc.fill("P4", stamp(4), after=gb3 + 1, before=gb3 + 2, prio=0)
     return sc
 
 
@@ -844,7 +899,12 @@ def generate(stats_out=None):
     stream, stats = sc.run()
     if stats_out is not None:
         stats_out.extend(stats)
-    body = stream + epilogue()
+    ep = epilogue()
+    if PROF:
+        cut = next(i for i, it in enumerate(ep) if it.kind == "raw" and "nodz0" in it.text and it.text.endswith(":"))
+        ep = stamp(8) + ep[:cut + 1] + stamp(9) + ep[cut + 1:] + stamp(10)
+        stream = stamp(0) + stream
+    body = stream + ep
     lines = []
     lines += kernel_setup()
     lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")
@@ -867,6 +927,13 @@ def generate(stats_out=None):
     lines.append(f"s_add_i32 {sg('tile')}, {sg('tile')}, {sg('NWG')}")
     lines.append(f"s_cmp_lt_i32 {sg('tile')}, {sg('nwork')}")
     lines.append("s_cbranch_scc1 .Lv5_loop%=")
+    if PROF:                                   # lane 0 of every wave: its stamps of the last tile -> dbg[(wg * 4 + wave) * 16 + k]
+        lines += [f"s_cmp_eq_u64 {sg('dbg', 2)}, 0", "s_cbranch_scc1 .Lv5_end%=",
+                  f"s_lshl_b32 {sg('t0')}, {sg('WG')}, 2", f"s_add_i32 {sg('t0')}, {sg('t0')}, {sg('wave')}", f"s_lshl_b32 {sg('t0')}, {sg('t0')}, 6",
+                  f"s_add_u32 {sg('t0')}, {sg('dbg')}, {sg('t0')}", f"s_addc_u32 {sg('t1')}, {sr(S['dbg'] + 1)}, 0",
+                  "s_mov_b64 exec, 1", f"v_mov_b32 {vr(TQ + 1)}, 0"]
+        for k in range(N_STAMP):
+            lines += [f"v_mov_b32 {vr(TQ)}, {sr(4 + k)}", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * k}"]
     lines.append(".Lv5_end%=:")
     lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     txt = ["// GENERATED by gen_et5.py -- do not edit; `python pepflowww_amd/csrc/gen_et5.py` rewrites it, tests/test_host_cpu.py checks it is current.",
@@ -882,6 +949,13 @@ def main():
         generate(st)
         import collections
         print("fillers per gap (weighted):", dict(sorted(collections.Counter(round(x) for x in st).items())))
+        return 0
+    if "--prof" in sys.argv:
+        global PROF
+        PROF = True
+        with open(OUT.replace(".inc", "_prof.inc"), "w") as f:
+            f.write(generate())
+        print("wrote the stamped variant")
         return 0
     text = generate()
     if "--check" in sys.argv:

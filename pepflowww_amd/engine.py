@@ -230,19 +230,19 @@ def pack_et_stream32(w1z, w2, wf, z_frag=False):
 def _pack_et_stream64_ref(w1z_p, w2, wf, wfz_p):
     """EdgeTransition weights as the 128-entry stream of csrc/edge_transition_v5.hip (gen_et5.py `entries()`), in execution order --
     GEMM2 K-outer: h1 chunk c (32 features, two K-steps) meets all six 32-feature tiles of W2 as soon as it exists:
-      E0-3 W1z tile 0 | E4-7 W1z tile 1 | E8-19 W2[:, K-chunk 0] as (tile mt, half s) | for c = 2..5: W1z tile c (4), W2[:, K-chunk c-1] (12) |
-      E84-91 Wf[:, :64] as (K-step ks, tile mt) | E92-103 W2[:, K-chunk 5] | E104-127 Wf on h2: (chunk c, half s, tile mt).
+      E0-3 W1z tile 0 | E4-7 W1z tile 1 | E8-19 W2[:, K-chunk 0] as (half s, tile mt) -- chunk 5 as (tile mt, half s) | for c = 2..5: W1z tile c (4), W2[:, K-chunk c-1] (12) |
+      E84-95 W2[:, K-chunk 5] | E96-103 Wf[:, :64] as (K-step ks, tile mt) | E104-127 Wf on h2: (chunk c, half s, tile mt).
     w1z_p / wfz_p: the z-multiplying matrices with their columns in the fragment-ordered pair tensor's K order (_z_frag_perm).
     Layout/packing only -- no model arithmetic."""
     dev = w2.device
     nat, perm = _k_nat(dev), _k_perm(dev)
     g1 = lambda c: [_frag32(w1z_p, c, nat(ks)) for ks in range(4)]
-    g2 = lambda c: [_frag32(w2, mt, perm(c, s)) for mt in range(6) for s in range(2)]
+    g2 = lambda c: [_frag32(w2, mt, perm(c, s)) for s in range(2) for mt in range(6)] if c < 5 else [_frag32(w2, mt, perm(c, s)) for mt in range(6) for s in range(2)]
     out = g1(0) + g1(1) + g2(0)
     for c in range(2, 6):
         out += g1(c) + g2(c - 1)
-    out += [_frag32(wfz_p, mt, nat(ks)) for ks in range(4) for mt in range(2)]
     out += g2(5)
+    out += [_frag32(wfz_p, mt, nat(ks)) for ks in range(4) for mt in range(2)]
     out += [_frag32(wf, mt, perm(c, s)) for c in range(6) for s in range(2) for mt in range(2)]
     stream = torch.cat(out).contiguous()
     assert stream.numel() * 2 == 256 * 1024

@@ -1,0 +1,38 @@
+# dev-only: phase stamps of the hand-scheduled EdgeTransition (build: python pepflowww_amd/csrc/gen_et5.py --prof &&
+# tools/dev/build_variant.sh prof edge_transition_v5.hip -DPF_ET5_PROF; run: PF_LIB_PATH=pepflowww_amd/lib/variants/libpf_prof.so python tools/dev/et5_prof.py)
+import sys, os, ctypes as C
+sys.path.insert(0, '.')
+import torch
+from pepflowww_amd import _capi
+from pepflowww_amd.engine import pack_et_stream32, pack_et_stream64, pack_bias_frags32
+dev = torch.device('cuda'); lib = _capi.load(); raw = C.CDLL(_capi.LIB_PATH)
+B, L = 64, 128
+g = torch.Generator().manual_seed(0)
+r = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dev)
+z = r(B, L, L, 64); pre = r(B * L, 512)
+w1, w2, wf = r(192, 192) * 0.3, r(192, 192) * 0.3, r(64, 192) * 0.3
+wb, wdz, bb = r(8, 64), r(16, 64), r(8)
+b2, lng, lnb = r(192), 1 + 0.2 * r(64), r(64)
+mask = torch.ones(B * L, device=dev)
+s32 = pack_et_stream32(w1[:, :64], w2, wf, z_frag=True); s64 = pack_et_stream64(w1[:, :64], w2, wf); wbf = pack_bias_frags32(wb, wdz)
+zo = torch.zeros_like(z); bi = torch.zeros(B, 8, L, L, device=dev); dz = torch.zeros(B, L, L, 16, device=dev)
+dbg = torch.zeros(256 * 4 * 16, device=dev, dtype=torch.int32)
+raw.pf_debug_et5_set_dbg(C.c_void_p(dbg.data_ptr()))
+a = _capi.EdgeTransitionArgs()
+a.z_in, a.z_out, a.pre = z.data_ptr(), zo.data_ptr(), pre.data_ptr()
+a.w_stream32, a.wb_frags32, a.w_stream64 = s32.data_ptr(), wbf.data_ptr(), s64.data_ptr()
+a.b2, a.ln_g, a.ln_b, a.mask, a.B, a.L = b2.data_ptr(), lng.data_ptr(), lnb.data_ptr(), mask.data_ptr(), B, L
+a.bias_out, a.bb, a.dz_out = bi.data_ptr(), bb.data_ptr(), dz.data_ptr()
+a.z_in_frag = a.z_out_frag = 1
+for _ in range(3):
+    rc = lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()); assert rc == 0
+torch.cuda.synchronize()
+t = dbg.view(256, 4, 16).cpu().to(torch.int64) & 0xffffffff
+names = ["loop top -> first MFMA (head)", "G1(0), G1(1)", "G2(0) .. B(3)", "B(3): wait + barrier", "B(3) .. WfZ", "WfZ", "G2(5)", "G3", "epilogue group 0", "epilogue group 1"]
+d = [(t[:, :, k + 1] - t[:, :, k]) & 0xffffffff for k in range(0, 10)]
+# stamp order in time: 0 loop top, 1 first MFMA, 2 G2(0), 3 before B(3), 4 after B(3), 5 WfZ, 6 G2(5), 7 G3, 8 end of stream, 9 after group 0, 10 end
+tot = ((t[:, :, 10] - t[:, :, 0]) & 0xffffffff).float()
+print(f"tile: mean {tot.mean():.0f} ticks, min {tot.min():.0f}, max {tot.max():.0f}  (s_memtime ticks = 100 MHz? see ratio below)")
+for k, nm in enumerate(names):
+    x = d[k].float()
+    print(f"{nm:34s} mean {x.mean():8.0f}  per wave {[round(v) for v in x.mean(0).tolist()]}  share {x.mean() / tot.mean():.3f}")
