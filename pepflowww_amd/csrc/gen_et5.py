@@ -31,13 +31,13 @@ OUT = os.path.join(HERE, "edge_transition_v5_body.inc")
 # ------------------------------------------------------------------ LDS map (bytes)
 STAGE_B = 32768
 NSLOT = 3
-RING = 0
+WB = 0                                    # 4 entries of the [linear_b; down_z] tile (hi 1 KiB | lo 1 KiB): read with lane * 16 + an instruction offset
+RING = WB + 8192
 ROWS_AD = RING + NSLOT * STAGE_B          # 16 rows i: [a 768 B | d 256 B], stride 1040
 ROWS_CE = ROWS_AD + 16 * 1040             # 16 columns j: [c 768 B | e 256 B]
 MASK = ROWS_CE + 16 * 1040                # mask_i (lanes 0..15 of a 256-byte piece) | mask_j (second piece)
 CS = MASK + 512                           # ln_g 64 | ln_b 64 | b2 192 | b_b 8 (+ pad) floats
-WB = CS + 336 * 4                         # 4 entries of the [linear_b; down_z] tile (hi 1 KiB | lo 1 KiB)
-LDS_BYTES = WB + 8192
+LDS_BYTES = CS + 336 * 4
 assert LDS_BYTES <= 160 * 1024 and CS % 16 == 0 and WB % 16 == 0
 
 # ------------------------------------------------------------------ kernarg layout (struct Et5Args, edge_transition_v5.hip)
@@ -170,10 +170,6 @@ def last_entry(pred):
     return max(e for e, d in enumerate(ENT) if pred(d))
 
 
-def mi(e, j=0):
-    return 6 * e + j                        # index of MFMA j of entry e
-
-
 # ------------------------------------------------------------------ building blocks
 MIX = os.environ.get("GEN_ET5_MIX", "0") == "1"      # lo halves by v_fma_mix{lo,hi}_f16 (3.2 - 4.8 cycles each beside MFMAs, tools/dev/filler_bench.py) instead of plain VALU
 
@@ -277,6 +273,8 @@ class Sched:
                 rec[2] = dl
         heads = {k: 0 for k in self.chains}
         out, stats = [], []
+        placed = {}                            # LDS tag -> gap its read sits in: a dependent filler keeps LDS_DIST gaps of distance (an
+        dist = int(os.environ.get("GEN_ET5_LDSDIST", "4"))   # s_waitcnt on a read issued a few cycles ago parks the in-order wave, MFMAs included)
         for g in range(-1, n):
             if g >= 0:
                 out.append(self.mf[g])
@@ -290,13 +288,15 @@ class Sched:
                     it, after, before = ch[i]
                     if after > g:
                         continue
+                    if it.kind != "mfma" and it.need_lds and before > g + 1 and g < n - 1 and any(placed.get(tg, -99) + dist > g for tg in it.need_lds):
+                        continue
                     cands.append(((before, self.prio[name], name), name, it, before))
                 cands.sort(key=lambda c: c[0])
                 pick = None
                 for key, name, it, before in cands:
                     if before <= g:
                         raise RuntimeError(f"chain {name}: deadline {before} missed at gap {g}: {it.text}")
-                    forced = before <= g + 1
+                    forced = before <= g + 1 or g == n - 1
                     if forced:
                         pick = (name, it)
                         break
@@ -312,6 +312,8 @@ class Sched:
                 out.append(it)
                 load += it.w
                 nlds += it.kind == "lds"
+                if it.kind == "lds":
+                    placed[it.lds_tag] = g
                 heads[name] += 1
             stats.append(load)
         for name, ch in self.chains.items():
@@ -412,66 +414,219 @@ def tile_head():
 
 
 PROF = False                                # --prof: s_memtime stamps at phase boundaries (dev builds only, edge_transition_v5_body_prof.inc)
-N_STAMP = 12
+N_STAMP = 8
 
 
 def stamp(k):
     return [raw(f"s_memtime {sr(98, 2)}"), Ins("s_waitcnt lgkmcnt(0)", "wait_lds_all", w=0.0), raw(f"s_mov_b32 {sr(4 + k)}, s98")]
 
 
+# ---- MFMA positions.  Entries 0..111: six MFMAs each (t0 / t1 alternating over the three products).  The last 16 entries (the final
+# layer on h2 chunks 2..5 = ring stage 7) run as TWO passes, group 0 then group 1 (their fragments are read twice), so that group 0's
+# LayerNorm / stores / operand split have the 48 MFMAs of pass B to hide under; then the two [linear_b; down_z] tiles.
+N_MAIN, PA0, PB0, BI0, N_MF = 112, 672, 720, 768, 792
+
+
+def mi(e, j=0):
+    assert e < N_MAIN or e < 0, e
+    return 6 * e + j
+
+
+def pa(e, p=0):
+    return PA0 + 3 * (e - N_MAIN) + p
+
+
+def pb(e, p=0):
+    return PB0 + 3 * (e - N_MAIN) + p
+
+
+def bi(t, q, p=0):
+    return BI0 + 12 * t + 3 * q + p
+
+
+def ep_regs(t):
+    """Registers of group t's epilogue: y / z' (2 x 16) in the group's halves of the h1 blocks, the operand planes of z' (4 octets) in the
+    group's halves of GEMM1's accumulator blocks, the [linear_b; down_z] tile over y's first block once z' is stored and split."""
+    Y = [H1 + 32 * mt + 16 * t for mt in range(2)]
+    X = [ACC1 + 32 * (q // 2) + 16 * t + 8 * (q % 2) for q in range(4)]
+    return Y, X, Y[0]
+
+
+def epilogue_items(t, y_ready):
+    """Group t: LayerNorm over the 64 features of a pair (32 here, 32 in lane ^ 32), edge mask, z' store, operand planes of z' for the
+    next block's pair bias / pair values (ipa_pytorch.py:391,440).  Returns (items up to the split, items behind the tile's MFMAs)."""
+    Y, X, BM = ep_regs(t)
+    yr = lambda i: Y[i // 16] + i % 16
+    s1, s2 = V_TMP, Z0                         # per-lane scalars (Z[0..7]: the first z operand octet, dead behind WfZ)
+    a = []
+    for mt in range(2):
+        for r in range(16):
+            a.append(valu(f"v_accvgpr_read_b32 {vr(Y[mt] + r)}, {ar(m3(mt, t) + r)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(yr(0))}, {vr(yr(1))}"))
+    a.append(valu(f"v_add_f32 {vr(s2)}, {vr(yr(2))}, {vr(yr(3))}"))
+    for i in range(4, 32, 2):
+        a.append(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(yr(i))}"))
+        a.append(valu(f"v_add_f32 {vr(s2)}, {vr(s2)}, {vr(yr(i + 1))}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(s2)}"))
+    a.append(valu(f"v_mov_b32 {vr(s2)}, {vr(s1)}"))
+    a.append(raw("s_nop 1"))
+    a.append(valu(f"v_permlane32_swap_b32 {vr(s1)}, {vr(s2)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(s2)}"))
+    a.append(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))                 # mean
+    a.append(valu(f"v_sub_f32 {vr(yr(0))}, {vr(yr(0))}, {vr(s1)}"))
+    a.append(valu(f"v_mul_f32 {vr(s2)}, {vr(yr(0))}, {vr(yr(0))}"))
+    for i in range(1, 32):
+        a.append(valu(f"v_sub_f32 {vr(yr(i))}, {vr(yr(i))}, {vr(s1)}"))
+        a.append(valu(f"v_fmac_f32 {vr(s2)}, {vr(yr(i))}, {vr(yr(i))}"))
+    a.append(valu(f"v_mov_b32 {vr(s1)}, {vr(s2)}"))
+    a.append(raw("s_nop 1"))
+    a.append(valu(f"v_permlane32_swap_b32 {vr(s2)}, {vr(s1)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(s2)}, {vr(s1)}"))
+    a.append(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, 0x3727c5ac, {vr(s1)}"))                 # + 1e-5
+    a.append(valu(f"v_rsq_f32 {vr(s1)}, {vr(s1)}"))
+    a.append(raw("s_nop 0"))
+    # z' = (y - mean) * rstd * gamma + beta; gamma / beta of this lane's features 32 mt + 8 b + 4 g + e through two quad pairs
+    quads = [(TQ, TQ + 4), (Z0, Z0 + 4)]
+    rd = lambda n: [lds(f"ds_read_b128 {vr(quads[n & 1][0], 4)}, {vr(V_CSADDR)} offset:{(32 * (n // 4) + 8 * (n % 4)) * 4}", f"gm{t}{n}"),
+                    lds(f"ds_read_b128 {vr(quads[n & 1][1], 4)}, {vr(V_CSADDR)} offset:{(64 + 32 * (n // 4) + 8 * (n % 4)) * 4}", f"bt{t}{n}")]
+    a += rd(0) + rd(1)
+    for n in range(8):                         # n = 4 mt + b; the quad pair of n + 2 is requested behind the last use of n's
+        g_, b_ = quads[n & 1]
+        for k in range(4):
+            r = Y[n // 4] + 4 * (n % 4) + k
+            a.append(valu(f"v_mul_f32 {vr(r)}, {vr(r)}, {vr(s1)}", need_lds=(f"gm{t}{n}", f"bt{t}{n}") if k == 0 else ()))
+            a.append(valu(f"v_fma_f32 {vr(r)}, {vr(r)}, {vr(g_ + k)}, {vr(b_ + k)}"))
+        if n + 2 < 8:
+            a += rd(n + 2)
+    # edge mask (ga.py:118): skipped for a wave whose 64 pairs are all unmasked (x * 1 is x)
+    blk = [f"s_cmp_eq_u32 {sg('zmask')}, 0", f"s_cbranch_scc1 .Lv5_nomask{t}%="]
+    blk += [f"v_mul_f32 {vr(yr(i))}, {vr(yr(i))}, {vr(V_MK + t)}" for i in range(32)]
+    blk += [f".Lv5_nomask{t}%=:"]
+    a.append(Ins("\n".join(blk), "raw", w=2.0))
+    # z' in fragment order: piece 4 mt + b of block (tile, 2 w + t): byte (8 t + p) * 1024 of the wave's 16 KiB = j * 4096 + imm;
+    # no store when z_out is NULL (the last EdgeTransition of a step): the stores run under an all-zero exec mask
+    blk = [f"s_mov_b64 exec, {sr(12, 2)}"]
+    for mt in range(2):
+        for b in range(4):
+            p = 8 * t + 4 * mt + b
+            blk.append(f"global_store_dwordx4 {vr(V_ZOFF + p // 4)}, {vr(Y[mt] + 4 * b, 4)}, {sg('zout', 2)} offset:{(p % 4) * 1024}")
+    blk.append("s_mov_b64 exec, -1")
+    a.append(Ins("\n".join(blk), "raw", w=8.0))
+    # operand planes of z' (no ReLU): K-step q = 2 mt + s2 = registers 16 mt + 8 s2 .. + 7 of z'
+    for q in range(4):
+        a += split8(Y[q // 2] + 8 * (q % 2), X[q], False)
+    # behind the [linear_b; down_z] tile: pair bias [B,8,L,L] (heads 4 g + e, one plane = hs bytes apart), pair values
+    f = [lds(f"ds_read_b128 {vr(TQ, 4)}, {vr(V_CSADDR)} offset:{320 * 4}", f"bb{t}")]
+    for k in range(4):
+        f.append(valu(f"v_add_f32 {vr(BM + k)}, {vr(BM + k)}, {vr(TQ + k)}", need_lds=(f"bb{t}",) if k == 0 else ()))
+        f.append(valu(f"v_mul_f32 {vr(BM + k)}, 0x3f13cd3a, {vr(BM + k)}"))     # sqrt(1/3), ipa_pytorch.py:404
+    f.append(raw(f"s_mov_b64 {sg('t0', 2)}, {sg('bias', 2)}"))
+    for k in range(4):
+        f.append(vmem(f"global_store_dword {vr(V_BIASOFF + t)}, {vr(BM + k)}, {sg('t0', 2)}"))
+        if k < 3:
+            f.append(raw(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('hs')}"))
+            f.append(raw(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0"))
+    blk = [f"s_mov_b64 exec, {sr(14, 2)}",
+           f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 4, 4)}, {sg('dz', 2)}",
+           f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 8, 4)}, {sg('dz', 2)} offset:32", "s_mov_b64 exec, -1"]
+    f.append(Ins("\n".join(blk), "raw", w=2.0))
+    return a, f
+
+
 def build_stream():
     sc = Sched()
-    tail_cap = float(os.environ.get("GEN_ET5_TAILCAP", "5.0"))
-    sc.cap_fn = lambda g: tail_cap if (g >= mi(84) or g < mi(8)) else sc.cap      # the drain phase and the first two chunks carry more than 4 per MFMA
-    # ---- MFMAs, entry by entry: per entry t0 / t1 alternating over the three products w.h x.l, w.h x.h, w.l x.h
-    for e, d in enumerate(ENT):
-        w = WREG + 8 * (e % 3)
-        for j in range(6):
-            t, prod = j & 1, j >> 1
-            if d["kind"] == "G1":
-                acc, ag, x = acc1(d["c"] & 1, t), False, zop(t, d["ks"])
-            elif d["kind"] == "G2":
-                acc, ag, x = a2(d["mt"], t), True, h1(d["c"] & 1, t, d["s"])
-            elif d["kind"] == "WFZ":
-                acc, ag, x = m3(d["mt"], t), True, zop(t, d["ks"])
-            else:
-                acc, ag, x = m3(d["mt"], t), True, h2(d["c"] % 4, t, d["s"])
-            a = w + (4 if prod == 2 else 0)
-            b = x + (4 if prod == 0 else 0)
-            need = (f"W{e}h",) if j == 0 else ((f"W{e}l",) if j == 4 else ())
-            sc.mfma(Ins(mfma_text(acc, a, b, ag), "mfma", need_lds=need, w=0.0))
+    tail_cap, mid_cap = float(os.environ.get("GEN_ET5_TAILCAP", "5.0")), float(os.environ.get("GEN_ET5_MIDCAP", "3.0"))
+    # the drain phase and the first two chunks carry more than 4 per MFMA; the K loop has idle gaps to spread into (3 per gap measured
+    # 517 cycles per tile better than 4, 6 measured 854 worse)
+    sc.cap_fn = lambda g: tail_cap if (g >= mi(84) or g < mi(8)) else mid_cap
+    # ---- fragment uses in order: entries 0..127 (pass A for the last sixteen), their second reading for pass B, the two bias tiles
+    uses = [("E", e) for e in range(128)] + [("B", e) for e in range(N_MAIN, 128)] + [("W", t, q) for t in range(2) for q in range(4)]
+    wreg = lambda u: WREG + 8 * (u % 3)
+
+    def operand(d, t):
+        if d["kind"] == "G1":
+            return acc1(d["c"] & 1, t), False, zop(t, d["ks"])
+        if d["kind"] == "G2":
+            return a2(d["mt"], t), True, h1(d["c"] & 1, t, d["s"])
+        if d["kind"] == "WFZ":
+            return m3(d["mt"], t), True, zop(t, d["ks"])
+        return m3(d["mt"], t), True, h2(d["c"] % 4, t, d["s"])
+
+    def three(u, acc, ag, x, tag, first_c0=False):
+        w = wreg(u)
+        out = []
+        for prod in range(3):
+            a_, b_ = w + (4 if prod == 2 else 0), x + (4 if prod == 0 else 0)
+            need = (tag + "h",) if prod == 0 else ((tag + "l",) if prod == 2 else ())
+            d_ = ar(acc, 16) if ag else vr(acc, 16)
+            c_ = "0" if (first_c0 and prod == 0) else d_
+            out.append(Ins(f"v_mfma_f32_32x32x16_f16 {d_}, {vr(a_, 4)}, {vr(b_, 4)}, {c_}", "mfma", need_lds=need, w=0.0))
+        return out
+
+    first_of, last_of = {}, {}                 # use index -> first / last MFMA that reads its fragment registers
+    for u, use in enumerate(uses):
+        if use[0] == "E" and use[1] < N_MAIN:
+            e = use[1]
+            ops = [three(u, *operand(ENT[e], t), f"U{u}") for t in range(2)]
+            seq = [ops[j & 1][j >> 1] for j in range(6)]
+        elif use[0] in ("E", "B"):
+            t = 0 if use[0] == "E" else 1
+            seq = three(u, *operand(ENT[use[1]], t), f"U{u}")
+        else:
+            _, t, q = use
+            Y, X, BM = ep_regs(t)
+            seq = three(u, BM, False, X[q], f"U{u}", first_c0=(q == 0))
+        first_of[u] = len(sc.mf)
+        for m in seq:
+            sc.mfma(m)
+        last_of[u] = len(sc.mf) - 1
+    assert len(sc.mf) == N_MF and first_of[128] == PB0 and first_of[144] == BI0
 
     # ---- chain HEAD: forced in front of MFMA 0
     sc.fill("HEAD", tile_head(), after=-1, before=0, prio=1)
 
-    # ---- chain W: fragment reads (up to 2 entries ahead, three register sets) and the stage barriers, in stream order
-    def wreads(e):
-        w = WREG + 8 * (e % 3)
-        es = e % 16
-        return [lds(f"ds_read_b128 {vr(w, 4)}, {vr(V_WADDR)} offset:{es * 2048}", f"W{e}h"),
-                lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(V_WADDR)} offset:{es * 2048 + 1024}", f"W{e}l")]
+    # ---- chain W: fragment reads (up to 2 uses ahead, three register sets) and the stage barriers, in stream order
+    def wreads(u):
+        use, w = uses[u], wreg(u)
+        if use[0] == "W":
+            base, off = V_L16, WB + 2048 * use[2]
+        else:
+            base, off = V_WADDR, (use[1] % 16) * 2048
+        return [lds(f"ds_read_b128 {vr(w, 4)}, {vr(base)} offset:{off}", f"U{u}h"), lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(base)} offset:{off + 1024}", f"U{u}l")]
 
-    for e in range(128):
-        sc.fill("W", wreads(e), after=mi(e - 3, 5) if e >= 3 else -1, before=mi(e), prio=0)
-        if e % 16 == 15:
-            # B(st), in the gap in front of the LAST entry of stage st (its fragments are requested just above): every wave has confirmed
-            # its own pieces of stage st + 1 and holds everything it will read of stage st in registers; behind the barrier stage st + 1
-            # is complete for everybody and the slot of stage st takes stage st + 3
-            st = e // 16
-            g = mi(e) - 1
-            blk = [Ins("", "wait_vm", need_vm=(f"stg{(st + 1) % 8}",), w=0.0),
-                   Ins("s_waitcnt lgkmcnt(0)", "wait_lds_all", w=0.0),
-                   Ins("s_barrier", "raw", w=0.0),
-                   salu(f"s_mov_b32 {sg('slot_wr')}, {sg('slot_rd')}"),
-                   salu(f"s_add_i32 {sg('slot_rd')}, {sg('slot_rd')}, 0x{STAGE_B:x}"),
-                   salu(f"s_cmp_eq_u32 {sg('slot_rd')}, 0x{NSLOT * STAGE_B:x}"),
-                   salu(f"s_cselect_b32 {sg('slot_rd')}, 0, {sg('slot_rd')}"),
-                   valu(f"v_add_u32 {vr(V_WADDR)}, {sg('slot_rd')}, {vr(V_L16)}")]
-            sc.fill("W", blk, after=g, before=g + 1, prio=0)
-            d_items = dma_stage((st + 3) % 8)
-            if st == 4:
-                d_items = d_items + dma_rows()     # every wave is past the last reader of the rows (seeds of chunk 5, the m3 seeds)
-            sc.fill("D", d_items, after=g, before=g + 1 + 36)
+    def barrier_block(st):
+        # B(st), in the gap in front of the LAST fragment use of stage st (its fragments are requested just above): every wave has
+        # confirmed its own pieces of stage st + 1 and holds everything it will read of stage st in registers; behind the barrier
+        # stage st + 1 is complete for everybody and the slot of stage st takes stage st + 3
+        return [Ins("", "wait_vm", need_vm=(f"stg{(st + 1) % 8}",), w=0.0),
+                Ins("s_waitcnt lgkmcnt(0)", "wait_lds_all", w=0.0),
+                Ins("s_barrier", "raw", w=0.0),
+                salu(f"s_mov_b32 {sg('slot_wr')}, {sg('slot_rd')}"),
+                salu(f"s_add_i32 {sg('slot_rd')}, {sg('slot_rd')}, 0x{STAGE_B:x}"),
+                salu(f"s_cmp_eq_u32 {sg('slot_rd')}, 0x{RING + NSLOT * STAGE_B:x}"),
+                salu(f"s_cselect_b32 {sg('slot_rd')}, 0x{RING:x}, {sg('slot_rd')}"),
+                valu(f"v_add_u32 {vr(V_WADDR)}, {sg('slot_rd')}, {vr(V_L16)}")]
+
+    last_use_of_stage = {st: 16 * st + 15 for st in range(7)}
+    last_use_of_stage[7] = 143                 # pass B of entry 127
+    for u in range(len(uses)):
+        sc.fill("W", wreads(u), after=last_of[u - 3] if u >= 3 else -1, before=first_of[u], prio=0)
+        for st, lu in last_use_of_stage.items():
+            if lu == u:
+                g = first_of[u] - 1
+                sc.fill("W", barrier_block(st), after=g, before=g + 1, prio=0)
+                d_items = dma_stage((st + 3) % 8)
+                if st == 4:
+                    d_items = d_items + dma_rows()     # every wave is past the last reader of the rows (seeds of chunk 5, the m3 seeds)
+                # one LDS-DMA piece every few MFMAs (an LDS-DMA instruction costs its wave 60 - 185 cycles of issue: eight in a row
+                # right behind the barrier, in all four waves at once, stall the matrix pipes and skew the waves)
+                npieces = sum(it.kind == "vmem" for it in d_items)
+                span = 84 if st < 7 else 20
+                step, k = max(1, span // npieces), 0
+                for it in d_items:
+                    sc.fill("D", it, after=min(g + step * k, N_MF - 2), before=min(g + step * k + 24, N_MF))
+                    k += it.kind == "vmem"
 
     # ---- chain ZS: the z operands of K-steps 1..3 (K-step 0 is converted in the head)
     global MIX
@@ -486,37 +641,50 @@ def build_stream():
         first = first_entry(lambda d: d["kind"] == "G2" and d["mt"] == mt)
         for t in range(2):
             for b in range(4):
+                if "noa2s" in WHATIF:
+                    continue
                 sc.fill("A2S", lds(f"ds_read_b128 {ar(a2(mt, t) + 4 * b, 4)}, {vr(V_CSADDR)} offset:{(128 + 32 * mt + 8 * b) * 4}", f"a2s{mt}{t}{b}"),
                         after=-1, before=mi(first))
             m = sc.mf[mi(first, t)]
-            m.need_lds = m.need_lds + tuple(f"a2s{mt}{t}{b}" for b in range(4))
+            if "noa2s" not in WHATIF:
+                m.need_lds = m.need_lds + tuple(f"a2s{mt}{t}{b}" for b in range(4))
 
     # ---- chain ACT: seeds of GEMM1's accumulators, re-splits, the drain of GEMM2's accumulators (one chain: they share registers)
     g1_last = lambda c: mi(last_entry(lambda d: d["kind"] == "G1" and d["c"] == c), 5)
     g1_first = lambda c: mi(first_entry(lambda d: d["kind"] == "G1" and d["c"] == c))
     g2_first = lambda c: mi(first_entry(lambda d: d["kind"] == "G2" and d["c"] == c))
-    g3_first = lambda c: mi(first_entry(lambda d: d["kind"] == "G3" and d["c"] == c))
-    g3_last = lambda c: mi(last_entry(lambda d: d["kind"] == "G3" and d["c"] == c), 5)
     wfz_first = mi(first_entry(lambda d: d["kind"] == "WFZ"))
     wfz_last = mi(last_entry(lambda d: d["kind"] == "WFZ"), 5)
+    e3 = lambda c: [e for e, d in enumerate(ENT) if d["kind"] == "G3" and d["c"] == c]
     sc.fill("ACT", seeds(1), after=-1, before=g1_first(1))
     for c in range(6):
         for s_ in range(2):                    # (GEMM2 of chunks 0..4 runs half-major: the second half of h1 is needed six entries later)
             sc.fill("ACT", split_acc1(c, s_), after=g1_last(c) + 2, before=mi(first_entry(lambda d: d["kind"] == "G2" and d["c"] == c and d["s"] == s_)))
-        if c + 2 < 6:
+        if c + 2 < 6 and "noseed" not in WHATIF:
             sc.fill("ACT", seeds(c + 2), after=g1_last(c) + 2, before=g1_first(c + 2))
-    # drain: a2[c'] -> ReLU -> h2 chunk c' (three buffers); temporaries: the two quads of TQ as one octet (in-order issue: the next
+    # drain: a2[c'] -> ReLU -> h2 chunk c' (four buffers); temporaries: the two quads of TQ as one octet (in-order issue: the next
     # unit's reads follow the last instruction that reads this unit's)
+    g2_last5 = mi(last_entry(lambda d: d["kind"] == "G2" and d["c"] == 5), 5)
     for c in range(6):
         ready = mi(last_entry(lambda d: d["kind"] == "G2" and d["c"] == 5 and d["mt"] == c), 5) + 2
-        g2_last5 = mi(last_entry(lambda d: d["kind"] == "G2" and d["c"] == 5), 5)
-        after = max(ready, g2_last5 + 1 if c == 3 else -1, g3_last(c - 4) + 1 if c >= 4 else -1)      # (buffer 3 = h1 chunk 5's registers)
+        after = max(ready, g2_last5 + 1 if c == 3 else -1, mi(e3(c - 4)[-1], 5) + 1 if c >= 4 else -1)      # (buffer 3 = h1 chunk 5's registers)
         for t in range(2):
             for s in range(2):
-                tmp = TQ
-                items = [valu(f"v_accvgpr_read_b32 {vr(tmp + k)}, {ar(a2(c, t) + 8 * s + k)}") for k in range(8)]
-                items += split8(tmp, h2(c % 4, t, s), True)
-                sc.fill("ACT", items, after=after, before=g3_first(c))
+                items = [valu(f"v_accvgpr_read_b32 {vr(TQ + k)}, {ar(a2(c, t) + 8 * s + k)}") for k in range(8)]
+                items += split8(TQ, h2(c % 4, t, s), True)
+                if c < 2:
+                    dl = mi(e3(c)[0])
+                else:                          # every drain is over when pass B starts: the epilogue of group 0 takes the temporaries
+                    dl = pa(e3(c)[0]) if t == 0 else min(pb(e3(c)[0]), PB0)
+                sc.fill("ACT", items, after=after, before=dl)
+
+    # ---- the epilogues, one chain behind the drains (they share TQ): group 0 under pass B, group 1 behind it
+    ep0, fin0 = epilogue_items(0, None)
+    ep1, fin1 = epilogue_items(1, None)
+    sc.fill("ACT", ep0, after=max(PB0 - 1 + 2, wfz_last + 1), before=BI0)
+    sc.fill("ACT", ep1, after=BI0 - 1 + 2, before=bi(1, 0))
+    sc.fill("ACT", fin0, after=bi(0, 3, 2) + 2, before=N_MF + 1)
+    sc.fill("ACT", [raw("s_nop 7"), raw("s_nop 7")] + fin1, after=N_MF - 1, before=N_MF + 1)
 
     # ---- chain M3: the final layer's accumulators start from d_i + e_j (bf folded into e); temporaries Z[64..71]
     for mt in range(2):
@@ -530,17 +698,17 @@ def build_stream():
                     items.append(valu(f"v_add_f32 {vr(qa + k)}, {vr(qa + k)}, {vr(qb + k)}", need_lds=(tg + "d", tg + "e") if k == 0 else ()))
                 for k in range(4):
                     items.append(valu(f"v_accvgpr_write_b32 {ar(m3(mt, t) + 4 * b + k)}, {vr(qa + k)}"))
+                if "nom3" in WHATIF:
+                    continue
                 sc.fill("M3", items, after=mi(7, 5), before=mi(72), prio=2)      # (behind the last z conversion: Z[64..71] is its raw input; in front of B(4): the rows are refilled behind it)
 
     # ---- chain VM: the next tile's z behind the last MFMA that reads this tile's
-    sc.fill("VM", z_loads(), after=wfz_last + 1, before=wfz_last + 1 + 72, prio=2)
-    if PROF:                                   # stamps: 1 = first MFMA, 2 = G2(0), 3 = in front of B(3), 4 = behind it, 5 = WfZ, 6 = G2(5), 7 = G3
+    for k, it in enumerate(z_loads()):         # (spread: four waves x 16 loads in one burst queue in front of the LDS-DMA pieces)
+        sc.fill("VM", it, after=wfz_last + 1 + 3 * k, before=wfz_last + 1 + 3 * k + 40, prio=2)
+    if PROF:     # stamps: 0 top, 1 first MFMA, 2 G2(0), 3 G2(5), 4 WfZ, 5 final layer on h2, 6 pass B, 7 bias tiles; the end of the tile = the next tile's 0
         sc.fill("HEAD", stamp(1), after=-1, before=0)
-        for k, g in ((2, g2_first(0)), (5, wfz_first), (6, g2_first(5)), (7, g3_first(0))):
+        for k, g in ((2, g2_first(0)), (3, g2_first(5)), (4, wfz_first), (5, mi(e3(0)[0])), (6, PB0), (7, BI0)):
             sc.fill(f"P{k}", stamp(k), after=g - 1, before=g, prio=0)
-        gb3 = mi(16 * 3 + 15) - 1
-        sc.fill("P3", stamp(3), after=gb3 - 1, before=gb3, prio=0)
-        sc.fill("P4", stamp(4), after=gb3 + 1, before=gb3 + 2, prio=0)
     return sc
 
 
@@ -568,6 +736,11 @@ def kernel_setup():
     a(".Lv5_nolist%=:")
     a(f"s_cmp_ge_i32 {sg('WG')}, {sg('nwork')}")
     a("s_cbranch_scc1 .Lv5_end%=")
+    # exec masks of the optional stores: all lanes, or none when the pointer is NULL (z_out: the last EdgeTransition of a step)
+    a(f"s_cmp_lg_u64 {sg('z_out', 2)}, 0")
+    a(f"s_cselect_b64 {sr(12, 2)}, -1, 0")
+    a(f"s_cmp_lg_u64 {sg('dz_out', 2)}, 0")
+    a(f"s_cselect_b64 {sr(14, 2)}, -1, 0")
     # lane-level constants (TQ .. TQ+7 are scratch here)
     a(f"v_lshrrev_b32 {vr(TQ)}, 6, {vr(V_TMP)}")
     a("s_nop 0")
@@ -741,114 +914,19 @@ def prologue_loads():
     L += [it.text for it in z_loads()]
     L.append(f"s_mov_b32 {sg('woff')}, 0x{(8 - 1) * STAGE_B:x}")                # dma_stage pre-increments (and wraps): first issue = offset 0
     for st in range(3):
-        L.append(f"s_mov_b32 {sg('slot_wr')}, 0x{st * STAGE_B:x}")
+        L.append(f"s_mov_b32 {sg('slot_wr')}, 0x{RING + st * STAGE_B:x}")
         L += [it.text for it in dma_stage(st)]
-    L.append(f"s_mov_b32 {sg('slot_rd')}, 0")
-    L.append(f"v_mov_b32 {vr(V_WADDR)}, {vr(V_L16)}")
+    L.append(f"s_mov_b32 {sg('slot_rd')}, 0x{RING:x}")
+    L.append(f"v_add_u32 {vr(V_WADDR)}, 0x{RING:x}, {vr(V_L16)}")
     L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     L.append("s_barrier")
     return L
 
 
-def epilogue():
-    """LayerNorm over the 64 features of a pair (32 in this lane, 32 in lane ^ 32), edge mask, z' store, the next block's pair bias and
-    pair values from z' in registers (ipa_pytorch.py:391,440).  Straight-line per 32-pair group."""
-    L = []
-    Y = H1                                    # 32 registers: y, then y - mean, then z'
-    X = H1 + 32                               # 32 registers: z' as operand planes, 4 K-steps x (hi 4 | lo 4)
-    BM = ACC1                                 # 16: the [linear_b; down_z] tile
-    G = ACC1 + 32                             # 32: gamma | beta quads
-    a = L.append
-    for t in range(2):
-        for mt in range(2):
-            for r in range(16):
-                a(valu(f"v_accvgpr_read_b32 {vr(Y + 16 * mt + r)}, {ar(m3(mt, t) + r)}"))
-        s1, s2 = V_TMP, TQ
-        a(valu(f"v_add_f32 {vr(s1)}, {vr(Y)}, {vr(Y + 1)}"))
-        for r in range(2, 32):
-            a(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(Y + r)}"))
-        a(valu(f"v_mov_b32 {vr(s2)}, {vr(s1)}"))
-        a(raw("s_nop 1"))
-        a(valu(f"v_permlane32_swap_b32 {vr(s1)}, {vr(s2)}"))
-        a(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(s2)}"))
-        a(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))                 # mean
-        a(valu(f"v_sub_f32 {vr(Y)}, {vr(Y)}, {vr(s1)}"))
-        a(valu(f"v_mul_f32 {vr(s2)}, {vr(Y)}, {vr(Y)}"))
-        for r in range(1, 32):
-            a(valu(f"v_sub_f32 {vr(Y + r)}, {vr(Y + r)}, {vr(s1)}"))
-            a(valu(f"v_fmac_f32 {vr(s2)}, {vr(Y + r)}, {vr(Y + r)}"))
-        a(valu(f"v_mov_b32 {vr(s1)}, {vr(s2)}"))
-        a(raw("s_nop 1"))
-        a(valu(f"v_permlane32_swap_b32 {vr(s2)}, {vr(s1)}"))
-        a(valu(f"v_add_f32 {vr(s1)}, {vr(s2)}, {vr(s1)}"))
-        a(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))
-        a(valu(f"v_add_f32 {vr(s1)}, 0x3727c5ac, {vr(s1)}"))                 # + 1e-5
-        a(valu(f"v_rsq_f32 {vr(s1)}, {vr(s1)}"))
-        a(raw("s_nop 0"))
-        # z' = (y - mean) * rstd * gamma + beta; gamma / beta of this lane's features 32 mt + 8 b + 4 g + e, 16 features at a time
-        for mt in range(2):
-            for b in range(4):
-                a(lds(f"ds_read_b128 {vr(G + 8 * b, 4)}, {vr(V_CSADDR)} offset:{(32 * mt + 8 * b) * 4}", f"gm{t}{mt}{b}"))
-                a(lds(f"ds_read_b128 {vr(G + 8 * b + 4, 4)}, {vr(V_CSADDR)} offset:{(64 + 32 * mt + 8 * b) * 4}", f"bt{t}{mt}{b}"))
-            for b in range(4):
-                for k in range(4):
-                    r = Y + 16 * mt + 4 * b + k
-                    a(valu(f"v_mul_f32 {vr(r)}, {vr(r)}, {vr(s1)}"))
-                    a(valu(f"v_fma_f32 {vr(r)}, {vr(r)}, {vr(G + 8 * b + k)}, {vr(G + 8 * b + 4 + k)}", need_lds=(f"gm{t}{mt}{b}", f"bt{t}{mt}{b}") if k == 0 else ()))
-        # edge mask (ga.py:118): skipped for a wave whose 64 pairs are all unmasked (x * 1 is x)
-        a(raw(f"s_cmp_eq_u32 {sg('zmask')}, 0"))
-        a(raw(f"s_cbranch_scc1 .Lv5_nomask{t}%="))
-        for r in range(32):
-            a(valu(f"v_mul_f32 {vr(Y + r)}, {vr(Y + r)}, {vr(V_MK + t)}"))
-        a(raw(f".Lv5_nomask{t}%=:"))
-        # z' in fragment order: piece 4 mt + b of block (tile, 2 w + t): byte (8 t + p) * 1024 of the wave's 16 KiB = j * 4096 + imm
-        a(raw(f"s_cmp_eq_u64 {sg('z_out', 2)}, 0"))
-        a(raw(f"s_cbranch_scc1 .Lv5_nozout{t}%="))
-        for mt in range(2):
-            for b in range(4):
-                p = 8 * t + 4 * mt + b
-                a(vmem(f"global_store_dwordx4 {vr(V_ZOFF + p // 4)}, {vr(Y + 16 * mt + 4 * b, 4)}, {sg('zout', 2)} offset:{(p % 4) * 1024}", counted=False))
-        a(raw(f".Lv5_nozout{t}%=:"))
-        # operand planes of z' (no ReLU): K-step (mt, s2) = registers 16 mt + 8 s2 .. + 7
-        for mt in range(2):
-            for s2 in range(2):
-                L.extend(split8(Y + 16 * mt + 8 * s2, X + 8 * (2 * mt + s2), False))
-        # [linear_b; down_z] tile: 4 entries x 3 products, accumulator from 0
-        a(valu(f"v_add_u32 {vr(TQ + 1)}, 0x{WB:x}, {vr(V_L16)}"))
-        wbuf = lambda q: WREG + 8 * q if q < 3 else G + 8      # four fragment pairs in flight: the stream's three sets + a gamma / beta octet
-        for q in range(4):
-            w = wbuf(q)
-            a(lds(f"ds_read_b128 {vr(w, 4)}, {vr(TQ + 1)} offset:{q * 2048}", f"wb{t}{q}h"))
-            a(lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(TQ + 1)} offset:{q * 2048 + 1024}", f"wb{t}{q}l"))
-        for q in range(4):
-            w = wbuf(q)
-            x = X + 8 * q
-            c0 = "0" if q == 0 else vr(BM, 16)
-            a(Ins(f"v_mfma_f32_32x32x16_f16 {vr(BM, 16)}, {vr(w, 4)}, {vr(x + 4, 4)}, {c0}", "mfma", need_lds=(f"wb{t}{q}h",)))
-            a(Ins(f"v_mfma_f32_32x32x16_f16 {vr(BM, 16)}, {vr(w, 4)}, {vr(x, 4)}, {vr(BM, 16)}", "mfma"))
-            a(Ins(f"v_mfma_f32_32x32x16_f16 {vr(BM, 16)}, {vr(w + 4, 4)}, {vr(x, 4)}, {vr(BM, 16)}", "mfma", need_lds=(f"wb{t}{q}l",)))
-        a(lds(f"ds_read_b128 {vr(G, 4)}, {vr(V_CSADDR)} offset:{320 * 4}", f"bb{t}"))
-        a(raw("s_nop 7"))
-        a(raw("s_nop 7"))
-        for k in range(4):
-            a(valu(f"v_add_f32 {vr(BM + k)}, {vr(BM + k)}, {vr(G + k)}", need_lds=(f"bb{t}",) if k == 0 else ()))
-            a(valu(f"v_mul_f32 {vr(BM + k)}, 0x3f13cd3a, {vr(BM + k)}"))     # sqrt(1/3), ipa_pytorch.py:404
-        # pair bias [B,8,L,L]: heads 4 g + e, e = 0..3, one plane (hs bytes) apart
-        a(raw(f"s_mov_b64 {sg('t0', 2)}, {sg('bias', 2)}"))
-        for k in range(4):
-            a(vmem(f"global_store_dword {vr(V_BIASOFF + t)}, {vr(BM + k)}, {sg('t0', 2)}"))
-            if k < 3:
-                a(raw(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('hs')}"))
-                a(raw(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0"))
-        a(raw(f"s_cmp_eq_u64 {sg('dz_out', 2)}, 0"))
-        a(raw(f"s_cbranch_scc1 .Lv5_nodz{t}%="))
-        a(vmem(f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 4, 4)}, {sg('dz', 2)}", counted=False))
-        a(vmem(f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 8, 4)}, {sg('dz', 2)} offset:32", counted=False))
-        a(raw(f".Lv5_nodz{t}%=:"))
-    return L
-
-
 # ------------------------------------------------------------------ s_waitcnt from the issue order
+WHATIF = set(os.environ.get("GEN_ET5_WHATIF", "").split(","))      # dev: timing-only variants (WRONG results): nobar, nodma, noseed, nom3, noa2s
+
+
 def finalize(body):
     """Two passes over the loop body (the second sees what the first left in flight); returns the text of the second pass.  LDS
     operations and vector memory operations complete in issue order (AMDGPUUsage, memory model GFX6-GFX9: completion is reported
@@ -883,7 +961,7 @@ def finalize(body):
             if it.kind == "wait_vm":
                 continue
             if it.text:
-                out.append(it.text)
+                out.extend(it.text.split("\n"))
             if it.kind == "lds":
                 assert rep == 1 or it.lds_tag not in lds_tag, it.lds_tag
                 lds_tag[it.lds_tag] = lds_seq
@@ -899,12 +977,13 @@ def generate(stats_out=None):
     stream, stats = sc.run()
     if stats_out is not None:
         stats_out.extend(stats)
-    ep = epilogue()
     if PROF:
-        cut = next(i for i, it in enumerate(ep) if it.kind == "raw" and "nodz0" in it.text and it.text.endswith(":"))
-        ep = stamp(8) + ep[:cut + 1] + stamp(9) + ep[cut + 1:] + stamp(10)
         stream = stamp(0) + stream
-    body = stream + ep
+    body = stream
+    if "nobar" in WHATIF:
+        body = [it for it in body if it.text != "s_barrier"]
+    if "nodma" in WHATIF:
+        body = [it for it in body if "global_load_lds" not in it.text]
     lines = []
     lines += kernel_setup()
     lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")
@@ -922,7 +1001,7 @@ def generate(stats_out=None):
     lines.append(f"s_cselect_b32 {sg('ntile')}, {sg('ntile')}, {sg('tile')}")      # no next tile: prefetch this one again (valid addresses)
     lines += decode_tile("ntile", "nid", "nb", "ni0", "nj0", "dec1")
     lines += next_tile_addresses()
-    lines.append("; ---- tile body: head, 768 MFMAs with everything else in their issue slots, epilogue")
+    lines.append("; ---- tile body: head, 792 MFMAs with everything else in their issue slots")
     lines += finalize(body)
     lines.append(f"s_add_i32 {sg('tile')}, {sg('tile')}, {sg('NWG')}")
     lines.append(f"s_cmp_lt_i32 {sg('tile')}, {sg('nwork')}")
@@ -953,7 +1032,7 @@ def main():
     if "--prof" in sys.argv:
         global PROF
         PROF = True
-        with open(OUT.replace(".inc", "_prof.inc"), "w") as f:
+        with open(OUT.replace(".inc", "_prof.inc") if "--out" not in sys.argv else sys.argv[sys.argv.index("--out") + 1], "w") as f:
             f.write(generate())
         print("wrote the stamped variant")
         return 0

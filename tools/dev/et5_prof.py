@@ -28,11 +28,13 @@ for _ in range(3):
     rc = lib.pf_edge_transition_fwd(C.byref(a), _capi.stream_ptr()); assert rc == 0
 torch.cuda.synchronize()
 t = dbg.view(256, 4, 16).cpu().to(torch.int64) & 0xffffffff
-names = ["loop top -> first MFMA (head)", "G1(0), G1(1)", "G2(0) .. B(3)", "B(3): wait + barrier", "B(3) .. WfZ", "WfZ", "G2(5)", "G3", "epilogue group 0", "epilogue group 1"]
-d = [(t[:, :, k + 1] - t[:, :, k]) & 0xffffffff for k in range(0, 10)]
-# stamp order in time: 0 loop top, 1 first MFMA, 2 G2(0), 3 before B(3), 4 after B(3), 5 WfZ, 6 G2(5), 7 G3, 8 end of stream, 9 after group 0, 10 end
-tot = ((t[:, :, 10] - t[:, :, 0]) & 0xffffffff).float()
-print(f"tile: mean {tot.mean():.0f} ticks, min {tot.min():.0f}, max {tot.max():.0f}  (s_memtime ticks = 100 MHz? see ratio below)")
-for k, nm in enumerate(names):
+names = ["loop top -> first MFMA (head)", "G1(0), G1(1)", "G2(0) .. G2(5) (432 MFMAs)", "G2(5) (72)", "WfZ (48)", "final layer: chunks 0, 1 + pass A (96)", "pass B (48)", "bias tiles + exposed rest"]
+# stamps: 0 top, 1 first MFMA, 2 G2(0), 3 G2(5), 4 WfZ, 5 final layer on h2, 6 pass B, 7 bias tiles; the kernel stores the LAST tile's stamps,
+# so "7 -> end of tile" is not stamped: it is the tile time minus the stamped phases (tile time from the launch duration)
+d = [(t[:, :, k + 1] - t[:, :, k]) & 0xffffffff for k in range(0, 7)]
+tot = ((t[:, :, 7] - t[:, :, 0]) & 0xffffffff).float()
+print(f"stamped part of a tile: mean {tot.mean():.0f} cycles, min {tot.min():.0f}, max {tot.max():.0f}")
+floors = [0, 48, 432, 72, 48, 96, 48]
+for k, nm in enumerate(names[:7]):
     x = d[k].float()
-    print(f"{nm:34s} mean {x.mean():8.0f}  per wave {[round(v) for v in x.mean(0).tolist()]}  share {x.mean() / tot.mean():.3f}")
+    print(f"{nm:42s} mean {x.mean():8.0f}  per wave {[round(v) for v in x.mean(0).tolist()]}  MFMA floor {floors[k] * 32}")
