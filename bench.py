@@ -109,6 +109,7 @@ def check_final_state(smp, batch, K_total):
 
 
 _MODELS = {}
+ENGINE_OPTIONS = {}       # --engine-opt name=0|1: forced plan choices of DenoiseEngine (same-box A/B runs); recorded in the line's config
 USE_BUCKETS = True        # ragged workloads (cfg3) run through the length buckets, as FlowModel.sample() does by default (--no-buckets: one engine)
 
 
@@ -124,6 +125,8 @@ def get_model(dev, precision):
         model = model.to(dev).eval()
         if precision != "fp32":
             model.ga_encoder.set_precision(precision)
+        if ENGINE_OPTIONS:
+            model.ga_encoder.engine_options = dict(ENGINE_OPTIONS)
         _MODELS[key] = (model, sd)
     return _MODELS[key]
 
@@ -245,6 +248,12 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
     return elapsed, info
 
 
+def _parse_engine_opts(items):
+    for it in items:
+        k, v = it.split("=")
+        ENGINE_OPTIONS[k] = bool(int(v))
+
+
 def kernel_src_sha():
     """Hash of the kernel sources and their build recipe (csrc/*.hip, csrc/*.h, include/*.h, build.py): what the PMC passes record and the bench line compares --
     `git rev-parse` is not available on the GPU box (the snapshot ships without .git)."""
@@ -333,7 +342,9 @@ def main():
     ap.add_argument("--no-buckets", action="store_true", help="ragged workloads (cfg3): one engine at the longest sample's padded length instead of length buckets")
     ap.add_argument("--no-per-call", action="store_true", help="skip the inference.py-style per-call accounting")
     ap.add_argument("--per-call-steps", type=int, default=200)
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=0|1", help="force a plan choice of DenoiseEngine (A/B runs), e.g. --engine-opt et_v5=0")
     args = ap.parse_args()
+    _parse_engine_opts(args.engine_opt)
     if os.environ.get("PF_BENCH_O_PREMUL") == "0":              # same-box A/B of the folded value projection (DenoiseEngine.O_PREMUL)
         from pepflowww_amd.engine import DenoiseEngine
         DenoiseEngine.O_PREMUL = False
@@ -482,6 +493,8 @@ def main():
         rf["traffic_stale"] = traffic_stale
         if traffic_stale:
             rf["traffic_note"] = "STALE (recorded for other kernel sources than the ones timed here; tools/pmc_traffic.sh regenerates it) -- " + rf["traffic_note"]
+    if ENGINE_OPTIONS:
+        out["config"]["engine_options_forced"] = {k: int(v) for k, v in ENGINE_OPTIONS.items()}
     if info.get("buckets"):
         out["config"]["length_buckets"] = info["buckets"]
         out["config"]["length_buckets_note"] = ("samples split by padded length at the fused attention kernel's limit (128); one engine, launch plan and "

@@ -452,9 +452,58 @@ def ep_regs(t):
     return Y, X, Y[0]
 
 
-def epilogue_items(t, y_ready):
+def ln_packed(t, Y, a):
+    """LayerNorm of group t on packed fp32 instructions (two values per instruction; no op_sel: every operand is a register pair).  For
+    code that runs with no MFMA in flight: a packed instruction costs what a plain one does there (5.3 cycles, tools/dev/filler_bench.py),
+    beside MFMAs it is the known anti-lever.  Same operations per value as the plain form (the sums pair up differently)."""
+    yp = lambda i: vr(Y[i // 16] + i % 16, 2)
+    s1 = V_TMP
+    PS, MP, PQ = Z0, Z0 + 2, Z0 + 4            # pairs: running sum, (mean, mean) then (rstd, rstd), sum of squares
+    a.append(valu(f"v_pk_add_f32 {vr(PS, 2)}, {yp(0)}, {yp(2)}"))
+    for i in range(4, 32, 2):
+        a.append(valu(f"v_pk_add_f32 {vr(PS, 2)}, {vr(PS, 2)}, {yp(i)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(PS)}, {vr(PS + 1)}"))
+    a.append(valu(f"v_mov_b32 {vr(PS)}, {vr(s1)}"))
+    a.append(raw("s_nop 1"))
+    a.append(valu(f"v_permlane32_swap_b32 {vr(s1)}, {vr(PS)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(PS)}"))
+    a.append(valu(f"v_mul_f32 {vr(MP)}, 0x3c800000, {vr(s1)}"))                 # mean
+    a.append(valu(f"v_mov_b32 {vr(MP + 1)}, {vr(MP)}"))
+    for i in range(0, 32, 2):
+        a.append(valu(f"v_pk_add_f32 {yp(i)}, {yp(i)}, {vr(MP, 2)} neg_lo:[0,1] neg_hi:[0,1]"))
+        a.append(valu(f"v_pk_mul_f32 {vr(PQ, 2)}, {yp(i)}, {yp(i)}" if i == 0 else f"v_pk_fma_f32 {vr(PQ, 2)}, {yp(i)}, {yp(i)}, {vr(PQ, 2)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(PQ)}, {vr(PQ + 1)}"))
+    a.append(valu(f"v_mov_b32 {vr(PQ)}, {vr(s1)}"))
+    a.append(raw("s_nop 1"))
+    a.append(valu(f"v_permlane32_swap_b32 {vr(s1)}, {vr(PQ)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(PQ)}"))
+    a.append(valu(f"v_mul_f32 {vr(s1)}, 0x3c800000, {vr(s1)}"))
+    a.append(valu(f"v_add_f32 {vr(s1)}, 0x3727c5ac, {vr(s1)}"))                 # + 1e-5
+    a.append(valu(f"v_rsq_f32 {vr(MP)}, {vr(s1)}"))
+    a.append(raw("s_nop 0"))
+    a.append(valu(f"v_mov_b32 {vr(MP + 1)}, {vr(MP)}"))
+    # gamma / beta quads: three pairs in flight -- TQ, and the second y block of group 0 (dead behind its split)
+    Y0 = ep_regs(0)[0]
+    quads = [(TQ, TQ + 4), (Y0[1], Y0[1] + 4), (Y0[1] + 8, Y0[1] + 12)]
+    rd = lambda n: [lds(f"ds_read_b128 {vr(quads[n % 3][0], 4)}, {vr(V_CSADDR)} offset:{(32 * (n // 4) + 8 * (n % 4)) * 4}", f"gm{t}{n}"),
+                    lds(f"ds_read_b128 {vr(quads[n % 3][1], 4)}, {vr(V_CSADDR)} offset:{(64 + 32 * (n // 4) + 8 * (n % 4)) * 4}", f"bt{t}{n}")]
+    pre = rd(0) + rd(1) + rd(2)
+    for n in range(8):
+        g_, b_ = quads[n % 3]
+        for k in range(0, 4, 2):
+            r = vr(Y[n // 4] + 4 * (n % 4) + k, 2)
+            a.append(valu(f"v_pk_mul_f32 {r}, {r}, {vr(MP, 2)}", need_lds=(f"gm{t}{n}", f"bt{t}{n}") if k == 0 else ()))
+            a.append(valu(f"v_pk_fma_f32 {r}, {r}, {vr(g_ + k, 2)}, {vr(b_ + k, 2)}"))
+        if n + 3 < 8:
+            a += rd(n + 3)
+    return pre
+
+
+def epilogue_items(t, packed=False):
     """Group t: LayerNorm over the 64 features of a pair (32 here, 32 in lane ^ 32), edge mask, z' store, operand planes of z' for the
-    next block's pair bias / pair values (ipa_pytorch.py:391,440).  Returns (items up to the split, items behind the tile's MFMAs)."""
+    next block's pair bias / pair values (ipa_pytorch.py:391,440).  Returns (items up to the split, items behind the tile's MFMAs).
+    packed: the form for the group whose epilogue runs with no MFMA left to hide under (fewer instructions: packed fp32 LayerNorm, the
+    split with v_fma_mix)."""
     Y, X, BM = ep_regs(t)
     yr = lambda i: Y[i // 16] + i % 16
     s1, s2 = V_TMP, Z0                         # per-lane scalars (Z[0..7]: the first z operand octet, dead behind WfZ)
@@ -462,6 +511,11 @@ def epilogue_items(t, y_ready):
     for mt in range(2):
         for r in range(16):
             a.append(valu(f"v_accvgpr_read_b32 {vr(Y[mt] + r)}, {ar(m3(mt, t) + r)}"))
+    if packed:
+        body = []
+        pre = ln_packed(t, Y, body)
+        a += pre + body                        # (the first gamma / beta quads are requested in front of the sums)
+        return a + epilogue_tail(t, True)[0], epilogue_tail(t, True)[1]
     a.append(valu(f"v_add_f32 {vr(s1)}, {vr(yr(0))}, {vr(yr(1))}"))
     a.append(valu(f"v_add_f32 {vr(s2)}, {vr(yr(2))}, {vr(yr(3))}"))
     for i in range(4, 32, 2):
@@ -499,6 +553,14 @@ def epilogue_items(t, y_ready):
             a.append(valu(f"v_fma_f32 {vr(r)}, {vr(r)}, {vr(g_ + k)}, {vr(b_ + k)}"))
         if n + 2 < 8:
             a += rd(n + 2)
+    tail, f = epilogue_tail(t, os.environ.get("GEN_ET5_EP0MIX", "1") == "1")    # (the short split: with the plain one 123 instructions of this group end up behind pass B, exposed)
+    return a + tail, f
+
+
+def epilogue_tail(t, short_split):
+    Y, X, BM = ep_regs(t)
+    yr = lambda i: Y[i // 16] + i % 16
+    a = []
     # edge mask (ga.py:118): skipped for a wave whose 64 pairs are all unmasked (x * 1 is x)
     blk = [f"s_cmp_eq_u32 {sg('zmask')}, 0", f"s_cbranch_scc1 .Lv5_nomask{t}%="]
     blk += [f"v_mul_f32 {vr(yr(i))}, {vr(yr(i))}, {vr(V_MK + t)}" for i in range(32)]
@@ -514,8 +576,11 @@ def epilogue_items(t, y_ready):
     blk.append("s_mov_b64 exec, -1")
     a.append(Ins("\n".join(blk), "raw", w=8.0))
     # operand planes of z' (no ReLU): K-step q = 2 mt + s2 = registers 16 mt + 8 s2 .. + 7 of z'
+    global MIX
+    keep, MIX = MIX, MIX or short_split
     for q in range(4):
         a += split8(Y[q // 2] + 8 * (q % 2), X[q], False)
+    MIX = keep
     # behind the [linear_b; down_z] tile: pair bias [B,8,L,L] (heads 4 g + e, one plane = hs bytes apart), pair values
     f = [lds(f"ds_read_b128 {vr(TQ, 4)}, {vr(V_CSADDR)} offset:{320 * 4}", f"bb{t}")]
     for k in range(4):
@@ -539,7 +604,8 @@ def build_stream():
     tail_cap, mid_cap = float(os.environ.get("GEN_ET5_TAILCAP", "5.0")), float(os.environ.get("GEN_ET5_MIDCAP", "3.0"))
     # the drain phase and the first two chunks carry more than 4 per MFMA; the K loop has idle gaps to spread into (3 per gap measured
     # 517 cycles per tile better than 4, 6 measured 854 worse)
-    sc.cap_fn = lambda g: tail_cap if (g >= mi(84) or g < mi(8)) else mid_cap
+    pb_cap = float(os.environ.get("GEN_ET5_PBCAP", "6.0"))
+    sc.cap_fn = lambda g: pb_cap if g >= PB0 else (tail_cap if (g >= mi(84) or g < mi(8)) else mid_cap)
     # ---- fragment uses in order: entries 0..127 (pass A for the last sixteen), their second reading for pass B, the two bias tiles
     uses = [("E", e) for e in range(128)] + [("B", e) for e in range(N_MAIN, 128)] + [("W", t, q) for t in range(2) for q in range(4)]
     wreg = lambda u: WREG + 8 * (u % 3)
@@ -679,8 +745,8 @@ def build_stream():
                 sc.fill("ACT", items, after=after, before=dl)
 
     # ---- the epilogues, one chain behind the drains (they share TQ): group 0 under pass B, group 1 behind it
-    ep0, fin0 = epilogue_items(0, None)
-    ep1, fin1 = epilogue_items(1, None)
+    ep0, fin0 = epilogue_items(0)
+    ep1, fin1 = epilogue_items(1, packed=os.environ.get("GEN_ET5_EP1PACKED", "1") == "1")
     sc.fill("ACT", ep0, after=max(PB0 - 1 + 2, wfz_last + 1), before=BI0)
     sc.fill("ACT", ep1, after=BI0 - 1 + 2, before=bi(1, 0))
     sc.fill("ACT", fin0, after=bi(0, 3, 2) + 2, before=N_MF + 1)
@@ -700,7 +766,20 @@ def build_stream():
                     items.append(valu(f"v_accvgpr_write_b32 {ar(m3(mt, t) + 4 * b + k)}, {vr(qa + k)}"))
                 if "nom3" in WHATIF:
                     continue
-                sc.fill("M3", items, after=mi(7, 5), before=mi(72), prio=2)      # (behind the last z conversion: Z[64..71] is its raw input; in front of B(4): the rows are refilled behind it)
+                sc.fill("M3", items, after=mi(7, 5), before=mi(78), prio=2)      # (behind the last z conversion: Z[64..71] is its raw input; in front of B(4): the rows are refilled behind it)
+
+    # ---- chain TOP: this tile's output addresses and the NEXT tile's decode + prefetch addresses (scalar unit; consumed from B(4) on)
+    top = []
+    for x in tile_scalars():
+        if x == "@VMLOAD@":
+            top.append(vmem(f"global_load_dword {vr(V_TMP)}, {vr(V_TMP)}, {sg('t0', 2)}", "tl"))
+        elif x == "@VMWAIT@":
+            top.append(Ins("s_nop 0", "raw", need_vm=("tl",), w=0.5))
+        elif x.startswith("v_"):
+            top.append(valu(x))
+        else:
+            top.append(salu(x))
+    sc.fill("TOP", top, after=mi(9), before=mi(60), prio=2)
 
     # ---- chain VM: the next tile's z behind the last MFMA that reads this tile's
     for k, it in enumerate(z_loads()):         # (spread: four waves x 16 loads in one burst queue in front of the LDS-DMA pieces)
@@ -908,6 +987,40 @@ def cur_tile_addresses():
     return L
 
 
+def tile_scalars():
+    """In the stream (scalar instructions in the K loop's gaps): output bases of the current tile, then pick / decode / address the next.
+    The work list is read with a vector load (a scalar load would put an out-of-order SMEM return into lgkmcnt, which the stream's
+    counted LDS waits cannot have); with no list the load reads the mask buffer instead and its result is dropped."""
+    L = cur_tile_addresses()
+    L += [f"s_add_i32 {sg('ntile')}, {sg('tile')}, {sg('NWG')}",
+          f"s_cmp_lt_i32 {sg('ntile')}, {sg('nwork')}",
+          f"s_cselect_b32 {sg('ntile')}, {sg('ntile')}, {sg('tile')}",        # no next tile: prefetch this one again (valid addresses)
+          f"s_cmp_lg_u64 {sg('tile_list', 2)}, 0",
+          f"s_cselect_b64 {sg('t0', 2)}, {sg('tile_list', 2)}, {sg('mask', 2)}",
+          f"s_cselect_b32 {sg('t2')}, {sg('ntile')}, 0",
+          f"s_lshl_b32 {sg('t2')}, {sg('t2')}, 2",
+          f"v_mov_b32 {vr(V_TMP)}, {sg('t2')}",
+          "@VMLOAD@",
+          "@VMWAIT@",
+          f"v_readfirstlane_b32 {sg('nid')}, {vr(V_TMP)}",
+          f"s_cmp_lg_u64 {sg('tile_list', 2)}, 0",
+          f"s_cselect_b32 {sg('nid')}, {sg('nid')}, {sg('ntile')}"]
+    L += decode_only("nid", "nb", "ni0", "nj0")
+    L += next_tile_addresses()
+    return L
+
+
+def decode_only(tid, b, i0, j0):
+    return [f"s_mul_hi_u32 {sg(b)}, {sg(tid)}, {sg('magic_per')}",
+            f"s_mul_i32 {sg('t4')}, {sg(b)}, {sg('per')}",
+            f"s_sub_i32 {sg('t4')}, {sg(tid)}, {sg('t4')}",
+            f"s_mul_hi_u32 {sg(i0)}, {sg('t4')}, {sg('magic_nb')}",
+            f"s_mul_i32 {sg(j0)}, {sg(i0)}, {sg('NB')}",
+            f"s_sub_i32 {sg(j0)}, {sg('t4')}, {sg(j0)}",
+            f"s_lshl_b32 {sg(i0)}, {sg(i0)}, 4",
+            f"s_lshl_b32 {sg(j0)}, {sg(j0)}, 4"]
+
+
 def prologue_loads():
     """First tile: its rows / masks / z (the 'next tile' machinery pointed at it) and ring stages 0, 1, 2; everything waited for."""
     L = [it.text for it in dma_rows()]
@@ -977,8 +1090,8 @@ def generate(stats_out=None):
     stream, stats = sc.run()
     if stats_out is not None:
         stats_out.extend(stats)
-    if PROF:
-        stream = stamp(0) + stream
+    if PROF:                                   # (s3 keeps the previous tile's stamp 7: "bias tiles -> end of the tile" = this stamp 0 - s3)
+        stream = [raw("s_mov_b32 s3, s11")] + stamp(0) + stream
     body = stream
     if "nobar" in WHATIF:
         body = [it for it in body if it.text != "s_barrier"]
@@ -995,12 +1108,7 @@ def generate(stats_out=None):
     lines.append("; ---- the prefetched tile becomes the current one; pick, decode and address the next")
     for d, s_ in (("cid", "nid"), ("b", "nb"), ("i0", "ni0"), ("j0", "nj0")):
         lines.append(f"s_mov_b32 {sg(d)}, {sg(s_)}")
-    lines += cur_tile_addresses()
-    lines.append(f"s_add_i32 {sg('ntile')}, {sg('tile')}, {sg('NWG')}")
-    lines.append(f"s_cmp_lt_i32 {sg('ntile')}, {sg('nwork')}")
-    lines.append(f"s_cselect_b32 {sg('ntile')}, {sg('ntile')}, {sg('tile')}")      # no next tile: prefetch this one again (valid addresses)
-    lines += decode_tile("ntile", "nid", "nb", "ni0", "nj0", "dec1")
-    lines += next_tile_addresses()
+    # (this tile's output addresses and the next tile's decode run on the scalar unit inside the stream: chain TOP)
     lines.append("; ---- tile body: head, 792 MFMAs with everything else in their issue slots")
     lines += finalize(body)
     lines.append(f"s_add_i32 {sg('tile')}, {sg('tile')}, {sg('NWG')}")
@@ -1013,6 +1121,7 @@ def generate(stats_out=None):
                   "s_mov_b64 exec, 1", f"v_mov_b32 {vr(TQ + 1)}, 0"]
         for k in range(N_STAMP):
             lines += [f"v_mov_b32 {vr(TQ)}, {sr(4 + k)}", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * k}"]
+        lines += [f"v_mov_b32 {vr(TQ)}, s3", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP}"]
     lines.append(".Lv5_end%=:")
     lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     txt = ["// GENERATED by gen_et5.py -- do not edit; `python pepflowww_amd/csrc/gen_et5.py` rewrites it, tests/test_host_cpu.py checks it is current.",

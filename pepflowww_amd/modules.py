@@ -228,11 +228,11 @@ class GAEncoder(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             try:
-                eng = DenoiseEngine(w, B, L, device, precision=prec, owner=self)
+                eng = DenoiseEngine(w, B, L, device, precision=prec, owner=self, options=getattr(self, "engine_options", None))
             except torch.cuda.OutOfMemoryError:
                 self._engines.clear()            # every cached engine goes; one retry
                 torch.cuda.empty_cache()
-                eng = DenoiseEngine(w, B, L, device, precision=prec, owner=self)
+                eng = DenoiseEngine(w, B, L, device, precision=prec, owner=self, options=getattr(self, "engine_options", None))
             self._engines[key] = eng
             self._trim(device, key)
         else:

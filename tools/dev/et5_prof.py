@@ -34,6 +34,8 @@ names = ["loop top -> first MFMA (head)", "G1(0), G1(1)", "G2(0) .. G2(5) (432 M
 d = [(t[:, :, k + 1] - t[:, :, k]) & 0xffffffff for k in range(0, 7)]
 tot = ((t[:, :, 7] - t[:, :, 0]) & 0xffffffff).float()
 print(f"stamped part of a tile: mean {tot.mean():.0f} cycles, min {tot.min():.0f}, max {tot.max():.0f}")
+end = ((t[:, :, 0] - t[:, :, 8]) & 0xffffffff).float()
+print(f"bias tiles + exposed rest (previous tile's stamp 7 -> this tile's top): mean {end.mean():.0f}  (MFMA floor 768)   whole tile = {tot.mean() + end.mean():.0f} cycles (floor 25344)")
 floors = [0, 48, 432, 72, 48, 96, 48]
 for k, nm in enumerate(names[:7]):
     x = d[k].float()

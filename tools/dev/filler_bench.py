@@ -59,10 +59,24 @@ for kind in KINDS:
             asm = "\n".join('        "' + l + '\\n\\t"' for l in lines)
             clob = ", ".join(f'"v{i}"' for i in range(0, 190)) + ", " + ", ".join(f'"a{i}"' for i in range(0, 256)) + ', "s20","s21","s22","s23","s24","s25","s26","s27","memory","vcc","scc"'
             src.append(f'__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void {nm}(unsigned* out) {{\n    extern __shared__ unsigned char sm[];\n    unsigned off = (blockIdx.x * 4 + threadIdx.x / 64) * 4; unsigned tid = threadIdx.x & 63;\n    asm volatile(\n{asm}\n        : : "s"(out), "v"(tid), "v"(off) : {clob});\n}}')
+KINDS["v_pk_add_f32"] = lambda i: f"v_pk_add_f32 v[{100 + 2 * (i % 8)}:{101 + 2 * (i % 8)}], v[{100 + 2 * (i % 8)}:{101 + 2 * (i % 8)}], v[120:121]"
+KINDS["v_pk_fma_f32"] = lambda i: f"v_pk_fma_f32 v[{100 + 2 * (i % 8)}:{101 + 2 * (i % 8)}], v[{100 + 2 * (i % 8)}:{101 + 2 * (i % 8)}], v[120:121], v[122:123]"
+KINDS["v_pk_mul_f32"] = lambda i: f"v_pk_mul_f32 v[{100 + 2 * (i % 8)}:{101 + 2 * (i % 8)}], v[{100 + 2 * (i % 8)}:{101 + 2 * (i % 8)}], v[120:121]"
+KINDS["v_fma_f32"] = lambda i: f"v_fma_f32 v{100 + i % 16}, v{100 + i % 16}, v{120 + i % 4}, v{121}"
+KINDS["v_add_dep"] = lambda i: f"v_add_f32 v100, v100, v{120 + i % 4}"
+for kind in ("v_add_f32", "v_add_dep", "v_fma_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_fma_mixlo", "v_fma_mixhi", "v_cvt_pk_f16", "sdwa_cvt", "v_cvt_f32_f16", "accvgpr_read", "accvgpr_write", "split_new", "split_old", "ds_read_b128", "s_add_i32"):
+    nm = f"x_{kind}"
+    names.append((nm, kind, -1, 0))
+    lines = ["s_mov_b32 s20, 0xbf800000", "s_mov_b32 s21, 0", "v_lshlrev_b32 v99, 4, %1", "s_memtime s[24:25]", "s_waitcnt lgkmcnt(0)", ".Lloop%=:"] + [KINDS[kind](i) for i in range(48)] + \
+            ["s_add_i32 s21, s21, 1", "s_cmp_lt_i32 s21, 200", "s_cbranch_scc1 .Lloop%=", "s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7", "s_memtime s[26:27]", "s_waitcnt lgkmcnt(0)",
+             "s_sub_u32 s26, s26, s24", "v_mov_b32 v98, s26", "global_store_dword %2, v98, %0"]
+    asm = "\n".join('        "' + l + '\\n\\t"' for l in lines)
+    clob = ", ".join(f'"v{i}"' for i in range(0, 190)) + ", " + ", ".join(f'"a{i}"' for i in range(0, 256)) + ', "s20","s21","s22","s23","s24","s25","s26","s27","memory","vcc","scc"'
+    src.append(f'__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void {nm}(unsigned* out) {{\n    extern __shared__ unsigned char sm[];\n    unsigned off = (blockIdx.x * 4 + threadIdx.x / 64) * 4; unsigned tid = threadIdx.x & 63;\n    asm volatile(\n{asm}\n        : : "s"(out), "v"(tid), "v"(off) : {clob});\n}}')
 src.append("int main() {\n    unsigned* d; hipMalloc(&d, 256 * 4 * 4); std::vector<unsigned> h(1024);")
 for nm, kind, k, agpr in names:
     src.append(f'    hipLaunchKernelGGL({nm}, dim3(256), dim3(256), 65536, 0, d); hipDeviceSynchronize(); hipLaunchKernelGGL({nm}, dim3(256), dim3(256), 65536, 0, d); hipDeviceSynchronize();\n'
-               f'    hipMemcpy(h.data(), d, 4096, hipMemcpyDeviceToHost); {{ double s = 0; for (int i = 0; i < 1024; ++i) s += h[i]; printf("{kind:16s} k={k} acc={"agpr" if agpr else "vgpr"}: %.1f cycles per MFMA\\n", s / 1024 / 1600.0); }}')
+               f'    hipMemcpy(h.data(), d, 4096, hipMemcpyDeviceToHost); {{ double s = 0; for (int i = 0; i < 1024; ++i) s += h[i]; printf("{kind:16s} k={k} acc={"agpr" if agpr else "vgpr"}: %.2f cycles per {"MFMA" if k >= 0 else "instruction (no MFMAs)"}\\n", s / 1024 / {1600.0 if k >= 0 else 9600.0}); }}')
 src.append("    return 0;\n}")
 open("tools/dev/filler_bench.hip", "w").write("\n".join(src))
 print("kernels:", len(names))
