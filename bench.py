@@ -189,6 +189,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             ck.lap("sampler_init_ms")                                # once per call: noise H2D + state init
             engines = [eng]
         info["z16"] = bool(getattr(engines[0], "z16", False))
+        info["et_v5"] = all(bool(getattr(e, "et_v5", False)) for e in engines)
         if use_graph and smp.needs_capture():
             smp.capture()                                            # (runs the plan once eagerly first: kernel attribute set-up)
         ck.lap("graph_capture_ms")                                   # once per (B, L, num_steps): two hipGraphs (1 and 4 steps)
@@ -229,22 +230,36 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             evs = {}
             st = _capi.stream_ptr()
             for _ in range(min(K, 10)):
-                for entry in [en for e in engines for en in e.plan]:
-                    fn, a, name = entry[0], entry[1], entry[2]
-                    if fn is None:
-                        continue
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    rc = fn(*a, st) if isinstance(a, tuple) else fn(a, st)
-                    e1.record()
-                    evs.setdefault(name, []).append((e0, e1))
-                    assert rc == 0, name
+                for bi_, e in enumerate(engines):
+                    for entry in e.plan:
+                        fn, a, name = entry[0], entry[1], entry[2]
+                        if fn is None:
+                            continue
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        rc = fn(*a, st) if isinstance(a, tuple) else fn(a, st)
+                        e1.record()
+                        evs.setdefault((name, bi_), []).append((e0, e1))
+                        assert rc == 0, name
             torch.cuda.synchronize()
             n_it = min(K, 10)
-            nb = len(engines)        # (length buckets: a "launch" below = one launch per bucket, i.e. one pass over ALL the batch's pairs / rows)
-            info["kernel_us"] = {k: {"avg_launch_us": sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e3 * nb,
-                                     "launches_per_step": len(v) // n_it // nb,
-                                     "us_per_step": sum(a.elapsed_time(b) for a, b in v) / n_it * 1e3} for k, v in evs.items()}
+            # Aggregated per (entry point, bucket) first (an entry point that only ONE bucket's plan launches -- the projection's
+            # own launch exists for L > 128 only -- must not be normalised by the bucket count).  Per entry point: us_per_step = the sum over
+            # the buckets, launches_per_step = the launches of one step over all buckets, avg_launch_us = us_per_step / (launches per step
+            # and bucket that has it) = the time of "one launch over the whole batch" (one per bucket that runs it, timed one after the other).
+            per = {}
+            for (name, bi_), v in evs.items():
+                us = sum(a.elapsed_time(b) for a, b in v) / n_it * 1e3
+                d = per.setdefault(name, {"us_per_step": 0.0, "launches_per_step": 0, "per_bucket": []})
+                d["us_per_step"] += us
+                d["launches_per_step"] += len(v) // n_it
+                d["per_bucket"].append({"bucket": bi_, "launches_per_step": len(v) // n_it, "us_per_step": round(us, 3)})
+            for name, d in per.items():
+                lpb = max(b_["launches_per_step"] for b_ in d["per_bucket"])          # launches per step in a bucket that has the entry point
+                d["avg_launch_us"] = d["us_per_step"] / max(1, lpb)
+                if len(engines) == 1:
+                    del d["per_bucket"]
+            info["kernel_us"] = per
     return elapsed, info
 
 
@@ -421,13 +436,16 @@ def main():
     et_s = ku["pf_edge_transition_fwd"]["avg_launch_us"] * 1e-6
     ipa_s = ku["pf_ipa_attn_fwd"]["avg_launch_us"] * 1e-6
     traffic, traffic_src, traffic_stale = pmc_traffic(args.workload, prec)
-    t_et = (traffic.get("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") or traffic.get("edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
+    # which EdgeTransition kernel this plan launches: the hand-scheduled stream (v5) for the fp32-parity step with the pair tensor in
+    # fragment order, the 32x32 kernel (v4) for other fp32 forms, the 16x16x32 kernel (v3) in the f16 mode
+    et_kernel = "edge_transition_v3_kernel" if prec != "fp32" else ("edge_transition_v5_kernel" if info.get("et_v5") else "edge_transition_v4_kernel")
+    t_et = (traffic.get(et_kernel) or traffic.get("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
     t_ipa = (traffic.get("ipa_two_kernel_form") or traffic.get("ipa_attn_kernel") or {}).get("hbm_bytes_corrected")
     step_us = sum(v["us_per_step"] for v in ku.values())
     share = {k: round(v["us_per_step"] / step_us, 3) for k, v in sorted(ku.items(), key=lambda kv: -kv[1]["us_per_step"])}
     dominant = next(iter(share))
     rf_et = {
-        "kernel": ("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") + " (pf_edge_transition_fwd)", "bound": "mfma",
+        "kernel": et_kernel + " (pf_edge_transition_fwd)", "bound": "mfma",
         "achieved": pairs * ET_FLOPS_EXEC / et_s / 1e12, "peak": MFMA_F16_PEAK / split / 1e12, "unit": "TFLOP/s",
         "frac": pairs * ET_FLOPS_EXEC * split / et_s / MFMA_F16_PEAK, "traffic": t_et,
         "traffic_note": f"HBM bytes per launch from {traffic_src} (separate rocprofv3 --pmc passes); algorithmic = 512 B/pair = {pairs * ET_BYTES} B "

@@ -6,7 +6,7 @@ Public surface mirrors the reference (models_con/flow_model.py, models_con/ga.py
 All arithmetic of the denoise step runs in libpepflow_hip.so (include/pepflow_hip.h).
 """
 from .config import AttrDict, default_config  # noqa: F401
-from .flow_model import FlowModel  # noqa: F401
+from .flow_model import FlowModel, PepflowRangeError  # noqa: F401
 from .modules import GAEncoder  # noqa: F401
 
-__all__ = ["FlowModel", "GAEncoder", "AttrDict", "default_config"]
+__all__ = ["FlowModel", "GAEncoder", "AttrDict", "default_config", "PepflowRangeError"]

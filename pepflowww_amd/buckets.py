@@ -211,7 +211,9 @@ class BucketedSampler:
         for st in self._streams[:len(self.samplers)]:
             cur.wait_stream(st)
 
-    CALIBRATE = True      # measure which stream assignment lets the buckets overlap (once per process, device and bucket count)
+    CALIBRATE = True      # class-wide switch; per call: FlowModel.sample(..., calibrate=False) / BucketedSampler.calibrate
+    MAX_PROBES = 12       # bound of the candidate search (each probe = a few steps of the call on one stream assignment)
+    calibrate = True
 
     def _choose_streams(self, use_graph):
         """Which HIP stream each bucket runs on -- MEASURED once per process, device and bucket count.  Two streams do not always run
@@ -236,12 +238,18 @@ class BucketedSampler:
             for b, st in zip(rest, other_streams):
                 out[b] = st
             return out
-        if n in cache:
-            return by_role(*cache[n])
+        #  the choice is kept per bucket SHAPES (sorted (samples, padded length) roles), not per bucket count: which streams
+        # overlap depends on how long each bucket's kernels hold the chip
+        ckey = tuple(sorted((s.eng.B, s.eng.L) for s in self.samplers))
+        if ckey in cache:
+            return by_role(*cache[ckey])
         cands = [torch.cuda.Stream() for _ in range(n + 3)]
-        if not self.CALIBRATE or n < 2:
-            cache[n] = (cands[0], cands[1:n])
-            return by_role(*cache[n])
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not (self.CALIBRATE and self.calibrate) or n < 2 or capturing:      # (no timed probes inside a caller's stream capture)
+            if not capturing:
+                cache[ckey] = (cands[0], cands[1:n])
+                return by_role(*cache[ckey])
+            return by_role(cands[0], cands[1:n])
         k = max(1, min(4, self.N))
 
         def timed(assign):                    # assign: {bucket: stream}; the other buckets sit this one out
@@ -258,25 +266,28 @@ class BucketedSampler:
         timed({b: cands[0] for b in [big]})                                   # (first use: lazy set-up)
         alone = [min(timed({b: cands[0]}) for _ in range(2)) for b in range(n)]
         serial, best = sum(alone), None
+        probes = 0
         for xi, X in enumerate(cands):                                        # the big bucket's stream ...
             others = [c for c in cands if c is not X]
             for rot in range(len(others)):                                    # ... and the others' (every rotation of the remaining ones)
                 assign = {big: X}
                 assign.update({b: others[(rot + i) % len(others)] for i, b in enumerate(rest)})
                 t = timed(assign)
+                probes += 1
                 if best is None or t < best[0]:
                     best = (t, assign)
-                if t < alone[big] + 0.6 * (serial - alone[big]):              # clearly below "one after the other": take it
+                if t < alone[big] + 0.6 * (serial - alone[big]) or probes >= self.MAX_PROBES:   # clearly below "one after the other" (or enough tried): take it
                     break
             else:
                 continue
             break
-        cache[n] = (best[1][big], [best[1][b] for b in rest])
-        self.calibration = {"steps": k, "alone_ms": [round(a / k * 1e3, 3) for a in alone], "chosen_ms": round(best[0] / k * 1e3, 3)}
+        cache[ckey] = (best[1][big], [best[1][b] for b in rest])
+        self.calibration = {"steps": k, "probes": probes, "alone_ms": [round(a / k * 1e3, 3) for a in alone], "chosen_ms": round(best[0] / k * 1e3, 3)}
         for smp, nz in zip(self.samplers, self._nz):                          # the probe steps moved the states: start over
             smp.init_state(nz)
+        self._nz = []                                                         # (the buckets' noise is not kept alive beyond the calibration)
         torch.cuda.synchronize()
-        return by_role(*cache[n])
+        return by_role(*cache[ckey])
 
     def operand_range(self):
         reps = [e.operand_range() for e in self.engines]

@@ -1097,6 +1097,10 @@ def generate(stats_out=None):
         body = [it for it in body if it.text != "s_barrier"]
     if "nodma" in WHATIF:
         body = [it for it in body if "global_load_lds" not in it.text]
+    if "novalu" in WHATIF:                     # the MFMA stream with its fragment reads, barriers and DMA only
+        body = [it for it in body if it.kind not in ("valu",) or "v_add_u32" in it.text]
+    if "nolds" in WHATIF:
+        body = [it for it in body if not (it.kind == "lds" and "v225" not in it.text and "v224" not in it.text)]
     lines = []
     lines += kernel_setup()
     lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")

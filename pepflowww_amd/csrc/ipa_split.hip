@@ -676,7 +676,7 @@ __device__ __forceinline__ void proj_head16(const pf_ipa_attn_args& a, size_t ro
 // KFRAG (without PROJ): the k rows come from pf_ipa_attn_args.k_frag (fp32 fragments written by the projection launch) -- a COMPILE-TIME
 // variant: as a run-time test inside loadk the branch cost the loop its load pipelining (113 -> 166 us at B=64, L=144, and 136 with the
 // fragments: hipcc drains vmcnt at every control-flow join -- the lesson of round 2 once more).
-template <bool VEC4, bool FUSE = false, bool PROJ = false, bool KFRAG = false, bool KF = false>   // (KF: with PROJ, the keys are the node state: pj_live)  L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
+template <bool VEC4, bool FUSE = false, bool PROJ = false, bool KFRAG = false, bool KF = false, bool HELP = true>   // (HELP: with PROJ, helper waves may exist (L <= 64) -- proj_head's role is a run-time value; false (L > 64): role 0 at compile time, the straight-line prologue;  KF: with PROJ, the keys are the node state: pj_live)  L % 4 == 0: bias / probability rows are read / written as float4; FUSE: pair aggregation on a.dz (fp32) here, P not stored; PROJ: the head's projection here (proj_head)
 __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int nrb, int rows_per_block, int LP, int SLD) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool KSPLIT = PROJ && !FUSE;         // first product on split f16 MFMAs, k rows as hi | lo fragments (proj_head<true>)
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
     const size_t rowb = (size_t)b * L;
     // PROJ with helper waves (blockDim = 2 x the query tiles, L <= 64): wave ntq + w helps query wave w through the prologue and leaves
     const int ntq = rows_per_block >> 4;
-    const bool helper = PROJ && wave >= ntq;
+    const bool helper = PROJ && HELP && wave >= ntq;
     const int i0 = rb * rows_per_block + (helper ? wave - ntq : wave) * 16;
     // Le: keys / query rows from here on are masked (pf_ipa_attn_args.key_end; L without it): nothing beyond is read or written
     const int Le = a.key_end ? min(__builtin_amdgcn_readfirstlane(a.key_end[b]), L) : L;
@@ -759,7 +759,10 @@ __global__ __launch_bounds__(512) void ipa_scores_kernel(pf_ipa_attn_args a, int
         unsigned char* WS = reinterpret_cast<unsigned char*>(SW);      // (the score regions are dead until the barrier below; the launcher
         float* QPW = reinterpret_cast<float*>(WS + PJ_STAGE_B) + (helper ? 0 : wave) * 16 * 24;   //  sizes the allocation for staging + query points)
         float* PB = reinterpret_cast<float*>(WS + PJ_STAGE_B) + ntq * 16 * 24;
-        const int role = (int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0;
+        // (round 6: without helper waves -- every launch beyond L = 64 -- the role is the compile-time constant 0 and proj_head's role tests
+        //  fold away: cfg4 2.788 -> 2.774 ms same box, profiles/r06/r06_straight_ab.txt; the run-time failures once blamed on this form were
+        //  the compiler-formed packed multiply that -fno-slp-vectorize removed)
+        const int role = HELP ? ((int)(blockDim.x >> 6) > ntq ? (helper ? 2 : 1) : 0) : 0;
         const int VTG = (L + 31) & ~31;                // key stride of the value planes (pf_ipa_attn_args.att_vt as this launch's scratch)
         _Float16* VTH = reinterpret_cast<_Float16*>(const_cast<void*>(a.att_vt)) + ((size_t)b * H + h) * 512 * VTG;   // values 256 VTG | k rows 256 VTG (as f16 counts)
         proj_head<KSPLIT, KF>(a, rowb, iq, h, i0 + r, LPe, wave_on, role, helper ? wave - ntq : wave, KP, reinterpret_cast<_Float16*>(VP), pj_vtl(LP), VTH, VTG, WS, QPW,
@@ -1800,10 +1803,14 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
         if (pj) {
             static PfOncePerDevice attr_pj;
             if (attr_pj.first()) {
-                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, false, true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)ipa_scores_kernel<true, true, true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
             // the score regions double as the weight staging buffers + the waves' query-point regions during the prologue
             const size_t need = fixed + (size_t)PJ_STAGE_B + (size_t)wpb * 16 * 24 * sizeof(float) + (size_t)PJ_TILES * 16 * sizeof(float);
@@ -1811,11 +1818,15 @@ int pf_ipa_split_launch(const pf_ipa_attn_args* a, hipStream_t s) {
             if (ldsp > 160 * 1024) return PF_E_TOOLARGE;
             // L <= 64: as many helper waves as query waves for the prologue (proj_head roles)
             const int nwv = wpb <= 4 ? 2 * wpb : wpb;
+#define PF_SCORES_PJ(FUSEv, KFv) do { \
+                if (nwv != wpb) hipLaunchKernelGGL((ipa_scores_kernel<true, FUSEv, true, false, KFv, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD); \
+                else hipLaunchKernelGGL((ipa_scores_kernel<true, FUSEv, true, false, KFv, false>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD); } while (0)
             if (a->k_from_s) {
-                if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
-                else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
-            } else if (fuse) hipLaunchKernelGGL((ipa_scores_kernel<true, true, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
-            else hipLaunchKernelGGL((ipa_scores_kernel<true, false, true>), dim3((unsigned)(a->B * H * nrb)), dim3(64 * nwv), ldsp, s, *a, nrb, 16 * wpb, LP, SLD);
+                if (fuse) PF_SCORES_PJ(true, true);
+                else PF_SCORES_PJ(false, true);
+            } else if (fuse) PF_SCORES_PJ(true, false);
+            else PF_SCORES_PJ(false, false);
+#undef PF_SCORES_PJ
         } else if (planes) {
             const int L32 = (L + 31) & ~31, SLD16 = L32 + 4 < 36 ? 36 : L32 + 4;
             const size_t fixed16 = ((size_t)L * KPS + L) * sizeof(float), pw16 = (size_t)16 * SLD16 * sizeof(float);

@@ -115,9 +115,16 @@ def all_gather_final_state(sampler, group=None, sizes=None):
     return unpack_state(all_gather_packed(local, sizes, group))
 
 
+SEEDED_NOISE_VERSION = 2     # stream layout of seeded_noise: 1 = rounds 1-4 (four draws per sample), 2 = round 5 on (one normal block [L,27] +
+                             # one uniform block [L,5] per sample).  Results of sample(seed=...) without explicit noise are comparable only
+                             # between builds of the same version; tests/golden/f12_seeded_noise.npz pins version 2.
+
+
 def seeded_noise(lo, hi, L, seed):
     """Initial noise of the GLOBAL samples [lo, hi) as a pure function of (seed, global sample index): one torch CPU
     generator per sample, so a shard draws exactly the rows the unsharded run draws, for every world size.
+    The mapping (seed, sample) -> noise is VERSIONED (SEEDED_NOISE_VERSION) and pinned by a golden fixture: it is part of what a caller
+    who passes seed= gets back, and it changed once (round 5).
     Two draws per sample (one normal block, one uniform block, split afterwards) and the quaternion -> rotation algebra once for the
     whole shard: the per-sample Python work is what a call pays on the host (round 4: four draws + ten small tensor ops per sample,
     5 - 15 ms per 64 samples)."""

@@ -2,6 +2,9 @@
 state_dict layout, `sample()` signature and return format) running on hand-written gfx950
 kernels.  See INTEGRATION.md for how train.py / inference.py pick it up.
 """
+import gc
+import threading
+
 import torch
 from torch import nn
 
@@ -52,6 +55,25 @@ def _pad_residues(batch, noise, L0, L):
         else:
             nz[k] = _pad_axis1(v, L - L0, 0)
     return out, nz
+
+
+_GC_LOCK = threading.Lock()
+_GC_STATE = {"depth": 0, "was": True}      # sample() calls in flight in this process and the collector's state the first of them found
+
+
+class PepflowRangeError(_capi.PepflowHipError):
+    """An activation left the range the split-precision matrix products can carry (|x| > 65504): the result of the call is not the
+    fp32 reference's (the reference forces fp32 where range matters, openfold/utils/rigid_utils.py:327-329)."""
+
+
+def _raise_if_saturated(rep, precision):
+    over = {k: v for k, v in rep.items() if k not in ("limit", "ok") and not (v <= rep["limit"])}
+    if over:
+        raise PepflowRangeError(
+            "pepflowww_amd: activations left the f16 range of the matrix operands (" + ", ".join(f"{k}={v:.4g}" for k, v in over.items()) +
+            f" > {rep['limit']:g}): " + ("the hi | lo split saturated there, the fp32-parity contract (1e-4) does not hold for this call"
+                                          if precision == "fp32" else "the f16 mode overflowed") +
+            " -- rescale the checkpoint or run the reference for this input (INTEGRATION.md, numeric range); sample(check_range=False) skips the verdict")
 
 
 class FlowModel(nn.Module):
@@ -114,20 +136,27 @@ class FlowModel(nn.Module):
         full collection costs 60 - 180 ms in a process that holds a few engines, and it used to land in whatever phase allocated the
         object that tripped it -- five of eight first-visit calls of the per-call benchmark (profiles/r05/README.md, gc trace).  The
         one collection a call does need runs where it is free: while the device works through the step loop (GC_UNDER_LOOP)."""
-        import gc
-        was = gc.isenabled()
-        if was:
-            gc.disable()
-        self._gc_was_enabled = was
+        # (ADVICE r5: the collector's switch is process-global.  The state lives in a lock-protected counter of calls in flight, not on
+        #  `self`: the FIRST call to enter turns the collector off and remembers what it found, the LAST one to leave restores it -- a
+        #  nested or concurrent call neither re-enables it under another call's host phases nor records "was off" as the state to restore.)
+        with _GC_LOCK:
+            if _GC_STATE["depth"] == 0:
+                _GC_STATE["was"] = gc.isenabled()
+                if _GC_STATE["was"]:
+                    gc.disable()
+            _GC_STATE["depth"] += 1
+            was = _GC_STATE["was"]
         try:
-            return self._sample_impl(batch, num_steps, sample_bb, sample_ang, sample_seq, **kw)
+            return self._sample_impl(batch, num_steps, sample_bb, sample_ang, sample_seq, _gc_was_enabled=was, **kw)
         finally:
-            if was:
-                gc.enable()
+            with _GC_LOCK:
+                _GC_STATE["depth"] -= 1
+                if _GC_STATE["depth"] == 0 and _GC_STATE["was"]:
+                    gc.enable()
 
     def _sample_impl(self, batch, num_steps=100, sample_bb=True, sample_ang=True, sample_seq=True, *,
                noise=None, seed=None, first_sample=0, use_graph=True, return_sampler=False, timings=None, pageable=False, check_range=True,
-               buckets="auto"):
+               buckets="auto", gc_collect=True, calibrate=True, _gc_was_enabled=None):
         """Reference signature + keyword-only extensions:
         noise        dict(rot0, trans0, ang0, simplex0[, expo]) of pre-drawn noise (parity tests);
         seed         Philox seed for the in-kernel categorical draws (default: from torch's CPU generator); with noise=None an
@@ -147,6 +176,11 @@ class FlowModel(nn.Module):
                      BASELINE configs[2]); False: one engine at the batch's padded length, whatever the samples' lengths; a tuple of
                      padded-length bounds: those bucket edges.  Samples are independent, so the values agree with the unsplit run
                      to kernel-form precision (~1e-6) and the in-kernel draws are keyed by the caller's sample index either way;
+        gc_collect   (default on) run ONE full pass of the cyclic collector while the device works through the step loop of a long call
+                     (it is held off for the rest of the call); False: no collection inside sample() -- an embedding application that
+                     schedules its own;
+        calibrate    (default on) length buckets only: the first bucketed call of a (device, bucket shapes) pair times a few steps on
+                     candidate HIP stream assignments and keeps the first that overlaps (buckets.py); False: take the default streams;
         timings      optional dict: filled with the wall-clock seconds of the call's phases (noise / engine / encode / bind / setup /
                      capture / loop / d2h; each phase is followed by a device synchronisation when this is given -- bench.py's
                      per-call accounting)."""
@@ -175,7 +209,7 @@ class FlowModel(nn.Module):
             plan = _bk.plan_length_buckets(_bk.sample_lengths(batch["res_mask"]), edges)
             if len(plan) > 1:
                 return self._sample_bucketed(plan, batch, num_steps, (sample_bb, sample_ang, sample_seq), noise, seed, first_sample,
-                                             use_graph, return_sampler, timings, pageable, check_range, stamp)
+                                             use_graph, return_sampler, timings, pageable, check_range, stamp, gc_collect, calibrate, _gc_was_enabled)
         # Residue axis padded to a multiple of 16 internally (what PaddingCollate does to a shorter sample of a batch: pad values,
         # res_mask False -- padded residues are inert, tests/test_gpu_parity.py ragged cases): every kernel then runs its
         # full-tile path (16-row / 16-key tiles, float4 rows of the [B,8,L,L] buffers).  In-kernel random draws are keyed by
@@ -208,9 +242,8 @@ class FlowModel(nn.Module):
         # trajectory), so a loop over complexes triggers full collections anyway -- 15 - 90 ms each, in whatever host phase they hit
         # (BENCH r05: three of eight warm calls, 180 of 295 ms of all overhead); collecting here, under >= ~40 ms of device work,
         # takes them out of the call's critical path.  Only when the collector is enabled at all.
-        if self.GC_UNDER_LOOP and B * L * L * num_steps >= self.GC_MIN_PAIR_STEPS:
-            import gc
-            if getattr(self, "_gc_was_enabled", gc.isenabled()):
+        if gc_collect and self.GC_UNDER_LOOP and B * L * L * num_steps >= self.GC_MIN_PAIR_STEPS:
+            if gc.isenabled() if _gc_was_enabled is None else _gc_was_enabled:
                 gc.collect()
         stamp("loop")
         if check_range:
@@ -218,6 +251,7 @@ class FlowModel(nn.Module):
             # per CALL, not per step): loud, because no trained checkpoint could be tried in this build
             rep = eng.operand_range()
             self.last_range_report = rep
+            _raise_if_saturated(rep, eng.precision)
             if not rep["ok"]:
                 import warnings
                 warnings.warn("pepflowww_amd: activations reached " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if k not in ("limit", "ok")) +
@@ -233,7 +267,7 @@ class FlowModel(nn.Module):
         return traj
 
     def _sample_bucketed(self, plan, batch, num_steps, flags, noise, seed, first_sample, use_graph, return_sampler, timings, pageable,
-                         check_range, stamp):
+                         check_range, stamp, gc_collect=True, calibrate=True, _gc_was_enabled=None):
         """sample() of a ragged batch through its length buckets (pepflowww_amd/buckets.py): same inputs, noise, Philox streams and
         output format as the unsplit path."""
         from .buckets import BucketedSampler
@@ -243,19 +277,20 @@ class FlowModel(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         smp = BucketedSampler(self, plan, B, L, num_steps, flags)
+        smp.calibrate = bool(calibrate)
         smp.bind(batch, noise, L0, seed, first_sample, stamp)
         if use_graph and timings is not None and smp.needs_capture():
             smp.capture()
             stamp("capture")
         smp.run(num_steps, use_graph=use_graph)
-        if self.GC_UNDER_LOOP and B * L * L * num_steps >= self.GC_MIN_PAIR_STEPS:
-            import gc
-            if getattr(self, "_gc_was_enabled", gc.isenabled()):
+        if gc_collect and self.GC_UNDER_LOOP and B * L * L * num_steps >= self.GC_MIN_PAIR_STEPS:
+            if gc.isenabled() if _gc_was_enabled is None else _gc_was_enabled:
                 gc.collect()
         stamp("loop")
         if check_range:
             rep = smp.operand_range()
             self.last_range_report = rep
+            _raise_if_saturated(rep, getattr(self.ga_encoder, "_precision", "fp32"))
             if not rep["ok"]:
                 import warnings
                 warnings.warn("pepflowww_amd: activations reached " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if k not in ("limit", "ok")) +

@@ -167,7 +167,8 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
                     next_dz=None, single_pass=False, dz_f16=False, z_frag=False):
     """w1/w2/wf: fp32 reference-layout weights; split into the f16 hi/lo planes the kernel takes.
     persistent=True: the 16x16x32 LDS-ring kernel (w_stream, csrc/edge_transition_v3.hip); "v4": the 32x32 kernel
-    (w_stream32 / wb_frags32, csrc/edge_transition_v4.hip).
+    (w_stream32 / wb_frags32, csrc/edge_transition_v4.hip); "v5": additionally w_stream64 (csrc/edge_transition_v5.hip takes the call when
+    it has the form that kernel covers: z_frag, next_bias, fp32 mode, 32 <= L, L % 16 == 0).
     next_dz: down_z.weight [16,64] of the next IPA block (with next_bias): also returns dz [B,L,L,16] = W_dz z'."""
     from pepflowww_amd.engine import split_f16, pack_et_stream
     lib = _capi.load()
@@ -179,7 +180,7 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
     a.ln_g, a.ln_b, a.mask, a.B, a.L = _p(ln_g), _p(ln_b), _p(mask), B, L
     ws = pack_et_stream(w1[:, :64], w2, wf) if persistent else None
     a.w_stream = _p(ws)
-    if persistent == "v4":
+    if persistent in ("v4", "v5"):
         from pepflowww_amd.engine import pack_et_stream32, pack_bias_frags32
         ws32 = pack_et_stream32(w1[:, :64], w2, wf, z_frag=z_frag)
         a.w_stream32 = _p(ws32)
@@ -187,6 +188,10 @@ def edge_transition(z, pre, w1, w2, b2, wf, ln_g, ln_b, mask, B, L, inplace=Fals
             from pepflowww_amd.engine import z_to_frag
             zf = z_to_frag(z.reshape(B, L, L, 64))
             a.z_in, a.z_in_frag, a.z_out_frag = _p(zf), 1, 1
+        if persistent == "v5":     # the hand-scheduled kernel's stream (pf_edge_transition_args.w_stream64, csrc/edge_transition_v5.hip); it takes
+            from pepflowww_amd.engine import pack_et_stream64       # fragment-ordered calls with a pair bias, every other form falls through to v4
+            ws64 = pack_et_stream64(w1[:, :64], w2, wf)
+            a.w_stream64 = _p(ws64)
         if next_bias is not None:
             wbf32 = pack_bias_frags32(next_bias[0], next_dz if next_dz is not None else torch.zeros(16, 64, device=z.device))
             a.wb_frags32 = _p(wbf32)

@@ -327,7 +327,7 @@ def test_engine_options_are_validated_and_noise_is_shard_invariant():
     import inspect
     from pepflowww_amd import distributed as D
     from pepflowww_amd.engine import DenoiseEngine
-    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_zfrag", "k_frag", "et_last_store", "o_premul", "k_fold"}
+    assert set(DenoiseEngine.OPTIONS) == {"fused_proj", "fused_pair", "et_v4", "et_v5", "et_zfrag", "k_frag", "et_last_store", "o_premul", "k_fold"}
     assert "options" in inspect.signature(DenoiseEngine.__init__).parameters
     with pytest.raises(AssertionError):
         DenoiseEngine(None, 1, 16, torch.device("cpu"), options={"no_such_switch": True})
@@ -549,6 +549,120 @@ def test_lds_dma_bases_are_never_fresh_valu_results():
     assert dma > 500, dma
     assert not bad, (len(bad), bad[:5])
     print(f"{dma} LDS-DMA instructions, none reads an SGPR inside the wait states of the v_readfirstlane that wrote it")
+
+
+def test_generated_edge_transition_stream_is_current():
+    """csrc/edge_transition_v5_body.inc is GENERATED (csrc/gen_et5.py: the hand-scheduled EdgeTransition's instruction stream).  The
+    committed file must be what the script writes today -- an edit of the generator that was not followed by a regeneration (or an
+    edit of the .inc by hand) fails here -- and the stream must hold exactly the 792 MFMAs of a tile with every s_waitcnt in range."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_et5", os.path.join(ROOT, "pepflowww_amd", "csrc", "gen_et5.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.generate()
+    assert text == open(gen.OUT).read(), "run: python pepflowww_amd/csrc/gen_et5.py"
+    assert text.count("v_mfma_f32_32x32x16_f16") == 792
+    assert gen.LDS_BYTES <= 160 * 1024
+    src = open(os.path.join(ROOT, "pepflowww_amd", "csrc", "edge_transition_v5.hip")).read()
+    assert f"ET5_LDS_BYTES = {gen.LDS_BYTES};" in src, "the launcher's dynamic LDS size is not the generator's LDS map"
+    for m in re.finditer(r"vmcnt\((\d+)\)", text):
+        assert int(m.group(1)) <= 63
+    for m in re.finditer(r"lgkmcnt\((\d+)\)", text):
+        assert int(m.group(1)) <= 15
+    # every register the stream names lies inside the ranges the kernel declares as clobbered (v0..v253, a0..a255, s12..s97)
+    assert max(int(x) for x in re.findall(r"\bv(\d+)\b", text)) <= 253 and max(int(x) for x in re.findall(r"\bv\[(?:\d+):(\d+)\]", text)) <= 253
+    assert max(int(x) for x in re.findall(r"\ba\[(?:\d+):(\d+)\]", text)) <= 255
+    sregs = [int(x) for x in re.findall(r"\bs(\d+)\b", text)] + [int(x) for x in re.findall(r"\bs\[(?:\d+):(\d+)\]", text)]
+    assert max(sregs) <= 97 and min(sregs) >= 12
+
+
+def test_edge_transition_stream64_layout():
+    """engine.pack_et_stream64 (the v5 kernel's weight stream): the cached-gather packer equals the entry-by-entry reference packer bit
+    for bit; 128 entries of 2 KiB; the entry order is the generator's (gen_et5.entries): same kinds and chunk / tile / K-step indices."""
+    import importlib.util
+    from pepflowww_amd import engine as E
+    g = torch.Generator().manual_seed(11)
+    w1z, w2, wf = torch.randn(192, 64, generator=g), torch.randn(192, 192, generator=g), torch.randn(64, 192, generator=g)
+    fast = E.pack_et_stream64(w1z, w2, wf)
+    perm = E._z_frag_perm(w1z.device)
+    ref = E._pack_et_stream64_ref(w1z[:, perm].contiguous(), w2, wf, wf[:, :64][:, perm].contiguous())
+    assert fast.dtype == torch.float16 and fast.numel() == 128 * 1024 and torch.equal(fast, ref)
+    spec = importlib.util.spec_from_file_location("gen_et5", os.path.join(ROOT, "pepflowww_amd", "csrc", "gen_et5.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    # entry e of the packed stream = the fragment the generator's entry e multiplies: rebuild each expected fragment and compare
+    nat, kperm = E._k_nat(w2.device), E._k_perm(w2.device)
+    w1z_p, wfz_p = w1z[:, perm].contiguous(), wf[:, :64][:, perm].contiguous()
+    for e, d in enumerate(gen.ENT):
+        if d["kind"] == "G1":
+            want = E._frag32(w1z_p, d["c"], nat(d["ks"]))
+        elif d["kind"] == "G2":
+            want = E._frag32(w2, d["mt"], kperm(d["c"], d["s"]))
+        elif d["kind"] == "WFZ":
+            want = E._frag32(wfz_p, d["mt"], nat(d["ks"]))
+        else:
+            want = E._frag32(wf, d["mt"], kperm(d["c"], d["s"]))
+        assert torch.equal(fast[e * 1024:(e + 1) * 1024], want), (e, d)
+
+
+def test_sample_holds_the_collector_off_reentrantly_and_range_verdict_raises():
+    """FlowModel.sample() holds the process-global cyclic collector off for its host phases.  Nested / concurrent calls: the
+    first call in turns it off, the LAST one out restores what the first found (host logic: _sample_impl stubbed).  VERDICT r5 item 8:
+    an activation beyond the f16 range of the matrix operands RAISES (PepflowRangeError), half of that range still warns."""
+    import gc
+    from pepflowww_amd import flow_model as F
+    model = pepflowww_amd.FlowModel(pepflowww_amd.default_config())
+    seen = []
+
+    def fake(self, batch, num_steps, bb, ang, seq, _gc_was_enabled=None, depth=0, **kw):
+        seen.append((depth, gc.isenabled(), _gc_was_enabled))
+        if depth < 2:
+            type(self).sample(self, batch, depth=depth + 1)          # a nested call (an embedding application's callback, a second thread)
+            seen.append((depth, gc.isenabled(), "after-nested"))
+        return depth
+    orig = F.FlowModel._sample_impl
+    F.FlowModel._sample_impl = fake
+    try:
+        assert gc.isenabled()
+        model.sample({}, depth=0)
+        assert gc.isenabled() and F._GC_STATE["depth"] == 0
+        assert all(not en for _, en, _ in seen), seen                      # off in every phase of every call, also behind a nested return
+        assert all(w is True for _, _, w in seen if w != "after-nested")   # every call knows the collector WAS on when the outermost entered
+        gc.disable()
+        try:
+            seen.clear()
+            model.sample({}, depth=2)
+            assert not gc.isenabled() and seen[0][2] is False              # a process that runs with the collector off keeps it off
+        finally:
+            gc.enable()
+    finally:
+        F.FlowModel._sample_impl = orig
+    with pytest.raises(pepflowww_amd.PepflowRangeError):
+        F._raise_if_saturated({"node_state": 3.0, "pair_tensor": 7.0e4, "limit": 65504.0, "ok": False}, "fp32")
+    with pytest.raises(pepflowww_amd.PepflowRangeError):
+        F._raise_if_saturated({"node_state": float("inf"), "limit": 65504.0, "ok": False}, "f16")
+    F._raise_if_saturated({"node_state": 4.0e4, "limit": 65504.0, "ok": False}, "fp32")      # beyond half the range: the warning's business
+    assert issubclass(pepflowww_amd.PepflowRangeError, _capi.PepflowHipError)
+
+
+def test_seeded_noise_mapping_is_pinned(golden_dir):
+    """FlowModel.sample(seed=...) without explicit noise draws its initial noise per GLOBAL sample from
+    distributed.seeded_noise; that mapping is versioned (SEEDED_NOISE_VERSION) and pinned bit for bit by F12
+    (tests/golden/make_golden_seeded_noise.py) -- a change of the stream layout must bump the version and regenerate the fixture.
+    A shard draws the rows of the full run (world-size independence)."""
+    import numpy as np
+    from pepflowww_amd.distributed import SEEDED_NOISE_VERSION, seeded_noise
+    g = np.load(os.path.join(golden_dir, "f12_seeded_noise.npz"))
+    assert int(g["version"]) == SEEDED_NOISE_VERSION == 2
+    for seed, lo, hi, L in ((0, 0, 2, 5), (1234, 7, 9, 6)):
+        nz = seeded_noise(lo, hi, L, seed)
+        for k, v in nz.items():
+            assert np.array_equal(v.numpy(), g[f"s{seed}_{lo}_{hi}_{L}_{k}"]), (seed, k)
+    full, part = seeded_noise(0, 9, 6, 1234), seeded_noise(7, 9, 6, 1234)
+    assert all(torch.equal(full[k][7:], part[k]) for k in full)
+    R = full["rot0"]
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand_as(R), atol=1e-5)
 
 
 def test_length_bucket_plan_and_sub_batches():

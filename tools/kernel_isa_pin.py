@@ -28,8 +28,10 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 # the instantiations that run a projection prologue: fp32 mode without / with the pair phase, f16 mode
 # (template parameters: ipa_scores_kernel<VEC4, FUSE, PROJ, KFRAG, KF>, ipa_scores16_kernel<FUSE, PROJ, KF>; KF = keys from the node state, ABI 58)
-PINNED = ("ipa_scores_kernelILb1ELb0ELb1ELb0ELb0EE", "ipa_scores_kernelILb1ELb1ELb1ELb0ELb0EE", "ipa_scores16_kernelILb1ELb1ELb0EE",
-          "ipa_scores_kernelILb1ELb0ELb1ELb0ELb1EE", "ipa_scores_kernelILb1ELb1ELb1ELb0ELb1EE", "ipa_scores16_kernelILb1ELb1ELb1EE")
+# (template parameters: ipa_scores_kernel<VEC4, FUSE, PROJ, KFRAG, KF, HELP>, ipa_scores16_kernel<FUSE, PROJ, KF>; KF = keys from the node state, ABI 58;
+#  HELP (round 6) = helper waves may exist: the L <= 64 launches; HELP = false: the straight-line prologue of every launch beyond 64)
+PINNED = tuple(f"ipa_scores_kernelILb1ELb{fuse}ELb1ELb0ELb{kf}ELb{hp}EE" for hp in (1, 0) for kf in (0, 1) for fuse in (0, 1)) + \
+         ("ipa_scores16_kernelILb1ELb1ELb0EE", "ipa_scores16_kernelILb1ELb1ELb1EE")
 
 
 def tools_present():
@@ -94,10 +96,10 @@ def main():
     if "--update" in sys.argv:
         pin = {"hipcc": hipcc_version(),
                "validated_by": "library built with -fno-slp-vectorize (no compiler-formed packed fp32 instruction: profiles/r05/r05_pkmul_bisect.txt), hi | lo "
-                               "splits through pf_pin, query points handed over in registers: 0 of 20 000 launches in each of three kernel forms "
-                               "(keys from the state / projected, fused form), bit-identical to the packed build launch by launch "
-                               "(tools/dev/r05_launch_trace.py), GPU suite profiles/r05/r05fin9_gputest.log, fresh-process campaign "
-                               "profiles/r05/r05_campaign_noslp.txt, tests/test_gpu_fresh_process.py",
+                               "splits through pf_pin, query points handed over in registers.  HELP = true instantiations (L <= 64, run-time roles) and the f16 "
+                               "kernels: the machine code of round 5 (0 of 20 000 launches in each of three kernel forms, profiles/r05/r05_campaign_noslp.txt).  "
+                               "HELP = false instantiations (round 6: straight-line prologue beyond L = 64): fresh-process campaign "
+                               "profiles/r06/r06_campaign_straight.txt (0 of 96 processes, six shapes x two modes), tests/test_gpu_fresh_process.py, the GPU suite",
                "kernels": got}
         with open(PIN, "w") as f:
             json.dump(pin, f, indent=1, sort_keys=True)

@@ -2,9 +2,9 @@
 # PMC passes over one kernel of the bench (run ON the GPU box through gpurun):
 #   tools/pmc_kernel.sh <kernel-substring> <workload> [extra bench args]
 # Counters only with --kernel-trace (never with sys/hip/hsa trace domains).  Summary -> gpurun_out/pmc_<kernel>_<workload>.txt
-K=${1:-edge_transition_kernel}; W=${2:-cfg4}; shift 2
+K=${1:-edge_transition_v5_kernel}; W=${2:-cfg4}; shift 2
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-OUT=gpurun_out/pmc_${K}_${W}
+OUT=gpurun_out/pmc_${PMC_TAG:-$(echo $K | cut -d, -f1)}_${W}
 rm -rf $OUT && mkdir -p $OUT
 PASSES=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES"
@@ -17,7 +17,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  PF_BENCH_NO_SCLK=1 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-secondary "$@" > $OUT/p$i.log 2>&1
+  PF_BENCH_NO_SCLK=1 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --no-modes --no-per-call "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python - "$OUT" "$K" <<'PY'
