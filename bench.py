@@ -189,7 +189,7 @@ def run_sampler(wl, K, W, dev, dist, rank, world, use_graph, precision, time_ker
             ck.lap("sampler_init_ms")                                # once per call: noise H2D + state init
             engines = [eng]
         info["z16"] = bool(getattr(engines[0], "z16", False))
-        info["et_v5"] = all(bool(getattr(e, "et_v5", False)) for e in engines)
+        info["et_v5"] = all(bool(getattr(e, "et_v5", False) or getattr(e, "et_v5h", False)) for e in engines)
         if use_graph and smp.needs_capture():
             smp.capture()                                            # (runs the plan once eagerly first: kernel attribute set-up)
         ck.lap("graph_capture_ms")                                   # once per (B, L, num_steps): two hipGraphs (1 and 4 steps)
@@ -287,7 +287,7 @@ def pmc_traffic(workload, precision):
     """HBM bytes per launch of the two big kernels from the PMC passes recorded under profiles/ (rocprofv3 cannot run
     inside this process; tools/pmc_traffic.sh regenerates the file); corrected as MI355X_MICROARCH.md prescribes.
     Returns (per-kernel dict, source string, stale): stale = the file was recorded for other kernel sources than the ones timed here."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 d = json.load(f)
@@ -297,6 +297,18 @@ def pmc_traffic(workload, precision):
         except Exception:
             continue
     return {}, None, None
+
+
+def pmc_counters(workload, precision, kernel):
+    """SQ counter summary of one kernel from profiles/r06/pmc_counters.json (tools/pmc_kernel.sh + tools/pmc_summary.py: separate rocprofv3
+    --pmc passes, never in this process): (dict or None, source string)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06", "pmc_counters.json")) as f:
+            d = json.load(f)
+        key = workload if precision == "fp32" else f"{workload}_{precision}"
+        return d[key][kernel], "profiles/r06/pmc_counters.json"
+    except Exception:
+        return None, None
 
 
 def sclk_under_load(smp, use_graph):
@@ -438,7 +450,8 @@ def main():
     traffic, traffic_src, traffic_stale = pmc_traffic(args.workload, prec)
     # which EdgeTransition kernel this plan launches: the hand-scheduled stream (v5) for the fp32-parity step with the pair tensor in
     # fragment order, the 32x32 kernel (v4) for other fp32 forms, the 16x16x32 kernel (v3) in the f16 mode
-    et_kernel = "edge_transition_v3_kernel" if prec != "fp32" else ("edge_transition_v5_kernel" if info.get("et_v5") else "edge_transition_v4_kernel")
+    et_kernel = (("edge_transition_v5h_kernel" if info.get("et_v5") else "edge_transition_v3_kernel") if prec != "fp32"
+                 else ("edge_transition_v5_kernel" if info.get("et_v5") else "edge_transition_v4_kernel"))
     t_et = (traffic.get(et_kernel) or traffic.get("edge_transition_v4_kernel" if prec == "fp32" else "edge_transition_v3_kernel") or {}).get("hbm_bytes_corrected")
     t_ipa = (traffic.get("ipa_two_kernel_form") or traffic.get("ipa_attn_kernel") or {}).get("hbm_bytes_corrected")
     step_us = sum(v["us_per_step"] for v in ku.values())
@@ -456,6 +469,12 @@ def main():
         "achieved_reference_flops": pairs * ET_FLOPS_REF / et_s / 1e12,
         "hbm_achieved_GBps": pairs * ET_BYTES / et_s / 1e9,
     }
+    cnt, cnt_src = pmc_counters(args.workload, prec, et_kernel)
+    if cnt is not None:
+        rf_et["mfma_busy"] = cnt["mfma_busy"]
+        rf_et["mfma_busy_note"] = (f"SQ_VALU_MFMA_BUSY_CYCLES / SIMD / launch cycles from {cnt_src} (recorded under rocprofv3, separate --pmc passes); "
+                                   f"waves parked {cnt['wave_cycles_parked']}, issue-stalled {cnt['wave_cycles_issue_stalled']} of their cycles, "
+                                   f"LDS bank conflicts {cnt['lds_bank_conflict_frac_of_lds_cycles']} of the LDS cycles")
     rf_ipa = {
         "kernel": "ipa attention (pf_ipa_attn_fwd)", "bound": "hbm",
         "achieved": pairs * IPA_BYTES / ipa_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

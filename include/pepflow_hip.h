@@ -426,7 +426,11 @@ typedef struct {
      * execution order of the hand-scheduled kernel (csrc/edge_transition_v5.hip: one 512-register wave per SIMD, every fragment
      * feeding 64 pairs, GEMM2 K-outer) -- pepflowww_amd.engine.pack_et_stream64(..., z_frag=True).  When set and the call has that
      * form, that kernel runs; any other form of call falls through to w_stream32 / w_stream as before.  Same inputs, outputs and
-     * work-list semantics; results differ from the 32x32 kernel's only by the summation order inside the fp32 accumulators. */
+     * work-list semantics; results differ from the 32x32 kernel's only by the summation order inside the fp32 accumulators.
+     * f16 mode (single_pass with z_in_f16 / z_out_f16 / dz_out_f16 and the frag flags): w_stream64 = the hi planes only (128 KiB,
+     * pack_et_stream64(..., f16=True)) and the f16 pair tensor in THAT kernel's fragment order (pepflowww_amd.engine.z16_to_frag64: block
+     * (tile, 32-pair group) of 4 KiB = K-step (1 KiB) x lane (the 8 halves of its MFMA operand)) -- not the 16x16x32 kernel's: a
+     * single_pass call with w_stream64 set that the kernel does not cover is REFUSED (PF_E_BADARG) instead of falling through. */
     const void* w_stream64;
 } pf_edge_transition_args;
 int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_stream_t stream);

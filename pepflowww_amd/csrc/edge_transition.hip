@@ -22,7 +22,9 @@ extern "C" int pf_edge_transition_fwd(const pf_edge_transition_args* a, pf_strea
         return PF_E_BADARG;
     if (a->w_stream64) {                                         // hand-scheduled form: covers the inference step's calls (fp32 mode, fragment order)
         const int rc = pf_edge_transition_v5_launch(a, (hipStream_t)stream);
-        if (rc != PF_E_BADARG) return rc;
+        // (f16 mode: that kernel's fragment order of the f16 pair tensor is its own -- a call it does not take must not fall through
+        //  to the 16x16x32 kernel, which would read the tensor in ANOTHER order)
+        if (rc != PF_E_BADARG || a->single_pass) return rc;
     }
     if (a->w_stream32 && !(a->dump_h1 || a->dump_h2 || a->dump_y)) return pf_edge_transition_v4_launch(a, (hipStream_t)stream);
     if (a->w_stream) return pf_edge_transition_v3_launch(a, (hipStream_t)stream);

@@ -93,6 +93,8 @@ def zk(t, ks):
 
 
 def zop(t, ks):
+    if SP:                                     # f16 pair tensor: the loaded 16 bytes ARE the operand (Z[0..7] stays free for temporaries)
+        return Z0 + 8 + 4 * (4 * t + ks)
     return Z0 + 8 * zk(t, ks)
 
 
@@ -180,6 +182,13 @@ def split8(src, dst, relu, need_lds=(), need_vm=()):
     lo without v_fma_mix: hi back to fp32 (v_cvt_f32_f16, the high half through SDWA), x - hi in fp32 (exact: the difference has at
     most 13 significant bits), one v_cvt_pk_f16_f32 per pair -- the same bits as the single-rounded fma, six plain VALU per pair."""
     out = []
+    if SP:                                     # f16 mode: round, then ReLU on the packed halves (signed-integer max with 0, as v3)
+        for k in range(4):
+            out.append(valu(f"v_cvt_pk_f16_f32 {vr(dst + k)}, {vr(src + 2 * k)}, {vr(src + 2 * k + 1)}", need_lds if k == 0 else (), need_vm if k == 0 else ()))
+        if relu:
+            for k in range(4):
+                out.append(valu(f"v_pk_max_i16 {vr(dst + k)}, {vr(dst + k)}, 0"))
+        return out
     if not MIX:
         if relu:
             for k in range(8):
@@ -325,7 +334,7 @@ class Sched:
 def dma_stage(st):
     """This wave's 8 pieces (contiguous 8 KiB) of tile-relative ring stage st into the slot s_slot_wr."""
     out = [salu(f"s_add_i32 {sg('woff')}, {sg('woff')}, 0x{STAGE_B:x}"),
-           salu(f"s_and_b32 {sg('woff')}, {sg('woff')}, 0x3ffff"),
+           salu(f"s_and_b32 {sg('woff')}, {sg('woff')}, 0x{NST * STAGE_B - 1:x}"),
            salu(f"s_add_u32 {sg('wp')}, {sg('w_stream')}, {sg('woff')}"),
            salu(f"s_addc_u32 {sr(S['wp'] + 1)}, {sr(S['w_stream'] + 1)}, 0"),
            salu(f"s_add_i32 m0, {sg('slot_wr')}, {sg('w8192')}"),
@@ -376,6 +385,11 @@ def dma_rows():
 
 def z_loads():
     zl = []
+    if SP:                                     # block (tile, 2 w + t) = 4 KiB = K-step ks (1 KiB) x lane (16 bytes = the 8 halves of its operand)
+        for t in range(2):
+            for ks in range(4):
+                zl.append(vmem(f"global_load_dwordx4 {vr(zop(t, ks), 4)}, {vr(V_ZOFF + t)}, {sg('zin_next', 2)} offset:{ks * 1024}", "zraw"))
+        return zl
     for t in range(2):
         for k in range(8):
             p = 8 * t + k                      # 1 KiB piece p of the wave's 16 KiB: offset p * 1024 = j * 4096 + imm
@@ -399,7 +413,8 @@ def tile_head():
           lds(f"ds_read_b32 {vr(TQ + 2)}, {vr(V_RL4)} offset:8", "mki1")]
     global MIX
     keep, MIX = MIX, True                      # exposed code: the form with fewer instructions
-    it += zsplit(0, 0, need_vm=("zraw",)) + zsplit(1, 0)
+    if not SP:
+        it += zsplit(0, 0, need_vm=("zraw",)) + zsplit(1, 0)
     MIX = keep
     it += [valu(f"v_mul_f32 {vr(V_MK)}, {vr(TQ)}, {vr(TQ + 1)}", need_lds=("mkj", "mki0")),
            valu(f"v_mul_f32 {vr(V_MK + 1)}, {vr(TQ)}, {vr(TQ + 2)}", need_lds=("mki1",)),
@@ -424,24 +439,43 @@ def stamp(k):
 # ---- MFMA positions.  Entries 0..111: six MFMAs each (t0 / t1 alternating over the three products).  The last 16 entries (the final
 # layer on h2 chunks 2..5 = ring stage 7) run as TWO passes, group 0 then group 1 (their fragments are read twice), so that group 0's
 # LayerNorm / stores / operand split have the 48 MFMAs of pass B to hide under; then the two [linear_b; down_z] tiles.
-N_MAIN, PA0, PB0, BI0, N_MF = 112, 672, 720, 768, 792
+N_MAIN = 112
+SP = False        # --f16: the f16 precision mode (pf_edge_transition_args.single_pass): ONE MFMA per product (hi planes only), f16 pair tensor
+
+
+def configure(sp):
+    """Mode-dependent constants: products per (entry, group), entries per 32 KiB ring stage, bytes per entry, stages per tile, MFMA positions."""
+    global SP, NPG, EPS, ENT_B, NST, PA0, PB0, BI0, N_MF, OUT
+    SP = bool(sp)
+    NPG = 1 if SP else 3
+    EPS, ENT_B, NST = (32, 1024, 4) if SP else (16, 2048, 8)
+    PA0 = 2 * NPG * N_MAIN
+    PB0 = PA0 + 16 * NPG
+    BI0 = PB0 + 16 * NPG
+    N_MF = BI0 + 8 * NPG
+    OUT = os.path.join(HERE, "edge_transition_v5h_body.inc" if SP else "edge_transition_v5_body.inc")
+
+
+configure(False)
 
 
 def mi(e, j=0):
+    """MFMA j of main entry e; j counts the fp32 mode's six (2 * product + group): in the f16 mode the entry's two MFMAs are j = 0, 1 and
+    a caller's "last" (j = 5) means its second."""
     assert e < N_MAIN or e < 0, e
-    return 6 * e + j
+    return 2 * NPG * e + (min(j, 1) if SP else j)
 
 
 def pa(e, p=0):
-    return PA0 + 3 * (e - N_MAIN) + p
+    return PA0 + NPG * (e - N_MAIN) + min(p, NPG - 1)
 
 
 def pb(e, p=0):
-    return PB0 + 3 * (e - N_MAIN) + p
+    return PB0 + NPG * (e - N_MAIN) + min(p, NPG - 1)
 
 
 def bi(t, q, p=0):
-    return BI0 + 12 * t + 3 * q + p
+    return BI0 + 4 * NPG * t + NPG * q + min(p, NPG - 1)
 
 
 def ep_regs(t):
@@ -485,6 +519,9 @@ def ln_packed(t, Y, a):
     # gamma / beta quads: three pairs in flight -- TQ, and the second y block of group 0 (dead behind its split)
     Y0 = ep_regs(0)[0]
     quads = [(TQ, TQ + 4), (Y0[1], Y0[1] + 4), (Y0[1] + 8, Y0[1] + 12)]
+    if t == 0:                                 # (f16 mode, group 0: its own y lives there -- the z region beyond the f16 operands is free instead)
+        assert SP
+        quads = [(TQ, TQ + 4), (Z0 + 40, Z0 + 44), (Z0 + 48, Z0 + 52)]
     rd = lambda n: [lds(f"ds_read_b128 {vr(quads[n % 3][0], 4)}, {vr(V_CSADDR)} offset:{(32 * (n // 4) + 8 * (n % 4)) * 4}", f"gm{t}{n}"),
                     lds(f"ds_read_b128 {vr(quads[n % 3][1], 4)}, {vr(V_CSADDR)} offset:{(64 + 32 * (n // 4) + 8 * (n % 4)) * 4}", f"bt{t}{n}")]
     pre = rd(0) + rd(1) + rd(2)
@@ -574,13 +611,19 @@ def epilogue_tail(t, short_split):
             p = 8 * t + 4 * mt + b
             blk.append(f"global_store_dwordx4 {vr(V_ZOFF + p // 4)}, {vr(Y[mt] + 4 * b, 4)}, {sg('zout', 2)} offset:{(p % 4) * 1024}")
     blk.append("s_mov_b64 exec, -1")
-    a.append(Ins("\n".join(blk), "raw", w=8.0))
+    if SP:       # f16 pair tensor: what is stored is the operand the NEXT launch multiplies -- K-step q (1 KiB) x lane (the 8 halves of X[q])
+        blk = [f"s_mov_b64 exec, {sr(12, 2)}"] + [f"global_store_dwordx4 {vr(V_ZOFF + t)}, {vr(X[q], 4)}, {sg('zout', 2)} offset:{q * 1024}" for q in range(4)] + ["s_mov_b64 exec, -1"]
+        store = Ins("\n".join(blk), "raw", w=4.0)
+    else:
+        a.append(Ins("\n".join(blk), "raw", w=8.0))
     # operand planes of z' (no ReLU): K-step q = 2 mt + s2 = registers 16 mt + 8 s2 .. + 7 of z'
     global MIX
     keep, MIX = MIX, MIX or short_split
     for q in range(4):
         a += split8(Y[q // 2] + 8 * (q % 2), X[q], False)
     MIX = keep
+    if SP:
+        a.append(store)
     # behind the [linear_b; down_z] tile: pair bias [B,8,L,L] (heads 4 g + e, one plane = hs bytes apart), pair values
     f = [lds(f"ds_read_b128 {vr(TQ, 4)}, {vr(V_CSADDR)} offset:{320 * 4}", f"bb{t}")]
     for k in range(4):
@@ -595,6 +638,12 @@ def epilogue_tail(t, short_split):
     blk = [f"s_mov_b64 exec, {sr(14, 2)}",
            f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 4, 4)}, {sg('dz', 2)}",
            f"global_store_dwordx4 {vr(V_DZOFF + t)}, {vr(BM + 8, 4)}, {sg('dz', 2)} offset:32", "s_mov_b64 exec, -1"]
+    if SP:                                     # pair values as f16 (pf_edge_transition_args.dz_out_f16)
+        for k in range(4):
+            f.append(valu(f"v_cvt_pk_f16_f32 {vr(BM + 12 + k)}, {vr(BM + 4 + 2 * k)}, {vr(BM + 5 + 2 * k)}"))
+        blk = [f"s_mov_b64 exec, {sr(14, 2)}",
+               f"global_store_dwordx2 {vr(V_DZOFF + t)}, {vr(BM + 12, 2)}, {sg('dz', 2)}",
+               f"global_store_dwordx2 {vr(V_DZOFF + t)}, {vr(BM + 14, 2)}, {sg('dz', 2)} offset:16", "s_mov_b64 exec, -1"]
     f.append(Ins("\n".join(blk), "raw", w=2.0))
     return a, f
 
@@ -605,6 +654,8 @@ def build_stream():
     # the drain phase and the first two chunks carry more than 4 per MFMA; the K loop has idle gaps to spread into (3 per gap measured
     # 517 cycles per tile better than 4, 6 measured 854 worse)
     pb_cap = float(os.environ.get("GEN_ET5_PBCAP", "6.0"))
+    if SP:                                     # a third of the MFMAs, most of the VALU work: six per gap everywhere (37 cycles per MFMA, filler_bench)
+        tail_cap = mid_cap = pb_cap = float(os.environ.get("GEN_ET5_SPCAP", "6.0"))
     sc.cap_fn = lambda g: pb_cap if g >= PB0 else (tail_cap if (g >= mi(84) or g < mi(8)) else mid_cap)
     # ---- fragment uses in order: entries 0..127 (pass A for the last sixteen), their second reading for pass B, the two bias tiles
     uses = [("E", e) for e in range(128)] + [("B", e) for e in range(N_MAIN, 128)] + [("W", t, q) for t in range(2) for q in range(4)]
@@ -622,11 +673,11 @@ def build_stream():
     def three(u, acc, ag, x, tag, first_c0=False):
         w = wreg(u)
         out = []
-        for prod in range(3):
+        for prod in ((1,) if SP else range(3)):   # f16 mode: w.h x.h only
             a_, b_ = w + (4 if prod == 2 else 0), x + (4 if prod == 0 else 0)
-            need = (tag + "h",) if prod == 0 else ((tag + "l",) if prod == 2 else ())
+            need = (tag + "h",) if prod == (1 if SP else 0) else ((tag + "l",) if prod == 2 else ())
             d_ = ar(acc, 16) if ag else vr(acc, 16)
-            c_ = "0" if (first_c0 and prod == 0) else d_
+            c_ = "0" if (first_c0 and prod == (1 if SP else 0)) else d_
             out.append(Ins(f"v_mfma_f32_32x32x16_f16 {d_}, {vr(a_, 4)}, {vr(b_, 4)}, {c_}", "mfma", need_lds=need, w=0.0))
         return out
 
@@ -635,7 +686,7 @@ def build_stream():
         if use[0] == "E" and use[1] < N_MAIN:
             e = use[1]
             ops = [three(u, *operand(ENT[e], t), f"U{u}") for t in range(2)]
-            seq = [ops[j & 1][j >> 1] for j in range(6)]
+            seq = [ops[j & 1][j >> 1] for j in range(2 * NPG)]
         elif use[0] in ("E", "B"):
             t = 0 if use[0] == "E" else 1
             seq = three(u, *operand(ENT[use[1]], t), f"U{u}")
@@ -648,6 +699,9 @@ def build_stream():
             sc.mfma(m)
         last_of[u] = len(sc.mf) - 1
     assert len(sc.mf) == N_MF and first_of[128] == PB0 and first_of[144] == BI0
+    if SP:
+        for j in range(2):
+            sc.mf[j].need_vm = ("zraw",)
 
     # ---- chain HEAD: forced in front of MFMA 0
     sc.fill("HEAD", tile_head(), after=-1, before=0, prio=1)
@@ -658,14 +712,19 @@ def build_stream():
         if use[0] == "W":
             base, off = V_L16, WB + 2048 * use[2]
         else:
-            base, off = V_WADDR, (use[1] % 16) * 2048
-        return [lds(f"ds_read_b128 {vr(w, 4)}, {vr(base)} offset:{off}", f"U{u}h"), lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(base)} offset:{off + 1024}", f"U{u}l")]
+            base, off = V_WADDR, (use[1] % EPS) * ENT_B
+        rd = [lds(f"ds_read_b128 {vr(w, 4)}, {vr(base)} offset:{off}", f"U{u}h")]
+        if not SP:
+            rd.append(lds(f"ds_read_b128 {vr(w + 4, 4)}, {vr(base)} offset:{off + 1024}", f"U{u}l"))
+        return rd
 
     def barrier_block(st):
         # B(st), in the gap in front of the LAST fragment use of stage st (its fragments are requested just above): every wave has
         # confirmed its own pieces of stage st + 1 and holds everything it will read of stage st in registers; behind the barrier
         # stage st + 1 is complete for everybody and the slot of stage st takes stage st + 3
-        return [Ins("", "wait_vm", need_vm=(f"stg{(st + 1) % 8}",), w=0.0),
+        # (the last barrier of a tile also confirms the next tile's row pieces: in the f16 mode they are issued behind B(2), i.e. behind
+        #  the pieces of the stage that barrier waits for)
+        return [Ins("", "wait_vm", need_vm=(f"stg{(st + 1) % NST}",) + (("rows",) if st == NST - 1 else ()), w=0.0),
                 Ins("s_waitcnt lgkmcnt(0)", "wait_lds_all", w=0.0),
                 Ins("s_barrier", "raw", w=0.0),
                 salu(f"s_mov_b32 {sg('slot_wr')}, {sg('slot_rd')}"),
@@ -674,21 +733,21 @@ def build_stream():
                 salu(f"s_cselect_b32 {sg('slot_rd')}, 0x{RING:x}, {sg('slot_rd')}"),
                 valu(f"v_add_u32 {vr(V_WADDR)}, {sg('slot_rd')}, {vr(V_L16)}")]
 
-    last_use_of_stage = {st: 16 * st + 15 for st in range(7)}
-    last_use_of_stage[7] = 143                 # pass B of entry 127
+    last_use_of_stage = {st: EPS * st + EPS - 1 for st in range(NST - 1)}
+    last_use_of_stage[NST - 1] = 143           # pass B of entry 127
     for u in range(len(uses)):
         sc.fill("W", wreads(u), after=last_of[u - 3] if u >= 3 else -1, before=first_of[u], prio=0)
         for st, lu in last_use_of_stage.items():
             if lu == u:
                 g = first_of[u] - 1
                 sc.fill("W", barrier_block(st), after=g, before=g + 1, prio=0)
-                d_items = dma_stage((st + 3) % 8)
-                if st == 4:
+                d_items = dma_stage((st + 3) % NST)
+                if st == (2 if SP else 4):
                     d_items = d_items + dma_rows()     # every wave is past the last reader of the rows (seeds of chunk 5, the m3 seeds)
                 # one LDS-DMA piece every few MFMAs (an LDS-DMA instruction costs its wave 60 - 185 cycles of issue: eight in a row
                 # right behind the barrier, in all four waves at once, stall the matrix pipes and skew the waves)
                 npieces = sum(it.kind == "vmem" for it in d_items)
-                span = 84 if st < 7 else 20
+                span = (84 if st < 7 else 20) if not SP else (52 if st < 3 else 6)
                 step, k = max(1, span // npieces), 0
                 for it in d_items:
                     sc.fill("D", it, after=min(g + step * k, N_MF - 2), before=min(g + step * k + 24, N_MF))
@@ -699,7 +758,8 @@ def build_stream():
     keep, MIX = MIX, os.environ.get("GEN_ET5_ZMIX", "1") == "1"   # 24 instead of 48 instructions per K-step: they have the six gaps of ONE entry
     for ks in range(1, 4):
         for t in range(2):                     # (octet order: zk(t, ks) ascending)
-            sc.fill("ZS", zsplit(t, ks), after=-1, before=mi(first_entry(lambda d: d["kind"] == "G1" and d["ks"] == ks)))
+            if not SP:
+                sc.fill("ZS", zsplit(t, ks), after=-1, before=mi(first_entry(lambda d: d["kind"] == "G1" and d["ks"] == ks)))
     MIX = keep
 
     # ---- chain A2S: GEMM2's accumulators start from b2 (LDS -> AGPR, no VALU)
@@ -745,7 +805,7 @@ def build_stream():
                 sc.fill("ACT", items, after=after, before=dl)
 
     # ---- the epilogues, one chain behind the drains (they share TQ): group 0 under pass B, group 1 behind it
-    ep0, fin0 = epilogue_items(0)
+    ep0, fin0 = epilogue_items(0, packed=SP and os.environ.get("GEN_ET5_EP0PACKED", "1") == "1")   # (f16 mode: 16 MFMAs of pass B hide nothing -- both groups run exposed)
     ep1, fin1 = epilogue_items(1, packed=os.environ.get("GEN_ET5_EP1PACKED", "1") == "1")
     sc.fill("ACT", ep0, after=max(PB0 - 1 + 2, wfz_last + 1), before=BI0)
     sc.fill("ACT", ep1, after=BI0 - 1 + 2, before=bi(1, 0))
@@ -830,7 +890,7 @@ def kernel_setup():
     a("s_nop 2")
     a(f"s_lshl_b32 {sg('w8192')}, {sg('wave')}, 13")
     a(f"s_lshl_b32 {sg('w4')}, {sg('wave')}, 2")
-    a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, 14")
+    a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, {13 if SP else 14}")            # the wave's two blocks of the pair tensor: 2 x 8 KiB (f16: 2 x 4 KiB)
     a(f"v_add_u32 {vr(V_ZOFF)}, {sg('t0')}, {vr(V_L16)}")
     for j in range(1, 4):
         a(f"v_add_u32 {vr(V_ZOFF + j)}, 0x{4096 * j:x}, {vr(V_ZOFF)}")
@@ -873,8 +933,12 @@ def kernel_setup():
         a(f"v_mul_lo_u32 {vr(TQ + 6)}, {vr(TQ + 6)}, {sg('L')}")
         a(f"v_add_lshl_u32 {vr(V_BIASOFF + t)}, {vr(TQ + 6)}, {vr(TQ)}, 2")
         a(f"v_mul_lo_u32 {vr(TQ + 6)}, {vr(TQ + 4)}, {sg('L')}")
-        a(f"v_add_lshl_u32 {vr(TQ + 6)}, {vr(TQ + 6)}, {vr(TQ)}, 6")
-        a(f"v_add_u32 {vr(V_DZOFF + t)}, {vr(TQ + 6)}, {vr(TQ + 3)}")
+        a(f"v_add_lshl_u32 {vr(TQ + 6)}, {vr(TQ + 6)}, {vr(TQ)}, {5 if SP else 6}")
+        if SP:                                 # f16 pair values: 32 bytes per pair, channels 4 g .. at byte 8 g (and + 16)
+            a(f"v_lshrrev_b32 {vr(TQ + 7)}, 1, {vr(TQ + 3)}")
+            a(f"v_add_u32 {vr(V_DZOFF + t)}, {vr(TQ + 6)}, {vr(TQ + 7)}")
+        else:
+            a(f"v_add_u32 {vr(V_DZOFF + t)}, {vr(TQ + 6)}, {vr(TQ + 3)}")
     a(f"s_mul_i32 {sg('hs')}, {sg('L')}, {sg('L')}")
     a(f"s_lshl_b32 {sg('hs')}, {sg('hs')}, 2")
     # constants into LDS: wave 0: ln_g, ln_b; waves 0..2: b2; wave 3 lanes 0..7: b_b
@@ -941,8 +1005,8 @@ def next_tile_addresses():
     """From (nid, nb, ni0, nj0): the z block and the row bases of the NEXT tile (what the stream's prefetches read)."""
     L = []
     a = L.append
-    a(f"s_lshr_b32 {sg('t1')}, {sg('nid')}, 16")
-    a(f"s_lshl_b32 {sg('t0')}, {sg('nid')}, 16")
+    a(f"s_lshr_b32 {sg('t1')}, {sg('nid')}, {17 if SP else 16}")            # tile = 8 blocks of 8 KiB (f16: 4 KiB)
+    a(f"s_lshl_b32 {sg('t0')}, {sg('nid')}, {15 if SP else 16}")
     a(f"s_add_u32 {sg('zin_next')}, {sg('z_in')}, {sg('t0')}")
     a(f"s_addc_u32 {sr(S['zin_next'] + 1)}, {sr(S['z_in'] + 1)}, {sg('t1')}")
     a(f"s_mul_i32 {sg('t2')}, {sg('nb')}, {sg('L')}")
@@ -959,8 +1023,8 @@ def cur_tile_addresses():
     """Output bases of the CURRENT tile from (cid, b, i0, j0)."""
     L = []
     a = L.append
-    a(f"s_lshr_b32 {sg('t1')}, {sg('cid')}, 16")
-    a(f"s_lshl_b32 {sg('t0')}, {sg('cid')}, 16")
+    a(f"s_lshr_b32 {sg('t1')}, {sg('cid')}, {17 if SP else 16}")
+    a(f"s_lshl_b32 {sg('t0')}, {sg('cid')}, {15 if SP else 16}")
     a(f"s_add_u32 {sg('zout')}, {sg('z_out')}, {sg('t0')}")
     a(f"s_addc_u32 {sr(S['zout'] + 1)}, {sr(S['z_out'] + 1)}, {sg('t1')}")
     # bias: (b 8 L L + i0 L + j0) * 4 bytes  (hs = L L 4)
@@ -981,7 +1045,7 @@ def cur_tile_addresses():
     a(f"s_mul_i32 {sg('t0')}, {sg('t2')}, {sg('L')}")
     a(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('j0')}")
     a(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0")
-    a(f"s_lshl_b64 {sg('t0', 2)}, {sg('t0', 2)}, 6")
+    a(f"s_lshl_b64 {sg('t0', 2)}, {sg('t0', 2)}, {5 if SP else 6}")
     a(f"s_add_u32 {sg('dz')}, {sg('dz_out')}, {sg('t0')}")
     a(f"s_addc_u32 {sr(S['dz'] + 1)}, {sr(S['dz_out'] + 1)}, {sg('t1')}")
     return L
@@ -1025,7 +1089,7 @@ def prologue_loads():
     """First tile: its rows / masks / z (the 'next tile' machinery pointed at it) and ring stages 0, 1, 2; everything waited for."""
     L = [it.text for it in dma_rows()]
     L += [it.text for it in z_loads()]
-    L.append(f"s_mov_b32 {sg('woff')}, 0x{(8 - 1) * STAGE_B:x}")                # dma_stage pre-increments (and wraps): first issue = offset 0
+    L.append(f"s_mov_b32 {sg('woff')}, 0x{(NST - 1) * STAGE_B:x}")                # dma_stage pre-increments (and wraps): first issue = offset 0
     for st in range(3):
         L.append(f"s_mov_b32 {sg('slot_wr')}, 0x{RING + st * STAGE_B:x}")
         L += [it.text for it in dma_stage(st)]
@@ -1136,6 +1200,8 @@ def generate(stats_out=None):
 
 
 def main():
+    if "--f16" in sys.argv:
+        configure(True)
     if "--stats" in sys.argv:
         st = []
         generate(st)

@@ -249,16 +249,51 @@ def _pack_et_stream64_ref(w1z_p, w2, wf, wfz_p):
     return stream
 
 
-def pack_et_stream64(w1z, w2, wf):
+def z16_to_frag64(z, out=None):
+    """[B,L,L,64] f16 (L % 16 == 0) -> the fragment order of the hand-scheduled kernel's f16 mode (csrc/edge_transition_v5.hip,
+    edge_transition_v5h_kernel): block (b, 16 x 16 tile (ib, jb), 32-pair group w8 = rows 2 w8, 2 w8 + 1) of 4 KiB = K-step q = 2 mt + s2
+    (1 KiB) x lane g * 32 + rl * 16 + jl (16 bytes) = the 8 halves of that lane's MFMA operand: slot 4 h + e holds channel
+    32 mt + 16 s2 + 8 h + 4 g + e of pair (16 ib + 2 w8 + rl, 16 jb + jl) -- what the kernel stores IS what its next launch multiplies.
+    A pure permutation (layout only)."""
+    B, L = z.shape[0], z.shape[1]
+    assert L % 16 == 0 and z.shape[2] == L and z.shape[3] == 64
+    v = z.reshape(B, L // 16, 8, 2, L // 16, 16, 2, 2, 2, 2, 4)    # b, ib, w8, rl, jb, jl, mt, s2, h, g, e
+    v = v.permute(0, 1, 4, 2, 6, 7, 9, 3, 5, 8, 10)                # b, ib, jb, w8, mt, s2, g, rl, jl, h, e
+    if out is None:
+        return v.contiguous().reshape(B, L, L, 64)
+    out.view(v.shape).copy_(v)
+    return out
+
+
+def z16_from_frag64(zf):
+    """Inverse of z16_to_frag64."""
+    B, L = zf.shape[0], zf.shape[1]
+    v = zf.reshape(B, L // 16, L // 16, 8, 2, 2, 2, 2, 16, 2, 4)   # b, ib, jb, w8, mt, s2, g, rl, jl, h, e
+    return v.permute(0, 1, 3, 7, 2, 8, 4, 5, 9, 6, 10).contiguous().reshape(B, L, L, 64)
+
+
+def pack_et_stream64(w1z, w2, wf, f16=False, _zperm=True, _wf_h2=None):
     """The hand-scheduled kernel's stream (pf_edge_transition_args.w_stream64; layout: _pack_et_stream64_ref), packed with one cached
-    gather.  Always for a fragment-ordered pair tensor (the only form that kernel takes)."""
+    gather.  Always for a fragment-ordered pair tensor (the only form that kernel takes).
+    f16=True: the f16 mode's stream -- hi planes only ([128][512] f16 = 128 KiB) and the z operand in the K order of z16_to_frag64
+    (the order of every other register-resident activation: _k_perm)."""
+    if f16:
+        w1z_, w2_, wf_ = _f32(w1z), _f32(w2), _f32(wf)
+        dev = w2_.device
+        kp = _k_perm(dev)
+        cols = torch.cat([kp(ks // 2, ks % 2)[kg] for ks in range(4) for kg in range(2)])      # natural K position 16 ks + 8 kg + i -> channel
+        full = pack_et_stream64(w1z_[:, cols].contiguous(), w2_, torch.cat([wf_[:, :64][:, cols], wf_[:, 64:]], 1).contiguous(), _zperm=False, _wf_h2=wf_)
+        return full.view(128, 2, 512)[:, 0, :].contiguous().reshape(-1)
     w1z, w2, wf = _f32(w1z), _f32(w2), _f32(wf)
     assert w1z.shape == (192, 64) and w2.shape == (192, 192) and wf.shape == (64, 192)
     for m_, n_ in ((w1z, "trunk.0.weight[:, :64]"), (w2, "trunk.2.weight"), (wf, "final_layer.weight")):
         check_f16_range(m_, n_)
     dev = w2.device
-    perm = _z_frag_perm(dev)
-    mats = [w1z[:, perm].contiguous(), w2, wf, wf[:, :64][:, perm].contiguous()]
+    if _zperm:
+        perm = _z_frag_perm(dev)
+        mats = [w1z[:, perm].contiguous(), w2, wf, wf[:, :64][:, perm].contiguous()]
+    else:                                      # (the caller permuted the z columns already; the final layer ON h2 takes the unpermuted matrix)
+        mats = [w1z, w2, _wf_h2, wf[:, :64].contiguous()]
     key = (64, str(dev))
     if key not in _STREAM_IDX:
         sizes = [m.numel() for m in mats]
@@ -541,6 +576,7 @@ class PackedWeights:
                 t[f"{b}.et.stream32"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf)
                 t[f"{b}.et.stream32f"] = pack_et_stream32(w1[:, :64], g(q + "trunk.2.weight"), wf, z_frag=True)
                 t[f"{b}.et.stream64f"] = pack_et_stream64(w1[:, :64], g(q + "trunk.2.weight"), wf)
+                t[f"{b}.et.stream64h"] = pack_et_stream64(w1[:, :64], g(q + "trunk.2.weight"), wf, f16=True)
                 t[f"{b}.et.wbfrags32"] = pack_bias_frags32(g(f"trunk.ipa_{b + 1}.linear_b.weight"), g(f"trunk.ipa_{b + 1}.down_z.weight"))
                 t[f"{b}.et.pre.w"] = torch.cat([w1[:, 64:128], w1[:, 128:192], wf[:, 64:128], wf[:, 128:192]], 0).contiguous()
                 t[f"{b}.et.pre.b"] = torch.cat([torch.zeros_like(b1), b1, torch.zeros_like(bf), bf], 0).contiguous()
@@ -633,6 +669,9 @@ class DenoiseEngine:
         # the z' store is two contiguous KiB per row instead of four instructions of 8-byte pieces): 208 -> 200 us stand-alone.
         zf_ok = L % 16 == 0 and self.pair_dz is not None and opt.get("et_zfrag", True)
         self.z_frag = zf_ok and ((self.et_v4 and not self.z16) or (self.z16 and not self.et_v4 and self.et_rows == 16))
+        # round 6: the f16 mode of the hand-scheduled EdgeTransition (edge_transition_v5h_kernel): the f16 pair tensor in THAT kernel's
+        # fragment order (z16_to_frag64); every EdgeTransition call of the plan has the form it takes, so nothing falls through to v3
+        self.et_v5h = bool(self.z_frag and self.z16 and 32 <= L <= 4096 and opt.get("et_v5", True))
         self.edge_frag = e(B, L, L, 64, dt=torch.float16 if self.z16 else torch.float32) if self.z_frag else None
         # round 6: the hand-scheduled EdgeTransition stream (csrc/edge_transition_v5.hip, pf_edge_transition_args.w_stream64): one
         # 512-register wave per SIMD, every weight fragment feeding 64 pairs.  Takes the calls of the fp32-parity step with the pair
@@ -795,7 +834,9 @@ class DenoiseEngine:
         if self.z16:                            # one conversion per call (the reference re-reads the fp32 tensor in every step)
             self.edge16.copy_(ee.reshape(B, L, L, 64))
         if self.z_frag:                         # one permutation per call: block 0's EdgeTransition input in fragment order
-            if self.z16:
+            if self.et_v5h:
+                z16_to_frag64(self.edge16, out=self.edge_frag)
+            elif self.z16:
                 z16_to_frag(self.edge16, out=self.edge_frag)
             else:
                 z_to_frag(ee.reshape(B, L, L, 64), out=self.edge_frag)
@@ -993,6 +1034,8 @@ class DenoiseEngine:
                     et.w_stream32, et.wb_frags32 = w[f"{b}.et.stream32f" if self.z_frag else f"{b}.et.stream32"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()
                 if self.et_v5:
                     et.w_stream64 = w[f"{b}.et.stream64f"].data_ptr()
+                if self.et_v5h:
+                    et.w_stream64, et.wb_frags32 = w[f"{b}.et.stream64h"].data_ptr(), w[f"{b}.et.wbfrags32"].data_ptr()
                 et.bb = w[f"{b + 1}.linear_b.b"].data_ptr()
                 et.mask, et.B, et.L = self.mask.data_ptr(), B, L
                 et.single_pass = int(self.precision == "f16")

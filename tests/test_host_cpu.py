@@ -563,6 +563,14 @@ def test_generated_edge_transition_stream_is_current():
     text = gen.generate()
     assert text == open(gen.OUT).read(), "run: python pepflowww_amd/csrc/gen_et5.py"
     assert text.count("v_mfma_f32_32x32x16_f16") == 792
+    gen.configure(True)                                                # the f16 mode's stream (edge_transition_v5h_body.inc)
+    try:
+        text_h = gen.generate()
+        assert text_h == open(gen.OUT).read(), "run: python pepflowww_amd/csrc/gen_et5.py --f16"
+        assert text_h.count("v_mfma_f32_32x32x16_f16") == 264 and "v_fma_mix" not in text_h
+    finally:
+        gen.configure(False)
+    text = text + text_h
     assert gen.LDS_BYTES <= 160 * 1024
     src = open(os.path.join(ROOT, "pepflowww_amd", "csrc", "edge_transition_v5.hip")).read()
     assert f"ET5_LDS_BYTES = {gen.LDS_BYTES};" in src, "the launcher's dynamic LDS size is not the generator's LDS map"
@@ -588,6 +596,15 @@ def test_edge_transition_stream64_layout():
     perm = E._z_frag_perm(w1z.device)
     ref = E._pack_et_stream64_ref(w1z[:, perm].contiguous(), w2, wf, wf[:, :64][:, perm].contiguous())
     assert fast.dtype == torch.float16 and fast.numel() == 128 * 1024 and torch.equal(fast, ref)
+    # f16 mode: hi planes only, the z operand in the K order of the kernel's own f16 fragment order (engine.z16_to_frag64)
+    h = E.pack_et_stream64(w1z, w2, wf, f16=True)
+    assert h.numel() == 128 * 512
+    kp0 = E._k_perm(w2.device)
+    zf = E.z16_to_frag64(torch.arange(64, dtype=torch.float16).expand(1, 16, 16, 64).contiguous())     # every pair holds its channel numbers
+    blk = zf.reshape(8, 4, 64, 8)                                       # [group w8][K-step q][lane][slot]
+    for q in range(4):
+        ch = kp0(q // 2, q % 2)                                         # [kg][slot] -> channel
+        assert torch.equal(blk[3, q, 5 + 32 * 1].long(), ch[1]) and torch.equal(blk[0, q, 17].long(), ch[0])
     spec = importlib.util.spec_from_file_location("gen_et5", os.path.join(ROOT, "pepflowww_amd", "csrc", "gen_et5.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)

@@ -18,7 +18,7 @@ sys.path.insert(0, ".")
 import bench
 res = {"_commit": commit, "_src_sha": bench.kernel_src_sha(),
        "_how": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE, separate pass) --kernel-trace --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-graph --workload W --precision P; per-kernel average of Counter_Value (KiB). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B for wide coalesced 16 B/lane reads -> doubled; WRITE_SIZE as reported."}
-KEYS = ("edge_transition_v5_kernel", "edge_transition_v4_kernel", "edge_transition_v3_kernel", "edge_transition_kernel", "ipa_attn_kernel", "ipa_scores_kernel", "ipa_scores16_kernel", "ipa_pair_kernel", "ipa_pair_dz_kernel", "ipa_pair_dz16_kernel", "linear_split_kernel", "linear_rows_kernel", "node_tfmr_kernel", "node_head_kernel", "node_head32_kernel")
+KEYS = ("edge_transition_v5h_kernel", "edge_transition_v5_kernel", "edge_transition_v4_kernel", "edge_transition_v3_kernel", "edge_transition_kernel", "ipa_attn_kernel", "ipa_scores_kernel", "ipa_scores16_kernel", "ipa_pair_kernel", "ipa_pair_dz_kernel", "ipa_pair_dz16_kernel", "linear_split_kernel", "linear_rows_kernel", "node_tfmr_kernel", "node_head_kernel", "node_head32_kernel")
 for W in ("cfg2", "cfg4"):
     for P in ("fp32", "f16"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
