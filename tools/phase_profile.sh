@@ -3,8 +3,8 @@
 set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/pfprof/lib
-for f in selftest linear edge_transition edge_transition_v3 edge_transition_v4 ipa_attn ipa_split node_ops flow_step encode node_track train_fwd backward ipa_bwd et_bwd full_atom; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPF_PROFILE $PFX $([ $f = edge_transition_v3 ] && echo -fno-slp-vectorize) $([ $f = edge_transition_v4 ] && echo -fno-slp-vectorize -Wno-inline-asm) -c $R/pepflowww_amd/csrc/$f.hip -o /tmp/pfprof/lib/$f.o &
+for f in $(python -c "from pepflowww_amd import build; print(' '.join(x[:-4] for x in build.SOURCES))"); do
+  /opt/rocm/bin/hipcc $(python -c "from pepflowww_amd import build; print(' '.join(build.FLAGS))") -Wno-inline-asm -DPF_PROFILE $PFX -c $R/pepflowww_amd/csrc/$f.hip -o /tmp/pfprof/lib/$f.o 2>/dev/null &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/pfprof/libpepflow_hip.so /tmp/pfprof/lib/*.o
