@@ -12,7 +12,7 @@ for W in cfg2 cfg4; do
   done
 done
 python - "$TAG" "$COMMIT" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, re, sys, collections
 tag, commit = sys.argv[1], sys.argv[2]
 sys.path.insert(0, ".")
 import bench
@@ -46,7 +46,8 @@ for W in ("cfg2", "cfg4"):
                 for row in csv.DictReader(open(f)):
                     k = row["Kernel_Name"]
                     if "anonymous namespace" in k and "at::" not in k and "rocprim" not in k and row["Counter_Name"] == C and "edge_features" not in k and "node_features" not in k:
-                        short = k.split("::")[-1].split("(")[0].split("<")[0].strip()
+                        m_ = re.search(r"(\w+_kernel)\b", k)                  # (a kernel whose ARGUMENT type lives in a namespace: the name is not the last "::" piece)
+                        short = m_.group(1) if m_ else k.split("::")[-1].split("(")[0].split("<")[0].strip()
                         allk[short][C].append(float(row["Counter_Value"]))
         per = {}
         for short, d in allk.items():
