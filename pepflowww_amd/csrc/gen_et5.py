@@ -605,6 +605,10 @@ def epilogue_tail(t, short_split):
     a.append(Ins("\n".join(blk), "raw", w=2.0))
     # z' in fragment order: piece 4 mt + b of block (tile, 2 w + t): byte (8 t + p) * 1024 of the wave's 16 KiB = j * 4096 + imm;
     # no store when z_out is NULL (the last EdgeTransition of a step): the stores run under an all-zero exec mask
+    if t == 1:
+        # the next tile's z must have landed when its head converts it; the wait sits HERE, in front of this group's stores: stores are
+        # not counted in a wait's allowance (finalize), so a wait behind them would also wait for them -- an HBM write round trip at every tile start
+        a.append(Ins("", "wait_vm", need_vm=("zraw",), w=0.0))
     blk = [f"s_mov_b64 exec, {sr(12, 2)}"]
     for mt in range(2):
         for b in range(4):
@@ -631,7 +635,7 @@ def epilogue_tail(t, short_split):
         f.append(valu(f"v_mul_f32 {vr(BM + k)}, 0x3f13cd3a, {vr(BM + k)}"))     # sqrt(1/3), ipa_pytorch.py:404
     f.append(raw(f"s_mov_b64 {sg('t0', 2)}, {sg('bias', 2)}"))
     for k in range(4):
-        f.append(vmem(f"global_store_dword {vr(V_BIASOFF + t)}, {vr(BM + k)}, {sg('t0', 2)}"))
+        f.append(vmem(f"global_store_dword {vr(V_BIASOFF + t)}, {vr(BM + k)}, {sg('t0', 2)}", counted=False))   # (stores are never counted: see finalize)
         if k < 3:
             f.append(raw(f"s_add_u32 {sg('t0')}, {sg('t0')}, {sg('hs')}"))
             f.append(raw(f"s_addc_u32 {sg('t1')}, {sg('t1')}, 0"))
@@ -1108,7 +1112,10 @@ def finalize(body):
     """Two passes over the loop body (the second sees what the first left in flight); returns the text of the second pass.  LDS
     operations and vector memory operations complete in issue order (AMDGPUUsage, memory model GFX6-GFX9: completion is reported
     to a wavefront in execution order), so "operation k has completed" = at most (number of operations issued behind k) outstanding.
-    Conditional stores (counted = False) are left out of that number: the wait is then stricter than needed when they were issued."""
+    That holds for LOADS (LDS-DMA pieces included) among themselves.  STORES are left out of the number (counted = False), all of them:
+    the projection prologue of ipa_split.hip once counted its stores into such an allowance and failed -- a store's vmcnt decrement can
+    overtake an older LDS-DMA piece's (NOTES.md 3.3) -- and the conditional ones may not be issued at all.  Without them the wait is
+    stricter than needed while stores are in flight, never wrong."""
     lds_seq, vm_seq = 0, 0
     lds_tag, vm_tag = {}, {}
     lds_done, vm_done = -1, -1
