@@ -945,41 +945,32 @@ def kernel_setup():
             a(f"v_add_u32 {vr(V_DZOFF + t)}, {vr(TQ + 6)}, {vr(TQ + 3)}")
     a(f"s_mul_i32 {sg('hs')}, {sg('L')}, {sg('L')}")
     a(f"s_lshl_b32 {sg('hs')}, {sg('hs')}, 2")
-    # constants into LDS: wave 0: ln_g, ln_b; waves 0..2: b2; wave 3 lanes 0..7: b_b
+    # constants into LDS, REQUESTED here and written behind the prologue's loads (prologue_loads): every wave ln_g / ln_b of its lane
+    # (four times the same bytes), waves 0..2 b2[64 wave + lane], wave 3 b_b[lane & 7] -- no branch, one round trip shared with the
+    # first tile's inputs instead of three of their own in front of them (a launch of ONE tile per workgroup, B=16 x 64, is mostly prologue)
     a(f"v_lshlrev_b32 {vr(TQ + 4)}, 2, {vr(V_TMP)}")                         # lane * 4
     a(f"v_add_u32 {vr(TQ + 3)}, 0x{CS:x}, {vr(TQ + 4)}")                     # CS + lane * 4
-    a(f"s_cmp_lg_u32 {sg('wave')}, 0")
-    a("s_cbranch_scc1 .Lv5_c1%=")
     a(f"global_load_dword {vr(TQ + 5)}, {vr(TQ + 4)}, {sg('ln_g', 2)}")
     a(f"global_load_dword {vr(TQ + 6)}, {vr(TQ + 4)}, {sg('ln_b', 2)}")
-    a("s_waitcnt vmcnt(0)")
-    a(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 5)}")
-    a(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 6)} offset:256")
-    a(".Lv5_c1%=:")
+    a(f"s_lshl_b32 {sg('t2')}, {sg('wave')}, 8")
     a(f"s_cmp_eq_u32 {sg('wave')}, 3")
-    a("s_cbranch_scc1 .Lv5_c2%=")
-    a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, 8")
-    a(f"v_add_u32 {vr(TQ + 7)}, {sg('t0')}, {vr(TQ + 4)}")                   # (64 wave + lane) * 4
-    a(f"global_load_dword {vr(TQ + 5)}, {vr(TQ + 7)}, {sg('b2', 2)}")
-    a("s_waitcnt vmcnt(0)")
-    a(f"v_add_u32 {vr(TQ + 2)}, {sg('t0')}, {vr(TQ + 3)}")
-    a(f"ds_write_b32 {vr(TQ + 2)}, {vr(TQ + 5)} offset:512")
-    a("s_branch .Lv5_c3%=")
-    a(".Lv5_c2%=:")
-    a(f"s_mov_b64 {sg('ex', 2)}, exec")
-    a("s_mov_b64 exec, 0xff")
-    a(f"global_load_dword {vr(TQ + 5)}, {vr(TQ + 4)}, {sg('bb', 2)}")
-    a("s_waitcnt vmcnt(0)")
-    a(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 5)} offset:1280")
-    a(f"s_mov_b64 exec, {sg('ex', 2)}")
-    a(".Lv5_c3%=:")
+    a(f"s_cselect_b64 {sg('t0', 2)}, {sg('bb', 2)}, {sg('b2', 2)}")
+    a(f"s_cselect_b32 {sg('t2')}, 0, {sg('t2')}")
+    a(f"s_movk_i32 {sg('t3')}, 0xfc")
+    a(f"s_cselect_b32 {sg('t3')}, 0x1c, {sg('t3')}")
+    a(f"s_mov_b32 {sg('t4')}, 0x{CS + 512:x}")
+    a(f"s_cselect_b32 {sg('t4')}, 0x{CS + 1280:x}, {sg('t4')}")
+    a(f"v_and_b32 {vr(TQ + 7)}, {sg('t3')}, {vr(TQ + 4)}")
+    a(f"v_add_u32 {vr(TQ + 7)}, {sg('t2')}, {vr(TQ + 7)}")
+    a(f"v_add_u32 {vr(TQ + 2)}, {sg('t4')}, {vr(TQ + 7)}")
+    a(f"global_load_dword {vr(TQ)}, {vr(TQ + 7)}, {sg('t0', 2)}")
     # the [linear_b; down_z] tile: 8 KiB, two pieces per wave
     a(f"s_lshl_b32 {sg('t0')}, {sg('wave')}, 11")
     a(f"s_add_i32 m0, {sg('t0')}, 0x{WB:x}")
-    a(f"v_add_u32 {vr(TQ + 7)}, {sg('t0')}, {vr(V_L16)}")
+    a(f"v_add_u32 {vr(TQ + 1)}, {sg('t0')}, {vr(V_L16)}")
     a("s_nop 0")
-    a(f"global_load_lds_dwordx4 {vr(TQ + 7)}, {sg('wb_frags', 2)}")
-    a(f"global_load_lds_dwordx4 {vr(TQ + 7)}, {sg('wb_frags', 2)} offset:1024")
+    a(f"global_load_lds_dwordx4 {vr(TQ + 1)}, {sg('wb_frags', 2)}")
+    a(f"global_load_lds_dwordx4 {vr(TQ + 1)}, {sg('wb_frags', 2)} offset:1024")
     return L
 
 
@@ -1099,13 +1090,24 @@ def prologue_loads():
         L += [it.text for it in dma_stage(st)]
     L.append(f"s_mov_b32 {sg('slot_rd')}, 0x{RING:x}")
     L.append(f"v_add_u32 {vr(V_WADDR)}, 0x{RING:x}, {vr(V_L16)}")
-    L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    # the three constant loads of kernel_setup are the oldest: everything issued since may still be in flight
+    n_young = 2 + sum(it.kind == "vmem" for it in dma_rows()) + len(z_loads()) + 3 * 8
+    L.append(f"s_waitcnt vmcnt({n_young})")
+    L.append(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 5)}")
+    L.append(f"ds_write_b32 {vr(TQ + 3)}, {vr(TQ + 6)} offset:256")
+    L.append(f"ds_write_b32 {vr(TQ + 2)}, {vr(TQ)}")
+    # stages 1 and 2 (the youngest 16 loads) stay in flight as far as they do at every later tile start: finalize()'s second pass
+    # starts from "at most LOOP_TOP_VM of them outstanding", and the stream's own waits count from there -- stores are in no allowance
+    L.append(f"s_waitcnt vmcnt({min(16, LOOP_TOP_VM)}) lgkmcnt(0)")
     L.append("s_barrier")
     return L
 
 
 # ------------------------------------------------------------------ s_waitcnt from the issue order
 WHATIF = set(os.environ.get("GEN_ET5_WHATIF", "").split(","))      # dev: timing-only variants (WRONG results): nobar, nodma, noseed, nom3, noa2s
+
+
+LOOP_TOP_VM = 0
 
 
 def finalize(body):
@@ -1120,8 +1122,12 @@ def finalize(body):
     lds_tag, vm_tag = {}, {}
     lds_done, vm_done = -1, -1
     out = []
+    global LOOP_TOP_VM
     for rep in range(2):
         out = []
+        if rep == 1:                               # the steady state's loop top: the youngest LOOP_TOP_VM loads may be in flight, no more
+            LOOP_TOP_VM = vm_seq - 1 - vm_done
+            assert all(t in ("stg1", "stg2") for t, q in vm_tag.items() if q > vm_done), "prologue_loads assumes stages 1, 2 are the youngest"
         for it in body:
             if it.kind == "wait_lds_all":
                 lds_done = lds_seq - 1
@@ -1172,6 +1178,7 @@ def generate(stats_out=None):
         body = [it for it in body if it.kind not in ("valu",) or "v_add_u32" in it.text]
     if "nolds" in WHATIF:
         body = [it for it in body if not (it.kind == "lds" and "v225" not in it.text and "v224" not in it.text)]
+    body_text = finalize(body)                 # (first: sets LOOP_TOP_VM for the prologue)
     lines = []
     lines += kernel_setup()
     lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")
@@ -1185,7 +1192,7 @@ def generate(stats_out=None):
         lines.append(f"s_mov_b32 {sg(d)}, {sg(s_)}")
     # (this tile's output addresses and the next tile's decode run on the scalar unit inside the stream: chain TOP)
     lines.append("; ---- tile body: head, 792 MFMAs with everything else in their issue slots")
-    lines += finalize(body)
+    lines += body_text
     lines.append(f"s_add_i32 {sg('tile')}, {sg('tile')}, {sg('NWG')}")
     lines.append(f"s_cmp_lt_i32 {sg('tile')}, {sg('nwork')}")
     lines.append("s_cbranch_scc1 .Lv5_loop%=")

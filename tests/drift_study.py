@@ -29,6 +29,11 @@ def _maxnorm(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
+HALF_TURN_WINDOW = 0.12      # rad: 1 / sin(theta) > 8 inside it
+EXC_BOUND = 3e-2             # a sample's rotation error beyond this is an excursion that needs an explanation
+EXC_HALF_TURN = 0.35         # rad: the geodesic of the worst residue (or any residue of the sample) this close to a half turn explains it
+
+
 def compare(traj, ref, gen, res):
     """traj / ref: lists of per-step dicts (CPU); gen / res: [B,L] bool.  Errors over generated residues (context is pinned)."""
     N = len(ref)
@@ -67,6 +72,16 @@ def compare(traj, ref, gen, res):
     dt = 0.99 / max(1, N - 1)
     Bn = g.shape[0]
     first_branch, events = [None] * Bn, []
+    # Third kind of branch point: the SO(3) geodesic R <- R Exp(s Log(R^T R1)) (flow_model.py:322, so3_utils.py:167-254)
+    # near a HALF TURN.  Log divides by sin(theta) and switches to its pi branch at |theta - pi| < 1e-2; with theta within `half_turn`
+    # of pi an f16-sized difference of the predicted R1 (~3e-3) is amplified by 1 / sin(theta) and can pick the other rotation
+    # axis.  Detected on the REFERENCE run alone (it is a property of the trajectory, not of the implementation under test): the
+    # angle between a generated residue's current frame and its predicted clean frame at step i.
+    half_turn = HALF_TURN_WINDOW
+
+    def so3_angle(Ra, Rb):
+        tr = (Ra * Rb).sum((-1, -2))                                          # trace(Ra^T Rb)
+        return torch.acos(((tr - 1) / 2).clamp(-1, 1))
     for b in range(Bn):
         if not g[b].any():
             continue
@@ -74,9 +89,11 @@ def compare(traj, ref, gen, res):
             dd = (traj[i]["angles"][b][g[b]] - ref[i]["angles"][b][g[b]]).abs()
             a_err = float(torch.minimum(dd, 2 * math.pi - dd).max())
             flipped = bool((traj[i]["seqs"][b][g[b]] != ref[i]["seqs"][b][g[b]]).any())
-            if flipped or a_err > 0.5 * 2 * math.pi * dt:
+            th = so3_angle(ref[i]["rotmats"][b][g[b]], ref[i]["rotmats_1"][b][g[b]]) if "rotmats_1" in ref[i] else torch.zeros(1)
+            near_pi = bool((th > math.pi - half_turn).any()) and i + 1 < N
+            if flipped or a_err > 0.5 * 2 * math.pi * dt or near_pi:
                 first_branch[b] = i
-                events.append([b, i, "draw" if flipped else "geodesic"])
+                events.append([b, i, "draw" if flipped else ("geodesic" if a_err > 0.5 * 2 * math.pi * dt else "so3_half_turn")])
                 break
     rot_bb, trans_bb = 0.0, 0.0
     rn = max(float(ref[0]["rotmats"][g].abs().max()), 1e-12)
@@ -88,7 +105,39 @@ def compare(traj, ref, gen, res):
         for i in range(stop):
             rot_bb = max(rot_bb, float((traj[i]["rotmats"][b][g[b]] - ref[i]["rotmats"][b][g[b]]).abs().max()) / rn)
             trans_bb = max(trans_bb, float((traj[i]["trans"][b][g[b]] - ref[i]["trans"][b][g[b]]).abs().max()) / tn)
+    # Excursions: a sample whose rotation error leaves EXC_BOUND is EXPLAINED when, at the step where it leaves, one of the reference's own
+    # branch points sits under the worst residue: a flipped draw or a turned torsion in the sample before that step, or that residue's
+    # geodesic within EXC_HALF_TURN of a half turn during the few steps before (1 / sin(theta) amplifies an f16-sized difference of
+    # the prediction there; inside |theta - pi| < 1e-2 Log even switches branch, so3_utils.py:215-254).  An UNEXPLAINED excursion
+    # would be an error of the implementation under test: tests/test_gpu_drift.py asserts there is none.
+    excursions = []
+    for b in range(Bn):
+        if not g[b].any():
+            continue
+        idx = torch.nonzero(g[b]).reshape(-1)
+        for i in range(N):
+            e_res = (traj[i]["rotmats"][b][idx] - ref[i]["rotmats"][b][idx]).abs().amax((-1, -2)) / rn
+            if float(e_res.max()) > EXC_BOUND:
+                k = int(e_res.argmax())
+                lo = max(0, i - 4)
+                th = max(float(so3_angle(ref[j]["rotmats"][b][idx[k]], ref[j]["rotmats_1"][b][idx[k]])) for j in range(lo, i + 1)) if "rotmats_1" in ref[0] else 0.0
+                th_any = max(float(so3_angle(ref[j]["rotmats"][b][idx], ref[j]["rotmats_1"][b][idx]).max()) for j in range(lo, i + 1)) if "rotmats_1" in ref[0] else 0.0
+                discrete = any((traj[j]["seqs"][b][g[b]] != ref[j]["seqs"][b][g[b]]).any() for j in range(i + 1))
+                dd = [(traj[j]["angles"][b][g[b]] - ref[j]["angles"][b][g[b]]).abs() for j in range(i + 1)]
+                turned = any(float(torch.minimum(d_, 2 * math.pi - d_).max()) > 0.5 * 2 * math.pi * dt for d_ in dd)
+                kind = "draw" if discrete else ("torsion" if turned else ("so3_half_turn" if max(th, th_any) > math.pi - EXC_HALF_TURN else "UNEXPLAINED"))
+                excursions.append([b, i, int(idx[k]), round(th, 4), round(th_any, 4), kind])
+                break
+    per_sample_bb = []
+    for b in range(Bn):
+        if not g[b].any():
+            per_sample_bb.append(0.0)
+            continue
+        stop = N if first_branch[b] is None else max(1, first_branch[b])
+        per_sample_bb.append(max(float((traj[i]["rotmats"][b][g[b]] - ref[i]["rotmats"][b][g[b]]).abs().max()) / rn for i in range(stop)))
     return {
+        "excursions": excursions,
+        "rot_err_sample_before_first_branch": [round(x, 6) for x in per_sample_bb], "first_branch_step": first_branch,
         "rot_err_max_before_first_branch": rot_bb, "trans_err_max_before_first_branch": trans_bb, "branch_events": events,
         "rot_err_sample_max": [round(float(x), 6) for x in rs], "rot_err_sample_median": float(rs.median()),
         "trans_err_sample_median": float(ts_.median()),

@@ -53,8 +53,18 @@ def test_f16_mode_over_100_free_steps(drift):
     #  score kernel == the three-buffer form, bit for bit), ::test_attention_planes_in_fragment_order and
     #  ::test_edge_transition_with_the_pair_tensor_in_fragment_order (fragment order == row order, bit for bit), and
     #  tests/test_gpu_fresh_process.py (run-to-run, f16 mode included).  This test is the statistical view on top of those.)
-    assert r["rot_err_sample_median"] < 3e-2 and r["trans_err_sample_median"] < 1e-2, (r["rot_err_sample_median"], r["trans_err_sample_median"])
-    assert sum(x > 3e-2 for x in r["rot_err_sample_max"]) <= len(r["rot_err_sample_max"]) // 4, r["rot_err_sample_max"]
+    assert r["rot_err_sample_median"] < 2e-2 and r["trans_err_sample_median"] < 1e-2, (r["rot_err_sample_median"], r["trans_err_sample_median"])
+    # (round 6, VERDICT r5 item 8: every sample that leaves 3e-2 must be EXPLAINED by one of the reference's own branch points at the step
+    #  where it leaves -- a flipped draw or a turned torsion before it, or the worst residue's SO(3) geodesic within 0.35 rad of a half
+    #  turn (drift_study.compare: "excursions"); an UNEXPLAINED excursion would be an error of the f16 data path.  Detecting the half
+    #  turn per SAMPLE instead cannot work as an exclusion: with Haar-uniform initial frames every sample has a generated residue within
+    #  0.12 rad of a half turn during its first five steps (first_branch_step of the 8 x 64 case: 1 0 0 1 4 1 0 0), which would exclude
+    #  everything; measured: one excursion in eight samples, at step 86, behind a flipped draw at step 59.)
+    exc = r["excursions"]
+    assert all(e[-1] != "UNEXPLAINED" for e in exc), exc
+    assert len(exc) <= len(r["rot_err_sample_max"]) // 4, exc
+    assert sum(x > 3e-2 for x in r["rot_err_sample_max"]) == len(exc)
+    assert r["rot_err_max_before_first_branch"] < 1e-2, r["rot_err_max_before_first_branch"]      # (measured 3.8e-3: a teacher-forced-sized error while nothing has branched)
     assert r["rot_err_max"] < 0.5, r["rot_err_max"]
     assert r["flip_rate"] < 3e-3, r["flip_rate"]                 # measured 4e-4: a flipped draw changes that residue's type for a step or more
     assert r["final_ca_rmsd_A_mean"] < 0.1 and r["final_ca_rmsd_A_max"] < 0.3, r
