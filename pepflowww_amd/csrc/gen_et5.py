@@ -1180,6 +1180,8 @@ def generate(stats_out=None):
         body = [it for it in body if not (it.kind == "lds" and "v225" not in it.text and "v224" not in it.text)]
     body_text = finalize(body)                 # (first: sets LOOP_TOP_VM for the prologue)
     lines = []
+    if PROF:                                   # kernel entry (slot 9) .. exit (slot 10): (exit - entry - prologue) / tiles = the AVERAGE tile
+        lines += [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s100, s98"]
     lines += kernel_setup()
     lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")
     lines.append(f"s_mov_b32 {sg('ntile')}, {sg('WG')}")
@@ -1197,6 +1199,7 @@ def generate(stats_out=None):
     lines.append(f"s_cmp_lt_i32 {sg('tile')}, {sg('nwork')}")
     lines.append("s_cbranch_scc1 .Lv5_loop%=")
     if PROF:                                   # lane 0 of every wave: its stamps of the last tile -> dbg[(wg * 4 + wave) * 16 + k]
+        lines += [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s101, s98"]
         lines += [f"s_cmp_eq_u64 {sg('dbg', 2)}, 0", "s_cbranch_scc1 .Lv5_end%=",
                   f"s_lshl_b32 {sg('t0')}, {sg('WG')}, 2", f"s_add_i32 {sg('t0')}, {sg('t0')}, {sg('wave')}", f"s_lshl_b32 {sg('t0')}, {sg('t0')}, 6",
                   f"s_add_u32 {sg('t0')}, {sg('dbg')}, {sg('t0')}", f"s_addc_u32 {sg('t1')}, {sr(S['dbg'] + 1)}, 0",
@@ -1204,6 +1207,8 @@ def generate(stats_out=None):
         for k in range(N_STAMP):
             lines += [f"v_mov_b32 {vr(TQ)}, {sr(4 + k)}", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * k}"]
         lines += [f"v_mov_b32 {vr(TQ)}, s3", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP}"]
+        lines += [f"v_mov_b32 {vr(TQ)}, s100", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP + 4}"]
+        lines += [f"v_mov_b32 {vr(TQ)}, s101", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP + 8}"]
     lines.append(".Lv5_end%=:")
     lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     txt = ["// GENERATED by gen_et5.py -- do not edit; `python pepflowww_amd/csrc/gen_et5.py` rewrites it, tests/test_host_cpu.py checks it is current.",

@@ -1,8 +1,9 @@
 #!/bin/bash
-# same-box A/B of two libraries in the step
-W=$1; shift
-for r in 1 2; do for lib in old new; do
-  if [ $lib = old ]; then export PF_LIB_PATH=$PWD/pepflowww_amd/lib/variants/libpf_old.so; else unset PF_LIB_PATH; fi
+# dev: same-box A/B of a variant library (tools/dev/build_variant.sh) against the shipped one inside the step, alternating:
+#   tools/dev/ab_lib.sh <variant> <workload> [bench flags]
+V=$1; W=$2; shift 2
+for r in 1 2; do for lib in $V new; do
+  if [ $lib = new ]; then unset PF_LIB_PATH; else export PF_LIB_PATH=$PWD/pepflowww_amd/lib/variants/libpf_$V.so; fi
   python bench.py --workload $W --no-modes --no-per-call --no-cpu-baseline --no-secondary "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

@@ -40,3 +40,5 @@ floors = [0, 48, 432, 72, 48, 96, 48]
 for k, nm in enumerate(names[:7]):
     x = d[k].float()
     print(f"{nm:42s} mean {x.mean():8.0f}  per wave {[round(v) for v in x.mean(0).tolist()]}  MFMA floor {floors[k] * 32}")
+whole = ((t[:, :, 10] - t[:, :, 9]) & 0xffffffff).float()
+print(f"kernel entry -> exit per wave: mean {whole.mean():.0f} cycles, min {whole.min():.0f}, max {whole.max():.0f}; / 16 tiles = {whole.mean() / 16:.0f} per tile (prologue included)")
