@@ -1180,14 +1180,27 @@ def generate(stats_out=None):
         body = [it for it in body if not (it.kind == "lds" and "v225" not in it.text and "v224" not in it.text)]
     body_text = finalize(body)                 # (first: sets LOOP_TOP_VM for the prologue)
     lines = []
-    if PROF:                                   # kernel entry (slot 9) .. exit (slot 10): (exit - entry - prologue) / tiles = the AVERAGE tile
-        lines += [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s100, s98"]
+
+    def pstamp(dst, hi):                       # prof: cycles since the previous prologue stamp (s3), as a 16-bit half of dst  (102 SGPRs ...)
+        return [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s99, s98, s3", "s_mov_b32 s3, s98", "s_min_u32 s99, s99, 0xffff"] + \
+               ([f"s_lshl_b32 {dst}, s99, 16"] if hi else [f"s_or_b32 {dst}, {dst}, s99"])
+    if PROF:                                   # slot 9 = (setup << 16 | decode + addresses), slot 11 = (rows + z issue << 16 | stages issue)
+        lines += [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s3, s98"]
     lines += kernel_setup()
+    if PROF:
+        lines += pstamp("s100", True)
     lines.append(f"s_mov_b32 {sg('tile')}, {sg('WG')}")
     lines.append(f"s_mov_b32 {sg('ntile')}, {sg('WG')}")
     lines += decode_tile("ntile", "nid", "nb", "ni0", "nj0", "dec0")
     lines += next_tile_addresses()
-    lines += prologue_loads()
+    if PROF:
+        lines += pstamp("s100", False)
+        pl = prologue_loads()
+        i1 = [i for i, l in enumerate(pl) if l.startswith(f"s_mov_b32 {sg('woff')}")][0]
+        i2 = [i for i, l in enumerate(pl) if l.startswith("s_waitcnt vmcnt(")][0]
+        lines += pl[:i1] + pstamp("s101", True) + pl[i1:i2] + pstamp("s101", False) + pl[i2:]
+    else:
+        lines += prologue_loads()
     lines.append(".Lv5_loop%=:")
     lines.append("; ---- the prefetched tile becomes the current one; pick, decode and address the next")
     for d, s_ in (("cid", "nid"), ("b", "nb"), ("i0", "ni0"), ("j0", "nj0")):
@@ -1199,7 +1212,7 @@ def generate(stats_out=None):
     lines.append(f"s_cmp_lt_i32 {sg('tile')}, {sg('nwork')}")
     lines.append("s_cbranch_scc1 .Lv5_loop%=")
     if PROF:                                   # lane 0 of every wave: its stamps of the last tile -> dbg[(wg * 4 + wave) * 16 + k]
-        lines += [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s101, s98"]
+        lines += [f"s_memtime {sr(98, 2)}", "s_waitcnt lgkmcnt(0)"]
         lines += [f"s_cmp_eq_u64 {sg('dbg', 2)}, 0", "s_cbranch_scc1 .Lv5_end%=",
                   f"s_lshl_b32 {sg('t0')}, {sg('WG')}, 2", f"s_add_i32 {sg('t0')}, {sg('t0')}, {sg('wave')}", f"s_lshl_b32 {sg('t0')}, {sg('t0')}, 6",
                   f"s_add_u32 {sg('t0')}, {sg('dbg')}, {sg('t0')}", f"s_addc_u32 {sg('t1')}, {sr(S['dbg'] + 1)}, 0",
@@ -1208,7 +1221,8 @@ def generate(stats_out=None):
             lines += [f"v_mov_b32 {vr(TQ)}, {sr(4 + k)}", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * k}"]
         lines += [f"v_mov_b32 {vr(TQ)}, s3", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP}"]
         lines += [f"v_mov_b32 {vr(TQ)}, s100", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP + 4}"]
-        lines += [f"v_mov_b32 {vr(TQ)}, s101", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP + 8}"]
+        lines += [f"v_mov_b32 {vr(TQ)}, s98", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP + 8}"]
+        lines += [f"v_mov_b32 {vr(TQ)}, s101", f"global_store_dword {vr(TQ + 1)}, {vr(TQ)}, {sg('t0', 2)} offset:{4 * N_STAMP + 12}"]
     lines.append(".Lv5_end%=:")
     lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     txt = ["// GENERATED by gen_et5.py -- do not edit; `python pepflowww_amd/csrc/gen_et5.py` rewrites it, tests/test_host_cpu.py checks it is current.",

@@ -40,5 +40,7 @@ floors = [0, 48, 432, 72, 48, 96, 48]
 for k, nm in enumerate(names[:7]):
     x = d[k].float()
     print(f"{nm:42s} mean {x.mean():8.0f}  per wave {[round(v) for v in x.mean(0).tolist()]}  MFMA floor {floors[k] * 32}")
-whole = ((t[:, :, 10] - t[:, :, 9]) & 0xffffffff).float()
-print(f"kernel entry -> exit per wave: mean {whole.mean():.0f} cycles, min {whole.min():.0f}, max {whole.max():.0f}; / 16 tiles = {whole.mean() / 16:.0f} per tile (prologue included)")
+h = lambda k: ((t[:, :, k] >> 16).float().mean().item(), (t[:, :, k] & 0xffff).float().mean().item())
+ex = ((t[:, :, 10] - t[:, :, 7]) & 0xffffffff).float()
+print("prologue (cycles): kernel_setup %.0f | decode + addresses %.0f | rows + masks + z issue %.0f | ring stages 0..2 issue %.0f  (then ~900 until everything has landed + barrier);   last tile's stamp 7 -> exit %.0f"
+      % (*h(9), *h(11), ex.mean().item()))
