@@ -135,6 +135,15 @@ def _grad_buffer(*shape, device):
     return torch.empty(*shape, device=device), False
 
 
+def _grad_out(*shape, device, zero=False):
+    """Buffer a kernel WRITES a parameter gradient into (zero: it accumulates / adds atomically): a slice of the step's gradient arena
+    when there is one -- the flat buffer the data-parallel step all-reduces -- so that GradArena.adopt has nothing to copy."""
+    v, zeroed = _grad_buffer(*shape, device=device)
+    if zero and not zeroed:
+        v = _zeros(*shape, device=device)
+    return v
+
+
 _RANGE_FLAGS = {}
 
 
@@ -696,7 +705,7 @@ class IpaBlock:
         _capi.check(lib.pf_ipa_bwd_points(C.byref(a), st), "pf_ipa_bwd_points")
         # parameters of the pair projections: dW_b = g_bias^T z, dW_dz = g_pz^T z (K = pairs)
         if g_bp is not None:       # both in ONE [24,64] product over z (one pass over the pair tensor instead of two)
-            dW = e(24, 64)
+            dW = _grad_out(24, 64, device=dev)
             db, zeroed = _grad_buffer(24, device=dev)
             if not zeroed:
                 db = _zeros(24, device=dev)
@@ -713,7 +722,7 @@ class IpaBlock:
                 G[p + nm + ".weight"], G[p + nm + ".bias"] = dW, db
         gg = e(8)
         _capi.check(lib.pf_colsum_f32(g_gam.data_ptr(), 8, rows, 8, gg.data_ptr(), 0, st), "pf_colsum_f32")
-        ghw = e(8)
+        ghw = _grad_out(8, device=dev)
         _capi.check(lib.pf_ipa_headw_bwd(gg.data_ptr(), W[p + "head_weights"].data_ptr(), ghw.data_ptr(), st), "pf_ipa_headw_bwd")
         G[p + "head_weights"] = ghw
         g_s, dWp, dbp = linear_bwd(sv["s"], self.w_proj, g_proj)
@@ -1031,12 +1040,12 @@ class TrunkTrainer:
         feat = self.saved["feat"]
         g_feat = _zeros(rows, 640, device=dev)
         _gemm(g_m1, 128, 1, w0, K, 1, g_feat, rows, K, 128, ldc=640)
-        dW0 = torch.empty(128, K, device=dev)
+        dW0 = _grad_out(128, K, device=dev)
         _gemm(g_m1, 1, 128, feat, 640, 1, dW0, 128, K, rows)
-        db0 = torch.empty(128, device=dev)
+        db0 = _grad_out(128, device=dev)
         _capi.check(lib.pf_colsum_f32(g_m1.data_ptr(), 128, rows, 128, db0.data_ptr(), 0, st), "pf_colsum_f32")
         G["res_feat_mixer.0.weight"], G["res_feat_mixer.0.bias"] = dW0, db0
-        tg = torch.empty(22, 128, device=dev)
+        tg = _grad_out(22, 128, device=dev)
         _capi.check(lib.pf_embedding_bwd(g_feat.data_ptr() + 4 * 128, 640, self.seq_t.data_ptr(), rows, 22, 128, tg.data_ptr(), st), "pf_embedding_bwd")
         G["current_seq_embedder.weight"] = tg
         g_node_embed = g_feat[:, :128].contiguous()
@@ -1069,12 +1078,12 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     K = w0.shape[1]
     g_feat = e(rows, 128)
     _gemm(g0, 256, 1, w0, K, 1, g_feat, rows, 128, 256, ldc=128)              # only the aa-embedding columns are needed
-    dW0 = e(256, K)
+    dW0 = _grad_out(256, K, device=dev)
     _gemm(g0, 1, 256, saved["feat"], 1168, 1, dW0, 256, K, rows)
-    db0 = e(256)
+    db0 = _grad_out(256, device=dev)
     _capi.check(lib.pf_colsum_f32(g0.data_ptr(), 256, rows, 256, db0.data_ptr(), 0, st), "pf_colsum_f32")
     G["node_embedder.mlp.0.weight"], G["node_embedder.mlp.0.bias"] = dW0, db0
-    tg = e(22, 128)
+    tg = _grad_out(22, 128, device=dev)
     _capi.check(lib.pf_embedding_bwd(g_feat.data_ptr(), 128, aa_node.data_ptr(), rows, 22, 128, tg.data_ptr(), st), "pf_embedding_bwd")
     G["node_embedder.aatype_embed.weight"] = tg
     # ---- edge embedder
@@ -1088,13 +1097,13 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
     else:
         _gemm(g_o1, 64, 1, wo0, 218, 1, g_cat, P, 218, 64, ldc=224)
     dWp = e(64, 224)                                                            # against the 224-wide (zero-padded) concat tile
-    dbo0 = e(64)
+    dbo0 = _grad_out(64, device=dev)
     ws = _tn_workspace(dev)
     _capi.check(lib.pf_gemm_tn_wide(g_o1.data_ptr(), 64, 64, saved["cat"].data_ptr(), 224, 224, dWp.data_ptr(), 224, P, 0,
                                     dbo0.data_ptr(), 0, ws.data_ptr(), ws.numel(), st), "pf_gemm_tn_wide")
     dWo0 = dWp[:, :218]
     G["edge_embedder.out_mlp.0.weight"], G["edge_embedder.out_mlp.0.bias"] = dWo0, dbo0
-    t_aap, t_rel = _zeros(484, 64, device=dev), _zeros(65, 64, device=dev)
+    t_aap, t_rel = _grad_out(484, 64, device=dev, zero=True), _grad_out(65, 64, device=dev, zero=True)
     _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr(), 224, aap.data_ptr(), None, P, 64, t_aap.data_ptr(), st), "pf_embedding_bwd_atomic")
     _capi.check(lib.pf_embedding_bwd_atomic(g_cat.data_ptr() + 4 * 64, 224, rel.data_ptr(), same.data_ptr(), P, 64, t_rel.data_ptr(), st), "pf_embedding_bwd_atomic")
     G["edge_embedder.aa_pair_embed.weight"], G["edge_embedder.relpos_embed.weight"] = t_aap, t_rel
@@ -1111,7 +1120,7 @@ def encoder_backward(model_sd, saved, g_node, g_edge, B, L):
         _, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], wd0, g_h1, need_dx=False)
     else:
         g_g, G["edge_embedder.distance_embed.0.weight"], G["edge_embedder.distance_embed.0.bias"] = linear_bwd(saved["g"], wd0, g_h1)
-    t_c = _zeros(484, 225, device=dev)
+    t_c = _grad_out(484, 225, device=dev, zero=True)
     _capi.check(lib.pf_edge_distcoef_bwd(g_g.data_ptr(), g_g.shape[1], saved["g"].data_ptr(), aap.data_ptr(),
                                          w("edge_embedder.aapair_to_distcoef.weight").data_ptr(), e(484, 225).data_ptr(), P, t_c.data_ptr(), st),
                 "pf_edge_distcoef_bwd")
