@@ -1178,6 +1178,10 @@ def generate(stats_out=None):
         body = [it for it in body if it.kind not in ("valu",) or "v_add_u32" in it.text]
     if "nolds" in WHATIF:
         body = [it for it in body if not (it.kind == "lds" and "v225" not in it.text and "v224" not in it.text)]
+    if "sleep" in WHATIF:                      # power what-if: ~1 k idle cycles per tile (a cycle-bound kernel slows by 1 k / tile, a power-bound one by less)
+        body = [raw("s_sleep 15")] + body
+    if "sleep3" in WHATIF:
+        body = [raw("s_sleep 15"), raw("s_sleep 15"), raw("s_sleep 15")] + body
     body_text = finalize(body)                 # (first: sets LOOP_TOP_VM for the prologue)
     lines = []
 
@@ -1249,6 +1253,10 @@ def main():
         print("wrote the stamped variant")
         return 0
     text = generate()
+    if "--out" in sys.argv:                    # (what-if variants: never over the committed file)
+        with open(sys.argv[sys.argv.index("--out") + 1], "w") as f:
+            f.write(text)
+        return 0
     if "--check" in sys.argv:
         cur = open(OUT).read() if os.path.exists(OUT) else ""
         if cur != text:
