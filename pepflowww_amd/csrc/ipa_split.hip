@@ -270,6 +270,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
                                           float* PB /* [PJ_TILES * 16] the head's bias, staged here */,
                                           float4 (&qf)[8], float4 (&qp4)[6], int lane, int wave, int nw) {
     const int r = lane & 15, g = lane >> 4;
+    PROFS(8);                                  // (PF_PROFILE builds: 8 entry | 30 .. 33 the front matter | 9 + 2 c, 10 + 2 c chunk c's wait, barrier passed)
     const unsigned char* whp = reinterpret_cast<const unsigned char*>(a.proj_w_f16);
     const unsigned char* wlp = whp + (size_t)PJ_NPAD * 128 * 2;
     const unsigned ws0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)WS;
@@ -295,6 +296,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
     // product and must be finite (the point tiles write them eight chunk barriers later)
     for (int i = wave * 64 + lane; i < 24 * VTL; i += nw * 64) reinterpret_cast<float2*>(VPT)[i] = make_float2(0.f, 0.f);   // (2 x 48 x VTL f16)
     // x operand: row iq, K-step ks, slots 8 g .. + 7, as hi / lo planes (split4: the same conversion as the stand-alone kernel)
+    PROFS(30);
     half8 xh[4], xl[4];
     float R[9], T[3];
     {
@@ -318,6 +320,7 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
             for (int e = 0; e < 4; ++e) { xh[ks][e] = h0[e]; xh[ks][4 + e] = h1[e]; xl[ks][e] = l0[e]; xl[ks][4 + e] = l1[e]; }
         }
     }
+    PROFS(31);
     if constexpr (KF) {
         _Float16* kfrag = VTH + (size_t)8 * (VTG >> 5) * 1024 + (size_t)tile * 4096 + lane * 8;  // (layout: below; formed here for this form only --
                                                                                                  //  the other form keeps its instruction stream)
@@ -353,10 +356,12 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         }
     }
     // (the row loads above are OLDER than every LDS-DMA piece: the waits below count what is younger than a chunk's pieces)
+    PROFS(32);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < PJ_NB - 1; ++c)
         if (c < NCH) issue(c);
+    PROFS(33);
     // k rows: fragment order too.  KS (the form without the pair phase): as the hi | lo f16 operands of the first product (three f16
     // MFMAs per product, like the second one) --
     // block (key tile `tile`, 32-channel K-step s, plane) = 1 KiB = the 64 lanes' 16 bytes: lane (key r, g) holds channels 32 s + 4 g .. + 3
@@ -393,11 +398,13 @@ __device__ __forceinline__ void proj_head(const pf_ipa_attn_args& a, size_t rowb
         // allowance the wait also covers the stores of the previous chunks: +1.4 k cycles on the 44 k prologue.
         constexpr int NDY = (c + 1 < NCH) + (PJ_NB > 3 && c + 2 < NCH) + (PJ_NB > 4 && c + 3 < NCH);
         static_assert(PJ_NB == 2 || PJ_NB == 4, "wait accounting written for 2 or 4 staging buffers");
+        PROFS(9 + 2 * c);
         pj_wait_vm_dyn(PJ_NB == 2 ? 0 : NDY * ppw);
         // (the bare s_barrier does not wait for this wave's own LDS writes, unlike __syncthreads(): the bias staging and the zero fill of
         //  the point planes above must have LANDED before anybody passes the first barrier)
         if constexpr (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        PROFS(10 + 2 * c);
         asm volatile("" ::: "memory");
         if constexpr (c + PJ_NB - 1 < NCH) issue(c + PJ_NB - 1);
         if (wave_on) {

@@ -30,7 +30,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     raw = C.CDLL(_capi.LIB_PATH)
     out = (C.c_longlong * 256)()
-    for sym, n in (("pf_debug_prof", 14), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 8), ("pf_debug_prof_et3", 156)):
+    for sym, n in (("pf_debug_prof", 14), ("pf_debug_prof_ipa", 8), ("pf_debug_prof_ipas", 48), ("pf_debug_prof_et3", 156)):
         if not hasattr(raw, sym):               # (the tiled EdgeTransition kernel and the v4 stamps left the source in round 4)
             continue
         getattr(raw, sym)(out, 256 if sym.endswith("et3") else 64)
