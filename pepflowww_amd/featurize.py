@@ -51,10 +51,38 @@ def _encoder_weights(model):
     return w
 
 
-def encode(model, batch, save=None, edge_out=None):
+class _EmbedderPair:
+    """What encode() reads of a FlowModel, for a stand-alone call of ONE embedder (NodeEmbedder.forward / EdgeEmbedder.forward)."""
+
+    def __init__(self, node_embedder=None, edge_embedder=None, sample_structure=True, sample_sequence=True):
+        self.node_embedder, self.edge_embedder = node_embedder, edge_embedder
+        self.sample_structure, self.sample_sequence = sample_structure, sample_sequence
+
+
+def embedder_forward(which, module, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask=None, sequence_mask=None):
+    """NodeEmbedder.forward (models_con/node.py:35-104) / EdgeEmbedder.forward (models_con/edge.py:39-111) as stand-alone calls with the
+    reference's signature, on the same kernels as encode().  structure_mask / sequence_mask: the CONTEXT mask (True = known), or None
+    -- flow_model.py:80-84 passes the same mask for both; two different masks are refused (the featurisers take one context mask and
+    the two `sample_*` switches)."""
+    if structure_mask is not None and sequence_mask is not None and not torch.equal(structure_mask.bool(), sequence_mask.bool()):
+        raise _capi.PepflowHipError("structure_mask and sequence_mask differ: the HIP featurisers take ONE context mask plus the "
+                                    "sample_structure / sample_sequence switches (flow_model.py:80-84 passes the same mask twice)")
+    ctx = structure_mask if structure_mask is not None else sequence_mask
+    mres = mask_atoms[:, :, 1].bool()                            # BBHeavyAtom.CA
+    gen = (mres & ~ctx.bool()) if ctx is not None else torch.zeros_like(mres)
+    batch = dict(aa=aa, res_nb=res_nb, chain_nb=chain_nb, pos_heavyatom=pos_atoms, mask_heavyatom=mask_atoms, generate_mask=gen,
+                 torsion_angle=torch.zeros(*aa.shape, 5, device=aa.device))
+    pair = _EmbedderPair(module if which == "node" else None, module if which == "edge" else None,
+                         structure_mask is not None, sequence_mask is not None)
+    out = encode(pair, batch, parts=(which,))
+    return out[4] if which == "node" else out[5]
+
+
+def encode(model, batch, save=None, edge_out=None, parts=("node", "edge")):
     """save: optional dict that receives every intermediate the encoder backward needs (training path).
     edge_out: optional fp32 [B,L,L,64] buffer the pair embedding is written to (FlowModel.sample hands the denoise engine's own
-    input buffer, so that the engine's launch plan / captured graphs keep their pointers from one call to the next)."""
+    input buffer, so that the engine's launch plan / captured graphs keep their pointers from one call to the next).
+    parts: which embedder runs (a stand-alone NodeEmbedder / EdgeEmbedder call, embedder_forward; the other output is None)."""
     lib = _capi.load()
     aa = batch["aa"]
     _capi.dptr(aa.contiguous(), torch.int64, "batch['aa']")
@@ -66,7 +94,7 @@ def encode(model, batch, save=None, edge_out=None):
     pos = _f32(batch["pos_heavyatom"][:, :, :15])
     mat = _f32(batch["mask_heavyatom"][:, :, :15])
     gen = _f32(batch["generate_mask"])
-    W = _encoder_weights(model) if save is None else None      # (the training path keeps the live parameters' views)
+    W = _encoder_weights(model) if save is None and len(parts) == 2 else None      # (the training path keeps the live parameters' views)
     ne, ee = model.node_embedder, model.edge_embedder
     e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     feat, rot1, trans1, mres, ctx = e(rows, 1168), e(rows, 9), e(rows, 3), e(rows), e(rows)
@@ -74,7 +102,12 @@ def encode(model, batch, save=None, edge_out=None):
     na = _capi.NodeFeatArgs()
     na.aa, na.res_nb, na.chain_nb = aa_c.data_ptr(), res_nb.data_ptr(), chain_nb.data_ptr()
     na.pos, na.mask_atoms, na.gen_mask = pos.data_ptr(), mat.data_ptr(), gen.data_ptr()
-    aa_table, freq_n = (W["aa_table"], W["freq_n"]) if W else (_f32(ne.aatype_embed.weight), _f32(ne.dihed_embed.freq_bands))
+    if W:
+        aa_table, freq_n = W["aa_table"], W["freq_n"]
+    elif ne is not None:
+        aa_table, freq_n = _f32(ne.aatype_embed.weight), _f32(ne.dihed_embed.freq_bands)
+    else:                                                        # (edge embedder alone: only the masks / frames of this kernel are used)
+        aa_table, freq_n = torch.zeros(22, 128, device=dev), _f32(ee.dihedral_embed.freq_bands)
     na.aa_table, na.freq3 = aa_table.data_ptr(), freq_n.data_ptr()
     na.feat, na.rot1, na.trans1, na.mres, na.ctx = feat.data_ptr(), rot1.data_ptr(), trans1.data_ptr(), mres.data_ptr(), ctx.data_ptr()
     na.B, na.L = B, L
@@ -83,15 +116,20 @@ def encode(model, batch, save=None, edge_out=None):
 
     # node MLP 1157 -> 256 -> 128 -> 128 -> 128 (node.py:20-25), x residue mask (node.py:102)
     h0, h1, h2, node = e(rows, 256), e(rows, 128), e(rows, 128), e(rows, 128)
-    if W:
+    if "node" not in parts:
+        node = None
+    elif W:
         nw = [W["n0w"], W["n0b"], W["n2w"], W["n2b"], W["n4w"], W["n4b"], W["n6w"], W["n6b"]]
     else:
         nw = [F.pad(_f32(ne.mlp[0].weight), (0, 1168 - 1157)).contiguous(), _f32(ne.mlp[0].bias), _f32(ne.mlp[2].weight),
               _f32(ne.mlp[2].bias), _f32(ne.mlp[4].weight), _f32(ne.mlp[4].bias), _f32(ne.mlp[6].weight), _f32(ne.mlp[6].bias)]
-    _linear(lib, feat, nw[0], nw[1], h0, rows, 256, 1168, relu=True)
-    _linear(lib, h0, nw[2], nw[3], h1, rows, 128, 256, relu=True)
-    _linear(lib, h1, nw[4], nw[5], h2, rows, 128, 128, relu=True)
-    _linear(lib, h2, nw[6], nw[7], node, rows, 128, 128, mask=mres)
+    if node is not None:
+        _linear(lib, feat, nw[0], nw[1], h0, rows, 256, 1168, relu=True)
+        _linear(lib, h0, nw[2], nw[3], h1, rows, 128, 256, relu=True)
+        _linear(lib, h1, nw[4], nw[5], h2, rows, 128, 128, relu=True)
+        _linear(lib, h2, nw[6], nw[7], node, rows, 128, 128, mask=mres)
+    if "edge" not in parts:
+        return (rot1.view(B, L, 3, 3), trans1.view(B, L, 3), _f32(batch["torsion_angle"]), aa_c, node.view(B, L, 128), None)
 
     ea = _capi.EdgeFeatArgs()
     ea.aa, ea.res_nb, ea.chain_nb, ea.pos, ea.mask_atoms = aa_c.data_ptr(), res_nb.data_ptr(), chain_nb.data_ptr(), pos.data_ptr(), mat.data_ptr()
@@ -128,4 +166,4 @@ def encode(model, batch, save=None, edge_out=None):
     # (no host sync: every launch above is on torch's CURRENT stream and the caching allocator is stream-ordered for
     #  tensors used on the stream that allocated them, so the temporaries cannot be recycled under the kernels)
     return (rot1.view(B, L, 3, 3), trans1.view(B, L, 3), _f32(batch["torsion_angle"]), aa_c,
-            node.view(B, L, 128), edge)
+            node.view(B, L, 128) if node is not None else None, edge)

@@ -21,6 +21,40 @@ from . import _capi
 from .engine import DenoiseEngine, PackedWeights
 
 
+def _standalone(module, *tensors):
+    """Guard of the sub-modules' stand-alone forwards: they run the HIP kernels of the training / encode paths on the module's own
+    parameters and carry NO autograd graph (training goes through FlowModel.forward), so they refuse a call that would silently drop one;
+    and they need device tensors -- there is no host path."""
+    if torch.is_grad_enabled() and module.training and any(p.requires_grad for p in module.parameters()):
+        raise _capi.PepflowHipError(f"{type(module).__name__}.forward called stand-alone carries no autograd graph: training goes through "
+                                    "FlowModel.forward (model(batch) -> six losses).  Call it under torch.no_grad() or in eval() mode")
+    _capi.load()
+    for t in tensors:
+        if torch.is_tensor(t) and not t.is_cuda:
+            raise _capi.PepflowHipError(f"{type(module).__name__}.forward: tensors must live on the GPU (the HIP library is the only execution path)")
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _rows(x):
+    return _f32(x.reshape(-1, x.shape[-1]))
+
+
+def _own(module, prefix):
+    """{prefix + parameter name: fp32 contiguous tensor}: the W dictionary the block classes of pepflowww_amd.backward take."""
+    return {prefix + k: _f32(v) for k, v in module.state_dict().items()}
+
+
+def _frames(r):
+    """(rot [..., 3, 3], trans [..., 3]) of what the reference passes as an OpenFold Rigid (ipa_pytorch.py:316-333): an object with
+    get_rots().get_rot_mats() / get_trans(), or the pair of tensors itself."""
+    if isinstance(r, (tuple, list)):
+        return r[0], r[1]
+    return r.get_rots().get_rot_mats(), r.get_trans()
+
+
 def _trunc_normal_(w, scale, fan):
     # ipa_pytorch.py:64-75: std = sqrt(scale/fan_in) / std(truncnorm(-2,2))
     std = math.sqrt(scale / max(1, fan)) / 0.87962566103423978
@@ -45,7 +79,11 @@ class Linear(nn.Linear):
                 raise ValueError("Invalid init string.")
 
     def forward(self, x):
-        raise _capi.PepflowHipError("Linear is executed inside the fused HIP denoise step; call GAEncoder / FlowModel")
+        """y = x W^T + b on the fp32-parity GEMM kernels (stand-alone use; inside the denoise step the layer is part of a fused kernel)."""
+        _standalone(self, x)
+        from .backward import linear_fwd
+        y = linear_fwd(_rows(x), _f32(self.weight), _f32(self.bias) if self.bias is not None else None)
+        return y.view(*x.shape[:-1], self.out_features)
 
 
 class AngularEncoding(nn.Module):
@@ -76,6 +114,16 @@ class StructureModuleTransition(nn.Module):
         self.linear_3 = Linear(c, c, init="final")
         self.ln = nn.LayerNorm(c)
 
+    def forward(self, s):
+        """ipa_pytorch.py:196-206, stand-alone: LN(s + l3(relu(l2(relu(l1(s))))))."""
+        _standalone(self, s)
+        from .backward import linear_fwd, layernorm_fwd
+        x = _rows(s)
+        h = linear_fwd(x, _f32(self.linear_1.weight), _f32(self.linear_1.bias), relu=True)
+        h = linear_fwd(h, _f32(self.linear_2.weight), _f32(self.linear_2.bias), relu=True)
+        h = linear_fwd(h, _f32(self.linear_3.weight), _f32(self.linear_3.bias), residual=x)
+        return layernorm_fwd(h, _f32(self.ln.weight), _f32(self.ln.bias)).view(s.shape)
+
 
 class EdgeTransition(nn.Module):
     def __init__(self, *, node_embed_size, edge_embed_in, edge_embed_out, num_layers=2, node_dilation=2):
@@ -89,6 +137,16 @@ class EdgeTransition(nn.Module):
         self.trunk = nn.Sequential(*layers)
         self.final_layer = Linear(hidden, edge_embed_out, init="final")
         self.layer_norm = nn.LayerNorm(edge_embed_out)
+
+    def forward(self, node_embed, edge_embed):
+        """ipa_pytorch.py:233-248, stand-alone: node_embed [B,L,128], edge_embed [B,L,L,64] -> [B,L,L,64] (no edge mask: ga.py:118
+        applies it outside).  Runs the persistent EdgeTransition kernel in its training form (pepflowww_amd.backward.EdgeTransitionBlock)."""
+        _standalone(self, node_embed, edge_embed)
+        from .backward import EdgeTransitionBlock
+        B, L = node_embed.shape[:2]
+        ones = torch.ones(B * L, device=node_embed.device)
+        blk = EdgeTransitionBlock(_own(self, "edge_transition_0."), 0, B, L, ones)
+        return blk.forward(_rows(node_embed), _rows(edge_embed)).view(B, L, L, -1)
 
 
 class InvariantPointAttention(nn.Module):
@@ -104,11 +162,27 @@ class InvariantPointAttention(nn.Module):
         self.head_weights = nn.Parameter(torch.full((conf.no_heads,), 0.541324854612918))
         self.linear_out = Linear(conf.no_heads * (conf.c_z // 4 + conf.c_hidden + conf.no_v_points * 4), conf.c_s, init="final")
 
+    def forward(self, s, z, r, mask):
+        """ipa_pytorch.py:316-484, stand-alone: s [B,L,128], z [B,L,L,64], r = Rigid-like (get_rots().get_rot_mats(), get_trans()) or
+        (rot [B,L,3,3], trans [B,L,3]), mask [B,L] -> [B,L,128] (not masked, as the reference; ga.py:102 masks outside).  Runs the
+        stand-alone projection / point / attention kernels of the training forward (pepflowww_amd.backward.IpaBlock)."""
+        _standalone(self, s, z, mask)
+        from .backward import IpaBlock, linear_fwd
+        B, L = s.shape[:2]
+        rot, trans = _frames(r)
+        blk = IpaBlock(_own(self, "ipa_0."), 0, B, L, _f32(mask.reshape(B * L)))
+        feats = blk.forward(_rows(s), _rows(z), _f32(rot.reshape(B * L, 9)), _f32(trans.reshape(B * L, 3)), feats_only=True)
+        return linear_fwd(feats, _f32(self.linear_out.weight), _f32(self.linear_out.bias)).view(B, L, -1)
+
 
 class BackboneUpdate(nn.Module):
     def __init__(self, c_s):
         super().__init__()
         self.linear = Linear(c_s, 6, init="final")
+
+    def forward(self, s):
+        """ipa_pytorch.py:562-572, stand-alone: [*, c_s] -> [*, 6]."""
+        return self.linear(s)
 
 
 class _SelfAttnParams(nn.Module):
@@ -293,6 +367,12 @@ class NodeEmbedder(nn.Module):
         infeat = feat_dim + max_aa_types * max_num_atoms * 3 + self.dihed_embed.get_out_dim(3)
         self.mlp = _mlp([infeat, feat_dim * 2, feat_dim, feat_dim, feat_dim])
 
+    def forward(self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask=None, sequence_mask=None):
+        """models_con/node.py:35-104 with the reference's signature -> [B,L,128]; stand-alone call of the encode() kernels."""
+        _standalone(self, aa, pos_atoms, mask_atoms)
+        from .featurize import embedder_forward
+        return embedder_forward("node", self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask, sequence_mask)
+
 
 class EdgeEmbedder(nn.Module):
     def __init__(self, feat_dim, max_num_atoms, max_aa_types=22, max_relpos=32):
@@ -306,3 +386,9 @@ class EdgeEmbedder(nn.Module):
         self.dihedral_embed = AngularEncoding()
         infeat = 3 * feat_dim + self.dihedral_embed.get_out_dim(2)
         self.out_mlp = _mlp([infeat, feat_dim, feat_dim, feat_dim])
+
+    def forward(self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask=None, sequence_mask=None):
+        """models_con/edge.py:39-111 with the reference's signature -> [B,L,L,64]; stand-alone call of the encode() kernels."""
+        _standalone(self, aa, pos_atoms, mask_atoms)
+        from .featurize import embedder_forward
+        return embedder_forward("edge", self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask, sequence_mask)

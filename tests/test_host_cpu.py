@@ -62,6 +62,21 @@ def test_no_cpu_fallback():
                          torch.zeros(1, 16, 16, 64), torch.ones(1, 16), torch.ones(1, 16))
     with pytest.raises(_capi.PepflowHipError):
         model(batch)
+    # the sub-modules' stand-alone forwards (modules.py) have no host path either
+    ga = model.ga_encoder.eval()
+    with torch.no_grad():
+        for call in (lambda: ga.trunk["post_tfmr_0"](torch.zeros(2, 128)),
+                     lambda: ga.trunk["node_transition_0"](torch.zeros(2, 128)),
+                     lambda: ga.trunk["bb_update_0"](torch.zeros(2, 128)),
+                     lambda: ga.trunk["edge_transition_0"](torch.zeros(1, 16, 128), torch.zeros(1, 16, 16, 64)),
+                     lambda: ga.trunk["ipa_0"](torch.zeros(1, 16, 128), torch.zeros(1, 16, 16, 64), (torch.eye(3).expand(1, 16, 3, 3), torch.zeros(1, 16, 3)), torch.ones(1, 16)),
+                     lambda: model.node_embedder(batch["aa"], batch["res_nb"], batch["chain_nb"], batch["pos_heavyatom"], batch["mask_heavyatom"]),
+                     lambda: model.edge_embedder(batch["aa"], batch["res_nb"], batch["chain_nb"], batch["pos_heavyatom"], batch["mask_heavyatom"])):
+            with pytest.raises(_capi.PepflowHipError):
+                call()
+    # ... and refuse a call that would silently drop the autograd graph
+    with pytest.raises(_capi.PepflowHipError, match="autograd"):
+        model.ga_encoder.train().trunk["post_tfmr_0"](torch.zeros(2, 128))
 
 
 def test_engine_cache_is_bounded_in_bytes_and_count():
