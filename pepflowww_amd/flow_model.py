@@ -236,7 +236,7 @@ class FlowModel(nn.Module):
         if use_graph and timings is not None and smp.needs_capture():
             smp.capture()
             stamp("capture")
-        smp.run(num_steps, use_graph=use_graph)
+        smp.run(num_steps, use_graph=use_graph, stream_out=not return_sampler)     # (the trajectory leaves for the host while the loop runs)
         # The step loop is enqueued (graph replays) and the host now only waits for the device: the one place where a full pass of
         # the cyclic garbage collector costs nothing.  A call returns ~2 000 tensor / dict objects (the reference's list-of-dicts
         # trajectory), so a loop over complexes triggers full collections anyway -- 15 - 90 ms each, in whatever host phase they hit

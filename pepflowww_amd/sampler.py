@@ -88,6 +88,7 @@ class DeviceSampler:
         self.graph = None
         self.graph_k = None
         self._graph_key = None
+        self._so, self._steps_done = None, 0
         self.set_seed(seed, first_sample)
 
     def set_seed(self, seed, first_sample=0):
@@ -136,6 +137,8 @@ class DeviceSampler:
                                       sx0.data_ptr(), _capi.stream_ptr())
         _capi.check(rc, "pf_sampler_init")
         self._init_keep = (rot0, tr0, ang0, sx0)
+        self._so = None                                # (a streamed trajectory copy belongs to ONE run from step 0; see run(stream_out=True))
+        self._steps_done = 0
 
     def _one_step(self):
         self.eng.run(concurrent=self.CONCURRENT)
@@ -171,21 +174,57 @@ class DeviceSampler:
     def needs_capture(self):
         return self.graph is None or self._graph_key != self._launch_key()
 
-    def run(self, n_steps=None, use_graph=True):
+    STREAM_OUT_CHUNK = 32     # steps per streamed piece of the trajectory (run(stream_out=True))
+
+    def _traj_tensors(self):
+        return (self.traj_rot, self.traj_trans, self.traj_ang, self.traj_seq, self.traj_simplex)
+
+    def _stream_chunk(self, upto):
+        """Steps [copied, upto) of the five trajectory buffers -> their pinned host twins, on the copy stream, behind an event recorded
+        on the compute stream HERE (the host runs ahead of the device: the event orders the copy behind the steps it copies)."""
+        so = self._so
+        if so is None or upto <= so["copied"]:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(so["stream"]):
+            so["stream"].wait_event(ev)
+            for h, t in zip(so["hosts"], self._traj_tensors()):
+                h[so["copied"]:upto].copy_(t[so["copied"]:upto], non_blocking=True)
+        so["copied"] = upto
+
+    def run(self, n_steps=None, use_graph=True, stream_out=False):
+        """stream_out: copy the trajectory to pinned host memory WHILE the loop runs (pieces of STREAM_OUT_CHUNK steps on a copy stream;
+        trajectory() then only waits for the last piece): the D2H of a 200-step call of B = 64 x 128 is 280 MB = 5 ms at the PCIe rate,
+        1 % of the call, otherwise spent after the loop with the device idle.  Only for a run that starts at step 0 (init_state)."""
         n = self.N if n_steps is None else n_steps
+        if stream_out and self._steps_done == 0 and use_graph:
+            copy_stream = getattr(self, "_copy_stream", None)
+            if copy_stream is None:
+                copy_stream = self._copy_stream = torch.cuda.Stream(device=self.eng.device)
+            self._so = dict(stream=copy_stream, copied=0, hosts=[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self._traj_tensors()])
+        else:
+            self._so = None
         if not use_graph:
             for _ in range(n):
                 self._one_step()
+            self._steps_done += n
             return
         if self.needs_capture():
             self.capture()
-        k = self.GRAPH_STEPS
+        k, done = self.GRAPH_STEPS, self._steps_done
+        self._steps_done += n
         if self.graph_k is not None:
             for _ in range(n // k):
                 self.graph_k.replay()
+                done += k
+                if self._so is not None and done - self._so["copied"] >= self.STREAM_OUT_CHUNK:
+                    self._stream_chunk(done)
             n -= (n // k) * k
         for _ in range(n):
             self.graph.replay()
+        if self._so is not None:
+            self._stream_chunk(min(self._steps_done, self.N))
 
     def trajectory(self, pageable=False):
         """One D2H copy -> list of num_steps dicts of CPU tensors (flow_model.py:313-314,371-374).
@@ -201,7 +240,12 @@ class DeviceSampler:
             h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
             h.copy_(t, non_blocking=True)
             return h
-        hosts = [to_host(t) for t in (self.traj_rot, self.traj_trans, self.traj_ang, self.traj_seq, self.traj_simplex)]
+        so, self._so = getattr(self, "_so", None), None
+        if so is not None and so["copied"] == N and self._steps_done == N:
+            so["stream"].synchronize()                 # the whole trajectory went out while the loop ran (run(stream_out=True))
+            hosts = so["hosts"]
+        else:
+            hosts = [to_host(t) for t in (self.traj_rot, self.traj_trans, self.traj_ang, self.traj_seq, self.traj_simplex)]   # (also BucketedSampler's gathered buffers)
         torch.cuda.current_stream().synchronize()
         if pageable:
             hosts = [torch.empty(h.shape, dtype=h.dtype).copy_(h) for h in hosts]
